@@ -1,0 +1,112 @@
+/* ctm_hip.h -- C-ABI of libctm_hip.so: the MI355X-native CTMRG + RDM engine.
+ *
+ * Drop-in boundary.  The reference (jurajHasik/peps-torch) has no FFI; the seam this ABI
+ * replaces is its family of "raw tensor tuple in, raw tensor tuple out" closures (the ones it
+ * wraps in torch.utils.checkpoint / offloads to a GPU), each cited below with the reference
+ * file:line (relative to the reference repo root).  All pointers are DEVICE pointers to
+ * C-contiguous (row-major, as torch) float64 buffers unless stated otherwise; nothing is
+ * retained after a call returns.  Every function returns an int status (CTM_OK == 0) and
+ * records a message retrievable with ctm_last_error().  One ctm_ctx is used by one host
+ * thread at a time; work is enqueued on the context's HIP stream and the call returns after
+ * enqueueing unless it needs a host decision (truncation logic), in which case it syncs.
+ *
+ * Tensor conventions (reference ctm/generic/env.py:57-76, ipeps/ipeps.py:117-124):
+ *   site a[p,u,l,d,r];  C(-1,-1)=(down,right) C(1,-1)=(left,down) C(1,1)=(up,left) C(-1,1)=(up,right)
+ *   T(0,-1)=(chi,D^2,chi) T(-1,0)=(chi,chi,D^2) T(0,1)=(D^2,chi,chi) T(1,0)=(chi,D^2,chi)
+ *   fused D^2 leg = (ket,bra), ket first.
+ */
+#ifndef CTM_HIP_H
+#define CTM_HIP_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ctm_ctx ctm_ctx;
+
+enum { CTM_OK = 0, CTM_ERR_BADARG = 1, CTM_ERR_SHAPE = 2, CTM_ERR_NOCONV = 3, CTM_ERR_HIP = 4,
+       CTM_ERR_UNSUPPORTED = 5, CTM_ERR_NOMEM = 6 };
+enum { CTM_F64 = 0, CTM_C128 = 1 };
+enum { CTM_LU = 0, CTM_RU = 1, CTM_RD = 2, CTM_LD = 3 };          /* enlarged corners          */
+enum { CTM_UP = 0, CTM_LEFT = 1, CTM_DOWN = 2, CTM_RIGHT = 3 };   /* directional moves         */
+
+/* truncation / projector options: reference config.py:370-409 (CTMARGS) */
+typedef struct ctm_trunc_cfg {
+    double svd_reltol;        /* projector_svd_reltol      (1e-8)  ctm_projectors.py:266            */
+    double eps_multiplet;     /* projector_eps_multiplet   (1e-8)  custom_svd.py:70-95              */
+    double multiplet_abstol;  /* projector_multiplet_abstol(1e-14)                                  */
+    int keep_multiplets;      /* 1                                                                  */
+    int fix_signs;            /* 1: apply fix_svd_signs (svd_gesdd.py:18-26)                        */
+} ctm_trunc_cfg;
+
+/* ---- context ------------------------------------------------------------------------------ */
+int ctm_create(ctm_ctx** out, void* hip_stream /* hipStream_t or NULL */, int dtype);
+int ctm_destroy(ctm_ctx* ctx);
+const char* ctm_last_error(ctm_ctx* ctx);
+const char* ctm_version(void);
+int ctm_sync(ctm_ctx* ctx);
+int ctm_set_option(ctm_ctx* ctx, const char* key, double value);   /* "jacobi_tol","jacobi_max_sweeps","jacobi_block","profile" */
+int ctm_get_stat(ctm_ctx* ctx, const char* key, double* value);    /* "last_sweeps","last_offnorm","gemm_flops","gemm_calls","arena_high" */
+int ctm_timers(ctm_ctx* ctx, double* out8, int reset);             /* corners,halves,svd,proj,absorb,norm,rdm,eig (s) */
+
+/* ---- primitives (replace tn_interface.py:3-27 contract/mm/permute) ------------------------------ */
+/* C[M,N] = alpha op(A) op(B) + beta C ; row-major; trans = 0 ('N') or 1 ('T', plain transpose) */
+int ctm_gemm(ctm_ctx* ctx, int transA, int transB, int M, int N, int K, double alpha, const double* A, long long lda,
+             const double* B, long long ldb, double beta, double* C, long long ldc);
+int ctm_permute(ctm_ctx* ctx, const double* in, double* out, int nd, const long long* dims, const int* perm);
+/* x /= max|x| (ord_inf=1, ctmrg.py:210-230) ; scale_out (device or NULL) receives the norm */
+int ctm_normalize_inf(ctm_ctx* ctx, double* x, long long n);
+
+/* ---- chi-truncation (linalg/custom_svd.py:38-101, svd_gesdd.py:77-96; custom_eig.py:7-65, eig_sym.py:25-34) */
+/* M is n x n; U,V are n x chi (row-major), S is chi.  Columns beyond the last complete multiplet are zeroed. */
+int ctm_truncated_svd(ctm_ctx* ctx, const double* M, int n, int chi, const ctm_trunc_cfg* cfg, double* U, double* S,
+                      double* V);
+/* A symmetric (lower triangle referenced); D (chi, signed, ordered by |D| descending), U n x chi */
+int ctm_truncated_eigh(ctm_ctx* ctx, const double* A, int n, int chi, const ctm_trunc_cfg* cfg, double* D, double* U);
+/* singular values of an n x n matrix, descending (ENV.get_spectra, env.py:204-209) */
+int ctm_svdvals(ctm_ctx* ctx, const double* M, int n, double* S);
+
+/* ---- generic directional move units ---------------------------------------------------------------- */
+/* c2x2_{LU,RU,RD,LD}_sl_c (ctm_components.py:372-434,532-586,683-733,832-884).
+ * adims = {p,Du,Dl,Dd,Dr}.  out: (chi*Dx^2) x (chi*Dy^2) [x p x p if open]. */
+int ctm_c2x2(ctm_ctx* ctx, int corner, int open, const double* C, const double* T1, const double* T2, const double* a,
+             int chi, const int* adims, double* out);
+/* halves_of_4x4_CTM_MOVE_<DIR>_c (ctm_components.py:52-75,117-139,180-201,244-265): 16 tensors in the
+ * reference's order (C,T1,T2,a) x 4 corners; adims 4x5; R, Rt are n x n. */
+int ctm_halves(ctm_ctx* ctx, int dir, const double* const* tensors16, int chi, const int* adims4x5, double* R,
+               double* Rt);
+/* ctm_get_projectors_from_matrices (ctm_projectors.py:142-293): P, Pt n x chi, S chi (may be NULL) */
+int ctm_projectors(ctm_ctx* ctx, const double* R, const double* Rt, int n, int chi, const ctm_trunc_cfg* cfg, double* P,
+                   double* Pt, double* S);
+/* absorb_truncate_CTM_MOVE_<DIR>_c (ctmrg.py:343-438,459-564,585-680,701-804), 'sl' mode, followed by
+ * move_normalize_c 'inf' (ctmrg.py:210-230) when normalize != 0.  tensors10 = C1,T1,T,T2,C2,A,P2,Pt2,P1,Pt1 */
+int ctm_absorb(ctm_ctx* ctx, int dir, const double* const* tensors10, int chi, const int* adims, int normalize,
+               double* nC1, double* nC2, double* nT);
+
+/* ---- one-site C4v move (ctm/one_site_c4v/ctmrg_c4v.py:325-463; ctm_components_c4v.py:52-130) ---------- */
+int ctm_c2x2_c4v(ctm_ctx* ctx, int open, const double* a, const double* C, const double* T, int chi, int p, int D,
+                 double* out);
+int ctm_move_c4v(ctm_ctx* ctx, const double* a, const double* C, const double* T, int chi, int p, int D,
+                 const ctm_trunc_cfg* cfg, double* C_out, double* T_out, double* D_out /* chi eigenvalues or NULL */);
+
+/* ---- RDMs (ctm/generic/rdm.py:1362-1592, 71-302, 304-500, 622-826; one_site_c4v/rdm_c4v.py) ---------- */
+/* rdm2x2: tensors16 = (C,T1,T2,a) for LU(coord), RU(coord+x), RD(coord+x+y), LD(coord+y); out p^8 raw
+ * (un-normalised, index order s0 s1 s2 s3 s0' s1' s2' s3'); symmetrisation/normalisation is host-side. */
+int ctm_rdm2x2(ctm_ctx* ctx, const double* const* tensors16, int chi, const int* adims4x5, double* out);
+/* rdm1x1 / rdm2x1 / rdm1x2 through the open-corner route; tensor lists documented in INTEGRATION.md */
+int ctm_rdm1x1(ctm_ctx* ctx, const double* const* tensors9 /* C1,C2,C3,C4,T1,T2,T3,T4,a */, int chi, const int* adims,
+               double* out /* p^2 */);
+int ctm_rdm2x1(ctm_ctx* ctx, const double* const* tensors12, int chi, const int* adims2x5, double* out /* p^4 */);
+int ctm_rdm1x2(ctm_ctx* ctx, const double* const* tensors12, int chi, const int* adims2x5, double* out /* p^4 */);
+/* C4v: which = 0 rdm2x1_sl, 1 rdm2x2_NN_lowmem_sl, 2 rdm2x2_NNN_lowmem_sl, 3 rdm2x2 ; raw output */
+int ctm_rdm_c4v(ctm_ctx* ctx, int which, const double* a, const double* C, const double* T, int chi, int p, int D,
+                double* out);
+
+/* ---- env initialisation pieces (ctm/generic/env.py:367-536; env_c4v.py:262-311) ---------------------- */
+/* double-layer partial trace: kind 0..3 corners C(-1,-1),C(1,-1),C(1,1),C(-1,1); 4..7 T(0,-1),T(-1,0),T(0,1),T(1,0);
+ * out is the un-padded, max-abs-normalised tensor of the NEIGHBOUR site `a`. */
+int ctm_init_piece(ctm_ctx* ctx, int kind, const double* a, const int* adims, double* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

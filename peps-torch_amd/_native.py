@@ -1,0 +1,337 @@
+"""ctypes binding of libctm_hip.so (the C-ABI in include/ctm_hip.h) for torch device tensors.
+
+torch is plumbing only: it owns device memory and the HIP stream; every contraction,
+decomposition and reduction of the hot path runs inside the native library.  There is NO
+fallback: if the shared library is missing or a call fails, this module raises.
+"""
+import ctypes as C
+import os
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIBPATH = os.path.join(_HERE, "libctm_hip.so")
+
+CTM_OK = 0
+_ERRNAMES = {1: "bad argument", 2: "shape mismatch", 3: "no convergence", 4: "HIP error", 5: "unsupported", 6: "out of memory"}
+LU, RU, RD, LD = 0, 1, 2, 3
+UP, LEFT, DOWN, RIGHT = 0, 1, 2, 3
+DIR_INDEX = {(0, -1): UP, (-1, 0): LEFT, (0, 1): DOWN, (1, 0): RIGHT}
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+class TruncCfg(C.Structure):
+    _fields_ = [("svd_reltol", C.c_double), ("eps_multiplet", C.c_double), ("multiplet_abstol", C.c_double),
+                ("keep_multiplets", C.c_int), ("fix_signs", C.c_int)]
+
+
+_lib = None
+
+_SIGS = {
+    "ctm_create": [C.POINTER(C.c_void_p), C.c_void_p, C.c_int],
+    "ctm_destroy": [C.c_void_p],
+    "ctm_sync": [C.c_void_p],
+    "ctm_set_option": [C.c_void_p, C.c_char_p, C.c_double],
+    "ctm_get_stat": [C.c_void_p, C.c_char_p, C.POINTER(C.c_double)],
+    "ctm_timers": [C.c_void_p, C.POINTER(C.c_double), C.c_int],
+    "ctm_gemm": [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_longlong,
+                 C.c_void_p, C.c_longlong, C.c_double, C.c_void_p, C.c_longlong],
+    "ctm_permute": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_longlong), C.POINTER(C.c_int)],
+    "ctm_normalize_inf": [C.c_void_p, C.c_void_p, C.c_longlong],
+    "ctm_truncated_svd": [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(TruncCfg), C.c_void_p, C.c_void_p, C.c_void_p],
+    "ctm_truncated_eigh": [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(TruncCfg), C.c_void_p, C.c_void_p],
+    "ctm_svdvals": [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p],
+    "ctm_c2x2": [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_void_p],
+    "ctm_halves": [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_int), C.c_void_p, C.c_void_p],
+    "ctm_projectors": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(TruncCfg), C.c_void_p, C.c_void_p, C.c_void_p],
+    "ctm_absorb": [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_int), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p],
+    "ctm_c2x2_c4v": [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p],
+    "ctm_move_c4v": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(TruncCfg),
+                     C.c_void_p, C.c_void_p, C.c_void_p],
+    "ctm_rdm2x2": [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_int), C.c_void_p],
+    "ctm_rdm1x1": [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_int), C.c_void_p],
+    "ctm_rdm2x1": [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_int), C.c_void_p],
+    "ctm_rdm1x2": [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_int), C.c_void_p],
+    "ctm_rdm_c4v": [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p],
+    "ctm_init_piece": [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_int), C.c_void_p],
+}
+EXPORTS = sorted(list(_SIGS) + ["ctm_last_error", "ctm_version"])
+
+
+def load_library(path=None):
+    """Load libctm_hip.so; raises NativeError when it is not there (no CPU fallback exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = path or _LIBPATH
+    if not os.path.exists(path):
+        raise NativeError(f"{path} not found: build it with `python peps-torch_amd/csrc/build.py` "
+                          "(the engine has no CPU fallback)")
+    lib = C.CDLL(path)
+    for name, args in _SIGS.items():
+        f = getattr(lib, name)
+        f.argtypes = args
+        f.restype = C.c_int
+    lib.ctm_last_error.argtypes = [C.c_void_p]
+    lib.ctm_last_error.restype = C.c_char_p
+    lib.ctm_version.argtypes = []
+    lib.ctm_version.restype = C.c_char_p
+    _lib = lib
+    return lib
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr())
+
+
+def _chk_t(t, name="tensor"):
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float64):
+        raise NativeError(f"{name}: expected a float64 CUDA(HIP) tensor, got {type(t)} "
+                          f"{getattr(t, 'dtype', None)} {getattr(t, 'device', None)}")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+class Engine:
+    """One native context bound to the current torch device and its current stream."""
+
+    def __init__(self, device=None):
+        self.lib = load_library()
+        if not torch.cuda.is_available():
+            raise NativeError("no HIP device visible: the CTM engine runs only on the GPU")
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        with torch.cuda.device(self.device):
+            self.stream = torch.cuda.current_stream(self.device)
+            h = C.c_void_p()
+            st = self.lib.ctm_create(C.byref(h), C.c_void_p(self.stream.cuda_stream), 0)
+            if st != CTM_OK:
+                raise NativeError(f"ctm_create failed: {_ERRNAMES.get(st, st)}")
+            self.h = h
+        self.default_cfg = TruncCfg(1e-8, 1e-8, 1e-14, 1, 1)
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.lib.ctm_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def _ck(self, st, what):
+        if st != CTM_OK:
+            msg = self.lib.ctm_last_error(self.h)
+            raise NativeError(f"{what}: {_ERRNAMES.get(st, st)}: {msg.decode() if msg else ''}")
+
+    def empty(self, *shape):
+        return torch.empty(shape, dtype=torch.float64, device=self.device)
+
+    # ---- options / stats ------------------------------------------------------------------
+    def set_option(self, key, value):
+        self._ck(self.lib.ctm_set_option(self.h, key.encode(), float(value)), "set_option")
+
+    def stat(self, key):
+        v = C.c_double()
+        self._ck(self.lib.ctm_get_stat(self.h, key.encode(), C.byref(v)), "get_stat")
+        return v.value
+
+    def timers(self, reset=False):
+        buf = (C.c_double * 8)()
+        self._ck(self.lib.ctm_timers(self.h, buf, int(reset)), "timers")
+        names = ["corners", "halves", "svd", "proj", "absorb", "norm", "rdm", "eig"]
+        return dict(zip(names, list(buf)))
+
+    def sync(self):
+        self._ck(self.lib.ctm_sync(self.h), "sync")
+
+    def cfg(self, svd_reltol=1e-8, eps_multiplet=1e-8, multiplet_abstol=1e-14, keep_multiplets=True, fix_signs=True):
+        return TruncCfg(svd_reltol, eps_multiplet, multiplet_abstol, int(keep_multiplets), int(fix_signs))
+
+    # ---- primitives ---------------------------------------------------------------------------
+    def gemm(self, A, B, transA=False, transB=False, alpha=1.0):
+        A = _chk_t(A, "A"); B = _chk_t(B, "B")
+        M, K = (A.shape[1], A.shape[0]) if transA else A.shape
+        K2, N = (B.shape[1], B.shape[0]) if transB else B.shape
+        if K != K2:
+            raise NativeError("gemm: inner dimensions differ")
+        out = self.empty(M, N)
+        self._ck(self.lib.ctm_gemm(self.h, int(transA), int(transB), M, N, K, alpha, _ptr(A), A.shape[1], _ptr(B),
+                                   B.shape[1], 0.0, _ptr(out), N), "gemm")
+        return out
+
+    def permute(self, x, perm):
+        x = _chk_t(x)
+        nd = x.dim()
+        out = self.empty(*[x.shape[p] for p in perm])
+        dims = (C.c_longlong * nd)(*x.shape)
+        pm = (C.c_int * nd)(*perm)
+        self._ck(self.lib.ctm_permute(self.h, _ptr(x), _ptr(out), nd, dims, pm), "permute")
+        return out
+
+    def normalize_inf_(self, x):
+        self._ck(self.lib.ctm_normalize_inf(self.h, _ptr(x), x.numel()), "normalize_inf")
+        return x
+
+    # ---- truncation -----------------------------------------------------------------------------
+    def truncated_svd(self, M, chi, cfg=None):
+        M = _chk_t(M, "M")
+        n = M.shape[0]
+        if M.dim() != 2 or M.shape[1] != n:
+            raise NativeError("truncated_svd: square matrices only on this path")
+        kc = min(chi, n)
+        U, S, V = self.empty(n, kc), self.empty(kc), self.empty(n, kc)
+        cfg = cfg or self.default_cfg
+        self._ck(self.lib.ctm_truncated_svd(self.h, _ptr(M), n, chi, C.byref(cfg), _ptr(U), _ptr(S), _ptr(V)), "truncated_svd")
+        return U, S, V
+
+    def truncated_eigh(self, A, chi, cfg=None):
+        A = _chk_t(A, "A")
+        n = A.shape[0]
+        kc = min(chi, n)
+        D, U = self.empty(kc), self.empty(n, kc)
+        cfg = cfg or self.cfg(eps_multiplet=1e-12)
+        self._ck(self.lib.ctm_truncated_eigh(self.h, _ptr(A), n, chi, C.byref(cfg), _ptr(D), _ptr(U)), "truncated_eigh")
+        return D, U
+
+    def svdvals(self, M):
+        M = _chk_t(M, "M")
+        n = M.shape[0]
+        S = self.empty(n)
+        self._ck(self.lib.ctm_svdvals(self.h, _ptr(M), n, _ptr(S)), "svdvals")
+        return S
+
+    # ---- generic move units -----------------------------------------------------------------------
+    @staticmethod
+    def _adims(a):
+        return (C.c_int * 5)(*a.shape)
+
+    def c2x2(self, corner, C_, T1, T2, a, open_=False):
+        C_, T1, T2, a = (_chk_t(x) for x in (C_, T1, T2, a))
+        chi = C_.shape[0]
+        ad = a.shape
+        leg0 = (3, 2, 1, 1)[corner]; leg1 = (4, 3, 2, 4)[corner]
+        n0, n1 = chi * ad[leg0] ** 2, chi * ad[leg1] ** 2
+        out = self.empty(n0, n1, ad[0], ad[0]) if open_ else self.empty(n0, n1)
+        self._ck(self.lib.ctm_c2x2(self.h, corner, int(open_), _ptr(C_), _ptr(T1), _ptr(T2), _ptr(a), chi,
+                                   self._adims(a), _ptr(out)), "c2x2")
+        return out
+
+    def _pack16(self, tensors):
+        ts = [_chk_t(t) for t in tensors]
+        arr = (C.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+        ad = []
+        for i in range(3, len(ts), 4):
+            ad += list(ts[i].shape)
+        return ts, arr, (C.c_int * len(ad))(*ad)
+
+    def halves(self, direction, tensors16):
+        """tensors16: (C,T1,T2,a) of corner A of R, corner B of R, corner A of Rt, corner B of Rt."""
+        ts, arr, ad = self._pack16(tensors16)
+        chi = ts[0].shape[0]
+        d = DIR_INDEX[direction] if isinstance(direction, tuple) else direction
+        # all four corners of a half share the fused dimension n = chi * D^2 for uniform D
+        a0 = ts[3].shape
+        n = chi * a0[1] ** 2
+        R, Rt = self.empty(n, n), self.empty(n, n)
+        self._ck(self.lib.ctm_halves(self.h, d, arr, chi, ad, _ptr(R), _ptr(Rt)), "halves")
+        return R, Rt
+
+    def projectors(self, R, Rt, chi, cfg=None, return_S=False):
+        R, Rt = _chk_t(R, "R"), _chk_t(Rt, "Rt")
+        if R.shape != Rt.shape or R.dim() != 2:
+            raise AssertionError("R and Rt must be matrices of equal shape")     # ctm_projectors.py:209
+        n = R.shape[0]
+        kc = min(chi, n)
+        P, Pt, S = self.empty(n, kc), self.empty(n, kc), self.empty(kc)
+        cfg = cfg or self.default_cfg
+        self._ck(self.lib.ctm_projectors(self.h, _ptr(R), _ptr(Rt), n, chi, C.byref(cfg), _ptr(P), _ptr(Pt), _ptr(S)), "projectors")
+        return (P, Pt, S) if return_S else (P, Pt)
+
+    def absorb(self, direction, tensors10, normalize=True):
+        ts = [_chk_t(t) for t in tensors10]
+        arr = (C.c_void_p * 10)(*[t.data_ptr() for t in ts])
+        A = ts[5]
+        chi = ts[0].shape[0]
+        d = DIR_INDEX[direction] if isinstance(direction, tuple) else direction
+        out_leg = (3, 4, 1, 2)[d]
+        D2 = A.shape[out_leg] ** 2
+        shapes = {UP: (chi, D2, chi), LEFT: (chi, chi, D2), DOWN: (D2, chi, chi), RIGHT: (chi, D2, chi)}
+        nC1, nC2, nT = self.empty(chi, chi), self.empty(chi, chi), self.empty(*shapes[d])
+        self._ck(self.lib.ctm_absorb(self.h, d, arr, chi, self._adims(A), int(normalize), _ptr(nC1), _ptr(nC2), _ptr(nT)), "absorb")
+        return nC1, nC2, nT
+
+    # ---- C4v ------------------------------------------------------------------------------------------
+    def c2x2_c4v(self, a, C_, T, open_=False):
+        a, C_, T = _chk_t(a), _chk_t(C_), _chk_t(T)
+        chi, p, D = C_.shape[0], a.shape[0], a.shape[1]
+        n = chi * D * D
+        out = self.empty(n, n, p, p) if open_ else self.empty(n, n)
+        self._ck(self.lib.ctm_c2x2_c4v(self.h, int(open_), _ptr(a), _ptr(C_), _ptr(T), chi, p, D, _ptr(out)), "c2x2_c4v")
+        return out
+
+    def move_c4v(self, a, C_, T, cfg=None):
+        a, C_, T = _chk_t(a), _chk_t(C_), _chk_t(T)
+        chi, p, D = C_.shape[0], a.shape[0], a.shape[1]
+        nC, nT, Dv = self.empty(chi, chi), self.empty(chi, chi, D * D), self.empty(chi)
+        cfg = cfg or self.cfg(eps_multiplet=1e-12)
+        self._ck(self.lib.ctm_move_c4v(self.h, _ptr(a), _ptr(C_), _ptr(T), chi, p, D, C.byref(cfg), _ptr(nC), _ptr(nT), _ptr(Dv)), "move_c4v")
+        return nC, nT, Dv
+
+    def rdm_c4v(self, which, a, C_, T):
+        a, C_, T = _chk_t(a), _chk_t(C_), _chk_t(T)
+        chi, p, D = C_.shape[0], a.shape[0], a.shape[1]
+        out = self.empty(*([p] * (8 if which == 3 else 4)))
+        self._ck(self.lib.ctm_rdm_c4v(self.h, which, _ptr(a), _ptr(C_), _ptr(T), chi, p, D, _ptr(out)), "rdm_c4v")
+        return out
+
+    # ---- RDMs ------------------------------------------------------------------------------------------
+    def rdm2x2(self, tensors16):
+        ts, arr, ad = self._pack16(tensors16)
+        p = ts[3].shape[0]
+        out = self.empty(*([p] * 8))
+        self._ck(self.lib.ctm_rdm2x2(self.h, arr, ts[0].shape[0], ad, _ptr(out)), "rdm2x2")
+        return out
+
+    def rdm1x1(self, tensors9):
+        ts = [_chk_t(t) for t in tensors9]
+        arr = (C.c_void_p * 9)(*[t.data_ptr() for t in ts])
+        a = ts[8]
+        out = self.empty(a.shape[0], a.shape[0])
+        self._ck(self.lib.ctm_rdm1x1(self.h, arr, ts[0].shape[0], self._adims(a), _ptr(out)), "rdm1x1")
+        return out
+
+    def _rdm2(self, fn, tensors12, name):
+        ts = [_chk_t(t) for t in tensors12]
+        arr = (C.c_void_p * 12)(*[t.data_ptr() for t in ts])
+        a0, a1 = ts[5], ts[11]
+        ad = (C.c_int * 10)(*(list(a0.shape) + list(a1.shape)))
+        p = a0.shape[0]
+        out = self.empty(p, p, p, p)
+        self._ck(fn(self.h, arr, ts[0].shape[0], ad, _ptr(out)), name)
+        return out
+
+    def rdm2x1(self, tensors12):
+        return self._rdm2(self.lib.ctm_rdm2x1, tensors12, "rdm2x1")
+
+    def rdm1x2(self, tensors12):
+        return self._rdm2(self.lib.ctm_rdm1x2, tensors12, "rdm1x2")
+
+    def init_piece(self, kind, a):
+        a = _chk_t(a)
+        kept = [(3, 4), (2, 3), (1, 2), (1, 4), (2, 3, 4), (1, 3, 4), (1, 2, 4), (1, 2, 3)][kind]
+        out = self.empty(*[a.shape[k] ** 2 for k in kept])
+        self._ck(self.lib.ctm_init_piece(self.h, kind, _ptr(a), self._adims(a), _ptr(out)), "init_piece")
+        return out
+
+
+_engines = {}
+
+
+def engine(device=None):
+    """Process-wide engine per device (created lazily)."""
+    if not torch.cuda.is_available():
+        raise NativeError("no HIP device visible: the CTM engine runs only on the GPU (no CPU fallback)")
+    idx = torch.cuda.current_device() if device is None else torch.device(device).index or 0
+    if idx not in _engines:
+        _engines[idx] = Engine(torch.device("cuda", idx))
+    return _engines[idx]

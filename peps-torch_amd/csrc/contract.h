@@ -1,0 +1,21 @@
+// Device tensors + pairwise-einsum executor (contract.hip).
+#pragma once
+#include "ctm_common.h"
+
+struct DT {
+    double* p = nullptr;
+    std::vector<long long> dims;
+    DT() {}
+    DT(const double* ptr, std::initializer_list<long long> d) : p(const_cast<double*>(ptr)), dims(d) {}
+    DT(const double* ptr, const std::vector<long long>& d) : p(const_cast<double*>(ptr)), dims(d) {}
+    long long numel() const;
+    DT view(std::initializer_list<long long> d) const { DT t; t.p = p; t.dims = d; return t; }
+    DT view(const std::vector<long long>& d) const { DT t; t.p = p; t.dims = d; return t; }
+};
+
+// C[io] = sum over indices shared by ia, ib and absent from io.  If out->p != nullptr the result is
+// written there, otherwise it is arena-allocated (valid until the caller's ArenaScope ends).
+int dev_einsum2(ctm_ctx* ctx, const std::string& ia, const DT& A, const std::string& ib, const DT& B,
+                const std::string& io, DT* out);
+// "ab,bcd,...->xyz" evaluated strictly left to right (same order as the oracle's seq_einsum).
+int dev_seq_einsum(ctm_ctx* ctx, const std::string& expr, const std::vector<DT>& ops, DT* out);

@@ -1,0 +1,120 @@
+// Device tensor-network contraction executor: pairwise einsum -> (optional coalesced permute) + FP64
+// MFMA GEMM.  Replaces the reference's tn_interface.contract/einsum (tn_interface.py:3-27), i.e. every
+// torch.tensordot / torch.einsum on the hot path.  Index strings are single letters; a pairwise step
+// has no batch (Hadamard) indices in any CTM contraction, so it is exactly one GEMM:
+//   C[freeA..., freeB...] = sum_K A[...] B[...]
+// An operand is used in place (N or T form, arbitrary leading stride) whenever its contracted indices
+// form a contiguous prefix/suffix in memory in a K-order both operands agree on; otherwise the SMALLER
+// operand is re-laid-out by the tiled permute kernel.
+#include "contract.h"
+#include <algorithm>
+
+long long DT::numel() const { long long n = 1; for (auto d : dims) n *= d; return n; }
+
+namespace {
+
+bool is_prefix(const std::string& idx, const std::string& c) { return idx.compare(0, c.size(), c) == 0; }
+bool is_suffix(const std::string& idx, const std::string& c) {
+    return idx.size() >= c.size() && idx.compare(idx.size() - c.size(), c.size(), c) == 0;
+}
+
+long long dim_of(const std::string& idx, const DT& t, char ch) {
+    const size_t p = idx.find(ch);
+    return t.dims[p];
+}
+
+// permute tensor t (indices `from`) into index order `to` (arena-allocated)
+int relayout(ctm_ctx* ctx, const std::string& from, const DT& t, const std::string& to, DT* out) {
+    const int nd = (int)from.size();
+    long long dims[CTM_MAXD]; int perm[CTM_MAXD];
+    out->dims.resize(nd);
+    for (int a = 0; a < nd; ++a) {
+        dims[a] = t.dims[a];
+        perm[a] = (int)from.find(to[a]);
+        out->dims[a] = t.dims[perm[a]];
+    }
+    if (!out->p) CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)t.numel(), (void**)&out->p));
+    return permute_f64(ctx, t.p, out->p, nd, dims, perm);
+}
+
+}  // namespace
+
+int dev_einsum2(ctm_ctx* ctx, const std::string& ia_, const DT& A_, const std::string& ib_, const DT& B_,
+                const std::string& io, DT* out) {
+    std::string ia = ia_, ib = ib_;
+    DT A = A_, B = B_;
+    if ((int)ia.size() != (int)A.dims.size() || (int)ib.size() != (int)B.dims.size()) {
+        ctx->set_error("einsum2: rank mismatch " + ia + "," + ib); return CTM_ERR_SHAPE;
+    }
+    std::string cA, cB, fA, fB;
+    for (char ch : ia) { if (ib.find(ch) != std::string::npos && io.find(ch) == std::string::npos) cA += ch; else fA += ch; }
+    for (char ch : ib) { if (ia.find(ch) != std::string::npos && io.find(ch) == std::string::npos) cB += ch; else fB += ch; }
+    for (char ch : cA) if (dim_of(ia, A, ch) != dim_of(ib, B, ch)) {
+        ctx->set_error(std::string("einsum2: dim mismatch on index ") + ch + " in " + ia + "," + ib); return CTM_ERR_SHAPE;
+    }
+    for (char ch : fA) if (fB.find(ch) != std::string::npos) { ctx->set_error("einsum2: batch index unsupported"); return CTM_ERR_UNSUPPORTED; }
+    if (cA.empty()) { ctx->set_error("einsum2: outer product unsupported"); return CTM_ERR_UNSUPPORTED; }
+
+    bool A_ok = is_prefix(ia, cA) || is_suffix(ia, cA);
+    bool B_ok = is_prefix(ib, cB) || is_suffix(ib, cB);
+    std::string korder;
+    if (A_ok && B_ok && cA == cB) korder = cA;
+    else if (A_ok && B_ok) { if (A.numel() >= B.numel()) { korder = cA; B_ok = false; } else { korder = cB; A_ok = false; } }
+    else if (A_ok) korder = cA;
+    else if (B_ok) korder = cB;
+    else korder = (A.numel() >= B.numel()) ? cA : cB;
+    if (!A_ok || (korder != cA)) {
+        if (!(is_prefix(ia, korder) || is_suffix(ia, korder))) {
+            DT An; const std::string to = fA + korder;
+            CTM_TRY(relayout(ctx, ia, A, to, &An)); A = An; ia = to;
+        }
+    }
+    if (!B_ok || (korder != cB)) {
+        if (!(is_prefix(ib, korder) || is_suffix(ib, korder))) {
+            DT Bn; const std::string to = korder + fB;
+            CTM_TRY(relayout(ctx, ib, B, to, &Bn)); B = Bn; ib = to;
+        }
+    }
+    long long M = 1, N = 1, K = 1;
+    for (char ch : fA) M *= dim_of(ia, A, ch);
+    for (char ch : fB) N *= dim_of(ib, B, ch);
+    for (char ch : korder) K *= dim_of(ia, A, ch);
+    GemmDesc g;
+    g.M = (int)M; g.N = (int)N; g.K = (int)K;
+    g.A = A.p; if (is_suffix(ia, korder)) { g.sam = K; g.sak = 1; } else { g.sam = 1; g.sak = M; }
+    g.B = B.p; if (is_prefix(ib, korder)) { g.sbk = N; g.sbn = 1; } else { g.sbk = 1; g.sbn = K; }
+    const std::string nat = fA + fB;
+    DT C;
+    C.dims.clear();
+    for (char ch : fA) C.dims.push_back(dim_of(ia, A, ch));
+    for (char ch : fB) C.dims.push_back(dim_of(ib, B, ch));
+    const bool direct = (nat == io);
+    if (direct && out->p) C.p = out->p; else CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)(M * N), (void**)&C.p));
+    g.C = C.p; g.ldc = N;
+    CTM_TRY(gemm_f64(ctx, g));
+    if (direct) { out->p = C.p; out->dims = C.dims; return CTM_OK; }
+    return relayout(ctx, nat, C, io, out);
+}
+
+int dev_seq_einsum(ctm_ctx* ctx, const std::string& expr, const std::vector<DT>& ops, DT* out) {
+    const size_t arrow = expr.find("->");
+    const std::string lhs = expr.substr(0, arrow), oidx = expr.substr(arrow + 2);
+    std::vector<std::string> ins;
+    { size_t s = 0; while (true) { size_t c = lhs.find(',', s); ins.push_back(lhs.substr(s, c == std::string::npos ? c : c - s)); if (c == std::string::npos) break; s = c + 1; } }
+    if (ins.size() != ops.size() || ins.size() < 2) { ctx->set_error("seq_einsum: operand count"); return CTM_ERR_BADARG; }
+    DT cur = ops[0];
+    std::string cidx = ins[0];
+    for (size_t k = 1; k < ins.size(); ++k) {
+        const bool last = (k + 1 == ins.size());
+        std::string later = oidx;
+        for (size_t j = k + 1; j < ins.size(); ++j) later += ins[j];
+        std::string nidx;
+        for (char ch : cidx + ins[k]) if (later.find(ch) != std::string::npos && nidx.find(ch) == std::string::npos) nidx += ch;
+        DT nxt;
+        if (last) { nxt.p = out->p; CTM_TRY(dev_einsum2(ctx, cidx, cur, ins[k], ops[k], oidx, &nxt)); }
+        else CTM_TRY(dev_einsum2(ctx, cidx, cur, ins[k], ops[k], nidx, &nxt));
+        cur = nxt; cidx = last ? oidx : nidx;
+    }
+    *out = cur;
+    return CTM_OK;
+}

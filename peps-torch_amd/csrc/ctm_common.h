@@ -1,0 +1,137 @@
+// Internal (non-ABI) declarations shared by the HIP translation units of libctm_hip.so.
+// gfx950 / CDNA4 only.  The public C-ABI is include/ctm_hip.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include <map>
+#include <chrono>
+
+#include "../../include/ctm_hip.h"
+
+#define CTM_HIP_CHECK(ctx, expr)                                                        \
+    do {                                                                                \
+        hipError_t _e = (expr);                                                         \
+        if (_e != hipSuccess) {                                                         \
+            (ctx)->set_error(std::string(#expr) + ": " + hipGetErrorString(_e));        \
+            return CTM_ERR_HIP;                                                         \
+        }                                                                               \
+    } while (0)
+
+#define CTM_TRY(expr)                        \
+    do {                                     \
+        int _s = (expr);                     \
+        if (_s != CTM_OK) return _s;         \
+    } while (0)
+
+// ---- device workspace arena: stack allocator over a chain of slabs, grown on demand ---------
+struct Slab { char* base = nullptr; size_t cap = 0; };
+struct Arena {
+    std::vector<Slab> slabs;
+    int cur = -1;                  // current slab
+    size_t top = 0;                // offset in the current slab
+    size_t high = 0, total = 0;
+};
+
+// per-phase timers (seconds, host wall time with stream sync when profiling is enabled)
+enum { CTM_T_CORNERS = 0, CTM_T_HALVES, CTM_T_SVD, CTM_T_PROJ, CTM_T_ABSORB, CTM_T_NORM, CTM_T_RDM, CTM_T_EIG, CTM_T_COUNT };
+
+struct ctm_ctx {
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int device = 0;
+    Arena arena;
+    std::string last_error;
+    // jacobi state
+    int jacobi_block = 32;
+    int jacobi_max_sweeps = 30;
+    double jacobi_tol = 1e-14;
+    int last_sweeps = 0;
+    double last_offnorm = 0;
+    std::map<int, int*> rr_tables;       // nblocks -> device round-robin pair table
+    double* d_scratch = nullptr;         // small device scalars (64 doubles)
+    double* h_scratch = nullptr;         // pinned host mirror
+    // timers
+    bool profile = false;
+    double timers[CTM_T_COUNT] = {0};
+    // GEMM instrumentation (flop count of all GEMM launches)
+    double gemm_flops = 0;
+    long gemm_calls = 0;
+    void set_error(const std::string& s) { last_error = s; }
+};
+
+// arena API (ctm_runtime.hip)
+int arena_alloc(ctm_ctx* ctx, size_t bytes, void** out);
+struct ArenaScope {
+    ctm_ctx* c; int cur; size_t top;
+    explicit ArenaScope(ctm_ctx* ctx) : c(ctx), cur(ctx->arena.cur), top(ctx->arena.top) {}
+    ~ArenaScope() { c->arena.cur = cur; c->arena.top = top; }
+};
+
+struct PhaseTimer {
+    ctm_ctx* c; int id; std::chrono::high_resolution_clock::time_point t0;
+    PhaseTimer(ctm_ctx* ctx, int i) : c(ctx), id(i) {
+        if (c->profile) { (void)hipStreamSynchronize(c->stream); t0 = std::chrono::high_resolution_clock::now(); }
+    }
+    ~PhaseTimer() {
+        if (c->profile) {
+            (void)hipStreamSynchronize(c->stream);
+            c->timers[id] += std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - t0).count();
+        }
+    }
+};
+
+// ---- GEMM (gemm_f64.hip) -----------------------------------------------------------------
+// C(m,n) = alpha * sum_k A(m,k) B(k,n) + beta * C(m,n),  element addresses
+//   A(m,k) = A + segA(m) + k*sak      with segA(m) = (m < splitA ? a0 + m*sam : a1 + (m-splitA)*sam)
+//   B(k,n) = B + segB(.) ...          the segmented dim of B is K (splitB_dim=1) or N (splitB_dim=2)
+//   C(m,n) = C + segC(m) + n          (row-major, unit column stride)
+// batched over `batch` entries of offsets (device array of GemmOff) or regular strides.
+struct GemmOff { long long a0, a1, b0, b1, c0, c1; };
+
+struct GemmDesc {
+    int M = 0, N = 0, K = 0;
+    const double* A = nullptr; long long sam = 0, sak = 0;
+    const double* B = nullptr; long long sbk = 0, sbn = 0;
+    double* C = nullptr; long long ldc = 0;
+    double alpha = 1.0, beta = 0.0;
+    int batch = 1;
+    long long strideA = 0, strideB = 0, strideC = 0;   // regular batching (used when offs == nullptr)
+    const GemmOff* offs = nullptr;                      // device pointer, optional
+    int splitA = 1 << 30, splitB = 1 << 30, splitC = 1 << 30;
+    int splitB_dim = 0;                                  // 0 none, 1 = K, 2 = N
+    // optional fused column scale of the output: C(m,n) *= colscale[n]
+    const double* colscale = nullptr;
+};
+int gemm_f64(ctm_ctx* ctx, const GemmDesc& d);
+
+// ---- elementwise / layout kernels (tensor_ops.hip) -----------------------------------------
+#define CTM_MAXD 8
+int permute_f64(ctm_ctx* ctx, const double* in, double* out, int nd, const long long* dims, const int* perm);
+int absmax_f64(ctm_ctx* ctx, const double* x, size_t n, double* d_out);           // d_out: device scalar
+int div_by_device_scalar(ctm_ctx* ctx, double* x, size_t n, const double* d_s, int use_abs);
+int fill_f64(ctm_ctx* ctx, double* x, size_t n, double v);
+int set_identity(ctm_ctx* ctx, double* x, int n, long long ld);
+int copy2d(ctm_ctx* ctx, const double* src, long long lds, double* dst, long long ldd, int rows, int cols);
+int row_norms(ctm_ctx* ctx, const double* x, int rows, int cols, long long ld, double* d_out);
+int row_dots(ctm_ctx* ctx, const double* x, const double* y, int rows, int cols, long long ld, double* d_out);
+int gather_rows(ctm_ctx* ctx, const double* src, long long lds, const int* d_idx, int nrows, int cols, double* dst,
+                long long ldd, const double* d_rowscale);
+int symmetrize_lower(ctm_ctx* ctx, const double* a, double* out, int n, double shift);
+int add_transposed01(ctm_ctx* ctx, double* t, int d0, int d2);   // t[i,j,s] = 0.5 (t[i,j,s] + t[j,i,s])
+int tril_correction(ctm_ctx* ctx, double* E, int k);             // E -> I - strict_lower(E) - diag(E)/2 with E=G-I
+int diag_to_matrix(ctm_ctx* ctx, const double* d, double* out, int n);
+int trace_partial(ctm_ctx* ctx, const double* in, double* out, long long n2, int p);  // out[ab] = sum_i in[ab,i,i]
+
+// ---- Jacobi SVD / eig (jacobi.hip) -----------------------------------------------------------
+// Full one-sided block Jacobi on the rows of M (n x n).  Outputs the k leading triplets:
+//   S[k] (descending), Ut (k x n, rows = u_i^T), Vt (k x n, rows = v_i^T).
+int jacobi_svd_top(ctm_ctx* ctx, const double* M, int n, int k, double* S, double* Ut, double* Vt);
+// Symmetric eigendecomposition (lower triangle of A is referenced), k leading eigenpairs by |lambda|:
+//   D[k] (signed), Ut (k x n, rows = eigenvectors).
+int jacobi_eigh_top(ctm_ctx* ctx, const double* A, int n, int k, double* D, double* Ut);
+// singular values only, small matrices (corner spectra)
+int jacobi_svdvals(ctm_ctx* ctx, const double* M, int n, double* S);

@@ -1,0 +1,130 @@
+// Context, workspace arena and the primitive entry points of the C-ABI (include/ctm_hip.h).
+#include "ctm_common.h"
+
+int arena_alloc(ctm_ctx* ctx, size_t bytes, void** out) {
+    Arena& a = ctx->arena;
+    bytes = (bytes + 255) & ~(size_t)255;
+    if (bytes == 0) bytes = 256;
+    if (a.cur >= 0 && a.top + bytes <= a.slabs[a.cur].cap) {
+        *out = a.slabs[a.cur].base + a.top;
+        a.top += bytes;
+        return CTM_OK;
+    }
+    // move to the next slab (reuse it if large enough, else replace it)
+    int nxt = a.cur + 1;
+    if (nxt < (int)a.slabs.size() && a.slabs[nxt].cap < bytes) {
+        // later slabs are unused at this point (stack discipline): free them all and regrow
+        (void)hipStreamSynchronize(ctx->stream);
+        for (int i = (int)a.slabs.size() - 1; i >= nxt; --i) {
+            (void)hipFree(a.slabs[i].base); a.total -= a.slabs[i].cap; a.slabs.pop_back();
+        }
+    }
+    if (nxt >= (int)a.slabs.size()) {
+        size_t cap = bytes;
+        const size_t min_cap = (size_t)64 << 20;
+        if (cap < min_cap) cap = min_cap;
+        if (!a.slabs.empty() && cap < a.slabs.back().cap) cap = a.slabs.back().cap;
+        Slab s;
+        hipError_t e = hipMalloc((void**)&s.base, cap);
+        if (e != hipSuccess && cap > bytes) { cap = bytes; e = hipMalloc((void**)&s.base, cap); }
+        if (e != hipSuccess) {
+            ctx->set_error("arena: hipMalloc of " + std::to_string(cap) + " bytes failed: " + hipGetErrorString(e));
+            return CTM_ERR_NOMEM;
+        }
+        s.cap = cap;
+        a.slabs.push_back(s);
+        a.total += cap;
+        if (a.total > a.high) a.high = a.total;
+    }
+    a.cur = nxt;
+    a.top = bytes;
+    *out = a.slabs[a.cur].base;
+    return CTM_OK;
+}
+
+extern "C" {
+
+const char* ctm_version(void) { return "ctm_hip 0.1 (gfx950, f64)"; }
+
+int ctm_create(ctm_ctx** out, void* hip_stream, int dtype) {
+    if (!out) return CTM_ERR_BADARG;
+    *out = nullptr;
+    if (dtype != CTM_F64) return CTM_ERR_UNSUPPORTED;   // complex128 planes: not in this build
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return CTM_ERR_HIP;
+    ctm_ctx* c = new ctm_ctx();
+    (void)hipGetDevice(&c->device);
+    if (hip_stream) c->stream = (hipStream_t)hip_stream;
+    else { if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return CTM_ERR_HIP; } c->own_stream = true; }
+    if (hipMalloc((void**)&c->d_scratch, 64 * sizeof(double)) != hipSuccess ||
+        hipHostMalloc((void**)&c->h_scratch, 64 * sizeof(double)) != hipSuccess) { delete c; return CTM_ERR_NOMEM; }
+    *out = c;
+    return CTM_OK;
+}
+
+int ctm_destroy(ctm_ctx* ctx) {
+    if (!ctx) return CTM_OK;
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto& s : ctx->arena.slabs) (void)hipFree(s.base);
+    if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
+    if (ctx->h_scratch) (void)hipHostFree(ctx->h_scratch);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return CTM_OK;
+}
+
+const char* ctm_last_error(ctm_ctx* ctx) { return ctx ? ctx->last_error.c_str() : "null context"; }
+
+int ctm_sync(ctm_ctx* ctx) {
+    CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return CTM_OK;
+}
+
+int ctm_set_option(ctm_ctx* ctx, const char* key, double value) {
+    const std::string k(key ? key : "");
+    if (k == "jacobi_tol") ctx->jacobi_tol = value;
+    else if (k == "jacobi_max_sweeps") ctx->jacobi_max_sweeps = (int)value;
+    else if (k == "jacobi_block") ctx->jacobi_block = (int)value;
+    else if (k == "profile") ctx->profile = value != 0.0;
+    else { ctx->set_error("unknown option " + k); return CTM_ERR_BADARG; }
+    return CTM_OK;
+}
+
+int ctm_get_stat(ctm_ctx* ctx, const char* key, double* value) {
+    const std::string k(key ? key : "");
+    if (k == "last_sweeps") *value = ctx->last_sweeps;
+    else if (k == "last_offnorm") *value = ctx->last_offnorm;
+    else if (k == "gemm_flops") *value = ctx->gemm_flops;
+    else if (k == "gemm_calls") *value = (double)ctx->gemm_calls;
+    else if (k == "arena_high") *value = (double)ctx->arena.high;
+    else { ctx->set_error("unknown stat " + k); return CTM_ERR_BADARG; }
+    return CTM_OK;
+}
+
+int ctm_timers(ctm_ctx* ctx, double* out8, int reset) {
+    for (int i = 0; i < CTM_T_COUNT; ++i) { if (out8) out8[i] = ctx->timers[i]; if (reset) ctx->timers[i] = 0.0; }
+    if (reset) { ctx->gemm_flops = 0; ctx->gemm_calls = 0; }
+    return CTM_OK;
+}
+
+int ctm_gemm(ctm_ctx* ctx, int transA, int transB, int M, int N, int K, double alpha, const double* A, long long lda,
+             const double* B, long long ldb, double beta, double* C, long long ldc) {
+    GemmDesc d;
+    d.M = M; d.N = N; d.K = K; d.alpha = alpha; d.beta = beta;
+    d.A = A; if (transA) { d.sam = 1; d.sak = lda; } else { d.sam = lda; d.sak = 1; }
+    d.B = B; if (transB) { d.sbk = 1; d.sbn = ldb; } else { d.sbk = ldb; d.sbn = 1; }
+    d.C = C; d.ldc = ldc;
+    return gemm_f64(ctx, d);
+}
+
+int ctm_permute(ctm_ctx* ctx, const double* in, double* out, int nd, const long long* dims, const int* perm) {
+    return permute_f64(ctx, in, out, nd, dims, perm);
+}
+
+int ctm_normalize_inf(ctm_ctx* ctx, double* x, long long n) {
+    double* s = ctx->d_scratch + 8;
+    CTM_TRY(absmax_f64(ctx, x, (size_t)n, s));
+    return div_by_device_scalar(ctx, x, (size_t)n, s, 0);
+}
+
+}  // extern "C"

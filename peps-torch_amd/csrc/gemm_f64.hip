@@ -1,0 +1,211 @@
+// FP64 GEMM for gfx950 on the matrix cores: v_mfma_f64_16x16x4_f64, LDS-staged, double-buffered.
+//
+// This is the kernel every heavy contraction of the CTM move lowers to (SURVEY 2.3 K2,K6,K7,K11,
+// K12,K13 and the Gram/apply steps of the block-Jacobi SVD).  Design (CDNA4):
+//   * block = 256 threads = 4 wave64 in a 2x2 grid; each wave owns TM x TN MFMA tiles of 16x16
+//     (accumulators stay in registers for the whole K loop: 4 f64 per lane per tile);
+//   * A and B tiles are staged global -> VGPR -> LDS in a k-major image As[k][m], Bs[k][n] so that
+//     the MFMA operand fetch (lane l: row/col l&15, k = l>>4) is one ds_read_b64 per operand;
+//   * two LDS buffers, one barrier per K tile: the global loads of tile t+1 are issued before
+//     the MFMA work of tile t and written to the other buffer after it;
+//   * operands are addressed with arbitrary (row, k) strides + an optional two-segment row
+//     map, so transposed operands, tensor slices and the (i,j) row-panel pairs of the Jacobi
+//     sweep need no gather copy; batching via blockIdx.z;
+//   * the blockIdx -> tile map walks tiles XCD-major so that the 8 XCD-private L2s each see a
+//     compact band of B columns.
+// FP64 MFMA peak on MI355X is 78.6 TFLOP/s (32 flop/clk/SIMD): one MFMA (2048 flop) issues every
+// 64 cycles, so LDS and global bandwidth needs are modest; the kernel is issue-bound on MFMA when
+// K is long.  C/D fragment layout of the f64 MFMA: col = lane&15, row = (lane>>4) + 4*reg.
+#include "ctm_common.h"
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int BK = 16;
+constexpr int PAD = 2;
+
+struct GemmParams {
+    int M, N, K;
+    const double* A; long long sam, sak;
+    const double* B; long long sbk, sbn;
+    double* C; long long ldc;
+    double alpha, beta;
+    long long strideA, strideB, strideC;
+    const GemmOff* offs;
+    int splitA, splitB, splitC, splitB_dim;
+    const double* colscale;
+    int tilesM, tilesN;
+};
+
+template <int TM, int TN>
+__global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmParams p) {
+    constexpr int BM = 32 * TM, BN = 32 * TN;
+    constexpr int LDA = BM + PAD, LDB = BN + PAD;
+    constexpr int EA = BM * BK / 256, EB = BN * BK / 256;
+    __shared__ double smem[2 * BK * LDA + 2 * BK * LDB];
+    double* As = smem;
+    double* Bs = smem + 2 * BK * LDA;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+
+    // XCD-aware tile walk: consecutive block ids land on consecutive XCDs (b % 8); give each XCD
+    // a contiguous range of tiles (bijective for any tile count).
+    const int ntiles = p.tilesM * p.tilesN;
+    int bid = blockIdx.x;
+    {
+        const int q = ntiles >> 3, r = ntiles & 7;
+        const int xcd = bid & 7, loc = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    }
+    const int tm = bid % p.tilesM, tn = bid / p.tilesM;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    long long a0, a1, b0, b1, c0, c1;
+    if (p.offs) {
+        const GemmOff o = p.offs[blockIdx.z];
+        a0 = o.a0; a1 = o.a1; b0 = o.b0; b1 = o.b1; c0 = o.c0; c1 = o.c1;
+    } else {
+        a0 = a1 = (long long)blockIdx.z * p.strideA;
+        b0 = b1 = (long long)blockIdx.z * p.strideB;
+        c0 = c1 = (long long)blockIdx.z * p.strideC;
+    }
+
+    const bool a_kfast = p.sak <= p.sam;   // lanes run along the faster global dimension
+    const bool b_nfast = p.sbn <= p.sbk;
+
+    // per-thread staging coordinates (tile-relative).  256 % BK == 0 and 256 % BM == 0, so one of
+    // the two coordinates is the same for every staged element i and the other advances by a constant.
+    const int a_k0 = a_kfast ? (tid % BK) : (tid / BM), a_m0 = a_kfast ? (tid / BK) : (tid % BM);
+    const int a_dk = a_kfast ? 0 : (256 / BM), a_dm = a_kfast ? (256 / BK) : 0;
+    const int b_k0 = b_nfast ? (tid / BN) : (tid % BK), b_n0 = b_nfast ? (tid % BN) : (tid / BK);
+    const int b_dk = b_nfast ? (256 / BN) : 0, b_dn = b_nfast ? 0 : (256 / BK);
+
+    d4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (d4){0., 0., 0., 0.};
+
+    double ra[EA], rb[EB];
+    const int nk = (p.K + BK - 1) / BK;
+
+    auto load_tile = [&](int kt) {
+        const int k0 = kt * BK;
+#pragma unroll
+        for (int i = 0; i < EA; ++i) {
+            const int k = k0 + a_k0 + i * a_dk, m = m0 + a_m0 + i * a_dm;
+            double v = 0.0;
+            if (m < p.M && k < p.K) {
+                const long long off = (m < p.splitA ? a0 + (long long)m * p.sam : a1 + (long long)(m - p.splitA) * p.sam);
+                v = p.A[off + (long long)k * p.sak];
+            }
+            ra[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < EB; ++i) {
+            const int k = k0 + b_k0 + i * b_dk, n = n0 + b_n0 + i * b_dn;
+            double v = 0.0;
+            if (n < p.N && k < p.K) {
+                long long off;
+                if (p.splitB_dim == 1)
+                    off = (k < p.splitB ? b0 + (long long)k * p.sbk : b1 + (long long)(k - p.splitB) * p.sbk) + (long long)n * p.sbn;
+                else if (p.splitB_dim == 2)
+                    off = (n < p.splitB ? b0 + (long long)n * p.sbn : b1 + (long long)(n - p.splitB) * p.sbn) + (long long)k * p.sbk;
+                else
+                    off = b0 + (long long)k * p.sbk + (long long)n * p.sbn;
+                v = p.B[off];
+            }
+            rb[i] = v;
+        }
+    };
+    auto store_tile = [&](int buf) {
+        double* as = As + buf * BK * LDA;
+        double* bs = Bs + buf * BK * LDB;
+#pragma unroll
+        for (int i = 0; i < EA; ++i) as[(a_k0 + i * a_dk) * LDA + a_m0 + i * a_dm] = ra[i];
+#pragma unroll
+        for (int i = 0; i < EB; ++i) bs[(b_k0 + i * b_dk) * LDB + b_n0 + i * b_dn] = rb[i];
+    };
+
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+
+    const int lr = lane & 15, lk = lane >> 4;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) load_tile(kt + 1);
+        const double* as = As + buf * BK * LDA + wm * 16 * TM + lr;
+        const double* bs = Bs + buf * BK * LDB + wn * 16 * TN + lr;
+#pragma unroll
+        for (int k4 = 0; k4 < BK / 4; ++k4) {
+            double af[TM], bf[TN];
+            const int kr = k4 * 4 + lk;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = as[kr * LDA + i * 16];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = bs[kr * LDB + j * 16];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nk) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue: row = (lane>>4) + 4*r, col = lane&15 inside each 16x16 tile
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = m0 + wm * 16 * TM + i * 16 + lk + 4 * r;
+            if (m >= p.M) continue;
+            const long long crow = (m < p.splitC ? c0 + (long long)m * p.ldc : c1 + (long long)(m - p.splitC) * p.ldc);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + wn * 16 * TN + j * 16 + lr;
+                if (n >= p.N) continue;
+                double v = p.alpha * acc[i][j][r];
+                if (p.colscale) v *= p.colscale[n];
+                if (p.beta != 0.0) v += p.beta * p.C[crow + n];
+                p.C[crow + n] = v;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+int gemm_f64(ctm_ctx* ctx, const GemmDesc& d) {
+    if (d.M <= 0 || d.N <= 0 || d.batch <= 0) return CTM_OK;
+    if (d.K <= 0) { ctx->set_error("gemm: K<=0"); return CTM_ERR_BADARG; }
+    GemmParams p;
+    p.M = d.M; p.N = d.N; p.K = d.K;
+    p.A = d.A; p.sam = d.sam; p.sak = d.sak;
+    p.B = d.B; p.sbk = d.sbk; p.sbn = d.sbn;
+    p.C = d.C; p.ldc = d.ldc;
+    p.alpha = d.alpha; p.beta = d.beta;
+    p.strideA = d.strideA; p.strideB = d.strideB; p.strideC = d.strideC;
+    p.offs = d.offs;
+    p.splitA = d.splitA; p.splitB = d.splitB; p.splitC = d.splitC; p.splitB_dim = d.splitB_dim;
+    p.colscale = d.colscale;
+    const bool small = (d.M <= 64 || d.N <= 64);
+    const int BM = small ? 64 : 128, BN = small ? 64 : 128;
+    p.tilesM = (d.M + BM - 1) / BM;
+    p.tilesN = (d.N + BN - 1) / BN;
+    dim3 grid((unsigned)(p.tilesM * p.tilesN), 1, (unsigned)d.batch);
+    if (small)
+        hipLaunchKernelGGL((gemm_f64_kernel<2, 2>), grid, dim3(256), 0, ctx->stream, p);
+    else
+        hipLaunchKernelGGL((gemm_f64_kernel<4, 4>), grid, dim3(256), 0, ctx->stream, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { ctx->set_error(std::string("gemm launch: ") + hipGetErrorString(e)); return CTM_ERR_HIP; }
+    ctx->gemm_flops += 2.0 * d.M * d.N * (double)d.K * d.batch;
+    ctx->gemm_calls += 1;
+    return CTM_OK;
+}

@@ -1,0 +1,373 @@
+// Layout / elementwise / reduction kernels of the CTM engine (HBM-bound work; gfx950).
+// All tensors are row-major float64.  Kernels use grid-stride loops capped at 2048 blocks
+// (256 CUs x 8) and keep the innermost OUTPUT index on consecutive lanes (coalesced stores);
+// the general permute stages 32x32 tiles through LDS when the innermost input and output
+// axes differ so that both the loads and the stores are coalesced.
+#include "ctm_common.h"
+
+namespace {
+
+constexpr int TB = 256;
+inline int nblocks(size_t n, int per = TB) {
+    size_t b = (n + per - 1) / per;
+    if (b > 2048) b = 2048;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+struct PermDesc {
+    int nd;
+    long long odims[CTM_MAXD];     // output dims
+    long long istr[CTM_MAXD];      // input stride of each OUTPUT axis
+    long long total;
+};
+
+// generic gather permute: one output element per thread iteration
+__global__ void permute_generic_kernel(const double* __restrict__ in, double* __restrict__ out, PermDesc d) {
+    for (long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x; o < d.total;
+         o += (long long)gridDim.x * blockDim.x) {
+        long long r = o, off = 0;
+#pragma unroll
+        for (int a = CTM_MAXD - 1; a >= 0; --a) {
+            if (a < d.nd) {
+                const long long q = r / d.odims[a];
+                off += (r - q * d.odims[a]) * d.istr[a];
+                r = q;
+            }
+        }
+        out[o] = in[off];
+    }
+}
+
+// tiled permute: the innermost output axis (size No, input stride so) and the innermost input axis
+// (size Ni, output stride = its position among the output axes) form a 2D transpose plane; the remaining
+// axes are "batch".  tile 32 x 32 through LDS.
+struct PermTileDesc {
+    int nd;                       // number of batch axes
+    long long bdims[CTM_MAXD];    // batch dims (output order, excluding the two plane axes)
+    long long bistr[CTM_MAXD];    // input strides of batch axes
+    long long bostr[CTM_MAXD];    // output strides of batch axes
+    long long No, Ni;             // plane extents: output-inner, input-inner
+    long long in_stride_o;        // input stride of the output-inner axis
+    long long out_stride_i;       // output stride of the input-inner axis
+    long long nbatch, tiles_o, tiles_i;
+};
+
+__global__ void permute_tiled_kernel(const double* __restrict__ in, double* __restrict__ out, PermTileDesc d) {
+    __shared__ double tile[32][33];
+    const long long ntile = d.nbatch * d.tiles_o * d.tiles_i;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    for (long long t = blockIdx.x; t < ntile; t += gridDim.x) {
+        long long r = t;
+        const long long ti = r % d.tiles_i; r /= d.tiles_i;
+        const long long to = r % d.tiles_o; r /= d.tiles_o;
+        long long ioff = 0, ooff = 0;
+        for (int a = d.nd - 1; a >= 0; --a) {
+            const long long q = r / d.bdims[a];
+            const long long c = r - q * d.bdims[a];
+            ioff += c * d.bistr[a];
+            ooff += c * d.bostr[a];
+            r = q;
+        }
+        // load: lanes along the input-inner axis (unit stride in `in`)
+        const long long i0 = ti * 32, o0 = to * 32;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const long long oo = o0 + ty + 8 * k, ii = i0 + tx;
+            if (oo < d.No && ii < d.Ni) tile[ty + 8 * k][tx] = in[ioff + oo * d.in_stride_o + ii];
+        }
+        __syncthreads();
+        // store: lanes along the output-inner axis (unit stride in `out`)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const long long ii = i0 + ty + 8 * k, oo = o0 + tx;
+            if (oo < d.No && ii < d.Ni) out[ooff + ii * d.out_stride_i + oo] = tile[tx][ty + 8 * k];
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void absmax_kernel(const double* __restrict__ x, size_t n, unsigned long long* out_bits) {
+    double m = 0.0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        m = fmax(m, fabs(x[i]));
+    for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_down(m, off, 64));
+    __shared__ double sm[TB / 64];
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < TB / 64; ++w) m = fmax(m, sm[w]);
+        // non-negative doubles order like their bit patterns
+        atomicMax(out_bits, (unsigned long long)__double_as_longlong(m));
+    }
+}
+
+__global__ void div_scalar_kernel(double* x, size_t n, const double* s, int use_abs) {
+    double v = *s;
+    if (use_abs) v = fabs(v);
+    const double inv = 1.0 / v;
+    (void)inv;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        x[i] = x[i] / v;      // true division: bit-identical to the reference's tensor / scalar
+}
+
+__global__ void fill_kernel(double* x, size_t n, double v) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) x[i] = v;
+}
+
+__global__ void identity_kernel(double* x, int n, long long ld) {
+    const size_t tot = (size_t)n * n;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = i / n, c = i - r * n;
+        x[r * ld + c] = (r == c) ? 1.0 : 0.0;
+    }
+}
+
+__global__ void copy2d_kernel(const double* src, long long lds, double* dst, long long ldd, int rows, int cols) {
+    const size_t tot = (size_t)rows * cols;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = i / cols, c = i - r * cols;
+        dst[r * ldd + c] = src[r * lds + c];
+    }
+}
+
+// one wave per row: sum of squares (scaled two-pass not needed: inputs are max-abs normalised O(1))
+__global__ void row_norms_kernel(const double* __restrict__ x, int rows, int cols, long long ld, double* out) {
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    const int nw = (gridDim.x * blockDim.x) >> 6;
+    for (int r = wave; r < rows; r += nw) {
+        double s = 0.0;
+        const double* p = x + (long long)r * ld;
+        for (int c = lane; c < cols; c += 64) s += p[c] * p[c];
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+        if (lane == 0) out[r] = sqrt(s);
+    }
+}
+
+__global__ void row_dots_kernel(const double* __restrict__ x, const double* __restrict__ y, int rows, int cols, long long ld,
+                                double* out) {
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    const int nw = (gridDim.x * blockDim.x) >> 6;
+    for (int r = wave; r < rows; r += nw) {
+        double s = 0.0;
+        const double* p = x + (long long)r * ld;
+        const double* q = y + (long long)r * ld;
+        for (int c = lane; c < cols; c += 64) s += p[c] * q[c];
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+        if (lane == 0) out[r] = s;
+    }
+}
+
+__global__ void gather_rows_kernel(const double* __restrict__ src, long long lds, const int* __restrict__ idx, int nrows,
+                                   int cols, double* __restrict__ dst, long long ldd, const double* __restrict__ rs) {
+    const size_t tot = (size_t)nrows * cols;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = i / cols, c = i - r * cols;
+        double v = src[(long long)idx[r] * lds + c];
+        if (rs) v *= rs[r];
+        dst[r * ldd + c] = v;
+    }
+}
+
+// out = sym(lower(a)) + shift * I
+__global__ void symmetrize_lower_kernel(const double* a, double* out, int n, double shift) {
+    const size_t tot = (size_t)n * n;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = i / n, c = i - r * n;
+        double v = (r >= c) ? a[r * n + c] : a[c * n + r];
+        if (r == c) v += shift;
+        out[i] = v;
+    }
+}
+
+// t[i,j,s] <- 0.5 (t[i,j,s] + t[j,i,s]), d0 x d0 x d2
+__global__ void symm01_kernel(double* t, int d0, int d2) {
+    const size_t tot = (size_t)d0 * d0 * d2;
+    for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < tot; q += (size_t)gridDim.x * blockDim.x) {
+        const size_t s = q % d2, ij = q / d2, j = ij % d0, i = ij / d0;
+        if (i < j) {
+            const size_t q2 = (j * (size_t)d0 + i) * d2 + s;
+            const double v = 0.5 * (t[q] + t[q2]);
+            t[q] = v; t[q2] = v;
+        }
+    }
+}
+
+// E = G - I on entry (G = V V^T);  E <- I - strict_lower(E) - diag(E)/2 : first-order inverse Cholesky factor
+__global__ void tril_corr_kernel(double* E, int k) {
+    const size_t tot = (size_t)k * k;
+    for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < tot; q += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = q / k, c = q - r * k;
+        const double g = E[q];
+        double v;
+        if (r == c) v = 1.0 - 0.5 * (g - 1.0);
+        else if (r > c) v = -g;
+        else v = 0.0;
+        E[q] = v;
+    }
+}
+
+__global__ void diag_kernel(const double* d, double* out, int n) {
+    const size_t tot = (size_t)n * n;
+    for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < tot; q += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = q / n, c = q - r * n;
+        out[q] = (r == c) ? d[r] : 0.0;
+    }
+}
+
+__global__ void trace_partial_kernel(const double* in, double* out, long long n2, int p) {
+    for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < n2; q += (long long)gridDim.x * blockDim.x) {
+        double s = 0.0;
+        for (int i = 0; i < p; ++i) s += in[q * p * p + i * p + i];
+        out[q] = s;
+    }
+}
+
+}  // namespace
+
+#define LAUNCH_CHECK(ctx, what)                                                                   \
+    do {                                                                                          \
+        hipError_t _e = hipGetLastError();                                                        \
+        if (_e != hipSuccess) { (ctx)->set_error(std::string(what) + ": " + hipGetErrorString(_e)); return CTM_ERR_HIP; } \
+    } while (0)
+
+int permute_f64(ctm_ctx* ctx, const double* in, double* out, int nd, const long long* dims, const int* perm) {
+    if (nd < 1 || nd > CTM_MAXD) { ctx->set_error("permute: rank"); return CTM_ERR_BADARG; }
+    // input strides
+    long long istr[CTM_MAXD], total = 1;
+    for (int a = nd - 1; a >= 0; --a) { istr[a] = total; total *= dims[a]; }
+    if (total == 0) return CTM_OK;
+    // drop size-1 axes and merge output axes that are adjacent in the input too
+    long long od[CTM_MAXD], os_in[CTM_MAXD];
+    int m = 0;
+    for (int a = 0; a < nd; ++a) {
+        const int src = perm[a];
+        if (src < 0 || src >= nd) { ctx->set_error("permute: perm"); return CTM_ERR_BADARG; }
+        if (dims[src] == 1) continue;
+        if (m > 0 && os_in[m - 1] == istr[src] * dims[src]) { od[m - 1] *= dims[src]; os_in[m - 1] = istr[src]; }
+        else { od[m] = dims[src]; os_in[m] = istr[src]; ++m; }
+    }
+    if (m == 0) { od[0] = 1; os_in[0] = 1; m = 1; }
+    if (m == 1 && os_in[0] == 1) {   // identity
+        if (in != out) {
+            hipError_t e = hipMemcpyAsync(out, in, sizeof(double) * total, hipMemcpyDeviceToDevice, ctx->stream);
+            if (e != hipSuccess) { ctx->set_error("permute memcpy"); return CTM_ERR_HIP; }
+        }
+        return CTM_OK;
+    }
+    // output strides of merged axes
+    long long ostr[CTM_MAXD]; { long long s = 1; for (int a = m - 1; a >= 0; --a) { ostr[a] = s; s *= od[a]; } }
+    // find the merged output axis that is input-innermost (stride 1 in the input)
+    int ai = -1;
+    for (int a = 0; a < m; ++a) if (os_in[a] == 1) ai = a;
+    if (ai >= 0 && ai != m - 1 && od[ai] >= 8 && od[m - 1] >= 8) {
+        PermTileDesc t;
+        t.nd = 0; t.nbatch = 1;
+        for (int a = 0; a < m - 1; ++a) {
+            if (a == ai) continue;
+            t.bdims[t.nd] = od[a]; t.bistr[t.nd] = os_in[a]; t.bostr[t.nd] = ostr[a]; t.nbatch *= od[a]; ++t.nd;
+        }
+        t.No = od[m - 1]; t.Ni = od[ai];
+        t.in_stride_o = os_in[m - 1]; t.out_stride_i = ostr[ai];
+        t.tiles_o = (t.No + 31) / 32; t.tiles_i = (t.Ni + 31) / 32;
+        const long long ntile = t.nbatch * t.tiles_o * t.tiles_i;
+        const int grid = (int)(ntile > 16384 ? 16384 : ntile);
+        hipLaunchKernelGGL(permute_tiled_kernel, dim3(grid), dim3(256), 0, ctx->stream, in, out, t);
+        LAUNCH_CHECK(ctx, "permute_tiled");
+        return CTM_OK;
+    }
+    PermDesc d;
+    d.nd = m; d.total = total;
+    for (int a = 0; a < CTM_MAXD; ++a) { d.odims[a] = a < m ? od[a] : 1; d.istr[a] = a < m ? os_in[a] : 0; }
+    hipLaunchKernelGGL(permute_generic_kernel, dim3(nblocks(total)), dim3(TB), 0, ctx->stream, in, out, d);
+    LAUNCH_CHECK(ctx, "permute_generic");
+    return CTM_OK;
+}
+
+int absmax_f64(ctm_ctx* ctx, const double* x, size_t n, double* d_out) {
+    hipError_t e = hipMemsetAsync(d_out, 0, sizeof(double), ctx->stream);
+    if (e != hipSuccess) { ctx->set_error("absmax memset"); return CTM_ERR_HIP; }
+    hipLaunchKernelGGL(absmax_kernel, dim3(nblocks(n, TB * 8)), dim3(TB), 0, ctx->stream, x, n, (unsigned long long*)d_out);
+    LAUNCH_CHECK(ctx, "absmax");
+    return CTM_OK;
+}
+
+int div_by_device_scalar(ctm_ctx* ctx, double* x, size_t n, const double* d_s, int use_abs) {
+    hipLaunchKernelGGL(div_scalar_kernel, dim3(nblocks(n, TB * 4)), dim3(TB), 0, ctx->stream, x, n, d_s, use_abs);
+    LAUNCH_CHECK(ctx, "div_scalar");
+    return CTM_OK;
+}
+
+int fill_f64(ctm_ctx* ctx, double* x, size_t n, double v) {
+    if (n == 0) return CTM_OK;
+    hipLaunchKernelGGL(fill_kernel, dim3(nblocks(n, TB * 4)), dim3(TB), 0, ctx->stream, x, n, v);
+    LAUNCH_CHECK(ctx, "fill");
+    return CTM_OK;
+}
+
+int set_identity(ctm_ctx* ctx, double* x, int n, long long ld) {
+    hipLaunchKernelGGL(identity_kernel, dim3(nblocks((size_t)n * n, TB * 4)), dim3(TB), 0, ctx->stream, x, n, ld);
+    LAUNCH_CHECK(ctx, "identity");
+    return CTM_OK;
+}
+
+int copy2d(ctm_ctx* ctx, const double* src, long long lds, double* dst, long long ldd, int rows, int cols) {
+    if (rows <= 0 || cols <= 0) return CTM_OK;
+    hipLaunchKernelGGL(copy2d_kernel, dim3(nblocks((size_t)rows * cols, TB * 4)), dim3(TB), 0, ctx->stream, src, lds, dst,
+                       ldd, rows, cols);
+    LAUNCH_CHECK(ctx, "copy2d");
+    return CTM_OK;
+}
+
+int row_norms(ctm_ctx* ctx, const double* x, int rows, int cols, long long ld, double* d_out) {
+    int blocks = (rows + 3) / 4; if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(row_norms_kernel, dim3(blocks), dim3(TB), 0, ctx->stream, x, rows, cols, ld, d_out);
+    LAUNCH_CHECK(ctx, "row_norms");
+    return CTM_OK;
+}
+
+int row_dots(ctm_ctx* ctx, const double* x, const double* y, int rows, int cols, long long ld, double* d_out) {
+    int blocks = (rows + 3) / 4; if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(row_dots_kernel, dim3(blocks), dim3(TB), 0, ctx->stream, x, y, rows, cols, ld, d_out);
+    LAUNCH_CHECK(ctx, "row_dots");
+    return CTM_OK;
+}
+
+int gather_rows(ctm_ctx* ctx, const double* src, long long lds, const int* d_idx, int nrows, int cols, double* dst,
+                long long ldd, const double* d_rowscale) {
+    if (nrows <= 0) return CTM_OK;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(nblocks((size_t)nrows * cols, TB * 4)), dim3(TB), 0, ctx->stream, src, lds,
+                       d_idx, nrows, cols, dst, ldd, d_rowscale);
+    LAUNCH_CHECK(ctx, "gather_rows");
+    return CTM_OK;
+}
+
+int symmetrize_lower(ctm_ctx* ctx, const double* a, double* out, int n, double shift) {
+    hipLaunchKernelGGL(symmetrize_lower_kernel, dim3(nblocks((size_t)n * n, TB * 4)), dim3(TB), 0, ctx->stream, a, out, n, shift);
+    LAUNCH_CHECK(ctx, "symmetrize_lower");
+    return CTM_OK;
+}
+
+int add_transposed01(ctm_ctx* ctx, double* t, int d0, int d2) {
+    hipLaunchKernelGGL(symm01_kernel, dim3(nblocks((size_t)d0 * d0 * d2, TB * 4)), dim3(TB), 0, ctx->stream, t, d0, d2);
+    LAUNCH_CHECK(ctx, "symm01");
+    return CTM_OK;
+}
+
+int tril_correction(ctm_ctx* ctx, double* E, int k) {
+    hipLaunchKernelGGL(tril_corr_kernel, dim3(nblocks((size_t)k * k)), dim3(TB), 0, ctx->stream, E, k);
+    LAUNCH_CHECK(ctx, "tril_corr");
+    return CTM_OK;
+}
+
+int diag_to_matrix(ctm_ctx* ctx, const double* d, double* out, int n) {
+    hipLaunchKernelGGL(diag_kernel, dim3(nblocks((size_t)n * n)), dim3(TB), 0, ctx->stream, d, out, n);
+    LAUNCH_CHECK(ctx, "diag");
+    return CTM_OK;
+}
+
+int trace_partial(ctm_ctx* ctx, const double* in, double* out, long long n2, int p) {
+    hipLaunchKernelGGL(trace_partial_kernel, dim3(nblocks((size_t)n2)), dim3(TB), 0, ctx->stream, in, out, n2, p);
+    LAUNCH_CHECK(ctx, "trace_partial");
+    return CTM_OK;
+}

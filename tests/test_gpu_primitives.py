@@ -1,0 +1,108 @@
+"""GPU parity of the native primitives (GEMM / permute / truncated SVD / eigh) through the C-ABI."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(x):
+    return torch.from_numpy(np.ascontiguousarray(x)).cuda()
+
+
+@pytest.mark.parametrize("M,N,K", [(16, 16, 4), (64, 64, 64), (128, 128, 128), (130, 70, 33), (257, 129, 515), (8, 300, 17), (512, 384, 1024), (1, 1, 1)])
+@pytest.mark.parametrize("tA", [False, True])
+@pytest.mark.parametrize("tB", [False, True])
+def test_gemm(eng, M, N, K, tA, tB):
+    rng = np.random.default_rng(M * 1000 + N * 10 + K)
+    A = rng.standard_normal((K, M) if tA else (M, K))
+    B = rng.standard_normal((N, K) if tB else (K, N))
+    ref = (A.T if tA else A) @ (B.T if tB else B)
+    out = eng.gemm(dev(A), dev(B), tA, tB).cpu().numpy()
+    assert np.abs(out - ref).max() <= 1e-12 * max(1.0, np.abs(ref).max()) * np.sqrt(K)
+
+
+@pytest.mark.parametrize("shape,perm", [((5, 7), (1, 0)), ((64, 48), (1, 0)), ((3, 4, 5), (2, 0, 1)), ((8, 2, 2, 8, 3, 3), (1, 2, 4, 0, 3, 5)),
+                                        ((6, 3, 3, 6, 2, 3, 3, 2), (1, 3, 6, 0, 4, 7, 2, 5)), ((40, 33, 17), (2, 1, 0)), ((4, 5, 6), (0, 1, 2)),
+                                        ((16, 9, 16, 9), (2, 3, 0, 1)), ((2, 2, 2, 2, 2, 2, 2, 2), (0, 2, 4, 6, 1, 3, 5, 7))])
+def test_permute(eng, shape, perm):
+    x = np.random.default_rng(1).standard_normal(shape)
+    out = eng.permute(dev(x), perm).cpu().numpy()
+    assert np.array_equal(out, np.ascontiguousarray(x.transpose(perm)))
+
+
+def _graded(n, rng, decay):
+    Q1, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    Q2, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    s = np.exp(-decay * np.arange(n))
+    return (Q1 * s) @ Q2.T, s
+
+
+@pytest.mark.parametrize("n,chi,decay", [(24, 8, 0.7), (64, 16, 0.3), (100, 20, 0.2), (288, 32, 0.05), (512, 64, 0.03)])
+def test_truncated_svd(eng, n, chi, decay):
+    rng = np.random.default_rng(n)
+    M, s = _graded(n, rng, decay)
+    U, S, V = (t.cpu().numpy() for t in eng.truncated_svd(dev(M), chi))
+    Sr = np.linalg.svd(M, compute_uv=False)[:chi]
+    assert np.abs(S - Sr).max() <= 1e-13 * Sr[0]
+    # orthonormality and reconstruction of the leading block (svd_symeig.py:88 style bound)
+    assert np.abs(U.T @ U - np.eye(chi)).max() < 1e-12
+    assert np.abs(V.T @ V - np.eye(chi)).max() < 1e-12
+    assert np.abs(U.T @ M @ V - np.diag(S)).max() < 1e-13 * Sr[0] * n
+
+
+def test_truncated_svd_random_dense(eng):
+    rng = np.random.default_rng(5)
+    M = rng.random((200, 200))
+    U, S, V = (t.cpu().numpy() for t in eng.truncated_svd(dev(M), 40))
+    Sr = np.linalg.svd(M, compute_uv=False)[:40]
+    assert np.abs(S - Sr).max() <= 1e-13 * Sr[0]
+    assert np.abs(U.T @ M @ V - np.diag(S)).max() < 1e-12 * Sr[0]
+
+
+def test_truncated_svd_golden(eng):
+    from conftest import golden
+    g = golden("decomp")
+    cfg = eng.cfg(eps_multiplet=1e-8)
+    for nm in "abc":
+        M = g[f"svd_{nm}_M"]
+        U, S, V = (t.cpu().numpy() for t in eng.truncated_svd(dev(M), 8, cfg))
+        assert np.abs(S - g[f"svd_{nm}_S"]).max() < 1e-13, nm
+        assert ((S == 0) == (g[f"svd_{nm}_S"] == 0)).all(), nm          # multiplet back-off / rank deficiency
+        nzc = S > 1e-10
+        # sign-fixed vectors agree entrywise where the spectrum is non-degenerate (case a)
+        if nm == "a":
+            assert np.abs(np.abs(U[:, nzc]) - np.abs(g["svd_a_U"][:, nzc])).max() < 1e-9
+            assert np.abs(U[:, nzc] - g["svd_a_U"][:, nzc]).max() < 1e-9
+
+
+@pytest.mark.parametrize("n,chi", [(24, 6), (81, 20), (144, 16), (256, 64)])
+def test_truncated_eigh(eng, n, chi):
+    rng = np.random.default_rng(n + 1)
+    Q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    lam = np.exp(-0.1 * np.arange(n)) * np.where(rng.random(n) < 0.3, -1.0, 1.0)
+    H = (Q * lam) @ Q.T
+    H = 0.5 * (H + H.T)
+    D, U = (t.cpu().numpy() for t in eng.truncated_eigh(dev(H), chi, eng.cfg(keep_multiplets=False)))
+    w = np.linalg.eigvalsh(H)
+    w = w[np.argsort(-np.abs(w))][:chi]
+    assert np.abs(D - w).max() < 1e-13
+    assert np.abs(U.T @ U - np.eye(chi)).max() < 1e-12
+    assert np.abs(H @ U - U * D[None, :]).max() < 1e-12
+
+
+def test_eigh_golden(eng):
+    from conftest import golden
+    g = golden("decomp")
+    H = g["eig_H"]
+    for nm, ch in (("a", 4), ("b", 6)):
+        D, U = (t.cpu().numpy() for t in eng.truncated_eigh(dev(H), ch))
+        assert np.abs(D - g[f"eig_{nm}_D"]).max() < 1e-13
+        assert ((D == 0) == (g[f"eig_{nm}_D"] == 0)).all()
+
+
+def test_svdvals(eng):
+    rng = np.random.default_rng(3)
+    C = rng.standard_normal((18, 18))
+    S = eng.svdvals(dev(C)).cpu().numpy()
+    assert np.abs(S - np.linalg.svd(C, compute_uv=False)).max() < 1e-13 * S[0]
