@@ -1,0 +1,19 @@
+"""Single access point to the compute engine used by the host layer.
+
+The product path always resolves to the native HIP engine (`_native.engine()`); it raises if the
+shared library or the GPU is missing -- there is no CPU fallback.  Tests of the host logic may
+install a stand-in with `set_engine` (e.g. an oracle-backed double for the gloo sharding tests).
+"""
+_override = None
+
+
+def set_engine(e):
+    global _override
+    _override = e
+
+
+def get_engine():
+    if _override is not None:
+        return _override
+    import _native
+    return _native.engine()

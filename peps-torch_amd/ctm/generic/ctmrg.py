@@ -1,0 +1,149 @@
+"""Directional CTMRG for a generic unit cell (reference ctm/generic/ctmrg.py:18-110,179-319,324-804).
+
+`run` and `ctm_MOVE` keep the reference's signatures.  One move = projectors for every site from the
+OLD environment, then absorb+truncate for every site, then each new tensor divided by its own max-abs
+and written to the site at `coord - direction`.  With torch.distributed initialised the per-site units
+of both phases are sharded over the ranks (one MI355X each) with one all-gather after each phase
+(parallel.py); without it everything runs on the current device.
+"""
+import time
+import copy
+import logging
+from math import ceil
+import torch
+import config as cfg
+from backend import get_engine
+import parallel
+from ctm.generic.ctm_projectors import ctm_get_projectors_4x4, _trunc_cfg
+from ctm.generic.ctm_components import _halves_t
+
+log = logging.getLogger(__name__)
+
+# per direction: relative vectors of (C1, T1, T, T2, C2), shift to the neighbour whose projectors are P1, Pt1
+_ABS = {
+    (0, -1): (((1, -1), (1, 0), (0, -1), (-1, 0), (-1, -1)), (1, 0)),
+    (-1, 0): (((-1, -1), (0, -1), (-1, 0), (0, 1), (-1, 1)), (0, -1)),
+    (0, 1): (((-1, 1), (-1, 0), (0, 1), (1, 0), (1, 1)), (-1, 0)),
+    (1, 0): (((1, 1), (0, 1), (1, 0), (0, -1), (1, -1)), (0, 1)),
+}
+# where the new tensors go (ctmrg.py:302-309)
+_REL = {(0, -1): ((1, -1), (-1, -1)), (-1, 0): ((-1, -1), (-1, 1)), (0, 1): ((-1, 1), (1, 1)), (1, 0): ((1, 1), (1, -1))}
+
+
+def run(state, env, conv_check=None, ctm_args=cfg.ctm_args, global_args=cfg.global_args):
+    """Sweep until `conv_check(state, env, history, ctm_args=)` says so or ctm_max_iter sweeps.
+    Returns (env, history, t_ctm, t_obs).  t_ctm is measured on this rank with device syncs around
+    each sweep (and, unlike the reference's quirk at ctmrg.py:101-108, includes the last sweep)."""
+    if ctm_args.ctm_force_dl:
+        raise NotImplementedError("ctm_force_dl: the engine always contracts layer by layer")
+    eng = get_engine()
+
+    def _ctmrg_iter(i, loc_ctm_args=ctm_args):
+        for direction in loc_ctm_args.ctm_move_sequence:
+            diagnostics = {"ctm_i": i, "ctm_d": direction} if loc_ctm_args.verbosity_projectors > 0 else None
+            n = state.lX if direction in [(-1, 0), (1, 0)] else state.lY
+            for _ in range(n):
+                ctm_MOVE(direction, state, env, ctm_args=loc_ctm_args, global_args=global_args,
+                         verbosity=loc_ctm_args.verbosity_ctm_move, diagnostics=diagnostics)
+
+    t_obs = t_ctm = 0.
+    history = None
+    if ctm_args.ctm_warmup_iter >= 0:
+        wargs = copy.deepcopy(ctm_args)
+        wargs.projector_svd_method = ctm_args.warmup_projector_svd_method
+        maxD = max(state.get_aux_bond_dims())
+        for i in range(max(ctm_args.ctm_warmup_iter, ceil(env.chi / maxD ** 2))):
+            t0 = time.perf_counter(); _ctmrg_iter(i, loc_ctm_args=wargs); eng.sync(); t_ctm += time.perf_counter() - t0
+    for i in range(ctm_args.ctm_max_iter):
+        t0 = time.perf_counter()
+        _ctmrg_iter(i)
+        eng.sync()
+        t1 = time.perf_counter()
+        t_ctm += t1 - t0
+        if conv_check is not None:
+            converged, history = conv_check(state, env, history, ctm_args=ctm_args)
+            t_obs += time.perf_counter() - t1
+            if converged:
+                if ctm_args.verbosity_ctm_convergence > 0:
+                    print(f"CTMRG  converged at iter= {i}, history= {history['conv_crit'][-1] if isinstance(history, dict) else ''}")
+                break
+    return env, history, t_ctm, t_obs
+
+
+def _absorb_tensors(direction, coord, state, env, P, Pt):
+    vecs, sh = _ABS[direction]
+    c = state.vertexToSite(coord)
+    nb = state.vertexToSite((coord[0] + sh[0], coord[1] + sh[1]))
+    return (env.C[(c, vecs[0])], env.T[(c, vecs[1])], env.T[(c, vecs[2])], env.T[(c, vecs[3])], env.C[(c, vecs[4])],
+            state.site(coord), P[c], Pt[c], P[nb], Pt[nb])
+
+
+def _absorb(direction, coord, state, env, P, Pt, ctm_args, normalize=False):
+    return get_engine().absorb(direction, _absorb_tensors(direction, coord, state, env, P, Pt), normalize=normalize)
+
+
+def absorb_truncate_CTM_MOVE_UP(coord, state, env, P, Pt, ctm_args=cfg.ctm_args): return _absorb((0, -1), coord, state, env, P, Pt, ctm_args)
+def absorb_truncate_CTM_MOVE_LEFT(coord, state, env, P, Pt, ctm_args=cfg.ctm_args): return _absorb((-1, 0), coord, state, env, P, Pt, ctm_args)
+def absorb_truncate_CTM_MOVE_DOWN(coord, state, env, P, Pt, ctm_args=cfg.ctm_args): return _absorb((0, 1), coord, state, env, P, Pt, ctm_args)
+def absorb_truncate_CTM_MOVE_RIGHT(coord, state, env, P, Pt, ctm_args=cfg.ctm_args): return _absorb((1, 0), coord, state, env, P, Pt, ctm_args)
+def absorb_truncate_CTM_MOVE_UP_c(*t): return get_engine().absorb((0, -1), t[:10], normalize=False)
+def absorb_truncate_CTM_MOVE_LEFT_c(*t): return get_engine().absorb((-1, 0), t[:10], normalize=False)
+def absorb_truncate_CTM_MOVE_DOWN_c(*t): return get_engine().absorb((0, 1), t[:10], normalize=False)
+def absorb_truncate_CTM_MOVE_RIGHT_c(*t): return get_engine().absorb((1, 0), t[:10], normalize=False)
+
+
+def ctm_MOVE(direction, state, env, ctm_args=cfg.ctm_args, global_args=cfg.global_args, verbosity=0, diagnostics=None):
+    if ctm_args.projector_method != '4X4':
+        raise ValueError("Invalid Projector method: " + str(ctm_args.projector_method))
+    if direction not in _ABS:
+        raise ValueError("Invalid direction: " + str(direction))
+    if ctm_args.ctm_absorb_normalization != 'inf':
+        raise NotImplementedError("ctm_absorb_normalization: only 'inf' is implemented natively")
+    eng = get_engine()
+    coords = list(state.sites.keys())
+    mine = parallel.my_units(coords)
+    chi = env.chi
+    like = next(iter(env.C.values()))
+
+    # phase A: projectors of my sites from the old env
+    P, Pt = {}, {}
+    for coord in mine:
+        P[coord], Pt[coord] = ctm_get_projectors_4x4(direction, coord, state, env, ctm_args, global_args, diagnostics=diagnostics)
+    if parallel.is_distributed():
+        shp = {}
+        for coord in coords:
+            R_n = _proj_rows(direction, coord, state, chi)
+            shp[coord] = (R_n, min(chi, R_n))
+        P = parallel.exchange(P, coords, shp, like)
+        Pt = parallel.exchange(Pt, coords, shp, like)
+
+    # phase B: absorb + normalise my sites
+    new = {}
+    for coord in mine:
+        new[coord] = _absorb(direction, coord, state, env, P, Pt, ctm_args, normalize=True)
+    if parallel.is_distributed():
+        packs = {c: torch.cat([t.reshape(-1) for t in v]) for c, v in new.items()}
+        shp = {c: (2 * chi * chi + chi * chi * _out_D2(direction, state.site(c)),) for c in coords}
+        packs = parallel.exchange(packs, coords, shp, like)
+        new = {}
+        for c in coords:
+            D2 = _out_D2(direction, state.site(c))
+            v = packs[c]
+            tshape = {(0, -1): (chi, D2, chi), (-1, 0): (chi, chi, D2), (0, 1): (D2, chi, chi), (1, 0): (chi, D2, chi)}[direction]
+            new[c] = (v[:chi * chi].view(chi, chi), v[chi * chi:2 * chi * chi].view(chi, chi), v[2 * chi * chi:].view(tshape))
+
+    r1, r2 = _REL[direction]
+    for coord in coords:
+        nc = state.vertexToSite((coord[0] - direction[0], coord[1] - direction[1]))
+        env.C[(nc, r1)], env.C[(nc, r2)], env.T[(nc, direction)] = new[coord]
+
+
+def _out_D2(direction, A):
+    return A.size({(0, -1): 3, (-1, 0): 4, (0, 1): 1, (1, 0): 2}[direction]) ** 2
+
+
+def _proj_rows(direction, coord, state, chi):
+    # n = chi * D^2 of the truncated bond: the leg of the anchor site pointing along the move's cut
+    A = state.site(coord)
+    leg = {(0, -1): 2, (-1, 0): 3, (0, 1): 4, (1, 0): 1}[direction]
+    return chi * A.size(leg) ** 2

@@ -1,0 +1,85 @@
+"""Reduced density matrices from the converged environment (reference ctm/generic/rdm.py:38-68,
+71-302, 304-500, 622-826, 1306-1592).  The network contraction (open enlarged corners -> halves ->
+trace) runs natively; the final p^N x p^N hermitisation / clamping / trace normalisation
+(`_sym_pos_def_rdm`) is host-side on <= 256 numbers."""
+import logging
+import torch
+import config as cfg
+from backend import get_engine
+from ctm.generic.ctm_components import _corner_t, LU, RU, RD, LD
+
+log = logging.getLogger(__name__)
+
+
+def _cast_to_real(t, fail_on_check=False, warn_on_check=True, imag_eps=1.0e-8, who="unknown", **kwargs):
+    if t.is_complex():
+        if abs(t.imag) / (abs(t.real) + 1.0e-8) > imag_eps:
+            if warn_on_check: log.warning("Unexpected imaginary part " + who + " " + str(t))
+            if fail_on_check: raise RuntimeError("Unexpected imaginary part " + who + " " + str(t))
+        return t.real
+    return t
+
+
+def _sym_pos_def_matrix(rdm, sym_pos_def=False, verbosity=0, who="unknown", **kwargs):
+    rdm = 0.5 * (rdm + rdm.conj().t())
+    if sym_pos_def:
+        D, U = torch.linalg.eigh(rdm.cpu())            # <= 16 x 16, host
+        if D.min() < 0:
+            log.info(f"{who} max(diag(rdm)) {D.max()} min(diag(rdm)) {D.min()}")
+            D = torch.clamp(D, min=0)
+            rdm = (U @ torch.diag(D).to(U.dtype) @ U.conj().t()).to(rdm.device)
+    norm = _cast_to_real(rdm.diagonal().sum(), who=who, **kwargs)
+    return rdm / norm
+
+
+def _sym_pos_def_rdm(rdm, sym_pos_def=False, verbosity=0, who=None, **kwargs):
+    assert len(rdm.size()) % 2 == 0, "invalid rank of RDM"
+    nsites = len(rdm.size()) // 2
+    shape = rdm.size()
+    n = 1
+    for d in shape[:nsites]: n *= d
+    m = _sym_pos_def_matrix(rdm.reshape(n, -1), sym_pos_def=sym_pos_def, verbosity=verbosity, who=who)
+    return m.reshape(shape)
+
+
+def rdm2x2(coord, state, env, open_sites=[0, 1, 2, 3], unroll=[], checkpoint_unrolled=False, checkpoint_on_device=False,
+           sym_pos_def=False, force_cpu=False, verbosity=0, global_args=cfg.global_args):
+    """rho(s0 s1 s2 s3 ; s0' s1' s2' s3') of the plaquette coord, +x, +y, +x+y (s0 s1 / s2 s3)."""
+    if list(open_sites) != [0, 1, 2, 3]:
+        raise NotImplementedError("rdm2x2: partially traced plaquettes are not on the native path")
+    x, y = coord
+    t = _corner_t(LU, (x, y), state, env) + _corner_t(RU, (x + 1, y), state, env) \
+        + _corner_t(RD, (x + 1, y + 1), state, env) + _corner_t(LD, (x, y + 1), state, env)
+    raw = get_engine().rdm2x2(t)
+    return _sym_pos_def_rdm(raw, sym_pos_def=sym_pos_def, verbosity=verbosity, who="rdm2x2")
+
+
+rdm2x2_legacy = lambda coord, state, env, sym_pos_def=False, verbosity=0: rdm2x2(coord, state, env, sym_pos_def=sym_pos_def)
+
+
+def rdm1x1(coord, state, env, operator=None, sym_pos_def=False, force_cpu=False, verbosity=0, mode='sl', **kwargs):
+    c = state.vertexToSite(coord)
+    t = (env.C[(c, (-1, -1))], env.C[(c, (1, -1))], env.C[(c, (1, 1))], env.C[(c, (-1, 1))],
+         env.T[(c, (0, -1))], env.T[(c, (1, 0))], env.T[(c, (0, 1))], env.T[(c, (-1, 0))], state.site(coord))
+    rdm = _sym_pos_def_rdm(get_engine().rdm1x1(t), sym_pos_def=sym_pos_def, verbosity=verbosity, who="rdm1x1")
+    if operator is not None:
+        return torch.einsum('ij,ji', rdm, operator.to(rdm.device))
+    return rdm
+
+
+def rdm2x1(coord, state, env, sym_pos_def=False, force_cpu=False, verbosity=0, mode='sl', **kwargs):
+    """Horizontal pair coord, coord+(1,0); index order s0 s1 ; s0' s1'."""
+    x, y = coord
+    c0, c1 = state.vertexToSite((x, y)), state.vertexToSite((x + 1, y))
+    t = (env.C[(c0, (-1, -1))], env.T[(c0, (0, -1))], env.T[(c0, (-1, 0))], env.C[(c0, (-1, 1))], env.T[(c0, (0, 1))], state.site((x, y)),
+         env.C[(c1, (1, -1))], env.T[(c1, (1, 0))], env.C[(c1, (1, 1))], env.T[(c1, (0, -1))], env.T[(c1, (0, 1))], state.site((x + 1, y)))
+    return _sym_pos_def_rdm(get_engine().rdm2x1(t), sym_pos_def=sym_pos_def, verbosity=verbosity, who="rdm2x1")
+
+
+def rdm1x2(coord, state, env, sym_pos_def=False, force_cpu=False, verbosity=0, mode='sl', **kwargs):
+    """Vertical pair coord, coord+(0,1); index order s0 s1 ; s0' s1'."""
+    x, y = coord
+    c0, c1 = state.vertexToSite((x, y)), state.vertexToSite((x, y + 1))
+    t = (env.C[(c0, (-1, -1))], env.T[(c0, (0, -1))], env.C[(c0, (1, -1))], env.T[(c0, (-1, 0))], env.T[(c0, (1, 0))], state.site((x, y)),
+         env.C[(c1, (-1, 1))], env.T[(c1, (0, 1))], env.C[(c1, (1, 1))], env.T[(c1, (-1, 0))], env.T[(c1, (1, 0))], state.site((x, y + 1)))
+    return _sym_pos_def_rdm(get_engine().rdm1x2(t), sym_pos_def=sym_pos_def, verbosity=verbosity, who="rdm1x2")

@@ -1,0 +1,105 @@
+"""C4v-symmetric single-site environment (reference ctm/one_site_c4v/env_c4v.py:7-154,166-311):
+one corner C (chi x chi, diagonal after every move) and one half-row tensor T (chi, chi, D^2)."""
+import torch
+import config as cfg
+from backend import get_engine
+from linalg.custom_eig import truncated_eig_sym
+
+
+class ENV_C4V():
+    def __init__(self, chi, state=None, bond_dim=None, ctm_args=cfg.ctm_args, global_args=cfg.global_args):
+        assert state or bond_dim, "either state or bond_dim must be supplied"
+        self.dtype, self.device = global_args.torch_dtype, global_args.device
+        if state:
+            assert len(state.sites) == 1, "Not a 1-site ipeps"
+            site = next(iter(state.sites.values()))
+            assert site.size(-4) == site.size(-3) == site.size(-2) == site.size(-1), \
+                "bond dimensions of on-site tensor are not equal"
+            bond_dim = site.size(-1)
+            self.dtype, self.device = site.dtype, site.device
+        self.chi = chi
+        self.bond_dim = bond_dim
+        self.keyC = ((0, 0), (-1, -1))
+        self.keyT = ((0, 0), (-1, 0))
+        self.C = {self.keyC: torch.zeros((chi, chi), dtype=self.dtype, device=self.device)}
+        self.T = {self.keyT: torch.zeros((chi, chi, bond_dim ** 2), dtype=self.dtype, device=self.device)}
+
+    def __str__(self):
+        return f"ENV_C4V chi={self.chi}\nC {self.get_C().size()}\nT {self.get_T().size()}\n"
+
+    def get_C(self): return self.C[self.keyC]
+    def get_T(self): return self.T[self.keyT]
+
+    def _like(self, f, ctm_args, global_args):
+        e = ENV_C4V(self.chi, bond_dim=self.bond_dim, ctm_args=ctm_args, global_args=global_args)
+        e.dtype, e.device = self.dtype, self.device
+        e.C[e.keyC] = f(self.get_C()); e.T[e.keyT] = f(self.get_T())
+        return e
+
+    def clone(self, ctm_args=cfg.ctm_args, global_args=cfg.global_args): return self._like(lambda t: t.clone(), ctm_args, global_args)
+    def detach(self, ctm_args=cfg.ctm_args, global_args=cfg.global_args): return self._like(lambda t: t.detach(), ctm_args, global_args)
+
+    def detach_(self):
+        self.get_C().detach_(); self.get_T().detach_()
+
+    def extend(self, new_chi, ctm_args=cfg.ctm_args, global_args=cfg.global_args):
+        e = ENV_C4V(new_chi, bond_dim=self.bond_dim, ctm_args=ctm_args, global_args=global_args)
+        e.dtype, e.device = self.dtype, self.device
+        e.C[e.keyC] = torch.zeros((new_chi, new_chi), dtype=self.dtype, device=self.device)
+        e.T[e.keyT] = torch.zeros((new_chi, new_chi, self.bond_dim ** 2), dtype=self.dtype, device=self.device)
+        x = min(self.chi, new_chi)
+        e.C[e.keyC][:x, :x] = self.get_C()[:x, :x]
+        e.T[e.keyT][:x, :x, :] = self.get_T()[:x, :x, :]
+        return e
+
+    def get_spectra(self):
+        d = torch.abs(torch.diagonal(self.get_C()))
+        d, _ = torch.sort(d, descending=True)
+        return {self.keyC: d / d[0]}
+
+
+def init_env(state, env, C_and_T=None, ctm_args=cfg.ctm_args):
+    if C_and_T:
+        x = C_and_T[0].size(0)
+        env.C[env.keyC][:x, :x] = C_and_T[0]
+        env.T[env.keyT] = torch.zeros((env.chi, env.chi, C_and_T[1].size(2)), dtype=env.dtype, device=env.device)
+        env.T[env.keyT][:x, :x, :] = C_and_T[1]
+        return
+    if ctm_args.ctm_env_init_type == 'RANDOM':
+        init_random(env, ctm_args.verbosity_initialization)
+    elif ctm_args.ctm_env_init_type == 'CTMRG':
+        init_from_ipeps_pbc(state, env, ctm_args.verbosity_initialization)
+    else:
+        raise ValueError("Invalid environment initialization: " + str(ctm_args.ctm_env_init_type))
+
+
+def init_random(env, verbosity=0):
+    c = torch.rand(env.get_C().size(), dtype=env.dtype, device=env.device)
+    env.C[env.keyC] = 0.5 * (c + c.conj().t())
+    env.T[env.keyT] = torch.rand(env.get_T().size(), dtype=env.dtype, device=env.device)
+
+
+def init_from_ipeps_pbc(state, env, verbosity=0):
+    """env_c4v.py:262-311: corner = eig-decomposed double-layer partial trace, C = diag(D); T rotated
+    into the eigenbasis, T_ijs = sum_ab U_ai t_abs conj(U_bj)."""
+    eng = get_engine()
+    a = state.site()
+    D2 = a.size(1) ** 2
+    c = eng.init_piece(0, a)                                   # 'mijef,mijab->eafb', /max-abs
+    asym = torch.norm(c.t() - c) / c.abs().max()
+    assert asym < 1.0e-8, "a is not symmetric"
+    Dv, U = truncated_eig_sym(c, c.size(0))
+    m = min(env.chi, D2)
+    C = torch.zeros(env.chi, env.chi, dtype=env.dtype, device=env.device)
+    C[:m, :m] = torch.diag(Dv)[:m, :m]
+    env.C[env.keyC] = C
+    t = eng.init_piece(5, a)                                   # 'meifg,maibc->eafbgc' -> (D^2, D^2, D^2), /max-abs
+    # 'ai,abs,bj->ijs' as two GEMMs
+    t1 = eng.gemm(U, t.reshape(D2, D2 * D2), transA=True).reshape(D2, D2, D2)         # [i, b, s]
+    t2 = eng.gemm(U, eng.permute(t1, (1, 0, 2)).reshape(D2, D2 * D2), transA=True)       # [j, (i s)]
+    t2 = eng.permute(t2.reshape(D2, D2, D2), (1, 0, 2))                                 # [i, j, s]
+    asym = (t2 - t2.permute(1, 0, 2)).norm() / t2.abs().max()
+    assert asym < 1.0e-8, "a is not symmetric"
+    T = torch.zeros((env.chi, env.chi, D2), dtype=env.dtype, device=env.device)
+    T[:m, :m, :] = t2[:m, :m, :]
+    env.T[env.keyT] = T

@@ -1,0 +1,129 @@
+"""J1-J2(-h) Heisenberg model on the square lattice: plaquette Hamiltonian and the energy / observable
+evaluation that consumes the native RDMs (reference models/j1j2.py:60-247,427-474,591-679).
+
+Hamiltonian tensors are tiny (<= 2^8 numbers) and live on the host (CPU); RDMs come back from the
+engine and are contracted with them on the host."""
+import itertools
+from math import sqrt
+import torch
+import groups.su2 as su2
+import config as cfg
+from ctm.generic import rdm
+from ctm.one_site_c4v import rdm_c4v
+import parallel
+
+
+def _cast_to_real(t):
+    return t.real if t.is_complex() else t
+
+
+class J1J2():
+    def __init__(self, j1=1.0, j2=0, j3=0, hz_stag=0.0, delta_zz=1.0, lmbd=0, h_uni=[0, 0, 0], global_args=cfg.global_args):
+        if j3 != 0 or lmbd != 0:
+            raise NotImplementedError("j3 / chiral terms need RDMs outside the 2x2 hot path")
+        self.dtype = global_args.torch_dtype
+        self.device = 'cpu'
+        self.phys_dim = 2
+        self.j1, self.j2, self.j3, self.lmbd, self.hz_stag, self.delta_zz = j1, j2, j3, lmbd, hz_stag, delta_zz
+        self.h_uni = torch.as_tensor(h_uni, dtype=self.dtype)
+        s2 = su2.SU2(self.phys_dim, dtype=self.dtype, device=self.device)
+        id2, id3 = s2.I_N(N=2), s2.I_N(N=3)
+        kron = 'ij,ab->iajb'
+        self.SS_delta_zz = s2.SS(xyz=(delta_zz, 1., 1.))
+        self.SS = s2.SS()
+        h_uni_1x1 = torch.einsum('x,xia->ia', self.h_uni, s2.S())
+        hz_2x1_nn = torch.einsum(kron, s2.SZ(), s2.I()) + torch.einsum(kron, s2.I(), -s2.SZ())
+        huni_2x1_nn = torch.einsum(kron, h_uni_1x1, s2.I()) + torch.einsum(kron, s2.I(), h_uni_1x1)
+        rot = s2.BP_rot()
+        _rot2 = lambda h: torch.einsum('ki,kjcb,ca->ijab', rot, h, rot).contiguous()
+        self.SS_rot, self.SS_delta_zz_rot = _rot2(self.SS), _rot2(self.SS_delta_zz)
+        self.hz_2x1_rot, self.huni_2x1_rot = _rot2(hz_2x1_nn), _rot2(huni_2x1_nn)
+        hSSd = torch.einsum('ijab,klcd->ijklabcd', self.SS_delta_zz, id2)
+        hSS = torch.einsum('ijab,klcd->ijklabcd', self.SS, id2)
+        hz = torch.einsum('ia,jklbcd->ijklabcd', s2.SZ(), id3)
+        hu = torch.einsum('ia,jklbcd->ijklabcd', h_uni_1x1, id3)
+
+        def get_hp(coord):
+            # all terms inside one plaquette s0 s1 / s2 s3 so that E/site = <h_p>
+            hp = 0.5 * self.j1 * (hSSd + hSSd.permute(0, 2, 1, 3, 4, 6, 5, 7) + hSSd.permute(2, 3, 0, 1, 6, 7, 4, 5)
+                                  + hSSd.permute(3, 1, 2, 0, 7, 5, 6, 4)) \
+                + self.j2 * (hSS.permute(0, 3, 2, 1, 4, 7, 6, 5) + hSS.permute(2, 1, 0, 3, 6, 5, 4, 7)) \
+                - 0.25 * self.hz_stag * ((-1) ** (coord[0] + coord[1])) * (hz - hz.permute(3, 0, 1, 2, 7, 4, 5, 6)
+                                                                            - hz.permute(2, 3, 0, 1, 6, 7, 4, 5) + hz.permute(1, 2, 3, 0, 5, 6, 7, 4)) \
+                + 0.25 * (hu + hu.permute(2, 3, 0, 1, 6, 7, 4, 5) + hu.permute(3, 0, 1, 2, 7, 4, 5, 6) + hu.permute(1, 2, 3, 0, 5, 6, 7, 4))
+            return hp
+        self.get_hp = get_hp
+        self.hp_rot = torch.einsum('xj,yk,ixylauvd,ub,vc->ijklabcd', rot, rot, self.get_hp((0, 0)), rot, rot).contiguous()
+        self.obs_ops = self.get_obs_ops()
+
+    def get_obs_ops(self):
+        s2 = su2.SU2(self.phys_dim, dtype=self.dtype, device=self.device)
+        return {"sz": s2.SZ(), "sp": s2.SP(), "sm": s2.SM()}
+
+    def energy_per_site(self, state, env):
+        """Mean over the unit cell of tr(rho_2x2(coord) h_p(coord)) (models/j1j2.py:223-247).  The per-site
+        RDMs are independent: with torch.distributed each rank evaluates its sites and the partial sums
+        are all-reduced."""
+        coords = list(state.sites.keys())
+        e = 0.
+        for coord in parallel.my_units(coords):
+            r = rdm.rdm2x2(coord, state, env).cpu()
+            e += float(_cast_to_real(torch.einsum('ijklabcd,ijklabcd', r, self.get_hp(coord))))
+        e = parallel.allreduce_sum_scalar(e, state.device)
+        return torch.as_tensor(e / len(coords), dtype=torch.float64)
+
+    def energy_2x2_2site(self, state, env): return self.energy_per_site(state, env)
+    def energy_2x2_4site(self, state, env): return self.energy_per_site(state, env)
+    def energy_2x2_8site(self, state, env): return self.energy_per_site(state, env)
+
+    def energy_2x2_1site_BP(self, state, env):
+        assert self.h_uni[:2].norm() == 0
+        r = rdm.rdm2x2((0, 0), state, env).cpu()
+        return _cast_to_real(torch.einsum('ijklabcd,ijklabcd', r, self.hp_rot))
+
+    def _eval_obs(self, state, env, ss):
+        obs = {"avg_m": 0.}
+        for coord in state.sites.keys():
+            r1 = rdm.rdm1x1(coord, state, env).cpu()
+            for label, op in self.obs_ops.items():
+                obs[f"{label}{coord}"] = torch.trace(r1 @ op)
+            obs[f"m{coord}"] = sqrt(abs(obs[f"sz{coord}"] ** 2 + obs[f"sp{coord}"] * obs[f"sm{coord}"]))
+            obs["avg_m"] += obs[f"m{coord}"]
+        obs["avg_m"] = obs["avg_m"] / len(state.sites.keys())
+        for coord in state.sites.keys():
+            obs[f"SS2x1{coord}"] = _cast_to_real(torch.einsum('ijab,ijab', rdm.rdm2x1(coord, state, env).cpu(), ss))
+            obs[f"SS1x2{coord}"] = _cast_to_real(torch.einsum('ijab,ijab', rdm.rdm1x2(coord, state, env).cpu(), ss))
+        labels = ["avg_m"] + [f"m{c}" for c in state.sites.keys()] \
+            + [f"{lc[1]}{lc[0]}" for lc in itertools.product(state.sites.keys(), self.obs_ops.keys())] \
+            + [f"SS2x1{c}" for c in state.sites.keys()] + [f"SS1x2{c}" for c in state.sites.keys()]
+        return [obs[l] for l in labels], labels
+
+    def eval_obs(self, state, env): return self._eval_obs(state, env, self.SS)
+    def eval_obs_1site_BP(self, state, env): return self._eval_obs(state, env, self.SS_rot)
+
+
+class J1J2_C4V_BIPARTITE(J1J2):
+    def energy_1x1(self, state, env_c4v, force_cpu=False, **kwargs):
+        r = rdm_c4v.rdm2x2(state, env_c4v, sym_pos_def=True).cpu()
+        return _cast_to_real(torch.einsum('ijklabcd,ijklabcd', r, self.hp_rot))
+
+    def energy_1x1_lowmem(self, state, env_c4v, force_cpu=False):
+        nn = rdm_c4v.rdm2x2_NN_lowmem_sl(state, env_c4v, sym_pos_def=True).cpu()
+        e = 2.0 * self.j1 * torch.einsum('ijkl,ijkl', nn, self.SS_delta_zz_rot) \
+            - 0.5 * self.hz_stag * torch.einsum('ijkl,ijkl', nn, self.hz_2x1_rot)
+        if abs(self.h_uni.norm()) > 0:
+            e = e + 0.5 * torch.einsum('ijkl,ijkl', nn, self.huni_2x1_rot)
+        if abs(self.j2) > 0:
+            nnn = rdm_c4v.rdm2x2_NNN_lowmem_sl(state, env_c4v, sym_pos_def=True).cpu()
+            e = e + 2.0 * self.j2 * torch.einsum('ijkl,ijkl', nnn, self.SS)
+        return _cast_to_real(e)
+
+    def eval_obs(self, state, env_c4v, force_cpu=False):
+        """<m>, <S^z>, <S^+>, <S^-> and nearest-neighbour S.S from rho_2x1 (models/j1j2.py:710-770)."""
+        r2 = rdm_c4v.rdm2x1_sl(state, env_c4v, sym_pos_def=True).cpu()
+        r1 = torch.einsum('ijaj->ia', r2)
+        obs = {l: torch.trace(r1 @ op) for l, op in self.obs_ops.items()}
+        obs["m"] = sqrt(abs(obs["sz"] ** 2 + obs["sp"] * obs["sm"]))
+        obs["SS2x1"] = _cast_to_real(torch.einsum('ijab,ijab', r2, self.SS_rot))
+        labels = ["m"] + list(self.obs_ops.keys()) + ["SS2x1"]
+        return [obs[l] for l in labels], labels

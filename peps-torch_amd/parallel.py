@@ -1,0 +1,75 @@
+"""Multi-GPU sharding of the per-site units of a directional move and of per-site RDMs.
+
+One process per GPU (torch.distributed; backend "nccl" == RCCL over xGMI on ROCm, "gloo" in the
+CPU tests).  Inside one ctm_MOVE all sites' projector computations read the SAME old environment and
+all absorbs read the old environment plus the full projector set (reference ctm/generic/ctmrg.py:
+238-275), so a move is two embarrassingly parallel phases over sites with one exchange after each:
+  phase A  rank r: (P, Pt) of its sites           -> all-gather of P, Pt   (2 n chi doubles / site)
+  phase B  rank r: (nC1, nC2, nT) of its sites    -> all-gather            ((2 chi^2 + chi^2 D^2) / site)
+The four directions stay sequential (move k+1 reads what move k wrote).  Environment tensors are
+replicated on every rank, so after the second exchange all ranks hold identical environments.
+"""
+import torch
+
+try:
+    import torch.distributed as dist
+except Exception:                                      # pragma: no cover
+    dist = None
+
+
+def is_distributed():
+    return dist is not None and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def world():
+    if is_distributed():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def owner_of(index, nranks):
+    """Static round-robin ownership of unit `index` (site number inside the unit cell)."""
+    return index % nranks
+
+
+def my_units(items):
+    """Subset of `items` (ordered) owned by this rank."""
+    rank, n = world()
+    return [x for i, x in enumerate(items) if owner_of(i, n) == rank]
+
+
+def exchange(local, keys, shapes, like):
+    """All ranks end up with `{key: tensor}` for every key of `keys` (ordered list, identical on all
+    ranks); `local` holds the entries this rank computed; `shapes[key]` is known to every rank (it
+    follows from chi and the bond dimensions), `like` supplies dtype/device.  When all tensors of the
+    exchange have one shape and every rank owns the same number of them (uniform-D cell, #sites a
+    multiple of #ranks) they travel as ONE all_gather of a stacked buffer (few, large messages: xGMI
+    is point-to-point, per-link bound); otherwise per-key broadcasts from the owner."""
+    if not is_distributed():
+        return dict(local)
+    rank, n = world()
+    out = dict(local)
+    owned = [[k for i, k in enumerate(keys) if owner_of(i, n) == r] for r in range(n)]
+    uniform = len({len(o) for o in owned}) == 1 and len({tuple(shapes[k]) for k in keys}) == 1 and len(owned[0]) > 0
+    if uniform:
+        send = torch.stack([local[k].contiguous() for k in owned[rank]]).contiguous()
+        recv = [torch.empty_like(send) for _ in range(n)]
+        dist.all_gather(recv, send)
+        for r in range(n):
+            for j, k in enumerate(owned[r]):
+                out[k] = recv[r][j]
+        return out
+    for i, k in enumerate(keys):
+        src = owner_of(i, n)
+        t = local[k].contiguous() if src == rank else torch.empty(tuple(shapes[k]), dtype=like.dtype, device=like.device)
+        dist.broadcast(t, src)
+        out[k] = t
+    return out
+
+
+def allreduce_sum_scalar(x, device):
+    if not is_distributed():
+        return x
+    t = torch.tensor([float(x)], dtype=torch.float64, device=device)
+    dist.all_reduce(t)
+    return float(t.item())

@@ -1,0 +1,125 @@
+"""GPU parity of the generic directional CTM move and RDMs: native HIP path (through the C-ABI and the
+host layer that mirrors the reference API) vs the numpy oracle and the committed golden vectors.
+
+Tolerances (float64): contractions 1e-12 relative; projector-dependent tensors 1e-8 on gauge invariants
+(|.|, P Pt^T) because singular triplets with S/S0 ~ 1e-7 amplify rounding by 1/S; converged spectra and
+rdm2x2 energies 1e-10 relative (the north-star bar)."""
+import numpy as np
+import pytest
+import torch
+from conftest import golden
+from helpers import DIRS, dev, sites_from, env_from, device_state_env, oracle_state_env, relerr
+
+pytestmark = pytest.mark.gpu
+CASES = [("generic_D2_chi8_f64", 8), ("generic_D3_chi18_f64", 18)]
+
+
+@pytest.fixture(scope="module", params=CASES, ids=[c[0] for c in CASES])
+def case(request):
+    name, chi = request.param
+    g = golden(name)
+    sites = sites_from(g)
+    C, T = env_from(g, "warm_")
+    return dict(g=g, chi=chi, sites=sites, C=C, T=T)
+
+
+def test_init_env(case, eng):
+    from ipeps.ipeps import IPEPS
+    from ctm.generic.env import ENV, init_env
+    st = IPEPS({k: dev(v) for k, v in case["sites"].items()})
+    env = ENV(case["chi"], st)
+    init_env(st, env)
+    C0, T0 = env_from(case["g"], "init_")
+    for k in C0: assert relerr(env.C[k], C0[k]) < 1e-13, k
+    for k in T0: assert relerr(env.T[k], T0[k]) < 1e-13, k
+
+
+def test_corners(case, eng):
+    from ctm.generic import ctm_components as cc
+    from oracle import ctm_oracle as O
+    st, env = device_state_env(case["sites"], case["C"], case["T"], case["chi"])
+    ost, oe = oracle_state_env(case["sites"], case["C"], case["T"], case["chi"])
+    fs = {0: cc.c2x2_LU, 1: cc.c2x2_RU, 2: cc.c2x2_RD, 3: cc.c2x2_LD}
+    for cid, f in fs.items():
+        assert relerr(f((0, 0), st, env, mode='sl'), case["g"][f"c2x2_{cid}"]) < 1e-12          # golden (reference output)
+        for coord in case["sites"]:
+            assert relerr(f(coord, st, env, mode='sl'), O.c2x2(cid, coord, ost, oe)) < 1e-12
+            assert relerr(f(coord, st, env, mode='sl-open'), O.c2x2(cid, coord, ost, oe, open_=True)) < 1e-12
+
+
+def test_halves_projectors_absorb(case, eng):
+    from ctm.generic import ctm_components as cc, ctm_projectors as cp, ctmrg
+    from oracle import ctm_oracle as O
+    g, chi = case["g"], case["chi"]
+    st, env = device_state_env(case["sites"], case["C"], case["T"], chi)
+    ost, oe = oracle_state_env(case["sites"], case["C"], case["T"], chi)
+    hf = {'UP': cc.halves_of_4x4_CTM_MOVE_UP, 'LEFT': cc.halves_of_4x4_CTM_MOVE_LEFT,
+          'DOWN': cc.halves_of_4x4_CTM_MOVE_DOWN, 'RIGHT': cc.halves_of_4x4_CTM_MOVE_RIGHT}
+    af = {'UP': ctmrg.absorb_truncate_CTM_MOVE_UP, 'LEFT': ctmrg.absorb_truncate_CTM_MOVE_LEFT,
+          'DOWN': ctmrg.absorb_truncate_CTM_MOVE_DOWN, 'RIGHT': ctmrg.absorb_truncate_CTM_MOVE_RIGHT}
+    for dn, d in DIRS.items():
+        R, Rt = hf[dn]((0, 0), st, env)
+        assert relerr(R, g[f"R_{dn}"]) < 1e-12 and relerr(Rt, g[f"Rt_{dn}"]) < 1e-12
+        P, Pt, S = eng.projectors(R, Rt, chi, return_S=True)
+        assert relerr(S, g[f"S_{dn}"]) < 1e-12
+        Pr, Ptr = g[f"P_{dn}"], g[f"Pt_{dn}"]
+        assert relerr(P.abs(), np.abs(Pr)) < 1e-6 and relerr(Pt.abs(), np.abs(Ptr)) < 1e-6
+        assert relerr(P @ Pt.t(), Pr @ Ptr.T) < 1e-6
+        # biorthogonality of the kept subspace: Pt^T P = 1 on the non-zero block
+        k = int((S.cpu().numpy() / S[0].item() > 1e-8).sum())
+        G = (Pt.t() @ P).cpu().numpy()[:k, :k]
+        assert np.abs(G - np.eye(k)).max() < 1e-7
+        # absorb with the REFERENCE's projectors -> entrywise comparable with the golden outputs
+        Pd = {c: dev(g[f"Pall_{dn}_{c[0]}_{c[1]}"]) for c in case["sites"]}
+        Ptd = {c: dev(g[f"Ptall_{dn}_{c[0]}_{c[1]}"]) for c in case["sites"]}
+        for c in case["sites"]:
+            out = af[dn](c, st, env, Pd, Ptd)
+            for t, nm in zip(out, ("nC1", "nC2", "nT")):
+                assert relerr(t, g[f"abs_{dn}_{c[0]}_{c[1]}_{nm}"]) < 1e-11, (dn, c, nm)
+
+
+def test_one_move_each_direction(case, eng):
+    from ctm.generic import ctmrg
+    g, chi = case["g"], case["chi"]
+    for dn, d in DIRS.items():
+        st, env = device_state_env(case["sites"], case["C"], case["T"], chi)
+        ctmrg.ctm_MOVE(d, st, env)
+        C2, T2 = env_from(g, f"move_{dn}_")
+        for k in C2: assert relerr(env.C[k].abs(), np.abs(C2[k])) < 1e-7, (dn, k)
+        for k in T2: assert relerr(env.T[k].abs(), np.abs(T2[k])) < 1e-7, (dn, k)
+
+
+def test_rdms_and_energy(case, eng):
+    from ctm.generic import rdm
+    from models import j1j2
+    g, chi = case["g"], case["chi"]
+    st, env = device_state_env(case["sites"], case["C"], case["T"], chi)
+    for c in case["sites"]:
+        assert relerr(rdm.rdm2x2(c, st, env), g[f"rdm2x2_{c[0]}_{c[1]}"]) < 1e-11
+    assert relerr(rdm.rdm1x1((0, 0), st, env), g["rdm1x1"]) < 1e-11
+    assert relerr(rdm.rdm2x1((0, 0), st, env), g["rdm2x1"]) < 1e-11
+    assert relerr(rdm.rdm1x2((0, 0), st, env), g["rdm1x2"]) < 1e-11
+    e = float(j1j2.J1J2(j1=1.0, j2=0.5).energy_per_site(st, env))
+    assert abs(e - float(g["energy_j2_0.5"])) < 1e-12 * abs(e)
+
+
+def test_converged_run(case, eng):
+    """ctmrg.run with ctmrg_conv_specC from the CTMRG init: same number of sweeps as the reference,
+    corner spectra and rdm2x2 energy within 1e-10."""
+    import config as cfg
+    from ipeps.ipeps import IPEPS
+    from ctm.generic.env import ENV, init_env, ctmrg_conv_specC
+    from ctm.generic import ctmrg
+    from models import j1j2
+    g, chi = case["g"], case["chi"]
+    st = IPEPS({k: dev(v) for k, v in case["sites"].items()})
+    env = ENV(chi, st)
+    init_env(st, env)
+    cfg.ctm_args.ctm_max_iter = 60
+    env, hist, t_ctm, t_obs = ctmrg.run(st, env, conv_check=ctmrg_conv_specC)
+    assert len(hist['conv_crit']) == int(g["conv_nsweeps"])
+    for k, s in env.get_spectra().items():
+        ref = g[f"conv_spec_{k[0][0]}_{k[0][1]}_{k[1][0]}_{k[1][1]}"]
+        assert np.abs(s.cpu().numpy() - ref).max() < 1e-10, k
+    e = float(j1j2.J1J2(j1=1.0, j2=0.5).energy_per_site(st, env))
+    assert abs(e - float(g["conv_energy"])) < 1e-10 * abs(e)
