@@ -1,0 +1,204 @@
+#!/usr/bin/env python
+"""bench.py -- CTM sweeps/s of the MI355X-native CTMRG engine (driver contract, see task prompt).
+
+    python bench.py --gpus N --steps K --warmup W [--config NAME]
+
+A "step" is one CTM sweep (`_ctmrg_iter` of the reference, ctm/generic/ctmrg.py:63-69: 4 directions x
+lX-or-lY repeats x all sites, conv_check excluded) on a synthetic random iPEPS built exactly like the
+reference scripts do (A ~ U[0,1), shape (2,D,D,D,D), A /= max|A|; env from init_from_ipeps_pbc).
+With N > 1 the per-site units of every directional move are sharded over the N ranks (one MI355X each,
+RCCL all-gather of projectors and of new C/T tensors) -- total work is fixed, so scaling is "strong".
+Rank 0 prints ONE JSON line with the metric, the roofline of the dominant kernel (FP64-MFMA GEMM, timed
+live with HIP events on the engine's stream) and a CPU baseline (numpy oracle on the host cores,
+bounded sample).
+"""
+import argparse, json, math, os, sys, time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(REPO, "peps-torch_amd"))
+sys.path.insert(0, REPO)
+
+import numpy as np
+import torch
+
+CONFIGS = {
+    # name: (kind, D, chi)          BASELINE.json configs[1..3]
+    "c4v_D4_chi64": ("c4v", 4, 64),
+    "generic_D4_chi64": ("generic", 4, 64),
+    "generic_D6_chi128": ("generic", 6, 128),
+    "generic_D8_chi256": ("generic", 8, 256),
+    "generic_D3_chi36": ("generic", 3, 36),
+}
+DEFAULT_CONFIG = "generic_D6_chi128"       # largest single-GPU configuration in BASELINE.json configs
+FP64_MFMA_PEAK_TFLOPS = 78.6               # MI355X FP64 matrix peak (v_mfma_f64_16x16x4_f64, 32 flop/clk/SIMD)
+
+
+def synth_sites(kind, D, seed=1):
+    rng = np.random.default_rng(seed)
+    if kind == "c4v":
+        from oracle.j1j2_oracle import make_c4v_symm_A1
+        A = make_c4v_symm_A1(rng.random((2, D, D, D, D)))
+        return {(0, 0): A / np.abs(A).max()}
+    sites = {}
+    for y in range(2):
+        for x in range(2):
+            A = rng.random((2, D, D, D, D))
+            sites[(x, y)] = A / np.abs(A).max()
+    return sites
+
+
+def gemm_macs_per_unit(D, chi, p=2):
+    """real MACs of the GEMM-shaped work of one (site, direction) unit, 'sl' mode."""
+    return 3 * chi ** 3 * D ** 6 + 8 * chi ** 3 * D ** 4 + 8 * chi ** 3 * D ** 2 + 10 * p * chi ** 2 * D ** 6
+
+
+def cpu_baseline(kind, D, chi, sites, budget_s=25.0):
+    """numpy oracle on the host cores: time ONE unit (site (0,0), UP move: halves -> projectors -> absorb) of
+    the generic sweep -- or ONE C4v sweep -- and extrapolate to sweeps/s.  Bounded sample."""
+    from oracle import ctm_oracle as O, c4v_oracle as O4
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([i.get("num_threads", 1) for i in threadpool_info()] + [1])
+    except Exception:
+        threads = os.cpu_count() or 1
+    if kind == "c4v":
+        A = sites[(0, 0)]
+        C, T = O4.init_env_ctmrg(A, chi)
+        for _ in range(2):
+            C, T = O4.ctm_move_sl(A, C, T)
+        n, t0 = 0, time.perf_counter()
+        while True:
+            C, T = O4.ctm_move_sl(A, C, T); n += 1
+            if time.perf_counter() - t0 > min(budget_s, 10.0) or n >= 20:
+                break
+        dt = (time.perf_counter() - t0) / n
+        return {"value": 1.0 / dt, "unit": "sweeps/s", "cores": threads, "kind": "port",
+                "sample": f"{n} full C4v sweeps of the numpy oracle (LAPACK eigh), {os.cpu_count()} host cpus"}
+    ost = O.State(sites)
+    env = O.init_env_ctmrg(ost, chi)
+    # make the environment dense with the cheapest possible warm-up: random dense env of the right shapes
+    rng = np.random.default_rng(7)
+    for k in env.C: env.C[k] = rng.random(env.C[k].shape)
+    for k in env.T: env.T[k] = rng.random(env.T[k].shape)
+    t0 = time.perf_counter()
+    P, Pt = O.get_projectors_4x4(O.UP, (0, 0), ost, env)
+    Pd = {c: P for c in ost.sites}; Ptd = {c: Pt for c in ost.sites}
+    O.absorb_truncate(O.UP, (0, 0), ost, env, Pd, Ptd)
+    dt = time.perf_counter() - t0
+    return {"value": 1.0 / (32 * dt), "unit": "sweeps/s", "cores": threads, "kind": "port",
+            "sample": f"1 of the 32 (site,direction) units of one sweep (numpy oracle: 4 corners, 2 halves, M, LAPACK gesdd, "
+                      f"projectors, absorb) = {dt:.2f} s, extrapolated x32; {os.cpu_count()} host cpus"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--config", default=DEFAULT_CONFIG, choices=sorted(CONFIGS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile", action="store_true", help="per-phase host timers (adds stream syncs)")
+    args = ap.parse_args()
+    kind, D, chi = CONFIGS[args.config]
+    steps = args.steps if args.steps is not None else (20 if kind == "c4v" else 2)
+    warmup = args.warmup if args.warmup is not None else (3 if kind == "c4v" else 1)
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the engine has no CPU path")
+    torch.cuda.set_device(local)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    if args.gpus != world and rank == 0 and world > 1:
+        print(f"# note: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+
+    import config as cfg
+    cfg.global_args.device = f"cuda:{local}"
+    import _native
+    from ipeps.ipeps import IPEPS
+    from ipeps.ipeps_c4v import IPEPS_C4V
+    from ctm.generic.env import ENV, init_env
+    from ctm.generic import ctmrg
+    from ctm.one_site_c4v.env_c4v import ENV_C4V, init_env as init_env_c4v
+    from ctm.one_site_c4v import ctmrg_c4v
+    eng = _native.engine()
+    dev = torch.device("cuda", local)
+    sites = synth_sites(kind, D)
+    if kind == "c4v":
+        state = IPEPS_C4V(torch.from_numpy(sites[(0, 0)]).to(dev))
+        env = ENV_C4V(chi, state); init_env_c4v(state, env)
+        a = state.site()
+        def step():
+            ctmrg_c4v.ctm_MOVE_sl(a, env)
+    else:
+        state = IPEPS({k: torch.from_numpy(v).to(dev) for k, v in sites.items()})
+        env = ENV(chi, state); init_env(state, env)
+        def step():
+            for d in cfg.ctm_args.ctm_move_sequence:
+                for _ in range(state.lX if d in [(-1, 0), (1, 0)] else state.lY):
+                    ctmrg.ctm_MOVE(d, state, env)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(warmup):
+        step()
+    fence()
+    eng.set_option("gemm_timing", 1)
+    eng.timers(reset=True)
+    if args.profile:
+        eng.set_option("profile", 1)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    k_ms = [eng.stat("k_ms0"), eng.stat("k_ms1")]
+    k_fl = [eng.stat("k_flops0"), eng.stat("k_flops1")]
+    k_n = [eng.stat("k_calls0"), eng.stat("k_calls1")]
+    eng.set_option("gemm_timing", 0)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        dom = 0 if k_ms[0] >= k_ms[1] else 1
+        names = ["gemm_f64_kernel<4,4> (128x128 tile)", "gemm_f64_kernel<2,2> (64x64 tile)"]
+        ach = (k_fl[dom] / max(k_n[dom], 1)) / max(k_ms[dom] / max(k_n[dom], 1) * 1e-3, 1e-30) / 1e12 if k_n[dom] else 0.0
+        roof = {"bound": "mfma", "kernel": names[dom], "achieved": round(ach, 3), "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(ach / FP64_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                "launches": int(k_n[dom]), "avg_launch_ms": round(k_ms[dom] / max(k_n[dom], 1), 5),
+                "gemm_time_share": round((k_ms[0] + k_ms[1]) * 1e-3 / dt, 4),
+                "other_gemm": {"kernel": names[1 - dom], "launches": int(k_n[1 - dom]), "ms": round(k_ms[1 - dom], 2),
+                               "tflops": round(k_fl[1 - dom] / max(k_ms[1 - dom] * 1e-3, 1e-30) / 1e12, 3) if k_n[1 - dom] else 0.0}}
+        out = {"metric": "ctm_sweeps_per_sec", "value": steps / dt, "unit": "sweeps/s", "n_gpus": world, "steps": steps,
+               "warmup": warmup, "ms_per_step": 1e3 * dt / steps, "higher_is_better": True, "scaling": "strong",
+               "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+               "config": {"workload": args.config, "variant": kind, "D": D, "chi": chi, "n": chi * D * D,
+                          "unit_cell": "1x1 C4v" if kind == "c4v" else "2x2 (4 sites, 32 units/sweep)",
+                          "parallelism": f"site-sharded x{world}" if world > 1 else "single GPU"},
+               "roofline": roof,
+               "svd": {"decompositions": int(eng.stat("jacobi_calls")),
+                       "avg_jacobi_sweeps": round(eng.stat("total_sweeps") / max(eng.stat("jacobi_calls"), 1), 2)},
+               "phase_s": {k: round(v, 4) for k, v in eng.timers().items()}}
+        if not args.no_cpu_baseline and world == 1:
+            try:
+                out["cpu_baseline"] = cpu_baseline(kind, D, chi, sites)
+            except Exception as e:                      # the baseline is reporting only
+                out["cpu_baseline"] = {"error": repr(e)}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

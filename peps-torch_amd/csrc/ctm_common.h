@@ -49,7 +49,10 @@ struct ctm_ctx {
     int jacobi_block = 32;
     int jacobi_max_sweeps = 30;
     double jacobi_tol = 1e-14;
+    int jacobi_inner_sweeps = 4;
+    int jacobi_verbose = 0;
     int last_sweeps = 0;
+    long total_sweeps = 0, jacobi_calls = 0;
     double last_offnorm = 0;
     std::map<int, int*> rr_tables;       // nblocks -> device round-robin pair table
     double* d_scratch = nullptr;         // small device scalars (64 doubles)
@@ -60,6 +63,15 @@ struct ctm_ctx {
     // GEMM instrumentation (flop count of all GEMM launches)
     double gemm_flops = 0;
     long gemm_calls = 0;
+    // optional per-launch HIP-event timing of the GEMM kernels on ctx->stream (bench roofline):
+    // kind 0 = 128x128 tile kernel, kind 1 = 64x64 tile kernel
+    bool gemm_timing = false;
+    std::vector<hipEvent_t> ev_pool;
+    struct PendingEv { int e0, e1, kind; double flops; };
+    std::vector<PendingEv> ev_pending;
+    int ev_next = 0;
+    double k_ms[2] = {0, 0}, k_flops[2] = {0, 0};
+    long k_calls[2] = {0, 0};
     void set_error(const std::string& s) { last_error = s; }
 };
 
@@ -105,8 +117,11 @@ struct GemmDesc {
     int splitB_dim = 0;                                  // 0 none, 1 = K, 2 = N
     // optional fused column scale of the output: C(m,n) *= colscale[n]
     const double* colscale = nullptr;
+    // optional per-batch skip flags (device): batch z is skipped when skip_flags[z] == 0
+    const int* skip_flags = nullptr;
 };
 int gemm_f64(ctm_ctx* ctx, const GemmDesc& d);
+void gemm_timing_drain(ctm_ctx* ctx);
 
 // ---- elementwise / layout kernels (tensor_ops.hip) -----------------------------------------
 #define CTM_MAXD 8

@@ -66,6 +66,7 @@ int ctm_destroy(ctm_ctx* ctx) {
     if (!ctx) return CTM_OK;
     (void)hipStreamSynchronize(ctx->stream);
     for (auto& s : ctx->arena.slabs) (void)hipFree(s.base);
+    for (auto& e : ctx->ev_pool) (void)hipEventDestroy(e);
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
     if (ctx->h_scratch) (void)hipHostFree(ctx->h_scratch);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
@@ -85,7 +86,14 @@ int ctm_set_option(ctm_ctx* ctx, const char* key, double value) {
     if (k == "jacobi_tol") ctx->jacobi_tol = value;
     else if (k == "jacobi_max_sweeps") ctx->jacobi_max_sweeps = (int)value;
     else if (k == "jacobi_block") ctx->jacobi_block = (int)value;
+    else if (k == "jacobi_inner_sweeps") ctx->jacobi_inner_sweeps = (int)value;
+    else if (k == "jacobi_verbose") ctx->jacobi_verbose = (int)value;
     else if (k == "profile") ctx->profile = value != 0.0;
+    else if (k == "gemm_timing") {
+        gemm_timing_drain(ctx);
+        ctx->gemm_timing = value != 0.0;
+        for (int i = 0; i < 2; ++i) { ctx->k_ms[i] = 0; ctx->k_flops[i] = 0; ctx->k_calls[i] = 0; }
+    }
     else { ctx->set_error("unknown option " + k); return CTM_ERR_BADARG; }
     return CTM_OK;
 }
@@ -94,16 +102,27 @@ int ctm_get_stat(ctm_ctx* ctx, const char* key, double* value) {
     const std::string k(key ? key : "");
     if (k == "last_sweeps") *value = ctx->last_sweeps;
     else if (k == "last_offnorm") *value = ctx->last_offnorm;
+    else if (k == "total_sweeps") *value = (double)ctx->total_sweeps;
+    else if (k == "jacobi_calls") *value = (double)ctx->jacobi_calls;
     else if (k == "gemm_flops") *value = ctx->gemm_flops;
     else if (k == "gemm_calls") *value = (double)ctx->gemm_calls;
     else if (k == "arena_high") *value = (double)ctx->arena.high;
+    else if (k.rfind("k_", 0) == 0 && k.size() >= 5) {      // k_ms0, k_ms1, k_flops0, k_flops1, k_calls0, k_calls1
+        gemm_timing_drain(ctx);
+        const int i = k.back() - '0';
+        if (i < 0 || i > 1) { ctx->set_error("unknown stat " + k); return CTM_ERR_BADARG; }
+        if (k.compare(0, 4, "k_ms") == 0) *value = ctx->k_ms[i];
+        else if (k.compare(0, 7, "k_flops") == 0) *value = ctx->k_flops[i];
+        else if (k.compare(0, 7, "k_calls") == 0) *value = (double)ctx->k_calls[i];
+        else { ctx->set_error("unknown stat " + k); return CTM_ERR_BADARG; }
+    }
     else { ctx->set_error("unknown stat " + k); return CTM_ERR_BADARG; }
     return CTM_OK;
 }
 
 int ctm_timers(ctm_ctx* ctx, double* out8, int reset) {
     for (int i = 0; i < CTM_T_COUNT; ++i) { if (out8) out8[i] = ctx->timers[i]; if (reset) ctx->timers[i] = 0.0; }
-    if (reset) { ctx->gemm_flops = 0; ctx->gemm_calls = 0; }
+    if (reset) { ctx->gemm_flops = 0; ctx->gemm_calls = 0; ctx->total_sweeps = 0; ctx->jacobi_calls = 0; }
     return CTM_OK;
 }
 

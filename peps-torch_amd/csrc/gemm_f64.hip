@@ -35,6 +35,7 @@ struct GemmParams {
     const GemmOff* offs;
     int splitA, splitB, splitC, splitB_dim;
     const double* colscale;
+    const int* skip_flags;
     int tilesM, tilesN;
 };
 
@@ -47,6 +48,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmParams p) {
     double* As = smem;
     double* Bs = smem + 2 * BK * LDA;
 
+    if (p.skip_flags && p.skip_flags[blockIdx.z] == 0) return;   // uniform per workgroup
     const int tid = threadIdx.x;
     const int lane = tid & 63, wid = tid >> 6;
     const int wm = wid >> 1, wn = wid & 1;
@@ -194,18 +196,46 @@ int gemm_f64(ctm_ctx* ctx, const GemmDesc& d) {
     p.offs = d.offs;
     p.splitA = d.splitA; p.splitB = d.splitB; p.splitC = d.splitC; p.splitB_dim = d.splitB_dim;
     p.colscale = d.colscale;
+    p.skip_flags = d.skip_flags;
     const bool small = (d.M <= 64 || d.N <= 64);
     const int BM = small ? 64 : 128, BN = small ? 64 : 128;
     p.tilesM = (d.M + BM - 1) / BM;
     p.tilesN = (d.N + BN - 1) / BN;
     dim3 grid((unsigned)(p.tilesM * p.tilesN), 1, (unsigned)d.batch);
+    int e0 = -1, e1 = -1;
+    if (ctx->gemm_timing) {
+        if (ctx->ev_next + 2 > (int)ctx->ev_pool.size()) {
+            if (ctx->ev_pool.size() >= 8192) gemm_timing_drain(ctx);
+            else { for (int i = 0; i < 512; ++i) { hipEvent_t e; (void)hipEventCreate(&e); ctx->ev_pool.push_back(e); } }
+        }
+        e0 = ctx->ev_next++; e1 = ctx->ev_next++;
+        (void)hipEventRecord(ctx->ev_pool[e0], ctx->stream);
+    }
     if (small)
         hipLaunchKernelGGL((gemm_f64_kernel<2, 2>), grid, dim3(256), 0, ctx->stream, p);
     else
         hipLaunchKernelGGL((gemm_f64_kernel<4, 4>), grid, dim3(256), 0, ctx->stream, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { ctx->set_error(std::string("gemm launch: ") + hipGetErrorString(e)); return CTM_ERR_HIP; }
-    ctx->gemm_flops += 2.0 * d.M * d.N * (double)d.K * d.batch;
+    const double fl = 2.0 * d.M * d.N * (double)d.K * d.batch;
+    if (e1 >= 0) {
+        (void)hipEventRecord(ctx->ev_pool[e1], ctx->stream);
+        ctx->ev_pending.push_back({e0, e1, small ? 1 : 0, fl});
+    }
+    ctx->gemm_flops += fl;
     ctx->gemm_calls += 1;
     return CTM_OK;
+}
+
+void gemm_timing_drain(ctm_ctx* ctx) {
+    if (ctx->ev_pending.empty()) { ctx->ev_next = 0; return; }
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto& pe : ctx->ev_pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, ctx->ev_pool[pe.e0], ctx->ev_pool[pe.e1]) == hipSuccess) {
+            ctx->k_ms[pe.kind] += ms; ctx->k_flops[pe.kind] += pe.flops; ctx->k_calls[pe.kind] += 1;
+        }
+    }
+    ctx->ev_pending.clear();
+    ctx->ev_next = 0;
 }

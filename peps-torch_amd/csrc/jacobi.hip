@@ -36,8 +36,10 @@ struct SmallEigParams {
     int m;
     double tol;          // relative off-diagonal tolerance for a rotation
     int max_sweeps;
-    unsigned long long* stat_rel;   // max |g_ij| / sqrt(g_ii g_jj)  (bits of a non-negative double)
-    unsigned long long* stat_abs;   // max |g_ij| / max(g_ii, g_jj)
+    double tau2;         // scale floor: a pair (i,j) is measured against max(sqrt(g_ii g_jj), tau2)
+    unsigned long long* stat_rel;   // max |g_ij| / max(sqrt(g_ii g_jj), tau2)  (bits of a non-negative double)
+    unsigned long long* stat_abs;   // max |g_ij| / sqrt(g_ii g_jj) (classical measure, diagnostics only)
+    int* flags;          // per pair: 1 if J != I (the apply GEMM skips the others)
 };
 
 __global__ __launch_bounds__(256) void small_eig_kernel(SmallEigParams p) {
@@ -67,9 +69,10 @@ __global__ __launch_bounds__(256) void small_eig_kernel(SmallEigParams p) {
             const int r = q / m, c = q - r * m;
             if (r < c) {
                 const double g = fabs(W[r][c]), a = W[r][r], b = W[c][c];
-                if (g > 0.0 && a > 0.0 && b > 0.0) {
-                    srel = fmax(srel, g / sqrt(a * b));
-                    sabs = fmax(sabs, g / fmax(a, b));
+                if (g > 0.0) {
+                    const double sc = sqrt(fabs(a * b));
+                    srel = fmax(srel, g / fmax(sc, p.tau2));
+                    if (sc > 0.0) sabs = fmax(sabs, g / sc);
                 }
             }
         }
@@ -95,10 +98,11 @@ __global__ __launch_bounds__(256) void small_eig_kernel(SmallEigParams p) {
         }
         __syncthreads();
         if (srel <= p.tol) {
-            // already diagonal to tolerance: J = I (keeps the rows untouched; sorting is deferred)
-            for (int q = tid; q < m * m; q += 256) { const int r = q / m, c = q - r * m; Jout[q] = (r == c) ? 1.0 : 0.0; }
+            // already diagonal to tolerance: rows stay untouched, the apply GEMM skips this pair
+            if (tid == 0) p.flags[blockIdx.x] = 0;
             return;
         }
+        if (tid == 0) p.flags[blockIdx.x] = 1;
     }
 
     const int half = m / 2, mm1 = m - 1;
@@ -113,7 +117,7 @@ __global__ __launch_bounds__(256) void small_eig_kernel(SmallEigParams p) {
                 if (pi > qi) { const int t = pi; pi = qi; qi = t; }
                 const double a = W[pi][pi], b = W[qi][qi], g = W[pi][qi];
                 double c = 1.0, s = 0.0;
-                if (g != 0.0 && fabs(g) > p.tol * sqrt(fabs(a * b))) {
+                if (g != 0.0 && fabs(g) > p.tol * fmax(sqrt(fabs(a * b)), p.tau2)) {
                     const double zeta = (b - a) / (2.0 * g);
                     const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
                     c = 1.0 / sqrt(1.0 + t * t);
@@ -213,52 +217,65 @@ int get_tables(ctm_ctx* ctx, int nbk, int np, int b, RRTables** out) {
     return CTM_OK;
 }
 
-// Core: X[0], X[1] are ping-pong buffers of 2*np*np doubles: [W (np x np); Q (np x np)].
-// On return *final_buf tells which buffer holds the result.
-int jacobi_core(ctm_ctx* ctx, double* X0, double* X1, int np, int b, bool with_q, int* final_buf) {
+// Core: X holds [W (np x np); Q (np x np)] and is transformed IN PLACE (each workgroup of the apply GEMM
+// owns a column strip of all 2b rows of its pair and finishes reading it before it writes).
+// ktop > 0: only the ktop largest rows need full relative accuracy -- pairs of smaller rows are measured
+// against tau = (ktop-th largest row norm), which still bounds the spectral norm of the tail by tau(1+n tol).
+int jacobi_core(ctm_ctx* ctx, double* X, int np, int b, bool with_q, int ktop, double fro) {
     const int nbk = np / b, rounds = nbk - 1, pairs = nbk / 2, m = 2 * b;
     RRTables* T;
     CTM_TRY(get_tables(ctx, nbk, np, b, &T));
     ArenaScope scope(ctx);
-    double *G, *J;
+    double *G, *J, *norms;
+    int* flags;
     CTM_TRY(arena_alloc(ctx, sizeof(double) * pairs * m * m, (void**)&G));
     CTM_TRY(arena_alloc(ctx, sizeof(double) * pairs * m * m, (void**)&J));
-    unsigned long long* stat = (unsigned long long*)ctx->d_scratch;   // [0]=rel, [1]=abs
-    double* X[2] = {X0, X1};
-    int cur = 0;
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * np, (void**)&norms));
+    CTM_TRY(arena_alloc(ctx, sizeof(int) * pairs, (void**)&flags));
+    unsigned long long* stat = (unsigned long long*)ctx->d_scratch;   // [0]=scaled, [1]=classical
+    std::vector<double> h(np);
+    const double floor2 = (1e-14 * fro) * (1e-14 * fro);
     ctx->last_sweeps = 0;
     for (int sweep = 0; sweep < ctx->jacobi_max_sweeps; ++sweep) {
+        double tau2 = floor2;
+        if (ktop > 0 && ktop < np) {
+            CTM_TRY(row_norms(ctx, X, np, np, np, norms));
+            CTM_HIP_CHECK(ctx, hipMemcpyAsync(h.data(), norms, sizeof(double) * np, hipMemcpyDeviceToHost, ctx->stream));
+            CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+            std::nth_element(h.begin(), h.begin() + (ktop - 1), h.end(), std::greater<double>());
+            tau2 = std::max(floor2, h[ktop - 1] * h[ktop - 1]);
+        }
         CTM_HIP_CHECK(ctx, hipMemsetAsync(stat, 0, 2 * sizeof(double), ctx->stream));
         for (int r = 0; r < rounds; ++r) {
             GemmDesc g;
             g.M = m; g.N = m; g.K = np;
-            g.A = X[cur]; g.sam = np; g.sak = 1; g.splitA = b;
-            g.B = X[cur]; g.sbk = 1; g.sbn = np; g.splitB = b; g.splitB_dim = 2;
+            g.A = X; g.sam = np; g.sak = 1; g.splitA = b;
+            g.B = X; g.sbk = 1; g.sbn = np; g.splitB = b; g.splitB_dim = 2;
             g.C = G; g.ldc = m;
             g.batch = pairs; g.offs = T->d_gram + (size_t)r * pairs;
             CTM_TRY(gemm_f64(ctx, g));
             SmallEigParams sp;
-            sp.G = G; sp.J = J; sp.m = m; sp.tol = ctx->jacobi_tol * 0.1; sp.max_sweeps = 12;
-            sp.stat_rel = stat; sp.stat_abs = stat + 1;
+            sp.G = G; sp.J = J; sp.m = m; sp.tol = ctx->jacobi_tol * 0.1; sp.max_sweeps = ctx->jacobi_inner_sweeps;
+            sp.tau2 = tau2; sp.stat_rel = stat; sp.stat_abs = stat + 1; sp.flags = flags;
             hipLaunchKernelGGL(small_eig_kernel, dim3(pairs), dim3(256), 0, ctx->stream, sp);
             GemmDesc a;
             a.M = m; a.N = np; a.K = m;
             a.A = J; a.sam = 1; a.sak = m;                       // J^T
-            a.B = X[cur]; a.sbk = np; a.sbn = 1; a.splitB = b; a.splitB_dim = 1;
-            a.C = X[cur ^ 1]; a.ldc = np; a.splitC = b;
-            a.batch = with_q ? 2 * pairs : pairs;
-            a.offs = T->d_apply + (size_t)r * 2 * pairs;
+            a.B = X; a.sbk = np; a.sbn = 1; a.splitB = b; a.splitB_dim = 1;
+            a.C = X; a.ldc = np; a.splitC = b;
+            a.batch = pairs; a.offs = T->d_apply + (size_t)r * 2 * pairs; a.skip_flags = flags;
             CTM_TRY(gemm_f64(ctx, a));
-            cur ^= 1;
+            if (with_q) { a.offs = T->d_apply + (size_t)r * 2 * pairs + pairs; CTM_TRY(gemm_f64(ctx, a)); }
         }
         CTM_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_scratch, stat, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
         const double srel = ctx->h_scratch[0];
         ctx->last_sweeps = sweep + 1;
         ctx->last_offnorm = srel;
+        if (ctx->jacobi_verbose) fprintf(stderr, "[jacobi] np=%d sweep %d  scaled=%.3e classical=%.3e tau=%.3e\n", np, sweep + 1, srel, ctx->h_scratch[1], std::sqrt(tau2));
         if (srel <= ctx->jacobi_tol) break;
     }
-    *final_buf = cur;
+    ctx->total_sweeps += ctx->last_sweeps; ctx->jacobi_calls += 1;
     return CTM_OK;
 }
 
@@ -319,20 +336,23 @@ int jacobi_svd_top(ctm_ctx* ctx, const double* M, int n, int k, double* S, doubl
     if (n <= 0 || k <= 0 || k > n) { ctx->set_error("jacobi_svd_top: bad n/k"); return CTM_ERR_BADARG; }
     const int b = choose_block(ctx, n), np = padded(n, b);
     ArenaScope scope(ctx);
-    double *X0, *X1, *norms;
+    double *X, *norms;
     int* d_idx;
-    CTM_TRY(arena_alloc(ctx, sizeof(double) * 2 * (size_t)np * np, (void**)&X0));
-    CTM_TRY(arena_alloc(ctx, sizeof(double) * 2 * (size_t)np * np, (void**)&X1));
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * 2 * (size_t)np * np, (void**)&X));
     CTM_TRY(arena_alloc(ctx, sizeof(double) * np, (void**)&norms));
     CTM_TRY(arena_alloc(ctx, sizeof(int) * np, (void**)&d_idx));
-    hipLaunchKernelGGL(pad_copy_kernel, dim3(2048), dim3(256), 0, ctx->stream, M, n, X0, np);
+    hipLaunchKernelGGL(pad_copy_kernel, dim3(2048), dim3(256), 0, ctx->stream, M, n, X, np);
     const bool with_q = (Ut != nullptr);
-    if (with_q) CTM_TRY(set_identity(ctx, X0 + (size_t)np * np, np, np));
-    int fb = 0;
-    CTM_TRY(jacobi_core(ctx, X0, X1, np, b, with_q, &fb));
-    double* X = fb ? X1 : X0;
-    CTM_TRY(row_norms(ctx, X, np, np, np, norms));
+    if (with_q) CTM_TRY(set_identity(ctx, X + (size_t)np * np, np, np));
     std::vector<double> h(np);
+    CTM_TRY(row_norms(ctx, X, np, np, np, norms));
+    CTM_HIP_CHECK(ctx, hipMemcpyAsync(h.data(), norms, sizeof(double) * np, hipMemcpyDeviceToHost, ctx->stream));
+    CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    double fro = 0.0;
+    for (int i = 0; i < np; ++i) fro += h[i] * h[i];
+    fro = std::sqrt(fro);
+    CTM_TRY(jacobi_core(ctx, X, np, b, with_q, (k < n) ? k : 0, fro));
+    CTM_TRY(row_norms(ctx, X, np, np, np, norms));
     CTM_HIP_CHECK(ctx, hipMemcpyAsync(h.data(), norms, sizeof(double) * np, hipMemcpyDeviceToHost, ctx->stream));
     CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     std::vector<int> idx(np);
@@ -371,10 +391,9 @@ int jacobi_eigh_top(ctm_ctx* ctx, const double* A, int n, int k, double* D, doub
     if (n <= 0 || k <= 0 || k > n) { ctx->set_error("jacobi_eigh_top: bad n/k"); return CTM_ERR_BADARG; }
     const int b = choose_block(ctx, n), np = padded(n, b);
     ArenaScope scope(ctx);
-    double *X0, *X1, *norms, *As;
+    double *X, *norms, *As;
     int* d_idx;
-    CTM_TRY(arena_alloc(ctx, sizeof(double) * 2 * (size_t)np * np, (void**)&X0));
-    CTM_TRY(arena_alloc(ctx, sizeof(double) * 2 * (size_t)np * np, (void**)&X1));
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * 2 * (size_t)np * np, (void**)&X));
     CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)n * n, (void**)&As));
     CTM_TRY(arena_alloc(ctx, sizeof(double) * np, (void**)&norms));
     CTM_TRY(arena_alloc(ctx, sizeof(int) * np, (void**)&d_idx));
@@ -389,11 +408,9 @@ int jacobi_eigh_top(ctm_ctx* ctx, const double* A, int n, int k, double* D, doub
     fro = std::sqrt(fro);
     const double shift = fro * 1.0009765625 + 1e-300;
     CTM_TRY(symmetrize_lower(ctx, A, As, n, shift));
-    hipLaunchKernelGGL(pad_copy_kernel, dim3(2048), dim3(256), 0, ctx->stream, As, n, X0, np);
-    CTM_TRY(set_identity(ctx, X0 + (size_t)np * np, np, np));
-    int fb = 0;
-    CTM_TRY(jacobi_core(ctx, X0, X1, np, b, true, &fb));
-    double* X = fb ? X1 : X0;
+    hipLaunchKernelGGL(pad_copy_kernel, dim3(2048), dim3(256), 0, ctx->stream, As, n, X, np);
+    CTM_TRY(set_identity(ctx, X + (size_t)np * np, np, np));
+    CTM_TRY(jacobi_core(ctx, X, np, b, true, 0, shift * std::sqrt((double)n)));
     CTM_TRY(row_norms(ctx, X, np, np, np, norms));
     CTM_HIP_CHECK(ctx, hipMemcpyAsync(h.data(), norms, sizeof(double) * np, hipMemcpyDeviceToHost, ctx->stream));
     CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));

@@ -25,7 +25,7 @@ TILINGS = {
     "1SITE": lambda c: (0, 0),
     "2SITE": lambda c: ((c[0] + abs(c[0]) * 2) % 2, 0),
     "4SITE": lambda c: ((c[0] + abs(c[0]) * 2) % 2, (c[1] + abs(c[1]) * 2) % 2),
-    "8SITE": lambda c: ((c[0] + (c[1] + abs(c[1]) * 2) // 2 * 2 + abs(c[0]) * 4) % 4, (c[1] + abs(c[1]) * 2) % 2),
+    "8SITE": lambda c: ((c[0] + 2 * (c[1] // 2)) % 4, c[1] % 2),          # 4x2 cell with a shift of 2 every second row
 }
 NSITES = {"BIPARTITE": [(0, 0), (1, 0)], "1SITE": [(0, 0)], "2SITE": [(0, 0), (1, 0)],
           "4SITE": [(0, 0), (1, 0), (0, 1), (1, 1)],

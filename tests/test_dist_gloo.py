@@ -1,0 +1,69 @@
+"""CPU, world_size 2, gloo: the site-sharded directional move (parallel.py) gives every rank the same
+environment as the single-process move.  Compute runs on the oracle-backed engine double."""
+import os, sys
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    here = os.path.dirname(os.path.abspath(__file__))
+    for p in (os.path.dirname(here), os.path.join(os.path.dirname(here), "peps-torch_amd"), here):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import config as cfg
+    cfg.global_args.device = 'cpu'
+    import backend
+    from fake_engine import FakeEngine
+    backend.set_engine(FakeEngine())
+    from conftest import golden
+    from helpers_cpu import sites_from
+    from ipeps.ipeps import IPEPS
+    from ctm.generic.env import ENV, init_env
+    from ctm.generic import ctmrg
+    from models import j1j2
+    import parallel
+    g = golden("generic_D2_chi8_f64")
+    st = IPEPS({k: torch.from_numpy(v.copy()) for k, v in sites_from(g).items()})
+    env = ENV(8, st)
+    init_env(st, env)
+    assert parallel.is_distributed() and len(parallel.my_units(list(st.sites))) == 2
+    for _ in range(2):
+        for d in cfg.ctm_args.ctm_move_sequence:
+            for _r in range(2):
+                ctmrg.ctm_MOVE(d, st, env)
+    e = float(j1j2.J1J2(j1=1.0, j2=0.5).energy_per_site(st, env))
+    key = lambda k: f"{k[0][0]}_{k[0][1]}_{k[1][0]}_{k[1][1]}"
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), energy=e, **{"C" + key(k): t.numpy() for k, t in env.C.items()},
+             **{"T" + key(k): t.numpy() for k, t in env.T.items()})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_move_equals_single_process(tmp_path):
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    for k in r0.files:
+        assert np.array_equal(r0[k], r1[k]), k          # replicated env identical on both ranks
+    # single-process oracle reference
+    from conftest import golden
+    from helpers_cpu import sites_from
+    from oracle import ctm_oracle as O, j1j2_oracle as OJ
+    g = golden("generic_D2_chi8_f64")
+    ost = O.State(sites_from(g))
+    oe = O.init_env_ctmrg(ost, 8)
+    for _ in range(2):
+        O.ctm_sweep(ost, oe)
+    key = lambda k: f"{k[0][0]}_{k[0][1]}_{k[1][0]}_{k[1][1]}"
+    for k, t in oe.C.items():
+        assert np.abs(r0["C" + key(k)] - t).max() < 1e-12
+    for k, t in oe.T.items():
+        assert np.abs(r0["T" + key(k)] - t).max() < 1e-12
+    e = OJ.energy_per_site([O.rdm2x2(c, ost, oe) for c in ost.sites], 1.0, 0.5)
+    assert abs(float(r0["energy"]) - e) < 1e-12

@@ -1,0 +1,124 @@
+"""CPU: host-side logic of the drop-in layer (state container, JSON I/O, config flags, tilings, the move
+orchestration on an oracle-backed engine double)."""
+import json, os
+import numpy as np
+import pytest
+import torch
+import backend
+from fake_engine import FakeEngine
+from helpers_cpu import sites_from, env_from
+from conftest import golden
+
+
+@pytest.fixture()
+def cpu_cfg():
+    import config as cfg
+    old = cfg.global_args.device
+    cfg.global_args.device = 'cpu'
+    backend.set_engine(FakeEngine())
+    yield cfg
+    backend.set_engine(None)
+    cfg.global_args.device = old
+
+
+def test_vertex_to_site_default_and_pattern(cpu_cfg):
+    from ipeps.ipeps import IPEPS
+    t = lambda: torch.rand(2, 2, 2, 2, 2, dtype=torch.float64)
+    st = IPEPS({(0, 0): t(), (1, 0): t(), (0, 1): t(), (1, 1): t()})
+    assert (st.lX, st.lY) == (2, 2)
+    assert st.vertexToSite((-1, -1)) == (1, 1) and st.vertexToSite((2, 3)) == (0, 1) and st.vertexToSite((-3, 0)) == (1, 0)
+    st2 = IPEPS({(0, 0): t(), (1, 0): t()}, pattern=[[0, 1], [1, 0]])
+    assert st2.vertexToSite((0, 1)) == (1, 0) and st2.vertexToSite((1, 1)) == (0, 0) and st2.vertexToSite((-1, 0)) == (1, 0)
+    assert len(st.get_aux_bond_dims()) == 16
+
+
+def test_script_tilings():
+    import importlib.util, sys
+    from conftest import PKG
+    spec = importlib.util.spec_from_file_location("ctmrg_j1j2_script", os.path.join(PKG, "examples", "j1j2", "ctmrg_j1j2.py"))
+    m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
+    bp = m.TILINGS["BIPARTITE"]
+    assert [bp((x, y)) for y in range(2) for x in range(2)] == [(0, 0), (1, 0), (1, 0), (0, 0)]
+    assert m.TILINGS["4SITE"]((-1, 3)) == (1, 1)
+    e8 = m.TILINGS["8SITE"]
+    assert e8((0, 0)) == (0, 0) and e8((0, 2)) == (2, 0) and e8((3, 1)) == (3, 1)
+
+
+def test_json_roundtrip(tmp_path, cpu_cfg):
+    from ipeps.ipeps import IPEPS, read_ipeps, write_ipeps
+    rng = np.random.default_rng(0)
+    st = IPEPS({(0, 0): torch.from_numpy(rng.random((2, 2, 3, 2, 3))), (1, 0): torch.from_numpy(rng.random((2, 2, 3, 2, 3)))})
+    f = str(tmp_path / "s.json")
+    write_ipeps(st, f)
+    st2 = read_ipeps(f)
+    for c in st.sites:
+        assert torch.equal(st.sites[c], st2.sites[c].cpu())
+    assert (st2.lX, st2.lY) == (2, 1)
+    # aux_seq: file stores [left, up, right, down]
+    write_ipeps(st, f, aux_seq=[1, 0, 3, 2])
+    st3 = read_ipeps(f, aux_seq=[1, 0, 3, 2])
+    assert torch.equal(st.sites[(0, 0)], st3.sites[(0, 0)].cpu())
+    # legacy sparse entries "s u l d r re" with physDim/auxDim
+    js = {"lX": 1, "lY": 1, "sites": [{"siteId": "A0", "physDim": 2, "auxDim": 2, "entries": ["0 0 0 0 0 1.5", "1 1 0 1 0 -2.0 0.0"]}],
+          "map": [{"siteId": "A0", "x": 0, "y": 0}]}
+    json.dump(js, open(f, "w"))
+    s4 = read_ipeps(f)
+    a = s4.sites[(0, 0)]
+    assert a.shape == (2, 2, 2, 2, 2) and a[0, 0, 0, 0, 0] == 1.5 and a[1, 1, 0, 1, 0] == -2.0 and a.abs().sum() == 3.5
+
+
+def test_config_flags_roundtrip(cpu_cfg):
+    cfg = cpu_cfg
+    p = cfg.get_args_parser()
+    args = p.parse_args(["--chi", "32", "--bond_dim", "3", "--CTMARGS_ctm_max_iter", "7", "--CTMARGS_projector_svd_reltol", "1e-9",
+                         "--GLOBALARGS_dtype", "float64", "--out_prefix", "/tmp/_ctm_test"])
+    old = cfg.ctm_args.ctm_max_iter
+    cfg.configure(args)
+    assert cfg.ctm_args.ctm_max_iter == 7 and cfg.ctm_args.projector_svd_reltol == 1e-9 and cfg.main_args.chi == 32
+    assert cfg.global_args.torch_dtype == torch.float64
+    cfg.ctm_args.ctm_max_iter = old; cfg.ctm_args.projector_svd_reltol = 1e-8
+    # defaults of the fields the hot path reads (reference config.py:370-409)
+    c = cfg.CTMARGS()
+    assert (c.ctm_max_iter, c.ctm_conv_tol, c.ctm_env_init_type, c.projector_method, c.projector_svd_reltol,
+            c.projector_eps_multiplet, c.projector_multiplet_abstol) == (50, 1e-8, 'CTMRG', '4X4', 1e-8, 1e-8, 1e-14)
+    assert c.ctm_move_sequence == [(0, -1), (-1, 0), (0, 1), (1, 0)]
+
+
+def test_move_orchestration_matches_oracle(cpu_cfg):
+    """ctm_MOVE / run / conv_specC / energy on the host layer (engine double) == oracle end to end."""
+    from ipeps.ipeps import IPEPS
+    from ctm.generic.env import ENV, init_env, ctmrg_conv_specC
+    from ctm.generic import ctmrg
+    from models import j1j2
+    from oracle import ctm_oracle as O, j1j2_oracle as OJ
+    cfg = cpu_cfg
+    g = golden("generic_D2_chi8_f64")
+    sites = sites_from(g)
+    st = IPEPS({k: torch.from_numpy(v.copy()) for k, v in sites.items()})
+    env = ENV(8, st)
+    init_env(st, env)
+    C0, T0 = env_from(g, "init_")
+    for k in C0: assert np.abs(env.C[k].numpy() - C0[k]).max() < 1e-13
+    cfg.ctm_args.ctm_max_iter = 60
+    env, hist, t_ctm, t_obs = ctmrg.run(st, env, conv_check=ctmrg_conv_specC)
+    assert len(hist['conv_crit']) == int(g["conv_nsweeps"])
+    e = float(j1j2.J1J2(j1=1.0, j2=0.5).energy_per_site(st, env))
+    assert abs(e - float(g["conv_energy"])) < 1e-10 * abs(e)
+    with pytest.raises(ValueError):
+        ctmrg.ctm_MOVE((1, 1), st, env)
+    cfg.ctm_args.ctm_max_iter = 50
+
+
+def test_error_conventions(cpu_cfg):
+    from ipeps.ipeps import IPEPS
+    from ctm.generic.env import ENV, init_env
+    cfg = cpu_cfg
+    st = IPEPS({(0, 0): torch.rand(2, 2, 2, 2, 2, dtype=torch.float64)})
+    env = ENV(4, st)
+    old = cfg.ctm_args.ctm_env_init_type
+    cfg.ctm_args.ctm_env_init_type = "BOGUS"
+    with pytest.raises(ValueError):
+        init_env(st, env)
+    cfg.ctm_args.ctm_env_init_type = old
+    e2 = env.extend(6)
+    assert e2.C[((0, 0), (-1, -1))].shape == (6, 6) and e2.T[((0, 0), (0, 1))].shape == (4, 6, 6)

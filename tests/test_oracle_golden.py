@@ -1,0 +1,116 @@
+"""CPU: the oracle reproduces the committed golden vectors (which were produced by the REAL reference in
+oracle/gen_golden.py) -- this is what pins the oracle on machines where /root/reference does not exist."""
+import numpy as np
+import pytest
+from conftest import golden
+from helpers_cpu import sites_from, env_from
+from oracle import ctm_oracle as O, c4v_oracle as O4, j1j2_oracle as OJ
+
+DIRS = {'UP': (0, -1), 'LEFT': (-1, 0), 'DOWN': (0, 1), 'RIGHT': (1, 0)}
+
+
+def rel(a, b):
+    return float(np.abs(np.asarray(a) - np.asarray(b)).max() / max(np.abs(b).max(), 1e-300))
+
+
+@pytest.mark.parametrize("name,chi", [("generic_D2_chi8_f64", 8), ("generic_D3_chi18_f64", 18), ("generic_D2_chi8_c128", 8)])
+def test_generic_oracle_vs_reference_vectors(name, chi):
+    g = golden(name)
+    sites = sites_from(g)
+    ost = O.State(sites)
+    e0 = O.init_env_ctmrg(ost, chi)
+    C0, T0 = env_from(g, "init_")
+    for k in C0: assert rel(e0.C[k], C0[k]) < 1e-13
+    for k in T0: assert rel(e0.T[k], T0[k]) < 1e-13
+    C, T = env_from(g, "warm_")
+    oe = O.Env(chi); oe.C = C; oe.T = T
+    for cid in range(4):
+        assert rel(O.c2x2(cid, (0, 0), ost, oe), g[f"c2x2_{cid}"]) < 1e-12
+    for dn, d in DIRS.items():
+        R, Rt = O.halves(d, (0, 0), ost, oe)
+        assert rel(R, g[f"R_{dn}"]) < 1e-12 and rel(Rt, g[f"Rt_{dn}"]) < 1e-12
+        P, Pt, S = O.projectors_from_matrices(R, Rt, chi, return_S=True)
+        assert rel(S, g[f"S_{dn}"]) < 1e-12
+        assert rel(np.abs(P), np.abs(g[f"P_{dn}"])) < 1e-6
+        assert rel(P @ Pt.T, g[f"P_{dn}"] @ g[f"Pt_{dn}"].T) < 1e-6
+        Pd = {c: g[f"Pall_{dn}_{c[0]}_{c[1]}"] for c in sites}
+        Ptd = {c: g[f"Ptall_{dn}_{c[0]}_{c[1]}"] for c in sites}
+        for c in sites:
+            for t, nm in zip(O.absorb_truncate(d, c, ost, oe, Pd, Ptd), ("nC1", "nC2", "nT")):
+                assert rel(t, g[f"abs_{dn}_{c[0]}_{c[1]}_{nm}"]) < 1e-12
+    rd = [O.rdm2x2(c, ost, oe) for c in sites]
+    for c, r in zip(sites, rd):
+        assert rel(r, g[f"rdm2x2_{c[0]}_{c[1]}"]) < 1e-10
+    assert abs(OJ.energy_per_site(rd, 1.0, 0.5) - float(g["energy_j2_0.5"])) < 1e-12
+    assert rel(O.rdm1x1((0, 0), ost, oe), g["rdm1x1"]) < 1e-10
+    assert rel(O.rdm2x1((0, 0), ost, oe), g["rdm2x1"]) < 1e-10
+    assert rel(O.rdm1x2((0, 0), ost, oe), g["rdm1x2"]) < 1e-10
+
+
+def test_generic_oracle_converged_run():
+    g = golden("generic_D2_chi8_f64")
+    sites = sites_from(g)
+    ost = O.State(sites)
+    oe = O.init_env_ctmrg(ost, 8)
+    hist = None
+    for _ in range(60):
+        O.ctm_sweep(ost, oe)
+        done, hist = O.conv_specC(oe, hist, tol=1e-8, max_iter=60)
+        if done:
+            break
+    assert len(hist['conv_crit']) == int(g["conv_nsweeps"])
+    e = OJ.energy_per_site([O.rdm2x2(c, ost, oe) for c in sites], 1.0, 0.5)
+    assert abs(e - float(g["conv_energy"])) < 1e-10 * abs(e)
+
+
+def test_decompositions():
+    g = golden("decomp")
+    for nm in "abc":
+        U, S, V = O.truncated_svd_gesdd(g[f"svd_{nm}_M"], 8, keep_multiplets=True, eps_multiplet=1e-8)
+        assert np.abs(S - g[f"svd_{nm}_S"]).max() < 1e-13
+        assert ((S == 0) == (g[f"svd_{nm}_S"] == 0)).all()
+    assert (g["svd_b_S"] == 0).sum() == 2          # multiplet back-off dropped the cut 4-fold multiplet
+    assert (g["svd_c_S"] == 0).sum() == 3          # rank 5 < chi 8
+    for nm, ch in (("a", 4), ("b", 6)):
+        D, U = O.truncated_eig_sym(g["eig_H"], ch, keep_multiplets=True)
+        assert np.abs(D - g[f"eig_{nm}_D"]).max() < 1e-13
+
+
+@pytest.mark.parametrize("name", ["c4v_D2_chi8", "c4v_D3_chi18"])
+def test_c4v_oracle(name):
+    g = golden(name)
+    A, C, T = g["site"], g["warm_C"], g["warm_T"]
+    assert rel(O4.c2x2_sl(A, C, T), g["c2x2"]) < 1e-12
+    nC, nT = O4.ctm_move_sl(A, C, T)
+    assert rel(np.diag(nC), np.diag(g["move_C"])) < 1e-10
+    assert rel(np.abs(nT), np.abs(g["move_T"])) < 1e-8
+    for nm, f in (("rdm2x1", O4.rdm2x1_sl), ("rdmNN", O4.rdm2x2_NN_lowmem_sl), ("rdmNNN", O4.rdm2x2_NNN_lowmem_sl), ("rdm2x2", O4.rdm2x2)):
+        assert rel(f(A, C, T, sym_pos_def=True), g[nm]) < 1e-10
+    assert abs(OJ.energy_1x1_lowmem(g["rdmNN"], g["rdmNNN"], 1.0, 0.5) - float(g["e_lowmem"])) < 1e-12
+    assert abs(OJ.energy_1x1(g["rdm2x2"], 1.0, 0.5) - float(g["e_2x2"])) < 1e-12
+
+
+def test_rvb_known_answer_oracle():
+    """The reference's own known-answer test (examples/j1j2/ctmrg_j1j2_c4v.py:254-256)."""
+    g = golden("rvb_c4v")
+    A = g["site"]
+    C, T = O4.init_env_ctmrg(A, 16)
+    for _ in range(int(g["nsweeps"])):
+        C, T = O4.ctm_move_sl(A, C, T)
+    e = OJ.energy_1x1_lowmem(O4.rdm2x2_NN_lowmem_sl(A, C, T, True), O4.rdm2x2_NNN_lowmem_sl(A, C, T, True), 1.0, 0.5)
+    assert abs(e - (-0.47684229)) < 1e-8
+    assert (np.diag(C) == 0).sum() == 3
+
+
+def test_two_site_golden_state_energy():
+    """examples/j1j2/ctmrg_j1j2.py:258-266: 2SITE D=2 chi=32 j2=0.55 -> E = -0.4434603770143078 (tol 1e-6)."""
+    g = golden("twosite_D2_chi32")
+    sites = sites_from(g)
+    v2s = lambda c: ((c[0] + abs(c[0]) * 2) % 2, 0)
+    ost = O.State(sites, lX=int(g["lX"]), lY=int(g["lY"]), vertexToSite=v2s)
+    oe = O.init_env_ctmrg(ost, 32)
+    for _ in range(int(g["nsweeps"])):
+        O.ctm_sweep(ost, oe)
+    e = OJ.energy_per_site([O.rdm2x2(c, ost, oe) for c in ost.sites], 1.0, 0.55)
+    assert abs(e - (-0.4434603770143078)) < 1e-6
+    assert abs(e - float(g["energy"])) < 1e-10
