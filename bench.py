@@ -98,6 +98,7 @@ def main():
     ap.add_argument("--config", default=DEFAULT_CONFIG, choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile", action="store_true", help="per-phase host timers (adds stream syncs)")
+    ap.add_argument("--opt", action="append", default=[], help="engine option key=value (development)")
     args = ap.parse_args()
     kind, D, chi = CONFIGS[args.config]
     steps = args.steps if args.steps is not None else (20 if kind == "c4v" else 2)
@@ -126,6 +127,8 @@ def main():
     from ctm.one_site_c4v.env_c4v import ENV_C4V, init_env as init_env_c4v
     from ctm.one_site_c4v import ctmrg_c4v
     eng = _native.engine()
+    for kv in args.opt:
+        k_, v_ = kv.split("="); eng.set_option(k_, float(v_))
     dev = torch.device("cuda", local)
     sites = synth_sites(kind, D)
     if kind == "c4v":
@@ -187,7 +190,9 @@ def main():
                           "parallelism": f"site-sharded x{world}" if world > 1 else "single GPU"},
                "roofline": roof,
                "svd": {"decompositions": int(eng.stat("jacobi_calls")),
-                       "avg_jacobi_sweeps": round(eng.stat("total_sweeps") / max(eng.stat("jacobi_calls"), 1), 2)},
+                       "avg_jacobi_sweeps": round(eng.stat("total_sweeps") / max(eng.stat("jacobi_calls"), 1), 2),
+                       "power_iter_hits": int(eng.stat("si_hits")), "power_iter_fallbacks_to_full": int(eng.stat("si_fallbacks")),
+                       "avg_half_steps": round(eng.stat("si_total_iters") / max(eng.stat("si_hits") + eng.stat("si_fallbacks"), 1), 2)},
                "phase_s": {k: round(v, 4) for k, v in eng.timers().items()}}
         if not args.no_cpu_baseline and world == 1:
             try:

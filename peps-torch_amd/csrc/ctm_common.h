@@ -49,8 +49,13 @@ struct ctm_ctx {
     int jacobi_block = 32;
     int jacobi_max_sweeps = 30;
     double jacobi_tol = 1e-14;
-    int jacobi_inner_sweeps = 4;
+    int jacobi_inner_sweeps = 3;
     int jacobi_verbose = 0;
+    // leading-k block power iteration (svd_iter): enabled for n >= si_min_n, residual tolerance relative to s_0
+    bool si_enable = true;
+    int si_min_n = 512, si_max_iter = 40, si_last_iters = 0, si_rr_sweeps = 40;
+    double si_tol = 2e-14;
+    long si_hits = 0, si_fallbacks = 0, si_total_iters = 0;
     int last_sweeps = 0;
     long total_sweeps = 0, jacobi_calls = 0;
     double last_offnorm = 0;
@@ -102,7 +107,7 @@ struct PhaseTimer {
 //   B(k,n) = B + segB(.) ...          the segmented dim of B is K (splitB_dim=1) or N (splitB_dim=2)
 //   C(m,n) = C + segC(m) + n          (row-major, unit column stride)
 // batched over `batch` entries of offsets (device array of GemmOff) or regular strides.
-struct GemmOff { long long a0, a1, b0, b1, c0, c1; };
+struct GemmOff { long long a0, a1, b0, b1, c0, c1; int klen; int pad_; };   // klen > 0: this batch entry contracts only klen values of K
 
 struct GemmDesc {
     int M = 0, N = 0, K = 0;

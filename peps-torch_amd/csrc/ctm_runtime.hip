@@ -88,6 +88,11 @@ int ctm_set_option(ctm_ctx* ctx, const char* key, double value) {
     else if (k == "jacobi_block") ctx->jacobi_block = (int)value;
     else if (k == "jacobi_inner_sweeps") ctx->jacobi_inner_sweeps = (int)value;
     else if (k == "jacobi_verbose") ctx->jacobi_verbose = (int)value;
+    else if (k == "si_enable") ctx->si_enable = value != 0.0;
+    else if (k == "si_min_n") ctx->si_min_n = (int)value;
+    else if (k == "si_max_iter") ctx->si_max_iter = (int)value;
+    else if (k == "si_tol") ctx->si_tol = value;
+    else if (k == "si_rr_sweeps") ctx->si_rr_sweeps = (int)value;
     else if (k == "profile") ctx->profile = value != 0.0;
     else if (k == "gemm_timing") {
         gemm_timing_drain(ctx);
@@ -104,6 +109,10 @@ int ctm_get_stat(ctm_ctx* ctx, const char* key, double* value) {
     else if (k == "last_offnorm") *value = ctx->last_offnorm;
     else if (k == "total_sweeps") *value = (double)ctx->total_sweeps;
     else if (k == "jacobi_calls") *value = (double)ctx->jacobi_calls;
+    else if (k == "si_hits") *value = (double)ctx->si_hits;
+    else if (k == "si_fallbacks") *value = (double)ctx->si_fallbacks;
+    else if (k == "si_last_iters") *value = (double)ctx->si_last_iters;
+    else if (k == "si_total_iters") *value = (double)ctx->si_total_iters;
     else if (k == "gemm_flops") *value = ctx->gemm_flops;
     else if (k == "gemm_calls") *value = (double)ctx->gemm_calls;
     else if (k == "arena_high") *value = (double)ctx->arena.high;
@@ -122,7 +131,7 @@ int ctm_get_stat(ctm_ctx* ctx, const char* key, double* value) {
 
 int ctm_timers(ctm_ctx* ctx, double* out8, int reset) {
     for (int i = 0; i < CTM_T_COUNT; ++i) { if (out8) out8[i] = ctx->timers[i]; if (reset) ctx->timers[i] = 0.0; }
-    if (reset) { ctx->gemm_flops = 0; ctx->gemm_calls = 0; ctx->total_sweeps = 0; ctx->jacobi_calls = 0; }
+    if (reset) { ctx->gemm_flops = 0; ctx->gemm_calls = 0; ctx->total_sweeps = 0; ctx->jacobi_calls = 0; ctx->si_hits = 0; ctx->si_fallbacks = 0; ctx->si_total_iters = 0; }
     return CTM_OK;
 }
 

@@ -69,6 +69,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmParams p) {
     if (p.offs) {
         const GemmOff o = p.offs[blockIdx.z];
         a0 = o.a0; a1 = o.a1; b0 = o.b0; b1 = o.b1; c0 = o.c0; c1 = o.c1;
+        if (o.klen > 0) p.K = o.klen;
     } else {
         a0 = a1 = (long long)blockIdx.z * p.strideA;
         b0 = b1 = (long long)blockIdx.z * p.strideB;
@@ -197,7 +198,8 @@ int gemm_f64(ctm_ctx* ctx, const GemmDesc& d) {
     p.splitA = d.splitA; p.splitB = d.splitB; p.splitC = d.splitC; p.splitB_dim = d.splitB_dim;
     p.colscale = d.colscale;
     p.skip_flags = d.skip_flags;
-    const bool small = (d.M <= 64 || d.N <= 64);
+    const long long tiles128 = (long long)((d.M + 127) / 128) * ((d.N + 127) / 128) * d.batch;
+    const bool small = (d.M <= 64 || d.N <= 64 || tiles128 < 200);
     const int BM = small ? 64 : 128, BN = small ? 64 : 128;
     p.tilesM = (d.M + BM - 1) / BM;
     p.tilesN = (d.N + BN - 1) / BN;

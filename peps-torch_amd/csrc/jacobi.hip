@@ -31,7 +31,8 @@ constexpr int MAXM = 64;   // largest pair-Gram the LDS solver handles (2 * bloc
 // batched small symmetric eigensolver: one workgroup (256 threads) per m x m Gram matrix
 // ---------------------------------------------------------------------------------------------
 struct SmallEigParams {
-    const double* G;     // batch x m x m
+    const double* G;     // nsplit x batch x m x m partial Gram matrices (summed on load)
+    int nsplit; long long split_stride;
     double* J;           // batch x m x m (columns = eigenvectors, eigenvalues descending)
     int m;
     double tol;          // relative off-diagonal tolerance for a rotation
@@ -42,6 +43,10 @@ struct SmallEigParams {
     int* flags;          // per pair: 1 if J != I (the apply GEMM skips the others)
 };
 
+// Two-sided cyclic Jacobi on one m x m (m <= 64, even) symmetric matrix per workgroup, everything in LDS.
+// Round-robin ordering: m/2 disjoint rotations per round; per round the rotation parameters are computed by
+// m/2 lanes, then every thread transforms whole 2x2 blocks W[{p1,q1}][{p2,q2}] <- R1^T B R2 (row and column
+// update fused: each block is owned by exactly one thread) and the eigenvector columns -- two barriers per round.
 __global__ __launch_bounds__(256) void small_eig_kernel(SmallEigParams p) {
     __shared__ double W[MAXM][MAXM + 1];
     __shared__ double Jm[MAXM][MAXM + 1];
@@ -49,16 +54,28 @@ __global__ __launch_bounds__(256) void small_eig_kernel(SmallEigParams p) {
     __shared__ int pr_p[MAXM / 2], pr_q[MAXM / 2];
     __shared__ double red[4];
     __shared__ int rot_flag;
+    __shared__ int round_rot[2];
+    __shared__ unsigned char pair_tab[MAXM - 1][MAXM / 2][2];
     __shared__ int rank_of[MAXM];
 
     const int m = p.m, tid = threadIdx.x;
     const double* G = p.G + (size_t)blockIdx.x * m * m;
     double* Jout = p.J + (size_t)blockIdx.x * m * m;
 
-    for (int q = tid; q < m * m; q += 256) {
-        const int r = q / m, c = q - r * m;
-        W[r][c] = G[q];
-        Jm[r][c] = (r == c) ? 1.0 : 0.0;
+    {   // sum the split-K partial Grams: 16 independent accumulators per thread keep the loads in flight
+        double acc[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) acc[u] = 0.0;
+        for (int s = 0; s < p.nsplit; ++s) {
+            const double* Gs = G + (size_t)s * p.split_stride;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) { const int q = tid + u * 256; if (q < m * m) acc[u] += Gs[q]; }
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int q = tid + u * 256;
+            if (q < m * m) { const int r = q / m, c = q - r * m; W[r][c] = acc[u]; Jm[r][c] = (r == c) ? 1.0 : 0.0; }
+        }
     }
     __syncthreads();
 
@@ -106,48 +123,86 @@ __global__ __launch_bounds__(256) void small_eig_kernel(SmallEigParams p) {
     }
 
     const int half = m / 2, mm1 = m - 1;
+    for (int q = tid; q < mm1 * half; q += 256) {      // round-robin schedule of all rounds, once
+        const int r = q / half, k = q - r * half;
+        int pi, qi;
+        if (k == 0) { pi = mm1; qi = r % mm1; }
+        else { pi = (r + k) % mm1; qi = (r - k + mm1) % mm1; }
+        if (pi > qi) { const int t = pi; pi = qi; qi = t; }
+        pair_tab[r][k][0] = (unsigned char)pi; pair_tab[r][k][1] = (unsigned char)qi;
+    }
+    __syncthreads();
+    const int k2 = tid % half;            // column pair owned by this thread
+    const int g0 = tid / half;            // first row-pair / row group
+    const int ngrp = 256 / half;          // thread groups along the other dimension
     for (int sweep = 0; sweep < p.max_sweeps; ++sweep) {
-        if (tid == 0) rot_flag = 0;
+        if (tid == 0) { rot_flag = 0; round_rot[0] = 0; }
         __syncthreads();
         for (int r = 0; r < mm1; ++r) {
+            if (tid == 0) round_rot[(r + 1) & 1] = 0;      // slot of the NEXT round (nobody reads it before the next barrier pair)
             if (tid < half) {
-                int pi, qi;
-                if (tid == 0) { pi = mm1; qi = r % mm1; }
-                else { pi = (r + tid) % mm1; qi = (r - tid + mm1) % mm1; }
-                if (pi > qi) { const int t = pi; pi = qi; qi = t; }
+                const int pi = pair_tab[r][tid][0], qi = pair_tab[r][tid][1];
                 const double a = W[pi][pi], b = W[qi][qi], g = W[pi][qi];
                 double c = 1.0, s = 0.0;
                 if (g != 0.0 && fabs(g) > p.tol * fmax(sqrt(fabs(a * b)), p.tau2)) {
-                    const double zeta = (b - a) / (2.0 * g);
-                    const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-                    c = 1.0 / sqrt(1.0 + t * t);
+                    // tan of the rotation angle: t = 2g / (d + sign(d) hypot(d, 2g)), d = b - a.  Only c^2 + s^2 = 1 has to
+                    // hold to machine precision (orthogonality); the angle itself may carry the ~1e-8 error of the
+                    // hardware rsq/rcp seeds, so t uses the fast seeds and c = rsqrt(1 + t^2) gets two Newton steps.
+                    const double d = b - a, g2 = 2.0 * g;
+                    const double hh = d * d + g2 * g2;
+                    double rh = __builtin_amdgcn_rsq(hh);
+                    rh = rh * (1.5 - 0.5 * hh * rh * rh);
+                    const double h = hh * rh;                                  // hypot
+                    const double den = d + (d >= 0.0 ? h : -h);
+                    double rd = __builtin_amdgcn_rcp(den);
+                    rd = rd * (2.0 - den * rd);
+                    const double t = g2 * rd;
+                    const double x = 1.0 + t * t;
+                    double y = __builtin_amdgcn_rsq(x);
+                    y = y * (1.5 - 0.5 * x * y * y);
+                    y = y * (1.5 - 0.5 * x * y * y);
+                    c = y;
                     s = t * c;
                     rot_flag = 1;
+                    round_rot[r & 1] = 1;
                 }
                 cs_c[tid] = c; cs_s[tid] = s; pr_p[tid] = pi; pr_q[tid] = qi;
             }
             __syncthreads();
-            // column update of W and J:  [x_p x_q] <- [c x_p - s x_q,  s x_p + c x_q]
-            for (int q = tid; q < half * m; q += 256) {
-                const int k = q / m, i = q - k * m;
-                const double c = cs_c[k], s = cs_s[k];
-                if (s != 0.0) {
-                    const int pi = pr_p[k], qi = pr_q[k];
-                    const double wp = W[i][pi], wq = W[i][qi];
-                    W[i][pi] = c * wp - s * wq; W[i][qi] = s * wp + c * wq;
-                    const double jp = Jm[i][pi], jq = Jm[i][qi];
-                    Jm[i][pi] = c * jp - s * jq; Jm[i][qi] = s * jp + c * jq;
+            if (round_rot[r & 1]) {      // uniform: skip the whole update when no pair of this round rotates
+                const double c2 = cs_c[k2], s2 = cs_s[k2];
+                const int p2 = pr_p[k2], q2 = pr_q[k2];
+                // stage 1: all LDS loads (2x2 blocks (k1,k2) and the eigenvector columns of pair k2)
+                double b00[4], b01[4], b10[4], b11[4], c1[4], s1[4], jp[8], jq[8];
+                int p1[4], q1[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int k1 = g0 + u * ngrp;
+                    if (k1 < half) {
+                        c1[u] = cs_c[k1]; s1[u] = cs_s[k1]; p1[u] = pr_p[k1]; q1[u] = pr_q[k1];
+                        b00[u] = W[p1[u]][p2]; b01[u] = W[p1[u]][q2]; b10[u] = W[q1[u]][p2]; b11[u] = W[q1[u]][q2];
+                    }
                 }
-            }
-            __syncthreads();
-            // row update of W
-            for (int q = tid; q < half * m; q += 256) {
-                const int k = q / m, j = q - k * m;
-                const double c = cs_c[k], s = cs_s[k];
-                if (s != 0.0) {
-                    const int pi = pr_p[k], qi = pr_q[k];
-                    const double wp = W[pi][j], wq = W[qi][j];
-                    W[pi][j] = c * wp - s * wq; W[qi][j] = s * wp + c * wq;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int i = g0 + u * ngrp;
+                    if (i < m) { jp[u] = Jm[i][p2]; jq[u] = Jm[i][q2]; }
+                }
+                // stage 2: B <- R1^T B R2 ; J columns <- J R2 ; stage 3: stores (each element is owned by one thread)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int k1 = g0 + u * ngrp;
+                    if (k1 < half) {
+                        const double t00 = c2 * b00[u] - s2 * b01[u], t01 = s2 * b00[u] + c2 * b01[u];
+                        const double t10 = c2 * b10[u] - s2 * b11[u], t11 = s2 * b10[u] + c2 * b11[u];
+                        W[p1[u]][p2] = c1[u] * t00 - s1[u] * t10; W[p1[u]][q2] = c1[u] * t01 - s1[u] * t11;
+                        W[q1[u]][p2] = s1[u] * t00 + c1[u] * t10; W[q1[u]][q2] = s1[u] * t01 + c1[u] * t11;
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int i = g0 + u * ngrp;
+                    if (i < m) { Jm[i][p2] = c2 * jp[u] - s2 * jq[u]; Jm[i][q2] = s2 * jp[u] + c2 * jq[u]; }
                 }
             }
             __syncthreads();
@@ -173,23 +228,26 @@ __global__ __launch_bounds__(256) void small_eig_kernel(SmallEigParams p) {
     }
 }
 
-// build the per-round batched-GEMM offset tables on the host (uploaded once per problem size)
+// per-round batched-GEMM offset tables (built on the host once per (blocks, leading dim, block size))
 struct RRTables {
-    int nbk = 0, np = 0, b = 0;
+    int nbk = 0, b = 0, nsplit = 1, klen = 0; long long ld = 0;
     GemmOff* d_gram = nullptr;    // [rounds][pairs]
-    GemmOff* d_apply = nullptr;   // [rounds][2*pairs]   (W panels then Q panels)
+    GemmOff* d_apply = nullptr;   // [rounds][pairs]
 };
 
-std::map<long long, RRTables>& tables() { static std::map<long long, RRTables> t; return t; }
+std::map<std::string, RRTables>& tables() { static std::map<std::string, RRTables> t; return t; }
 
-int get_tables(ctm_ctx* ctx, int nbk, int np, int b, RRTables** out) {
-    const long long key = ((long long)nbk << 40) ^ ((long long)np << 8) ^ b ^ ((long long)ctx->device << 60);
+int get_tables(ctm_ctx* ctx, int nbk, long long ld, int b, int Cg, RRTables** out) {
+    const std::string key = std::to_string(ctx->device) + ":" + std::to_string(nbk) + ":" + std::to_string(ld) + ":" + std::to_string(b) + ":" + std::to_string(Cg);
     auto& T = tables();
     auto it = T.find(key);
     if (it != T.end()) { *out = &it->second; return CTM_OK; }
     const int rounds = nbk - 1, pairs = nbk / 2, m = 2 * b;
-    std::vector<GemmOff> gram((size_t)rounds * pairs), app((size_t)rounds * 2 * pairs);
-    const long long ld = np, qbase = (long long)np * np;
+    // split the long K (= Cg) of the pair Grams over enough workgroups to fill the chip (>= ~512 WGs per launch)
+    int nsplit = std::max(1, std::min(512 / std::max(pairs, 1), Cg / 256));
+    int klen = (((Cg + nsplit - 1) / nsplit) + 15) / 16 * 16;
+    nsplit = (Cg + klen - 1) / klen;
+    std::vector<GemmOff> gram((size_t)rounds * pairs * nsplit), app((size_t)rounds * pairs);
     for (int r = 0; r < rounds; ++r) {
         for (int k = 0; k < pairs; ++k) {
             int i, j;
@@ -197,15 +255,18 @@ int get_tables(ctm_ctx* ctx, int nbk, int np, int b, RRTables** out) {
             else { i = (r + k) % (nbk - 1); j = (r - k + (nbk - 1)) % (nbk - 1); }
             if (i > j) std::swap(i, j);
             const long long oi = (long long)i * b * ld, oj = (long long)j * b * ld;
-            GemmOff g; g.a0 = oi; g.a1 = oj; g.b0 = oi; g.b1 = oj; g.c0 = g.c1 = (long long)k * m * m;
-            gram[(size_t)r * pairs + k] = g;
-            GemmOff a; a.a0 = a.a1 = (long long)k * m * m; a.b0 = oi; a.b1 = oj; a.c0 = oi; a.c1 = oj;
-            app[(size_t)r * 2 * pairs + k] = a;
-            a.b0 += qbase; a.b1 += qbase; a.c0 += qbase; a.c1 += qbase;
-            app[(size_t)r * 2 * pairs + pairs + k] = a;
+            for (int s = 0; s < nsplit; ++s) {
+                const long long k0 = (long long)s * klen;
+                GemmOff g; g.a0 = oi + k0; g.a1 = oj + k0; g.b0 = oi + k0; g.b1 = oj + k0;
+                g.c0 = g.c1 = ((long long)s * pairs + k) * m * m;
+                g.klen = (int)std::min<long long>(klen, Cg - k0);
+                gram[((size_t)r * nsplit + s) * pairs + k] = g;
+            }
+            GemmOff a; a.a0 = a.a1 = (long long)k * m * m; a.b0 = oi; a.b1 = oj; a.c0 = oi; a.c1 = oj; a.klen = 0;
+            app[(size_t)r * pairs + k] = a;
         }
     }
-    RRTables t; t.nbk = nbk; t.np = np; t.b = b;
+    RRTables t; t.nbk = nbk; t.ld = ld; t.b = b; t.nsplit = nsplit; t.klen = klen;
     if (hipMalloc(&t.d_gram, gram.size() * sizeof(GemmOff)) != hipSuccess ||
         hipMalloc(&t.d_apply, app.size() * sizeof(GemmOff)) != hipSuccess) {
         ctx->set_error("jacobi: table alloc"); return CTM_ERR_NOMEM;
@@ -217,30 +278,32 @@ int get_tables(ctm_ctx* ctx, int nbk, int np, int b, RRTables** out) {
     return CTM_OK;
 }
 
-// Core: X holds [W (np x np); Q (np x np)] and is transformed IN PLACE (each workgroup of the apply GEMM
-// owns a column strip of all 2b rows of its pair and finishes reading it before it writes).
-// ktop > 0: only the ktop largest rows need full relative accuracy -- pairs of smaller rows are measured
-// against tau = (ktop-th largest row norm), which still bounds the spectral norm of the tail by tau(1+n tol).
-int jacobi_core(ctm_ctx* ctx, double* X, int np, int b, bool with_q, int ktop, double fro) {
-    const int nbk = np / b, rounds = nbk - 1, pairs = nbk / 2, m = 2 * b;
+// Core: orthogonalise the rows of the R x Cg matrix held in the first Cg columns of X (R x ld, row-major),
+// applying the same row rotations to ALL Ctot columns (the extra columns carry the accumulated left factor
+// or any companion basis).  In place: each workgroup of the apply GEMM owns a column strip of all 2b rows of
+// its pair and finishes reading it before it writes.
+// ktop > 0: only the ktop largest rows need full relative accuracy -- pairs of smaller rows are measured against
+// tau = (ktop-th largest row norm), which still bounds the spectral norm of the remaining rows by tau(1 + R tol).
+int jacobi_rows(ctm_ctx* ctx, double* X, int R, long long ld, int Cg, int Ctot, int b, int ktop, double fro, int max_sweeps) {
+    const int nbk = R / b, rounds = nbk - 1, pairs = nbk / 2, m = 2 * b;
     RRTables* T;
-    CTM_TRY(get_tables(ctx, nbk, np, b, &T));
+    CTM_TRY(get_tables(ctx, nbk, ld, b, Cg, &T));
     ArenaScope scope(ctx);
     double *G, *J, *norms;
     int* flags;
-    CTM_TRY(arena_alloc(ctx, sizeof(double) * pairs * m * m, (void**)&G));
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)T->nsplit * pairs * m * m, (void**)&G));
     CTM_TRY(arena_alloc(ctx, sizeof(double) * pairs * m * m, (void**)&J));
-    CTM_TRY(arena_alloc(ctx, sizeof(double) * np, (void**)&norms));
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * R, (void**)&norms));
     CTM_TRY(arena_alloc(ctx, sizeof(int) * pairs, (void**)&flags));
     unsigned long long* stat = (unsigned long long*)ctx->d_scratch;   // [0]=scaled, [1]=classical
-    std::vector<double> h(np);
+    std::vector<double> h(R);
     const double floor2 = (1e-14 * fro) * (1e-14 * fro);
     ctx->last_sweeps = 0;
-    for (int sweep = 0; sweep < ctx->jacobi_max_sweeps; ++sweep) {
+    for (int sweep = 0; sweep < max_sweeps; ++sweep) {
         double tau2 = floor2;
-        if (ktop > 0 && ktop < np) {
-            CTM_TRY(row_norms(ctx, X, np, np, np, norms));
-            CTM_HIP_CHECK(ctx, hipMemcpyAsync(h.data(), norms, sizeof(double) * np, hipMemcpyDeviceToHost, ctx->stream));
+        if (ktop > 0 && ktop < R) {
+            CTM_TRY(row_norms(ctx, X, R, Cg, ld, norms));
+            CTM_HIP_CHECK(ctx, hipMemcpyAsync(h.data(), norms, sizeof(double) * R, hipMemcpyDeviceToHost, ctx->stream));
             CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
             std::nth_element(h.begin(), h.begin() + (ktop - 1), h.end(), std::greater<double>());
             tau2 = std::max(floor2, h[ktop - 1] * h[ktop - 1]);
@@ -248,31 +311,30 @@ int jacobi_core(ctm_ctx* ctx, double* X, int np, int b, bool with_q, int ktop, d
         CTM_HIP_CHECK(ctx, hipMemsetAsync(stat, 0, 2 * sizeof(double), ctx->stream));
         for (int r = 0; r < rounds; ++r) {
             GemmDesc g;
-            g.M = m; g.N = m; g.K = np;
-            g.A = X; g.sam = np; g.sak = 1; g.splitA = b;
-            g.B = X; g.sbk = 1; g.sbn = np; g.splitB = b; g.splitB_dim = 2;
+            g.M = m; g.N = m; g.K = Cg;
+            g.A = X; g.sam = ld; g.sak = 1; g.splitA = b;
+            g.B = X; g.sbk = 1; g.sbn = ld; g.splitB = b; g.splitB_dim = 2;
             g.C = G; g.ldc = m;
-            g.batch = pairs; g.offs = T->d_gram + (size_t)r * pairs;
+            g.batch = pairs * T->nsplit; g.offs = T->d_gram + (size_t)r * pairs * T->nsplit;
             CTM_TRY(gemm_f64(ctx, g));
             SmallEigParams sp;
-            sp.G = G; sp.J = J; sp.m = m; sp.tol = ctx->jacobi_tol * 0.1; sp.max_sweeps = ctx->jacobi_inner_sweeps;
+            sp.G = G; sp.nsplit = T->nsplit; sp.split_stride = (long long)pairs * m * m; sp.J = J; sp.m = m; sp.tol = ctx->jacobi_tol * 0.1; sp.max_sweeps = ctx->jacobi_inner_sweeps;
             sp.tau2 = tau2; sp.stat_rel = stat; sp.stat_abs = stat + 1; sp.flags = flags;
             hipLaunchKernelGGL(small_eig_kernel, dim3(pairs), dim3(256), 0, ctx->stream, sp);
             GemmDesc a;
-            a.M = m; a.N = np; a.K = m;
+            a.M = m; a.N = Ctot; a.K = m;
             a.A = J; a.sam = 1; a.sak = m;                       // J^T
-            a.B = X; a.sbk = np; a.sbn = 1; a.splitB = b; a.splitB_dim = 1;
-            a.C = X; a.ldc = np; a.splitC = b;
-            a.batch = pairs; a.offs = T->d_apply + (size_t)r * 2 * pairs; a.skip_flags = flags;
+            a.B = X; a.sbk = ld; a.sbn = 1; a.splitB = b; a.splitB_dim = 1;
+            a.C = X; a.ldc = ld; a.splitC = b;
+            a.batch = pairs; a.offs = T->d_apply + (size_t)r * pairs; a.skip_flags = flags;
             CTM_TRY(gemm_f64(ctx, a));
-            if (with_q) { a.offs = T->d_apply + (size_t)r * 2 * pairs + pairs; CTM_TRY(gemm_f64(ctx, a)); }
         }
         CTM_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_scratch, stat, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
         const double srel = ctx->h_scratch[0];
         ctx->last_sweeps = sweep + 1;
         ctx->last_offnorm = srel;
-        if (ctx->jacobi_verbose) fprintf(stderr, "[jacobi] np=%d sweep %d  scaled=%.3e classical=%.3e tau=%.3e\n", np, sweep + 1, srel, ctx->h_scratch[1], std::sqrt(tau2));
+        if (ctx->jacobi_verbose > 1) fprintf(stderr, "[jacobi] R=%d sweep %d  scaled=%.3e classical=%.3e tau=%.3e\n", R, sweep + 1, srel, ctx->h_scratch[1], std::sqrt(tau2));
         if (srel <= ctx->jacobi_tol) break;
     }
     ctx->total_sweeps += ctx->last_sweeps; ctx->jacobi_calls += 1;
@@ -293,22 +355,55 @@ inline int padded(int n, int b) {
     return nbk * b;
 }
 
-__global__ void pad_copy_kernel(const double* src, int n, double* dst, int np) {
-    const size_t tot = (size_t)np * np;
+// dst (R x ld) <- [ src (rows x cols, lds) zero padded to R rows | identity (R x R) if with_eye ] ; other columns untouched
+__global__ void fill_wq_kernel(const double* src, int rows, int cols, long long lds, double* dst, int R, long long ld, int with_eye) {
+    const long long W = cols + (with_eye ? R : 0);
+    const size_t tot = (size_t)R * W;
     for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < tot; q += (size_t)gridDim.x * blockDim.x) {
-        const size_t r = q / np, c = q - r * np;
-        dst[q] = (r < (size_t)n && c < (size_t)n) ? src[r * n + c] : 0.0;
+        const long long r = q / W, c = q - r * W;
+        double v;
+        if (c < cols) v = (r < rows) ? src[r * lds + c] : 0.0;
+        else v = ((c - cols) == r) ? 1.0 : 0.0;
+        dst[r * ld + c] = v;
     }
 }
 
-__global__ void scale_rows_kernel(double* x, int rows, int cols, const double* rs) {
+__global__ void scale_rows_kernel(double* x, int rows, int cols, long long ld, const double* rs) {
     const size_t tot = (size_t)rows * cols;
-    for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < tot; q += (size_t)gridDim.x * blockDim.x) x[q] *= rs[q / cols];
+    for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < tot; q += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = q / cols, c = q - r * cols;
+        x[r * ld + c] *= rs[r];
+    }
 }
 
 __global__ void inv_or_zero_kernel(const double* s, double* out, int k) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < k) out[i] = s[i] > 0.0 ? 1.0 / s[i] : 0.0;
+}
+
+// deterministic pseudo-random fill in (-0.5, 0.5) (splitmix64 hash of the element index)
+__global__ void hash_fill_kernel(double* x, int rows, int cols, long long ld, unsigned long long seed) {
+    const size_t tot = (size_t)rows * cols;
+    for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < tot; q += (size_t)gridDim.x * blockDim.x) {
+        unsigned long long z = (q + 1) * 0x9E3779B97F4A7C15ULL + seed;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL; z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL; z ^= (z >> 31);
+        const size_t r = q / cols, c = q - r * cols;
+        x[r * ld + c] = (double)(z >> 11) * (1.0 / 9007199254740992.0) - 0.5;
+    }
+}
+
+// out[r] = | a[r,:] - s[r] * b[r,:] |
+__global__ void resid_rows_kernel(const double* a, long long lda, const double* b, long long ldb, const double* s, int rows, int cols,
+                                  double* out) {
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    const int nw = (gridDim.x * blockDim.x) >> 6;
+    for (int r = wave; r < rows; r += nw) {
+        double acc = 0.0;
+        const double sr = s[r];
+        for (int c = lane; c < cols; c += 64) { const double d = a[(long long)r * lda + c] - sr * b[(long long)r * ldb + c]; acc += d * d; }
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+        if (lane == 0) out[r] = sqrt(acc);
+    }
 }
 
 // re-orthonormalise the rows of V (k x n) against the rows above them: V <- (I - tril(E) - diag(E)/2) V, E = V V^T - I
@@ -330,29 +425,37 @@ int reorth_rows(ctm_ctx* ctx, double* V, int k, int n, long long ld, int iters) 
     return CTM_OK;
 }
 
-}  // namespace
+double host_fro(ctm_ctx* ctx, const double* M, int rows, int cols, long long ld, double* d_tmp, std::vector<double>& h, int* status) {
+    *status = row_norms(ctx, M, rows, cols, ld, d_tmp);
+    if (*status != CTM_OK) return 0.0;
+    h.resize(rows);
+    if (hipMemcpyAsync(h.data(), d_tmp, sizeof(double) * rows, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+        hipStreamSynchronize(ctx->stream) != hipSuccess) { *status = CTM_ERR_HIP; return 0.0; }
+    double f = 0.0;
+    for (int i = 0; i < rows; ++i) f += h[i] * h[i];
+    return std::sqrt(f);
+}
 
-int jacobi_svd_top(ctm_ctx* ctx, const double* M, int n, int k, double* S, double* Ut, double* Vt) {
-    if (n <= 0 || k <= 0 || k > n) { ctx->set_error("jacobi_svd_top: bad n/k"); return CTM_ERR_BADARG; }
+// ---------------------------------------------------------------------------------------------
+// full decomposition: every row pair is orthogonalised (O(n^3) per sweep)
+// ---------------------------------------------------------------------------------------------
+int svd_full(ctm_ctx* ctx, const double* M, int n, int k, double* S, double* Ut, double* Vt) {
     const int b = choose_block(ctx, n), np = padded(n, b);
     ArenaScope scope(ctx);
+    const bool with_q = (Ut != nullptr);
+    const long long ld = (long long)n + (with_q ? np : 0);
     double *X, *norms;
     int* d_idx;
-    CTM_TRY(arena_alloc(ctx, sizeof(double) * 2 * (size_t)np * np, (void**)&X));
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)np * ld, (void**)&X));
     CTM_TRY(arena_alloc(ctx, sizeof(double) * np, (void**)&norms));
     CTM_TRY(arena_alloc(ctx, sizeof(int) * np, (void**)&d_idx));
-    hipLaunchKernelGGL(pad_copy_kernel, dim3(2048), dim3(256), 0, ctx->stream, M, n, X, np);
-    const bool with_q = (Ut != nullptr);
-    if (with_q) CTM_TRY(set_identity(ctx, X + (size_t)np * np, np, np));
-    std::vector<double> h(np);
-    CTM_TRY(row_norms(ctx, X, np, np, np, norms));
-    CTM_HIP_CHECK(ctx, hipMemcpyAsync(h.data(), norms, sizeof(double) * np, hipMemcpyDeviceToHost, ctx->stream));
-    CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-    double fro = 0.0;
-    for (int i = 0; i < np; ++i) fro += h[i] * h[i];
-    fro = std::sqrt(fro);
-    CTM_TRY(jacobi_core(ctx, X, np, b, with_q, (k < n) ? k : 0, fro));
-    CTM_TRY(row_norms(ctx, X, np, np, np, norms));
+    hipLaunchKernelGGL(fill_wq_kernel, dim3(2048), dim3(256), 0, ctx->stream, M, n, n, (long long)n, X, np, ld, with_q ? 1 : 0);
+    std::vector<double> h;
+    int st;
+    const double fro = host_fro(ctx, X, np, n, ld, norms, h, &st);
+    CTM_TRY(st);
+    CTM_TRY(jacobi_rows(ctx, X, np, ld, n, (int)ld, b, (k < n) ? k : 0, fro, ctx->jacobi_max_sweeps));
+    CTM_TRY(row_norms(ctx, X, np, n, ld, norms));
     CTM_HIP_CHECK(ctx, hipMemcpyAsync(h.data(), norms, sizeof(double) * np, hipMemcpyDeviceToHost, ctx->stream));
     CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     std::vector<int> idx(np);
@@ -363,12 +466,10 @@ int jacobi_svd_top(ctm_ctx* ctx, const double* M, int n, int k, double* S, doubl
     CTM_HIP_CHECK(ctx, hipMemcpyAsync(d_idx, idx.data(), sizeof(int) * k, hipMemcpyHostToDevice, ctx->stream));
     CTM_HIP_CHECK(ctx, hipMemcpyAsync(S, hs.data(), sizeof(double) * k, hipMemcpyHostToDevice, ctx->stream));
     CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));   // host vectors go out of scope
-    if (!Ut) {   // singular values only: row norms of the converged W
-        return CTM_OK;
-    }
+    if (!Ut) return CTM_OK;   // singular values only: row norms of the converged W
     // U = accumulated rotations (orthonormalised against drift); then Sigma V^T = U^T M is recomputed by one
     // k x n x n GEMM so that S and V carry no accumulated rounding of the sweeps (|error| = O(eps |M|)).
-    CTM_TRY(gather_rows(ctx, X + (size_t)np * np, np, d_idx, k, n, Ut, n, nullptr));
+    CTM_TRY(gather_rows(ctx, X + n, ld, d_idx, k, n, Ut, n, nullptr));
     CTM_TRY(reorth_rows(ctx, Ut, k, n, n, 2));
     if (Vt) {
         double* inv;
@@ -377,65 +478,208 @@ int jacobi_svd_top(ctm_ctx* ctx, const double* M, int n, int k, double* S, doubl
         CTM_TRY(gemm_f64(ctx, g));
         CTM_TRY(row_norms(ctx, Vt, k, n, n, S));
         hipLaunchKernelGGL(inv_or_zero_kernel, dim3((k + 255) / 256), dim3(256), 0, ctx->stream, S, inv, k);
-        hipLaunchKernelGGL(scale_rows_kernel, dim3(1024), dim3(256), 0, ctx->stream, Vt, k, n, inv);
+        hipLaunchKernelGGL(scale_rows_kernel, dim3(1024), dim3(256), 0, ctx->stream, Vt, k, n, (long long)n, inv);
         CTM_TRY(reorth_rows(ctx, Vt, k, n, n, 2));
     }
     return CTM_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// leading-k decomposition by alternating block power iteration with Jacobi Rayleigh-Ritz:
+//   U M = C  ->  rows of C orthogonalised (same rotations applied to U)  ->  V = rows/|rows|, s = |rows|
+//   V M^T = C' ->  ...                                                    ->  U = rows/|rows|
+// Each half step is ONE big GEMM (p x n x n, FP64 MFMA) plus a row-Jacobi on p = k + oversampling rows (a few
+// rounds, rows already nearly orthogonal after the first steps).  One relation (e.g. U M = S V^T) holds exactly by
+// construction; the iteration stops when the other one's residual |V_i M^T - s_i U_i| <= tol * s_0 for all i < k.
+// If that does not happen within max_iter half steps the caller falls back to svd_full (same answer, O(n^3)).
+// `sym`: M is symmetric (eigenproblem) -- identical iteration, M^T = M.
+// ---------------------------------------------------------------------------------------------
+int svd_iter(ctm_ctx* ctx, const double* M, int n, int k, double* S, double* Ut, double* Vt, bool* converged) {
+    *converged = false;
+    const int b = 32;
+    int p = k + std::max(32, k / 2);
+    p = ((p + 2 * b - 1) / (2 * b)) * (2 * b);                 // even number of blocks
+    if (p >= n / 2) return CTM_OK;                              // not worth it: caller uses the full path
+    ArenaScope scope(ctx);
+    const long long ld = 2LL * n;
+    double *XA, *XB, *norms, *inv, *res, *sprev;
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)p * ld, (void**)&XA));     // [C | companion]
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)p * ld, (void**)&XB));
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * p, (void**)&norms));
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * p, (void**)&inv));
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * p, (void**)&res));
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * p, (void**)&sprev));
+    std::vector<double> h(p), hr(p);
+    // start: companion of XB = pseudo-random basis (need not be orthonormal)
+    hipLaunchKernelGGL(hash_fill_kernel, dim3(1024), dim3(256), 0, ctx->stream, XB, p, n, ld, 0x1234567ULL);
+    double* cur = XB;          // rows [0,n) of `cur` hold the current basis B (p x n)
+    double* nxt = XA;
+    bool have_prev = false;
+    int side = 0;              // 0: C = B M^T (B = right basis V, produces U) ; 1: C = B M (B = U, produces V)
+    double s0 = 0.0, last_res = 1e300, last_orth = 1e300;
+    const int max_half = 2 * ctx->si_max_iter;
+    int it = 0;
+    for (; it < max_half; ++it) {
+        // C = B op(M) -> nxt[:, 0:n] ; companion nxt[:, n:2n] = B
+        GemmDesc g; g.M = p; g.N = n; g.K = n; g.A = cur; g.sam = ld; g.sak = 1; g.B = M;
+        if (side == 0) { g.sbk = 1; g.sbn = n; } else { g.sbk = n; g.sbn = 1; }
+        g.C = nxt; g.ldc = ld;
+        CTM_TRY(gemm_f64(ctx, g));
+        CTM_TRY(copy2d(ctx, cur, ld, nxt + n, ld, p, n));
+        if (have_prev) {
+            // residual of the relation that is NOT exact by construction: |C_i - s_i A_i| with A = previous normalised rows,
+            // which sit in cur[:, n:2n] (companion of the previous half step, rotated along)
+            hipLaunchKernelGGL(resid_rows_kernel, dim3((p + 3) / 4), dim3(256), 0, ctx->stream, nxt, ld, cur + n, ld, sprev, p, n, res);
+            CTM_HIP_CHECK(ctx, hipMemcpyAsync(hr.data(), res, sizeof(double) * p, hipMemcpyDeviceToHost, ctx->stream));
+            CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+            // rows are kept (nearly) sorted by the pairwise ordering; take the k largest s
+            std::vector<int> idx(p); std::iota(idx.begin(), idx.end(), 0);
+            std::stable_sort(idx.begin(), idx.end(), [&](int a, int c) { return h[a] > h[c]; });
+            double worst = 0.0;
+            for (int i = 0; i < k; ++i) worst = std::max(worst, hr[idx[i]]);
+            if (ctx->jacobi_verbose) fprintf(stderr, "[si] n=%d p=%d half-step %d  max resid/s0 = %.3e  last_orth = %.2e\n", n, p, it, worst / std::max(s0, 1e-300), last_orth);
+            if (worst <= ctx->si_tol * s0) { *converged = true; break; }
+            last_res = worst;
+        }
+        // Rayleigh-Ritz: orthogonalise the rows of C, rotating the companion basis along
+        int st;
+        const double fro = host_fro(ctx, nxt, p, n, ld, norms, h, &st);
+        CTM_TRY(st);
+        // the very first Rayleigh-Ritz only has to orthonormalise a power step: cap its sweeps
+        // Rayleigh-Ritz to convergence (the bases must be orthonormal for the residual test to certify the triplets);
+        // the very first one only orthonormalises a power step of the random start, so it is capped
+        CTM_TRY(jacobi_rows(ctx, nxt, p, ld, n, (int)ld, b, k, fro, have_prev ? ctx->si_rr_sweeps : std::min(3, ctx->si_rr_sweeps)));
+        last_orth = ctx->last_offnorm;     // off-diagonal measure of the Gram that entered the LAST sweep
+        CTM_TRY(row_norms(ctx, nxt, p, n, ld, norms));
+        CTM_HIP_CHECK(ctx, hipMemcpyAsync(h.data(), norms, sizeof(double) * p, hipMemcpyDeviceToHost, ctx->stream));
+        CTM_HIP_CHECK(ctx, hipMemcpyAsync(sprev, norms, sizeof(double) * p, hipMemcpyDeviceToDevice, ctx->stream));
+        CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        s0 = *std::max_element(h.begin(), h.end());
+        hipLaunchKernelGGL(inv_or_zero_kernel, dim3((p + 255) / 256), dim3(256), 0, ctx->stream, norms, inv, p);
+        hipLaunchKernelGGL(scale_rows_kernel, dim3(1024), dim3(256), 0, ctx->stream, nxt, p, n, ld, inv);
+        // now: nxt[:, 0:n] = new orthonormal basis A (left if side==0), nxt[:, n:2n] = rotated B, s = h
+        have_prev = true;
+        std::swap(cur, nxt);
+        side ^= 1;
+    }
+    ctx->si_last_iters = it; ctx->si_total_iters += it;
+    if (!*converged) return CTM_OK;
+    // At the break: `nxt` holds C = B op(M) (un-orthogonalised, already within tol of s_i A_i), `cur` holds
+    // [B | A-rotated]: B = cur[:, 0:n] (normalised rows from the last RR), A = cur[:, n:2n], s = h (host) / sprev (device).
+    // side tells what B is: side==1 -> B = U (C = U M), A = V ; side==0 -> B = V, A = U.
+    std::vector<int> idx(p); std::iota(idx.begin(), idx.end(), 0);
+    std::stable_sort(idx.begin(), idx.end(), [&](int a, int c) { return h[a] > h[c]; });
+    std::vector<double> hs(k);
+    for (int i = 0; i < k; ++i) hs[i] = h[idx[i]];
+    int* d_idx;
+    CTM_TRY(arena_alloc(ctx, sizeof(int) * k, (void**)&d_idx));
+    CTM_HIP_CHECK(ctx, hipMemcpyAsync(d_idx, idx.data(), sizeof(int) * k, hipMemcpyHostToDevice, ctx->stream));
+    CTM_HIP_CHECK(ctx, hipMemcpyAsync(S, hs.data(), sizeof(double) * k, hipMemcpyHostToDevice, ctx->stream));
+    CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    const double* Bp = cur; const double* Ap = cur + n;
+    CTM_TRY(gather_rows(ctx, side == 1 ? Bp : Ap, ld, d_idx, k, n, Ut, n, nullptr));
+    CTM_TRY(gather_rows(ctx, side == 1 ? Ap : Bp, ld, d_idx, k, n, Vt, n, nullptr));
+    CTM_TRY(reorth_rows(ctx, Ut, k, n, n, 1));
+    CTM_TRY(reorth_rows(ctx, Vt, k, n, n, 1));
+    return CTM_OK;
+}
+
+}  // namespace
+
+int jacobi_svd_top(ctm_ctx* ctx, const double* M, int n, int k, double* S, double* Ut, double* Vt) {
+    if (n <= 0 || k <= 0 || k > n) { ctx->set_error("jacobi_svd_top: bad n/k"); return CTM_ERR_BADARG; }
+    if (Ut && Vt && ctx->si_enable && k < n && n >= ctx->si_min_n) {
+        bool ok = false;
+        CTM_TRY(svd_iter(ctx, M, n, k, S, Ut, Vt, &ok));
+        if (ok) { ctx->si_hits += 1; return CTM_OK; }
+        ctx->si_fallbacks += 1;
+    }
+    return svd_full(ctx, M, n, k, S, Ut, Vt);
+}
+
 int jacobi_svdvals(ctm_ctx* ctx, const double* M, int n, double* S) {
-    return jacobi_svd_top(ctx, M, n, n, S, nullptr, nullptr);
+    return svd_full(ctx, M, n, n, S, nullptr, nullptr);
 }
 
 int jacobi_eigh_top(ctm_ctx* ctx, const double* A, int n, int k, double* D, double* Ut) {
     if (n <= 0 || k <= 0 || k > n) { ctx->set_error("jacobi_eigh_top: bad n/k"); return CTM_ERR_BADARG; }
-    const int b = choose_block(ctx, n), np = padded(n, b);
     ArenaScope scope(ctx);
-    double *X, *norms, *As;
-    int* d_idx;
-    CTM_TRY(arena_alloc(ctx, sizeof(double) * 2 * (size_t)np * np, (void**)&X));
+    double* As;
     CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)n * n, (void**)&As));
+    CTM_TRY(symmetrize_lower(ctx, A, As, n, 0.0));
+    // (1) large problems with k << n: leading |lambda| invariant subspace by the SVD iteration on the symmetric matrix,
+    //     then a small symmetric Rayleigh-Ritz on it.
+    if (ctx->si_enable && k < n && n >= ctx->si_min_n) {
+        // a few extra vectors so that a cluster of equal |lambda| with both signs is never cut inside the RR space
+        const int kk = std::min(n, k + 8), k_out = k;
+        double *S, *Uk, *Vk;
+        CTM_TRY(arena_alloc(ctx, sizeof(double) * kk, (void**)&S));
+        CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)kk * n, (void**)&Uk));
+        CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)kk * n, (void**)&Vk));
+        bool ok = false;
+        CTM_TRY(svd_iter(ctx, As, n, kk, S, Uk, Vk, &ok));
+        if (ok) {
+            const int k = kk;
+            ctx->si_hits += 1;
+            // T = U A U^T (k x k, symmetric, diagonal except inside clusters of equal |lambda|)
+            double *Y, *T, *Dk, *Th;
+            CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)k * n, (void**)&Y));
+            CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)k * k, (void**)&T));
+            CTM_TRY(arena_alloc(ctx, sizeof(double) * k, (void**)&Dk));
+            CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)k * k, (void**)&Th));
+            GemmDesc g; g.M = k; g.N = n; g.K = n; g.A = Uk; g.sam = n; g.sak = 1; g.B = As; g.sbk = n; g.sbn = 1; g.C = Y; g.ldc = n;
+            CTM_TRY(gemm_f64(ctx, g));
+            GemmDesc t; t.M = k; t.N = k; t.K = n; t.A = Y; t.sam = n; t.sak = 1; t.B = Uk; t.sbk = 1; t.sbn = n; t.C = T; t.ldc = k;
+            CTM_TRY(gemm_f64(ctx, t));
+            const bool save = ctx->si_enable; ctx->si_enable = false;
+            const int st = jacobi_eigh_top(ctx, T, k, k, Dk, Th);      // full small problem (rows of Th = eigenvectors)
+            ctx->si_enable = save;
+            CTM_TRY(st);
+            // eigen-pairs of T come ordered by |lambda|: keep the leading k_out
+            GemmDesc r; r.M = k_out; r.N = n; r.K = k; r.A = Th; r.sam = k; r.sak = 1; r.B = Uk; r.sbk = n; r.sbn = 1; r.C = Ut; r.ldc = n;
+            CTM_TRY(gemm_f64(ctx, r));
+            CTM_HIP_CHECK(ctx, hipMemcpyAsync(D, Dk, sizeof(double) * k_out, hipMemcpyDeviceToDevice, ctx->stream));
+            return CTM_OK;
+        }
+        ctx->si_fallbacks += 1;
+    }
+    // (2) full path: one-sided Jacobi on A + shift*I (positive definite)
+    const int b = choose_block(ctx, n), np = padded(n, b);
+    const long long ld = (long long)n + np;
+    double *X, *norms;
+    int* d_idx;
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)np * ld, (void**)&X));
     CTM_TRY(arena_alloc(ctx, sizeof(double) * np, (void**)&norms));
     CTM_TRY(arena_alloc(ctx, sizeof(int) * np, (void**)&d_idx));
-    // shift = Frobenius norm of sym(lower(A)) >= spectral norm
-    CTM_TRY(symmetrize_lower(ctx, A, As, n, 0.0));
-    CTM_TRY(row_norms(ctx, As, n, n, n, norms));
-    std::vector<double> h(np);
-    CTM_HIP_CHECK(ctx, hipMemcpyAsync(h.data(), norms, sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream));
-    CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-    double fro = 0.0;
-    for (int i = 0; i < n; ++i) fro += h[i] * h[i];
-    fro = std::sqrt(fro);
+    std::vector<double> h;
+    int st;
+    const double fro = host_fro(ctx, As, n, n, n, norms, h, &st);     // >= spectral norm
+    CTM_TRY(st);
     const double shift = fro * 1.0009765625 + 1e-300;
     CTM_TRY(symmetrize_lower(ctx, A, As, n, shift));
-    hipLaunchKernelGGL(pad_copy_kernel, dim3(2048), dim3(256), 0, ctx->stream, As, n, X, np);
-    CTM_TRY(set_identity(ctx, X + (size_t)np * np, np, np));
-    CTM_TRY(jacobi_core(ctx, X, np, b, true, 0, shift * std::sqrt((double)n)));
-    CTM_TRY(row_norms(ctx, X, np, np, np, norms));
+    hipLaunchKernelGGL(fill_wq_kernel, dim3(2048), dim3(256), 0, ctx->stream, As, n, n, (long long)n, X, np, ld, 1);
+    CTM_TRY(jacobi_rows(ctx, X, np, ld, n, (int)ld, b, 0, shift * std::sqrt((double)n), ctx->jacobi_max_sweeps));
+    CTM_TRY(row_norms(ctx, X, np, n, ld, norms));
+    h.resize(np);
     CTM_HIP_CHECK(ctx, hipMemcpyAsync(h.data(), norms, sizeof(double) * np, hipMemcpyDeviceToHost, ctx->stream));
     CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-    // the n genuine rows are those with norm >= shift - fro > 0; padded rows are exactly zero
+    // the n genuine rows have norm >= shift - fro > 0; padded rows are exactly zero
     std::vector<int> idx;
     for (int i = 0; i < np; ++i) if (h[i] > 0.0) idx.push_back(i);
     if ((int)idx.size() != n) { ctx->set_error("jacobi_eigh_top: rank bookkeeping failed"); return CTM_ERR_NOCONV; }
     std::vector<double> lam(np);
     for (int i : idx) lam[i] = h[i] - shift;
     std::stable_sort(idx.begin(), idx.end(), [&](int a, int c) { return std::fabs(lam[a]) > std::fabs(lam[c]); });
-    std::vector<double> hd(k);
-    for (int i = 0; i < k; ++i) hd[i] = lam[idx[i]];
     CTM_HIP_CHECK(ctx, hipMemcpyAsync(d_idx, idx.data(), sizeof(int) * k, hipMemcpyHostToDevice, ctx->stream));
-    CTM_HIP_CHECK(ctx, hipMemcpyAsync(D, hd.data(), sizeof(double) * k, hipMemcpyHostToDevice, ctx->stream));
     CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-    CTM_TRY(gather_rows(ctx, X + (size_t)np * np, np, d_idx, k, n, Ut, n, nullptr));
+    CTM_TRY(gather_rows(ctx, X + n, ld, d_idx, k, n, Ut, n, nullptr));
     CTM_TRY(reorth_rows(ctx, Ut, k, n, n, 2));
     // eigenvalues as Rayleigh quotients u^T A u (drift-free, |error| = O(eps |A|))
-    {
-        double* Y;
-        CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)k * n, (void**)&Y));
-        CTM_TRY(symmetrize_lower(ctx, A, As, n, 0.0));
-        GemmDesc g; g.M = k; g.N = n; g.K = n; g.A = Ut; g.sam = n; g.sak = 1; g.B = As; g.sbk = n; g.sbn = 1; g.C = Y; g.ldc = n;
-        CTM_TRY(gemm_f64(ctx, g));
-        CTM_TRY(row_dots(ctx, Y, Ut, k, n, n, D));
-    }
+    double* Y;
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)k * n, (void**)&Y));
+    CTM_TRY(symmetrize_lower(ctx, A, As, n, 0.0));
+    GemmDesc g; g.M = k; g.N = n; g.K = n; g.A = Ut; g.sam = n; g.sak = 1; g.B = As; g.sbk = n; g.sbn = 1; g.C = Y; g.ldc = n;
+    CTM_TRY(gemm_f64(ctx, g));
+    CTM_TRY(row_dots(ctx, Y, Ut, k, n, n, D));
     return CTM_OK;
 }

@@ -38,7 +38,7 @@ def _graded(n, rng, decay):
     return (Q1 * s) @ Q2.T, s
 
 
-@pytest.mark.parametrize("n,chi,decay", [(24, 8, 0.7), (64, 16, 0.3), (100, 20, 0.2), (288, 32, 0.05), (512, 64, 0.03)])
+@pytest.mark.parametrize("n,chi,decay", [(24, 8, 0.7), (64, 16, 0.3), (100, 20, 0.2), (288, 32, 0.05), (512, 64, 0.03), (1024, 64, 0.02), (1536, 96, 0.05)])
 def test_truncated_svd(eng, n, chi, decay):
     rng = np.random.default_rng(n)
     M, s = _graded(n, rng, decay)
@@ -76,7 +76,7 @@ def test_truncated_svd_golden(eng):
             assert np.abs(U[:, nzc] - g["svd_a_U"][:, nzc]).max() < 1e-9
 
 
-@pytest.mark.parametrize("n,chi", [(24, 6), (81, 20), (144, 16), (256, 64)])
+@pytest.mark.parametrize("n,chi", [(24, 6), (81, 20), (144, 16), (256, 64), (768, 48), (1024, 64)])
 def test_truncated_eigh(eng, n, chi):
     rng = np.random.default_rng(n + 1)
     Q, _ = np.linalg.qr(rng.standard_normal((n, n)))
