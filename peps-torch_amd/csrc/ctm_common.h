@@ -53,7 +53,7 @@ struct ctm_ctx {
     int jacobi_verbose = 0;
     // leading-k block power iteration (svd_iter): enabled for n >= si_min_n, residual tolerance relative to s_0
     bool si_enable = true;
-    int si_min_n = 512, si_max_iter = 40, si_last_iters = 0, si_rr_sweeps = 40;
+    int si_min_n = 512, si_max_iter = 40, si_last_iters = 0, si_rr_sweeps = 40, si_last_rank = 0;
     double si_tol = 2e-14;
     long si_hits = 0, si_fallbacks = 0, si_total_iters = 0;
     int last_sweeps = 0;

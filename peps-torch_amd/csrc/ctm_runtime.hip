@@ -113,6 +113,7 @@ int ctm_get_stat(ctm_ctx* ctx, const char* key, double* value) {
     else if (k == "si_fallbacks") *value = (double)ctx->si_fallbacks;
     else if (k == "si_last_iters") *value = (double)ctx->si_last_iters;
     else if (k == "si_total_iters") *value = (double)ctx->si_total_iters;
+    else if (k == "si_last_rank") *value = (double)ctx->si_last_rank;
     else if (k == "gemm_flops") *value = ctx->gemm_flops;
     else if (k == "gemm_calls") *value = (double)ctx->gemm_calls;
     else if (k == "arena_high") *value = (double)ctx->arena.high;

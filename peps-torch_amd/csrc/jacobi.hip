@@ -318,7 +318,7 @@ int jacobi_rows(ctm_ctx* ctx, double* X, int R, long long ld, int Cg, int Ctot, 
             g.batch = pairs * T->nsplit; g.offs = T->d_gram + (size_t)r * pairs * T->nsplit;
             CTM_TRY(gemm_f64(ctx, g));
             SmallEigParams sp;
-            sp.G = G; sp.nsplit = T->nsplit; sp.split_stride = (long long)pairs * m * m; sp.J = J; sp.m = m; sp.tol = ctx->jacobi_tol * 0.1; sp.max_sweeps = ctx->jacobi_inner_sweeps;
+            sp.G = G; sp.nsplit = T->nsplit; sp.split_stride = (long long)pairs * m * m; sp.J = J; sp.m = m; sp.tol = ctx->jacobi_tol * 0.1; sp.max_sweeps = (pairs == 1) ? 12 : ctx->jacobi_inner_sweeps;
             sp.tau2 = tau2; sp.stat_rel = stat; sp.stat_abs = stat + 1; sp.flags = flags;
             hipLaunchKernelGGL(small_eig_kernel, dim3(pairs), dim3(256), 0, ctx->stream, sp);
             GemmDesc a;
@@ -497,26 +497,32 @@ int svd_full(ctm_ctx* ctx, const double* M, int n, int k, double* S, double* Ut,
 int svd_iter(ctm_ctx* ctx, const double* M, int n, int k, double* S, double* Ut, double* Vt, bool* converged) {
     *converged = false;
     const int b = 32;
-    int p = k + std::max(32, k / 2);
-    p = ((p + 2 * b - 1) / (2 * b)) * (2 * b);                 // even number of blocks
-    if (p >= n / 2) return CTM_OK;                              // not worth it: caller uses the full path
+    int p_full = k + std::max(32, k / 2);
+    p_full = ((p_full + 2 * b - 1) / (2 * b)) * (2 * b);       // even number of blocks
+    if (p_full >= n / 2) return CTM_OK;                         // not worth it: caller uses the full path
+    // Rank-adaptive block: start with 64 vectors and double while the spectrum is not exhausted inside the block.
+    // Environments of weakly entangled / random states are numerically low rank (tens of singular values above
+    // eps * s_0 out of thousands): then the whole decomposition costs a few 64-row power steps.
+    int p = std::min(64, p_full);
     ArenaScope scope(ctx);
     const long long ld = 2LL * n;
     double *XA, *XB, *norms, *inv, *res, *sprev;
-    CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)p * ld, (void**)&XA));     // [C | companion]
-    CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)p * ld, (void**)&XB));
-    CTM_TRY(arena_alloc(ctx, sizeof(double) * p, (void**)&norms));
-    CTM_TRY(arena_alloc(ctx, sizeof(double) * p, (void**)&inv));
-    CTM_TRY(arena_alloc(ctx, sizeof(double) * p, (void**)&res));
-    CTM_TRY(arena_alloc(ctx, sizeof(double) * p, (void**)&sprev));
-    std::vector<double> h(p), hr(p);
-    // start: companion of XB = pseudo-random basis (need not be orthonormal)
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)p_full * ld, (void**)&XA));     // [C | companion]
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)p_full * ld, (void**)&XB));
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * p_full, (void**)&norms));
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * p_full, (void**)&inv));
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * p_full, (void**)&res));
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * p_full, (void**)&sprev));
+    std::vector<double> h(p_full, 0.0), hr(p_full, 0.0);
+    // start: pseudo-random basis (need not be orthonormal)
     hipLaunchKernelGGL(hash_fill_kernel, dim3(1024), dim3(256), 0, ctx->stream, XB, p, n, ld, 0x1234567ULL);
-    double* cur = XB;          // rows [0,n) of `cur` hold the current basis B (p x n)
+    double* cur = XB;          // columns [0,n) of `cur` hold the current basis B (p x n)
     double* nxt = XA;
     bool have_prev = false;
     int side = 0;              // 0: C = B M^T (B = right basis V, produces U) ; 1: C = B M (B = U, produces V)
-    double s0 = 0.0, last_res = 1e300, last_orth = 1e300;
+    double s0 = 0.0;
+    int rank = 0, kk = k;
+    const double rank_tol = 1e-14;
     const int max_half = 2 * ctx->si_max_iter;
     int it = 0;
     for (; it < max_half; ++it) {
@@ -532,29 +538,38 @@ int svd_iter(ctm_ctx* ctx, const double* M, int n, int k, double* S, double* Ut,
             hipLaunchKernelGGL(resid_rows_kernel, dim3((p + 3) / 4), dim3(256), 0, ctx->stream, nxt, ld, cur + n, ld, sprev, p, n, res);
             CTM_HIP_CHECK(ctx, hipMemcpyAsync(hr.data(), res, sizeof(double) * p, hipMemcpyDeviceToHost, ctx->stream));
             CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-            // rows are kept (nearly) sorted by the pairwise ordering; take the k largest s
             std::vector<int> idx(p); std::iota(idx.begin(), idx.end(), 0);
             std::stable_sort(idx.begin(), idx.end(), [&](int a, int c) { return h[a] > h[c]; });
+            rank = 0;
+            for (int i = 0; i < p; ++i) rank += (h[i] > rank_tol * s0);
+            const bool exhausted = rank <= p - 8;            // the block holds every singular value above eps * s_0
+            if (!exhausted && p < p_full) {
+                // grow the block: fresh pseudo-random rows appended to the current basis
+                const int pn = std::min(p_full, 2 * p);
+                hipLaunchKernelGGL(hash_fill_kernel, dim3(1024), dim3(256), 0, ctx->stream, cur + (size_t)p * ld, pn - p, n, ld,
+                                   0x9876543ULL + (unsigned long long)pn);
+                if (ctx->jacobi_verbose) fprintf(stderr, "[si] n=%d grow block %d -> %d (rank so far %d)\n", n, p, pn, rank);
+                p = pn; have_prev = false;
+                continue;
+            }
+            kk = exhausted ? std::min(k, rank) : k;
             double worst = 0.0;
-            for (int i = 0; i < k; ++i) worst = std::max(worst, hr[idx[i]]);
-            if (ctx->jacobi_verbose) fprintf(stderr, "[si] n=%d p=%d half-step %d  max resid/s0 = %.3e  last_orth = %.2e\n", n, p, it, worst / std::max(s0, 1e-300), last_orth);
+            for (int i = 0; i < kk; ++i) worst = std::max(worst, hr[idx[i]]);
+            if (ctx->jacobi_verbose) fprintf(stderr, "[si] n=%d p=%d half-step %d  rank=%d  max resid/s0 = %.3e\n", n, p, it, rank, worst / std::max(s0, 1e-300));
             if (worst <= ctx->si_tol * s0) { *converged = true; break; }
-            last_res = worst;
         }
-        // Rayleigh-Ritz: orthogonalise the rows of C, rotating the companion basis along
+        // Rayleigh-Ritz to convergence (the bases must be orthonormal for the residual test to certify the triplets);
+        // the very first one only orthonormalises a power step of the random start, so it is capped
         int st;
         const double fro = host_fro(ctx, nxt, p, n, ld, norms, h, &st);
         CTM_TRY(st);
-        // the very first Rayleigh-Ritz only has to orthonormalise a power step: cap its sweeps
-        // Rayleigh-Ritz to convergence (the bases must be orthonormal for the residual test to certify the triplets);
-        // the very first one only orthonormalises a power step of the random start, so it is capped
-        CTM_TRY(jacobi_rows(ctx, nxt, p, ld, n, (int)ld, b, k, fro, have_prev ? ctx->si_rr_sweeps : std::min(3, ctx->si_rr_sweeps)));
-        last_orth = ctx->last_offnorm;     // off-diagonal measure of the Gram that entered the LAST sweep
+        CTM_TRY(jacobi_rows(ctx, nxt, p, ld, n, (int)ld, b, std::min(k, p - 1), fro, have_prev ? ctx->si_rr_sweeps : std::min(3, ctx->si_rr_sweeps)));
         CTM_TRY(row_norms(ctx, nxt, p, n, ld, norms));
+        h.assign(p_full, 0.0);
         CTM_HIP_CHECK(ctx, hipMemcpyAsync(h.data(), norms, sizeof(double) * p, hipMemcpyDeviceToHost, ctx->stream));
         CTM_HIP_CHECK(ctx, hipMemcpyAsync(sprev, norms, sizeof(double) * p, hipMemcpyDeviceToDevice, ctx->stream));
         CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-        s0 = *std::max_element(h.begin(), h.end());
+        s0 = *std::max_element(h.begin(), h.begin() + p);
         hipLaunchKernelGGL(inv_or_zero_kernel, dim3((p + 255) / 256), dim3(256), 0, ctx->stream, norms, inv, p);
         hipLaunchKernelGGL(scale_rows_kernel, dim3(1024), dim3(256), 0, ctx->stream, nxt, p, n, ld, inv);
         // now: nxt[:, 0:n] = new orthonormal basis A (left if side==0), nxt[:, n:2n] = rotated B, s = h
@@ -564,23 +579,27 @@ int svd_iter(ctm_ctx* ctx, const double* M, int n, int k, double* S, double* Ut,
     }
     ctx->si_last_iters = it; ctx->si_total_iters += it;
     if (!*converged) return CTM_OK;
-    // At the break: `nxt` holds C = B op(M) (un-orthogonalised, already within tol of s_i A_i), `cur` holds
-    // [B | A-rotated]: B = cur[:, 0:n] (normalised rows from the last RR), A = cur[:, n:2n], s = h (host) / sprev (device).
-    // side tells what B is: side==1 -> B = U (C = U M), A = V ; side==0 -> B = V, A = U.
+    // At the break: `cur` holds [B | A-rotated]: B = cur[:, 0:n] (normalised rows from the last RR), A = cur[:, n:2n],
+    // s = h (host).  side==1 -> B = U, A = V ; side==0 -> B = V, A = U.  Triplets beyond the numerical rank (or beyond the
+    // block) are returned as exact zeros: they are below eps * s_0 and every consumer masks them.
     std::vector<int> idx(p); std::iota(idx.begin(), idx.end(), 0);
     std::stable_sort(idx.begin(), idx.end(), [&](int a, int c) { return h[a] > h[c]; });
-    std::vector<double> hs(k);
-    for (int i = 0; i < k; ++i) hs[i] = h[idx[i]];
+    const int kv = std::min(k, std::min(p, std::max(kk, 1)));           // verified triplets
+    std::vector<double> hs(k, 0.0);
+    for (int i = 0; i < kv; ++i) hs[i] = h[idx[i]];
     int* d_idx;
     CTM_TRY(arena_alloc(ctx, sizeof(int) * k, (void**)&d_idx));
-    CTM_HIP_CHECK(ctx, hipMemcpyAsync(d_idx, idx.data(), sizeof(int) * k, hipMemcpyHostToDevice, ctx->stream));
+    CTM_HIP_CHECK(ctx, hipMemcpyAsync(d_idx, idx.data(), sizeof(int) * kv, hipMemcpyHostToDevice, ctx->stream));
     CTM_HIP_CHECK(ctx, hipMemcpyAsync(S, hs.data(), sizeof(double) * k, hipMemcpyHostToDevice, ctx->stream));
     CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    CTM_TRY(fill_f64(ctx, Ut, (size_t)k * n, 0.0));
+    CTM_TRY(fill_f64(ctx, Vt, (size_t)k * n, 0.0));
     const double* Bp = cur; const double* Ap = cur + n;
-    CTM_TRY(gather_rows(ctx, side == 1 ? Bp : Ap, ld, d_idx, k, n, Ut, n, nullptr));
-    CTM_TRY(gather_rows(ctx, side == 1 ? Ap : Bp, ld, d_idx, k, n, Vt, n, nullptr));
-    CTM_TRY(reorth_rows(ctx, Ut, k, n, n, 1));
-    CTM_TRY(reorth_rows(ctx, Vt, k, n, n, 1));
+    CTM_TRY(gather_rows(ctx, side == 1 ? Bp : Ap, ld, d_idx, kv, n, Ut, n, nullptr));
+    CTM_TRY(gather_rows(ctx, side == 1 ? Ap : Bp, ld, d_idx, kv, n, Vt, n, nullptr));
+    CTM_TRY(reorth_rows(ctx, Ut, kv, n, n, 1));
+    CTM_TRY(reorth_rows(ctx, Vt, kv, n, n, 1));
+    ctx->si_last_rank = rank;
     return CTM_OK;
 }
 
