@@ -77,6 +77,11 @@ int ctm_halves(ctm_ctx* ctx, int dir, const double* const* tensors16, int chi, c
 /* ctm_get_projectors_from_matrices (ctm_projectors.py:142-293): P, Pt n x chi, S chi (may be NULL) */
 int ctm_projectors(ctm_ctx* ctx, const double* R, const double* Rt, int n, int chi, const ctm_trunc_cfg* cfg, double* P,
                    double* Pt, double* S);
+/* ctm_get_projectors_4x4 (ctm_projectors.py:14-64) as ONE call: the four enlarged corners of the move are built and
+ * M = R^T Rt is applied implicitly (R, Rt, M are only materialised if the leading-chi iteration falls back to the full
+ * decomposition).  tensors16 / adims4x5 as for ctm_halves. */
+int ctm_projectors_4x4(ctm_ctx* ctx, int dir, const double* const* tensors16, int chi, const int* adims4x5,
+                       const ctm_trunc_cfg* cfg, double* P, double* Pt, double* S);
 /* absorb_truncate_CTM_MOVE_<DIR>_c (ctmrg.py:343-438,459-564,585-680,701-804), 'sl' mode, followed by
  * move_normalize_c 'inf' (ctmrg.py:210-230) when normalize != 0.  tensors10 = C1,T1,T,T2,C2,A,P2,Pt2,P1,Pt1 */
 int ctm_absorb(ctm_ctx* ctx, int dir, const double* const* tensors10, int chi, const int* adims, int normalize,

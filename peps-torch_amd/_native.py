@@ -46,6 +46,7 @@ _SIGS = {
     "ctm_c2x2": [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_void_p],
     "ctm_halves": [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_int), C.c_void_p, C.c_void_p],
     "ctm_projectors": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(TruncCfg), C.c_void_p, C.c_void_p, C.c_void_p],
+    "ctm_projectors_4x4": [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_int), C.POINTER(TruncCfg), C.c_void_p, C.c_void_p, C.c_void_p],
     "ctm_absorb": [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_int), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p],
     "ctm_c2x2_c4v": [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p],
     "ctm_move_c4v": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(TruncCfg),
@@ -245,6 +246,18 @@ class Engine:
         P, Pt, S = self.empty(n, kc), self.empty(n, kc), self.empty(kc)
         cfg = cfg or self.default_cfg
         self._ck(self.lib.ctm_projectors(self.h, _ptr(R), _ptr(Rt), n, chi, C.byref(cfg), _ptr(P), _ptr(Pt), _ptr(S)), "projectors")
+        return (P, Pt, S) if return_S else (P, Pt)
+
+    def projectors_4x4(self, direction, tensors16, chi, cfg=None, return_S=False):
+        """Fused corners -> implicit R^T Rt -> leading-chi triplets -> P, Pt (never forms the n x n halves)."""
+        ts, arr, ad = self._pack16(tensors16)
+        d = DIR_INDEX[direction] if isinstance(direction, tuple) else direction
+        chi_env = ts[0].shape[0]
+        n = chi_env * ts[3].shape[1] ** 2
+        kc = min(chi, n)
+        P, Pt, S = self.empty(n, kc), self.empty(n, kc), self.empty(kc)
+        cfg = cfg or self.default_cfg
+        self._ck(self.lib.ctm_projectors_4x4(self.h, d, arr, chi, ad, C.byref(cfg), _ptr(P), _ptr(Pt), _ptr(S)), "projectors_4x4")
         return (P, Pt, S) if return_S else (P, Pt)
 
     def absorb(self, direction, tensors10, normalize=True):

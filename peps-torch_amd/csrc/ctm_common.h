@@ -146,6 +146,16 @@ int tril_correction(ctm_ctx* ctx, double* E, int k);             // E -> I - str
 int diag_to_matrix(ctm_ctx* ctx, const double* d, double* out, int n);
 int trace_partial(ctm_ctx* ctx, const double* in, double* out, long long n2, int p);  // out[ab] = sum_i in[ab,i,i]
 
+// linear operator for the leading-k decomposition: either an explicit n x n matrix M, or the implicit product
+// M = R^T Rt with R = opA(cA) opB(cB), Rt = opC(cC) opD(cD) of four n x n enlarged corners (never formed).
+struct MatOp {
+    int n = 0;
+    const double* M = nullptr;
+    const double* c[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool t[4] = {false, false, false, false};
+};
+int jacobi_svd_top_op(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* Ut, double* Vt);
+
 // ---- Jacobi SVD / eig (jacobi.hip) -----------------------------------------------------------
 // Full one-sided block Jacobi on the rows of M (n x n).  Outputs the k leading triplets:
 //   S[k] (descending), Ut (k x n, rows = u_i^T), Vt (k x n, rows = v_i^T).

@@ -69,10 +69,10 @@ const ctm_trunc_cfg kDefaultCfg = {1.0e-8, 1.0e-8, 1.0e-14, 1, 1};
 struct TruncOut { std::vector<double> S; int keep_last; int k; };
 
 // leading triplets of M (n x n) as ROW factors Ut, Vt (k x n), S on host, multiplet-aware keep index
-int svd_rows(ctm_ctx* ctx, const double* M, int n, int chi, const ctm_trunc_cfg& cfg, double* Ut, double* Vt, double* dS,
-             TruncOut* to) {
+int svd_rows_op(ctm_ctx* ctx, const MatOp& op, int chi, const ctm_trunc_cfg& cfg, double* Ut, double* Vt, double* dS, TruncOut* to) {
+    const int n = op.n;
     const int k = (chi < n) ? chi + 1 : n;
-    CTM_TRY(jacobi_svd_top(ctx, M, n, k, dS, Ut, Vt));
+    CTM_TRY(jacobi_svd_top_op(ctx, op, k, dS, Ut, Vt));
     to->S.resize(k); to->k = k;
     CTM_HIP_CHECK(ctx, hipMemcpyAsync(to->S.data(), dS, sizeof(double) * k, hipMemcpyDeviceToHost, ctx->stream));
     CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
@@ -83,7 +83,35 @@ int svd_rows(ctm_ctx* ctx, const double* M, int n, int chi, const ctm_trunc_cfg&
     return CTM_OK;
 }
 
-std::vector<long long> vdims(std::initializer_list<long long> l) { return std::vector<long long>(l); }
+int svd_rows(ctm_ctx* ctx, const double* M, int n, int chi, const ctm_trunc_cfg& cfg, double* Ut, double* Vt, double* dS,
+             TruncOut* to) {
+    MatOp op; op.n = n; op.M = M;
+    return svd_rows_op(ctx, op, chi, cfg, Ut, Vt, dS, to);
+}
+
+// S_sqrt = rsqrt(S) where S/S[0] > reltol (ctm_projectors.py:266-270), zero beyond the kept multiplets
+void proj_scale(const TruncOut& to, int kc, double reltol, std::vector<double>* Sh, std::vector<double>* sc) {
+    Sh->assign(kc, 0.0); sc->assign(kc, 0.0);
+    for (int i = 0; i < kc; ++i) (*Sh)[i] = (i <= to.keep_last) ? to.S[i] : 0.0;
+    int nz = 0;
+    for (int i = 0; i < kc; ++i) if ((*Sh)[0] > 0.0 && (*Sh)[i] / (*Sh)[0] > reltol) { (*sc)[nz] = 1.0 / std::sqrt((*Sh)[i]); ++nz; }
+}
+
+// out (n x kc) = opA(cA) * ( opB(cB) * rows^T ) * diag(scale)   with rows = kc x n row factors
+int corner_chain_times_rowsT(ctm_ctx* ctx, int n, int kc, const double* cA, bool tA, const double* cB, bool tB, const double* rows,
+                             const double* d_scale, double* out) {
+    ArenaScope scope(ctx);
+    double* t1;
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)n * kc, (void**)&t1));
+    GemmDesc g; g.M = n; g.N = kc; g.K = n;
+    g.A = cB; if (tB) { g.sam = 1; g.sak = n; } else { g.sam = n; g.sak = 1; }
+    g.B = rows; g.sbk = 1; g.sbn = n; g.C = t1; g.ldc = kc;
+    CTM_TRY(gemm_f64(ctx, g));
+    GemmDesc h; h.M = n; h.N = kc; h.K = n;
+    h.A = cA; if (tA) { h.sam = 1; h.sak = n; } else { h.sam = n; h.sak = 1; }
+    h.B = t1; h.sbk = kc; h.sbn = 1; h.C = out; h.ldc = kc; h.colscale = d_scale;
+    return gemm_f64(ctx, h);
+}
 
 // ---------------------------------------------------------------------------------------------
 // enlarged corners: table (same specs as oracle/ctm_oracle.py _CORNER)
@@ -275,6 +303,50 @@ int ctm_projectors(ctm_ctx* ctx, const double* R, const double* Rt, int n, int c
     CTM_TRY(gemm_f64(ctx, g));
     g.A = Rt; g.B = Vt; g.C = Pt;
     CTM_TRY(gemm_f64(ctx, g));
+    CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return CTM_OK;
+}
+
+int ctm_projectors_4x4(ctm_ctx* ctx, int dir, const double* const* t, int chi, const int* adims4x5, const ctm_trunc_cfg* cfg_,
+                       double* P, double* Pt, double* S_out) {
+    const ctm_trunc_cfg cfg = cfg_ ? *cfg_ : kDefaultCfg;
+    if (dir < 0 || dir > 3) { ctx->set_error("projectors_4x4: bad direction"); return CTM_ERR_BADARG; }
+    ArenaScope scope(ctx);
+    // the four enlarged corners of the move (reference order: A,B of R then A,B of Rt)
+    double* c[4]; long long d0[4], d1[4]; int cid[4]; bool tr[4];
+    for (int h = 0; h < 2; ++h) {
+        const HalfSpec& hs = kHalves[dir][h];
+        cid[2 * h] = hs.cA; cid[2 * h + 1] = hs.cB; tr[2 * h] = hs.tA != 0; tr[2 * h + 1] = hs.tB != 0;
+    }
+    {
+        PhaseTimer pt(ctx, CTM_T_CORNERS);
+        for (int i = 0; i < 4; ++i) {
+            corner_dims(cid[i], chi, adims4x5 + 5 * i, &d0[i], &d1[i]);
+            CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)(d0[i] * d1[i]), (void**)&c[i]));
+            ArenaScope s2(ctx);
+            CTM_TRY(corner_impl(ctx, cid[i], 0, t[4 * i], t[4 * i + 1], t[4 * i + 2], t[4 * i + 3], chi, adims4x5 + 5 * i, c[i]));
+        }
+    }
+    const long long n = d0[0];
+    for (int i = 0; i < 4; ++i) if (d0[i] != n || d1[i] != n) { ctx->set_error("projectors_4x4: non-uniform bond dimensions are not supported on the fused path"); return CTM_ERR_UNSUPPORTED; }
+    const int k = (chi < n) ? chi + 1 : (int)n, kc = std::min(chi, (int)n);
+    double *Ut, *Vt, *dS, *dScale;
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)k * n, (void**)&Ut));
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)k * n, (void**)&Vt));
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * k, (void**)&dS));
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * kc, (void**)&dScale));
+    MatOp op; op.n = (int)n;
+    for (int i = 0; i < 4; ++i) { op.c[i] = c[i]; op.t[i] = tr[i]; }
+    TruncOut to;
+    { PhaseTimer pt(ctx, CTM_T_SVD); CTM_TRY(svd_rows_op(ctx, op, chi, cfg, Ut, Vt, dS, &to)); }
+    PhaseTimer pt(ctx, CTM_T_PROJ);
+    std::vector<double> Sh, sc;
+    proj_scale(to, kc, cfg.svd_reltol, &Sh, &sc);
+    CTM_HIP_CHECK(ctx, hipMemcpyAsync(dScale, sc.data(), sizeof(double) * kc, hipMemcpyHostToDevice, ctx->stream));
+    if (S_out) CTM_HIP_CHECK(ctx, hipMemcpyAsync(S_out, Sh.data(), sizeof(double) * kc, hipMemcpyHostToDevice, ctx->stream));
+    // P = R conj(U) S^-1/2 = opA(cA) opB(cB) U ... ; Pt = Rt V S^-1/2 = opC(cC) opD(cD) V ...
+    CTM_TRY(corner_chain_times_rowsT(ctx, (int)n, kc, c[0], tr[0], c[1], tr[1], Ut, dScale, P));
+    CTM_TRY(corner_chain_times_rowsT(ctx, (int)n, kc, c[2], tr[2], c[3], tr[3], Vt, dScale, Pt));
     CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     return CTM_OK;
 }

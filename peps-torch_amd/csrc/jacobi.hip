@@ -484,6 +484,36 @@ int svd_full(ctm_ctx* ctx, const double* M, int n, int k, double* S, double* Ut,
     return CTM_OK;
 }
 
+// Y (p x n, ldy) = X (p x n, ldx) * op(Z) for a dense n x n matrix Z (row-major): op = 'N' or 'T'
+int rows_times(ctm_ctx* ctx, const double* X, long long ldx, int p, int n, const double* Z, bool transZ, double* Y, long long ldy) {
+    GemmDesc g; g.M = p; g.N = n; g.K = n; g.A = X; g.sam = ldx; g.sak = 1; g.B = Z;
+    if (transZ) { g.sbk = 1; g.sbn = n; } else { g.sbk = n; g.sbn = 1; }
+    g.C = Y; g.ldc = ldy;
+    return gemm_f64(ctx, g);
+}
+
+// C = B * M (transpose == false) or B * M^T (transpose == true) for the operator M of `op`
+int matop_apply(ctm_ctx* ctx, const MatOp& op, bool transpose, const double* B, long long ldb, int p, double* C, long long ldc) {
+    const int n = op.n;
+    if (op.M) return rows_times(ctx, B, ldb, p, n, op.M, transpose, C, ldc);
+    // implicit M = R^T Rt,  R = opA(cA) opB(cB),  Rt = opC(cC) opD(cD)
+    ArenaScope scope(ctx);
+    double *t1, *t2;
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)p * n, (void**)&t1));
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)p * n, (void**)&t2));
+    if (!transpose) {   // B R^T Rt = ((B opB(cB)^T) opA(cA)^T) opC(cC) opD(cD)
+        CTM_TRY(rows_times(ctx, B, ldb, p, n, op.c[1], !op.t[1], t1, n));
+        CTM_TRY(rows_times(ctx, t1, n, p, n, op.c[0], !op.t[0], t2, n));
+        CTM_TRY(rows_times(ctx, t2, n, p, n, op.c[2], op.t[2], t1, n));
+        return rows_times(ctx, t1, n, p, n, op.c[3], op.t[3], C, ldc);
+    }
+    // B Rt^T R = ((B opD(cD)^T) opC(cC)^T) opA(cA) opB(cB)
+    CTM_TRY(rows_times(ctx, B, ldb, p, n, op.c[3], !op.t[3], t1, n));
+    CTM_TRY(rows_times(ctx, t1, n, p, n, op.c[2], !op.t[2], t2, n));
+    CTM_TRY(rows_times(ctx, t2, n, p, n, op.c[0], op.t[0], t1, n));
+    return rows_times(ctx, t1, n, p, n, op.c[1], op.t[1], C, ldc);
+}
+
 // ---------------------------------------------------------------------------------------------
 // leading-k decomposition by alternating block power iteration with Jacobi Rayleigh-Ritz:
 //   U M = C  ->  rows of C orthogonalised (same rotations applied to U)  ->  V = rows/|rows|, s = |rows|
@@ -494,8 +524,9 @@ int svd_full(ctm_ctx* ctx, const double* M, int n, int k, double* S, double* Ut,
 // If that does not happen within max_iter half steps the caller falls back to svd_full (same answer, O(n^3)).
 // `sym`: M is symmetric (eigenproblem) -- identical iteration, M^T = M.
 // ---------------------------------------------------------------------------------------------
-int svd_iter(ctm_ctx* ctx, const double* M, int n, int k, double* S, double* Ut, double* Vt, bool* converged) {
+int svd_iter(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* Ut, double* Vt, bool* converged) {
     *converged = false;
+    const int n = op.n;
     const int b = 32;
     int p_full = k + std::max(32, k / 2);
     p_full = ((p_full + 2 * b - 1) / (2 * b)) * (2 * b);       // even number of blocks
@@ -527,10 +558,7 @@ int svd_iter(ctm_ctx* ctx, const double* M, int n, int k, double* S, double* Ut,
     int it = 0;
     for (; it < max_half; ++it) {
         // C = B op(M) -> nxt[:, 0:n] ; companion nxt[:, n:2n] = B
-        GemmDesc g; g.M = p; g.N = n; g.K = n; g.A = cur; g.sam = ld; g.sak = 1; g.B = M;
-        if (side == 0) { g.sbk = 1; g.sbn = n; } else { g.sbk = n; g.sbn = 1; }
-        g.C = nxt; g.ldc = ld;
-        CTM_TRY(gemm_f64(ctx, g));
+        CTM_TRY(matop_apply(ctx, op, side == 0, cur, ld, p, nxt, ld));
         CTM_TRY(copy2d(ctx, cur, ld, nxt + n, ld, p, n));
         if (have_prev) {
             // residual of the relation that is NOT exact by construction: |C_i - s_i A_i| with A = previous normalised rows,
@@ -605,15 +633,29 @@ int svd_iter(ctm_ctx* ctx, const double* M, int n, int k, double* S, double* Ut,
 
 }  // namespace
 
-int jacobi_svd_top(ctm_ctx* ctx, const double* M, int n, int k, double* S, double* Ut, double* Vt) {
+int jacobi_svd_top_op(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* Ut, double* Vt) {
+    const int n = op.n;
     if (n <= 0 || k <= 0 || k > n) { ctx->set_error("jacobi_svd_top: bad n/k"); return CTM_ERR_BADARG; }
     if (Ut && Vt && ctx->si_enable && k < n && n >= ctx->si_min_n) {
         bool ok = false;
-        CTM_TRY(svd_iter(ctx, M, n, k, S, Ut, Vt, &ok));
+        CTM_TRY(svd_iter(ctx, op, k, S, Ut, Vt, &ok));
         if (ok) { ctx->si_hits += 1; return CTM_OK; }
         ctx->si_fallbacks += 1;
     }
+    if (op.M) return svd_full(ctx, op.M, n, k, S, Ut, Vt);
+    // materialise M = R^T Rt for the full decomposition: M = I * M
+    ArenaScope scope(ctx);
+    double *M, *I;
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)n * n, (void**)&M));
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)n * n, (void**)&I));
+    CTM_TRY(set_identity(ctx, I, n, n));
+    CTM_TRY(matop_apply(ctx, op, false, I, n, n, M, n));
     return svd_full(ctx, M, n, k, S, Ut, Vt);
+}
+
+int jacobi_svd_top(ctm_ctx* ctx, const double* M, int n, int k, double* S, double* Ut, double* Vt) {
+    MatOp op; op.n = n; op.M = M;
+    return jacobi_svd_top_op(ctx, op, k, S, Ut, Vt);
 }
 
 int jacobi_svdvals(ctm_ctx* ctx, const double* M, int n, double* S) {
@@ -636,7 +678,8 @@ int jacobi_eigh_top(ctm_ctx* ctx, const double* A, int n, int k, double* D, doub
         CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)kk * n, (void**)&Uk));
         CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)kk * n, (void**)&Vk));
         bool ok = false;
-        CTM_TRY(svd_iter(ctx, As, n, kk, S, Uk, Vk, &ok));
+        MatOp aop; aop.n = n; aop.M = As;
+        CTM_TRY(svd_iter(ctx, aop, kk, S, Uk, Vk, &ok));
         if (ok) {
             const int k = kk;
             ctx->si_hits += 1;
