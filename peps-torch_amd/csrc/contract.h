@@ -19,3 +19,12 @@ int dev_einsum2(ctm_ctx* ctx, const std::string& ia, const DT& A, const std::str
                 const std::string& io, DT* out);
 // "ab,bcd,...->xyz" evaluated strictly left to right (same order as the oracle's seq_einsum).
 int dev_seq_einsum(ctm_ctx* ctx, const std::string& expr, const std::vector<DT>& ops, DT* out);
+
+// Fused two-layer site absorption (layer2.hip): out[io] = sum Z[iz] a[ia] a[ib] with both site operands the same tensor.
+bool layer2_roles(const std::string& iz, const DT& Z, const std::string& ia, const std::string& ib, const DT& A,
+                  char ck[2], char cb[2], char ek[2], char eb[2], char sp[2]);
+int dev_layer2(ctm_ctx* ctx, const std::string& iz, const DT& Z, const std::string& ia, const std::string& ib, const DT& A,
+               const std::string& io, DT* out);
+// Whole network "i0,i1,...->o": like dev_seq_einsum, but a consecutive (a, conj a) pair of site operands is absorbed by
+// the fused kernel when the pattern fits (otherwise plain left-to-right pairwise evaluation).
+int dev_network(ctm_ctx* ctx, const std::string& expr, const std::vector<DT>& ops, DT* out);

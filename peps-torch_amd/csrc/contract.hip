@@ -118,3 +118,89 @@ int dev_seq_einsum(ctm_ctx* ctx, const std::string& expr, const std::vector<DT>&
     *out = cur;
     return CTM_OK;
 }
+
+namespace {
+std::vector<std::string> split_inputs(const std::string& lhs) {
+    std::vector<std::string> ins; size_t s = 0;
+    while (true) { size_t c = lhs.find(',', s); ins.push_back(lhs.substr(s, c == std::string::npos ? c : c - s)); if (c == std::string::npos) break; s = c + 1; }
+    return ins;
+}
+std::string join_expr(const std::vector<std::string>& ins, size_t a, size_t b, const std::string& o) {
+    std::string e;
+    for (size_t i = a; i < b; ++i) { if (i > a) e += ","; e += ins[i]; }
+    return e + "->" + o;
+}
+}  // namespace
+
+int dev_network(ctm_ctx* ctx, const std::string& expr, const std::vector<DT>& ops, DT* out) {
+    const size_t arrow = expr.find("->");
+    const std::string oidx = expr.substr(arrow + 2);
+    const std::vector<std::string> ins = split_inputs(expr.substr(0, arrow));
+    size_t k = 0;
+    bool found = false;
+    if (ctx->use_layer2)
+        for (k = 1; k + 1 < ins.size(); ++k)
+            if (ops[k].p == ops[k + 1].p && ins[k].size() == 5 && ins[k + 1].size() == 5 && ins[k][0] == ins[k + 1][0]) { found = true; break; }
+    if (!found) return dev_seq_einsum(ctx, expr, ops, out);
+    // natural index order of the prefix result (same rule as dev_seq_einsum)
+    std::string later = oidx;
+    for (size_t j = k; j < ins.size(); ++j) later += ins[j];
+    std::string zidx = ins[0];
+    for (size_t i = 1; i < k; ++i) {
+        std::string need = oidx;
+        for (size_t j = i + 1; j < ins.size(); ++j) need += ins[j];
+        std::string nidx;
+        for (char ch : zidx + ins[i]) if (need.find(ch) != std::string::npos && nidx.find(ch) == std::string::npos) nidx += ch;
+        zidx = nidx;
+    }
+    DT Z;
+    if (k == 1) Z = ops[0];
+    else {
+        std::vector<DT> pre(ops.begin(), ops.begin() + k);
+        CTM_TRY(dev_seq_einsum(ctx, join_expr(ins, 0, k, zidx), pre, &Z));
+    }
+    char ck[2], cb[2], ek[2], eb[2], sp[2];
+    if (zidx.size() != 6 || !layer2_roles(zidx, Z, ins[k], ins[k + 1], ops[k], ck, cb, ek, eb, sp)) {
+        // pattern does not fit: finish pairwise from Z
+        std::vector<DT> rest; rest.push_back(Z);
+        std::vector<std::string> rins; rins.push_back(zidx);
+        for (size_t j = k; j < ins.size(); ++j) { rest.push_back(ops[j]); rins.push_back(ins[j]); }
+        return dev_seq_einsum(ctx, join_expr(rins, 0, rins.size(), oidx), rest, out);
+    }
+    const std::string six = std::string() + sp[0] + sp[1] + ek[0] + eb[0] + ek[1] + eb[1];
+    const bool has_suffix = (k + 2 < ins.size());
+    std::string io;
+    if (!has_suffix) {
+        io = oidx;
+        if (io.size() != 6) { ctx->set_error("network: fused output rank"); return CTM_ERR_BADARG; }
+    } else {
+        const std::string& nx = ins[k + 2];
+        std::string keep_later = oidx;
+        for (size_t j = k + 3; j < ins.size(); ++j) keep_later += ins[j];
+        std::string cn, others;
+        for (char ch : nx) if (six.find(ch) != std::string::npos && keep_later.find(ch) == std::string::npos) cn += ch;
+        for (char ch : oidx) if (six.find(ch) != std::string::npos && cn.find(ch) == std::string::npos) others += ch;
+        for (char ch : six) if (cn.find(ch) == std::string::npos && others.find(ch) == std::string::npos) others += ch;
+        io = others + cn;
+    }
+    DT O;
+    long long numel = 1;
+    {   // dims of the six output letters
+        auto dimA = [&](char ch) { return ops[k].dims[ins[k].find(ch)]; };
+        for (char ch : io) {
+            long long d;
+            if (ch == sp[0] || ch == sp[1]) d = Z.dims[zidx.find(ch)];
+            else if (ch == ek[0] || ch == eb[0]) d = dimA(ek[0]);
+            else d = dimA(ek[1]);
+            numel *= d;
+        }
+    }
+    if (!has_suffix && out->p) O.p = out->p;
+    else CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)numel, (void**)&O.p));
+    CTM_TRY(dev_layer2(ctx, zidx, Z, ins[k], ins[k + 1], ops[k], io, &O));
+    if (!has_suffix) { *out = O; return CTM_OK; }
+    std::vector<DT> rest; rest.push_back(O);
+    std::vector<std::string> rins; rins.push_back(io);
+    for (size_t j = k + 2; j < ins.size(); ++j) { rest.push_back(ops[j]); rins.push_back(ins[j]); }
+    return dev_seq_einsum(ctx, join_expr(rins, 0, rins.size(), oidx), rest, out);
+}

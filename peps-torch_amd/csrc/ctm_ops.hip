@@ -140,7 +140,7 @@ int corner_impl(ctm_ctx* ctx, int corner, int open, const double* C, const doubl
     DT tT2(T2, t_view(sp.t2_axis, chi, ad[sp.t2_leg]));
     DT tA(a, {ad[0], ad[1], ad[2], ad[3], ad[4]});
     DT res; res.p = out;
-    return dev_seq_einsum(ctx, open ? sp.open : sp.closed, {tC, tT1, tT2, tA, tA}, &res);
+    return dev_network(ctx, open ? sp.open : sp.closed, {tC, tT1, tT2, tA, tA}, &res);
 }
 
 // output extents of a corner: (n0, n1)
@@ -374,7 +374,7 @@ int ctm_absorb(ctm_ctx* ctx, int dir, const double* const* t, int chi, const int
         DT tT(T, t_view(sp.t_axis, chi, Dt));
         DT tPt2(Pt2, {chi, Dpt2, Dpt2, chi}), tP1(P1, {chi, Dp1, Dp1, chi});
         DT tA(A, {ad[0], ad[1], ad[2], ad[3], ad[4]});
-        DT r3; r3.p = nT; CTM_TRY(dev_seq_einsum(ctx, sp.nT, {tT, tPt2, tA, tA, tP1}, &r3));
+        DT r3; r3.p = nT; CTM_TRY(dev_network(ctx, sp.nT, {tT, tPt2, tA, tA, tP1}, &r3));
         (void)sp.fuse0;   // the fused output axes are adjacent: the 4-index result IS the 3-index tensor in memory
     }
     if (normalize) {
@@ -397,8 +397,8 @@ int ctm_c2x2_c4v(ctm_ctx* ctx, int open, const double* a, const double* C, const
     ArenaScope scope(ctx);
     DT tC(C, {chi, chi}), tT(T, {chi, chi, D, D}), tA(a, {p, D, D, D, D});
     DT res; res.p = out;
-    return dev_seq_einsum(ctx, open ? "xy,cyuU,xelL,suldr,tULDR->edDcrRst" : "xy,cyuU,xelL,suldr,sULDR->edDcrR",
-                          {tC, tT, tT, tA, tA}, &res);
+    return dev_network(ctx, open ? "xy,cyuU,xelL,suldr,tULDR->edDcrRst" : "xy,cyuU,xelL,suldr,sULDR->edDcrR",
+                       {tC, tT, tT, tA, tA}, &res);
 }
 
 int ctm_move_c4v(ctm_ctx* ctx, const double* a, const double* C, const double* T, int chi, int p, int D,
@@ -418,7 +418,7 @@ int ctm_move_c4v(ctm_ctx* ctx, const double* a, const double* C, const double* T
     if (D_out) CTM_HIP_CHECK(ctx, hipMemcpyAsync(D_out, Dv, sizeof(double) * chi, hipMemcpyDeviceToDevice, ctx->stream));
     DT tP(P, {chi, D, D, chi}), tT(T, {chi, chi, D, D}), tA(a, {p, D, D, D, D});
     DT res; res.p = T_out;
-    CTM_TRY(dev_seq_einsum(ctx, "xuUi,xelL,suldr,sULDR,edDj->ijrR", {tP, tT, tA, tA, tP}, &res));   // :383-443
+    CTM_TRY(dev_network(ctx, "xuUi,xelL,suldr,sULDR,edDj->ijrR", {tP, tT, tA, tA, tP}, &res));   // :383-443
     CTM_TRY(add_transposed01(ctx, T_out, chi, D * D));                                 // :446
     // C /= |C[0,0]| ; T /= max|T|   (:182-197)
     CTM_TRY(div_by_device_scalar(ctx, C_out, (size_t)chi * chi, Dv, 1));

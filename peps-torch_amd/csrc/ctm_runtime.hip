@@ -94,6 +94,8 @@ int ctm_set_option(ctm_ctx* ctx, const char* key, double value) {
     else if (k == "si_tol") ctx->si_tol = value;
     else if (k == "si_rr_sweeps") ctx->si_rr_sweeps = (int)value;
     else if (k == "profile") ctx->profile = value != 0.0;
+    else if (k == "use_layer2") ctx->use_layer2 = value != 0.0;
+    else if (k == "layer2_dbg") ctx->layer2_dbg = (int)value;
     else if (k == "gemm_timing") {
         gemm_timing_drain(ctx);
         ctx->gemm_timing = value != 0.0;
@@ -116,6 +118,8 @@ int ctm_get_stat(ctm_ctx* ctx, const char* key, double* value) {
     else if (k == "si_last_rank") *value = (double)ctx->si_last_rank;
     else if (k == "gemm_flops") *value = ctx->gemm_flops;
     else if (k == "gemm_calls") *value = (double)ctx->gemm_calls;
+    else if (k == "layer2_flops") *value = ctx->layer2_flops;
+    else if (k == "layer2_calls") *value = (double)ctx->layer2_calls;
     else if (k == "arena_high") *value = (double)ctx->arena.high;
     else if (k.rfind("k_", 0) == 0 && k.size() >= 5) {      // k_ms0, k_ms1, k_flops0, k_flops1, k_calls0, k_calls1
         gemm_timing_drain(ctx);
@@ -132,7 +136,7 @@ int ctm_get_stat(ctm_ctx* ctx, const char* key, double* value) {
 
 int ctm_timers(ctm_ctx* ctx, double* out8, int reset) {
     for (int i = 0; i < CTM_T_COUNT; ++i) { if (out8) out8[i] = ctx->timers[i]; if (reset) ctx->timers[i] = 0.0; }
-    if (reset) { ctx->gemm_flops = 0; ctx->gemm_calls = 0; ctx->total_sweeps = 0; ctx->jacobi_calls = 0; ctx->si_hits = 0; ctx->si_fallbacks = 0; ctx->si_total_iters = 0; }
+    if (reset) { ctx->gemm_flops = 0; ctx->gemm_calls = 0; ctx->layer2_flops = 0; ctx->layer2_calls = 0; ctx->total_sweeps = 0; ctx->jacobi_calls = 0; ctx->si_hits = 0; ctx->si_fallbacks = 0; ctx->si_total_iters = 0; }
     return CTM_OK;
 }
 

@@ -1,0 +1,283 @@
+// Fused two-layer site absorption (SURVEY 2.3 K3+K4+K5): for every pair (x,y) of spectator (chi) indices
+//
+//   out[x,y,(e1k,e2k),(e1b,e2b)] = sum_{c1k,c2k,c1b,c2b,s}  Z[x,y,c1k,c1b,c2k,c2b] a[s,c1k,c2k,e1k,e2k] conj(a)[s,c1b,c2b,e1b,e2b]
+//
+// i.e. the ket layer and the bra layer of the on-site tensor are absorbed into a (chi,chi,D^2,D^2) block tensor in
+// ONE pass: the reference does it as two tensordots on non-adjacent legs with a 6-index permute before, between and
+// after (ctm_components.py:406-414, ctmrg.py:405-425, ctmrg_c4v.py:383-443) -- three n^2-sized round trips through
+// HBM that are pure layout work.  Here Z is gathered once (arbitrary strides), both layers run on the FP64 matrix
+// cores out of LDS, and the result is scattered once in the layout the NEXT contraction wants (arbitrary strides):
+//   step A (per phys s):  W[kb][e] = sum_kk Zs[kb][kk] As[kk][s][e]     kb=(c1b,c2b) kk=(c1k,c2k) e=(e1k,e2k)
+//   step B (acc over s):  O[e][E] += sum_kb W[kb][e] As[kb][s][E]       E=(e1b,e2b)
+// The site tensor (p D^4 <= 8192 doubles) lives in LDS for the whole kernel in ONE image [c][s][e] that serves both
+// layers (real dtype: conj(a) = a).  One workgroup = 4 waves; each (x,y) costs 2 p (KAp/16)(NEp/16)(KAp/4) MFMAs.
+#include "contract.h"
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+struct Layer2Params {
+    const double* Z; long long zs_x, zs_y, zs_c1k, zs_c1b, zs_c2k, zs_c2b;
+    int nx, ny;
+    const double* A;                 // [c1][c2][s][e1][e2] contiguous
+    int D1, D2, E1, E2, p;
+    double* out; long long os_x, os_y, os_e1k, os_e1b, os_e2k, os_e2b;
+    int KA, KAp, NE, NEp;
+    int ldz, lda, ldw;               // LDS row strides (doubles)
+    int dbg;                         // development: 1 skip gather, 2 skip MFMA, 4 skip scatter
+};
+
+// KT = KAp/16 = NEp/16 (square case: contracted and open leg pairs have the same padded size), 512 threads = 8 waves
+// (2 per SIMD).  Per pair (x,y): gather of the NEXT pair is issued into registers before the MFMA phases of the
+// current one; k loops are fully unrolled (compile-time KT) so LDS operand reads are batched ahead of the MFMAs.
+template <int KT>
+__global__ __launch_bounds__(512) void layer2_kernel(Layer2Params p) {
+    constexpr int KAp = 16 * KT, NEp = 16 * KT;
+    constexpr int NT = KT * KT;                       // tiles per step
+    constexpr int TPW = (NT + 7) / 8;                 // tiles per wave
+    constexpr int NZ = (KAp * KAp + 511) / 512;       // gathered elements per thread
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double* Zs = smem;                               // KAp x ldz
+    double* As = Zs + (size_t)KAp * p.ldz;           // KAp x lda   (row kk: [s][e], e padded to NEp)
+    double* Ws = As + (size_t)KAp * p.lda;           // KAp x ldw
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int lr = lane & 15, lk = lane >> 4;
+
+    const int tot = KAp * (p.ldz + p.lda + p.ldw);
+    for (int q = tid; q < tot; q += 512) smem[q] = 0.0;
+    __syncthreads();
+    {
+        const int na = p.KA * p.p * p.NE;
+        for (int q = tid; q < na; q += 512) {
+            const int e = q % p.NE, s = (q / p.NE) % p.p, kk = q / (p.NE * p.p);
+            As[kk * p.lda + s * NEp + e] = p.A[q];
+        }
+    }
+    // per-thread gather map (identical for every pair): element j of this thread
+    long long zoff[NZ]; int zdst[NZ];
+    const int nz = p.KA * p.KA;
+#pragma unroll
+    for (int j = 0; j < NZ; ++j) {
+        const int e = tid + 512 * j;
+        if (e < nz) {
+            const int c2b = e % p.D2; int r = e / p.D2;
+            const int c2k = r % p.D2; r /= p.D2;
+            const int c1b = r % p.D1; const int c1k = r / p.D1;
+            zoff[j] = c1k * p.zs_c1k + c1b * p.zs_c1b + c2k * p.zs_c2k + c2b * p.zs_c2b;
+            zdst[j] = (c1b * p.D2 + c2b) * p.ldz + (c1k * p.D2 + c2k);
+        } else { zoff[j] = 0; zdst[j] = -1; }
+    }
+    // per-thread tiles and scatter map
+    int tm[TPW], tn[TPW]; bool tv[TPW];
+    long long ooff[TPW][4]; bool ook[TPW][4];
+#pragma unroll
+    for (int u = 0; u < TPW; ++u) {
+        const int t = wid + 8 * u;
+        tv[u] = t < NT;
+        const int tc = tv[u] ? t : 0;
+        tm[u] = tc / KT; tn[u] = tc % KT;
+        const int E = tn[u] * 16 + lr;
+        const long long ob = (long long)(E / p.E2) * p.os_e1b + (long long)(E % p.E2) * p.os_e2b;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int e = tm[u] * 16 + lk + 4 * r;
+            ook[u][r] = tv[u] && E < p.NE && e < p.NE && !(p.dbg & 4);
+            ooff[u][r] = (long long)(e / p.E2) * p.os_e1k + (long long)(e % p.E2) * p.os_e2k + ob;
+        }
+    }
+    const long long npair = (long long)p.nx * p.ny;
+    double zreg[NZ];
+    {   // first pair of this workgroup
+        const long long q = blockIdx.x;
+        if (q < npair) {
+            const double* z = p.Z + (q / p.ny) * p.zs_x + (q % p.ny) * p.zs_y;
+#pragma unroll
+            for (int j = 0; j < NZ; ++j) if (zdst[j] >= 0) zreg[j] = z[zoff[j]];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NZ; ++j) if (zdst[j] >= 0) Zs[zdst[j]] = zreg[j];
+
+    for (long long q = blockIdx.x; q < npair; q += gridDim.x) {
+        __syncthreads();                               // Zs of this pair is complete
+        const long long qn = q + gridDim.x;
+        if (qn < npair && !(p.dbg & 1)) {              // prefetch the next pair into registers
+            const double* z = p.Z + (qn / p.ny) * p.zs_x + (qn % p.ny) * p.zs_y;
+#pragma unroll
+            for (int j = 0; j < NZ; ++j) if (zdst[j] >= 0) zreg[j] = z[zoff[j]];
+        }
+        d4 acc[TPW];
+#pragma unroll
+        for (int u = 0; u < TPW; ++u) acc[u] = (d4){0., 0., 0., 0.};
+        for (int s = 0; s < ((p.dbg & 2) ? 0 : p.p); ++s) {
+            // ---- step A: W[kb][e] = sum_kk Zs[kb][kk] As[kk][s][e]
+            d4 w[TPW];
+#pragma unroll
+            for (int u = 0; u < TPW; ++u) w[u] = (d4){0., 0., 0., 0.};
+#pragma unroll
+            for (int k0 = 0; k0 < KAp; k0 += 4) {
+#pragma unroll
+                for (int u = 0; u < TPW; ++u) {
+                    const double a = Zs[(tm[u] * 16 + lr) * p.ldz + lk + k0];
+                    const double b = As[(lk + k0) * p.lda + s * NEp + tn[u] * 16 + lr];
+                    w[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, w[u], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < TPW; ++u)
+                if (tv[u]) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) Ws[(tm[u] * 16 + lk + 4 * r) * p.ldw + tn[u] * 16 + lr] = w[u][r];
+                }
+            __syncthreads();
+            // ---- step B: O[e][E] += sum_kb W[kb][e] As[kb][s][E]
+#pragma unroll
+            for (int k0 = 0; k0 < KAp; k0 += 4) {
+#pragma unroll
+                for (int u = 0; u < TPW; ++u) {
+                    const double a = Ws[(lk + k0) * p.ldw + tm[u] * 16 + lr];
+                    const double b = As[(lk + k0) * p.lda + s * NEp + tn[u] * 16 + lr];
+                    acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[u], 0, 0, 0);
+                }
+            }
+            __syncthreads();
+        }
+        // ---- scatter O[(e1k,e2k)][(e1b,e2b)] in the caller's layout
+        double* o = p.out + (q / p.ny) * p.os_x + (q % p.ny) * p.os_y;
+#pragma unroll
+        for (int u = 0; u < TPW; ++u)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (ook[u][r]) o[ooff[u][r]] = acc[u][r];
+        // ---- stage the prefetched pair (all step-A reads of Zs finished before the last barrier)
+        if (qn < npair) {
+#pragma unroll
+            for (int j = 0; j < NZ; ++j) if (zdst[j] >= 0) Zs[zdst[j]] = zreg[j];
+        }
+    }
+}
+
+template <int KT>
+int launch_layer2(ctm_ctx* ctx, const Layer2Params& p, size_t lds_bytes) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)layer2_kernel<KT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    const long long npair = (long long)p.nx * p.ny;
+    const int per_cu = (lds_bytes <= 40 * 1024) ? 3 : (lds_bytes <= 76 * 1024 ? 2 : 1);
+    const int grid = (int)std::min<long long>(npair, 256LL * per_cu * 2);
+    hipLaunchKernelGGL(layer2_kernel<KT>, dim3(grid), dim3(512), lds_bytes, ctx->stream, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { ctx->set_error(std::string("layer2 launch: ") + hipGetErrorString(e)); return CTM_ERR_HIP; }
+    return CTM_OK;
+}
+
+long long stride_of(const std::string& idx, const DT& t, char ch) {
+    long long s = 1;
+    for (int a = (int)idx.size() - 1; a >= 0; --a) { if (idx[a] == ch) return s; s *= t.dims[a]; }
+    return -1;
+}
+
+}  // namespace
+
+// Is the pair of site operands (a with indices ia, conj(a) with ib) absorbable by the fused kernel into a tensor Z
+// with indices iz?  Fills the role letters.
+bool layer2_roles(const std::string& iz, const DT& Z, const std::string& ia, const std::string& ib, const DT& A,
+                  char ck[2], char cb[2], char ek[2], char eb[2], char sp[2]) {
+    if (ia.size() != 5 || ib.size() != 5 || A.dims.size() != 5 || ia[0] != ib[0]) return false;
+    int nc = 0, ne = 0;
+    for (int pos = 1; pos < 5; ++pos) {
+        const bool inz_k = iz.find(ia[pos]) != std::string::npos, inz_b = iz.find(ib[pos]) != std::string::npos;
+        if (inz_k != inz_b) return false;
+        if (inz_k) { if (nc == 2) return false; ck[nc] = ia[pos]; cb[nc] = ib[pos]; ++nc; }
+        else { if (ne == 2) return false; ek[ne] = ia[pos]; eb[ne] = ib[pos]; ++ne; }
+    }
+    if (nc != 2 || ne != 2) return false;
+    int ns = 0;
+    for (char ch : iz) {
+        if (ch == ck[0] || ch == ck[1] || ch == cb[0] || ch == cb[1]) continue;
+        if (ns == 2) return false;
+        sp[ns++] = ch;
+    }
+    if (ns != 2) return false;
+    for (int i = 1; i < 5; ++i) if (A.dims[i] > 8) return false;
+    {   // the fused kernel handles equal padded sizes of the contracted and the open leg pair
+        auto dimA = [&](char ch) { return (int)A.dims[ia.find(ch)]; };
+        const int KA = dimA(ck[0]) * dimA(ck[1]), NE = dimA(ek[0]) * dimA(ek[1]);
+        if ((KA + 15) / 16 != (NE + 15) / 16) return false;
+    }
+    (void)Z;
+    return true;
+}
+
+// out[io] = sum Z[iz] a[ia] a[ib]  (both site operands are the same real tensor A); io must contain exactly the two
+// spectator letters and the four open letters in any order.
+int dev_layer2(ctm_ctx* ctx, const std::string& iz, const DT& Z, const std::string& ia, const std::string& ib, const DT& A,
+               const std::string& io, DT* out) {
+    char ck[2], cb[2], ek[2], eb[2], sp[2];
+    if (!layer2_roles(iz, Z, ia, ib, A, ck, cb, ek, eb, sp)) { ctx->set_error("layer2: pattern mismatch"); return CTM_ERR_BADARG; }
+    // choose "leg 2" = the contracted leg whose bra index is the fastest-varying in Z (coalesced gather)
+    if (stride_of(iz, Z, cb[0]) < stride_of(iz, Z, cb[1])) { std::swap(ck[0], ck[1]); std::swap(cb[0], cb[1]); }
+    // the open legs keep the site-tensor order: e1 before e2
+    auto dimA = [&](char ch) { return (int)A.dims[ia.find(ch)]; };
+    Layer2Params p;
+    p.D1 = dimA(ck[0]); p.D2 = dimA(ck[1]); p.E1 = dimA(ek[0]); p.E2 = dimA(ek[1]); p.p = (int)A.dims[0];
+    p.KA = p.D1 * p.D2; p.NE = p.E1 * p.E2;
+    p.KAp = (p.KA + 15) / 16 * 16; p.NEp = (p.NE + 15) / 16 * 16;
+    if (p.KAp > 64 || p.NEp > 64 || p.KAp != p.NEp) { ctx->set_error("layer2: shape not supported by the fused kernel"); return CTM_ERR_UNSUPPORTED; }
+    p.ldz = p.KAp + 1; p.lda = p.p * p.NEp + 1; p.ldw = p.NEp + 1;
+    const size_t lds_bytes = sizeof(double) * (size_t)p.KAp * (p.ldz + p.lda + p.ldw);
+    if (lds_bytes > 150 * 1024) { ctx->set_error("layer2: LDS budget"); return CTM_ERR_UNSUPPORTED; }
+    ArenaScope scope(ctx);
+    // site tensor image [c1][c2][s][e1][e2]
+    double* Ap;
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)A.numel(), (void**)&Ap));
+    {
+        long long dims[5]; int perm[5];
+        for (int i = 0; i < 5; ++i) dims[i] = A.dims[i];
+        perm[0] = (int)ia.find(ck[0]); perm[1] = (int)ia.find(ck[1]); perm[2] = 0; perm[3] = (int)ia.find(ek[0]); perm[4] = (int)ia.find(ek[1]);
+        CTM_TRY(permute_f64(ctx, A.p, Ap, 5, dims, perm));
+    }
+    p.A = Ap;
+    p.Z = Z.p;
+    p.zs_x = stride_of(iz, Z, sp[0]); p.zs_y = stride_of(iz, Z, sp[1]);
+    p.nx = (int)Z.dims[iz.find(sp[0])]; p.ny = (int)Z.dims[iz.find(sp[1])];
+    p.zs_c1k = stride_of(iz, Z, ck[0]); p.zs_c1b = stride_of(iz, Z, cb[0]);
+    p.zs_c2k = stride_of(iz, Z, ck[1]); p.zs_c2b = stride_of(iz, Z, cb[1]);
+    // output tensor
+    DT O;
+    O.dims.resize(io.size());
+    for (size_t a = 0; a < io.size(); ++a) {
+        const char ch = io[a];
+        if (ch == sp[0]) O.dims[a] = p.nx; else if (ch == sp[1]) O.dims[a] = p.ny;
+        else if (ch == ek[0] || ch == eb[0]) O.dims[a] = p.E1; else if (ch == ek[1] || ch == eb[1]) O.dims[a] = p.E2;
+        else { ctx->set_error("layer2: unexpected output index"); return CTM_ERR_BADARG; }
+    }
+    if (io.size() != 6) { ctx->set_error("layer2: output rank"); return CTM_ERR_BADARG; }
+    O.p = out->p;
+    if (!O.p) {
+        // allocate OUTSIDE this function's scope: caller-visible result must survive -> use the caller's arena position
+        ctx->set_error("layer2: output buffer must be provided"); return CTM_ERR_BADARG;
+    }
+    p.out = O.p;
+    p.os_x = stride_of(io, O, sp[0]); p.os_y = stride_of(io, O, sp[1]);
+    p.os_e1k = stride_of(io, O, ek[0]); p.os_e1b = stride_of(io, O, eb[0]);
+    p.os_e2k = stride_of(io, O, ek[1]); p.os_e2b = stride_of(io, O, eb[1]);
+    p.dbg = ctx->layer2_dbg;
+    const long long npair = (long long)p.nx * p.ny;
+    int st;
+    switch (p.KAp / 16) {
+        case 1: st = launch_layer2<1>(ctx, p, lds_bytes); break;
+        case 2: st = launch_layer2<2>(ctx, p, lds_bytes); break;
+        case 3: st = launch_layer2<3>(ctx, p, lds_bytes); break;
+        default: st = launch_layer2<4>(ctx, p, lds_bytes); break;
+    }
+    CTM_TRY(st);
+    ctx->layer2_flops += 2.0 * npair * p.p * ((double)p.KA * p.KA * p.NE + (double)p.KA * p.NE * p.NE);
+    ctx->layer2_calls += 1;
+    out->dims = O.dims;
+    return CTM_OK;
+}
