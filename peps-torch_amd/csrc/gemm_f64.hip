@@ -17,6 +17,7 @@
 // 64 cycles, so LDS and global bandwidth needs are modest; the kernel is issue-bound on MFMA when
 // K is long.  C/D fragment layout of the f64 MFMA: col = lane&15, row = (lane>>4) + 4*reg.
 #include "ctm_common.h"
+#include <algorithm>
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
@@ -37,6 +38,7 @@ struct GemmParams {
     const double* colscale;
     const int* skip_flags;
     int tilesM, tilesN;
+    int ksplit, klen; long long split_stride;      // split-K: blockIdx.z = K slice, partial C written at z*split_stride
 };
 
 template <int TM, int TN>
@@ -70,6 +72,12 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmParams p) {
         const GemmOff o = p.offs[blockIdx.z];
         a0 = o.a0; a1 = o.a1; b0 = o.b0; b1 = o.b1; c0 = o.c0; c1 = o.c1;
         if (o.klen > 0) p.K = o.klen;
+    } else if (p.ksplit > 1) {
+        const long long k0 = (long long)blockIdx.z * p.klen;
+        a0 = a1 = k0 * p.sak;
+        b0 = b1 = k0 * p.sbk;
+        c0 = c1 = (long long)blockIdx.z * p.split_stride;
+        p.K = (int)((p.K - k0) < p.klen ? (p.K - k0) : p.klen);
     } else {
         a0 = a1 = (long long)blockIdx.z * p.strideA;
         b0 = b1 = (long long)blockIdx.z * p.strideB;
@@ -182,11 +190,26 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmParams p) {
     }
 }
 
+__global__ void splitk_reduce_kernel(const double* __restrict__ part, int nsplit, long long stride, double* __restrict__ C, int M, int N,
+                                     long long ldc, double alpha, double beta, const double* __restrict__ colscale) {
+    const long long tot = (long long)M * N;
+    for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < tot; q += (long long)gridDim.x * blockDim.x) {
+        double v = 0.0;
+        for (int s = 0; s < nsplit; ++s) v += part[s * stride + q];
+        const long long m = q / N, n = q - m * N;
+        v *= alpha;
+        if (colscale) v *= colscale[n];
+        if (beta != 0.0) v += beta * C[m * ldc + n];
+        C[m * ldc + n] = v;
+    }
+}
+
 }  // namespace
 
 int gemm_f64(ctm_ctx* ctx, const GemmDesc& d) {
     if (d.M <= 0 || d.N <= 0 || d.batch <= 0) return CTM_OK;
     if (d.K <= 0) { ctx->set_error("gemm: K<=0"); return CTM_ERR_BADARG; }
+    ArenaScope split_scope(ctx);      // split-K partials live only until the (stream-ordered) reduce kernel
     GemmParams p;
     p.M = d.M; p.N = d.N; p.K = d.K;
     p.A = d.A; p.sam = d.sam; p.sak = d.sak;
@@ -198,12 +221,30 @@ int gemm_f64(ctm_ctx* ctx, const GemmDesc& d) {
     p.splitA = d.splitA; p.splitB = d.splitB; p.splitC = d.splitC; p.splitB_dim = d.splitB_dim;
     p.colscale = d.colscale;
     p.skip_flags = d.skip_flags;
+    p.ksplit = 1; p.klen = 0; p.split_stride = 0;
     const long long tiles128 = (long long)((d.M + 127) / 128) * ((d.N + 127) / 128) * d.batch;
     const bool small = (d.M <= 64 || d.N <= 64 || tiles128 < 200);
     const int BM = small ? 64 : 128, BN = small ? 64 : 128;
     p.tilesM = (d.M + BM - 1) / BM;
     p.tilesN = (d.N + BN - 1) / BN;
     dim3 grid((unsigned)(p.tilesM * p.tilesN), 1, (unsigned)d.batch);
+    // split-K for skinny outputs with a long K (few tiles cannot fill 256 CUs): partial products into the arena,
+    // summed in a fixed order by a second tiny kernel (deterministic, no atomics)
+    double* part = nullptr;
+    const int ntile = p.tilesM * p.tilesN;
+    if (d.batch == 1 && !d.offs && d.splitB_dim == 0 && d.splitA >= d.M && d.splitC >= d.M && ntile < 128 && d.K >= 1024) {
+        int ks = std::min(16, std::min(512 / std::max(ntile, 1), d.K / 256));
+        if (ks > 1) {
+            p.klen = (((d.K + ks - 1) / ks) + 15) / 16 * 16;
+            ks = (d.K + p.klen - 1) / p.klen;
+        }
+        if (ks > 1) {
+            if (arena_alloc(ctx, sizeof(double) * (size_t)ks * d.M * d.N, (void**)&part) != CTM_OK) return CTM_ERR_NOMEM;
+            p.ksplit = ks; p.split_stride = (long long)d.M * d.N;
+            p.C = part; p.ldc = d.N; p.alpha = 1.0; p.beta = 0.0; p.colscale = nullptr;
+            grid.z = (unsigned)ks;
+        }
+    }
     int e0 = -1, e1 = -1;
     if (ctx->gemm_timing) {
         if (ctx->ev_next + 2 > (int)ctx->ev_pool.size()) {
@@ -219,6 +260,12 @@ int gemm_f64(ctm_ctx* ctx, const GemmDesc& d) {
         hipLaunchKernelGGL((gemm_f64_kernel<4, 4>), grid, dim3(256), 0, ctx->stream, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { ctx->set_error(std::string("gemm launch: ") + hipGetErrorString(e)); return CTM_ERR_HIP; }
+    if (part) {
+        const long long tot = (long long)d.M * d.N;
+        int blocks = (int)std::min<long long>((tot + 255) / 256, 2048);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, ctx->stream, (const double*)part, p.ksplit, p.split_stride, d.C,
+                           d.M, d.N, d.ldc, d.alpha, d.beta, d.colscale);
+    }
     const double fl = 2.0 * d.M * d.N * (double)d.K * d.batch;
     if (e1 >= 0) {
         (void)hipEventRecord(ctx->ev_pool[e1], ctx->stream);

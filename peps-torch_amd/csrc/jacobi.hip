@@ -47,12 +47,13 @@ struct SmallEigParams {
 // Round-robin ordering: m/2 disjoint rotations per round; per round the rotation parameters are computed by
 // m/2 lanes, then every thread transforms whole 2x2 blocks W[{p1,q1}][{p2,q2}] <- R1^T B R2 (row and column
 // update fused: each block is owned by exactly one thread) and the eigenvector columns -- two barriers per round.
-__global__ __launch_bounds__(256) void small_eig_kernel(SmallEigParams p) {
+__global__ __launch_bounds__(1024) void small_eig_kernel(SmallEigParams p) {
+    const int NTH = blockDim.x;      // 1024 for m = 64 (one 2x2 block + two eigenvector rows per thread), 256 for m <= 32
     __shared__ double W[MAXM][MAXM + 1];
     __shared__ double Jm[MAXM][MAXM + 1];
     __shared__ double cs_c[MAXM / 2], cs_s[MAXM / 2];
     __shared__ int pr_p[MAXM / 2], pr_q[MAXM / 2];
-    __shared__ double red[4];
+    __shared__ double red[16];
     __shared__ int rot_flag;
     __shared__ int round_rot[2];
     __shared__ unsigned char pair_tab[MAXM - 1][MAXM / 2][2];
@@ -69,11 +70,11 @@ __global__ __launch_bounds__(256) void small_eig_kernel(SmallEigParams p) {
         for (int s = 0; s < p.nsplit; ++s) {
             const double* Gs = G + (size_t)s * p.split_stride;
 #pragma unroll
-            for (int u = 0; u < 16; ++u) { const int q = tid + u * 256; if (q < m * m) acc[u] += Gs[q]; }
+            for (int u = 0; u < 16; ++u) { const int q = tid + u * NTH; if (q < m * m) acc[u] += Gs[q]; }
         }
 #pragma unroll
         for (int u = 0; u < 16; ++u) {
-            const int q = tid + u * 256;
+            const int q = tid + u * NTH;
             if (q < m * m) { const int r = q / m, c = q - r * m; W[r][c] = acc[u]; Jm[r][c] = (r == c) ? 1.0 : 0.0; }
         }
     }
@@ -82,7 +83,7 @@ __global__ __launch_bounds__(256) void small_eig_kernel(SmallEigParams p) {
     // convergence statistics of the INCOMING Gram matrix
     {
         double srel = 0.0, sabs = 0.0;
-        for (int q = tid; q < m * m; q += 256) {
+        for (int q = tid; q < m * m; q += NTH) {
             const int r = q / m, c = q - r * m;
             if (r < c) {
                 const double g = fabs(W[r][c]), a = W[r][r], b = W[c][c];
@@ -100,7 +101,8 @@ __global__ __launch_bounds__(256) void small_eig_kernel(SmallEigParams p) {
         if ((tid & 63) == 0) red[tid >> 6] = srel;
         __syncthreads();
         if (tid == 0) {
-            double v = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+            double v = 0.0;
+            for (int w = 0; w < (NTH >> 6); ++w) v = fmax(v, red[w]);
             atomicMax(p.stat_rel, (unsigned long long)__double_as_longlong(v));
             red[0] = v;
         }
@@ -110,7 +112,8 @@ __global__ __launch_bounds__(256) void small_eig_kernel(SmallEigParams p) {
         if ((tid & 63) == 0) red[tid >> 6] = sabs;
         __syncthreads();
         if (tid == 0) {
-            double v = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+            double v = 0.0;
+            for (int w = 0; w < (NTH >> 6); ++w) v = fmax(v, red[w]);
             atomicMax(p.stat_abs, (unsigned long long)__double_as_longlong(v));
         }
         __syncthreads();
@@ -123,7 +126,7 @@ __global__ __launch_bounds__(256) void small_eig_kernel(SmallEigParams p) {
     }
 
     const int half = m / 2, mm1 = m - 1;
-    for (int q = tid; q < mm1 * half; q += 256) {      // round-robin schedule of all rounds, once
+    for (int q = tid; q < mm1 * half; q += NTH) {      // round-robin schedule of all rounds, once
         const int r = q / half, k = q - r * half;
         int pi, qi;
         if (k == 0) { pi = mm1; qi = r % mm1; }
@@ -134,7 +137,7 @@ __global__ __launch_bounds__(256) void small_eig_kernel(SmallEigParams p) {
     __syncthreads();
     const int k2 = tid % half;            // column pair owned by this thread
     const int g0 = tid / half;            // first row-pair / row group
-    const int ngrp = 256 / half;          // thread groups along the other dimension
+    const int ngrp = NTH / half;          // thread groups along the other dimension
     for (int sweep = 0; sweep < p.max_sweeps; ++sweep) {
         if (tid == 0) { rot_flag = 0; round_rot[0] = 0; }
         __syncthreads();
@@ -222,7 +225,7 @@ __global__ __launch_bounds__(256) void small_eig_kernel(SmallEigParams p) {
         rank_of[tid] = rk;
     }
     __syncthreads();
-    for (int q = tid; q < m * m; q += 256) {
+    for (int q = tid; q < m * m; q += NTH) {
         const int r = q / m, c = q - r * m;
         Jout[r * m + rank_of[c]] = Jm[r][c];
     }
@@ -320,7 +323,7 @@ int jacobi_rows(ctm_ctx* ctx, double* X, int R, long long ld, int Cg, int Ctot, 
             SmallEigParams sp;
             sp.G = G; sp.nsplit = T->nsplit; sp.split_stride = (long long)pairs * m * m; sp.J = J; sp.m = m; sp.tol = ctx->jacobi_tol * 0.1; sp.max_sweeps = (pairs == 1) ? 12 : ctx->jacobi_inner_sweeps;
             sp.tau2 = tau2; sp.stat_rel = stat; sp.stat_abs = stat + 1; sp.flags = flags;
-            hipLaunchKernelGGL(small_eig_kernel, dim3(pairs), dim3(256), 0, ctx->stream, sp);
+            hipLaunchKernelGGL(small_eig_kernel, dim3(pairs), dim3(m > 32 ? 1024 : 256), 0, ctx->stream, sp);
             GemmDesc a;
             a.M = m; a.N = Ctot; a.K = m;
             a.A = J; a.sam = 1; a.sak = m;                       // J^T
