@@ -71,6 +71,7 @@ struct ctm_ctx {
     double layer2_flops = 0;
     long layer2_calls = 0;
     bool use_layer2 = true;
+    bool gemm_fast = true;
     int layer2_dbg = 0;
     // optional per-launch HIP-event timing of the GEMM kernels on ctx->stream (bench roofline):
     // kind 0 = 128x128 tile kernel, kind 1 = 64x64 tile kernel

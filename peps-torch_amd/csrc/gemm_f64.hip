@@ -190,6 +190,116 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmParams p) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// Fast path: plain (un-segmented, un-batched-by-offsets) GEMM whose M, N are multiples of 128 and K of 16, with
+// 16-byte aligned operands.  Same 128x128x16 double-buffered structure, but every global access is a 16-byte
+// vector load along the operand's contiguous dimension, addresses are one pointer bump per K tile, and there is
+// no bounds / segment logic in the loop.  AK: A is k-contiguous (row-major M x K); BNF: B is n-contiguous (K x N).
+// ---------------------------------------------------------------------------------------------------------
+typedef double d2 __attribute__((ext_vector_type(2)));
+
+template <bool AK, bool BNF>
+__global__ __launch_bounds__(256, 2) void gemm_f64_fast_kernel(GemmParams p) {
+    constexpr int BM = 128, BN = 128, LDA = BM + PAD, LDB = BN + PAD;
+    __shared__ __attribute__((aligned(16))) double smem[2 * BK * LDA + 2 * BK * LDB];
+    double* As = smem;
+    double* Bs = smem + 2 * BK * LDA;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+    const int ntiles = p.tilesM * p.tilesN;
+    int bid = blockIdx.x;
+    {
+        const int q = ntiles >> 3, r = ntiles & 7;
+        const int xcd = bid & 7, loc = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    }
+    const int tm = bid % p.tilesM, tn = bid / p.tilesM;
+    const long long zb = blockIdx.z;
+    const double* Ab = p.A + zb * p.strideA;
+    const double* Bb = p.B + zb * p.strideB;
+    double* Cb = p.C + zb * p.strideC;
+
+    // staging: 4 x d2 per operand per thread
+    const double* ap[4]; const double* bp[4];
+    int a_lds[4], b_lds[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int u = tid + 256 * i;
+        if (AK) { const int row = u >> 3, kp = u & 7; ap[i] = Ab + (long long)(tm * BM + row) * p.sam + 2 * kp; a_lds[i] = (2 * kp) * LDA + row; }
+        else    { const int kk = u >> 6, mp = u & 63; ap[i] = Ab + (long long)kk * p.sak + tm * BM + 2 * mp; a_lds[i] = kk * LDA + 2 * mp; }
+        if (BNF) { const int kk = u >> 6, np = u & 63; bp[i] = Bb + (long long)kk * p.sbk + tn * BN + 2 * np; b_lds[i] = kk * LDB + 2 * np; }
+        else     { const int col = u >> 3, kp = u & 7; bp[i] = Bb + (long long)(tn * BN + col) * p.sbn + 2 * kp; b_lds[i] = (2 * kp) * LDB + col; }
+    }
+    const long long a_step = AK ? BK : (long long)BK * p.sak;
+    const long long b_step = BNF ? (long long)BK * p.sbk : BK;
+
+    d4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (d4){0., 0., 0., 0.};
+    d2 ra[4], rb[4];
+    const int nk = p.K / BK;
+    auto load_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { ra[i] = *(const d2*)ap[i]; ap[i] += a_step; }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { rb[i] = *(const d2*)bp[i]; bp[i] += b_step; }
+    };
+    auto store_tile = [&](int buf) {
+        double* as = As + buf * BK * LDA;
+        double* bs = Bs + buf * BK * LDB;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (AK) { as[a_lds[i]] = ra[i][0]; as[a_lds[i] + LDA] = ra[i][1]; }
+            else *(d2*)(as + a_lds[i]) = ra[i];
+            if (BNF) *(d2*)(bs + b_lds[i]) = rb[i];
+            else { bs[b_lds[i]] = rb[i][0]; bs[b_lds[i] + LDB] = rb[i][1]; }
+        }
+    };
+    load_tile();
+    store_tile(0);
+    __syncthreads();
+    const int lr = lane & 15, lk = lane >> 4;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) load_tile();
+        const double* as = As + buf * BK * LDA + wm * 64 + lr;
+        const double* bs = Bs + buf * BK * LDB + wn * 64 + lr;
+#pragma unroll
+        for (int k4 = 0; k4 < BK / 4; ++k4) {
+            double af[4], bf[4];
+            const int kr = k4 * 4 + lk;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[i] = as[kr * LDA + i * 16];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bf[j] = bs[kr * LDB + j * 16];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nk) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = tm * BM + wm * 64 + i * 16 + lk + 4 * r;
+            double* crow = Cb + (long long)m * p.ldc + tn * BN + wn * 64 + lr;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                double v = p.alpha * acc[i][j][r];
+                if (p.colscale) v *= p.colscale[tn * BN + wn * 64 + j * 16 + lr];
+                if (p.beta != 0.0) v += p.beta * crow[j * 16];
+                crow[j * 16] = v;
+            }
+        }
+}
+
 __global__ void splitk_reduce_kernel(const double* __restrict__ part, int nsplit, long long stride, double* __restrict__ C, int M, int N,
                                      long long ldc, double alpha, double beta, const double* __restrict__ colscale) {
     const long long tot = (long long)M * N;
@@ -254,7 +364,17 @@ int gemm_f64(ctm_ctx* ctx, const GemmDesc& d) {
         e0 = ctx->ev_next++; e1 = ctx->ev_next++;
         (void)hipEventRecord(ctx->ev_pool[e0], ctx->stream);
     }
-    if (small)
+    const bool ak = d.sak == 1, amf = d.sam == 1, bnf = d.sbn == 1, bkf = d.sbk == 1;
+    const bool fast = ctx->gemm_fast && !small && !part && !d.offs && d.splitB_dim == 0 && d.splitA >= d.M && d.splitC >= d.M && !d.skip_flags &&
+                      d.M % 128 == 0 && d.N % 128 == 0 && d.K % 16 == 0 && (ak || amf) && (bnf || bkf) &&
+                      (((uintptr_t)d.A | (uintptr_t)d.B) & 15) == 0 && ((ak ? d.sam : d.sak) % 2 == 0) && ((bnf ? d.sbk : d.sbn) % 2 == 0) &&
+                      (d.strideA % 2 == 0) && (d.strideB % 2 == 0);
+    if (fast) {
+        if (ak && bnf) hipLaunchKernelGGL((gemm_f64_fast_kernel<true, true>), grid, dim3(256), 0, ctx->stream, p);
+        else if (ak && !bnf) hipLaunchKernelGGL((gemm_f64_fast_kernel<true, false>), grid, dim3(256), 0, ctx->stream, p);
+        else if (!ak && bnf) hipLaunchKernelGGL((gemm_f64_fast_kernel<false, true>), grid, dim3(256), 0, ctx->stream, p);
+        else hipLaunchKernelGGL((gemm_f64_fast_kernel<false, false>), grid, dim3(256), 0, ctx->stream, p);
+    } else if (small)
         hipLaunchKernelGGL((gemm_f64_kernel<2, 2>), grid, dim3(256), 0, ctx->stream, p);
     else
         hipLaunchKernelGGL((gemm_f64_kernel<4, 4>), grid, dim3(256), 0, ctx->stream, p);
