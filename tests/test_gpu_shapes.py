@@ -1,0 +1,115 @@
+"""GPU: shape/edge coverage of the native kernels against the oracle -- every padded variant of the fused
+two-layer kernel (D = 2..8 -> KT = 1..4), non-square GEMM edges, rank-deficient and flat spectra (fallback from the
+block power iteration to the full Jacobi), chi >= n."""
+import numpy as np
+import pytest
+import torch
+from helpers import dev, relerr
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("D,chi", [(2, 5), (3, 7), (4, 6), (5, 9), (6, 8), (7, 5), (8, 6)])
+def test_corners_and_absorb_all_bond_dims(eng, D, chi):
+    """c2x2 (4 corners, closed + open), the C4v corner and one absorb per direction for every D (fused kernel
+    variants KT=1..4 incl. zero padding 25->32, 36->48, 49->64) vs the oracle."""
+    from oracle import ctm_oracle as O, c4v_oracle as O4
+    rng = np.random.default_rng(100 * D + chi)
+    a = rng.standard_normal((2, D, D, D, D))
+    C = rng.standard_normal((chi, chi))
+    Ts = {(0, -1): rng.standard_normal((chi, D * D, chi)), (-1, 0): rng.standard_normal((chi, chi, D * D)),
+          (0, 1): rng.standard_normal((D * D, chi, chi)), (1, 0): rng.standard_normal((chi, D * D, chi))}
+    for cid in range(4):
+        sp = O._CORNER[cid]
+        T1, T2 = Ts[sp['T1']], Ts[sp['T2']]
+        ref = O.c2x2_sl(cid, C, T1, T2, a)
+        out = eng.c2x2(cid, dev(C), dev(T1), dev(T2), dev(a))
+        assert relerr(out, ref) < 1e-12, (D, cid)
+        if D <= 4:
+            refo = O.c2x2_sl(cid, C, T1, T2, a, open_=True)
+            assert relerr(eng.c2x2(cid, dev(C), dev(T1), dev(T2), dev(a), open_=True), refo) < 1e-12
+    Tc = rng.standard_normal((chi, chi, D * D))
+    assert relerr(eng.c2x2_c4v(dev(a), dev(C), dev(Tc)), O4.c2x2_sl(a, C, Tc)) < 1e-12
+    # absorb: random projectors
+    sites = {(0, 0): a}
+    ost = O.State(sites, lX=1, lY=1)
+    env = O.Env(chi)
+    for v in [(-1, -1), (1, -1), (1, 1), (-1, 1)]: env.C[((0, 0), v)] = rng.standard_normal((chi, chi))
+    for v, t in Ts.items(): env.T[((0, 0), v)] = t
+    n = chi * D * D
+    P = {(0, 0): rng.standard_normal((n, chi))}; Pt = {(0, 0): rng.standard_normal((n, chi))}
+    from ctm.generic import ctmrg
+    from ipeps.ipeps import IPEPS
+    from ctm.generic.env import ENV
+    st = IPEPS({(0, 0): dev(a)}, lX=1, lY=1)
+    denv = ENV(chi, st)
+    denv.C = {k: dev(v) for k, v in env.C.items()}; denv.T = {k: dev(v) for k, v in env.T.items()}
+    dP = {(0, 0): dev(P[(0, 0)])}; dPt = {(0, 0): dev(Pt[(0, 0)])}
+    for d in O.DIRECTIONS:
+        ref = O.absorb_truncate(d, (0, 0), ost, env, P, Pt)
+        out = ctmrg._absorb(d, (0, 0), st, denv, dP, dPt, None, normalize=False)
+        for r, o in zip(ref, out):
+            assert relerr(o, r) < 1e-12, (D, d)
+
+
+def test_gemm_fast_and_generic_agree(eng):
+    rng = np.random.default_rng(0)
+    A = rng.standard_normal((256, 384)); B = rng.standard_normal((384, 128))
+    ref = A @ B
+    eng.set_option("gemm_fast", 1); f = eng.gemm(dev(A), dev(B)).cpu().numpy()
+    eng.set_option("gemm_fast", 0); g = eng.gemm(dev(A), dev(B)).cpu().numpy()
+    eng.set_option("gemm_fast", 1)
+    assert np.abs(f - ref).max() < 1e-11 and np.abs(g - ref).max() < 1e-11
+    for tA, tB in ((True, False), (False, True), (True, True)):
+        a = A.T.copy() if tA else A; b = B.T.copy() if tB else B
+        assert np.abs(eng.gemm(dev(a), dev(b), tA, tB).cpu().numpy() - ref).max() < 1e-11
+
+
+def test_flat_spectrum_falls_back_to_full_jacobi(eng):
+    """A dense random matrix has a flat spectrum: the block power iteration cannot converge and the engine must fall
+    back to the full decomposition -- same answer as LAPACK."""
+    rng = np.random.default_rng(2)
+    n, chi = 640, 40
+    M = rng.random((n, n)) - 0.5
+    eng.set_option("si_max_iter", 6)
+    fb0 = eng.stat("si_fallbacks")
+    U, S, V = (t.cpu().numpy() for t in eng.truncated_svd(dev(M), chi))
+    eng.set_option("si_max_iter", 40)
+    assert eng.stat("si_fallbacks") == fb0 + 1
+    Sr = np.linalg.svd(M, compute_uv=False)[:chi]
+    assert np.abs(S - Sr).max() < 1e-12 * Sr[0]
+    assert np.abs(U.T @ M @ V - np.diag(S)).max() < 1e-11 * Sr[0]
+
+
+def test_rank_deficient_and_small_chi_ge_n(eng):
+    rng = np.random.default_rng(3)
+    n = 600
+    X = rng.standard_normal((n, 7)); Y = rng.standard_normal((7, n))
+    M = X @ Y                                   # rank 7
+    U, S, V = (t.cpu().numpy() for t in eng.truncated_svd(dev(M), 32))
+    Sr = np.linalg.svd(M, compute_uv=False)[:32]
+    assert np.abs(S[:7] - Sr[:7]).max() < 1e-12 * Sr[0]
+    assert (S[7:] < 1e-10 * Sr[0]).all()
+    assert np.abs((U[:, :7] * S[:7]) @ V[:, :7].T - M).max() < 1e-10 * Sr[0]
+    # chi >= n : no truncation
+    m = rng.standard_normal((20, 20))
+    U, S, V = (t.cpu().numpy() for t in eng.truncated_svd(dev(m), 32))
+    assert S.shape == (20,) and np.abs(S - np.linalg.svd(m, compute_uv=False)).max() < 1e-13 * S[0]
+    assert np.abs((U * S) @ V.T - m).max() < 1e-12
+
+
+def test_projectors_fused_equals_explicit(eng):
+    """ctm_projectors_4x4 (implicit M) == ctm_halves + ctm_projectors (explicit R, Rt) on gauge invariants."""
+    from conftest import golden
+    from helpers import sites_from, env_from, device_state_env, DIRS
+    from ctm.generic.ctm_components import _halves_t
+    g = golden("generic_D3_chi18_f64")
+    C, T = env_from(g, "warm_")
+    st, env = device_state_env(sites_from(g), C, T, 18)
+    for dn, d in DIRS.items():
+        t16 = _halves_t(d, (0, 0), st, env)
+        R, Rt = eng.halves(d, t16)
+        P, Pt, S = eng.projectors(R, Rt, 18, return_S=True)
+        P2, Pt2, S2 = eng.projectors_4x4(d, t16, 18, return_S=True)
+        assert relerr(S2, S) < 1e-12
+        assert relerr(P2 @ Pt2.t(), P @ Pt.t()) < 1e-7
