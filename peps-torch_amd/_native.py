@@ -87,35 +87,60 @@ def _ptr(t):
     return C.c_void_p(t.data_ptr())
 
 
-def _chk_t(t, name="tensor"):
-    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float64):
-        raise NativeError(f"{name}: expected a float64 CUDA(HIP) tensor, got {type(t)} "
+_DTYPES = {torch.float64: 0, torch.complex128: 1}     # CTM_F64, CTM_C128
+
+
+def _chk_t(t, name="tensor", dtype=None):
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype in _DTYPES and (dtype is None or t.dtype == dtype)):
+        raise NativeError(f"{name}: expected a {dtype or 'float64/complex128'} CUDA(HIP) tensor, got {type(t)} "
                           f"{getattr(t, 'dtype', None)} {getattr(t, 'device', None)}")
     return t if t.is_contiguous() else t.contiguous()
 
 
 class Engine:
-    """One native context bound to the current torch device and its current stream."""
+    """Native contexts (one per dtype: float64, complex128) bound to a torch device and its current stream.
+
+    Every call binds the context matching the dtype of its tensor arguments (`_bind`); a complex128 tensor is handed
+    to the library as torch stores it (interleaved re,im)."""
 
     def __init__(self, device=None):
         self.lib = load_library()
         if not torch.cuda.is_available():
             raise NativeError("no HIP device visible: the CTM engine runs only on the GPU")
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-        with torch.cuda.device(self.device):
-            self.stream = torch.cuda.current_stream(self.device)
-            h = C.c_void_p()
-            st = self.lib.ctm_create(C.byref(h), C.c_void_p(self.stream.cuda_stream), 0)
-            if st != CTM_OK:
-                raise NativeError(f"ctm_create failed: {_ERRNAMES.get(st, st)}")
-            self.h = h
+        self._handles = {}
+        self._options = {}
         self.default_cfg = TruncCfg(1e-8, 1e-8, 1e-14, 1, 1)
+        self._bind_dtype(torch.float64)
+
+    def _bind_dtype(self, dtype):
+        if dtype not in _DTYPES:
+            raise NativeError(f"unsupported dtype {dtype}: the engine computes in float64 or complex128")
+        if dtype not in self._handles:
+            with torch.cuda.device(self.device):
+                self.stream = torch.cuda.current_stream(self.device)
+                h = C.c_void_p()
+                st = self.lib.ctm_create(C.byref(h), C.c_void_p(self.stream.cuda_stream), _DTYPES[dtype])
+                if st != CTM_OK:
+                    raise NativeError(f"ctm_create failed: {_ERRNAMES.get(st, st)}")
+            self._handles[dtype] = h
+            for k, v in self._options.items():
+                self.lib.ctm_set_option(h, k.encode(), float(v))
+        self.h = self._handles[dtype]
+        self.dtype = dtype
+
+    def _bind(self, *tensors):
+        """Select the native context for the dtype of the tensor arguments and validate them."""
+        dt = tensors[0].dtype if isinstance(tensors[0], torch.Tensor) else None
+        self._bind_dtype(dt)
+        out = [_chk_t(t, "tensor", dt) for t in tensors]
+        return out[0] if len(out) == 1 else out
 
     def __del__(self):
         try:
-            if getattr(self, "h", None):
-                self.lib.ctm_destroy(self.h)
-                self.h = None
+            for h in getattr(self, "_handles", {}).values():
+                self.lib.ctm_destroy(h)
+            self._handles = {}
         except Exception:
             pass
 
@@ -125,32 +150,51 @@ class Engine:
             raise NativeError(f"{what}: {_ERRNAMES.get(st, st)}: {msg.decode() if msg else ''}")
 
     def empty(self, *shape):
+        return torch.empty(shape, dtype=self.dtype, device=self.device)
+
+    def empty_real(self, *shape):
         return torch.empty(shape, dtype=torch.float64, device=self.device)
 
-    # ---- options / stats ------------------------------------------------------------------
+    # ---- options / stats (applied to / summed over the contexts of both dtypes) ----------------
     def set_option(self, key, value):
-        self._ck(self.lib.ctm_set_option(self.h, key.encode(), float(value)), "set_option")
+        self._options[key] = value
+        for h in self._handles.values():
+            st = self.lib.ctm_set_option(h, key.encode(), float(value))
+            if st != CTM_OK:
+                self.h = h
+                self._ck(st, "set_option")
 
     def stat(self, key):
-        v = C.c_double()
-        self._ck(self.lib.ctm_get_stat(self.h, key.encode(), C.byref(v)), "get_stat")
-        return v.value
+        tot = 0.0
+        for h in self._handles.values():
+            v = C.c_double()
+            st = self.lib.ctm_get_stat(h, key.encode(), C.byref(v))
+            if st != CTM_OK:
+                self.h = h
+                self._ck(st, "get_stat")
+            tot += v.value
+        return tot
 
     def timers(self, reset=False):
-        buf = (C.c_double * 8)()
-        self._ck(self.lib.ctm_timers(self.h, buf, int(reset)), "timers")
         names = ["corners", "halves", "svd", "proj", "absorb", "norm", "rdm", "eig"]
-        return dict(zip(names, list(buf)))
+        tot = dict.fromkeys(names, 0.0)
+        for h in self._handles.values():
+            buf = (C.c_double * 8)()
+            self.lib.ctm_timers(h, buf, int(reset))
+            for n, v in zip(names, list(buf)):
+                tot[n] += v
+        return tot
 
     def sync(self):
-        self._ck(self.lib.ctm_sync(self.h), "sync")
+        for h in self._handles.values():
+            self.lib.ctm_sync(h)
 
     def cfg(self, svd_reltol=1e-8, eps_multiplet=1e-8, multiplet_abstol=1e-14, keep_multiplets=True, fix_signs=True):
         return TruncCfg(svd_reltol, eps_multiplet, multiplet_abstol, int(keep_multiplets), int(fix_signs))
 
     # ---- primitives ---------------------------------------------------------------------------
     def gemm(self, A, B, transA=False, transB=False, alpha=1.0):
-        A = _chk_t(A, "A"); B = _chk_t(B, "B")
+        A, B = self._bind(A, B)          # complex128: trans = 0/False 'N', 1/True 'T', 2 'C' (conjugate transpose)
         M, K = (A.shape[1], A.shape[0]) if transA else A.shape
         K2, N = (B.shape[1], B.shape[0]) if transB else B.shape
         if K != K2:
@@ -161,7 +205,7 @@ class Engine:
         return out
 
     def permute(self, x, perm):
-        x = _chk_t(x)
+        x = self._bind(x)
         nd = x.dim()
         out = self.empty(*[x.shape[p] for p in perm])
         dims = (C.c_longlong * nd)(*x.shape)
@@ -170,34 +214,35 @@ class Engine:
         return out
 
     def normalize_inf_(self, x):
+        self._bind(x)
         self._ck(self.lib.ctm_normalize_inf(self.h, _ptr(x), x.numel()), "normalize_inf")
         return x
 
     # ---- truncation -----------------------------------------------------------------------------
     def truncated_svd(self, M, chi, cfg=None):
-        M = _chk_t(M, "M")
+        M = self._bind(M)
         n = M.shape[0]
         if M.dim() != 2 or M.shape[1] != n:
             raise NativeError("truncated_svd: square matrices only on this path")
         kc = min(chi, n)
-        U, S, V = self.empty(n, kc), self.empty(kc), self.empty(n, kc)
+        U, S, V = self.empty(n, kc), self.empty_real(kc), self.empty(n, kc)
         cfg = cfg or self.default_cfg
         self._ck(self.lib.ctm_truncated_svd(self.h, _ptr(M), n, chi, C.byref(cfg), _ptr(U), _ptr(S), _ptr(V)), "truncated_svd")
         return U, S, V
 
     def truncated_eigh(self, A, chi, cfg=None):
-        A = _chk_t(A, "A")
+        A = self._bind(A)
         n = A.shape[0]
         kc = min(chi, n)
-        D, U = self.empty(kc), self.empty(n, kc)
+        D, U = self.empty_real(kc), self.empty(n, kc)
         cfg = cfg or self.cfg(eps_multiplet=1e-12)
         self._ck(self.lib.ctm_truncated_eigh(self.h, _ptr(A), n, chi, C.byref(cfg), _ptr(D), _ptr(U)), "truncated_eigh")
         return D, U
 
     def svdvals(self, M):
-        M = _chk_t(M, "M")
+        M = self._bind(M)
         n = M.shape[0]
-        S = self.empty(n)
+        S = self.empty_real(n)
         self._ck(self.lib.ctm_svdvals(self.h, _ptr(M), n, _ptr(S)), "svdvals")
         return S
 
@@ -207,7 +252,7 @@ class Engine:
         return (C.c_int * 5)(*a.shape)
 
     def c2x2(self, corner, C_, T1, T2, a, open_=False):
-        C_, T1, T2, a = (_chk_t(x) for x in (C_, T1, T2, a))
+        C_, T1, T2, a = self._bind(C_, T1, T2, a)
         chi = C_.shape[0]
         ad = a.shape
         leg0 = (3, 2, 1, 1)[corner]; leg1 = (4, 3, 2, 4)[corner]
@@ -218,7 +263,7 @@ class Engine:
         return out
 
     def _pack16(self, tensors):
-        ts = [_chk_t(t) for t in tensors]
+        ts = self._bind(*tensors)
         arr = (C.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
         ad = []
         for i in range(3, len(ts), 4):
@@ -238,12 +283,12 @@ class Engine:
         return R, Rt
 
     def projectors(self, R, Rt, chi, cfg=None, return_S=False):
-        R, Rt = _chk_t(R, "R"), _chk_t(Rt, "Rt")
+        R, Rt = self._bind(R, Rt)
         if R.shape != Rt.shape or R.dim() != 2:
             raise AssertionError("R and Rt must be matrices of equal shape")     # ctm_projectors.py:209
         n = R.shape[0]
         kc = min(chi, n)
-        P, Pt, S = self.empty(n, kc), self.empty(n, kc), self.empty(kc)
+        P, Pt, S = self.empty(n, kc), self.empty(n, kc), self.empty_real(kc)
         cfg = cfg or self.default_cfg
         self._ck(self.lib.ctm_projectors(self.h, _ptr(R), _ptr(Rt), n, chi, C.byref(cfg), _ptr(P), _ptr(Pt), _ptr(S)), "projectors")
         return (P, Pt, S) if return_S else (P, Pt)
@@ -255,13 +300,13 @@ class Engine:
         chi_env = ts[0].shape[0]
         n = chi_env * ts[3].shape[1] ** 2
         kc = min(chi, n)
-        P, Pt, S = self.empty(n, kc), self.empty(n, kc), self.empty(kc)
+        P, Pt, S = self.empty(n, kc), self.empty(n, kc), self.empty_real(kc)
         cfg = cfg or self.default_cfg
         self._ck(self.lib.ctm_projectors_4x4(self.h, d, arr, chi, ad, C.byref(cfg), _ptr(P), _ptr(Pt), _ptr(S)), "projectors_4x4")
         return (P, Pt, S) if return_S else (P, Pt)
 
     def absorb(self, direction, tensors10, normalize=True):
-        ts = [_chk_t(t) for t in tensors10]
+        ts = self._bind(*tensors10)
         arr = (C.c_void_p * 10)(*[t.data_ptr() for t in ts])
         A = ts[5]
         chi = ts[0].shape[0]
@@ -275,7 +320,7 @@ class Engine:
 
     # ---- C4v ------------------------------------------------------------------------------------------
     def c2x2_c4v(self, a, C_, T, open_=False):
-        a, C_, T = _chk_t(a), _chk_t(C_), _chk_t(T)
+        a, C_, T = self._bind(a, C_, T)
         chi, p, D = C_.shape[0], a.shape[0], a.shape[1]
         n = chi * D * D
         out = self.empty(n, n, p, p) if open_ else self.empty(n, n)
@@ -283,15 +328,15 @@ class Engine:
         return out
 
     def move_c4v(self, a, C_, T, cfg=None):
-        a, C_, T = _chk_t(a), _chk_t(C_), _chk_t(T)
+        a, C_, T = self._bind(a, C_, T)
         chi, p, D = C_.shape[0], a.shape[0], a.shape[1]
-        nC, nT, Dv = self.empty(chi, chi), self.empty(chi, chi, D * D), self.empty(chi)
+        nC, nT, Dv = self.empty(chi, chi), self.empty(chi, chi, D * D), self.empty_real(chi)
         cfg = cfg or self.cfg(eps_multiplet=1e-12)
         self._ck(self.lib.ctm_move_c4v(self.h, _ptr(a), _ptr(C_), _ptr(T), chi, p, D, C.byref(cfg), _ptr(nC), _ptr(nT), _ptr(Dv)), "move_c4v")
         return nC, nT, Dv
 
     def rdm_c4v(self, which, a, C_, T):
-        a, C_, T = _chk_t(a), _chk_t(C_), _chk_t(T)
+        a, C_, T = self._bind(a, C_, T)
         chi, p, D = C_.shape[0], a.shape[0], a.shape[1]
         out = self.empty(*([p] * (8 if which == 3 else 4)))
         self._ck(self.lib.ctm_rdm_c4v(self.h, which, _ptr(a), _ptr(C_), _ptr(T), chi, p, D, _ptr(out)), "rdm_c4v")
@@ -306,7 +351,7 @@ class Engine:
         return out
 
     def rdm1x1(self, tensors9):
-        ts = [_chk_t(t) for t in tensors9]
+        ts = self._bind(*tensors9)
         arr = (C.c_void_p * 9)(*[t.data_ptr() for t in ts])
         a = ts[8]
         out = self.empty(a.shape[0], a.shape[0])
@@ -314,7 +359,7 @@ class Engine:
         return out
 
     def _rdm2(self, fn, tensors12, name):
-        ts = [_chk_t(t) for t in tensors12]
+        ts = self._bind(*tensors12)
         arr = (C.c_void_p * 12)(*[t.data_ptr() for t in ts])
         a0, a1 = ts[5], ts[11]
         ad = (C.c_int * 10)(*(list(a0.shape) + list(a1.shape)))
@@ -330,7 +375,7 @@ class Engine:
         return self._rdm2(self.lib.ctm_rdm1x2, tensors12, "rdm1x2")
 
     def init_piece(self, kind, a):
-        a = _chk_t(a)
+        a = self._bind(a)
         kept = [(3, 4), (2, 3), (1, 2), (1, 4), (2, 3, 4), (1, 3, 4), (1, 2, 4), (1, 2, 3)][kind]
         out = self.empty(*[a.shape[k] ** 2 for k in kept])
         self._ck(self.lib.ctm_init_piece(self.h, kind, _ptr(a), self._adims(a), _ptr(out)), "init_piece")

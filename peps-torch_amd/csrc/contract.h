@@ -3,14 +3,17 @@
 #include "ctm_common.h"
 
 struct DT {
-    double* p = nullptr;
+    double* p = nullptr;          // the tensor (real contexts) or its real plane
+    double* q = nullptr;          // imaginary plane (complex128 contexts), same layout as p
+    bool cj = false;              // operand is read conjugated (folded into the GEMM signs, never materialised)
     std::vector<long long> dims;
     DT() {}
     DT(const double* ptr, std::initializer_list<long long> d) : p(const_cast<double*>(ptr)), dims(d) {}
     DT(const double* ptr, const std::vector<long long>& d) : p(const_cast<double*>(ptr)), dims(d) {}
     long long numel() const;
-    DT view(std::initializer_list<long long> d) const { DT t; t.p = p; t.dims = d; return t; }
-    DT view(const std::vector<long long>& d) const { DT t; t.p = p; t.dims = d; return t; }
+    DT view(std::initializer_list<long long> d) const { DT t = *this; t.dims = d; return t; }
+    DT view(const std::vector<long long>& d) const { DT t = *this; t.dims = d; return t; }
+    DT conj() const { DT t = *this; if (q) t.cj = !cj; return t; }
 };
 
 // C[io] = sum over indices shared by ia, ib and absent from io.  If out->p != nullptr the result is

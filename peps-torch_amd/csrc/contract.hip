@@ -33,8 +33,15 @@ int relayout(ctm_ctx* ctx, const std::string& from, const DT& t, const std::stri
         perm[a] = (int)from.find(to[a]);
         out->dims[a] = t.dims[perm[a]];
     }
-    if (!out->p) CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)t.numel(), (void**)&out->p));
-    return permute_f64(ctx, t.p, out->p, nd, dims, perm);
+    const size_t ne = (size_t)t.numel();
+    if (!out->p) {
+        CTM_TRY(arena_alloc(ctx, sizeof(double) * ne * (t.q ? 2 : 1), (void**)&out->p));
+        if (t.q) out->q = out->p + ne;
+    }
+    out->cj = t.cj;
+    CTM_TRY(permute_f64(ctx, t.p, out->p, nd, dims, perm));
+    if (t.q) CTM_TRY(permute_f64(ctx, t.q, out->q, nd, dims, perm));
+    return CTM_OK;
 }
 
 }  // namespace
@@ -79,20 +86,25 @@ int dev_einsum2(ctm_ctx* ctx, const std::string& ia_, const DT& A_, const std::s
     for (char ch : fA) M *= dim_of(ia, A, ch);
     for (char ch : fB) N *= dim_of(ib, B, ch);
     for (char ch : korder) K *= dim_of(ia, A, ch);
-    GemmDesc g;
-    g.M = (int)M; g.N = (int)N; g.K = (int)K;
-    g.A = A.p; if (is_suffix(ia, korder)) { g.sam = K; g.sak = 1; } else { g.sam = 1; g.sak = M; }
-    g.B = B.p; if (is_prefix(ib, korder)) { g.sbk = N; g.sbn = 1; } else { g.sbk = 1; g.sbn = K; }
+    const bool cx = (A.q != nullptr) || (B.q != nullptr);
+    if (cx && !(A.q && B.q)) { ctx->set_error("einsum2: mixed real/complex operands"); return CTM_ERR_BADARG; }
+    XM xa, xb;
+    xa.re = A.p; xa.im = A.q; xa.c = A.cj; if (is_suffix(ia, korder)) { xa.ld = K; xa.t = false; } else { xa.ld = M; xa.t = true; }
+    xb.re = B.p; xb.im = B.q; xb.c = B.cj; if (is_prefix(ib, korder)) { xb.ld = N; xb.t = false; } else { xb.ld = K; xb.t = true; }
     const std::string nat = fA + fB;
     DT C;
     C.dims.clear();
     for (char ch : fA) C.dims.push_back(dim_of(ia, A, ch));
     for (char ch : fB) C.dims.push_back(dim_of(ib, B, ch));
     const bool direct = (nat == io);
-    if (direct && out->p) C.p = out->p; else CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)(M * N), (void**)&C.p));
-    g.C = C.p; g.ldc = N;
-    CTM_TRY(gemm_f64(ctx, g));
-    if (direct) { out->p = C.p; out->dims = C.dims; return CTM_OK; }
+    if (direct && out->p) { C.p = out->p; C.q = out->q; }
+    else {
+        CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)(M * N) * (cx ? 2 : 1), (void**)&C.p));
+        if (cx) C.q = C.p + M * N;
+    }
+    if (cx && !C.q) { ctx->set_error("einsum2: complex result needs two planes"); return CTM_ERR_BADARG; }
+    CTM_TRY(xgemm(ctx, (int)M, (int)N, (int)K, xa, xb, C.p, C.q, N));
+    if (direct) { out->p = C.p; out->q = C.q; out->cj = false; out->dims = C.dims; return CTM_OK; }
     return relayout(ctx, nat, C, io, out);
 }
 
@@ -111,7 +123,7 @@ int dev_seq_einsum(ctm_ctx* ctx, const std::string& expr, const std::vector<DT>&
         std::string nidx;
         for (char ch : cidx + ins[k]) if (later.find(ch) != std::string::npos && nidx.find(ch) == std::string::npos) nidx += ch;
         DT nxt;
-        if (last) { nxt.p = out->p; CTM_TRY(dev_einsum2(ctx, cidx, cur, ins[k], ops[k], oidx, &nxt)); }
+        if (last) { nxt.p = out->p; nxt.q = out->q; CTM_TRY(dev_einsum2(ctx, cidx, cur, ins[k], ops[k], oidx, &nxt)); }
         else CTM_TRY(dev_einsum2(ctx, cidx, cur, ins[k], ops[k], nidx, &nxt));
         cur = nxt; cidx = last ? oidx : nidx;
     }
@@ -138,7 +150,7 @@ int dev_network(ctm_ctx* ctx, const std::string& expr, const std::vector<DT>& op
     const std::vector<std::string> ins = split_inputs(expr.substr(0, arrow));
     size_t k = 0;
     bool found = false;
-    if (ctx->use_layer2)
+    if (ctx->use_layer2 && !ops[0].q)
         for (k = 1; k + 1 < ins.size(); ++k)
             if (ops[k].p == ops[k + 1].p && ins[k].size() == 5 && ins[k + 1].size() == 5 && ins[k][0] == ins[k + 1][0]) { found = true; break; }
     if (!found) return dev_seq_einsum(ctx, expr, ops, out);

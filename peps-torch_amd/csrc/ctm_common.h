@@ -82,6 +82,7 @@ struct ctm_ctx {
     int ev_next = 0;
     double k_ms[2] = {0, 0}, k_flops[2] = {0, 0};
     long k_calls[2] = {0, 0};
+    bool cplx = false;                   // CTM_C128 context: every tensor pointer of the C-ABI is interleaved complex128
     void set_error(const std::string& s) { last_error = s; }
 };
 
@@ -150,15 +151,30 @@ int add_transposed01(ctm_ctx* ctx, double* t, int d0, int d2);   // t[i,j,s] = 0
 int tril_correction(ctm_ctx* ctx, double* E, int k);             // E -> I - strict_lower(E) - diag(E)/2 with E=G-I
 int diag_to_matrix(ctm_ctx* ctx, const double* d, double* out, int n);
 int trace_partial(ctm_ctx* ctx, const double* in, double* out, long long n2, int p);  // out[ab] = sum_i in[ab,i,i]
+// complex128: the C-ABI carries torch's interleaved (re,im) layout, the engine computes on two planes
+int deinterleave_c128(ctm_ctx* ctx, const double* z, double* re, double* im, size_t n);
+int interleave_c128(ctm_ctx* ctx, const double* re, const double* im /* nullptr: zero */, double* z, size_t n);
+int absmax_c128(ctm_ctx* ctx, const double* re, const double* im, size_t n, double* d_out);   // max |z|
+int row_norms_c128(ctm_ctx* ctx, const double* re, const double* im, int rows, int cols, long long ld, double* d_out);
+int tril_correction_c128(ctm_ctx* ctx, double* Er, double* Ei, int k);
+
+// op(X) of a (possibly complex, planar) matrix: t = stored transposed, c = conjugated; im == nullptr for real data
+struct XM { const double* re; const double* im; long long ld; bool t; bool c; };
+// C (M x N, planar) = op(A) (M x K) op(B) (K x N) [* diag(colscale)] ; one real GEMM, or four for complex operands
+int xgemm(ctm_ctx* ctx, int M, int N, int K, const XM& A, const XM& B, double* Cre, double* Cim, long long ldc,
+          const double* colscale = nullptr);
 
 // linear operator for the leading-k decomposition: either an explicit n x n matrix M, or the implicit product
 // M = R^T Rt with R = opA(cA) opB(cB), Rt = opC(cC) opD(cD) of four n x n enlarged corners (never formed).
 struct MatOp {
     int n = 0;
     const double* M = nullptr;
+    const double* Mi = nullptr;                                      // imaginary plane (complex128)
     const double* c[4] = {nullptr, nullptr, nullptr, nullptr};
+    const double* ci[4] = {nullptr, nullptr, nullptr, nullptr};      // imaginary planes of the corners (complex128)
     bool t[4] = {false, false, false, false};
 };
+// complex128 operators: Ut, Vt are planar (re plane k x n, then im plane), rows = u_k^H, v_k^H
 int jacobi_svd_top_op(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* Ut, double* Vt);
 
 // ---- Jacobi SVD / eig (jacobi.hip) -----------------------------------------------------------
@@ -169,4 +185,4 @@ int jacobi_svd_top(ctm_ctx* ctx, const double* M, int n, int k, double* S, doubl
 //   D[k] (signed), Ut (k x n, rows = eigenvectors).
 int jacobi_eigh_top(ctm_ctx* ctx, const double* A, int n, int k, double* D, double* Ut);
 // singular values only, small matrices (corner spectra)
-int jacobi_svdvals(ctm_ctx* ctx, const double* M, int n, double* S);
+int jacobi_svdvals(ctm_ctx* ctx, const double* M, const double* Mi /* nullptr: real */, int n, double* S);

@@ -41,11 +41,45 @@ __global__ void fix_signs_rows_kernel(double* Ut, double* Vt, int k, int n) {
 }
 
 // out (n x chi, row-major) = transpose of rows[0:chi] (k x n) with columns > keep zeroed
-__global__ void rows_to_cols_kernel(const double* rows, int n, int chi, int keep_last, double* out) {
+__global__ void rows_to_cols_kernel(const double* rows, int n, int chi, int keep_last, double* out, double sign) {
     const size_t tot = (size_t)n * chi;
     for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < tot; q += (size_t)gridDim.x * blockDim.x) {
         const size_t i = q / chi, j = q - i * chi;
-        out[q] = ((int)j <= keep_last) ? rows[j * n + i] : 0.0;
+        out[q] = ((int)j <= keep_last) ? sign * rows[j * n + i] : 0.0;
+    }
+}
+
+// complex fix_svd_signs on planar row factors (rows = u^H, v^H): the phase of the max-|U| entry is divided out, i.e.
+// both rows are multiplied by conj(ut)/|ut| with ut the (conjugated) pivot entry of the row.
+__global__ void fix_phase_rows_c_kernel(double* Ur, double* Ui, double* Vr, double* Vi, int k, int n) {
+    const int r = blockIdx.x;
+    if (r >= k) return;
+    double* ur = Ur + (size_t)r * n; double* ui = Ui + (size_t)r * n;
+    double* vr = Vr + (size_t)r * n; double* vi = Vi + (size_t)r * n;
+    long long best = -1; int bi = 0;
+    for (int c = threadIdx.x; c < n; c += blockDim.x) {
+        const long long a = (long long)(sqrt(ur[c] * ur[c] + ui[c] * ui[c]) * 1099511627776.0);
+        if (a > best) { best = a; bi = c; }
+    }
+    __shared__ long long sb[256]; __shared__ int si[256];
+    sb[threadIdx.x] = best; si[threadIdx.x] = bi;
+    __syncthreads();
+    for (int s = blockDim.x / 2; s > 0; s >>= 1) {
+        if (threadIdx.x < s) {
+            const long long ob = sb[threadIdx.x + s]; const int oi = si[threadIdx.x + s];
+            if (ob > sb[threadIdx.x] || (ob == sb[threadIdx.x] && oi < si[threadIdx.x])) { sb[threadIdx.x] = ob; si[threadIdx.x] = oi; }
+        }
+        __syncthreads();
+    }
+    const double a = ur[si[0]], b = ui[si[0]];
+    const double m = sqrt(a * a + b * b);
+    __syncthreads();
+    if (m > 0.0) {
+        const double pr = a / m, pi = -b / m;
+        for (int c = threadIdx.x; c < n; c += blockDim.x) {
+            double x = ur[c], y = ui[c]; ur[c] = x * pr - y * pi; ui[c] = x * pi + y * pr;
+            x = vr[c]; y = vi[c]; vr[c] = x * pr - y * pi; vi[c] = x * pi + y * pr;
+        }
     }
 }
 
@@ -66,6 +100,62 @@ int multiplet_chi(const std::vector<double>& S, int chi, double eps_multiplet, d
 
 const ctm_trunc_cfg kDefaultCfg = {1.0e-8, 1.0e-8, 1.0e-14, 1, 1};
 
+// Boundary marshalling.  Real contexts: a DT aliases the caller's buffer.  Complex128 contexts: the caller's
+// interleaved (re,im) tensor is split into two planes in the arena on the way in, and planar results are interleaved
+// into the caller's buffer by finish().
+struct IO {
+    ctm_ctx* ctx; bool cx;
+    struct Out { double* user; double* re; size_t n; };
+    std::vector<Out> outs;
+    explicit IO(ctm_ctx* c) : ctx(c), cx(c->cplx) {}
+    int in(const double* ptr, const std::vector<long long>& dims, DT* t) {
+        *t = DT(ptr, dims);
+        if (!cx) return CTM_OK;
+        const size_t n = (size_t)t->numel();
+        double* buf;
+        CTM_TRY(arena_alloc(ctx, sizeof(double) * 2 * n, (void**)&buf));
+        CTM_TRY(deinterleave_c128(ctx, ptr, buf, buf + n, n));
+        t->p = buf; t->q = buf + n;
+        return CTM_OK;
+    }
+    int out(double* user, size_t n, DT* t) {
+        t->p = user; t->q = nullptr; t->cj = false;
+        if (!cx) return CTM_OK;
+        double* buf;
+        CTM_TRY(arena_alloc(ctx, sizeof(double) * 2 * n, (void**)&buf));
+        t->p = buf; t->q = buf + n;
+        outs.push_back({user, buf, n});
+        return CTM_OK;
+    }
+    int finish() {
+        for (auto& o : outs) CTM_TRY(interleave_c128(ctx, o.re, o.re + o.n, o.user, o.n));
+        outs.clear();
+        return CTM_OK;
+    }
+};
+
+// arena tensor (two planes in complex contexts)
+int alloc_dt(ctm_ctx* ctx, const std::vector<long long>& dims, DT* t) {
+    *t = DT(nullptr, dims);
+    const size_t n = (size_t)t->numel();
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * n * (ctx->cplx ? 2 : 1), (void**)&t->p));
+    if (ctx->cplx) t->q = t->p + n;
+    return CTM_OK;
+}
+
+XM xm(const DT& t, long long ld, bool trans, bool conj = false) { XM x; x.re = t.p; x.im = t.q; x.ld = ld; x.t = trans; x.c = conj; return x; }
+
+// x /= max|x|
+int normalize_dt(ctm_ctx* ctx, const DT& t) {
+    const size_t n = (size_t)t.numel();
+    double* s = ctx->d_scratch + 8;
+    if (!t.q) { CTM_TRY(absmax_f64(ctx, t.p, n, s)); return div_by_device_scalar(ctx, t.p, n, s, 0); }
+    CTM_TRY(absmax_c128(ctx, t.p, t.q, n, s));
+    CTM_TRY(div_by_device_scalar(ctx, t.p, n, s, 0));
+    return div_by_device_scalar(ctx, t.q, n, s, 0);
+}
+
+
 struct TruncOut { std::vector<double> S; int keep_last; int k; };
 
 // leading triplets of M (n x n) as ROW factors Ut, Vt (k x n), S on host, multiplet-aware keep index
@@ -76,17 +166,27 @@ int svd_rows_op(ctm_ctx* ctx, const MatOp& op, int chi, const ctm_trunc_cfg& cfg
     to->S.resize(k); to->k = k;
     CTM_HIP_CHECK(ctx, hipMemcpyAsync(to->S.data(), dS, sizeof(double) * k, hipMemcpyDeviceToHost, ctx->stream));
     CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-    if (cfg.fix_signs) hipLaunchKernelGGL(fix_signs_rows_kernel, dim3(std::min(k, chi)), dim3(256), 0, ctx->stream, Ut, Vt, std::min(k, chi), n);
+    if (cfg.fix_signs) {
+        const int kf = std::min(k, chi);
+        const size_t kn = (size_t)k * n;
+        if (ctx->cplx) hipLaunchKernelGGL(fix_phase_rows_c_kernel, dim3(kf), dim3(256), 0, ctx->stream, Ut, Ut + kn, Vt, Vt + kn, kf, n);
+        else hipLaunchKernelGGL(fix_signs_rows_kernel, dim3(kf), dim3(256), 0, ctx->stream, Ut, Vt, kf, n);
+    }
     const int kc = std::min(chi, n);
     to->keep_last = kc - 1;
     if (cfg.keep_multiplets && chi < n) to->keep_last = std::min(kc - 1, multiplet_chi(to->S, chi, cfg.eps_multiplet, cfg.multiplet_abstol));
     return CTM_OK;
 }
 
-int svd_rows(ctm_ctx* ctx, const double* M, int n, int chi, const ctm_trunc_cfg& cfg, double* Ut, double* Vt, double* dS,
-             TruncOut* to) {
-    MatOp op; op.n = n; op.M = M;
+int svd_rows(ctm_ctx* ctx, const DT& M, int n, int chi, const ctm_trunc_cfg& cfg, double* Ut, double* Vt, double* dS, TruncOut* to) {
+    MatOp op; op.n = n; op.M = M.p; op.Mi = M.q;
     return svd_rows_op(ctx, op, chi, cfg, Ut, Vt, dS, to);
+}
+
+// U (n x kc) = (rows 0..kc of the k x n row factor)^H with the columns beyond keep_last zeroed; planar in complex contexts
+void rows_to_cols(ctm_ctx* ctx, const double* rows, int k, int n, int kc, int keep_last, const DT& out) {
+    hipLaunchKernelGGL(rows_to_cols_kernel, dim3(1024), dim3(256), 0, ctx->stream, rows, n, kc, keep_last, out.p, 1.0);
+    if (out.q) hipLaunchKernelGGL(rows_to_cols_kernel, dim3(1024), dim3(256), 0, ctx->stream, rows + (size_t)k * n, n, kc, keep_last, out.q, -1.0);
 }
 
 // S_sqrt = rsqrt(S) where S/S[0] > reltol (ctm_projectors.py:266-270), zero beyond the kept multiplets
@@ -97,20 +197,15 @@ void proj_scale(const TruncOut& to, int kc, double reltol, std::vector<double>* 
     for (int i = 0; i < kc; ++i) if ((*Sh)[0] > 0.0 && (*Sh)[i] / (*Sh)[0] > reltol) { (*sc)[nz] = 1.0 / std::sqrt((*Sh)[i]); ++nz; }
 }
 
-// out (n x kc) = opA(cA) * ( opB(cB) * rows^T ) * diag(scale)   with rows = kc x n row factors
-int corner_chain_times_rowsT(ctm_ctx* ctx, int n, int kc, const double* cA, bool tA, const double* cB, bool tB, const double* rows,
-                             const double* d_scale, double* out) {
+// out (n x kc) = opA(cA) * ( opB(cB) * rows^T[^H] ) * diag(scale)   with rows = k x n row factors (kc leading ones used)
+int corner_chain_times_rowsT(ctm_ctx* ctx, int n, int k, int kc, const DT& cA, bool tA, const DT& cB, bool tB, const double* rows,
+                             bool conj_rows, const double* d_scale, const DT& out) {
     ArenaScope scope(ctx);
-    double* t1;
-    CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)n * kc, (void**)&t1));
-    GemmDesc g; g.M = n; g.N = kc; g.K = n;
-    g.A = cB; if (tB) { g.sam = 1; g.sak = n; } else { g.sam = n; g.sak = 1; }
-    g.B = rows; g.sbk = 1; g.sbn = n; g.C = t1; g.ldc = kc;
-    CTM_TRY(gemm_f64(ctx, g));
-    GemmDesc h; h.M = n; h.N = kc; h.K = n;
-    h.A = cA; if (tA) { h.sam = 1; h.sak = n; } else { h.sam = n; h.sak = 1; }
-    h.B = t1; h.sbk = kc; h.sbn = 1; h.C = out; h.ldc = kc; h.colscale = d_scale;
-    return gemm_f64(ctx, h);
+    DT t1;
+    CTM_TRY(alloc_dt(ctx, {n, kc}, &t1));
+    XM r; r.re = rows; r.im = ctx->cplx ? rows + (size_t)k * n : nullptr; r.ld = n; r.t = true; r.c = conj_rows;
+    CTM_TRY(xgemm(ctx, n, kc, n, xm(cB, n, tB), r, t1.p, t1.q, kc));
+    return xgemm(ctx, n, kc, n, xm(cA, n, tA), xm(t1, kc, false), out.p, out.q, kc, d_scale);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -131,16 +226,26 @@ std::vector<long long> t_view(int axis, long long chi, long long D) {
     return d;
 }
 
-int corner_impl(ctm_ctx* ctx, int corner, int open, const double* C, const double* T1, const double* T2, const double* a,
-                int chi, const int* ad, double* out) {
+int corner_impl(ctm_ctx* ctx, int corner, int open, const DT& C, const DT& T1, const DT& T2, const DT& a, int chi, const int* ad,
+                DT* res) {
     if (corner < 0 || corner > 3) { ctx->set_error("c2x2: bad corner"); return CTM_ERR_BADARG; }
     const CornerSpec& sp = kCorner[corner];
-    DT tC(C, {chi, chi});
-    DT tT1(T1, t_view(sp.t1_axis, chi, ad[sp.t1_leg]));
-    DT tT2(T2, t_view(sp.t2_axis, chi, ad[sp.t2_leg]));
-    DT tA(a, {ad[0], ad[1], ad[2], ad[3], ad[4]});
-    DT res; res.p = out;
-    return dev_network(ctx, open ? sp.open : sp.closed, {tC, tT1, tT2, tA, tA}, &res);
+    DT tC = C.view({chi, chi});
+    DT tT1 = T1.view(t_view(sp.t1_axis, chi, ad[sp.t1_leg]));
+    DT tT2 = T2.view(t_view(sp.t2_axis, chi, ad[sp.t2_leg]));
+    DT tA = a.view({ad[0], ad[1], ad[2], ad[3], ad[4]});
+    return dev_network(ctx, open ? sp.open : sp.closed, {tC, tT1, tT2, tA, tA.conj()}, res);
+}
+
+// the four input tensors (C, T1, T2, a) of one enlarged corner, marshalled
+struct CornerIn { DT C, T1, T2, a; };
+int corner_in(IO& io, const double* const* t, int chi, const int* ad, int corner, CornerIn* ci) {
+    const CornerSpec& sp = kCorner[corner];
+    const long long X = chi, D1 = (long long)ad[sp.t1_leg] * ad[sp.t1_leg], D2 = (long long)ad[sp.t2_leg] * ad[sp.t2_leg];
+    CTM_TRY(io.in(t[0], {X, X}, &ci->C));
+    CTM_TRY(io.in(t[1], {X, X, D1}, &ci->T1));       // only the element count matters here: corner_impl re-views
+    CTM_TRY(io.in(t[2], {X, X, D2}, &ci->T2));
+    return io.in(t[3], {ad[0], ad[1], ad[2], ad[3], ad[4]}, &ci->a);
 }
 
 // output extents of a corner: (n0, n1)
@@ -183,14 +288,25 @@ extern "C" {
 
 int ctm_c2x2(ctm_ctx* ctx, int corner, int open, const double* C, const double* T1, const double* T2, const double* a,
              int chi, const int* adims, double* out) {
+    if (corner < 0 || corner > 3) { ctx->set_error("c2x2: bad corner"); return CTM_ERR_BADARG; }
     PhaseTimer pt(ctx, CTM_T_CORNERS);
     ArenaScope scope(ctx);
-    return corner_impl(ctx, corner, open, C, T1, T2, a, chi, adims, out);
+    IO io(ctx);
+    const double* t4[4] = {C, T1, T2, a};
+    CornerIn ci;
+    CTM_TRY(corner_in(io, t4, chi, adims, corner, &ci));
+    long long n0, n1; corner_dims(corner, chi, adims, &n0, &n1);
+    const long long pp = open ? (long long)adims[0] * adims[0] : 1;
+    DT res;
+    CTM_TRY(io.out(out, (size_t)(n0 * n1 * pp), &res));
+    CTM_TRY(corner_impl(ctx, corner, open, ci.C, ci.T1, ci.T2, ci.a, chi, adims, &res));
+    return io.finish();
 }
 
 int ctm_halves(ctm_ctx* ctx, int dir, const double* const* t, int chi, const int* adims4x5, double* R, double* Rt) {
     if (dir < 0 || dir > 3) { ctx->set_error("halves: bad direction"); return CTM_ERR_BADARG; }
     ArenaScope scope(ctx);
+    IO io(ctx);
     double* outs[2] = {R, Rt};
     for (int h = 0; h < 2; ++h) {
         const HalfSpec& hs = kHalves[dir][h];
@@ -198,27 +314,26 @@ int ctm_halves(ctm_ctx* ctx, int dir, const double* const* t, int chi, const int
         long long a0, a1, b0, b1;
         corner_dims(hs.cA, chi, adims4x5 + 5 * ia, &a0, &a1);
         corner_dims(hs.cB, chi, adims4x5 + 5 * ib, &b0, &b1);
-        ArenaScope inner(ctx);
-        double *cA, *cB;
-        CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)(a0 * a1), (void**)&cA));
-        CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)(b0 * b1), (void**)&cB));
-        {
-            PhaseTimer pt(ctx, CTM_T_CORNERS);
-            { ArenaScope s2(ctx); CTM_TRY(corner_impl(ctx, hs.cA, 0, t[4 * ia], t[4 * ia + 1], t[4 * ia + 2], t[4 * ia + 3], chi, adims4x5 + 5 * ia, cA)); }
-            { ArenaScope s2(ctx); CTM_TRY(corner_impl(ctx, hs.cB, 0, t[4 * ib], t[4 * ib + 1], t[4 * ib + 2], t[4 * ib + 3], chi, adims4x5 + 5 * ib, cB)); }
-        }
-        PhaseTimer pt(ctx, CTM_T_HALVES);
         const long long M = hs.tA ? a1 : a0, Ka = hs.tA ? a0 : a1;
         const long long N = hs.tB ? b0 : b1, Kb = hs.tB ? b1 : b0;
         if (Ka != Kb) { ctx->set_error("halves: contracted dims differ"); return CTM_ERR_SHAPE; }
-        GemmDesc g;
-        g.M = (int)M; g.N = (int)N; g.K = (int)Ka;
-        g.A = cA; if (hs.tA) { g.sam = 1; g.sak = a1; } else { g.sam = a1; g.sak = 1; }
-        g.B = cB; if (hs.tB) { g.sbk = 1; g.sbn = b1; } else { g.sbk = b1; g.sbn = 1; }
-        g.C = outs[h]; g.ldc = N;
-        CTM_TRY(gemm_f64(ctx, g));
+        DT res;
+        CTM_TRY(io.out(outs[h], (size_t)(M * N), &res));
+        ArenaScope inner(ctx);
+        DT cA, cB;
+        CTM_TRY(alloc_dt(ctx, {a0, a1}, &cA));
+        CTM_TRY(alloc_dt(ctx, {b0, b1}, &cB));
+        {
+            PhaseTimer pt(ctx, CTM_T_CORNERS);
+            { ArenaScope s2(ctx); CornerIn ci; CTM_TRY(corner_in(io, t + 4 * ia, chi, adims4x5 + 5 * ia, hs.cA, &ci));
+              CTM_TRY(corner_impl(ctx, hs.cA, 0, ci.C, ci.T1, ci.T2, ci.a, chi, adims4x5 + 5 * ia, &cA)); }
+            { ArenaScope s2(ctx); CornerIn ci; CTM_TRY(corner_in(io, t + 4 * ib, chi, adims4x5 + 5 * ib, hs.cB, &ci));
+              CTM_TRY(corner_impl(ctx, hs.cB, 0, ci.C, ci.T1, ci.T2, ci.a, chi, adims4x5 + 5 * ib, &cB)); }
+        }
+        PhaseTimer pt(ctx, CTM_T_HALVES);
+        CTM_TRY(xgemm(ctx, (int)M, (int)N, (int)Ka, xm(cA, a1, hs.tA != 0), xm(cB, b1, hs.tB != 0), res.p, res.q, N));
     }
-    return CTM_OK;
+    return io.finish();
 }
 
 int ctm_truncated_svd(ctm_ctx* ctx, const double* M, int n, int chi, const ctm_trunc_cfg* cfg_, double* U, double* S, double* V) {
@@ -226,18 +341,24 @@ int ctm_truncated_svd(ctm_ctx* ctx, const double* M, int n, int chi, const ctm_t
     if (chi < 1 || n < 1) { ctx->set_error("truncated_svd: bad dims"); return CTM_ERR_BADARG; }
     PhaseTimer pt(ctx, CTM_T_SVD);
     ArenaScope scope(ctx);
-    const int k = (chi < n) ? chi + 1 : n, kc = std::min(chi, n);
+    IO io(ctx);
+    const int k = (chi < n) ? chi + 1 : n, kc = std::min(chi, n), cz = ctx->cplx ? 2 : 1;
+    DT tM, tU, tV;
+    CTM_TRY(io.in(M, {n, n}, &tM));
+    CTM_TRY(io.out(U, (size_t)n * kc, &tU));
+    CTM_TRY(io.out(V, (size_t)n * kc, &tV));
     double *Ut, *Vt, *dS;
-    CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)k * n, (void**)&Ut));
-    CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)k * n, (void**)&Vt));
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)k * n * cz, (void**)&Ut));
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)k * n * cz, (void**)&Vt));
     CTM_TRY(arena_alloc(ctx, sizeof(double) * k, (void**)&dS));
     TruncOut to;
-    CTM_TRY(svd_rows(ctx, M, n, chi, cfg, Ut, Vt, dS, &to));
+    CTM_TRY(svd_rows(ctx, tM, n, chi, cfg, Ut, Vt, dS, &to));
     std::vector<double> Sh(kc);
     for (int i = 0; i < kc; ++i) Sh[i] = (i <= to.keep_last) ? to.S[i] : 0.0;
     CTM_HIP_CHECK(ctx, hipMemcpyAsync(S, Sh.data(), sizeof(double) * kc, hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(rows_to_cols_kernel, dim3(1024), dim3(256), 0, ctx->stream, Ut, n, kc, to.keep_last, U);
-    hipLaunchKernelGGL(rows_to_cols_kernel, dim3(1024), dim3(256), 0, ctx->stream, Vt, n, kc, to.keep_last, V);
+    rows_to_cols(ctx, Ut, k, n, kc, to.keep_last, tU);
+    rows_to_cols(ctx, Vt, k, n, kc, to.keep_last, tV);
+    CTM_TRY(io.finish());
     CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     return CTM_OK;
 }
@@ -246,6 +367,7 @@ int ctm_truncated_eigh(ctm_ctx* ctx, const double* A, int n, int chi, const ctm_
     ctm_trunc_cfg cfg = cfg_ ? *cfg_ : kDefaultCfg;
     if (!cfg_) { cfg.eps_multiplet = 1.0e-12; }
     if (chi < 1 || n < 1) { ctx->set_error("truncated_eigh: bad dims"); return CTM_ERR_BADARG; }
+    if (ctx->cplx) { ctx->set_error("truncated_eigh: the symmetric eigensolver (C4v path) is float64 only in this build"); return CTM_ERR_UNSUPPORTED; }
     PhaseTimer pt(ctx, CTM_T_EIG);
     ArenaScope scope(ctx);
     const int k = (chi < n) ? chi + 1 : n, kc = std::min(chi, n);
@@ -261,48 +383,64 @@ int ctm_truncated_eigh(ctm_ctx* ctx, const double* A, int n, int chi, const ctm_
     std::vector<double> Do(kc);
     for (int i = 0; i < kc; ++i) Do[i] = (i <= keep_last) ? Dh[i] : 0.0;
     CTM_HIP_CHECK(ctx, hipMemcpyAsync(D, Do.data(), sizeof(double) * kc, hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(rows_to_cols_kernel, dim3(1024), dim3(256), 0, ctx->stream, Ut, n, kc, keep_last, U);
+    hipLaunchKernelGGL(rows_to_cols_kernel, dim3(1024), dim3(256), 0, ctx->stream, Ut, n, kc, keep_last, U, 1.0);
     CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     return CTM_OK;
 }
 
 int ctm_svdvals(ctm_ctx* ctx, const double* M, int n, double* S) {
     ArenaScope scope(ctx);
-    return jacobi_svdvals(ctx, M, n, S);
+    IO io(ctx);
+    DT tM;
+    CTM_TRY(io.in(M, {n, n}, &tM));
+    return jacobi_svdvals(ctx, tM.p, tM.q, n, S);
 }
+
+namespace {
+// shared tail of the projector constructions: scale vector from the kept spectrum
+int upload_scale(ctm_ctx* ctx, const TruncOut& to, int kc, double reltol, double* dScale, double* S_out) {
+    std::vector<double> Sh, sc;
+    proj_scale(to, kc, reltol, &Sh, &sc);
+    CTM_HIP_CHECK(ctx, hipMemcpyAsync(dScale, sc.data(), sizeof(double) * kc, hipMemcpyHostToDevice, ctx->stream));
+    if (S_out) CTM_HIP_CHECK(ctx, hipMemcpyAsync(S_out, Sh.data(), sizeof(double) * kc, hipMemcpyHostToDevice, ctx->stream));
+    CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));     // host vectors go out of scope
+    return CTM_OK;
+}
+}  // namespace
 
 int ctm_projectors(ctm_ctx* ctx, const double* R, const double* Rt, int n, int chi, const ctm_trunc_cfg* cfg_, double* P,
                    double* Pt, double* S_out) {
     const ctm_trunc_cfg cfg = cfg_ ? *cfg_ : kDefaultCfg;
     if (chi < 1 || n < 1) { ctx->set_error("projectors: bad dims"); return CTM_ERR_BADARG; }
     ArenaScope scope(ctx);
-    const int k = (chi < n) ? chi + 1 : n, kc = std::min(chi, n);
-    double *M, *Ut, *Vt, *dS, *dScale;
-    CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)n * n, (void**)&M));
-    CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)k * n, (void**)&Ut));
-    CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)k * n, (void**)&Vt));
+    IO io(ctx);
+    const int k = (chi < n) ? chi + 1 : n, kc = std::min(chi, n), cz = ctx->cplx ? 2 : 1;
+    DT tR, tRt, tM, tP, tPt;
+    CTM_TRY(io.in(R, {n, n}, &tR));
+    CTM_TRY(io.in(Rt, {n, n}, &tRt));
+    CTM_TRY(io.out(P, (size_t)n * kc, &tP));
+    CTM_TRY(io.out(Pt, (size_t)n * kc, &tPt));
+    CTM_TRY(alloc_dt(ctx, {n, n}, &tM));
+    double *Ut, *Vt, *dS, *dScale;
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)k * n * cz, (void**)&Ut));
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)k * n * cz, (void**)&Vt));
     CTM_TRY(arena_alloc(ctx, sizeof(double) * k, (void**)&dS));
     CTM_TRY(arena_alloc(ctx, sizeof(double) * kc, (void**)&dScale));
     {   // M = R^T Rt  (ctm_projectors.py:263, plain transpose)
         PhaseTimer pt(ctx, CTM_T_HALVES);
-        GemmDesc g; g.M = n; g.N = n; g.K = n; g.A = R; g.sam = 1; g.sak = n; g.B = Rt; g.sbk = n; g.sbn = 1; g.C = M; g.ldc = n;
-        CTM_TRY(gemm_f64(ctx, g));
+        CTM_TRY(xgemm(ctx, n, n, n, xm(tR, n, true), xm(tRt, n, false), tM.p, tM.q, n));
     }
     TruncOut to;
-    { PhaseTimer pt(ctx, CTM_T_SVD); CTM_TRY(svd_rows(ctx, M, n, chi, cfg, Ut, Vt, dS, &to)); }
+    { PhaseTimer pt(ctx, CTM_T_SVD); CTM_TRY(svd_rows(ctx, tM, n, chi, cfg, Ut, Vt, dS, &to)); }
     PhaseTimer pt(ctx, CTM_T_PROJ);
-    // S_sqrt = rsqrt(S) where S/S[0] > reltol (ctm_projectors.py:266-270), zero beyond the kept multiplets
-    std::vector<double> Sh(kc), sc(kc, 0.0);
-    for (int i = 0; i < kc; ++i) Sh[i] = (i <= to.keep_last) ? to.S[i] : 0.0;
-    int nz = 0;
-    for (int i = 0; i < kc; ++i) if (Sh[0] > 0.0 && Sh[i] / Sh[0] > cfg.svd_reltol) { sc[nz] = 1.0 / std::sqrt(Sh[i]); ++nz; }
-    CTM_HIP_CHECK(ctx, hipMemcpyAsync(dScale, sc.data(), sizeof(double) * kc, hipMemcpyHostToDevice, ctx->stream));
-    if (S_out) CTM_HIP_CHECK(ctx, hipMemcpyAsync(S_out, Sh.data(), sizeof(double) * kc, hipMemcpyHostToDevice, ctx->stream));
-    // P = R conj(U) diag(S_sqrt),  Pt = Rt V diag(S_sqrt)   (:283); U,V as row factors -> NT GEMM + fused column scale
-    GemmDesc g; g.M = n; g.N = kc; g.K = n; g.A = R; g.sam = n; g.sak = 1; g.B = Ut; g.sbk = 1; g.sbn = n; g.C = P; g.ldc = kc; g.colscale = dScale;
-    CTM_TRY(gemm_f64(ctx, g));
-    g.A = Rt; g.B = Vt; g.C = Pt;
-    CTM_TRY(gemm_f64(ctx, g));
+    CTM_TRY(upload_scale(ctx, to, kc, cfg.svd_reltol, dScale, S_out));
+    // P = R conj(U) diag(S_sqrt),  Pt = Rt V diag(S_sqrt)   (:283); with row factors Ut = U^H, Vt = V^H:
+    // conj(U) = Ut^T (plain transpose), V = Vt^H -> NT GEMMs + fused column scale
+    const size_t kn = (size_t)k * n;
+    XM u{Ut, ctx->cplx ? Ut + kn : nullptr, n, true, false}, v{Vt, ctx->cplx ? Vt + kn : nullptr, n, true, true};
+    CTM_TRY(xgemm(ctx, n, kc, n, xm(tR, n, false), u, tP.p, tP.q, kc, dScale));
+    CTM_TRY(xgemm(ctx, n, kc, n, xm(tRt, n, false), v, tPt.p, tPt.q, kc, dScale));
+    CTM_TRY(io.finish());
     CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     return CTM_OK;
 }
@@ -312,41 +450,45 @@ int ctm_projectors_4x4(ctm_ctx* ctx, int dir, const double* const* t, int chi, c
     const ctm_trunc_cfg cfg = cfg_ ? *cfg_ : kDefaultCfg;
     if (dir < 0 || dir > 3) { ctx->set_error("projectors_4x4: bad direction"); return CTM_ERR_BADARG; }
     ArenaScope scope(ctx);
+    IO io(ctx);
     // the four enlarged corners of the move (reference order: A,B of R then A,B of Rt)
-    double* c[4]; long long d0[4], d1[4]; int cid[4]; bool tr[4];
+    DT c[4]; long long d0[4], d1[4]; int cid[4]; bool tr[4];
     for (int h = 0; h < 2; ++h) {
         const HalfSpec& hs = kHalves[dir][h];
         cid[2 * h] = hs.cA; cid[2 * h + 1] = hs.cB; tr[2 * h] = hs.tA != 0; tr[2 * h + 1] = hs.tB != 0;
     }
+    for (int i = 0; i < 4; ++i) corner_dims(cid[i], chi, adims4x5 + 5 * i, &d0[i], &d1[i]);
+    const long long n = d0[0];
+    for (int i = 0; i < 4; ++i) if (d0[i] != n || d1[i] != n) { ctx->set_error("projectors_4x4: non-uniform bond dimensions are not supported on the fused path"); return CTM_ERR_UNSUPPORTED; }
+    const int k = (chi < n) ? chi + 1 : (int)n, kc = std::min(chi, (int)n), cz = ctx->cplx ? 2 : 1;
+    DT tP, tPt;
+    CTM_TRY(io.out(P, (size_t)n * kc, &tP));
+    CTM_TRY(io.out(Pt, (size_t)n * kc, &tPt));
     {
         PhaseTimer pt(ctx, CTM_T_CORNERS);
         for (int i = 0; i < 4; ++i) {
-            corner_dims(cid[i], chi, adims4x5 + 5 * i, &d0[i], &d1[i]);
-            CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)(d0[i] * d1[i]), (void**)&c[i]));
+            CTM_TRY(alloc_dt(ctx, {d0[i], d1[i]}, &c[i]));
             ArenaScope s2(ctx);
-            CTM_TRY(corner_impl(ctx, cid[i], 0, t[4 * i], t[4 * i + 1], t[4 * i + 2], t[4 * i + 3], chi, adims4x5 + 5 * i, c[i]));
+            CornerIn ci;
+            CTM_TRY(corner_in(io, t + 4 * i, chi, adims4x5 + 5 * i, cid[i], &ci));
+            CTM_TRY(corner_impl(ctx, cid[i], 0, ci.C, ci.T1, ci.T2, ci.a, chi, adims4x5 + 5 * i, &c[i]));
         }
     }
-    const long long n = d0[0];
-    for (int i = 0; i < 4; ++i) if (d0[i] != n || d1[i] != n) { ctx->set_error("projectors_4x4: non-uniform bond dimensions are not supported on the fused path"); return CTM_ERR_UNSUPPORTED; }
-    const int k = (chi < n) ? chi + 1 : (int)n, kc = std::min(chi, (int)n);
     double *Ut, *Vt, *dS, *dScale;
-    CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)k * n, (void**)&Ut));
-    CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)k * n, (void**)&Vt));
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)k * n * cz, (void**)&Ut));
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)k * n * cz, (void**)&Vt));
     CTM_TRY(arena_alloc(ctx, sizeof(double) * k, (void**)&dS));
     CTM_TRY(arena_alloc(ctx, sizeof(double) * kc, (void**)&dScale));
     MatOp op; op.n = (int)n;
-    for (int i = 0; i < 4; ++i) { op.c[i] = c[i]; op.t[i] = tr[i]; }
+    for (int i = 0; i < 4; ++i) { op.c[i] = c[i].p; op.ci[i] = c[i].q; op.t[i] = tr[i]; }
     TruncOut to;
     { PhaseTimer pt(ctx, CTM_T_SVD); CTM_TRY(svd_rows_op(ctx, op, chi, cfg, Ut, Vt, dS, &to)); }
     PhaseTimer pt(ctx, CTM_T_PROJ);
-    std::vector<double> Sh, sc;
-    proj_scale(to, kc, cfg.svd_reltol, &Sh, &sc);
-    CTM_HIP_CHECK(ctx, hipMemcpyAsync(dScale, sc.data(), sizeof(double) * kc, hipMemcpyHostToDevice, ctx->stream));
-    if (S_out) CTM_HIP_CHECK(ctx, hipMemcpyAsync(S_out, Sh.data(), sizeof(double) * kc, hipMemcpyHostToDevice, ctx->stream));
-    // P = R conj(U) S^-1/2 = opA(cA) opB(cB) U ... ; Pt = Rt V S^-1/2 = opC(cC) opD(cD) V ...
-    CTM_TRY(corner_chain_times_rowsT(ctx, (int)n, kc, c[0], tr[0], c[1], tr[1], Ut, dScale, P));
-    CTM_TRY(corner_chain_times_rowsT(ctx, (int)n, kc, c[2], tr[2], c[3], tr[3], Vt, dScale, Pt));
+    CTM_TRY(upload_scale(ctx, to, kc, cfg.svd_reltol, dScale, S_out));
+    // P = R conj(U) S^-1/2 = opA(cA) opB(cB) Ut^T ... ; Pt = Rt V S^-1/2 = opC(cC) opD(cD) Vt^H ...
+    CTM_TRY(corner_chain_times_rowsT(ctx, (int)n, k, kc, c[0], tr[0], c[1], tr[1], Ut, false, dScale, tP));
+    CTM_TRY(corner_chain_times_rowsT(ctx, (int)n, k, kc, c[2], tr[2], c[3], tr[3], Vt, true, dScale, tPt));
+    CTM_TRY(io.finish());
     CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     return CTM_OK;
 }
@@ -355,56 +497,69 @@ int ctm_absorb(ctm_ctx* ctx, int dir, const double* const* t, int chi, const int
                double* nC2, double* nT) {
     if (dir < 0 || dir > 3) { ctx->set_error("absorb: bad direction"); return CTM_ERR_BADARG; }
     const AbsorbSpec& sp = kAbsorb[dir];
-    const double *C1 = t[0], *T1 = t[1], *T = t[2], *T2 = t[3], *C2 = t[4], *A = t[5], *P2 = t[6], *Pt2 = t[7], *P1 = t[8], *Pt1 = t[9];
     // D^2 extents of the T tensors follow the site legs they attach to (uniform D assumed per leg pair)
-    const long long Dt = ad[sp.t_leg], Dpt2 = ad[sp.pt2_leg], Dp1 = ad[sp.p1_leg];
+    const long long X = chi, Dt = ad[sp.t_leg], Dpt2 = ad[sp.pt2_leg], Dp1 = ad[sp.p1_leg];
     // T1 carries the D^2 leg shared with Pt1, T2 the one shared with P2
     const long long Dt1 = Dp1 /* neighbour projector leg == this site's leg on that side */, Dt2 = Dpt2;
-    auto t3 = [&](const double* p, int axis, long long D2) {
-        std::vector<long long> d; for (int a = 0; a < 3; ++a) d.push_back(a == axis ? D2 : (long long)chi); return DT(p, d);
-    };
+    auto d3 = [&](int axis, long long D2) { std::vector<long long> d; for (int a = 0; a < 3; ++a) d.push_back(a == axis ? D2 : X); return d; };
+    // nT has one D^2 leg: the site leg opposite to the absorbed T (UP:d, LEFT:r, DOWN:u, RIGHT:l)
+    static const int out_leg[4] = {3, 4, 1, 2};
+    const long long D2out = (long long)ad[out_leg[dir]] * ad[out_leg[dir]];
+    ArenaScope scope(ctx);
+    IO io(ctx);
+    DT r1, r2, r3;
     {
         PhaseTimer pt(ctx, CTM_T_ABSORB);
-        ArenaScope scope(ctx);
-        DT tC1(C1, {chi, chi}), tC2(C2, {chi, chi});
-        DT tT1 = t3(T1, sp.t1_axis, Dt1 * Dt1), tT2 = t3(T2, sp.t2_axis, Dt2 * Dt2);
-        DT tPt1(Pt1, {chi, Dt1 * Dt1, chi}), tP2(P2, {chi, Dt2 * Dt2, chi});
-        DT r1; r1.p = nC1; CTM_TRY(dev_seq_einsum(ctx, sp.nC1, {tPt1, tC1, tT1}, &r1));
-        DT r2; r2.p = nC2; CTM_TRY(dev_seq_einsum(ctx, sp.nC2, {tC2, tT2, tP2}, &r2));
-        DT tT(T, t_view(sp.t_axis, chi, Dt));
-        DT tPt2(Pt2, {chi, Dpt2, Dpt2, chi}), tP1(P1, {chi, Dp1, Dp1, chi});
-        DT tA(A, {ad[0], ad[1], ad[2], ad[3], ad[4]});
-        DT r3; r3.p = nT; CTM_TRY(dev_network(ctx, sp.nT, {tT, tPt2, tA, tA, tP1}, &r3));
+        DT tC1, tT1, tT, tT2, tC2, tA, tP2, tPt2, tP1, tPt1;
+        CTM_TRY(io.in(t[0], {X, X}, &tC1));
+        CTM_TRY(io.in(t[1], d3(sp.t1_axis, Dt1 * Dt1), &tT1));
+        CTM_TRY(io.in(t[2], t_view(sp.t_axis, chi, Dt), &tT));
+        CTM_TRY(io.in(t[3], d3(sp.t2_axis, Dt2 * Dt2), &tT2));
+        CTM_TRY(io.in(t[4], {X, X}, &tC2));
+        CTM_TRY(io.in(t[5], {ad[0], ad[1], ad[2], ad[3], ad[4]}, &tA));
+        CTM_TRY(io.in(t[6], {X, Dt2 * Dt2, X}, &tP2));
+        CTM_TRY(io.in(t[7], {X, Dpt2, Dpt2, X}, &tPt2));
+        CTM_TRY(io.in(t[8], {X, Dp1, Dp1, X}, &tP1));
+        CTM_TRY(io.in(t[9], {X, Dt1 * Dt1, X}, &tPt1));
+        CTM_TRY(io.out(nC1, (size_t)(X * X), &r1));
+        CTM_TRY(io.out(nC2, (size_t)(X * X), &r2));
+        CTM_TRY(io.out(nT, (size_t)(X * X * D2out), &r3));
+        ArenaScope work(ctx);
+        CTM_TRY(dev_seq_einsum(ctx, sp.nC1, {tPt1, tC1, tT1}, &r1));
+        CTM_TRY(dev_seq_einsum(ctx, sp.nC2, {tC2, tT2, tP2}, &r2));
+        CTM_TRY(dev_network(ctx, sp.nT, {tT, tPt2, tA, tA.conj(), tP1}, &r3));
         (void)sp.fuse0;   // the fused output axes are adjacent: the 4-index result IS the 3-index tensor in memory
     }
     if (normalize) {
         PhaseTimer pt(ctx, CTM_T_NORM);
-        long long D2out = 0;
-        {   // nT has one D^2 leg: the site leg opposite to the absorbed T (UP:d, LEFT:r, DOWN:u, RIGHT:l)
-            static const int out_leg[4] = {3, 4, 1, 2};
-            D2out = (long long)ad[out_leg[dir]] * ad[out_leg[dir]];
-        }
-        CTM_TRY(ctm_normalize_inf(ctx, nC1, (long long)chi * chi));
-        CTM_TRY(ctm_normalize_inf(ctx, nC2, (long long)chi * chi));
-        CTM_TRY(ctm_normalize_inf(ctx, nT, (long long)chi * chi * D2out));
+        CTM_TRY(normalize_dt(ctx, r1.view({X * X})));
+        CTM_TRY(normalize_dt(ctx, r2.view({X * X})));
+        CTM_TRY(normalize_dt(ctx, r3.view({X * X * D2out})));
     }
-    return CTM_OK;
+    return io.finish();
 }
 
 // ---- C4v -------------------------------------------------------------------------------------------
 int ctm_c2x2_c4v(ctm_ctx* ctx, int open, const double* a, const double* C, const double* T, int chi, int p, int D, double* out) {
     PhaseTimer pt(ctx, CTM_T_CORNERS);
     ArenaScope scope(ctx);
-    DT tC(C, {chi, chi}), tT(T, {chi, chi, D, D}), tA(a, {p, D, D, D, D});
-    DT res; res.p = out;
-    return dev_network(ctx, open ? "xy,cyuU,xelL,suldr,tULDR->edDcrRst" : "xy,cyuU,xelL,suldr,sULDR->edDcrR",
-                       {tC, tT, tT, tA, tA}, &res);
+    IO io(ctx);
+    DT tC, tT, tA, res;
+    CTM_TRY(io.in(C, {chi, chi}, &tC));
+    CTM_TRY(io.in(T, {chi, chi, D, D}, &tT));
+    CTM_TRY(io.in(a, {p, D, D, D, D}, &tA));
+    const size_t n = (size_t)chi * D * D;
+    CTM_TRY(io.out(out, n * n * (open ? (size_t)p * p : 1), &res));
+    CTM_TRY(dev_network(ctx, open ? "xy,cyuU,xelL,suldr,tULDR->edDcrRst" : "xy,cyuU,xelL,suldr,sULDR->edDcrR",
+                        {tC, tT, tT, tA, tA.conj()}, &res));
+    return io.finish();
 }
 
 int ctm_move_c4v(ctm_ctx* ctx, const double* a, const double* C, const double* T, int chi, int p, int D,
                  const ctm_trunc_cfg* cfg_, double* C_out, double* T_out, double* D_out) {
     ctm_trunc_cfg cfg = cfg_ ? *cfg_ : kDefaultCfg;
     if (!cfg_) cfg.eps_multiplet = 1.0e-12;          // custom_eig.py default used by ctmrg_c4v.py:49-52
+    if (ctx->cplx) { ctx->set_error("move_c4v: the one-site C4v move is float64 only in this build"); return CTM_ERR_UNSUPPORTED; }
     const int n = chi * D * D;
     ArenaScope scope(ctx);
     double *C2X2, *Dv, *P;
@@ -430,65 +585,90 @@ int ctm_move_c4v(ctm_ctx* ctx, const double* a, const double* C, const double* T
 int ctm_rdm2x2(ctm_ctx* ctx, const double* const* t, int chi, const int* ad4, double* out) {
     PhaseTimer pt(ctx, CTM_T_RDM);
     ArenaScope scope(ctx);
+    IO io(ctx);
     static const int cid[4] = {CTM_LU, CTM_RU, CTM_RD, CTM_LD};
     DT c[4];
+    size_t pall = 1;
     for (int i = 0; i < 4; ++i) {
         long long n0, n1; corner_dims(cid[i], chi, ad4 + 5 * i, &n0, &n1);
         const long long p = ad4[5 * i];
-        double* buf; CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)(n0 * n1 * p * p), (void**)&buf));
-        { ArenaScope s2(ctx); CTM_TRY(corner_impl(ctx, cid[i], 1, t[4 * i], t[4 * i + 1], t[4 * i + 2], t[4 * i + 3], chi, ad4 + 5 * i, buf)); }
-        c[i] = DT(buf, {n0, n1, p, p});
+        pall *= (size_t)(p * p);
+        CTM_TRY(alloc_dt(ctx, {n0, n1, p, p}, &c[i]));
+        ArenaScope s2(ctx);
+        CornerIn ci;
+        CTM_TRY(corner_in(io, t + 4 * i, chi, ad4 + 5 * i, cid[i], &ci));
+        CTM_TRY(corner_impl(ctx, cid[i], 1, ci.C, ci.T1, ci.T2, ci.a, chi, ad4 + 5 * i, &c[i]));
+        c[i] = c[i].view({n0, n1, p, p});
     }
-    DT up, lo, r; r.p = out;
+    DT up, lo, r;
+    CTM_TRY(io.out(out, pall, &r));
     CTM_TRY(dev_einsum2(ctx, "akst", c[0], "kbuv", c[1], "abstuv", &up));          // rdm.py:1459-1460
     CTM_TRY(dev_einsum2(ctx, "akst", c[3], "bkuv", c[2], "abstuv", &lo));          // :1527-1528
     // rdm[s0 s1 s2 s3 ; t0 t1 t2 t3]                                                  // :1581-1588
-    return dev_einsum2(ctx, "abstuv", up, "abwxyz", lo, "suwytvxz", &r);
+    CTM_TRY(dev_einsum2(ctx, "abstuv", up, "abwxyz", lo, "suwytvxz", &r));
+    return io.finish();
 }
 
 int ctm_rdm1x1(ctm_ctx* ctx, const double* const* t, int chi, const int* ad, double* out) {
     PhaseTimer pt(ctx, CTM_T_RDM);
     ArenaScope scope(ctx);
+    IO io(ctx);
     const long long X = chi;
-    DT C1(t[0], {X, X}), C2(t[1], {X, X}), C3(t[2], {X, X}), C4(t[3], {X, X});
-    DT T1(t[4], {X, ad[1], ad[1], X}), T2(t[5], {X, ad[4], ad[4], X}), T3(t[6], {ad[3], ad[3], X, X}), T4(t[7], {X, X, ad[2], ad[2]});
-    DT A(t[8], {ad[0], ad[1], ad[2], ad[3], ad[4]});
-    DT r; r.p = out;
+    DT C1, C2, C3, C4, T1, T2, T3, T4, A, r;
+    CTM_TRY(io.in(t[0], {X, X}, &C1)); CTM_TRY(io.in(t[1], {X, X}, &C2)); CTM_TRY(io.in(t[2], {X, X}, &C3)); CTM_TRY(io.in(t[3], {X, X}, &C4));
+    CTM_TRY(io.in(t[4], {X, ad[1], ad[1], X}, &T1)); CTM_TRY(io.in(t[5], {X, ad[4], ad[4], X}, &T2));
+    CTM_TRY(io.in(t[6], {ad[3], ad[3], X, X}, &T3)); CTM_TRY(io.in(t[7], {X, X, ad[2], ad[2]}, &T4));
+    CTM_TRY(io.in(t[8], {ad[0], ad[1], ad[2], ad[3], ad[4]}, &A));
+    CTM_TRY(io.out(out, (size_t)ad[0] * ad[0], &r));
     // left column, then site ket/bra, then right column (every pairwise step is a plain GEMM)
-    return dev_seq_einsum(ctx, "ab,bUVc,aiLM,ih,XYhg,sULXR,tVMYQ,ce,eRQf,fg->st", {C1, T1, T4, C4, T3, A, A, C2, T2, C3}, &r);
+    CTM_TRY(dev_seq_einsum(ctx, "ab,bUVc,aiLM,ih,XYhg,sULXR,tVMYQ,ce,eRQf,fg->st", {C1, T1, T4, C4, T3, A, A.conj(), C2, T2, C3}, &r));
+    return io.finish();
 }
 
 int ctm_rdm2x1(ctm_ctx* ctx, const double* const* t, int chi, const int* ad2, double* out) {
     // tensors12: C1,T1a,T4,C4,T3a,a0 (site 0), C2,T2,C3,T1b,T3b,a1 (site 1 = coord+(1,0))
     PhaseTimer pt(ctx, CTM_T_RDM);
     ArenaScope scope(ctx);
+    IO io(ctx);
     const long long X = chi; const int* a0 = ad2; const int* a1 = ad2 + 5;
-    DT C1(t[0], {X, X}), T1a(t[1], {X, a0[1], a0[1], X}), T4(t[2], {X, X, a0[2], a0[2]}), C4(t[3], {X, X}), T3a(t[4], {a0[3], a0[3], X, X});
-    DT A0(t[5], {a0[0], a0[1], a0[2], a0[3], a0[4]});
-    DT C2(t[6], {X, X}), T2(t[7], {X, a1[4], a1[4], X}), C3(t[8], {X, X}), T1b(t[9], {X, a1[1], a1[1], X}), T3b(t[10], {a1[3], a1[3], X, X});
-    DT A1(t[11], {a1[0], a1[1], a1[2], a1[3], a1[4]});
-    DT left, right, r; r.p = out;
-    CTM_TRY(dev_seq_einsum(ctx, "ab,bUVc,aiLM,ih,XYhg,sULXR,tVMYQ->cRQgst", {C1, T1a, T4, C4, T3a, A0, A0}, &left));
-    CTM_TRY(dev_seq_einsum(ctx, "ce,eRQf,fg,jUVc,XYhg,sULXR,tVMYQ->jLMhst", {C2, T2, C3, T1b, T3b, A1, A1}, &right));
-    return dev_einsum2(ctx, "cRQgst", left, "cRQguv", right, "sutv", &r);
+    DT C1, T1a, T4, C4, T3a, A0, C2, T2, C3, T1b, T3b, A1;
+    CTM_TRY(io.in(t[0], {X, X}, &C1)); CTM_TRY(io.in(t[1], {X, a0[1], a0[1], X}, &T1a)); CTM_TRY(io.in(t[2], {X, X, a0[2], a0[2]}, &T4));
+    CTM_TRY(io.in(t[3], {X, X}, &C4)); CTM_TRY(io.in(t[4], {a0[3], a0[3], X, X}, &T3a));
+    CTM_TRY(io.in(t[5], {a0[0], a0[1], a0[2], a0[3], a0[4]}, &A0));
+    CTM_TRY(io.in(t[6], {X, X}, &C2)); CTM_TRY(io.in(t[7], {X, a1[4], a1[4], X}, &T2)); CTM_TRY(io.in(t[8], {X, X}, &C3));
+    CTM_TRY(io.in(t[9], {X, a1[1], a1[1], X}, &T1b)); CTM_TRY(io.in(t[10], {a1[3], a1[3], X, X}, &T3b));
+    CTM_TRY(io.in(t[11], {a1[0], a1[1], a1[2], a1[3], a1[4]}, &A1));
+    DT left, right, r;
+    CTM_TRY(io.out(out, (size_t)a0[0] * a0[0] * a1[0] * a1[0], &r));
+    CTM_TRY(dev_seq_einsum(ctx, "ab,bUVc,aiLM,ih,XYhg,sULXR,tVMYQ->cRQgst", {C1, T1a, T4, C4, T3a, A0, A0.conj()}, &left));
+    CTM_TRY(dev_seq_einsum(ctx, "ce,eRQf,fg,jUVc,XYhg,sULXR,tVMYQ->jLMhst", {C2, T2, C3, T1b, T3b, A1, A1.conj()}, &right));
+    CTM_TRY(dev_einsum2(ctx, "cRQgst", left, "cRQguv", right, "sutv", &r));
+    return io.finish();
 }
 
 int ctm_rdm1x2(ctm_ctx* ctx, const double* const* t, int chi, const int* ad2, double* out) {
     // tensors12: C1,T1,C2,T4a,T2a,a0 (site 0), C4,T3,C3,T4b,T2b,a1 (site 1 = coord+(0,1))
     PhaseTimer pt(ctx, CTM_T_RDM);
     ArenaScope scope(ctx);
+    IO io(ctx);
     const long long X = chi; const int* a0 = ad2; const int* a1 = ad2 + 5;
-    DT C1(t[0], {X, X}), T1(t[1], {X, a0[1], a0[1], X}), C2(t[2], {X, X}), T4a(t[3], {X, X, a0[2], a0[2]}), T2a(t[4], {X, a0[4], a0[4], X});
-    DT A0(t[5], {a0[0], a0[1], a0[2], a0[3], a0[4]});
-    DT C4(t[6], {X, X}), T3(t[7], {a1[3], a1[3], X, X}), C3(t[8], {X, X}), T4b(t[9], {X, X, a1[2], a1[2]}), T2b(t[10], {X, a1[4], a1[4], X});
-    DT A1(t[11], {a1[0], a1[1], a1[2], a1[3], a1[4]});
-    DT up, lo, r; r.p = out;
-    CTM_TRY(dev_seq_einsum(ctx, "ab,bUVc,ce,aiLM,eRQf,sULXR,tVMYQ->iXYfst", {C1, T1, C2, T4a, T2a, A0, A0}, &up));
-    CTM_TRY(dev_seq_einsum(ctx, "jh,XYhg,fg,ijLM,eRQf,sULXR,tVMYQ->iUVest", {C4, T3, C3, T4b, T2b, A1, A1}, &lo));
-    return dev_einsum2(ctx, "iXYfst", up, "iXYfuv", lo, "sutv", &r);
+    DT C1, T1, C2, T4a, T2a, A0, C4, T3, C3, T4b, T2b, A1;
+    CTM_TRY(io.in(t[0], {X, X}, &C1)); CTM_TRY(io.in(t[1], {X, a0[1], a0[1], X}, &T1)); CTM_TRY(io.in(t[2], {X, X}, &C2));
+    CTM_TRY(io.in(t[3], {X, X, a0[2], a0[2]}, &T4a)); CTM_TRY(io.in(t[4], {X, a0[4], a0[4], X}, &T2a));
+    CTM_TRY(io.in(t[5], {a0[0], a0[1], a0[2], a0[3], a0[4]}, &A0));
+    CTM_TRY(io.in(t[6], {X, X}, &C4)); CTM_TRY(io.in(t[7], {a1[3], a1[3], X, X}, &T3)); CTM_TRY(io.in(t[8], {X, X}, &C3));
+    CTM_TRY(io.in(t[9], {X, X, a1[2], a1[2]}, &T4b)); CTM_TRY(io.in(t[10], {X, a1[4], a1[4], X}, &T2b));
+    CTM_TRY(io.in(t[11], {a1[0], a1[1], a1[2], a1[3], a1[4]}, &A1));
+    DT up, lo, r;
+    CTM_TRY(io.out(out, (size_t)a0[0] * a0[0] * a1[0] * a1[0], &r));
+    CTM_TRY(dev_seq_einsum(ctx, "ab,bUVc,ce,aiLM,eRQf,sULXR,tVMYQ->iXYfst", {C1, T1, C2, T4a, T2a, A0, A0.conj()}, &up));
+    CTM_TRY(dev_seq_einsum(ctx, "jh,XYhg,fg,ijLM,eRQf,sULXR,tVMYQ->iUVest", {C4, T3, C3, T4b, T2b, A1, A1.conj()}, &lo));
+    CTM_TRY(dev_einsum2(ctx, "iXYfst", up, "iXYfuv", lo, "sutv", &r));
+    return io.finish();
 }
 
 int ctm_rdm_c4v(ctm_ctx* ctx, int which, const double* a, const double* C, const double* T, int chi, int p, int D, double* out) {
+    if (ctx->cplx) { ctx->set_error("rdm_c4v: float64 only in this build"); return CTM_ERR_UNSUPPORTED; }
     PhaseTimer pt(ctx, CTM_T_RDM);
     ArenaScope scope(ctx);
     const long long n = (long long)chi * D * D, X = chi, D2 = (long long)D * D;
@@ -546,17 +726,23 @@ int ctm_init_piece(ctm_ctx* ctx, int kind, const double* a, const int* ad, doubl
     for (int i = 0; i < 5; ++i) dims[i] = ad[i];
     for (int i = 0; i < 5; ++i) if (!is_kept[i]) { perm[np_++] = i; Ktr *= ad[i]; }
     for (int i = 0; i < nk; ++i) { perm[np_++] = kept[kind][i]; Mk *= ad[kept[kind][i]]; }
-    double *X, *G;
-    CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)(Ktr * Mk), (void**)&X));
-    CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)(Mk * Mk), (void**)&G));
-    CTM_TRY(permute_f64(ctx, a, X, 5, dims, perm));
-    GemmDesc g; g.M = (int)Mk; g.N = (int)Mk; g.K = (int)Ktr; g.A = X; g.sam = 1; g.sak = Mk; g.B = X; g.sbk = Mk; g.sbn = 1; g.C = G; g.ldc = Mk;
-    CTM_TRY(gemm_f64(ctx, g));
+    IO io(ctx);
+    DT A, X, G, O;
+    CTM_TRY(io.in(a, {dims[0], dims[1], dims[2], dims[3], dims[4]}, &A));
+    CTM_TRY(alloc_dt(ctx, {Ktr, Mk}, &X));
+    CTM_TRY(alloc_dt(ctx, {Mk, Mk}, &G));
+    CTM_TRY(io.out(out, (size_t)(Mk * Mk), &O));
+    CTM_TRY(permute_f64(ctx, A.p, X.p, 5, dims, perm));
+    if (A.q) CTM_TRY(permute_f64(ctx, A.q, X.q, 5, dims, perm));
+    // G[(kept ket),(kept bra)] = sum_traced X[.,ket] conj(X[.,bra])
+    CTM_TRY(xgemm(ctx, (int)Mk, (int)Mk, (int)Ktr, xm(X, Mk, true), xm(X, Mk, false, true), G.p, G.q, Mk));
     // G[(e f [g]), (a b [c])] -> out[e a f b [g c]]
     long long gd[6]; int gp[6];
     for (int i = 0; i < nk; ++i) { gd[i] = ad[kept[kind][i]]; gd[nk + i] = ad[kept[kind][i]]; gp[2 * i] = i; gp[2 * i + 1] = nk + i; }
-    CTM_TRY(permute_f64(ctx, G, out, 2 * nk, gd, gp));
-    return ctm_normalize_inf(ctx, out, Mk * Mk);
+    CTM_TRY(permute_f64(ctx, G.p, O.p, 2 * nk, gd, gp));
+    if (G.q) CTM_TRY(permute_f64(ctx, G.q, O.q, 2 * nk, gd, gp));
+    CTM_TRY(normalize_dt(ctx, O.view({Mk * Mk})));
+    return io.finish();
 }
 
 }  // extern "C"

@@ -49,10 +49,11 @@ const char* ctm_version(void) { return "ctm_hip 0.1 (gfx950, f64)"; }
 int ctm_create(ctm_ctx** out, void* hip_stream, int dtype) {
     if (!out) return CTM_ERR_BADARG;
     *out = nullptr;
-    if (dtype != CTM_F64) return CTM_ERR_UNSUPPORTED;   // complex128 planes: not in this build
+    if (dtype != CTM_F64 && dtype != CTM_C128) return CTM_ERR_UNSUPPORTED;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return CTM_ERR_HIP;
     ctm_ctx* c = new ctm_ctx();
+    c->cplx = (dtype == CTM_C128);
     (void)hipGetDevice(&c->device);
     if (hip_stream) c->stream = (hipStream_t)hip_stream;
     else { if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return CTM_ERR_HIP; } c->own_stream = true; }
@@ -143,22 +144,58 @@ int ctm_timers(ctm_ctx* ctx, double* out8, int reset) {
 
 int ctm_gemm(ctm_ctx* ctx, int transA, int transB, int M, int N, int K, double alpha, const double* A, long long lda,
              const double* B, long long ldb, double beta, double* C, long long ldc) {
-    GemmDesc d;
-    d.M = M; d.N = N; d.K = K; d.alpha = alpha; d.beta = beta;
-    d.A = A; if (transA) { d.sam = 1; d.sak = lda; } else { d.sam = lda; d.sak = 1; }
-    d.B = B; if (transB) { d.sbk = 1; d.sbn = ldb; } else { d.sbk = ldb; d.sbn = 1; }
-    d.C = C; d.ldc = ldc;
-    return gemm_f64(ctx, d);
+    if (!ctx->cplx) {
+        GemmDesc d;
+        d.M = M; d.N = N; d.K = K; d.alpha = alpha; d.beta = beta;
+        d.A = A; if (transA) { d.sam = 1; d.sak = lda; } else { d.sam = lda; d.sak = 1; }
+        d.B = B; if (transB) { d.sbk = 1; d.sbn = ldb; } else { d.sbk = ldb; d.sbn = 1; }
+        d.C = C; d.ldc = ldc;
+        return gemm_f64(ctx, d);
+    }
+    // complex128: trans = 0 'N', 1 'T', 2 'C' (conjugate transpose); dense operands (ld == row length), alpha real, beta == 0
+    const long long ra = transA ? K : M, ca = transA ? M : K, rb = transB ? N : K, cb = transB ? K : N;
+    if (lda != ca || ldb != cb || ldc != N || beta != 0.0) { ctx->set_error("gemm(c128): dense operands and beta == 0 only"); return CTM_ERR_UNSUPPORTED; }
+    ArenaScope scope(ctx);
+    double *a, *b, *c;
+    const size_t na = (size_t)ra * ca, nb = (size_t)rb * cb, nc = (size_t)M * N;
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * 2 * na, (void**)&a));
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * 2 * nb, (void**)&b));
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * 2 * nc, (void**)&c));
+    CTM_TRY(deinterleave_c128(ctx, A, a, a + na, na));
+    CTM_TRY(deinterleave_c128(ctx, B, b, b + nb, nb));
+    XM xa{a, a + na, lda, transA != 0, transA == 2}, xb{b, b + nb, ldb, transB != 0, transB == 2};
+    CTM_TRY(xgemm(ctx, M, N, K, xa, xb, c, c + nc, N));
+    if (alpha != 1.0) {
+        double* s = ctx->d_scratch + 9;
+        const double inv = 1.0 / alpha;
+        CTM_HIP_CHECK(ctx, hipMemcpyAsync(s, &inv, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        CTM_TRY(div_by_device_scalar(ctx, c, 2 * nc, s, 0));
+    }
+    return interleave_c128(ctx, c, c + nc, C, nc);
 }
 
 int ctm_permute(ctm_ctx* ctx, const double* in, double* out, int nd, const long long* dims, const int* perm) {
-    return permute_f64(ctx, in, out, nd, dims, perm);
+    if (!ctx->cplx) return permute_f64(ctx, in, out, nd, dims, perm);
+    if (nd + 1 > CTM_MAXD) { ctx->set_error("permute(c128): rank"); return CTM_ERR_UNSUPPORTED; }
+    long long d2[CTM_MAXD]; int p2[CTM_MAXD];
+    for (int i = 0; i < nd; ++i) { d2[i] = dims[i]; p2[i] = perm[i]; }
+    d2[nd] = 2; p2[nd] = nd;                       // the (re,im) pair travels as an innermost axis
+    return permute_f64(ctx, in, out, nd + 1, d2, p2);
 }
 
 int ctm_normalize_inf(ctm_ctx* ctx, double* x, long long n) {
     double* s = ctx->d_scratch + 8;
-    CTM_TRY(absmax_f64(ctx, x, (size_t)n, s));
-    return div_by_device_scalar(ctx, x, (size_t)n, s, 0);
+    if (!ctx->cplx) {
+        CTM_TRY(absmax_f64(ctx, x, (size_t)n, s));
+        return div_by_device_scalar(ctx, x, (size_t)n, s, 0);
+    }
+    ArenaScope scope(ctx);
+    double* pl;
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * 2 * (size_t)n, (void**)&pl));
+    CTM_TRY(deinterleave_c128(ctx, x, pl, pl + n, (size_t)n));
+    CTM_TRY(absmax_c128(ctx, pl, pl + n, (size_t)n, s));
+    return div_by_device_scalar(ctx, x, 2 * (size_t)n, s, 0);
 }
 
 }  // extern "C"

@@ -396,6 +396,24 @@ int gemm_f64(ctm_ctx* ctx, const GemmDesc& d) {
     return CTM_OK;
 }
 
+int xgemm(ctm_ctx* ctx, int M, int N, int K, const XM& A, const XM& B, double* Cre, double* Cim, long long ldc, const double* colscale) {
+    GemmDesc g;
+    g.M = M; g.N = N; g.K = K;
+    if (A.t) { g.sam = 1; g.sak = A.ld; } else { g.sam = A.ld; g.sak = 1; }
+    if (B.t) { g.sbk = 1; g.sbn = B.ld; } else { g.sbk = B.ld; g.sbn = 1; }
+    g.ldc = ldc; g.colscale = colscale;
+    if (!A.im && !B.im) {
+        g.A = A.re; g.B = B.re; g.C = Cre;
+        return gemm_f64(ctx, g);
+    }
+    if (!A.im || !B.im || !Cim) { ctx->set_error("xgemm: mixed real/complex operands"); return CTM_ERR_BADARG; }
+    const double sA = A.c ? -1.0 : 1.0, sB = B.c ? -1.0 : 1.0;
+    g.A = A.re; g.B = B.re; g.C = Cre; g.alpha = 1.0; g.beta = 0.0;        CTM_TRY(gemm_f64(ctx, g));
+    g.A = A.im; g.B = B.im; g.C = Cre; g.alpha = -sA * sB; g.beta = 1.0;   CTM_TRY(gemm_f64(ctx, g));
+    g.A = A.re; g.B = B.im; g.C = Cim; g.alpha = sB; g.beta = 0.0;         CTM_TRY(gemm_f64(ctx, g));
+    g.A = A.im; g.B = B.re; g.C = Cim; g.alpha = sA; g.beta = 1.0;         return gemm_f64(ctx, g);
+}
+
 void gemm_timing_drain(ctm_ctx* ctx) {
     if (ctx->ev_pending.empty()) { ctx->ev_next = 0; return; }
     (void)hipStreamSynchronize(ctx->stream);

@@ -231,6 +231,176 @@ __global__ __launch_bounds__(1024) void small_eig_kernel(SmallEigParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// complex128 variant.  A panel of bc = 16 complex rows is stored as 16 real rows (real parts) followed by 16 real
+// rows (imaginary parts), so a pair of panels is 64 REAL rows and the Gram / apply GEMMs of jacobi_rows() run
+// unchanged on real data.  This kernel turns the 64 x 64 real Gram of such a pair into the 32 x 32 Hermitian Gram
+//   G = W W^H :  Re G[a][c] = <x_a,x_c> + <y_a,y_c>,   Im G[a][c] = <y_a,x_c> - <x_a,y_c>
+// diagonalises it by two-sided cyclic Jacobi with complex rotations R = diag(1, e^{-i phi}) [[c, s], [-s, c]]
+// (phi = arg g_pq), and writes the unitary row transformation Q = J^H as the 64 x 64 real matrix the apply GEMM
+// consumes (in[.] x out[.], real/imag rows interleaved per panel like the data).
+// ---------------------------------------------------------------------------------------------
+constexpr int MC = 32;    // complex Gram order (2 panels of 16)
+__device__ __forceinline__ int re_row(int a) { return a + (a >= 16 ? 16 : 0); }
+
+__global__ __launch_bounds__(256) void small_eig_c_kernel(SmallEigParams p) {
+    __shared__ double Gs[2 * MC][2 * MC + 1];
+    __shared__ double Wr[MC][MC + 1], Wi[MC][MC + 1], Jr[MC][MC + 1], Ji[MC][MC + 1];
+    __shared__ double cs_c[MC / 2], cs_s[MC / 2], ph_r[MC / 2], ph_i[MC / 2];
+    __shared__ int pr_p[MC / 2], pr_q[MC / 2];
+    __shared__ double red[4];
+    __shared__ int rot_flag;
+    __shared__ int round_rot[2];
+    __shared__ unsigned char pair_tab[MC - 1][MC / 2][2];
+    __shared__ int rank_of[MC];
+    const int tid = threadIdx.x, NTH = 256, mh = 2 * MC;
+    const double* G = p.G + (size_t)blockIdx.x * mh * mh;
+    double* Jout = p.J + (size_t)blockIdx.x * mh * mh;
+    {
+        double acc[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) acc[u] = 0.0;
+        for (int s = 0; s < p.nsplit; ++s) {
+            const double* Gq = G + (size_t)s * p.split_stride;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) acc[u] += Gq[tid + u * NTH];
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { const int q = tid + u * NTH; Gs[q / mh][q % mh] = acc[u]; }
+    }
+    __syncthreads();
+    for (int q = tid; q < MC * MC; q += NTH) {
+        const int a = q / MC, c = q - a * MC;
+        const int ra = re_row(a), rc = re_row(c);
+        Wr[a][c] = Gs[ra][rc] + Gs[ra + 16][rc + 16];
+        Wi[a][c] = (a == c) ? 0.0 : (Gs[ra + 16][rc] - Gs[ra][rc + 16]);
+        Jr[a][c] = (a == c) ? 1.0 : 0.0; Ji[a][c] = 0.0;
+    }
+    __syncthreads();
+    {
+        double srel = 0.0, sabs = 0.0;
+        for (int q = tid; q < MC * MC; q += NTH) {
+            const int r = q / MC, c = q - r * MC;
+            if (r < c) {
+                const double g = sqrt(Wr[r][c] * Wr[r][c] + Wi[r][c] * Wi[r][c]), a = Wr[r][r], b = Wr[c][c];
+                if (g > 0.0) {
+                    const double sc = sqrt(fabs(a * b));
+                    srel = fmax(srel, g / fmax(sc, p.tau2));
+                    if (sc > 0.0) sabs = fmax(sabs, g / sc);
+                }
+            }
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            srel = fmax(srel, __shfl_down(srel, off, 64));
+            sabs = fmax(sabs, __shfl_down(sabs, off, 64));
+        }
+        if ((tid & 63) == 0) red[tid >> 6] = srel;
+        __syncthreads();
+        if (tid == 0) {
+            const double v = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+            atomicMax(p.stat_rel, (unsigned long long)__double_as_longlong(v));
+            red[0] = v;
+        }
+        __syncthreads();
+        srel = red[0];
+        __syncthreads();
+        if ((tid & 63) == 0) red[tid >> 6] = sabs;
+        __syncthreads();
+        if (tid == 0) atomicMax(p.stat_abs, (unsigned long long)__double_as_longlong(fmax(fmax(red[0], red[1]), fmax(red[2], red[3]))));
+        __syncthreads();
+        if (srel <= p.tol) { if (tid == 0) p.flags[blockIdx.x] = 0; return; }
+        if (tid == 0) p.flags[blockIdx.x] = 1;
+    }
+    const int half = MC / 2, mm1 = MC - 1;
+    for (int q = tid; q < mm1 * half; q += NTH) {
+        const int r = q / half, k = q - r * half;
+        int pi, qi;
+        if (k == 0) { pi = mm1; qi = r % mm1; }
+        else { pi = (r + k) % mm1; qi = (r - k + mm1) % mm1; }
+        if (pi > qi) { const int t = pi; pi = qi; qi = t; }
+        pair_tab[r][k][0] = (unsigned char)pi; pair_tab[r][k][1] = (unsigned char)qi;
+    }
+    __syncthreads();
+    const int k2 = tid % half, k1 = tid / half;     // this thread owns the 2x2 block (pair k1, pair k2) and rows k1, k1+16 of J
+    for (int sweep = 0; sweep < p.max_sweeps; ++sweep) {
+        if (tid == 0) { rot_flag = 0; round_rot[0] = 0; }
+        __syncthreads();
+        for (int r = 0; r < mm1; ++r) {
+            if (tid == 0) round_rot[(r + 1) & 1] = 0;
+            if (tid < half) {
+                const int pi = pair_tab[r][tid][0], qi = pair_tab[r][tid][1];
+                const double a = Wr[pi][pi], b = Wr[qi][qi], gr = Wr[pi][qi], gi = Wi[pi][qi];
+                const double g = sqrt(gr * gr + gi * gi);
+                double c = 1.0, s = 0.0, er = 1.0, ei = 0.0;
+                if (g != 0.0 && g > p.tol * fmax(sqrt(fabs(a * b)), p.tau2)) {
+                    er = gr / g; ei = gi / g;
+                    const double d = b - a, g2 = 2.0 * g;
+                    const double h = sqrt(d * d + g2 * g2);
+                    const double t = g2 / (d + (d >= 0.0 ? h : -h));
+                    c = 1.0 / sqrt(1.0 + t * t);
+                    s = t * c;
+                    rot_flag = 1;
+                    round_rot[r & 1] = 1;
+                }
+                cs_c[tid] = c; cs_s[tid] = s; ph_r[tid] = er; ph_i[tid] = ei; pr_p[tid] = pi; pr_q[tid] = qi;
+            }
+            __syncthreads();
+            if (round_rot[r & 1]) {
+                const double c2 = cs_c[k2], s2 = cs_s[k2], e2r = ph_r[k2], e2i = ph_i[k2];
+                const double c1 = cs_c[k1], s1 = cs_s[k1], e1r = ph_r[k1], e1i = ph_i[k1];
+                const int p2 = pr_p[k2], q2 = pr_q[k2], p1 = pr_p[k1], q1 = pr_q[k1];
+                // loads
+                double b00r = Wr[p1][p2], b00i = Wi[p1][p2], b01r = Wr[p1][q2], b01i = Wi[p1][q2];
+                double b10r = Wr[q1][p2], b10i = Wi[q1][p2], b11r = Wr[q1][q2], b11i = Wi[q1][q2];
+                double jpr[2], jpi[2], jqr[2], jqi[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) { const int i = k1 + u * 16; jpr[u] = Jr[i][p2]; jpi[u] = Ji[i][p2]; jqr[u] = Jr[i][q2]; jqi[u] = Ji[i][q2]; }
+                // column q2 *= e^{-i phi2}
+                double x;
+                x = b01r * e2r + b01i * e2i; b01i = b01i * e2r - b01r * e2i; b01r = x;
+                x = b11r * e2r + b11i * e2i; b11i = b11i * e2r - b11r * e2i; b11r = x;
+                // column rotation
+                const double t00r = c2 * b00r - s2 * b01r, t00i = c2 * b00i - s2 * b01i, t01r = s2 * b00r + c2 * b01r, t01i = s2 * b00i + c2 * b01i;
+                double t10r = c2 * b10r - s2 * b11r, t10i = c2 * b10i - s2 * b11i, t11r = s2 * b10r + c2 * b11r, t11i = s2 * b10i + c2 * b11i;
+                // row q1 *= e^{+i phi1}
+                x = t10r * e1r - t10i * e1i; t10i = t10i * e1r + t10r * e1i; t10r = x;
+                x = t11r * e1r - t11i * e1i; t11i = t11i * e1r + t11r * e1i; t11r = x;
+                // row rotation + stores
+                const bool dg = (k1 == k2);
+                Wr[p1][p2] = c1 * t00r - s1 * t10r; Wi[p1][p2] = dg ? 0.0 : (c1 * t00i - s1 * t10i);
+                Wr[p1][q2] = c1 * t01r - s1 * t11r; Wi[p1][q2] = c1 * t01i - s1 * t11i;
+                Wr[q1][p2] = s1 * t00r + c1 * t10r; Wi[q1][p2] = s1 * t00i + c1 * t10i;
+                Wr[q1][q2] = s1 * t01r + c1 * t11r; Wi[q1][q2] = dg ? 0.0 : (s1 * t01i + c1 * t11i);
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int i = k1 + u * 16;
+                    const double qr = jqr[u] * e2r + jqi[u] * e2i, qi_ = jqi[u] * e2r - jqr[u] * e2i;
+                    Jr[i][p2] = c2 * jpr[u] - s2 * qr; Ji[i][p2] = c2 * jpi[u] - s2 * qi_;
+                    Jr[i][q2] = s2 * jpr[u] + c2 * qr; Ji[i][q2] = s2 * jpi[u] + c2 * qi_;
+                }
+            }
+            __syncthreads();
+        }
+        if (rot_flag == 0) break;
+        __syncthreads();
+    }
+    if (tid < MC) {
+        const double d = Wr[tid][tid];
+        int rk = 0;
+        for (int j = 0; j < MC; ++j) { const double dj = Wr[j][j]; rk += (dj > d) || (dj == d && j < tid); }
+        rank_of[tid] = rk;
+    }
+    __syncthreads();
+    // Jhat[in][out]: out_re(k) <- +Jr in_re(a), +Ji in_im(a) ; out_im(k) <- -Ji in_re(a), +Jr in_im(a)
+    for (int q = tid; q < MC * MC; q += NTH) {
+        const int a = q / MC, k = q - a * MC;
+        const int ia = re_row(a), ok = re_row(rank_of[k]);
+        const double jr = Jr[a][k], ji = Ji[a][k];
+        Jout[(size_t)ia * mh + ok] = jr;          Jout[(size_t)(ia + 16) * mh + ok] = ji;
+        Jout[(size_t)ia * mh + ok + 16] = -ji;    Jout[(size_t)(ia + 16) * mh + ok + 16] = jr;
+    }
+}
+
 // per-round batched-GEMM offset tables (built on the host once per (blocks, leading dim, block size))
 struct RRTables {
     int nbk = 0, b = 0, nsplit = 1, klen = 0; long long ld = 0;
@@ -287,8 +457,9 @@ int get_tables(ctm_ctx* ctx, int nbk, long long ld, int b, int Cg, RRTables** ou
 // its pair and finishes reading it before it writes.
 // ktop > 0: only the ktop largest rows need full relative accuracy -- pairs of smaller rows are measured against
 // tau = (ktop-th largest row norm), which still bounds the spectral norm of the remaining rows by tau(1 + R tol).
-int jacobi_rows(ctm_ctx* ctx, double* X, int R, long long ld, int Cg, int Ctot, int b, int ktop, double fro, int max_sweeps) {
+int jacobi_rows(ctm_ctx* ctx, double* X, int R, long long ld, int Cg, int Ctot, int b, int ktop, double fro, int max_sweeps, bool cplx = false) {
     const int nbk = R / b, rounds = nbk - 1, pairs = nbk / 2, m = 2 * b;
+    if (cplx && b != 32) { ctx->set_error("jacobi_rows: complex panels are 16 + 16 real rows"); return CTM_ERR_BADARG; }
     RRTables* T;
     CTM_TRY(get_tables(ctx, nbk, ld, b, Cg, &T));
     ArenaScope scope(ctx);
@@ -304,11 +475,18 @@ int jacobi_rows(ctm_ctx* ctx, double* X, int R, long long ld, int Cg, int Ctot, 
     ctx->last_sweeps = 0;
     for (int sweep = 0; sweep < max_sweeps; ++sweep) {
         double tau2 = floor2;
-        if (ktop > 0 && ktop < R) {
+        if (ktop > 0 && ktop < (cplx ? R / 2 : R)) {
             CTM_TRY(row_norms(ctx, X, R, Cg, ld, norms));
             CTM_HIP_CHECK(ctx, hipMemcpyAsync(h.data(), norms, sizeof(double) * R, hipMemcpyDeviceToHost, ctx->stream));
             CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-            std::nth_element(h.begin(), h.begin() + (ktop - 1), h.end(), std::greater<double>());
+            int nr = R;
+            if (cplx) {      // squared norm of a complex row = its real-part row + its imaginary-part row (16 + 16 per panel)
+                nr = R / 2;
+                std::vector<double> hc(nr);
+                for (int cr = 0; cr < nr; ++cr) { const int rr = (cr / 16) * 32 + (cr % 16); hc[cr] = std::sqrt(h[rr] * h[rr] + h[rr + 16] * h[rr + 16]); }
+                std::copy(hc.begin(), hc.end(), h.begin());
+            }
+            std::nth_element(h.begin(), h.begin() + (ktop - 1), h.begin() + nr, std::greater<double>());
             tau2 = std::max(floor2, h[ktop - 1] * h[ktop - 1]);
         }
         CTM_HIP_CHECK(ctx, hipMemsetAsync(stat, 0, 2 * sizeof(double), ctx->stream));
@@ -323,7 +501,8 @@ int jacobi_rows(ctm_ctx* ctx, double* X, int R, long long ld, int Cg, int Ctot, 
             SmallEigParams sp;
             sp.G = G; sp.nsplit = T->nsplit; sp.split_stride = (long long)pairs * m * m; sp.J = J; sp.m = m; sp.tol = ctx->jacobi_tol * 0.1; sp.max_sweeps = (pairs == 1) ? 12 : ctx->jacobi_inner_sweeps;
             sp.tau2 = tau2; sp.stat_rel = stat; sp.stat_abs = stat + 1; sp.flags = flags;
-            hipLaunchKernelGGL(small_eig_kernel, dim3(pairs), dim3(m > 32 ? 1024 : 256), 0, ctx->stream, sp);
+            if (cplx) hipLaunchKernelGGL(small_eig_c_kernel, dim3(pairs), dim3(256), 0, ctx->stream, sp);
+            else hipLaunchKernelGGL(small_eig_kernel, dim3(pairs), dim3(m > 32 ? 1024 : 256), 0, ctx->stream, sp);
             GemmDesc a;
             a.M = m; a.N = Ctot; a.K = m;
             a.A = J; a.sam = 1; a.sak = m;                       // J^T
@@ -634,11 +813,304 @@ int svd_iter(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* Ut, double
     return CTM_OK;
 }
 
+// =============================================================================================
+// complex128 decomposition.  Working matrices hold complex rows in the panel layout of small_eig_c_kernel
+// (16 real-part rows, then the 16 imaginary-part rows of the same complex rows); operators and results are planar.
+// Row factors follow the real convention with ^T -> ^H:  Ut rows = u_k^H, Vt rows = v_k^H,  M = Ut^H diag(S) Vt.
+// =============================================================================================
+constexpr int BC = 16;
+inline int crow_re(int cr) { return (cr / BC) * (2 * BC) + (cr % BC); }
+
+// X (2*np real rows x ld) <- panel layout of [ M (n x n complex, planar) | identity (np complex columns) if with_eye ]
+__global__ void fill_wq_c_kernel(const double* Mr, const double* Mi, int n, double* X, int np, long long ld, int with_eye) {
+    const long long W = n + (with_eye ? np : 0);
+    const size_t tot = (size_t)np * W;
+    for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < tot; q += (size_t)gridDim.x * blockDim.x) {
+        const long long r = q / W, c = q - r * W;
+        double vr, vi = 0.0;
+        if (c < n) { vr = (r < n) ? Mr[r * n + c] : 0.0; vi = (r < n) ? Mi[r * n + c] : 0.0; }
+        else vr = ((c - n) == r) ? 1.0 : 0.0;
+        const long long rr = (r / BC) * (2 * BC) + (r % BC);
+        X[rr * ld + c] = vr; X[(rr + BC) * ld + c] = vi;
+    }
+}
+
+// dst = i * src on panel rows: real-part rows <- -imag rows, imag rows <- real-part rows
+__global__ void panel_times_i_kernel(const double* src, long long lds, double* dst, long long ldd, int R, int cols) {
+    const size_t tot = (size_t)R * cols;
+    for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < tot; q += (size_t)gridDim.x * blockDim.x) {
+        const long long r = q / cols, c = q - r * cols;
+        const bool is_im = ((r / BC) & 1) != 0;
+        dst[r * ldd + c] = is_im ? src[(r - BC) * lds + c] : -src[(r + BC) * lds + c];
+    }
+}
+
+// per real row r of a panel matrix: out[r] = norm of the complex row it belongs to (both of its real rows get the value)
+__global__ void panel_combine_kernel(const double* nr, double* out, int R) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < R) {
+        const int re = ((r / BC) & 1) ? r - BC : r;
+        out[r] = sqrt(nr[re] * nr[re] + nr[re + BC] * nr[re + BC]);
+    }
+}
+
+// row norms of the np complex rows of a panel matrix -> host (hc[np]); `norms` is device scratch of 2*np doubles
+int panel_row_norms(ctm_ctx* ctx, const double* X, int np, int cols, long long ld, double* norms, std::vector<double>& hc) {
+    std::vector<double> h(2 * np);
+    CTM_TRY(row_norms(ctx, X, 2 * np, cols, ld, norms));
+    CTM_HIP_CHECK(ctx, hipMemcpyAsync(h.data(), norms, sizeof(double) * 2 * np, hipMemcpyDeviceToHost, ctx->stream));
+    CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    hc.resize(np);
+    for (int cr = 0; cr < np; ++cr) { const int rr = crow_re(cr); hc[cr] = std::sqrt(h[rr] * h[rr] + h[rr + BC] * h[rr + BC]); }
+    return CTM_OK;
+}
+
+// gather complex rows idx[0..k) of a panel matrix (column window starting at X) into planar out (re plane, im plane = re + k*cols)
+int panel_gather(ctm_ctx* ctx, const double* X, long long ld, const std::vector<int>& idx, int k, int cols, double* out, int* d_idx2) {
+    std::vector<int> ir(2 * k);
+    for (int i = 0; i < k; ++i) { ir[i] = crow_re(idx[i]); ir[k + i] = ir[i] + BC; }
+    CTM_HIP_CHECK(ctx, hipMemcpyAsync(d_idx2, ir.data(), sizeof(int) * 2 * k, hipMemcpyHostToDevice, ctx->stream));
+    CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    // the index list is [re rows..., im rows...] and the planes are adjacent: ONE gather fills both
+    return gather_rows(ctx, X, ld, d_idx2, 2 * k, cols, out, cols, nullptr);
+}
+
+int scale_planar_rows(ctm_ctx* ctx, double* V, int k, int n, const double* inv) {
+    hipLaunchKernelGGL(scale_rows_kernel, dim3(1024), dim3(256), 0, ctx->stream, V, k, n, (long long)n, inv);
+    hipLaunchKernelGGL(scale_rows_kernel, dim3(1024), dim3(256), 0, ctx->stream, V + (size_t)k * n, k, n, (long long)n, inv);
+    return CTM_OK;
+}
+
+// re-orthonormalise the rows of planar V (k x n complex, planes k*n apart) against the rows above them
+int reorth_rows_c(ctm_ctx* ctx, double* V, int k, int n, int iters) {
+    ArenaScope scope(ctx);
+    double *E, *tmp;
+    const size_t kn = (size_t)k * n;
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * 2 * k * k, (void**)&E));
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * 2 * kn, (void**)&tmp));
+    for (int it = 0; it < iters; ++it) {
+        XM a{V, V + kn, n, false, false}, bh{V, V + kn, n, true, true};
+        CTM_TRY(xgemm(ctx, k, k, n, a, bh, E, E + (size_t)k * k, k));              // E = V V^H
+        CTM_TRY(tril_correction_c128(ctx, E, E + (size_t)k * k, k));
+        XM e{E, E + (size_t)k * k, k, false, false};
+        CTM_TRY(xgemm(ctx, k, n, k, e, a, tmp, tmp + kn, n));
+        CTM_HIP_CHECK(ctx, hipMemcpyAsync(V, tmp, sizeof(double) * 2 * kn, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    return CTM_OK;
+}
+
+int svd_full_c(ctm_ctx* ctx, const double* Mr, const double* Mi, int n, int k, double* S, double* Ut, double* Vt) {
+    const int np = padded(n, BC);
+    ArenaScope scope(ctx);
+    const bool with_q = (Ut != nullptr);
+    const long long ld = (long long)n + (with_q ? np : 0);
+    double *X, *norms;
+    int* d_idx;
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)2 * np * ld, (void**)&X));
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * 2 * np, (void**)&norms));
+    CTM_TRY(arena_alloc(ctx, sizeof(int) * 2 * np, (void**)&d_idx));
+    hipLaunchKernelGGL(fill_wq_c_kernel, dim3(2048), dim3(256), 0, ctx->stream, Mr, Mi, n, X, np, ld, with_q ? 1 : 0);
+    std::vector<double> h;
+    int st;
+    const double fro = host_fro(ctx, X, 2 * np, n, ld, norms, h, &st);
+    CTM_TRY(st);
+    CTM_TRY(jacobi_rows(ctx, X, 2 * np, ld, n, (int)ld, 2 * BC, (k < n) ? k : 0, fro, ctx->jacobi_max_sweeps, true));
+    std::vector<double> hc;
+    CTM_TRY(panel_row_norms(ctx, X, np, n, ld, norms, hc));
+    std::vector<int> idx(np);
+    std::iota(idx.begin(), idx.end(), 0);
+    std::stable_sort(idx.begin(), idx.end(), [&](int a, int c) { return hc[a] > hc[c]; });
+    std::vector<double> hs(k);
+    for (int i = 0; i < k; ++i) hs[i] = hc[idx[i]];
+    CTM_HIP_CHECK(ctx, hipMemcpyAsync(S, hs.data(), sizeof(double) * k, hipMemcpyHostToDevice, ctx->stream));
+    CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (!Ut) return CTM_OK;
+    // rows of the accumulated unitary Q are u_k^H; Sigma V^H = Q M is recomputed by one k x n x n product (drift-free)
+    CTM_TRY(panel_gather(ctx, X + n, ld, idx, k, n, Ut, d_idx));
+    CTM_TRY(reorth_rows_c(ctx, Ut, k, n, 2));
+    if (Vt) {
+        const size_t kn = (size_t)k * n;
+        double* inv;
+        CTM_TRY(arena_alloc(ctx, sizeof(double) * k, (void**)&inv));
+        XM u{Ut, Ut + kn, n, false, false}, m{Mr, Mi, n, false, false};
+        CTM_TRY(xgemm(ctx, k, n, n, u, m, Vt, Vt + kn, n));
+        CTM_TRY(row_norms_c128(ctx, Vt, Vt + kn, k, n, n, S));
+        hipLaunchKernelGGL(inv_or_zero_kernel, dim3((k + 255) / 256), dim3(256), 0, ctx->stream, S, inv, k);
+        CTM_TRY(scale_planar_rows(ctx, Vt, k, n, inv));
+        CTM_TRY(reorth_rows_c(ctx, Vt, k, n, 2));
+    }
+    return CTM_OK;
+}
+
+// Y (R real panel rows x n) = X * op(Z),  Z planar n x n complex, op in {N, T, C = conj, H = conj transpose};
+// scratch: R x n doubles for i*X.   (x + iy)(zr + i zi):  Y = X op(Zr) +- (iX) op(Zi)
+int rows_times_c(ctm_ctx* ctx, const double* X, long long ldx, int R, int n, const double* Zr, const double* Zi, bool trans, bool conj,
+                 double* Y, long long ldy, double* scratch) {
+    const size_t tot = (size_t)R * n;
+    hipLaunchKernelGGL(panel_times_i_kernel, dim3((int)std::min<size_t>((tot + 255) / 256, 2048)), dim3(256), 0, ctx->stream, X, ldx, scratch,
+                       (long long)n, R, n);
+    GemmDesc g; g.M = R; g.N = n; g.K = n; g.A = X; g.sam = ldx; g.sak = 1; g.B = Zr;
+    if (trans) { g.sbk = 1; g.sbn = n; } else { g.sbk = n; g.sbn = 1; }
+    g.C = Y; g.ldc = ldy;
+    CTM_TRY(gemm_f64(ctx, g));
+    g.A = scratch; g.sam = n; g.B = Zi; g.alpha = conj ? -1.0 : 1.0; g.beta = 1.0;
+    return gemm_f64(ctx, g);
+}
+
+// C = B * M (adjoint == false) or B * M^H (adjoint == true), B and C in panel layout
+int matop_apply_c(ctm_ctx* ctx, const MatOp& op, bool adjoint, const double* B, long long ldb, int R, double* C, long long ldc) {
+    const int n = op.n;
+    ArenaScope scope(ctx);
+    double *t1, *t2, *sc;
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)R * n, (void**)&sc));
+    if (op.M) return rows_times_c(ctx, B, ldb, R, n, op.M, op.Mi, adjoint, adjoint, C, ldc, sc);
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)R * n, (void**)&t1));
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)R * n, (void**)&t2));
+    if (!adjoint) {   // B R^T Rt = ((B opB(cB)^T) opA(cA)^T) opC(cC) opD(cD)       (plain transposes, ctm_projectors.py:263)
+        CTM_TRY(rows_times_c(ctx, B, ldb, R, n, op.c[1], op.ci[1], !op.t[1], false, t1, n, sc));
+        CTM_TRY(rows_times_c(ctx, t1, n, R, n, op.c[0], op.ci[0], !op.t[0], false, t2, n, sc));
+        CTM_TRY(rows_times_c(ctx, t2, n, R, n, op.c[2], op.ci[2], op.t[2], false, t1, n, sc));
+        return rows_times_c(ctx, t1, n, R, n, op.c[3], op.ci[3], op.t[3], false, C, ldc, sc);
+    }
+    // B M^H = B opD(cD)^H opC(cC)^H conj(opA(cA)) conj(opB(cB))
+    CTM_TRY(rows_times_c(ctx, B, ldb, R, n, op.c[3], op.ci[3], !op.t[3], true, t1, n, sc));
+    CTM_TRY(rows_times_c(ctx, t1, n, R, n, op.c[2], op.ci[2], !op.t[2], true, t2, n, sc));
+    CTM_TRY(rows_times_c(ctx, t2, n, R, n, op.c[0], op.ci[0], op.t[0], true, t1, n, sc));
+    return rows_times_c(ctx, t1, n, R, n, op.c[1], op.ci[1], op.t[1], true, C, ldc, sc);
+}
+
+// leading-k triplets of a complex operator: the iteration of svd_iter() on panel rows
+int svd_iter_c(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* Ut, double* Vt, bool* converged) {
+    *converged = false;
+    const int n = op.n;
+    int p_full = k + std::max(32, k / 2);
+    p_full = ((p_full + 63) / 64) * 64;
+    if (p_full >= n / 2) return CTM_OK;
+    int p = std::min(64, p_full);                 // complex rows; 2p real rows
+    ArenaScope scope(ctx);
+    const long long ld = 2LL * n;
+    double *XA, *XB, *norms, *nc, *inv, *res;
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)2 * p_full * ld, (void**)&XA));
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)2 * p_full * ld, (void**)&XB));
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * 2 * p_full, (void**)&norms));
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * 2 * p_full, (void**)&nc));      // complex row norm, replicated on both real rows
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * 2 * p_full, (void**)&inv));
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * 2 * p_full, (void**)&res));
+    std::vector<double> h(p_full, 0.0), hr(p_full, 0.0), tmp(2 * p_full);
+    hipLaunchKernelGGL(hash_fill_kernel, dim3(1024), dim3(256), 0, ctx->stream, XB, 2 * p, n, ld, 0x1234567ULL);
+    double* cur = XB; double* nxt = XA;
+    bool have_prev = false;
+    int side = 0;              // 0: C = B M^H (B = rows v^H, produces s u^H) ; 1: C = B M (B = rows u^H, produces s v^H)
+    double s0 = 0.0;
+    int rank = 0, kk = k;
+    const double rank_tol = 1e-14;
+    const int max_half = 2 * ctx->si_max_iter;
+    int it = 0;
+    for (; it < max_half; ++it) {
+        const int R = 2 * p;
+        CTM_TRY(matop_apply_c(ctx, op, side == 0, cur, ld, R, nxt, ld));
+        CTM_TRY(copy2d(ctx, cur, ld, nxt + n, ld, R, n));
+        if (have_prev) {
+            hipLaunchKernelGGL(resid_rows_kernel, dim3((R + 3) / 4), dim3(256), 0, ctx->stream, nxt, ld, cur + n, ld, nc, R, n, res);
+            CTM_HIP_CHECK(ctx, hipMemcpyAsync(tmp.data(), res, sizeof(double) * R, hipMemcpyDeviceToHost, ctx->stream));
+            CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+            for (int cr = 0; cr < p; ++cr) { const int rr = crow_re(cr); hr[cr] = std::sqrt(tmp[rr] * tmp[rr] + tmp[rr + BC] * tmp[rr + BC]); }
+            std::vector<int> idx(p); std::iota(idx.begin(), idx.end(), 0);
+            std::stable_sort(idx.begin(), idx.end(), [&](int a, int c) { return h[a] > h[c]; });
+            rank = 0;
+            for (int i = 0; i < p; ++i) rank += (h[i] > rank_tol * s0);
+            const bool exhausted = rank <= p - 8;
+            if (!exhausted && p < p_full) {
+                const int pn = std::min(p_full, 2 * p);
+                hipLaunchKernelGGL(hash_fill_kernel, dim3(1024), dim3(256), 0, ctx->stream, cur + (size_t)2 * p * ld, 2 * (pn - p), n, ld,
+                                   0x9876543ULL + (unsigned long long)pn);
+                if (ctx->jacobi_verbose) fprintf(stderr, "[si-c] n=%d grow block %d -> %d (rank so far %d)\n", n, p, pn, rank);
+                p = pn; have_prev = false;
+                continue;
+            }
+            kk = exhausted ? std::min(k, rank) : k;
+            double worst = 0.0;
+            for (int i = 0; i < kk; ++i) worst = std::max(worst, hr[idx[i]]);
+            if (ctx->jacobi_verbose) fprintf(stderr, "[si-c] n=%d p=%d half-step %d  rank=%d  max resid/s0 = %.3e\n", n, p, it, rank, worst / std::max(s0, 1e-300));
+            if (worst <= ctx->si_tol * s0) { *converged = true; break; }
+        }
+        int st;
+        std::vector<double> hh;
+        const double fro = host_fro(ctx, nxt, R, n, ld, norms, hh, &st);
+        CTM_TRY(st);
+        CTM_TRY(jacobi_rows(ctx, nxt, R, ld, n, (int)ld, 2 * BC, std::min(k, p - 1), fro, have_prev ? ctx->si_rr_sweeps : std::min(3, ctx->si_rr_sweeps), true));
+        CTM_TRY(row_norms(ctx, nxt, R, n, ld, norms));
+        hipLaunchKernelGGL(panel_combine_kernel, dim3((R + 255) / 256), dim3(256), 0, ctx->stream, norms, nc, R);
+        CTM_HIP_CHECK(ctx, hipMemcpyAsync(tmp.data(), nc, sizeof(double) * R, hipMemcpyDeviceToHost, ctx->stream));
+        CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        h.assign(p_full, 0.0);
+        for (int cr = 0; cr < p; ++cr) h[cr] = tmp[crow_re(cr)];
+        s0 = *std::max_element(h.begin(), h.begin() + p);
+        hipLaunchKernelGGL(inv_or_zero_kernel, dim3((R + 255) / 256), dim3(256), 0, ctx->stream, nc, inv, R);
+        hipLaunchKernelGGL(scale_rows_kernel, dim3(1024), dim3(256), 0, ctx->stream, nxt, R, n, ld, inv);
+        have_prev = true;
+        std::swap(cur, nxt);
+        side ^= 1;
+    }
+    ctx->si_last_iters = it; ctx->si_total_iters += it;
+    if (!*converged) return CTM_OK;
+    std::vector<int> idx(p); std::iota(idx.begin(), idx.end(), 0);
+    std::stable_sort(idx.begin(), idx.end(), [&](int a, int c) { return h[a] > h[c]; });
+    const int kv = std::min(k, std::min(p, std::max(kk, 1)));
+    std::vector<double> hs(k, 0.0);
+    for (int i = 0; i < kv; ++i) hs[i] = h[idx[i]];
+    int* d_idx;
+    CTM_TRY(arena_alloc(ctx, sizeof(int) * 2 * k, (void**)&d_idx));
+    CTM_HIP_CHECK(ctx, hipMemcpyAsync(S, hs.data(), sizeof(double) * k, hipMemcpyHostToDevice, ctx->stream));
+    CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    const size_t kn = (size_t)k * n;
+    CTM_TRY(fill_f64(ctx, Ut, 2 * kn, 0.0));
+    CTM_TRY(fill_f64(ctx, Vt, 2 * kn, 0.0));
+    // verified triplets first into compact planar (kv x n) buffers, re-orthonormalised, then placed into the k-row outputs
+    double *Uc, *Vc;
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * 2 * (size_t)kv * n, (void**)&Uc));
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * 2 * (size_t)kv * n, (void**)&Vc));
+    const double* Bp = cur; const double* Ap = cur + n;
+    CTM_TRY(panel_gather(ctx, side == 1 ? Bp : Ap, ld, idx, kv, n, Uc, d_idx));
+    CTM_TRY(panel_gather(ctx, side == 1 ? Ap : Bp, ld, idx, kv, n, Vc, d_idx));
+    CTM_TRY(reorth_rows_c(ctx, Uc, kv, n, 1));
+    CTM_TRY(reorth_rows_c(ctx, Vc, kv, n, 1));
+    const size_t kvn = (size_t)kv * n;
+    CTM_HIP_CHECK(ctx, hipMemcpyAsync(Ut, Uc, sizeof(double) * kvn, hipMemcpyDeviceToDevice, ctx->stream));
+    CTM_HIP_CHECK(ctx, hipMemcpyAsync(Ut + kn, Uc + kvn, sizeof(double) * kvn, hipMemcpyDeviceToDevice, ctx->stream));
+    CTM_HIP_CHECK(ctx, hipMemcpyAsync(Vt, Vc, sizeof(double) * kvn, hipMemcpyDeviceToDevice, ctx->stream));
+    CTM_HIP_CHECK(ctx, hipMemcpyAsync(Vt + kn, Vc + kvn, sizeof(double) * kvn, hipMemcpyDeviceToDevice, ctx->stream));
+    ctx->si_last_rank = rank;
+    return CTM_OK;
+}
+
 }  // namespace
 
 int jacobi_svd_top_op(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* Ut, double* Vt) {
     const int n = op.n;
     if (n <= 0 || k <= 0 || k > n) { ctx->set_error("jacobi_svd_top: bad n/k"); return CTM_ERR_BADARG; }
+    if (op.Mi || op.ci[0]) {        // complex128
+        if (Ut && Vt && ctx->si_enable && k < n && n >= ctx->si_min_n) {
+            bool ok = false;
+            CTM_TRY(svd_iter_c(ctx, op, k, S, Ut, Vt, &ok));
+            if (ok) { ctx->si_hits += 1; return CTM_OK; }
+            ctx->si_fallbacks += 1;
+        }
+        if (op.M) return svd_full_c(ctx, op.M, op.Mi, n, k, S, Ut, Vt);
+        ArenaScope scope(ctx);
+        const size_t nn = (size_t)n * n;
+        double *R, *Rt, *M;
+        CTM_TRY(arena_alloc(ctx, sizeof(double) * 2 * nn, (void**)&R));
+        CTM_TRY(arena_alloc(ctx, sizeof(double) * 2 * nn, (void**)&Rt));
+        CTM_TRY(arena_alloc(ctx, sizeof(double) * 2 * nn, (void**)&M));
+        XM a{op.c[0], op.ci[0], n, op.t[0], false}, b{op.c[1], op.ci[1], n, op.t[1], false};
+        XM c{op.c[2], op.ci[2], n, op.t[2], false}, d{op.c[3], op.ci[3], n, op.t[3], false};
+        CTM_TRY(xgemm(ctx, n, n, n, a, b, R, R + nn, n));
+        CTM_TRY(xgemm(ctx, n, n, n, c, d, Rt, Rt + nn, n));
+        XM rT{R, R + nn, n, true, false}, rt{Rt, Rt + nn, n, false, false};
+        CTM_TRY(xgemm(ctx, n, n, n, rT, rt, M, M + nn, n));
+        return svd_full_c(ctx, M, M + nn, n, k, S, Ut, Vt);
+    }
     if (Ut && Vt && ctx->si_enable && k < n && n >= ctx->si_min_n) {
         bool ok = false;
         CTM_TRY(svd_iter(ctx, op, k, S, Ut, Vt, &ok));
@@ -661,7 +1133,8 @@ int jacobi_svd_top(ctm_ctx* ctx, const double* M, int n, int k, double* S, doubl
     return jacobi_svd_top_op(ctx, op, k, S, Ut, Vt);
 }
 
-int jacobi_svdvals(ctm_ctx* ctx, const double* M, int n, double* S) {
+int jacobi_svdvals(ctm_ctx* ctx, const double* M, const double* Mi, int n, double* S) {
+    if (Mi) return svd_full_c(ctx, M, Mi, n, n, S, nullptr, nullptr);
     return svd_full(ctx, M, n, n, S, nullptr, nullptr);
 }
 

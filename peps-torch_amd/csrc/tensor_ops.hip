@@ -4,6 +4,7 @@
 // the general permute stages 32x32 tiles through LDS when the innermost input and output
 // axes differ so that both the loads and the stores are coalesced.
 #include "ctm_common.h"
+#include <algorithm>
 
 namespace {
 
@@ -223,6 +224,52 @@ __global__ void trace_partial_kernel(const double* in, double* out, long long n2
     }
 }
 
+
+// ---- complex128 support: interleaved (torch) <-> planar (engine) and planar reductions -----------------------
+__global__ void deinterleave_kernel(const double2* __restrict__ z, double* __restrict__ re, double* __restrict__ im, size_t n) {
+    for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (size_t)gridDim.x * blockDim.x) {
+        const double2 v = z[q]; re[q] = v.x; im[q] = v.y;
+    }
+}
+__global__ void interleave_kernel(const double* __restrict__ re, const double* __restrict__ im, double2* __restrict__ z, size_t n) {
+    for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (size_t)gridDim.x * blockDim.x) {
+        double2 v; v.x = re[q]; v.y = im ? im[q] : 0.0; z[q] = v;
+    }
+}
+// max |z|^2 over a planar complex array (bits of a non-negative double)
+__global__ void absmax2_c_kernel(const double* __restrict__ re, const double* __restrict__ im, size_t n, unsigned long long* out_bits) {
+    double m = 0.0;
+    for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (size_t)gridDim.x * blockDim.x) {
+        const double a = re[q], b = im[q]; m = fmax(m, a * a + b * b);
+    }
+    for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_down(m, off, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(out_bits, (unsigned long long)__double_as_longlong(m));
+}
+__global__ void sqrt_inplace_kernel(double* s) { s[0] = sqrt(s[0]); }
+// out[r] = sqrt(|re[r,:]|^2 + |im[r,:]|^2)
+__global__ void row_norms_c_kernel(const double* __restrict__ re, const double* __restrict__ im, int rows, int cols, long long ld, double* out) {
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    const int nw = (gridDim.x * blockDim.x) >> 6;
+    for (int r = wave; r < rows; r += nw) {
+        double acc = 0.0;
+        for (int c = lane; c < cols; c += 64) { const double a = re[(long long)r * ld + c], b = im[(long long)r * ld + c]; acc += a * a + b * b; }
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+        if (lane == 0) out[r] = sqrt(acc);
+    }
+}
+// Hermitian first-order correction on planar E (k x k): E -> I - strict_lower(E) - diag(E)/2 with E = G - I on entry G
+__global__ void tril_corr_c_kernel(double* Er, double* Ei, int k) {
+    const size_t tot = (size_t)k * k;
+    for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < tot; q += (size_t)gridDim.x * blockDim.x) {
+        const int r = (int)(q / k), c = (int)(q - (size_t)r * k);
+        double vr, vi;
+        if (r == c) { vr = 1.0 - 0.5 * (Er[q] - 1.0); vi = 0.0; }
+        else if (c < r) { vr = -Er[q]; vi = -Ei[q]; }
+        else { vr = 0.0; vi = 0.0; }
+        Er[q] = vr; Ei[q] = vi;
+    }
+}
+
 }  // namespace
 
 #define LAUNCH_CHECK(ctx, what)                                                                   \
@@ -369,5 +416,34 @@ int diag_to_matrix(ctm_ctx* ctx, const double* d, double* out, int n) {
 int trace_partial(ctm_ctx* ctx, const double* in, double* out, long long n2, int p) {
     hipLaunchKernelGGL(trace_partial_kernel, dim3(nblocks((size_t)n2)), dim3(TB), 0, ctx->stream, in, out, n2, p);
     LAUNCH_CHECK(ctx, "trace_partial");
+    return CTM_OK;
+}
+
+int deinterleave_c128(ctm_ctx* ctx, const double* z, double* re, double* im, size_t n) {
+    if (n == 0) return CTM_OK;
+    int blocks = (int)std::min<size_t>((n + 255) / 256, 4096);
+    hipLaunchKernelGGL(deinterleave_kernel, dim3(blocks), dim3(256), 0, ctx->stream, (const double2*)z, re, im, n);
+    return CTM_OK;
+}
+int interleave_c128(ctm_ctx* ctx, const double* re, const double* im, double* z, size_t n) {
+    if (n == 0) return CTM_OK;
+    int blocks = (int)std::min<size_t>((n + 255) / 256, 4096);
+    hipLaunchKernelGGL(interleave_kernel, dim3(blocks), dim3(256), 0, ctx->stream, re, im, (double2*)z, n);
+    return CTM_OK;
+}
+int absmax_c128(ctm_ctx* ctx, const double* re, const double* im, size_t n, double* d_out) {
+    CTM_HIP_CHECK(ctx, hipMemsetAsync(d_out, 0, sizeof(double), ctx->stream));
+    int blocks = (int)std::min<size_t>((n + 255) / 256, 2048);
+    hipLaunchKernelGGL(absmax2_c_kernel, dim3(blocks), dim3(256), 0, ctx->stream, re, im, n, (unsigned long long*)d_out);
+    hipLaunchKernelGGL(sqrt_inplace_kernel, dim3(1), dim3(1), 0, ctx->stream, d_out);
+    return CTM_OK;
+}
+int row_norms_c128(ctm_ctx* ctx, const double* re, const double* im, int rows, int cols, long long ld, double* d_out) {
+    hipLaunchKernelGGL(row_norms_c_kernel, dim3(std::max(1, std::min((rows + 3) / 4, 2048))), dim3(256), 0, ctx->stream, re, im, rows, cols, ld, d_out);
+    return CTM_OK;
+}
+int tril_correction_c128(ctm_ctx* ctx, double* Er, double* Ei, int k) {
+    const size_t tot = (size_t)k * k;
+    hipLaunchKernelGGL(tril_corr_c_kernel, dim3((int)std::min<size_t>((tot + 255) / 256, 2048)), dim3(256), 0, ctx->stream, Er, Ei, k);
     return CTM_OK;
 }

@@ -68,7 +68,7 @@ class J1J2():
         e = 0.
         for coord in parallel.my_units(coords):
             r = rdm.rdm2x2(coord, state, env).cpu()
-            e += float(_cast_to_real(torch.einsum('ijklabcd,ijklabcd', r, self.get_hp(coord))))
+            e += float(_cast_to_real(torch.einsum('ijklabcd,ijklabcd', r, self.get_hp(coord).to(r.dtype))))
         e = parallel.allreduce_sum_scalar(e, state.device)
         return torch.as_tensor(e / len(coords), dtype=torch.float64)
 

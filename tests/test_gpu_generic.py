@@ -11,7 +11,7 @@ from conftest import golden
 from helpers import DIRS, dev, sites_from, env_from, device_state_env, oracle_state_env, relerr
 
 pytestmark = pytest.mark.gpu
-CASES = [("generic_D2_chi8_f64", 8), ("generic_D3_chi18_f64", 18)]
+CASES = [("generic_D2_chi8_f64", 8), ("generic_D3_chi18_f64", 18), ("generic_D2_chi8_c128", 8)]
 
 
 @pytest.fixture(scope="module", params=CASES, ids=[c[0] for c in CASES])
