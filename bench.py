@@ -22,19 +22,29 @@ import numpy as np
 import torch
 
 CONFIGS = {
-    # name: (kind, D, chi)          BASELINE.json configs[1..3]
-    "c4v_D4_chi64": ("c4v", 4, 64),
-    "generic_D4_chi64": ("generic", 4, 64),
-    "generic_D6_chi128": ("generic", 6, 128),
-    "generic_D8_chi256": ("generic", 8, 256),
-    "generic_D3_chi36": ("generic", 3, 36),
+    # name: (kind, D, chi, dtype)          BASELINE.json configs[1..4]
+    "c4v_D4_chi64": ("c4v", 4, 64, "f64"),
+    "generic_D4_chi64": ("generic", 4, 64, "f64"),
+    "generic_D6_chi128": ("generic", 6, 128, "f64"),
+    "generic_D8_chi256": ("generic", 8, 256, "f64"),
+    "generic_D3_chi36": ("generic", 3, 36, "f64"),
+    "generic_D4_chi64_c128": ("generic", 4, 64, "c128"),
+    "generic_D6_chi128_c128": ("generic", 6, 128, "c128"),
+    "generic_D8_chi384_c128": ("generic", 8, 384, "c128"),     # BASELINE.json configs[4] (quoted there on 8 GPUs)
 }
 DEFAULT_CONFIG = "generic_D6_chi128"       # largest single-GPU configuration in BASELINE.json configs
 FP64_MFMA_PEAK_TFLOPS = 78.6               # MI355X FP64 matrix peak (v_mfma_f64_16x16x4_f64, 32 flop/clk/SIMD)
 
 
-def synth_sites(kind, D, seed=1):
+def synth_sites(kind, D, seed=1, dtype="f64"):
     rng = np.random.default_rng(seed)
+    if dtype == "c128":      # re and im parts each U[0,1)
+        sites = {}
+        for y in range(2):
+            for x in range(2):
+                A = rng.random((2, D, D, D, D)) + 1j * rng.random((2, D, D, D, D))
+                sites[(x, y)] = A / np.abs(A).max()
+        return sites
     if kind == "c4v":
         from oracle.j1j2_oracle import make_c4v_symm_A1
         A = make_c4v_symm_A1(rng.random((2, D, D, D, D)))
@@ -78,8 +88,9 @@ def cpu_baseline(kind, D, chi, sites, budget_s=25.0):
     env = O.init_env_ctmrg(ost, chi)
     # make the environment dense with the cheapest possible warm-up: random dense env of the right shapes
     rng = np.random.default_rng(7)
-    for k in env.C: env.C[k] = rng.random(env.C[k].shape)
-    for k in env.T: env.T[k] = rng.random(env.T[k].shape)
+    cx = np.iscomplexobj(sites[(0, 0)])
+    for k in env.C: env.C[k] = rng.random(env.C[k].shape) + (1j * rng.random(env.C[k].shape) if cx else 0.0)
+    for k in env.T: env.T[k] = rng.random(env.T[k].shape) + (1j * rng.random(env.T[k].shape) if cx else 0.0)
     t0 = time.perf_counter()
     P, Pt = O.get_projectors_4x4(O.UP, (0, 0), ost, env)
     Pd = {c: P for c in ost.sites}; Ptd = {c: Pt for c in ost.sites}
@@ -100,7 +111,7 @@ def main():
     ap.add_argument("--profile", action="store_true", help="per-phase host timers (adds stream syncs)")
     ap.add_argument("--opt", action="append", default=[], help="engine option key=value (development)")
     args = ap.parse_args()
-    kind, D, chi = CONFIGS[args.config]
+    kind, D, chi, dtype = CONFIGS[args.config]
     steps = args.steps if args.steps is not None else (20 if kind == "c4v" else 2)
     warmup = args.warmup if args.warmup is not None else (3 if kind == "c4v" else 1)
 
@@ -130,7 +141,7 @@ def main():
     for kv in args.opt:
         k_, v_ = kv.split("="); eng.set_option(k_, float(v_))
     dev = torch.device("cuda", local)
-    sites = synth_sites(kind, D)
+    sites = synth_sites(kind, D, dtype=dtype)
     if kind == "c4v":
         state = IPEPS_C4V(torch.from_numpy(sites[(0, 0)]).to(dev))
         env = ENV_C4V(chi, state); init_env_c4v(state, env)
@@ -174,7 +185,7 @@ def main():
 
     if rank == 0:
         dom = 0 if k_ms[0] >= k_ms[1] else 1
-        names = ["gemm_f64_kernel<4,4> (128x128 tile)", "gemm_f64_kernel<2,2> (64x64 tile)"]
+        names = ["gemm_f64_fast_kernel / gemm_f64_kernel<4,4> (128x128 tile)", "gemm_f64_kernel<2,2> (64x64 tile)"]
         ach = (k_fl[dom] / max(k_n[dom], 1)) / max(k_ms[dom] / max(k_n[dom], 1) * 1e-3, 1e-30) / 1e12 if k_n[dom] else 0.0
         roof = {"bound": "mfma", "kernel": names[dom], "achieved": round(ach, 3), "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(ach / FP64_MFMA_PEAK_TFLOPS, 4), "traffic": None,
@@ -184,7 +195,7 @@ def main():
                                "tflops": round(k_fl[1 - dom] / max(k_ms[1 - dom] * 1e-3, 1e-30) / 1e12, 3) if k_n[1 - dom] else 0.0}}
         out = {"metric": "ctm_sweeps_per_sec", "value": steps / dt, "unit": "sweeps/s", "n_gpus": world, "steps": steps,
                "warmup": warmup, "ms_per_step": 1e3 * dt / steps, "higher_is_better": True, "scaling": "strong",
-               "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+               "vs_baseline": None, "dtype": dtype, "data": "synthetic",
                "config": {"workload": args.config, "variant": kind, "D": D, "chi": chi, "n": chi * D * D,
                           "unit_cell": "1x1 C4v" if kind == "c4v" else "2x2 (4 sites, 32 units/sweep)",
                           "parallelism": f"site-sharded x{world}" if world > 1 else "single GPU"},

@@ -51,18 +51,22 @@ def exchange(local, keys, shapes, like):
     out = dict(local)
     owned = [[k for i, k in enumerate(keys) if owner_of(i, n) == r] for r in range(n)]
     uniform = len({len(o) for o in owned}) == 1 and len({tuple(shapes[k]) for k in keys}) == 1 and len(owned[0]) > 0
+    cx = like.dtype.is_complex       # RCCL has no complex type: complex128 travels as its (re,im) float64 view
     if uniform:
         send = torch.stack([local[k].contiguous() for k in owned[rank]]).contiguous()
+        if cx:
+            send = torch.view_as_real(send)
         recv = [torch.empty_like(send) for _ in range(n)]
         dist.all_gather(recv, send)
         for r in range(n):
+            buf = torch.view_as_complex(recv[r]) if cx else recv[r]
             for j, k in enumerate(owned[r]):
-                out[k] = recv[r][j]
+                out[k] = buf[j]
         return out
     for i, k in enumerate(keys):
         src = owner_of(i, n)
         t = local[k].contiguous() if src == rank else torch.empty(tuple(shapes[k]), dtype=like.dtype, device=like.device)
-        dist.broadcast(t, src)
+        dist.broadcast(torch.view_as_real(t) if cx else t, src)
         out[k] = t
     return out
 

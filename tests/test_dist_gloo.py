@@ -7,7 +7,7 @@ import torch
 import torch.multiprocessing as mp
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, name):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     here = os.path.dirname(os.path.abspath(__file__))
     for p in (os.path.dirname(here), os.path.join(os.path.dirname(here), "peps-torch_amd"), here):
@@ -27,7 +27,7 @@ def _worker(rank, world, port, out_dir):
     from ctm.generic import ctmrg
     from models import j1j2
     import parallel
-    g = golden("generic_D2_chi8_f64")
+    g = golden(name)
     st = IPEPS({k: torch.from_numpy(v.copy()) for k, v in sites_from(g).items()})
     env = ENV(8, st)
     init_env(st, env)
@@ -44,10 +44,11 @@ def _worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_sharded_move_equals_single_process(tmp_path):
+@pytest.mark.parametrize("name", ["generic_D2_chi8_f64", "generic_D2_chi8_c128"])
+def test_sharded_move_equals_single_process(tmp_path, name):
     import socket
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, str(tmp_path), name), nprocs=2, join=True)
     r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
     for k in r0.files:
         assert np.array_equal(r0[k], r1[k]), k          # replicated env identical on both ranks
@@ -55,7 +56,7 @@ def test_sharded_move_equals_single_process(tmp_path):
     from conftest import golden
     from helpers_cpu import sites_from
     from oracle import ctm_oracle as O, j1j2_oracle as OJ
-    g = golden("generic_D2_chi8_f64")
+    g = golden(name)
     ost = O.State(sites_from(g))
     oe = O.init_env_ctmrg(ost, 8)
     for _ in range(2):

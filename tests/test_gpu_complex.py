@@ -72,3 +72,38 @@ def test_projectors_c128_fused_vs_explicit(eng):
     assert relerr(P.abs(), np.abs(Pr)) < 1e-9
     G = (Pt.t() @ P).cpu().numpy()
     assert np.abs(G - np.eye(chi)).max() < 1e-9
+
+
+def test_projectors_4x4_c128_implicit_operator(eng):
+    """n = chi D^2 = 512: the fused path (four corners, M = R^T Rt applied implicitly inside the complex block power
+    iteration) equals the explicit halves -> projectors route and the oracle."""
+    from oracle import ctm_oracle as O
+    from ipeps.ipeps import IPEPS
+    from ctm.generic.env import ENV, init_env
+    from ctm.generic import ctmrg
+    from ctm.generic.ctm_components import _halves_t
+    rng = np.random.default_rng(11)
+    D, chi = 4, 32
+    sites = {}
+    for y in range(2):
+        for x in range(2):
+            A = rng.random((2, D, D, D, D)) + 1j * rng.random((2, D, D, D, D))
+            sites[(x, y)] = A / np.abs(A).max()
+    st = IPEPS({k: dev(v) for k, v in sites.items()})
+    env = ENV(chi, st); init_env(st, env)
+    for d in [(0, -1), (-1, 0), (0, 1), (1, 0)] * 2:
+        ctmrg.ctm_MOVE(d, st, env)                       # dense complex environment
+    ost = O.State(sites); oe = O.Env(chi)
+    oe.C = {k: v.cpu().numpy() for k, v in env.C.items()}; oe.T = {k: v.cpu().numpy() for k, v in env.T.items()}
+    h0 = eng.stat("si_hits")
+    for d in [(0, -1), (1, 0)]:
+        t16 = _halves_t(d, (0, 0), st, env)
+        R, Rt = eng.halves(d, t16)
+        Ro, Rto = O.halves(d, (0, 0), ost, oe)
+        assert relerr(R, Ro) < 1e-12 and relerr(Rt, Rto) < 1e-12
+        P, Pt, S = eng.projectors(R, Rt, chi, return_S=True)
+        P2, Pt2, S2 = eng.projectors_4x4(d, t16, chi, return_S=True)
+        Po, Pto, So = O.projectors_from_matrices(Ro, Rto, chi, return_S=True)
+        assert relerr(S, So) < 1e-11 and relerr(S2, So) < 1e-11
+        assert relerr(P2 @ Pt2.t(), Po @ Pto.T) < 1e-6 and relerr(P @ Pt.t(), Po @ Pto.T) < 1e-6
+    assert eng.stat("si_hits") >= h0 + 4
