@@ -47,6 +47,9 @@ int ctm_sync(ctm_ctx* ctx);
 int ctm_set_option(ctm_ctx* ctx, const char* key, double value);   /* "jacobi_tol","jacobi_max_sweeps","jacobi_block","profile" */
 int ctm_get_stat(ctm_ctx* ctx, const char* key, double* value);    /* "last_sweeps","last_offnorm","gemm_flops","gemm_calls","arena_high" */
 int ctm_timers(ctm_ctx* ctx, double* out8, int reset);             /* corners,halves,svd,proj,absorb,norm,rdm,eig (s) */
+/* GEMM launches timed with HIP events while the option "gemm_timing" is on: quadruples (kind, start_ms, end_ms, flops) on a
+ * process-wide clock (kind 0 = 128x128-tile kernels, 1 = 64x64-tile kernel).  out may be NULL to query *count (launches). */
+int ctm_gemm_intervals(ctm_ctx* ctx, double* out, long long capacity_doubles, long long* count);
 
 /* ---- primitives (replace tn_interface.py:3-27 contract/mm/permute) ------------------------------ */
 /* C[M,N] = alpha op(A) op(B) + beta C ; row-major; trans = 0 ('N') or 1 ('T', plain transpose) */
@@ -82,6 +85,12 @@ int ctm_projectors(ctm_ctx* ctx, const double* R, const double* Rt, int n, int c
  * decomposition).  tensors16 / adims4x5 as for ctm_halves. */
 int ctm_projectors_4x4(ctm_ctx* ctx, int dir, const double* const* tensors16, int chi, const int* adims4x5,
                        const ctm_trunc_cfg* cfg, double* P, double* Pt, double* S);
+/* Same, warm started: `basis` is an opaque caller-owned device workspace of min(chi+1,n) * n doubles (twice that for
+ * CTM_C128), zero-filled before the first call and passed again for the same (direction, site) on later sweeps.  It carries
+ * the right singular row basis of the previous call: the leading-chi iteration starts from it instead of a random block
+ * (the result is residual-verified either way, so a stale or zero basis only costs iterations).  basis == NULL: cold. */
+int ctm_projectors_4x4_ws(ctm_ctx* ctx, int dir, const double* const* tensors16, int chi, const int* adims4x5,
+                          const ctm_trunc_cfg* cfg, double* P, double* Pt, double* S, double* basis);
 /* absorb_truncate_CTM_MOVE_<DIR>_c (ctmrg.py:343-438,459-564,585-680,701-804), 'sl' mode, followed by
  * move_normalize_c 'inf' (ctmrg.py:210-230) when normalize != 0.  tensors10 = C1,T1,T,T2,C2,A,P2,Pt2,P1,Pt1 */
 int ctm_absorb(ctm_ctx* ctx, int dir, const double* const* tensors10, int chi, const int* adims, int normalize,

@@ -36,6 +36,7 @@ _SIGS = {
     "ctm_set_option": [C.c_void_p, C.c_char_p, C.c_double],
     "ctm_get_stat": [C.c_void_p, C.c_char_p, C.POINTER(C.c_double)],
     "ctm_timers": [C.c_void_p, C.POINTER(C.c_double), C.c_int],
+    "ctm_gemm_intervals": [C.c_void_p, C.POINTER(C.c_double), C.c_longlong, C.POINTER(C.c_longlong)],
     "ctm_gemm": [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_longlong,
                  C.c_void_p, C.c_longlong, C.c_double, C.c_void_p, C.c_longlong],
     "ctm_permute": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_longlong), C.POINTER(C.c_int)],
@@ -47,6 +48,7 @@ _SIGS = {
     "ctm_halves": [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_int), C.c_void_p, C.c_void_p],
     "ctm_projectors": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(TruncCfg), C.c_void_p, C.c_void_p, C.c_void_p],
     "ctm_projectors_4x4": [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_int), C.POINTER(TruncCfg), C.c_void_p, C.c_void_p, C.c_void_p],
+    "ctm_projectors_4x4_ws": [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_int), C.POINTER(TruncCfg), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
     "ctm_absorb": [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_int), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p],
     "ctm_c2x2_c4v": [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p],
     "ctm_move_c4v": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(TruncCfg),
@@ -110,8 +112,17 @@ class Engine:
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self._handles = {}
         self._options = {}
+        self.workers = []          # engines spawned for concurrent units (units.UnitPool): options/stats fan out to them
         self.default_cfg = TruncCfg(1e-8, 1e-8, 1e-14, 1, 1)
         self._bind_dtype(torch.float64)
+
+    def spawn_worker(self):
+        """A sibling engine on the CALLER's current stream (own native contexts and arenas), inheriting the options."""
+        w = Engine(self.device)
+        for k, v in self._options.items():
+            w.set_option(k, v)
+        self.workers.append(w)
+        return w
 
     def _bind_dtype(self, dtype):
         if dtype not in _DTYPES:
@@ -158,6 +169,8 @@ class Engine:
     # ---- options / stats (applied to / summed over the contexts of both dtypes) ----------------
     def set_option(self, key, value):
         self._options[key] = value
+        for w in self.workers:
+            w.set_option(key, value)
         for h in self._handles.values():
             st = self.lib.ctm_set_option(h, key.encode(), float(value))
             if st != CTM_OK:
@@ -165,7 +178,7 @@ class Engine:
                 self._ck(st, "set_option")
 
     def stat(self, key):
-        tot = 0.0
+        tot = sum(w.stat(key) for w in self.workers)
         for h in self._handles.values():
             v = C.c_double()
             st = self.lib.ctm_get_stat(h, key.encode(), C.byref(v))
@@ -178,6 +191,9 @@ class Engine:
     def timers(self, reset=False):
         names = ["corners", "halves", "svd", "proj", "absorb", "norm", "rdm", "eig"]
         tot = dict.fromkeys(names, 0.0)
+        for w in self.workers:
+            for n, v in w.timers(reset).items():
+                tot[n] += v
         for h in self._handles.values():
             buf = (C.c_double * 8)()
             self.lib.ctm_timers(h, buf, int(reset))
@@ -185,7 +201,25 @@ class Engine:
                 tot[n] += v
         return tot
 
+    def gemm_intervals(self):
+        """(kind, start_ms, end_ms, flops) of every GEMM launch timed since "gemm_timing" was switched on, over all
+        contexts of this engine and of its workers (one process-wide clock)."""
+        out = []
+        for w in self.workers:
+            out += w.gemm_intervals()
+        for h in self._handles.values():
+            cnt = C.c_longlong()
+            self.lib.ctm_gemm_intervals(h, None, 0, C.byref(cnt))
+            if cnt.value:
+                buf = (C.c_double * (4 * cnt.value))()
+                self.lib.ctm_gemm_intervals(h, buf, 4 * cnt.value, C.byref(cnt))
+                v = list(buf)
+                out += [tuple(v[i:i + 4]) for i in range(0, len(v), 4)]
+        return out
+
     def sync(self):
+        for w in self.workers:
+            w.sync()
         for h in self._handles.values():
             self.lib.ctm_sync(h)
 
@@ -293,8 +327,14 @@ class Engine:
         self._ck(self.lib.ctm_projectors(self.h, _ptr(R), _ptr(Rt), n, chi, C.byref(cfg), _ptr(P), _ptr(Pt), _ptr(S)), "projectors")
         return (P, Pt, S) if return_S else (P, Pt)
 
-    def projectors_4x4(self, direction, tensors16, chi, cfg=None, return_S=False):
-        """Fused corners -> implicit R^T Rt -> leading-chi triplets -> P, Pt (never forms the n x n halves)."""
+    def warm_basis(self, chi, n, dtype):
+        """Zero-filled warm-start workspace for projectors_4x4(..., basis=) of one (direction, site) unit."""
+        k = chi + 1 if chi < n else n
+        return torch.zeros((2 if dtype.is_complex else 1) * k, n, dtype=torch.float64, device=self.device)
+
+    def projectors_4x4(self, direction, tensors16, chi, cfg=None, return_S=False, basis=None):
+        """Fused corners -> implicit R^T Rt -> leading-chi triplets -> P, Pt (never forms the n x n halves).
+        basis: optional warm-start workspace (see warm_basis), updated in place."""
         ts, arr, ad = self._pack16(tensors16)
         d = DIR_INDEX[direction] if isinstance(direction, tuple) else direction
         chi_env = ts[0].shape[0]
@@ -302,7 +342,13 @@ class Engine:
         kc = min(chi, n)
         P, Pt, S = self.empty(n, kc), self.empty(n, kc), self.empty_real(kc)
         cfg = cfg or self.default_cfg
-        self._ck(self.lib.ctm_projectors_4x4(self.h, d, arr, chi, ad, C.byref(cfg), _ptr(P), _ptr(Pt), _ptr(S)), "projectors_4x4")
+        if basis is not None:
+            k = chi + 1 if chi < n else n
+            if not (basis.is_cuda and basis.dtype == torch.float64 and basis.is_contiguous()
+                    and tuple(basis.shape) == ((2 if ts[0].dtype.is_complex else 1) * k, n)):
+                raise NativeError("projectors_4x4: basis must come from warm_basis(chi, n, dtype)")
+        self._ck(self.lib.ctm_projectors_4x4_ws(self.h, d, arr, chi, ad, C.byref(cfg), _ptr(P), _ptr(Pt), _ptr(S),
+                                                _ptr(basis) if basis is not None else None), "projectors_4x4")
         return (P, Pt, S) if return_S else (P, Pt)
 
     def absorb(self, direction, tensors10, normalize=True):

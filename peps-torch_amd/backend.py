@@ -4,7 +4,15 @@ The product path always resolves to the native HIP engine (`_native.engine()`); 
 shared library or the GPU is missing -- there is no CPU fallback.  Tests of the host logic may
 install a stand-in with `set_engine` (e.g. an oracle-backed double for the gloo sharding tests).
 """
+import threading
+
 _override = None
+_tls = threading.local()
+
+
+def set_thread_engine(e):
+    """Engine used by get_engine() on the calling thread (worker threads of units.UnitPool run on their own HIP stream)."""
+    _tls.engine = e
 
 
 def set_engine(e):
@@ -13,6 +21,9 @@ def set_engine(e):
 
 
 def get_engine():
+    e = getattr(_tls, "engine", None)
+    if e is not None:
+        return e
     if _override is not None:
         return _override
     import _native

@@ -55,7 +55,7 @@ struct ctm_ctx {
     bool si_enable = true;
     int si_min_n = 512, si_max_iter = 40, si_last_iters = 0, si_rr_sweeps = 40, si_last_rank = 0;
     double si_tol = 2e-14;
-    long si_hits = 0, si_fallbacks = 0, si_total_iters = 0;
+    long si_hits = 0, si_fallbacks = 0, si_total_iters = 0, si_warm_starts = 0;
     int last_sweeps = 0;
     long total_sweeps = 0, jacobi_calls = 0;
     double last_offnorm = 0;
@@ -80,6 +80,7 @@ struct ctm_ctx {
     struct PendingEv { int e0, e1, kind; double flops; };
     std::vector<PendingEv> ev_pending;
     int ev_next = 0;
+    std::vector<double> intervals;       // (kind, start_ms, end_ms, flops) per timed GEMM launch, process-wide clock
     double k_ms[2] = {0, 0}, k_flops[2] = {0, 0};
     long k_calls[2] = {0, 0};
     bool cplx = false;                   // CTM_C128 context: every tensor pointer of the C-ABI is interleaved complex128
@@ -133,6 +134,7 @@ struct GemmDesc {
 };
 int gemm_f64(ctm_ctx* ctx, const GemmDesc& d);
 void gemm_timing_drain(ctm_ctx* ctx);
+void gemm_timing_base(ctm_ctx* ctx);
 
 // ---- elementwise / layout kernels (tensor_ops.hip) -----------------------------------------
 #define CTM_MAXD 8
@@ -173,6 +175,9 @@ struct MatOp {
     const double* c[4] = {nullptr, nullptr, nullptr, nullptr};
     const double* ci[4] = {nullptr, nullptr, nullptr, nullptr};      // imaginary planes of the corners (complex128)
     bool t[4] = {false, false, false, false};
+    // optional warm start (in/out): k x n row basis (planar for complex128) of the right singular vectors of a nearby
+    // operator; rows the caller does not have are zero.  Overwritten with this decomposition's right row factor.
+    double* warm = nullptr;
 };
 // complex128 operators: Ut, Vt are planar (re plane k x n, then im plane), rows = u_k^H, v_k^H
 int jacobi_svd_top_op(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* Ut, double* Vt);

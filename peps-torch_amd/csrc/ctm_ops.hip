@@ -447,6 +447,11 @@ int ctm_projectors(ctm_ctx* ctx, const double* R, const double* Rt, int n, int c
 
 int ctm_projectors_4x4(ctm_ctx* ctx, int dir, const double* const* t, int chi, const int* adims4x5, const ctm_trunc_cfg* cfg_,
                        double* P, double* Pt, double* S_out) {
+    return ctm_projectors_4x4_ws(ctx, dir, t, chi, adims4x5, cfg_, P, Pt, S_out, nullptr);
+}
+
+int ctm_projectors_4x4_ws(ctm_ctx* ctx, int dir, const double* const* t, int chi, const int* adims4x5, const ctm_trunc_cfg* cfg_,
+                          double* P, double* Pt, double* S_out, double* basis) {
     const ctm_trunc_cfg cfg = cfg_ ? *cfg_ : kDefaultCfg;
     if (dir < 0 || dir > 3) { ctx->set_error("projectors_4x4: bad direction"); return CTM_ERR_BADARG; }
     ArenaScope scope(ctx);
@@ -481,6 +486,7 @@ int ctm_projectors_4x4(ctm_ctx* ctx, int dir, const double* const* t, int chi, c
     CTM_TRY(arena_alloc(ctx, sizeof(double) * kc, (void**)&dScale));
     MatOp op; op.n = (int)n;
     for (int i = 0; i < 4; ++i) { op.c[i] = c[i].p; op.ci[i] = c[i].q; op.t[i] = tr[i]; }
+    op.warm = basis;
     TruncOut to;
     { PhaseTimer pt(ctx, CTM_T_SVD); CTM_TRY(svd_rows_op(ctx, op, chi, cfg, Ut, Vt, dS, &to)); }
     PhaseTimer pt(ctx, CTM_T_PROJ);

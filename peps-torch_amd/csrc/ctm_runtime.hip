@@ -101,6 +101,7 @@ int ctm_set_option(ctm_ctx* ctx, const char* key, double value) {
     else if (k == "gemm_timing") {
         gemm_timing_drain(ctx);
         ctx->gemm_timing = value != 0.0;
+        if (ctx->gemm_timing) { gemm_timing_base(ctx); ctx->intervals.clear(); }
         for (int i = 0; i < 2; ++i) { ctx->k_ms[i] = 0; ctx->k_flops[i] = 0; ctx->k_calls[i] = 0; }
     }
     else { ctx->set_error("unknown option " + k); return CTM_ERR_BADARG; }
@@ -118,6 +119,7 @@ int ctm_get_stat(ctm_ctx* ctx, const char* key, double* value) {
     else if (k == "si_last_iters") *value = (double)ctx->si_last_iters;
     else if (k == "si_total_iters") *value = (double)ctx->si_total_iters;
     else if (k == "si_last_rank") *value = (double)ctx->si_last_rank;
+    else if (k == "si_warm_starts") *value = (double)ctx->si_warm_starts;
     else if (k == "gemm_flops") *value = ctx->gemm_flops;
     else if (k == "gemm_calls") *value = (double)ctx->gemm_calls;
     else if (k == "layer2_flops") *value = ctx->layer2_flops;
@@ -136,9 +138,17 @@ int ctm_get_stat(ctm_ctx* ctx, const char* key, double* value) {
     return CTM_OK;
 }
 
+int ctm_gemm_intervals(ctm_ctx* ctx, double* out, long long capacity, long long* count) {
+    gemm_timing_drain(ctx);
+    const long long n = (long long)ctx->intervals.size();
+    if (count) *count = n / 4;
+    if (out) for (long long i = 0; i < n && i < capacity; ++i) out[i] = ctx->intervals[i];
+    return CTM_OK;
+}
+
 int ctm_timers(ctm_ctx* ctx, double* out8, int reset) {
     for (int i = 0; i < CTM_T_COUNT; ++i) { if (out8) out8[i] = ctx->timers[i]; if (reset) ctx->timers[i] = 0.0; }
-    if (reset) { ctx->gemm_flops = 0; ctx->gemm_calls = 0; ctx->layer2_flops = 0; ctx->layer2_calls = 0; ctx->total_sweeps = 0; ctx->jacobi_calls = 0; ctx->si_hits = 0; ctx->si_fallbacks = 0; ctx->si_total_iters = 0; }
+    if (reset) { ctx->gemm_flops = 0; ctx->gemm_calls = 0; ctx->layer2_flops = 0; ctx->layer2_calls = 0; ctx->total_sweeps = 0; ctx->jacobi_calls = 0; ctx->si_hits = 0; ctx->si_fallbacks = 0; ctx->si_total_iters = 0; ctx->si_warm_starts = 0; }
     return CTM_OK;
 }
 

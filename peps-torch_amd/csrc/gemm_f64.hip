@@ -17,6 +17,7 @@
 // 64 cycles, so LDS and global bandwidth needs are modest; the kernel is issue-bound on MFMA when
 // K is long.  C/D fragment layout of the f64 MFMA: col = lane&15, row = (lane>>4) + 4*reg.
 #include "ctm_common.h"
+#include <mutex>
 #include <algorithm>
 
 typedef double d4 __attribute__((ext_vector_type(4)));
@@ -414,6 +415,18 @@ int xgemm(ctm_ctx* ctx, int M, int N, int K, const XM& A, const XM& B, double* C
     g.A = A.im; g.B = B.re; g.C = Cim; g.alpha = sA; g.beta = 1.0;         return gemm_f64(ctx, g);
 }
 
+// process-wide time base of the GEMM intervals: contexts on different streams (concurrent units) report [start, end] on
+// one clock so that the host can take the union of overlapping launches
+static hipEvent_t g_base_event = nullptr;
+static std::mutex g_base_mutex;
+void gemm_timing_base(ctm_ctx* ctx) {
+    std::lock_guard<std::mutex> lock(g_base_mutex);
+    if (g_base_event) return;
+    if (hipEventCreate(&g_base_event) != hipSuccess) { g_base_event = nullptr; return; }
+    (void)hipEventRecord(g_base_event, ctx->stream);
+    (void)hipEventSynchronize(g_base_event);
+}
+
 void gemm_timing_drain(ctm_ctx* ctx) {
     if (ctx->ev_pending.empty()) { ctx->ev_next = 0; return; }
     (void)hipStreamSynchronize(ctx->stream);
@@ -421,6 +434,11 @@ void gemm_timing_drain(ctm_ctx* ctx) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, ctx->ev_pool[pe.e0], ctx->ev_pool[pe.e1]) == hipSuccess) {
             ctx->k_ms[pe.kind] += ms; ctx->k_flops[pe.kind] += pe.flops; ctx->k_calls[pe.kind] += 1;
+            float t0 = 0.f;
+            if (g_base_event && hipEventElapsedTime(&t0, g_base_event, ctx->ev_pool[pe.e0]) == hipSuccess && ctx->intervals.size() < (1u << 22)) {
+                ctx->intervals.push_back((double)pe.kind); ctx->intervals.push_back((double)t0);
+                ctx->intervals.push_back((double)t0 + ms); ctx->intervals.push_back(pe.flops);
+            }
         }
     }
     ctx->ev_pending.clear();

@@ -22,6 +22,7 @@
 #include <algorithm>
 #include <cmath>
 #include <numeric>
+#include <mutex>
 
 namespace {
 
@@ -409,9 +410,11 @@ struct RRTables {
 };
 
 std::map<std::string, RRTables>& tables() { static std::map<std::string, RRTables> t; return t; }
+std::mutex& tables_mutex() { static std::mutex m; return m; }   // contexts of several host threads share the tables
 
 int get_tables(ctm_ctx* ctx, int nbk, long long ld, int b, int Cg, RRTables** out) {
     const std::string key = std::to_string(ctx->device) + ":" + std::to_string(nbk) + ":" + std::to_string(ld) + ":" + std::to_string(b) + ":" + std::to_string(Cg);
+    std::lock_guard<std::mutex> lock(tables_mutex());
     auto& T = tables();
     auto it = T.find(key);
     if (it != T.end()) { *out = &it->second; return CTM_OK; }
@@ -727,8 +730,35 @@ int svd_iter(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* Ut, double
     CTM_TRY(arena_alloc(ctx, sizeof(double) * p_full, (void**)&res));
     CTM_TRY(arena_alloc(ctx, sizeof(double) * p_full, (void**)&sprev));
     std::vector<double> h(p_full, 0.0), hr(p_full, 0.0);
-    // start: pseudo-random basis (need not be orthonormal)
-    hipLaunchKernelGGL(hash_fill_kernel, dim3(1024), dim3(256), 0, ctx->stream, XB, p, n, ld, 0x1234567ULL);
+    // start: the caller's warm basis (orthonormal rows of a previous decomposition of a nearby operator; rows it does not
+    // have are zero) completed by pseudo-random rows projected onto its orthogonal complement -- or, cold, a
+    // pseudo-random basis (need not be orthonormal)
+    int kw = 0;
+    if (op.warm) {
+        CTM_TRY(row_norms(ctx, op.warm, k, n, n, norms));
+        CTM_HIP_CHECK(ctx, hipMemcpyAsync(h.data(), norms, sizeof(double) * std::min(k, p_full), hipMemcpyDeviceToHost, ctx->stream));
+        CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        while (kw < std::min(k, p_full) && std::fabs(h[kw] - 1.0) < 1e-6) ++kw;
+        std::fill(h.begin(), h.end(), 0.0);
+    }
+    if (kw > 0) {
+        p = std::min(p_full, std::max(64, ((kw + 16 + 63) / 64) * 64));
+        kw = std::min(kw, p - 8);
+        CTM_TRY(copy2d(ctx, op.warm, n, XB, ld, kw, n));
+        double* Rn = XB + (size_t)kw * ld;
+        const int pr = p - kw;
+        hipLaunchKernelGGL(hash_fill_kernel, dim3(1024), dim3(256), 0, ctx->stream, Rn, pr, n, ld, 0x1234567ULL);
+        ArenaScope ws(ctx);
+        double* Gw;
+        CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)pr * kw, (void**)&Gw));
+        GemmDesc g1; g1.M = pr; g1.N = kw; g1.K = n; g1.A = Rn; g1.sam = ld; g1.sak = 1; g1.B = XB; g1.sbk = 1; g1.sbn = ld; g1.C = Gw; g1.ldc = kw;
+        CTM_TRY(gemm_f64(ctx, g1));                                  // G = R V^T
+        GemmDesc g2; g2.M = pr; g2.N = n; g2.K = kw; g2.A = Gw; g2.sam = kw; g2.sak = 1; g2.B = XB; g2.sbk = ld; g2.sbn = 1; g2.C = Rn; g2.ldc = ld;
+        g2.alpha = -1.0; g2.beta = 1.0;
+        CTM_TRY(gemm_f64(ctx, g2));                                  // R -= G V
+    } else
+        hipLaunchKernelGGL(hash_fill_kernel, dim3(1024), dim3(256), 0, ctx->stream, XB, p, n, ld, 0x1234567ULL);
+    const bool warm = kw > 0;
     double* cur = XB;          // columns [0,n) of `cur` hold the current basis B (p x n)
     double* nxt = XA;
     bool have_prev = false;
@@ -773,7 +803,7 @@ int svd_iter(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* Ut, double
         int st;
         const double fro = host_fro(ctx, nxt, p, n, ld, norms, h, &st);
         CTM_TRY(st);
-        CTM_TRY(jacobi_rows(ctx, nxt, p, ld, n, (int)ld, b, std::min(k, p - 1), fro, have_prev ? ctx->si_rr_sweeps : std::min(3, ctx->si_rr_sweeps)));
+        CTM_TRY(jacobi_rows(ctx, nxt, p, ld, n, (int)ld, b, std::min(k, p - 1), fro, (have_prev || warm) ? ctx->si_rr_sweeps : std::min(3, ctx->si_rr_sweeps)));
         CTM_TRY(row_norms(ctx, nxt, p, n, ld, norms));
         h.assign(p_full, 0.0);
         CTM_HIP_CHECK(ctx, hipMemcpyAsync(h.data(), norms, sizeof(double) * p, hipMemcpyDeviceToHost, ctx->stream));
@@ -810,6 +840,7 @@ int svd_iter(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* Ut, double
     CTM_TRY(reorth_rows(ctx, Ut, kv, n, n, 1));
     CTM_TRY(reorth_rows(ctx, Vt, kv, n, n, 1));
     ctx->si_last_rank = rank;
+    ctx->si_warm_starts += warm ? 1 : 0;
     return CTM_OK;
 }
 
@@ -843,6 +874,20 @@ __global__ void panel_times_i_kernel(const double* src, long long lds, double* d
         const bool is_im = ((r / BC) & 1) != 0;
         dst[r * ldd + c] = is_im ? src[(r - BC) * lds + c] : -src[(r + BC) * lds + c];
     }
+}
+
+// panel rows [row0, row0 + rows) of dst <- planar complex rows (re, im: rows x cols, leading dim lds)
+__global__ void planar_to_panel_kernel(const double* re, const double* im, long long lds, int rows, int cols, double* dst, long long ldd, int row0) {
+    const size_t tot = (size_t)rows * cols;
+    for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < tot; q += (size_t)gridDim.x * blockDim.x) {
+        const long long r = q / cols, c = q - r * cols;
+        const long long cr = row0 + r, rr = (cr / BC) * (2 * BC) + (cr % BC);
+        dst[rr * ldd + c] = re[r * lds + c]; dst[(rr + BC) * ldd + c] = im[r * lds + c];
+    }
+}
+
+__global__ void sub_inplace_kernel(double* x, const double* y, size_t n) {
+    for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (size_t)gridDim.x * blockDim.x) x[q] -= y[q];
 }
 
 // per real row r of a panel matrix: out[r] = norm of the complex row it belongs to (both of its real rows get the value)
@@ -997,7 +1042,37 @@ int svd_iter_c(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* Ut, doub
     CTM_TRY(arena_alloc(ctx, sizeof(double) * 2 * p_full, (void**)&inv));
     CTM_TRY(arena_alloc(ctx, sizeof(double) * 2 * p_full, (void**)&res));
     std::vector<double> h(p_full, 0.0), hr(p_full, 0.0), tmp(2 * p_full);
-    hipLaunchKernelGGL(hash_fill_kernel, dim3(1024), dim3(256), 0, ctx->stream, XB, 2 * p, n, ld, 0x1234567ULL);
+    // warm start: see svd_iter(); the caller's basis is planar (k x n re plane, then im plane)
+    int kw = 0;
+    const size_t wkn = (size_t)k * n;
+    if (op.warm) {
+        CTM_TRY(row_norms_c128(ctx, op.warm, op.warm + wkn, std::min(k, p_full), n, n, norms));
+        CTM_HIP_CHECK(ctx, hipMemcpyAsync(h.data(), norms, sizeof(double) * std::min(k, p_full), hipMemcpyDeviceToHost, ctx->stream));
+        CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        while (kw < std::min(k, p_full) && std::fabs(h[kw] - 1.0) < 1e-6) ++kw;
+        std::fill(h.begin(), h.end(), 0.0);
+    }
+    if (kw > 0) {
+        p = std::min(p_full, std::max(64, ((kw + 16 + 63) / 64) * 64));
+        kw = std::min(kw, p - 8);
+        const int pr = p - kw;
+        ArenaScope ws(ctx);
+        double *Rn, *Gw, *Tw;
+        const size_t rn = (size_t)pr * n;
+        CTM_TRY(arena_alloc(ctx, sizeof(double) * 2 * rn, (void**)&Rn));
+        CTM_TRY(arena_alloc(ctx, sizeof(double) * 2 * (size_t)pr * kw, (void**)&Gw));
+        CTM_TRY(arena_alloc(ctx, sizeof(double) * 2 * rn, (void**)&Tw));
+        hipLaunchKernelGGL(hash_fill_kernel, dim3(1024), dim3(256), 0, ctx->stream, Rn, 2 * pr, n, (long long)n, 0x1234567ULL);
+        XM r{Rn, Rn + rn, n, false, false}, vh{op.warm, op.warm + wkn, n, true, true}, v{op.warm, op.warm + wkn, n, false, false};
+        CTM_TRY(xgemm(ctx, pr, kw, n, r, vh, Gw, Gw + (size_t)pr * kw, kw));            // G = R V^H
+        XM g{Gw, Gw + (size_t)pr * kw, kw, false, false};
+        CTM_TRY(xgemm(ctx, pr, n, kw, g, v, Tw, Tw + rn, n));                             // T = G V
+        hipLaunchKernelGGL(sub_inplace_kernel, dim3(2048), dim3(256), 0, ctx->stream, Rn, Tw, 2 * rn);
+        hipLaunchKernelGGL(planar_to_panel_kernel, dim3(2048), dim3(256), 0, ctx->stream, op.warm, op.warm + wkn, (long long)n, kw, n, XB, ld, 0);
+        hipLaunchKernelGGL(planar_to_panel_kernel, dim3(2048), dim3(256), 0, ctx->stream, Rn, Rn + rn, (long long)n, pr, n, XB, ld, kw);
+    } else
+        hipLaunchKernelGGL(hash_fill_kernel, dim3(1024), dim3(256), 0, ctx->stream, XB, 2 * p, n, ld, 0x1234567ULL);
+    const bool warm = kw > 0;
     double* cur = XB; double* nxt = XA;
     bool have_prev = false;
     int side = 0;              // 0: C = B M^H (B = rows v^H, produces s u^H) ; 1: C = B M (B = rows u^H, produces s v^H)
@@ -1038,7 +1113,7 @@ int svd_iter_c(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* Ut, doub
         std::vector<double> hh;
         const double fro = host_fro(ctx, nxt, R, n, ld, norms, hh, &st);
         CTM_TRY(st);
-        CTM_TRY(jacobi_rows(ctx, nxt, R, ld, n, (int)ld, 2 * BC, std::min(k, p - 1), fro, have_prev ? ctx->si_rr_sweeps : std::min(3, ctx->si_rr_sweeps), true));
+        CTM_TRY(jacobi_rows(ctx, nxt, R, ld, n, (int)ld, 2 * BC, std::min(k, p - 1), fro, (have_prev || warm) ? ctx->si_rr_sweeps : std::min(3, ctx->si_rr_sweeps), true));
         CTM_TRY(row_norms(ctx, nxt, R, n, ld, norms));
         hipLaunchKernelGGL(panel_combine_kernel, dim3((R + 255) / 256), dim3(256), 0, ctx->stream, norms, nc, R);
         CTM_HIP_CHECK(ctx, hipMemcpyAsync(tmp.data(), nc, sizeof(double) * R, hipMemcpyDeviceToHost, ctx->stream));
@@ -1081,6 +1156,7 @@ int svd_iter_c(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* Ut, doub
     CTM_HIP_CHECK(ctx, hipMemcpyAsync(Vt, Vc, sizeof(double) * kvn, hipMemcpyDeviceToDevice, ctx->stream));
     CTM_HIP_CHECK(ctx, hipMemcpyAsync(Vt + kn, Vc + kvn, sizeof(double) * kvn, hipMemcpyDeviceToDevice, ctx->stream));
     ctx->si_last_rank = rank;
+    ctx->si_warm_starts += warm ? 1 : 0;
     return CTM_OK;
 }
 
@@ -1089,14 +1165,19 @@ int svd_iter_c(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* Ut, doub
 int jacobi_svd_top_op(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* Ut, double* Vt) {
     const int n = op.n;
     if (n <= 0 || k <= 0 || k > n) { ctx->set_error("jacobi_svd_top: bad n/k"); return CTM_ERR_BADARG; }
+    const size_t wz = (op.Mi || op.ci[0]) ? 2 : 1;
+    auto keep_warm = [&]() -> int {     // the right row factor is the next call's starting basis
+        if (op.warm && Vt) CTM_HIP_CHECK(ctx, hipMemcpyAsync(op.warm, Vt, sizeof(double) * wz * (size_t)k * n, hipMemcpyDeviceToDevice, ctx->stream));
+        return CTM_OK;
+    };
     if (op.Mi || op.ci[0]) {        // complex128
         if (Ut && Vt && ctx->si_enable && k < n && n >= ctx->si_min_n) {
             bool ok = false;
             CTM_TRY(svd_iter_c(ctx, op, k, S, Ut, Vt, &ok));
-            if (ok) { ctx->si_hits += 1; return CTM_OK; }
+            if (ok) { ctx->si_hits += 1; return keep_warm(); }
             ctx->si_fallbacks += 1;
         }
-        if (op.M) return svd_full_c(ctx, op.M, op.Mi, n, k, S, Ut, Vt);
+        if (op.M) { CTM_TRY(svd_full_c(ctx, op.M, op.Mi, n, k, S, Ut, Vt)); return keep_warm(); }
         ArenaScope scope(ctx);
         const size_t nn = (size_t)n * n;
         double *R, *Rt, *M;
@@ -1109,15 +1190,16 @@ int jacobi_svd_top_op(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* U
         CTM_TRY(xgemm(ctx, n, n, n, c, d, Rt, Rt + nn, n));
         XM rT{R, R + nn, n, true, false}, rt{Rt, Rt + nn, n, false, false};
         CTM_TRY(xgemm(ctx, n, n, n, rT, rt, M, M + nn, n));
-        return svd_full_c(ctx, M, M + nn, n, k, S, Ut, Vt);
+        CTM_TRY(svd_full_c(ctx, M, M + nn, n, k, S, Ut, Vt));
+        return keep_warm();
     }
     if (Ut && Vt && ctx->si_enable && k < n && n >= ctx->si_min_n) {
         bool ok = false;
         CTM_TRY(svd_iter(ctx, op, k, S, Ut, Vt, &ok));
-        if (ok) { ctx->si_hits += 1; return CTM_OK; }
+        if (ok) { ctx->si_hits += 1; return keep_warm(); }
         ctx->si_fallbacks += 1;
     }
-    if (op.M) return svd_full(ctx, op.M, n, k, S, Ut, Vt);
+    if (op.M) { CTM_TRY(svd_full(ctx, op.M, n, k, S, Ut, Vt)); return keep_warm(); }
     // materialise M = R^T Rt for the full decomposition: M = I * M
     ArenaScope scope(ctx);
     double *M, *I;
@@ -1125,7 +1207,8 @@ int jacobi_svd_top_op(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* U
     CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)n * n, (void**)&I));
     CTM_TRY(set_identity(ctx, I, n, n));
     CTM_TRY(matop_apply(ctx, op, false, I, n, n, M, n));
-    return svd_full(ctx, M, n, k, S, Ut, Vt);
+    CTM_TRY(svd_full(ctx, M, n, k, S, Ut, Vt));
+    return keep_warm();
 }
 
 int jacobi_svd_top(ctm_ctx* ctx, const double* M, int n, int k, double* S, double* Ut, double* Vt) {

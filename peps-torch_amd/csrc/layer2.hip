@@ -12,6 +12,7 @@
 // The site tensor (p D^4 <= 8192 doubles) lives in LDS for the whole kernel in ONE image [c][s][e] that serves both
 // layers (real dtype: conj(a) = a).  One workgroup = 4 waves; each (x,y) costs 2 p (KAp/16)(NEp/16)(KAp/4) MFMAs.
 #include "contract.h"
+#include <mutex>
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
@@ -161,11 +162,8 @@ __global__ __launch_bounds__(512) void layer2_kernel(Layer2Params p) {
 
 template <int KT>
 int launch_layer2(ctm_ctx* ctx, const Layer2Params& p, size_t lds_bytes) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)layer2_kernel<KT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
+    static std::once_flag attr_once;
+    std::call_once(attr_once, [] { (void)hipFuncSetAttribute((const void*)layer2_kernel<KT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
     const long long npair = (long long)p.nx * p.ny;
     const int per_cu = (lds_bytes <= 40 * 1024) ? 3 : (lds_bytes <= 76 * 1024 ? 2 : 1);
     const int grid = (int)std::min<long long>(npair, 256LL * per_cu * 2);

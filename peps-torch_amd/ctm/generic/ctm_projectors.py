@@ -17,8 +17,22 @@ def ctm_get_projectors_4x4(direction, coord, state, env, ctm_args=cfg.ctm_args, 
         raise ValueError(f"Projector svd method \"{ctm_args.projector_svd_method}\" not implemented")
     eng = get_engine()
     if hasattr(eng, "projectors_4x4"):
-        # fused native path: corners -> implicit M = R^T Rt -> P, Pt (halves never materialised)
-        return eng.projectors_4x4(direction, _halves_t(direction, coord, state, env), env.chi, _trunc_cfg(eng, ctm_args))
+        # fused native path: corners -> implicit M = R^T Rt -> P, Pt (halves never materialised).  The environment
+        # remembers, per (direction, site), the right singular basis of the previous sweep: the leading-chi iteration of
+        # the next sweep starts from it (residual-verified either way; `projector_warm_start=False` disables it).
+        t16 = _halves_t(direction, coord, state, env)
+        basis = None
+        if getattr(ctm_args, "projector_warm_start", True) and hasattr(eng, "warm_basis"):
+            a = t16[3]
+            n = env.chi * a.shape[1] ** 2
+            ws = env.__dict__.setdefault("_warm", {})
+            key = (direction, coord)
+            k = env.chi + 1 if env.chi < n else n
+            b = ws.get(key)
+            if b is None or b.shape[1] != n or b.shape[0] != (2 if a.dtype.is_complex else 1) * k or b.device != a.device:
+                b = ws[key] = eng.warm_basis(env.chi, n, a.dtype)
+            basis = b
+        return eng.projectors_4x4(direction, t16, env.chi, _trunc_cfg(eng, ctm_args), basis=basis)
     R, Rt = _halves(direction, coord, state, env)
     return ctm_get_projectors_from_matrices(R, Rt, env.chi, ctm_args, global_args, diagnostics=diagnostics)
 

@@ -105,10 +105,20 @@ def ctm_MOVE(direction, state, env, ctm_args=cfg.ctm_args, global_args=cfg.globa
     chi = env.chi
     like = next(iter(env.C.values()))
 
+    # my units of a phase are independent: issue them concurrently (own context + stream each) when that pays
+    pool = None
+    if getattr(ctm_args, "concurrent_units", True) and len(mine) > 1:
+        import units
+        pool = units.pool_for(eng, len(mine), max(_proj_rows(direction, c, state, chi) for c in mine), like.dtype.is_complex)
+
+    def _each(fn, items):
+        return pool.map(fn, items) if pool is not None else [fn(it) for it in items]
+
     # phase A: projectors of my sites from the old env
     P, Pt = {}, {}
-    for coord in mine:
-        P[coord], Pt[coord] = ctm_get_projectors_4x4(direction, coord, state, env, ctm_args, global_args, diagnostics=diagnostics)
+    for coord, (p_, pt_) in zip(mine, _each(lambda c: ctm_get_projectors_4x4(direction, c, state, env, ctm_args, global_args,
+                                                                             diagnostics=diagnostics), mine)):
+        P[coord], Pt[coord] = p_, pt_
     if parallel.is_distributed():
         shp = {}
         for coord in coords:
@@ -118,9 +128,7 @@ def ctm_MOVE(direction, state, env, ctm_args=cfg.ctm_args, global_args=cfg.globa
         Pt = parallel.exchange(Pt, coords, shp, like)
 
     # phase B: absorb + normalise my sites
-    new = {}
-    for coord in mine:
-        new[coord] = _absorb(direction, coord, state, env, P, Pt, ctm_args, normalize=True)
+    new = dict(zip(mine, _each(lambda c: _absorb(direction, c, state, env, P, Pt, ctm_args, normalize=True), mine)))
     if parallel.is_distributed():
         packs = {c: torch.cat([t.reshape(-1) for t in v]) for c, v in new.items()}
         shp = {c: (2 * chi * chi + chi * chi * _out_D2(direction, state.site(c)),) for c in coords}

@@ -1,0 +1,76 @@
+"""Concurrent execution of the independent (site, direction) units of one directional move on ONE GPU.
+
+Inside a move the per-site projector constructions (and, after them, the per-site absorptions) only read the old
+environment (reference ctm/generic/ctmrg.py:238-275), so they are independent.  At small and medium n = chi D^2 a
+single unit cannot fill 256 CUs (its chi-truncation has latency-bound stages: one-workgroup LDS eigensolves, host
+decisions between half steps), so the units of a phase are issued from separate host threads, each with its own
+native context, workspace arena and HIP stream; the GPU overlaps them.  Stream order: every worker stream waits for
+an event recorded on the caller's stream before it starts, and the caller's stream waits for every worker's final
+event, so each phase is bracketed by full cross-stream barriers (which also makes cross-stream reuse of torch's
+cached blocks safe: tensors are only released at phase boundaries)."""
+import threading
+from concurrent.futures import ThreadPoolExecutor
+import torch
+import backend
+
+
+class UnitPool:
+    def __init__(self, main_engine, nworkers):
+        self.main = main_engine
+        self.device = main_engine.device
+        self.n = nworkers
+        self.streams = [torch.cuda.Stream(self.device) for _ in range(nworkers)]
+        self.engines = [None] * nworkers
+        self.pool = ThreadPoolExecutor(max_workers=nworkers, thread_name_prefix="ctm-unit")
+
+    def _run(self, slot, fn, item, ev0):
+        s = self.streams[slot]
+        with torch.cuda.device(self.device), torch.cuda.stream(s):
+            s.wait_event(ev0)
+            if self.engines[slot] is None:
+                self.engines[slot] = self.main.spawn_worker()        # binds the current (= worker) stream
+            backend.set_thread_engine(self.engines[slot])
+            try:
+                out = fn(item)
+            finally:
+                backend.set_thread_engine(None)
+            ev = torch.cuda.Event()
+            ev.record(s)
+        return out, ev
+
+    def map(self, fn, items):
+        """[fn(item) for item in items], at most `nworkers` at a time, each on its own stream/context."""
+        items = list(items)
+        main_stream = torch.cuda.current_stream(self.device)
+        outs = []
+        for c0 in range(0, len(items), self.n):
+            chunk = items[c0:c0 + self.n]
+            ev0 = torch.cuda.Event()
+            ev0.record(main_stream)
+            futs = [self.pool.submit(self._run, slot, fn, it, ev0) for slot, it in enumerate(chunk)]
+            res = [f.result() for f in futs]
+            for out, ev in res:
+                main_stream.wait_event(ev)
+                outs.append(out)
+        return outs
+
+
+_pools = {}
+_lock = threading.Lock()
+
+
+def pool_for(engine, nunits, n, is_complex):
+    """UnitPool sized for `nunits` concurrent units of fused dimension n, or None when concurrency is off / pointless
+    (stand-in engines, a single unit, or not enough HBM for one workspace arena per unit)."""
+    if nunits < 2 or not hasattr(engine, "spawn_worker"):
+        return None
+    total = torch.cuda.get_device_properties(engine.device).total_memory
+    est = 14.0 * n * n * 8 * (2 if is_complex else 1)            # peak workspace of one unit (corners, products, work)
+    nw = int(min(nunits, max(1, (0.5 * total) // max(est, 1.0))))
+    if nw < 2:
+        return None
+    key = (engine.device.index, nw)
+    with _lock:
+        if key not in _pools:
+            _pools[key] = UnitPool(engine, nw)
+        return _pools[key]
