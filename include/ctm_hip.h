@@ -101,6 +101,10 @@ int ctm_c2x2_c4v(ctm_ctx* ctx, int open, const double* a, const double* C, const
                  double* out);
 int ctm_move_c4v(ctm_ctx* ctx, const double* a, const double* C, const double* T, int chi, int p, int D,
                  const ctm_trunc_cfg* cfg, double* C_out, double* T_out, double* D_out /* chi eigenvalues or NULL */);
+/* Same, warm started: `basis` is an opaque caller-owned device workspace of (min(chi+1,n)+8) * n doubles, zero-filled before the
+ * first sweep and passed again on every later one (invariant subspace of the previous enlarged corner; see ctm_projectors_4x4_ws). */
+int ctm_move_c4v_ws(ctm_ctx* ctx, const double* a, const double* C, const double* T, int chi, int p, int D,
+                    const ctm_trunc_cfg* cfg, double* C_out, double* T_out, double* D_out, double* basis);
 
 /* ---- RDMs (ctm/generic/rdm.py:1362-1592, 71-302, 304-500, 622-826; one_site_c4v/rdm_c4v.py) ---------- */
 /* rdm2x2: tensors16 = (C,T1,T2,a) for LU(coord), RU(coord+x), RD(coord+x+y), LD(coord+y); out p^8 raw

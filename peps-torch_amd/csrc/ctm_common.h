@@ -188,6 +188,6 @@ int jacobi_svd_top_op(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* U
 int jacobi_svd_top(ctm_ctx* ctx, const double* M, int n, int k, double* S, double* Ut, double* Vt);
 // Symmetric eigendecomposition (lower triangle of A is referenced), k leading eigenpairs by |lambda|:
 //   D[k] (signed), Ut (k x n, rows = eigenvectors).
-int jacobi_eigh_top(ctm_ctx* ctx, const double* A, int n, int k, double* D, double* Ut);
+int jacobi_eigh_top(ctm_ctx* ctx, const double* A, int n, int k, double* D, double* Ut, double* warm = nullptr);
 // singular values only, small matrices (corner spectra)
 int jacobi_svdvals(ctm_ctx* ctx, const double* M, const double* Mi /* nullptr: real */, int n, double* S);

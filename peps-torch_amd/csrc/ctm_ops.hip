@@ -363,7 +363,14 @@ int ctm_truncated_svd(ctm_ctx* ctx, const double* M, int n, int chi, const ctm_t
     return CTM_OK;
 }
 
+namespace { int truncated_eigh_impl(ctm_ctx* ctx, const double* A, int n, int chi, const ctm_trunc_cfg* cfg_, double* D, double* U, double* warm); }
+
 int ctm_truncated_eigh(ctm_ctx* ctx, const double* A, int n, int chi, const ctm_trunc_cfg* cfg_, double* D, double* U) {
+    return truncated_eigh_impl(ctx, A, n, chi, cfg_, D, U, nullptr);
+}
+
+namespace {
+int truncated_eigh_impl(ctm_ctx* ctx, const double* A, int n, int chi, const ctm_trunc_cfg* cfg_, double* D, double* U, double* warm) {
     ctm_trunc_cfg cfg = cfg_ ? *cfg_ : kDefaultCfg;
     if (!cfg_) { cfg.eps_multiplet = 1.0e-12; }
     if (chi < 1 || n < 1) { ctx->set_error("truncated_eigh: bad dims"); return CTM_ERR_BADARG; }
@@ -374,7 +381,7 @@ int ctm_truncated_eigh(ctm_ctx* ctx, const double* A, int n, int chi, const ctm_
     double *Ut, *dD;
     CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)k * n, (void**)&Ut));
     CTM_TRY(arena_alloc(ctx, sizeof(double) * k, (void**)&dD));
-    CTM_TRY(jacobi_eigh_top(ctx, A, n, k, dD, Ut));
+    CTM_TRY(jacobi_eigh_top(ctx, A, n, k, dD, Ut, warm));
     std::vector<double> Dh(k);
     CTM_HIP_CHECK(ctx, hipMemcpyAsync(Dh.data(), dD, sizeof(double) * k, hipMemcpyDeviceToHost, ctx->stream));
     CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
@@ -387,6 +394,7 @@ int ctm_truncated_eigh(ctm_ctx* ctx, const double* A, int n, int chi, const ctm_
     CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     return CTM_OK;
 }
+}  // namespace
 
 int ctm_svdvals(ctm_ctx* ctx, const double* M, int n, double* S) {
     ArenaScope scope(ctx);
@@ -563,6 +571,11 @@ int ctm_c2x2_c4v(ctm_ctx* ctx, int open, const double* a, const double* C, const
 
 int ctm_move_c4v(ctm_ctx* ctx, const double* a, const double* C, const double* T, int chi, int p, int D,
                  const ctm_trunc_cfg* cfg_, double* C_out, double* T_out, double* D_out) {
+    return ctm_move_c4v_ws(ctx, a, C, T, chi, p, D, cfg_, C_out, T_out, D_out, nullptr);
+}
+
+int ctm_move_c4v_ws(ctm_ctx* ctx, const double* a, const double* C, const double* T, int chi, int p, int D,
+                    const ctm_trunc_cfg* cfg_, double* C_out, double* T_out, double* D_out, double* basis) {
     ctm_trunc_cfg cfg = cfg_ ? *cfg_ : kDefaultCfg;
     if (!cfg_) cfg.eps_multiplet = 1.0e-12;          // custom_eig.py default used by ctmrg_c4v.py:49-52
     if (ctx->cplx) { ctx->set_error("move_c4v: the one-site C4v move is float64 only in this build"); return CTM_ERR_UNSUPPORTED; }
@@ -573,7 +586,7 @@ int ctm_move_c4v(ctm_ctx* ctx, const double* a, const double* C, const double* T
     CTM_TRY(arena_alloc(ctx, sizeof(double) * chi, (void**)&Dv));
     CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)n * chi, (void**)&P));
     CTM_TRY(ctm_c2x2_c4v(ctx, 0, a, C, T, chi, p, D, C2X2));
-    CTM_TRY(ctm_truncated_eigh(ctx, C2X2, n, chi, &cfg, Dv, P));
+    CTM_TRY(truncated_eigh_impl(ctx, C2X2, n, chi, &cfg, Dv, P, basis));
     PhaseTimer pt(ctx, CTM_T_ABSORB);
     CTM_TRY(diag_to_matrix(ctx, Dv, C_out, chi));                                     // ctmrg_c4v.py:374
     if (D_out) CTM_HIP_CHECK(ctx, hipMemcpyAsync(D_out, Dv, sizeof(double) * chi, hipMemcpyDeviceToDevice, ctx->stream));

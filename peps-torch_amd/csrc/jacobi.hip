@@ -1221,7 +1221,7 @@ int jacobi_svdvals(ctm_ctx* ctx, const double* M, const double* Mi, int n, doubl
     return svd_full(ctx, M, n, n, S, nullptr, nullptr);
 }
 
-int jacobi_eigh_top(ctm_ctx* ctx, const double* A, int n, int k, double* D, double* Ut) {
+int jacobi_eigh_top(ctm_ctx* ctx, const double* A, int n, int k, double* D, double* Ut, double* warm) {
     if (n <= 0 || k <= 0 || k > n) { ctx->set_error("jacobi_eigh_top: bad n/k"); return CTM_ERR_BADARG; }
     ArenaScope scope(ctx);
     double* As;
@@ -1237,9 +1237,10 @@ int jacobi_eigh_top(ctm_ctx* ctx, const double* A, int n, int k, double* D, doub
         CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)kk * n, (void**)&Uk));
         CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)kk * n, (void**)&Vk));
         bool ok = false;
-        MatOp aop; aop.n = n; aop.M = As;
+        MatOp aop; aop.n = n; aop.M = As; aop.warm = warm;     // warm: (k + 8) x n rows of the previous invariant subspace
         CTM_TRY(svd_iter(ctx, aop, kk, S, Uk, Vk, &ok));
         if (ok) {
+            if (warm) CTM_HIP_CHECK(ctx, hipMemcpyAsync(warm, Vk, sizeof(double) * (size_t)kk * n, hipMemcpyDeviceToDevice, ctx->stream));
             const int k = kk;
             ctx->si_hits += 1;
             // T = U A U^T (k x k, symmetric, diagonal except inside clusters of equal |lambda|)
@@ -1253,7 +1254,7 @@ int jacobi_eigh_top(ctm_ctx* ctx, const double* A, int n, int k, double* D, doub
             GemmDesc t; t.M = k; t.N = k; t.K = n; t.A = Y; t.sam = n; t.sak = 1; t.B = Uk; t.sbk = 1; t.sbn = n; t.C = T; t.ldc = k;
             CTM_TRY(gemm_f64(ctx, t));
             const bool save = ctx->si_enable; ctx->si_enable = false;
-            const int st = jacobi_eigh_top(ctx, T, k, k, Dk, Th);      // full small problem (rows of Th = eigenvectors)
+            const int st = jacobi_eigh_top(ctx, T, k, k, Dk, Th, nullptr);      // full small problem (rows of Th = eigenvectors)
             ctx->si_enable = save;
             CTM_TRY(st);
             // eigen-pairs of T come ordered by |lambda|: keep the leading k_out

@@ -41,7 +41,15 @@ def ctm_MOVE_sl(a, env, f_c2x2_decomp=None, ctm_args=cfg.ctm_args, global_args=c
         raise NotImplementedError("ctm_absorb_normalization: only 'inf' is implemented natively")
     eng = get_engine()
     cfgT = eng.cfg(eps_multiplet=1.0e-12, multiplet_abstol=1.0e-14, keep_multiplets=True)
-    nC, nT, _D = eng.move_c4v(a, env.C[env.keyC], env.T[env.keyT], cfgT)
+    basis = None
+    if getattr(ctm_args, "projector_warm_start", True) and hasattr(eng, "warm_basis_c4v"):
+        # the environment remembers the invariant subspace of the previous enlarged corner (residual-verified restart)
+        n = env.chi * a.shape[1] ** 2
+        basis = env.__dict__.get("_warm")
+        k = env.chi + 1 if env.chi < n else n
+        if basis is None or tuple(basis.shape) != (min(n, k + 8), n) or basis.device != a.device:
+            basis = env.__dict__["_warm"] = eng.warm_basis_c4v(env.chi, n)
+    nC, nT, _D = eng.move_c4v(a, env.C[env.keyC], env.T[env.keyT], cfgT, **({"basis": basis} if basis is not None else {}))
     env.C[env.keyC] = nC
     env.T[env.keyT] = nT
 
