@@ -32,7 +32,7 @@ CONFIGS = {
     "generic_D6_chi128_c128": ("generic", 6, 128, "c128"),
     "generic_D8_chi384_c128": ("generic", 8, 384, "c128"),     # BASELINE.json configs[4] (quoted there on 8 GPUs)
 }
-DEFAULT_CONFIG = "generic_D6_chi128"       # largest single-GPU configuration in BASELINE.json configs
+DEFAULT_CONFIG = "generic_D8_chi256"       # the configuration BASELINE.json's north_star quotes the metric on (fits one GPU)
 FP64_MFMA_PEAK_TFLOPS = 78.6               # MI355X FP64 matrix peak (v_mfma_f64_16x16x4_f64, 32 flop/clk/SIMD)
 
 
@@ -86,6 +86,8 @@ def cpu_baseline(kind, D, chi, sites, budget_s=25.0):
                 "sample": f"{n} full C4v sweeps of the numpy oracle (LAPACK eigh), {os.cpu_count()} host cpus"}
     ost = O.State(sites)
     env = O.init_env_ctmrg(ost, chi)
+    if chi * D * D > 6000:
+        return cpu_baseline_large(O, ost, env, D, chi, threads)
     # make the environment dense with the cheapest possible warm-up: random dense env of the right shapes
     rng = np.random.default_rng(7)
     cx = np.iscomplexobj(sites[(0, 0)])
@@ -99,6 +101,34 @@ def cpu_baseline(kind, D, chi, sites, budget_s=25.0):
     return {"value": 1.0 / (32 * dt), "unit": "sweeps/s", "cores": threads, "kind": "port",
             "sample": f"1 of the 32 (site,direction) units of one sweep (numpy oracle: 4 corners, 2 halves, M, LAPACK gesdd, "
                       f"projectors, absorb) = {dt:.2f} s, extrapolated x32; {os.cpu_count()} host cpus"}
+
+
+def cpu_baseline_large(O, ost, env, D, chi, threads):
+    """n = chi D^2 > 6000: one full unit on the CPU takes many minutes (LAPACK gesdd of an n x n matrix), so the unit is
+    assembled from bounded pieces: the four enlarged corners and the absorb are timed at full size with the oracle, ONE
+    n x n x n product is timed and counted three times (two halves + M = R^T Rt), and the SVD is timed at n_s = 4096 and
+    scaled by (n / n_s)^3."""
+    rng = np.random.default_rng(7)
+    cx = np.iscomplexobj(next(iter(ost.sites.values())))
+    for k in env.C: env.C[k] = rng.random(env.C[k].shape) + (1j * rng.random(env.C[k].shape) if cx else 0.0)
+    for k in env.T: env.T[k] = rng.random(env.T[k].shape) + (1j * rng.random(env.T[k].shape) if cx else 0.0)
+    n = chi * D * D
+    t0 = time.perf_counter()
+    cs = [O.c2x2(cid, (0, 0), ost, env) for cid in range(4)]
+    t_corners = time.perf_counter() - t0
+    t0 = time.perf_counter(); R = cs[0] @ cs[1]; t_gemm = time.perf_counter() - t0
+    ns = 4096
+    t0 = time.perf_counter(); np.linalg.svd(cs[2][:ns, :ns]); t_svd_s = time.perf_counter() - t0
+    t_svd = t_svd_s * (n / ns) ** 3
+    P = rng.random((n, chi)) + (1j * rng.random((n, chi)) if cx else 0.0)
+    t0 = time.perf_counter(); _ = R @ P; _ = R @ P; t_proj = time.perf_counter() - t0
+    Pd = {c: P for c in ost.sites}
+    t0 = time.perf_counter(); O.absorb_truncate(O.UP, (0, 0), ost, env, Pd, Pd); t_abs = time.perf_counter() - t0
+    dt = t_corners + 3 * t_gemm + t_svd + t_proj + t_abs
+    return {"value": 1.0 / (32 * dt), "unit": "sweeps/s", "cores": threads, "kind": "port",
+            "sample": f"one (site,direction) unit of the numpy oracle assembled from bounded pieces: 4 corners {t_corners:.1f} s + 3 x (n^3 GEMM "
+                      f"{t_gemm:.1f} s) + gesdd at n_s=4096 {t_svd_s:.1f} s scaled by (n/n_s)^3 = {t_svd:.0f} s + projector GEMMs {t_proj:.1f} s + "
+                      f"absorb {t_abs:.1f} s = {dt:.0f} s/unit, x32 units/sweep (extrapolated); {os.cpu_count()} host cpus"}
 
 
 def main():
@@ -211,6 +241,22 @@ def main():
                 "gemm_time_share": round((u_ms[0] + u_ms[1]) * 1e-3 / dt, 4),
                 "other_gemm": {"kernel": names[1 - dom], "launches": int(k_n[1 - dom]), "ms": round(k_ms[1 - dom], 2),
                                "tflops": round(k_fl[1 - dom] / max(k_ms[1 - dom] * 1e-3, 1e-30) / 1e12, 3) if k_n[1 - dom] else 0.0}}
+        # HBM traffic of the dominant kernel family from the committed PMC pass of this same command (bench.py cannot attach
+        # counters to itself); null when the profile is for another workload
+        try:
+            import csv
+            prof = json.load(open(os.path.join(REPO, "profiles", "r01_bench_default.json")))
+            if prof["config"]["workload"] == args.config and world == 1:
+                key = "gemm_f64_fast_kernel" if dom == 0 else "gemm_f64_kernel<2, 2>"
+                tot_b = tot_n = 0.0
+                for row in csv.DictReader(open(os.path.join(REPO, "profiles", "r01_bench_default_pmc_hbm_traffic.csv"))):
+                    if key in row["kernel"] or (dom == 0 and "gemm_f64_kernel<4, 4>" in row["kernel"]):
+                        tot_b += float(row["hbm_bytes_per_launch(2x_fetch_corrected)"]) * float(row["launches"]); tot_n += float(row["launches"])
+                if tot_n:
+                    roof["traffic"] = round(tot_b / tot_n)
+                    roof["traffic_source"] = "profiles/r01_bench_default_pmc_hbm_traffic.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, bytes per launch)"
+        except Exception:
+            pass
         out = {"metric": "ctm_sweeps_per_sec", "value": steps / dt, "unit": "sweeps/s", "n_gpus": world, "steps": steps,
                "warmup": warmup, "ms_per_step": 1e3 * dt / steps, "higher_is_better": True, "scaling": "strong",
                "vs_baseline": None, "dtype": dtype, "data": "synthetic",

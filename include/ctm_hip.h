@@ -5,7 +5,10 @@
  * wraps in torch.utils.checkpoint / offloads to a GPU), each cited below with the reference
  * file:line (relative to the reference repo root).  All pointers are DEVICE pointers to
  * C-contiguous (row-major, as torch) float64 buffers unless stated otherwise; nothing is
- * retained after a call returns.  Every function returns an int status (CTM_OK == 0) and
+ * retained after a call returns.  In a CTM_C128 context every tensor pointer (declared double* below)
+ * addresses interleaved (re,im) complex128 elements exactly as torch stores them, all sizes/dims count
+ * complex elements, and singular values / spectra / S outputs stay real; the C4v entry points and
+ * ctm_truncated_eigh are float64 only (CTM_ERR_UNSUPPORTED).  Every function returns an int status (CTM_OK == 0) and
  * records a message retrievable with ctm_last_error().  One ctm_ctx is used by one host
  * thread at a time; work is enqueued on the context's HIP stream and the call returns after
  * enqueueing unless it needs a host decision (truncation logic), in which case it syncs.
@@ -44,15 +47,19 @@ int ctm_destroy(ctm_ctx* ctx);
 const char* ctm_last_error(ctm_ctx* ctx);
 const char* ctm_version(void);
 int ctm_sync(ctm_ctx* ctx);
-int ctm_set_option(ctm_ctx* ctx, const char* key, double value);   /* "jacobi_tol","jacobi_max_sweeps","jacobi_block","profile" */
-int ctm_get_stat(ctm_ctx* ctx, const char* key, double* value);    /* "last_sweeps","last_offnorm","gemm_flops","gemm_calls","arena_high" */
+int ctm_set_option(ctm_ctx* ctx, const char* key, double value);   /* "jacobi_tol","jacobi_max_sweeps","jacobi_block","jacobi_inner_sweeps","jacobi_verbose",
+                                                                      "si_enable","si_min_n","si_max_iter","si_tol","si_rr_sweeps","use_layer2","gemm_fast","gemm_timing","profile" */
+int ctm_get_stat(ctm_ctx* ctx, const char* key, double* value);    /* "last_sweeps","last_offnorm","total_sweeps","jacobi_calls","si_hits","si_fallbacks","si_total_iters",
+                                                                      "si_last_rank","si_warm_starts","gemm_flops","gemm_calls","layer2_flops","layer2_calls","arena_high",
+                                                                      "k_ms0|1","k_flops0|1","k_calls0|1" */
 int ctm_timers(ctm_ctx* ctx, double* out8, int reset);             /* corners,halves,svd,proj,absorb,norm,rdm,eig (s) */
 /* GEMM launches timed with HIP events while the option "gemm_timing" is on: quadruples (kind, start_ms, end_ms, flops) on a
  * process-wide clock (kind 0 = 128x128-tile kernels, 1 = 64x64-tile kernel).  out may be NULL to query *count (launches). */
 int ctm_gemm_intervals(ctm_ctx* ctx, double* out, long long capacity_doubles, long long* count);
 
 /* ---- primitives (replace tn_interface.py:3-27 contract/mm/permute) ------------------------------ */
-/* C[M,N] = alpha op(A) op(B) + beta C ; row-major; trans = 0 ('N') or 1 ('T', plain transpose) */
+/* C[M,N] = alpha op(A) op(B) + beta C ; row-major; trans = 0 ('N') or 1 ('T', plain transpose); CTM_C128 also 2 ('C', conjugate
+ * transpose), dense operands and beta == 0 */
 int ctm_gemm(ctm_ctx* ctx, int transA, int transB, int M, int N, int K, double alpha, const double* A, long long lda,
              const double* B, long long ldb, double beta, double* C, long long ldc);
 int ctm_permute(ctm_ctx* ctx, const double* in, double* out, int nd, const long long* dims, const int* perm);

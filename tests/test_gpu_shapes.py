@@ -113,3 +113,38 @@ def test_projectors_fused_equals_explicit(eng):
         P2, Pt2, S2 = eng.projectors_4x4(d, t16, 18, return_S=True)
         assert relerr(S2, S) < 1e-12
         assert relerr(P2 @ Pt2.t(), P @ Pt.t()) < 1e-7
+
+
+def test_concurrent_units_and_warm_start_do_not_change_the_environment(eng):
+    """Two sweeps with (concurrent streams + warm-started truncation) == two sweeps with both switched off,
+    on gauge invariants; n = 512 so the iterative truncation (the only consumer of the warm basis) is active."""
+    import config as cfg
+    from ipeps.ipeps import IPEPS
+    from ctm.generic.env import ENV, init_env
+    from ctm.generic import ctmrg
+    rng = np.random.default_rng(21)
+    D, chi = 4, 32
+    sites = {(x, y): rng.random((2, D, D, D, D)) for y in range(2) for x in range(2)}
+    sites = {k: v / np.abs(v).max() for k, v in sites.items()}
+    res = []
+    for flag in (True, False):
+        cfg.ctm_args.concurrent_units = flag
+        cfg.ctm_args.projector_warm_start = flag
+        st = IPEPS({k: dev(v) for k, v in sites.items()})
+        env = ENV(chi, st); init_env(st, env)
+        w0 = eng.stat("si_warm_starts")
+        for _ in range(2):
+            for d in cfg.ctm_args.ctm_move_sequence:
+                for _r in range(2):
+                    ctmrg.ctm_MOVE(d, st, env)
+        res.append(env)
+        if flag:
+            assert eng.stat("si_warm_starts") > w0 and len(eng.workers) >= 2
+        else:
+            assert eng.stat("si_warm_starts") == w0
+    cfg.ctm_args.concurrent_units = True
+    cfg.ctm_args.projector_warm_start = True
+    for k in res[0].C: assert relerr(res[0].C[k].abs(), res[1].C[k].abs()) < 1e-8, k
+    for k in res[0].T: assert relerr(res[0].T[k].abs(), res[1].T[k].abs()) < 1e-8, k
+    for k, s in res[0].get_spectra().items():
+        assert relerr(s, res[1].get_spectra()[k]) < 1e-9
