@@ -140,6 +140,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile", action="store_true", help="per-phase host timers (adds stream syncs)")
     ap.add_argument("--opt", action="append", default=[], help="engine option key=value (development)")
+    ap.add_argument("--signed", action="store_true", help="development: A ~ U(-1,1) instead of the reference's U[0,1) (flatter spectra)")
+    ap.add_argument("--serial-units", action="store_true", help="do not overlap the independent site-units of a move on streams")
+    ap.add_argument("--cold-start", action="store_true", help="no warm start of the leading-chi iteration")
     args = ap.parse_args()
     kind, D, chi, dtype = CONFIGS[args.config]
     steps = args.steps if args.steps is not None else (20 if kind == "c4v" else 2)
@@ -150,16 +153,20 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the engine has no CPU path")
+    if os.environ.get("CTM_BENCH_ONE_DEVICE"):      # development hook: several ranks on ONE GPU (gloo), to exercise the sharded path
+        local = 0
     torch.cuda.set_device(local)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(os.environ.get("CTM_BENCH_BACKEND", "nccl"), rank=rank, world_size=world)
     if args.gpus != world and rank == 0 and world > 1:
         print(f"# note: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
 
     import config as cfg
     cfg.global_args.device = f"cuda:{local}"
+    cfg.ctm_args.concurrent_units = not args.serial_units
+    cfg.ctm_args.projector_warm_start = not args.cold_start
     import _native
     from ipeps.ipeps import IPEPS
     from ipeps.ipeps_c4v import IPEPS_C4V
@@ -172,6 +179,9 @@ def main():
         k_, v_ = kv.split("="); eng.set_option(k_, float(v_))
     dev = torch.device("cuda", local)
     sites = synth_sites(kind, D, dtype=dtype)
+    if args.signed:
+        sites = {k: (2.0 * v - (1.0 + 1.0j if np.iscomplexobj(v) else 1.0)) for k, v in sites.items()}
+        sites = {k: v / np.abs(v).max() for k, v in sites.items()}
     if kind == "c4v":
         state = IPEPS_C4V(torch.from_numpy(sites[(0, 0)]).to(dev))
         env = ENV_C4V(chi, state); init_env_c4v(state, env)
@@ -205,9 +215,9 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     ivals = eng.gemm_intervals()
-    k_ms = [eng.stat("k_ms0"), eng.stat("k_ms1")]
-    k_fl = [eng.stat("k_flops0"), eng.stat("k_flops1")]
-    k_n = [eng.stat("k_calls0"), eng.stat("k_calls1")]
+    k_ms = [eng.stat("k_ms0"), eng.stat("k_ms1"), eng.stat("k_ms2")]
+    k_fl = [eng.stat("k_flops0"), eng.stat("k_flops1"), eng.stat("k_flops2")]
+    k_n = [eng.stat("k_calls0"), eng.stat("k_calls1"), eng.stat("k_calls2")]
     eng.set_option("gemm_timing", 0)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -229,7 +239,7 @@ def main():
                 else:
                     cur_b = max(cur_b, b)
             return tot + ((cur_b - cur_a) if cur_b is not None else 0.0)
-        u_ms = [union_ms(0), union_ms(1)]
+        u_ms = [union_ms(0), union_ms(1), union_ms(2)]
         ach = k_fl[dom] / max(u_ms[dom] * 1e-3, 1e-30) / 1e12 if k_n[dom] else 0.0
         per_launch = (k_fl[dom] / max(k_n[dom], 1)) / max(k_ms[dom] / max(k_n[dom], 1) * 1e-3, 1e-30) / 1e12 if k_n[dom] else 0.0
         roof = {"bound": "mfma", "kernel": names[dom], "achieved": round(ach, 3), "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -257,6 +267,11 @@ def main():
                     roof["traffic_source"] = "profiles/r01_bench_default_pmc_hbm_traffic.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, bytes per launch)"
         except Exception:
             pass
+        # the fused two-layer enlarged-corner / absorb kernel (MFMA from LDS; also the largest HBM consumer)
+        roof["enlarged_corner_kernel"] = {"kernel": "layer2_kernel<KT>", "launches": int(k_n[2]), "avg_launch_ms": round(k_ms[2] / max(k_n[2], 1), 4),
+                                          "busy_ms_union": round(u_ms[2], 3),
+                                          "mfma_tflops": round(k_fl[2] / max(u_ms[2] * 1e-3, 1e-30) / 1e12, 3) if k_n[2] else 0.0,
+                                          "mfma_frac": round(k_fl[2] / max(u_ms[2] * 1e-3, 1e-30) / 1e12 / FP64_MFMA_PEAK_TFLOPS, 4) if k_n[2] else 0.0}
         out = {"metric": "ctm_sweeps_per_sec", "value": steps / dt, "unit": "sweeps/s", "n_gpus": world, "steps": steps,
                "warmup": warmup, "ms_per_step": 1e3 * dt / steps, "higher_is_better": True, "scaling": "strong",
                "vs_baseline": None, "dtype": dtype, "data": "synthetic",

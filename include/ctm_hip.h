@@ -54,7 +54,7 @@ int ctm_get_stat(ctm_ctx* ctx, const char* key, double* value);    /* "last_swee
                                                                       "k_ms0|1","k_flops0|1","k_calls0|1" */
 int ctm_timers(ctm_ctx* ctx, double* out8, int reset);             /* corners,halves,svd,proj,absorb,norm,rdm,eig (s) */
 /* GEMM launches timed with HIP events while the option "gemm_timing" is on: quadruples (kind, start_ms, end_ms, flops) on a
- * process-wide clock (kind 0 = 128x128-tile kernels, 1 = 64x64-tile kernel).  out may be NULL to query *count (launches). */
+ * process-wide clock (kind 0 = 128x128-tile GEMM kernels, 1 = 64x64-tile GEMM kernel, 2 = fused two-layer kernel).  out may be NULL to query *count (launches). */
 int ctm_gemm_intervals(ctm_ctx* ctx, double* out, long long capacity_doubles, long long* count);
 
 /* ---- primitives (replace tn_interface.py:3-27 contract/mm/permute) ------------------------------ */
@@ -99,7 +99,8 @@ int ctm_projectors_4x4(ctm_ctx* ctx, int dir, const double* const* tensors16, in
 int ctm_projectors_4x4_ws(ctm_ctx* ctx, int dir, const double* const* tensors16, int chi, const int* adims4x5,
                           const ctm_trunc_cfg* cfg, double* P, double* Pt, double* S, double* basis);
 /* absorb_truncate_CTM_MOVE_<DIR>_c (ctmrg.py:343-438,459-564,585-680,701-804), 'sl' mode, followed by
- * move_normalize_c 'inf' (ctmrg.py:210-230) when normalize != 0.  tensors10 = C1,T1,T,T2,C2,A,P2,Pt2,P1,Pt1 */
+ * move_normalize_c (ctmrg.py:210-230): normalize = 0 none, 1 'inf' (max-abs), 2 vector 2-norm.
+ * tensors10 = C1,T1,T,T2,C2,A,P2,Pt2,P1,Pt1 */
 int ctm_absorb(ctm_ctx* ctx, int dir, const double* const* tensors10, int chi, const int* adims, int normalize,
                double* nC1, double* nC2, double* nT);
 

@@ -327,16 +327,18 @@ def absorb_truncate(direction, coord, state, env, P, Pt):
 _REL = {UP: ((1, -1), (-1, -1)), LEFT: ((-1, -1), (-1, 1)), DOWN: ((-1, 1), (1, 1)), RIGHT: ((1, 1), (1, -1))}
 
 
-def ctm_move(direction, state, env, **kw):
+def ctm_move(direction, state, env, norm_type='inf', **kw):
     """ctm_MOVE (ctmrg.py:179-319): projectors for all sites from the OLD env, absorb for all
-    sites, normalise each new tensor by its own max-abs, scatter to coord - direction."""
+    sites, normalise each new tensor by its own max-abs ('inf') or vector 2-norm (any other
+    ctm_absorb_normalization, ctmrg.py:210-230), scatter to coord - direction."""
+    nrm = _nrm if norm_type == 'inf' else (lambda a: a / np.linalg.norm(a.ravel()))
     P, Pt = {}, {}
     for coord in state.sites:
         P[coord], Pt[coord] = get_projectors_4x4(direction, coord, state, env, **kw)
     new = {}
     for coord in state.sites:
         nC1, nC2, nT = absorb_truncate(direction, coord, state, env, P, Pt)
-        new[coord] = (_nrm(nC1), _nrm(nC2), _nrm(nT))                  # :210-230 'inf'
+        new[coord] = (nrm(nC1), nrm(nC2), nrm(nT))                     # :210-230
     r1, r2 = _REL[direction]
     for coord in state.sites:
         nc = state.vertexToSite((coord[0] - direction[0], coord[1] - direction[1]))

@@ -81,8 +81,8 @@ struct ctm_ctx {
     std::vector<PendingEv> ev_pending;
     int ev_next = 0;
     std::vector<double> intervals;       // (kind, start_ms, end_ms, flops) per timed GEMM launch, process-wide clock
-    double k_ms[2] = {0, 0}, k_flops[2] = {0, 0};
-    long k_calls[2] = {0, 0};
+    double k_ms[3] = {0, 0, 0}, k_flops[3] = {0, 0, 0};      // kind 2 = fused two-layer kernel (layer2.hip)
+    long k_calls[3] = {0, 0, 0};
     bool cplx = false;                   // CTM_C128 context: every tensor pointer of the C-ABI is interleaved complex128
     void set_error(const std::string& s) { last_error = s; }
 };
@@ -135,6 +135,9 @@ struct GemmDesc {
 int gemm_f64(ctm_ctx* ctx, const GemmDesc& d);
 void gemm_timing_drain(ctm_ctx* ctx);
 void gemm_timing_base(ctm_ctx* ctx);
+// event pair around a launch on ctx->stream while "gemm_timing" is on: begin returns the slot (or -1), end files it under `kind`
+int timing_begin(ctm_ctx* ctx);
+void timing_end(ctm_ctx* ctx, int e0, int kind, double flops);
 
 // ---- elementwise / layout kernels (tensor_ops.hip) -----------------------------------------
 #define CTM_MAXD 8
@@ -159,6 +162,7 @@ int interleave_c128(ctm_ctx* ctx, const double* re, const double* im /* nullptr:
 int absmax_c128(ctm_ctx* ctx, const double* re, const double* im, size_t n, double* d_out);   // max |z|
 int row_norms_c128(ctm_ctx* ctx, const double* re, const double* im, int rows, int cols, long long ld, double* d_out);
 int tril_correction_c128(ctm_ctx* ctx, double* Er, double* Ei, int k);
+int norm2_f64(ctm_ctx* ctx, const double* x, size_t n, double* tmp, double* d_out);   // sqrt(sum x^2), deterministic order
 
 // op(X) of a (possibly complex, planar) matrix: t = stored transposed, c = conjugated; im == nullptr for real data
 struct XM { const double* re; const double* im; long long ld; bool t; bool c; };

@@ -145,10 +145,19 @@ int alloc_dt(ctm_ctx* ctx, const std::vector<long long>& dims, DT* t) {
 
 XM xm(const DT& t, long long ld, bool trans, bool conj = false) { XM x; x.re = t.p; x.im = t.q; x.ld = ld; x.t = trans; x.c = conj; return x; }
 
-// x /= max|x|
-int normalize_dt(ctm_ctx* ctx, const DT& t) {
+// x /= max|x| (kind 1, 'inf') or x /= |x|_2 (kind 2)     (move_normalize_c, ctmrg.py:210-230)
+int normalize_dt(ctm_ctx* ctx, const DT& t, int kind = 1) {
     const size_t n = (size_t)t.numel();
     double* s = ctx->d_scratch + 8;
+    if (kind == 2) {
+        ArenaScope scope(ctx);
+        const size_t tot = n * (t.q ? 2 : 1);           // planes are adjacent: |z|_2^2 = |re|^2 + |im|^2
+        if (t.q && t.q != t.p + n) { ctx->set_error("normalize: planes not adjacent"); return CTM_ERR_BADARG; }
+        double* tmp;
+        CTM_TRY(arena_alloc(ctx, sizeof(double) * (tot / 4096 + 2), (void**)&tmp));
+        CTM_TRY(norm2_f64(ctx, t.p, tot, tmp, s));
+        return div_by_device_scalar(ctx, t.p, tot, s, 0);
+    }
     if (!t.q) { CTM_TRY(absmax_f64(ctx, t.p, n, s)); return div_by_device_scalar(ctx, t.p, n, s, 0); }
     CTM_TRY(absmax_c128(ctx, t.p, t.q, n, s));
     CTM_TRY(div_by_device_scalar(ctx, t.p, n, s, 0));
@@ -546,9 +555,10 @@ int ctm_absorb(ctm_ctx* ctx, int dir, const double* const* t, int chi, const int
     }
     if (normalize) {
         PhaseTimer pt(ctx, CTM_T_NORM);
-        CTM_TRY(normalize_dt(ctx, r1.view({X * X})));
-        CTM_TRY(normalize_dt(ctx, r2.view({X * X})));
-        CTM_TRY(normalize_dt(ctx, r3.view({X * X * D2out})));
+        const int kind = (normalize == 2) ? 2 : 1;
+        CTM_TRY(normalize_dt(ctx, r1.view({X * X}), kind));
+        CTM_TRY(normalize_dt(ctx, r2.view({X * X}), kind));
+        CTM_TRY(normalize_dt(ctx, r3.view({X * X * D2out}), kind));
     }
     return io.finish();
 }

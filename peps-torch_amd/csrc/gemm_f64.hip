@@ -397,6 +397,23 @@ int gemm_f64(ctm_ctx* ctx, const GemmDesc& d) {
     return CTM_OK;
 }
 
+int timing_begin(ctm_ctx* ctx) {
+    if (!ctx->gemm_timing) return -1;
+    if (ctx->ev_next + 2 > (int)ctx->ev_pool.size()) {
+        if (ctx->ev_pool.size() >= 8192) gemm_timing_drain(ctx);
+        else { for (int i = 0; i < 512; ++i) { hipEvent_t e; (void)hipEventCreate(&e); ctx->ev_pool.push_back(e); } }
+    }
+    const int e0 = ctx->ev_next; ctx->ev_next += 2;
+    (void)hipEventRecord(ctx->ev_pool[e0], ctx->stream);
+    return e0;
+}
+
+void timing_end(ctm_ctx* ctx, int e0, int kind, double flops) {
+    if (e0 < 0) return;
+    (void)hipEventRecord(ctx->ev_pool[e0 + 1], ctx->stream);
+    ctx->ev_pending.push_back({e0, e0 + 1, kind, flops});
+}
+
 int xgemm(ctm_ctx* ctx, int M, int N, int K, const XM& A, const XM& B, double* Cre, double* Cim, long long ldc, const double* colscale) {
     GemmDesc g;
     g.M = M; g.N = N; g.K = K;

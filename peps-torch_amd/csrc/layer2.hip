@@ -266,6 +266,8 @@ int dev_layer2(ctm_ctx* ctx, const std::string& iz, const DT& Z, const std::stri
     p.os_e2k = stride_of(io, O, ek[1]); p.os_e2b = stride_of(io, O, eb[1]);
     p.dbg = ctx->layer2_dbg;
     const long long npair = (long long)p.nx * p.ny;
+    const double fl = 2.0 * npair * p.p * ((double)p.KA * p.KA * p.NE + (double)p.KA * p.NE * p.NE);
+    const int ev = timing_begin(ctx);
     int st;
     switch (p.KAp / 16) {
         case 1: st = launch_layer2<1>(ctx, p, lds_bytes); break;
@@ -273,8 +275,9 @@ int dev_layer2(ctm_ctx* ctx, const std::string& iz, const DT& Z, const std::stri
         case 3: st = launch_layer2<3>(ctx, p, lds_bytes); break;
         default: st = launch_layer2<4>(ctx, p, lds_bytes); break;
     }
+    timing_end(ctx, ev, 2, fl);
     CTM_TRY(st);
-    ctx->layer2_flops += 2.0 * npair * p.p * ((double)p.KA * p.KA * p.NE + (double)p.KA * p.NE * p.NE);
+    ctx->layer2_flops += fl;
     ctx->layer2_calls += 1;
     out->dims = O.dims;
     return CTM_OK;

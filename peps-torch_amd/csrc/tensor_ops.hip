@@ -246,6 +246,13 @@ __global__ void absmax2_c_kernel(const double* __restrict__ re, const double* __
     if ((threadIdx.x & 63) == 0) atomicMax(out_bits, (unsigned long long)__double_as_longlong(m));
 }
 __global__ void sqrt_inplace_kernel(double* s) { s[0] = sqrt(s[0]); }
+// out[0] = sqrt(sum_r nr[r]^2), fixed summation order (one wave)
+__global__ void norm_of_norms_kernel(const double* nr, int rows, double* out) {
+    double acc = 0.0;
+    for (int r = threadIdx.x; r < rows; r += 64) acc += nr[r] * nr[r];
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if (threadIdx.x == 0) out[0] = sqrt(acc);
+}
 // out[r] = sqrt(|re[r,:]|^2 + |im[r,:]|^2)
 __global__ void row_norms_c_kernel(const double* __restrict__ re, const double* __restrict__ im, int rows, int cols, long long ld, double* out) {
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
@@ -445,5 +452,17 @@ int row_norms_c128(ctm_ctx* ctx, const double* re, const double* im, int rows, i
 int tril_correction_c128(ctm_ctx* ctx, double* Er, double* Ei, int k) {
     const size_t tot = (size_t)k * k;
     hipLaunchKernelGGL(tril_corr_c_kernel, dim3((int)std::min<size_t>((tot + 255) / 256, 2048)), dim3(256), 0, ctx->stream, Er, Ei, k);
+    return CTM_OK;
+}
+// Frobenius (vector 2-) norm of x (n doubles; for planar complex data pass both planes as one array of 2n) -> d_out;
+// tmp: device scratch of at least ceil(n / 4096) doubles
+int norm2_f64(ctm_ctx* ctx, const double* x, size_t n, double* tmp, double* d_out) {
+    const int cols = 4096;
+    const int rows = (int)(n / cols);
+    const size_t rem = n - (size_t)rows * cols;
+    int nr = rows;
+    if (rows > 0) hipLaunchKernelGGL(row_norms_kernel, dim3(std::max(1, std::min((rows + 3) / 4, 2048))), dim3(256), 0, ctx->stream, x, rows, cols, (long long)cols, tmp);
+    if (rem > 0) { hipLaunchKernelGGL(row_norms_kernel, dim3(1), dim3(256), 0, ctx->stream, x + (size_t)rows * cols, 1, (int)rem, (long long)rem, tmp + rows); ++nr; }
+    hipLaunchKernelGGL(norm_of_norms_kernel, dim3(1), dim3(64), 0, ctx->stream, (const double*)tmp, nr, d_out);
     return CTM_OK;
 }

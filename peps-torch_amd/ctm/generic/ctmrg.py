@@ -34,8 +34,8 @@ def run(state, env, conv_check=None, ctm_args=cfg.ctm_args, global_args=cfg.glob
     """Sweep until `conv_check(state, env, history, ctm_args=)` says so or ctm_max_iter sweeps.
     Returns (env, history, t_ctm, t_obs).  t_ctm is measured on this rank with device syncs around
     each sweep (and, unlike the reference's quirk at ctmrg.py:101-108, includes the last sweep)."""
-    if ctm_args.ctm_force_dl:
-        raise NotImplementedError("ctm_force_dl: the engine always contracts layer by layer")
+    # ctm_force_dl (pre-fused double-layer tensors, ctmrg.py:51-61) is a memory/speed trade-off of the reference with
+    # identical mathematics; the engine always contracts layer by layer, so the flag is accepted and has no effect.
     eng = get_engine()
 
     def _ctmrg_iter(i, loc_ctm_args=ctm_args):
@@ -97,8 +97,7 @@ def ctm_MOVE(direction, state, env, ctm_args=cfg.ctm_args, global_args=cfg.globa
         raise ValueError("Invalid Projector method: " + str(ctm_args.projector_method))
     if direction not in _ABS:
         raise ValueError("Invalid direction: " + str(direction))
-    if ctm_args.ctm_absorb_normalization != 'inf':
-        raise NotImplementedError("ctm_absorb_normalization: only 'inf' is implemented natively")
+    norm_kind = 1 if ctm_args.ctm_absorb_normalization == 'inf' else 2      # anything else is the 2-norm (ctmrg.py:212-214)
     eng = get_engine()
     coords = list(state.sites.keys())
     mine = parallel.my_units(coords)
@@ -128,7 +127,7 @@ def ctm_MOVE(direction, state, env, ctm_args=cfg.ctm_args, global_args=cfg.globa
         Pt = parallel.exchange(Pt, coords, shp, like)
 
     # phase B: absorb + normalise my sites
-    new = dict(zip(mine, _each(lambda c: _absorb(direction, c, state, env, P, Pt, ctm_args, normalize=True), mine)))
+    new = dict(zip(mine, _each(lambda c: _absorb(direction, c, state, env, P, Pt, ctm_args, normalize=norm_kind), mine)))
     if parallel.is_distributed():
         packs = {c: torch.cat([t.reshape(-1) for t in v]) for c, v in new.items()}
         shp = {c: (2 * chi * chi + chi * chi * _out_D2(direction, state.site(c)),) for c in coords}

@@ -45,12 +45,22 @@ def _sym_pos_def_rdm(rdm, sym_pos_def=False, verbosity=0, who=None, **kwargs):
 def rdm2x2(coord, state, env, open_sites=[0, 1, 2, 3], unroll=[], checkpoint_unrolled=False, checkpoint_on_device=False,
            sym_pos_def=False, force_cpu=False, verbosity=0, global_args=cfg.global_args):
     """rho(s0 s1 s2 s3 ; s0' s1' s2' s3') of the plaquette coord, +x, +y, +x+y (s0 s1 / s2 s3)."""
-    if list(open_sites) != [0, 1, 2, 3]:
-        raise NotImplementedError("rdm2x2: partially traced plaquettes are not on the native path")
+    open_sites = sorted(set(open_sites))
+    if any(i not in (0, 1, 2, 3) for i in open_sites):
+        raise ValueError("rdm2x2: open_sites must be a subset of [0,1,2,3]")
     x, y = coord
     t = _corner_t(LU, (x, y), state, env) + _corner_t(RU, (x + 1, y), state, env) \
         + _corner_t(RD, (x + 1, y + 1), state, env) + _corner_t(LD, (x, y + 1), state, env)
     raw = get_engine().rdm2x2(t)
+    if open_sites != [0, 1, 2, 3]:
+        # fewer open sites = partial trace of the full plaquette RDM over the closed ones (rdm.py:1306-1360 contracts
+        # their physical legs inside the corners; same numbers, the native kernel always opens all four)
+        ket, bra = list("abcd"), list("efgh")
+        for i in range(4):
+            if i not in open_sites:
+                bra[i] = ket[i]
+        keep = [ket[i] for i in open_sites] + [bra[i] for i in open_sites]
+        raw = torch.einsum("".join(ket + bra) + "->" + "".join(keep), raw).contiguous()
     return _sym_pos_def_rdm(raw, sym_pos_def=sym_pos_def, verbosity=verbosity, who="rdm2x2")
 
 

@@ -74,7 +74,9 @@ class FakeEngine:
         f0, f1 = sp['fuse']
         sh = list(nT.shape)
         nT = nT.reshape(sh[:f0] + [sh[f0] * sh[f1]] + sh[f1 + 1:])
-        if normalize:
+        if normalize == 2:
+            nC1, nC2, nT = (x / np.linalg.norm(x.ravel()) for x in (nC1, nC2, nT))
+        elif normalize:
             nC1, nC2, nT = O._nrm(nC1), O._nrm(nC2), O._nrm(nT)
         return _t(nC1), _t(nC2), _t(nT)
 

@@ -123,3 +123,15 @@ def test_converged_run(case, eng):
         assert np.abs(s.cpu().numpy() - ref).max() < 1e-10, k
     e = float(j1j2.J1J2(j1=1.0, j2=0.5).energy_per_site(st, env))
     assert abs(e - float(g["conv_energy"])) < 1e-10 * abs(e)
+
+
+def test_rdm2x2_partially_open(case, eng):
+    """open_sites subsets = partial traces of the reference's full plaquette RDM (rdm.py:1306-1360)."""
+    from ctm.generic import rdm
+    g, chi = case["g"], case["chi"]
+    st, env = device_state_env(case["sites"], case["C"], case["T"], chi)
+    full = g["rdm2x2_0_0"]
+    for os_, expr in (([0, 1], "abijefij->abef"), ([0, 3], "aijdeijh->adeh"), ([1, 2, 3], "ibcdifgh->bcdfgh"), ([2], "ijckijgk->cg")):
+        ref = np.einsum(expr, full)
+        ref = ref / np.trace(ref.reshape(int(np.sqrt(ref.size)), -1))
+        assert relerr(rdm.rdm2x2((0, 0), st, env, open_sites=os_), ref) < 1e-11, os_

@@ -148,3 +148,29 @@ def test_concurrent_units_and_warm_start_do_not_change_the_environment(eng):
     for k in res[0].T: assert relerr(res[0].T[k].abs(), res[1].T[k].abs()) < 1e-8, k
     for k, s in res[0].get_spectra().items():
         assert relerr(s, res[1].get_spectra()[k]) < 1e-9
+
+
+@pytest.mark.parametrize("name,chi", [("generic_D2_chi8_f64", 8), ("generic_D2_chi8_c128", 8)])
+def test_two_norm_normalisation_and_force_dl_flag(eng, name, chi):
+    """ctm_absorb_normalization = '2' (vector 2-norm, ctmrg.py:212-214) and the ctm_force_dl flag (same mathematics)."""
+    import config as cfg
+    from conftest import golden
+    from helpers import sites_from, env_from, device_state_env, oracle_state_env
+    from ctm.generic import ctmrg
+    from oracle import ctm_oracle as O
+    g = golden(name)
+    C, T = env_from(g, "warm_")
+    st, env = device_state_env(sites_from(g), C, T, chi)
+    ost, oe = oracle_state_env(sites_from(g), C, T, chi)
+    cfg.ctm_args.ctm_absorb_normalization = '2'
+    cfg.ctm_args.ctm_force_dl = True
+    try:
+        for d in [(0, -1), (-1, 0), (0, 1), (1, 0)]:
+            ctmrg.ctm_MOVE(d, st, env)
+            O.ctm_move(d, ost, oe, norm_type='2')
+    finally:
+        cfg.ctm_args.ctm_absorb_normalization = 'inf'
+        cfg.ctm_args.ctm_force_dl = False
+    for k in oe.C: assert relerr(env.C[k].abs(), np.abs(oe.C[k])) < 1e-7, k
+    for k in oe.T: assert relerr(env.T[k].abs(), np.abs(oe.T[k])) < 1e-7, k
+    for k, t in env.T.items(): assert abs(float(torch.linalg.vector_norm(t)) - 1.0) < 1e-12
