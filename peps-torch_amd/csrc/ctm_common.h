@@ -72,6 +72,7 @@ struct ctm_ctx {
     long layer2_calls = 0;
     bool use_layer2 = true;
     bool gemm_fast = true;
+    bool eig64_pingpong = true;         // one-barrier-per-round LDS eigensolver for 64 x 64 pair Grams
     int layer2_dbg = 0;
     // optional per-launch HIP-event timing of the GEMM kernels on ctx->stream (bench roofline):
     // kind 0 = 128x128 tile kernel, kind 1 = 64x64 tile kernel

@@ -232,6 +232,143 @@ __global__ __launch_bounds__(1024) void small_eig_kernel(SmallEigParams p) {
     }
 }
 
+// m = 64 variant with ONE barrier per round: the matrix ping-pongs between two LDS images, every thread derives the two
+// rotations it needs (row pair k1, column pair k2) itself from the source image -- bitwise identical on all threads that share
+// a pair -- transforms its own 2x2 block into the other image and its two eigenvector rows in place.  1024 threads.
+__device__ __forceinline__ void jacobi_cs(double a, double b, double g, double tol, double tau2, double& c, double& s, bool& rot) {
+    c = 1.0; s = 0.0; rot = false;
+    if (g != 0.0 && fabs(g) > tol * fmax(sqrt(fabs(a * b)), tau2)) {
+        const double d = b - a, g2 = 2.0 * g;
+        const double hh = d * d + g2 * g2;
+        double rh = __builtin_amdgcn_rsq(hh);
+        rh = rh * (1.5 - 0.5 * hh * rh * rh);
+        const double h = hh * rh;
+        const double den = d + (d >= 0.0 ? h : -h);
+        double rd = __builtin_amdgcn_rcp(den);
+        rd = rd * (2.0 - den * rd);
+        const double t = g2 * rd;
+        const double x = 1.0 + t * t;
+        double y = __builtin_amdgcn_rsq(x);
+        y = y * (1.5 - 0.5 * x * y * y);
+        y = y * (1.5 - 0.5 * x * y * y);
+        c = y; s = t * c; rot = true;
+    }
+}
+
+__global__ __launch_bounds__(1024) void small_eig64_kernel(SmallEigParams p) {
+    constexpr int M = 64, H = 32, NTH = 1024;
+    __shared__ double Wb[2][M][M + 1];
+    __shared__ double Jm[M][M + 1];
+    __shared__ double red[16];
+    __shared__ int rot_flag;
+    __shared__ unsigned char pair_tab[M - 1][H][2];
+    __shared__ int rank_of[M];
+    const int tid = threadIdx.x;
+    const double* G = p.G + (size_t)blockIdx.x * M * M;
+    double* Jout = p.J + (size_t)blockIdx.x * M * M;
+    {
+        double acc[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int s = 0; s < p.nsplit; ++s) {
+            const double* Gs = G + (size_t)s * p.split_stride;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[u] += Gs[tid + u * NTH];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int q = tid + u * NTH, r = q >> 6, c = q & 63; Wb[0][r][c] = acc[u]; Jm[r][c] = (r == c) ? 1.0 : 0.0; }
+    }
+    __syncthreads();
+    {
+        double srel = 0.0, sabs = 0.0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int q = tid + u * NTH, r = q >> 6, c = q & 63;
+            if (r < c) {
+                const double g = fabs(Wb[0][r][c]), a = Wb[0][r][r], b = Wb[0][c][c];
+                if (g > 0.0) {
+                    const double sc = sqrt(fabs(a * b));
+                    srel = fmax(srel, g / fmax(sc, p.tau2));
+                    if (sc > 0.0) sabs = fmax(sabs, g / sc);
+                }
+            }
+        }
+        for (int off = 32; off > 0; off >>= 1) { srel = fmax(srel, __shfl_down(srel, off, 64)); sabs = fmax(sabs, __shfl_down(sabs, off, 64)); }
+        if ((tid & 63) == 0) red[tid >> 6] = srel;
+        __syncthreads();
+        if (tid == 0) {
+            double v = 0.0;
+            for (int w = 0; w < 16; ++w) v = fmax(v, red[w]);
+            atomicMax(p.stat_rel, (unsigned long long)__double_as_longlong(v));
+            red[0] = v;
+        }
+        __syncthreads();
+        srel = red[0];
+        __syncthreads();
+        if ((tid & 63) == 0) red[tid >> 6] = sabs;
+        __syncthreads();
+        if (tid == 0) {
+            double v = 0.0;
+            for (int w = 0; w < 16; ++w) v = fmax(v, red[w]);
+            atomicMax(p.stat_abs, (unsigned long long)__double_as_longlong(v));
+        }
+        if (srel <= p.tol) { if (tid == 0) p.flags[blockIdx.x] = 0; return; }
+        if (tid == 0) p.flags[blockIdx.x] = 1;
+    }
+    for (int q = tid; q < (M - 1) * H; q += NTH) {
+        const int r = q / H, k = q - r * H;
+        int pi, qi;
+        if (k == 0) { pi = M - 1; qi = r % (M - 1); }
+        else { pi = (r + k) % (M - 1); qi = (r - k + (M - 1)) % (M - 1); }
+        if (pi > qi) { const int t = pi; pi = qi; qi = t; }
+        pair_tab[r][k][0] = (unsigned char)pi; pair_tab[r][k][1] = (unsigned char)qi;
+    }
+    if (tid == 0) rot_flag = 0;
+    __syncthreads();
+    const int k2 = tid & 31, k1 = tid >> 5;
+    int par = 0;
+    for (int sweep = 0; sweep < p.max_sweeps; ++sweep) {
+        for (int r = 0; r < M - 1; ++r) {
+            const double (*S)[M + 1] = Wb[par];
+            double (*D)[M + 1] = Wb[par ^ 1];
+            const int p1 = pair_tab[r][k1][0], q1 = pair_tab[r][k1][1], p2 = pair_tab[r][k2][0], q2 = pair_tab[r][k2][1];
+            const double a2 = S[p2][p2], d2 = S[q2][q2], g2 = S[p2][q2];
+            const double b00 = S[p1][p2], b01 = S[p1][q2], b10 = S[q1][p2], b11 = S[q1][q2];
+            const double jp0 = Jm[k1][p2], jq0 = Jm[k1][q2], jp1 = Jm[k1 + 32][p2], jq1 = Jm[k1 + 32][q2];
+            double c2, s2; bool r2;
+            jacobi_cs(a2, d2, g2, p.tol, p.tau2, c2, s2, r2);
+            // the rotation of row pair k1 is the one the lane with k2 == k1 of this half-wave just computed
+            const int src = (tid & 32) | k1;
+            const double c1 = __shfl(c2, src, 64), s1 = __shfl(s2, src, 64);
+            const bool r1 = r2 && (k1 == k2);
+            const double t00 = c2 * b00 - s2 * b01, t01 = s2 * b00 + c2 * b01;
+            const double t10 = c2 * b10 - s2 * b11, t11 = s2 * b10 + c2 * b11;
+            D[p1][p2] = c1 * t00 - s1 * t10; D[p1][q2] = c1 * t01 - s1 * t11;
+            D[q1][p2] = s1 * t00 + c1 * t10; D[q1][q2] = s1 * t01 + c1 * t11;
+            if (r2) {
+                Jm[k1][p2] = c2 * jp0 - s2 * jq0; Jm[k1][q2] = s2 * jp0 + c2 * jq0;
+                Jm[k1 + 32][p2] = c2 * jp1 - s2 * jq1; Jm[k1 + 32][q2] = s2 * jp1 + c2 * jq1;
+            }
+            if (r1) rot_flag = 1;
+            par ^= 1;
+            __syncthreads();
+        }
+        const int any = rot_flag;
+        __syncthreads();
+        if (!any) break;
+        if (tid == 0) rot_flag = 0;
+        __syncthreads();
+    }
+    const double (*W)[M + 1] = Wb[par];
+    if (tid < M) {
+        const double d = W[tid][tid];
+        int rk = 0;
+        for (int j = 0; j < M; ++j) { const double dj = W[j][j]; rk += (dj > d) || (dj == d && j < tid); }
+        rank_of[tid] = rk;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const int q = tid + u * NTH, r = q >> 6, c = q & 63; Jout[r * M + rank_of[c]] = Jm[r][c]; }
+}
+
 // ---------------------------------------------------------------------------------------------
 // complex128 variant.  A panel of bc = 16 complex rows is stored as 16 real rows (real parts) followed by 16 real
 // rows (imaginary parts), so a pair of panels is 64 REAL rows and the Gram / apply GEMMs of jacobi_rows() run
@@ -505,6 +642,7 @@ int jacobi_rows(ctm_ctx* ctx, double* X, int R, long long ld, int Cg, int Ctot, 
             sp.G = G; sp.nsplit = T->nsplit; sp.split_stride = (long long)pairs * m * m; sp.J = J; sp.m = m; sp.tol = ctx->jacobi_tol * 0.1; sp.max_sweeps = (pairs == 1) ? 12 : ctx->jacobi_inner_sweeps;
             sp.tau2 = tau2; sp.stat_rel = stat; sp.stat_abs = stat + 1; sp.flags = flags;
             if (cplx) hipLaunchKernelGGL(small_eig_c_kernel, dim3(pairs), dim3(256), 0, ctx->stream, sp);
+            else if (m == 64 && ctx->eig64_pingpong) hipLaunchKernelGGL(small_eig64_kernel, dim3(pairs), dim3(1024), 0, ctx->stream, sp);
             else hipLaunchKernelGGL(small_eig_kernel, dim3(pairs), dim3(m > 32 ? 1024 : 256), 0, ctx->stream, sp);
             GemmDesc a;
             a.M = m; a.N = Ctot; a.K = m;
