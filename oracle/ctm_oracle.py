@@ -274,6 +274,22 @@ def get_projectors_4x4(direction, coord, state, env, **kw):
     return projectors_from_matrices(R, Rt, env.chi, **kw)
 
 
+def halves_4x2(direction, coord, state, env):
+    """ctm_get_projectors_4x2 (ctm_projectors.py:66-136): R, Rt are the single enlarged corners next to the cut --
+    the first corner of each half of the 4x4 network with the same transposes (:113-131)."""
+    out = []
+    for key in ('R', 'Rt'):
+        cA, shA, _cB, _shB, opA, _opB = _HALVES[direction][key]
+        m = c2x2(cA, (coord[0] + shA[0], coord[1] + shA[1]), state, env)
+        out.append(m if opA == 'N' else m.T)
+    return out[0], out[1]
+
+
+def get_projectors_4x2(direction, coord, state, env, **kw):
+    R, Rt = halves_4x2(direction, coord, state, env)
+    return projectors_from_matrices(R, Rt, env.chi, **kw)
+
+
 # ----------------------------------------------------------------------------------
 # absorb + truncate (ctm/generic/ctmrg.py:324-804), 'sl' mode
 # ----------------------------------------------------------------------------------
@@ -327,14 +343,14 @@ def absorb_truncate(direction, coord, state, env, P, Pt):
 _REL = {UP: ((1, -1), (-1, -1)), LEFT: ((-1, -1), (-1, 1)), DOWN: ((-1, 1), (1, 1)), RIGHT: ((1, 1), (1, -1))}
 
 
-def ctm_move(direction, state, env, norm_type='inf', **kw):
+def ctm_move(direction, state, env, norm_type='inf', projector_method='4X4', **kw):
     """ctm_MOVE (ctmrg.py:179-319): projectors for all sites from the OLD env, absorb for all
     sites, normalise each new tensor by its own max-abs ('inf') or vector 2-norm (any other
     ctm_absorb_normalization, ctmrg.py:210-230), scatter to coord - direction."""
     nrm = _nrm if norm_type == 'inf' else (lambda a: a / np.linalg.norm(a.ravel()))
     P, Pt = {}, {}
     for coord in state.sites:
-        P[coord], Pt[coord] = get_projectors_4x4(direction, coord, state, env, **kw)
+        P[coord], Pt[coord] = (get_projectors_4x4 if projector_method == '4X4' else get_projectors_4x2)(direction, coord, state, env, **kw)
     new = {}
     for coord in state.sites:
         nC1, nC2, nT = absorb_truncate(direction, coord, state, env, P, Pt)

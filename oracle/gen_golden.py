@@ -371,8 +371,38 @@ def file_state_case(name, fname, tiling, chi, j1, j2, E_pub, tol_pub):
     np.savez_compressed(os.path.join(GOLD, name + ".npz"), **out)
 
 
+def variants_check():
+    """Pins the oracle's non-default variants against the real reference (no vectors stored: assertions only):
+    projector_method='4X2' (ctm_projectors.py:66-136) and ctm_absorb_normalization='2' (ctmrg.py:210-230), two sweeps
+    from the CTMRG init on the committed D=2 chi=8 states, float64 and complex128."""
+    import config as cfg
+    from ipeps.ipeps import IPEPS
+    from ctm.generic.env import ENV, init_env
+    from ctm.generic import ctmrg
+    for name, cx in (("generic_D2_chi8_f64", False), ("generic_D2_chi8_c128", True)):
+        g = np.load(os.path.join(GOLD, name + ".npz"))
+        sites = {tuple(int(v) for v in k.split('_')[1:]): g[k] for k in g.files if k.startswith('site_')}
+        set_dtype(cx)
+        for method, norm in (("4X2", "inf"), ("4X4", "2")):
+            st = IPEPS({k: torch.from_numpy(v.copy()) for k, v in sites.items()})
+            cfg.ctm_args.projector_method, cfg.ctm_args.ctm_absorb_normalization = method, norm
+            env = ENV(8, st); init_env(st, env)
+            ost = O.State(sites); oe = O.init_env_ctmrg(ost, 8)
+            for _ in range(2):
+                for d in [(0, -1), (-1, 0), (0, 1), (1, 0)]:
+                    for _r in range(2):
+                        ctmrg.ctm_MOVE(d, st, env)
+                        O.ctm_move(d, ost, oe, norm_type=norm, projector_method=method)
+            for k in oe.C: close(np.abs(t2n(env.C[k])), np.abs(oe.C[k]), 1e-8, f"{name} {method} norm={norm} C{k}")
+            for k in oe.T: close(np.abs(t2n(env.T[k])), np.abs(oe.T[k]), 1e-8, f"{name} {method} norm={norm} T{k}")
+            print("variant ok:", name, method, norm)
+    cfg.ctm_args.projector_method, cfg.ctm_args.ctm_absorb_normalization = "4X4", "inf"
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["decomp", "generic", "c4v", "rvb", "files"]
+    which = sys.argv[1:] or ["decomp", "generic", "c4v", "rvb", "files", "variants"]
+    if "variants" in which:
+        variants_check()
     if "decomp" in which:
         svd_cases()
     if "generic" in which:

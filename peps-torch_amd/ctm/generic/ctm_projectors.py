@@ -1,7 +1,7 @@
 """Projectors of a directional move (reference ctm/generic/ctm_projectors.py:14-64,142-293)."""
 import config as cfg
 from backend import get_engine
-from ctm.generic.ctm_components import _halves, _halves_t
+from ctm.generic.ctm_components import _halves, _halves_t, _HALVES, _corner
 
 
 def _trunc_cfg(eng, ctm_args):
@@ -34,6 +34,24 @@ def ctm_get_projectors_4x4(direction, coord, state, env, ctm_args=cfg.ctm_args, 
             basis = b
         return eng.projectors_4x4(direction, t16, env.chi, _trunc_cfg(eng, ctm_args), basis=basis)
     R, Rt = _halves(direction, coord, state, env)
+    return ctm_get_projectors_from_matrices(R, Rt, env.chi, ctm_args, global_args, diagnostics=diagnostics)
+
+
+# plain transposes applied to the corner next to the cut in each half (ctm_projectors.py:113-131): (R, Rt) per direction
+_T4X2 = {(0, -1): (False, True), (-1, 0): (False, False), (0, 1): (True, True), (1, 0): (False, True)}
+
+
+def ctm_get_projectors_4x2(direction, coord, state, env, ctm_args=cfg.ctm_args, global_args=cfg.global_args, diagnostics=None):
+    """Projectors from the two enlarged corners of the 4x2 (2x4) network (reference ctm_projectors.py:66-136)."""
+    if direction not in _T4X2:
+        raise ValueError("Invalid direction: " + str(direction))
+    (cR, shR), _, (cRt, shRt), _ = _HALVES[direction]
+    R = _corner(cR, (coord[0] + shR[0], coord[1] + shR[1]), state, env, mode='sl')
+    Rt = _corner(cRt, (coord[0] + shRt[0], coord[1] + shRt[1]), state, env, mode='sl')
+    tR, tRt = _T4X2[direction]
+    eng = get_engine()
+    if tR: R = eng.permute(R, (1, 0))
+    if tRt: Rt = eng.permute(Rt, (1, 0))
     return ctm_get_projectors_from_matrices(R, Rt, env.chi, ctm_args, global_args, diagnostics=diagnostics)
 
 

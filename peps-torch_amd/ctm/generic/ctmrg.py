@@ -14,7 +14,7 @@ import torch
 import config as cfg
 from backend import get_engine
 import parallel
-from ctm.generic.ctm_projectors import ctm_get_projectors_4x4, _trunc_cfg
+from ctm.generic.ctm_projectors import ctm_get_projectors_4x4, ctm_get_projectors_4x2, _trunc_cfg
 from ctm.generic.ctm_components import _halves_t
 
 log = logging.getLogger(__name__)
@@ -93,7 +93,11 @@ def absorb_truncate_CTM_MOVE_RIGHT_c(*t): return get_engine().absorb((1, 0), t[:
 
 
 def ctm_MOVE(direction, state, env, ctm_args=cfg.ctm_args, global_args=cfg.global_args, verbosity=0, diagnostics=None):
-    if ctm_args.projector_method != '4X4':
+    if ctm_args.projector_method == '4X4':
+        get_projectors = ctm_get_projectors_4x4
+    elif ctm_args.projector_method == '4X2':
+        get_projectors = ctm_get_projectors_4x2
+    else:
         raise ValueError("Invalid Projector method: " + str(ctm_args.projector_method))
     if direction not in _ABS:
         raise ValueError("Invalid direction: " + str(direction))
@@ -115,7 +119,7 @@ def ctm_MOVE(direction, state, env, ctm_args=cfg.ctm_args, global_args=cfg.globa
 
     # phase A: projectors of my sites from the old env
     P, Pt = {}, {}
-    for coord, (p_, pt_) in zip(mine, _each(lambda c: ctm_get_projectors_4x4(direction, c, state, env, ctm_args, global_args,
+    for coord, (p_, pt_) in zip(mine, _each(lambda c: get_projectors(direction, c, state, env, ctm_args, global_args,
                                                                              diagnostics=diagnostics), mine)):
         P[coord], Pt[coord] = p_, pt_
     if parallel.is_distributed():

@@ -174,3 +174,38 @@ def test_two_norm_normalisation_and_force_dl_flag(eng, name, chi):
     for k in oe.C: assert relerr(env.C[k].abs(), np.abs(oe.C[k])) < 1e-7, k
     for k in oe.T: assert relerr(env.T[k].abs(), np.abs(oe.T[k])) < 1e-7, k
     for k, t in env.T.items(): assert abs(float(torch.linalg.vector_norm(t)) - 1.0) < 1e-12
+
+
+@pytest.mark.parametrize("name,chi", [("generic_D2_chi8_f64", 8), ("generic_D2_chi8_c128", 8)])
+def test_projector_method_4x2(eng, name, chi):
+    """projector_method = '4X2' (ctm_projectors.py:66-136): two sweeps vs the oracle (itself checked against the reference
+    on these states when this test was written)."""
+    import config as cfg
+    from conftest import golden
+    from helpers import sites_from
+    from ipeps.ipeps import IPEPS
+    from ctm.generic.env import ENV, init_env
+    from ctm.generic import ctmrg
+    from oracle import ctm_oracle as O
+    g = golden(name)
+    sites = sites_from(g)
+    st = IPEPS({k: dev(v) for k, v in sites.items()})
+    env = ENV(chi, st); init_env(st, env)
+    ost = O.State(sites); oe = O.init_env_ctmrg(ost, chi)
+    cfg.ctm_args.projector_method = '4X2'
+    try:
+        for _ in range(2):
+            for d in cfg.ctm_args.ctm_move_sequence:
+                for _r in range(2):
+                    ctmrg.ctm_MOVE(d, st, env)
+                    O.ctm_move(d, ost, oe, projector_method='4X2')
+    finally:
+        cfg.ctm_args.projector_method = '4X4'
+    for k in oe.C: assert relerr(env.C[k].abs(), np.abs(oe.C[k])) < 1e-7, k
+    for k in oe.T: assert relerr(env.T[k].abs(), np.abs(oe.T[k])) < 1e-7, k
+    with pytest.raises(ValueError):
+        cfg.ctm_args.projector_method = '4X3'
+        try:
+            ctmrg.ctm_MOVE((0, -1), st, env)
+        finally:
+            cfg.ctm_args.projector_method = '4X4'
