@@ -103,6 +103,34 @@ def cpu_baseline(kind, D, chi, sites, budget_s=25.0):
                       f"projectors, absorb) = {dt:.2f} s, extrapolated x32; {os.cpu_count()} host cpus"}
 
 
+def energy_parity(dev, dtype="f64", D=3, chi=36, nsweeps=3):
+    """rdm2x2 energy (J1-J2, j2 = 0.5) after `nsweeps` sweeps from the CTMRG init: native engine vs the numpy oracle on the SAME
+    synthetic state, at a size the oracle finishes in seconds (the second half of BASELINE.json's metric)."""
+    import config as cfg
+    from oracle import ctm_oracle as O, j1j2_oracle as OJ
+    from ipeps.ipeps import IPEPS
+    from ctm.generic.env import ENV, init_env
+    from ctm.generic import ctmrg
+    from models import j1j2
+    sites = synth_sites("generic", D, seed=3, dtype=dtype)
+    st = IPEPS({k: torch.from_numpy(v).to(dev) for k, v in sites.items()})
+    env = ENV(chi, st); init_env(st, env)
+    for _ in range(nsweeps):
+        for d in cfg.ctm_args.ctm_move_sequence:
+            for _r in range(2):
+                ctmrg.ctm_MOVE(d, st, env)
+    e = float(j1j2.J1J2(j1=1.0, j2=0.5).energy_per_site(st, env))
+    spec = {k: v.cpu().numpy() for k, v in env.get_spectra().items()}
+    ost = O.State(sites); oe = O.init_env_ctmrg(ost, chi)
+    for _ in range(nsweeps):
+        O.ctm_sweep(ost, oe)
+    eo = OJ.energy_per_site([O.rdm2x2(c, ost, oe) for c in ost.sites], 1.0, 0.5)
+    ospec = O.corner_spectra(oe)
+    return {"workload": f"generic 2x2 D={D} chi={chi} {dtype}, {nsweeps} sweeps from the CTMRG init, J1-J2 j2=0.5", "energy_native": e,
+            "energy_oracle": float(eo), "rel_err": abs(e - eo) / max(abs(eo), 1e-300),
+            "max_abs_err_corner_spectra": float(max(np.abs(spec[k] - ospec[k]).max() for k in ospec)), "tolerance": 1e-10}
+
+
 def cpu_baseline_large(O, ost, env, D, chi, threads):
     """n = chi D^2 > 6000: one full unit on the CPU takes many minutes (LAPACK gesdd of an n x n matrix), so the unit is
     assembled from bounded pieces: the four enlarged corners and the absorb are timed at full size with the oracle, ONE
@@ -289,6 +317,10 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(kind, D, chi, sites)
             except Exception as e:                      # the baseline is reporting only
                 out["cpu_baseline"] = {"error": repr(e)}
+            try:
+                out["energy_parity"] = energy_parity(dev, dtype)
+            except Exception as e:
+                out["energy_parity"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
