@@ -72,6 +72,7 @@ struct ctm_ctx {
     long layer2_calls = 0;
     bool use_layer2 = true;
     bool gemm_fast = true;
+    int splitk_max_tiles = 256, splitk_target_wgs = 1024;   // split-K of skinny GEMMs: when few output tiles, how many workgroups to aim for
     bool eig64_pingpong = true;         // one-barrier-per-round LDS eigensolver for 64 x 64 pair Grams
     int layer2_dbg = 0;
     // optional per-launch HIP-event timing of the GEMM kernels on ctx->stream (bench roofline):

@@ -343,8 +343,12 @@ int gemm_f64(ctm_ctx* ctx, const GemmDesc& d) {
     // summed in a fixed order by a second tiny kernel (deterministic, no atomics)
     double* part = nullptr;
     const int ntile = p.tilesM * p.tilesN;
-    if (d.batch == 1 && !d.offs && d.splitB_dim == 0 && d.splitA >= d.M && d.splitC >= d.M && ntile < 128 && d.K >= 1024) {
-        int ks = std::min(16, std::min(512 / std::max(ntile, 1), d.K / 256));
+    // very skinny outputs (one 64-row or 64-column strip, e.g. a 64-vector block times an n x n corner) stream the big operand
+    // once and are HBM-latency bound with one workgroup per CU: aim for ~4 workgroups per CU there, ~2 otherwise
+    const bool strip = (d.M <= 64 || d.N <= 64);
+    const int max_tiles = strip ? ctx->splitk_max_tiles : 127, target = strip ? ctx->splitk_target_wgs : 512;
+    if (d.batch == 1 && !d.offs && d.splitB_dim == 0 && d.splitA >= d.M && d.splitC >= d.M && ntile <= max_tiles && d.K >= 1024) {
+        int ks = std::min(16, std::min(target / std::max(ntile, 1), d.K / 256));
         if (ks > 1) {
             p.klen = (((d.K + ks - 1) / ks) + 15) / 16 * 16;
             ks = (d.K + p.klen - 1) / p.klen;
