@@ -49,7 +49,7 @@ struct ctm_ctx {
     int jacobi_block = 32;
     int jacobi_max_sweeps = 30;
     double jacobi_tol = 1e-14;
-    int jacobi_inner_sweeps = 3;
+    int jacobi_inner_sweeps = 2;
     int jacobi_verbose = 0;
     // leading-k block power iteration (svd_iter): enabled for n >= si_min_n, residual tolerance relative to s_0
     bool si_enable = true;
