@@ -47,6 +47,7 @@ int ctm_destroy(ctm_ctx* ctx);
 const char* ctm_last_error(ctm_ctx* ctx);
 const char* ctm_version(void);
 int ctm_sync(ctm_ctx* ctx);
+int ctm_trim(ctm_ctx* ctx);   /* release the context's workspace arena (regrown on demand); call between engine calls */
 int ctm_set_option(ctm_ctx* ctx, const char* key, double value);   /* "jacobi_tol","jacobi_max_sweeps","jacobi_block","jacobi_inner_sweeps","jacobi_verbose",
                                                                       "si_enable","si_min_n","si_max_iter","si_tol","si_rr_sweeps","use_layer2","gemm_fast","gemm_timing","profile" */
 int ctm_get_stat(ctm_ctx* ctx, const char* key, double* value);    /* "last_sweeps","last_offnorm","total_sweeps","jacobi_calls","si_hits","si_fallbacks","si_total_iters",

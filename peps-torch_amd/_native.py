@@ -33,6 +33,7 @@ _SIGS = {
     "ctm_create": [C.POINTER(C.c_void_p), C.c_void_p, C.c_int],
     "ctm_destroy": [C.c_void_p],
     "ctm_sync": [C.c_void_p],
+    "ctm_trim": [C.c_void_p],
     "ctm_set_option": [C.c_void_p, C.c_char_p, C.c_double],
     "ctm_get_stat": [C.c_void_p, C.c_char_p, C.POINTER(C.c_double)],
     "ctm_timers": [C.c_void_p, C.POINTER(C.c_double), C.c_int],
@@ -202,6 +203,14 @@ class Engine:
             for n, v in zip(names, list(buf)):
                 tot[n] += v
         return tot
+
+    def trim(self, workers_only=False):
+        """Give the workspace arenas back to the device (they regrow on demand): all worker contexts, and this engine's."""
+        for w in self.workers:
+            w.trim()
+        if not workers_only:
+            for h in self._handles.values():
+                self.lib.ctm_trim(h)
 
     def gemm_intervals(self):
         """(kind, start_ms, end_ms, flops) of every GEMM launch timed since "gemm_timing" was switched on, over all

@@ -243,6 +243,13 @@ int corner_impl(ctm_ctx* ctx, int corner, int open, const DT& C, const DT& T1, c
     DT tT1 = T1.view(t_view(sp.t1_axis, chi, ad[sp.t1_leg]));
     DT tT2 = T2.view(t_view(sp.t2_axis, chi, ad[sp.t2_leg]));
     DT tA = a.view({ad[0], ad[1], ad[2], ad[3], ad[4]});
+    if (open == 2) {      // open corner with the physical legs LEADING: [s][t][n0][n1] (contiguous n0 x n1 slices per (s,t))
+        std::string e(sp.open);
+        const size_t ar = e.find("->");
+        const std::string o = e.substr(ar + 2);
+        e = e.substr(0, ar + 2) + o.substr(o.size() - 2) + o.substr(0, o.size() - 2);
+        return dev_network(ctx, e, {tC, tT1, tT2, tA, tA.conj()}, res);
+    }
     return dev_network(ctx, open ? sp.open : sp.closed, {tC, tT1, tT2, tA, tA.conj()}, res);
 }
 
@@ -612,29 +619,71 @@ int ctm_move_c4v_ws(ctm_ctx* ctx, const double* a, const double* C, const double
 
 // ---- RDMs ------------------------------------------------------------------------------------------
 int ctm_rdm2x2(ctm_ctx* ctx, const double* const* t, int chi, const int* ad4, double* out) {
+    // rdm.py:1390-1588.  The reference holds the four open corners (n^2 p^2 each) and the two open halves (n^2 p^4 each) at
+    // once; here the physical legs are unrolled: the lower half is kept as p^4 slices L[(s2 t2 s3 t3)] (n x n), the upper
+    // half is produced one slice U[(s0 t0 s1 t1)] at a time and reduced against all of L immediately, so the peak is
+    // n^2 (p^4 + 2 p^2 + 1) elements instead of n^2 (2 p^4 + 4 p^2) -- same flops, every product a plain n x n x n GEMM.
     PhaseTimer pt(ctx, CTM_T_RDM);
     ArenaScope scope(ctx);
     IO io(ctx);
     static const int cid[4] = {CTM_LU, CTM_RU, CTM_RD, CTM_LD};
-    DT c[4];
-    size_t pall = 1;
-    for (int i = 0; i < 4; ++i) {
-        long long n0, n1; corner_dims(cid[i], chi, ad4 + 5 * i, &n0, &n1);
-        const long long p = ad4[5 * i];
-        pall *= (size_t)(p * p);
-        CTM_TRY(alloc_dt(ctx, {n0, n1, p, p}, &c[i]));
+    long long n0[4], n1[4], pp[4];
+    for (int i = 0; i < 4; ++i) { corner_dims(cid[i], chi, ad4 + 5 * i, &n0[i], &n1[i]); pp[i] = ad4[5 * i]; }
+    const long long A = n0[0], ku = n1[0], B = n1[1], kl = n1[3];
+    if (n0[1] != ku || n0[3] != A || n0[2] != B || n1[2] != kl) { ctx->set_error("rdm2x2: corner dimensions do not chain"); return CTM_ERR_SHAPE; }
+    const long long AB = A * B;
+    const long long Pu = pp[0] * pp[0] * pp[1] * pp[1], Pl = pp[3] * pp[3] * pp[2] * pp[2];
+    if (AB >= (1LL << 31)) { ctx->set_error("rdm2x2: n^2 exceeds the GEMM K range"); return CTM_ERR_UNSUPPORTED; }
+    DT r, R, Lall;
+    CTM_TRY(io.out(out, (size_t)(Pu * Pl), &r));
+    CTM_TRY(alloc_dt(ctx, {Pu, Pl}, &R));
+    CTM_TRY(alloc_dt(ctx, {Pl, AB}, &Lall));
+    auto slice = [&](const DT& c, long long idx, long long rows, long long cols) {     // (s,t) slice of a [p][p][rows][cols] corner
+        DT v = c.view({rows, cols});
+        v.p = c.p + idx * rows * cols;
+        if (c.q) v.q = c.q + idx * rows * cols;
+        return v;
+    };
+    auto build = [&](int i, DT* c) -> int {
+        CTM_TRY(alloc_dt(ctx, {pp[i], pp[i], n0[i], n1[i]}, c));
         ArenaScope s2(ctx);
         CornerIn ci;
         CTM_TRY(corner_in(io, t + 4 * i, chi, ad4 + 5 * i, cid[i], &ci));
-        CTM_TRY(corner_impl(ctx, cid[i], 1, ci.C, ci.T1, ci.T2, ci.a, chi, ad4 + 5 * i, &c[i]));
-        c[i] = c[i].view({n0, n1, p, p});
+        return corner_impl(ctx, cid[i], 2, ci.C, ci.T1, ci.T2, ci.a, chi, ad4 + 5 * i, c);
+    };
+    {   // lower half: L[(s2 t2 s3 t3)](a,b) = sum_k LD[s2,t2](a,k) RD[s3,t3](b,k)                  (rdm.py:1527-1528)
+        ArenaScope s1(ctx);
+        DT c3, c2;
+        CTM_TRY(build(3, &c3));
+        CTM_TRY(build(2, &c2));
+        for (long long i3 = 0; i3 < pp[3] * pp[3]; ++i3)
+            for (long long i2 = 0; i2 < pp[2] * pp[2]; ++i2) {
+                const DT x = slice(c3, i3, A, kl), y = slice(c2, i2, B, kl);
+                const long long cl = i3 * pp[2] * pp[2] + i2;
+                CTM_TRY(xgemm(ctx, (int)A, (int)B, (int)kl, xm(x, kl, false), xm(y, kl, true), Lall.p + cl * AB,
+                              Lall.q ? Lall.q + cl * AB : nullptr, B));
+            }
     }
-    DT up, lo, r;
-    CTM_TRY(io.out(out, pall, &r));
-    CTM_TRY(dev_einsum2(ctx, "akst", c[0], "kbuv", c[1], "abstuv", &up));          // rdm.py:1459-1460
-    CTM_TRY(dev_einsum2(ctx, "akst", c[3], "bkuv", c[2], "abstuv", &lo));          // :1527-1528
-    // rdm[s0 s1 s2 s3 ; t0 t1 t2 t3]                                                  // :1581-1588
-    CTM_TRY(dev_einsum2(ctx, "abstuv", up, "abwxyz", lo, "suwytvxz", &r));
+    {   // upper half, one slice at a time: U(a,b) = sum_k LU[s0,t0](a,k) RU[s1,t1](k,b); R[(s0 t0 s1 t1), :] = <U, L[:]>   (:1459-1460, 1581)
+        ArenaScope s1(ctx);
+        DT c0, c1, U;
+        CTM_TRY(build(0, &c0));
+        CTM_TRY(build(1, &c1));
+        CTM_TRY(alloc_dt(ctx, {A, B}, &U));
+        for (long long i0 = 0; i0 < pp[0] * pp[0]; ++i0)
+            for (long long i1 = 0; i1 < pp[1] * pp[1]; ++i1) {
+                const DT x = slice(c0, i0, A, ku), y = slice(c1, i1, ku, B);
+                CTM_TRY(xgemm(ctx, (int)A, (int)B, (int)ku, xm(x, ku, false), xm(y, B, false), U.p, U.q, B));
+                const long long cu = i0 * pp[1] * pp[1] + i1;
+                XM u{U.p, U.q, AB, false, false}, l{Lall.p, Lall.q, AB, true, false};
+                CTM_TRY(xgemm(ctx, 1, (int)Pl, (int)AB, u, l, R.p + cu * Pl, R.q ? R.q + cu * Pl : nullptr, Pl));
+            }
+    }
+    // R[s0 t0 s1 t1 ; s2 t2 s3 t3] -> rdm[s0 s1 s2 s3 ; t0 t1 t2 t3]                                               (:1581-1588)
+    long long dims[8] = {pp[0], pp[0], pp[1], pp[1], pp[3], pp[3], pp[2], pp[2]};
+    int perm[8] = {0, 2, 4, 6, 1, 3, 5, 7};
+    CTM_TRY(permute_f64(ctx, R.p, r.p, 8, dims, perm));
+    if (R.q) CTM_TRY(permute_f64(ctx, R.q, r.q, 8, dims, perm));
     return io.finish();
 }
 

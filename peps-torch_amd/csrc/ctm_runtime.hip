@@ -75,6 +75,17 @@ int ctm_destroy(ctm_ctx* ctx) {
     return CTM_OK;
 }
 
+int ctm_trim(ctm_ctx* ctx) {
+    // between calls the arena stack is empty: give every slab back to the device (it regrows on demand)
+    if (!ctx) return CTM_OK;
+    CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->arena.cur >= 0 || ctx->arena.top != 0) { ctx->set_error("trim: called inside an engine call"); return CTM_ERR_BADARG; }
+    for (auto& sl : ctx->arena.slabs) (void)hipFree(sl.base);
+    ctx->arena.slabs.clear();
+    ctx->arena.total = 0;
+    return CTM_OK;
+}
+
 const char* ctm_last_error(ctm_ctx* ctx) { return ctx ? ctx->last_error.c_str() : "null context"; }
 
 int ctm_sync(ctm_ctx* ctx) {

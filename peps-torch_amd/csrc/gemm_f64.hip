@@ -348,7 +348,9 @@ int gemm_f64(ctm_ctx* ctx, const GemmDesc& d) {
     const bool strip = (d.M <= 64 || d.N <= 64);
     const int max_tiles = strip ? ctx->splitk_max_tiles : 127, target = strip ? ctx->splitk_target_wgs : 512;
     if (d.batch == 1 && !d.offs && d.splitB_dim == 0 && d.splitA >= d.M && d.splitC >= d.M && ntile <= max_tiles && d.K >= 1024) {
-        int ks = std::min(16, std::min(target / std::max(ntile, 1), d.K / 256));
+        // partial products cost ks*M*N doubles: tiny outputs (reductions over a huge K) may split much further
+        const int ks_cap = ((long long)d.M * d.N <= 4096) ? 256 : 16;
+        int ks = std::min(ks_cap, std::min(target / std::max(ntile, 1), d.K / 256));
         if (ks > 1) {
             p.klen = (((d.K + ks - 1) / ks) + 15) / 16 * 16;
             ks = (d.K + p.klen - 1) / p.klen;

@@ -51,7 +51,16 @@ def rdm2x2(coord, state, env, open_sites=[0, 1, 2, 3], unroll=[], checkpoint_unr
     x, y = coord
     t = _corner_t(LU, (x, y), state, env) + _corner_t(RU, (x + 1, y), state, env) \
         + _corner_t(RD, (x + 1, y + 1), state, env) + _corner_t(LD, (x, y + 1), state, env)
-    raw = get_engine().rdm2x2(t)
+    eng = get_engine()
+    if hasattr(eng, "trim"):
+        # the open halves need n^2 (p^4 + 2 p^2) elements: at large n give the worker contexts' arenas (concurrent sweep
+        # units) back to the device first
+        a = t[3]
+        n = env.chi * a.shape[1] ** 2
+        need = n * n * (a.shape[0] ** 4 + 2 * a.shape[0] ** 2 + 4) * a.element_size()
+        if need > 0.15 * torch.cuda.get_device_properties(a.device).total_memory:
+            eng.trim(workers_only=True)
+    raw = eng.rdm2x2(t)
     if open_sites != [0, 1, 2, 3]:
         # fewer open sites = partial trace of the full plaquette RDM over the closed ones (rdm.py:1306-1360 contracts
         # their physical legs inside the corners; same numbers, the native kernel always opens all four)
