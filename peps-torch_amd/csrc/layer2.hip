@@ -160,6 +160,134 @@ __global__ __launch_bounds__(512) void layer2_kernel(Layer2Params p) {
     }
 }
 
+// Register-resident variant: KT waves per workgroup, wave w owns the open-ket block e in [16 w, 16 w + 16).  Step A produces the
+// W tiles (all KT contracted-bra blocks x this e block) in registers in the MFMA C/D layout, which IS the A-operand layout
+// of step B (lane l, register r of tile j holds W[kb = 16 j + 4 r + (l >> 4)][e = l & 15] = row e, k-slice r of block j), so W
+// never travels through LDS and the only workgroup barriers are the two around the staging of Z.
+template <int KT>
+__global__ __launch_bounds__(64 * KT) void layer2_reg_kernel(Layer2Params p) {
+    constexpr int KAp = 16 * KT, NEp = 16 * KT, NTH = 64 * KT;
+    constexpr int NZ = (KAp * KAp + NTH - 1) / NTH;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double* Zs = smem;                               // KAp x ldz
+    double* As = Zs + (size_t)KAp * p.ldz;           // KAp x lda   (row kk: [s][e], e padded to NEp)
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int lr = lane & 15, lk = lane >> 4;
+    const int tot = KAp * (p.ldz + p.lda);
+    for (int q = tid; q < tot; q += NTH) smem[q] = 0.0;
+    __syncthreads();
+    {
+        const int na = p.KA * p.p * p.NE;
+        for (int q = tid; q < na; q += NTH) {
+            const int e = q % p.NE, s = (q / p.NE) % p.p, kk = q / (p.NE * p.p);
+            As[kk * p.lda + s * NEp + e] = p.A[q];
+        }
+    }
+    long long zoff[NZ]; int zdst[NZ];
+    const int nz = p.KA * p.KA;
+#pragma unroll
+    for (int j = 0; j < NZ; ++j) {
+        const int e = tid + NTH * j;
+        if (e < nz) {
+            const int c2b = e % p.D2; int r = e / p.D2;
+            const int c2k = r % p.D2; r /= p.D2;
+            const int c1b = r % p.D1; const int c1k = r / p.D1;
+            zoff[j] = c1k * p.zs_c1k + c1b * p.zs_c1b + c2k * p.zs_c2k + c2b * p.zs_c2b;
+            zdst[j] = (c1b * p.D2 + c2b) * p.ldz + (c1k * p.D2 + c2k);
+        } else { zoff[j] = 0; zdst[j] = -1; }
+    }
+    long long ooff[KT][4]; bool ook[KT][4];
+#pragma unroll
+    for (int n = 0; n < KT; ++n) {
+        const int E = n * 16 + lr;
+        const long long ob = (long long)(E / p.E2) * p.os_e1b + (long long)(E % p.E2) * p.os_e2b;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int e = wid * 16 + lk + 4 * r;
+            ook[n][r] = E < p.NE && e < p.NE && !(p.dbg & 4);
+            ooff[n][r] = (long long)(e / p.E2) * p.os_e1k + (long long)(e % p.E2) * p.os_e2k + ob;
+        }
+    }
+    const long long npair = (long long)p.nx * p.ny;
+    double zreg[NZ];
+    {
+        const long long q = blockIdx.x;
+        if (q < npair) {
+            const double* z = p.Z + (q / p.ny) * p.zs_x + (q % p.ny) * p.zs_y;
+#pragma unroll
+            for (int j = 0; j < NZ; ++j) if (zdst[j] >= 0) zreg[j] = z[zoff[j]];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NZ; ++j) if (zdst[j] >= 0) Zs[zdst[j]] = zreg[j];
+
+    for (long long q = blockIdx.x; q < npair; q += gridDim.x) {
+        __syncthreads();                               // Zs of this pair is complete
+        const long long qn = q + gridDim.x;
+        if (qn < npair && !(p.dbg & 1)) {
+            const double* z = p.Z + (qn / p.ny) * p.zs_x + (qn % p.ny) * p.zs_y;
+#pragma unroll
+            for (int j = 0; j < NZ; ++j) if (zdst[j] >= 0) zreg[j] = z[zoff[j]];
+        }
+        d4 acc[KT];
+#pragma unroll
+        for (int n = 0; n < KT; ++n) acc[n] = (d4){0., 0., 0., 0.};
+        for (int s = 0; s < ((p.dbg & 2) ? 0 : p.p); ++s) {
+            const double* Asl = As + s * NEp;
+            // ---- step A: W[kb][e] = sum_kk Zs[kb][kk] As[kk][s][e]   (e block of this wave, every kb block)
+            d4 w[KT];
+#pragma unroll
+            for (int j = 0; j < KT; ++j) w[j] = (d4){0., 0., 0., 0.};
+#pragma unroll
+            for (int k0 = 0; k0 < KAp; k0 += 4) {
+                const double b = Asl[(lk + k0) * p.lda + wid * 16 + lr];
+#pragma unroll
+                for (int j = 0; j < KT; ++j) {
+                    const double a = Zs[(j * 16 + lr) * p.ldz + lk + k0];
+                    w[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, w[j], 0, 0, 0);
+                }
+            }
+            // ---- step B: O[e][E] += sum_kb W[kb][e] As[kb][s][E]   (W straight from the accumulator registers)
+#pragma unroll
+            for (int j = 0; j < KT; ++j) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const double a = w[j][r];
+                    const double* brow = Asl + (j * 16 + 4 * r + lk) * p.lda + lr;
+#pragma unroll
+                    for (int n = 0; n < KT; ++n) acc[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, brow[n * 16], acc[n], 0, 0, 0);
+                }
+            }
+        }
+        double* o = p.out + (q / p.ny) * p.os_x + (q % p.ny) * p.os_y;
+#pragma unroll
+        for (int n = 0; n < KT; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (ook[n][r]) o[ooff[n][r]] = acc[n][r];
+        __syncthreads();                               // every wave finished reading Zs
+        if (qn < npair) {
+#pragma unroll
+            for (int j = 0; j < NZ; ++j) if (zdst[j] >= 0) Zs[zdst[j]] = zreg[j];
+        }
+    }
+}
+
+template <int KT>
+int launch_layer2_reg(ctm_ctx* ctx, const Layer2Params& p) {
+    const size_t lds_bytes = sizeof(double) * (size_t)p.KAp * (p.ldz + p.lda);
+    static std::once_flag attr_once;
+    std::call_once(attr_once, [] { (void)hipFuncSetAttribute((const void*)layer2_reg_kernel<KT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
+    const long long npair = (long long)p.nx * p.ny;
+    const int per_cu = std::max(1, std::min(8, (int)((150 * 1024) / lds_bytes)));
+    const int grid = (int)std::min<long long>(npair, 256LL * per_cu * 2);
+    hipLaunchKernelGGL(layer2_reg_kernel<KT>, dim3(grid), dim3(64 * KT), lds_bytes, ctx->stream, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { ctx->set_error(std::string("layer2 launch: ") + hipGetErrorString(e)); return CTM_ERR_HIP; }
+    return CTM_OK;
+}
+
 template <int KT>
 int launch_layer2(ctm_ctx* ctx, const Layer2Params& p, size_t lds_bytes) {
     static std::once_flag attr_once;
@@ -269,6 +397,14 @@ int dev_layer2(ctm_ctx* ctx, const std::string& iz, const DT& Z, const std::stri
     const double fl = 2.0 * npair * p.p * ((double)p.KA * p.KA * p.NE + (double)p.KA * p.NE * p.NE);
     const int ev = timing_begin(ctx);
     int st;
+    if (ctx->layer2_reg >= 0 && p.KAp / 16 >= ctx->layer2_reg) {
+        switch (p.KAp / 16) {
+            case 1: st = launch_layer2_reg<1>(ctx, p); break;
+            case 2: st = launch_layer2_reg<2>(ctx, p); break;
+            case 3: st = launch_layer2_reg<3>(ctx, p); break;
+            default: st = launch_layer2_reg<4>(ctx, p); break;
+        }
+    } else
     switch (p.KAp / 16) {
         case 1: st = launch_layer2<1>(ctx, p, lds_bytes); break;
         case 2: st = launch_layer2<2>(ctx, p, lds_bytes); break;
