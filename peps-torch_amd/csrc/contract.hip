@@ -150,9 +150,10 @@ int dev_network(ctm_ctx* ctx, const std::string& expr, const std::vector<DT>& op
     const std::vector<std::string> ins = split_inputs(expr.substr(0, arrow));
     size_t k = 0;
     bool found = false;
-    if (ctx->use_layer2 && !ops[0].q)
+    if (ctx->use_layer2 && (!ops[0].q || ctx->layer2_cplx))
         for (k = 1; k + 1 < ins.size(); ++k)
-            if (ops[k].p == ops[k + 1].p && ins[k].size() == 5 && ins[k + 1].size() == 5 && ins[k][0] == ins[k + 1][0]) { found = true; break; }
+            if (ops[k].p == ops[k + 1].p && ins[k].size() == 5 && ins[k + 1].size() == 5 && ins[k][0] == ins[k + 1][0] &&
+                (!ops[k].q || (!ops[k].cj && ops[k + 1].cj))) { found = true; break; }      // complex: (a, conj a) in this order
     if (!found) return dev_seq_einsum(ctx, expr, ops, out);
     // natural index order of the prefix result (same rule as dev_seq_einsum)
     std::string later = oidx;
@@ -207,8 +208,12 @@ int dev_network(ctm_ctx* ctx, const std::string& expr, const std::vector<DT>& op
             numel *= d;
         }
     }
-    if (!has_suffix && out->p) O.p = out->p;
-    else CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)numel, (void**)&O.p));
+    const bool cx = ops[k].q != nullptr;
+    if (!has_suffix && out->p) { O.p = out->p; O.q = out->q; }
+    else {
+        CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)numel * (cx ? 2 : 1), (void**)&O.p));
+        if (cx) O.q = O.p + numel;
+    }
     CTM_TRY(dev_layer2(ctx, zidx, Z, ins[k], ins[k + 1], ops[k], io, &O));
     if (!has_suffix) { *out = O; return CTM_OK; }
     std::vector<DT> rest; rest.push_back(O);

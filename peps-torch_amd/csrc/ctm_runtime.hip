@@ -111,6 +111,7 @@ int ctm_set_option(ctm_ctx* ctx, const char* key, double value) {
     else if (k == "gemm_fast") ctx->gemm_fast = value != 0.0;
     else if (k == "splitk_max_tiles") ctx->splitk_max_tiles = (int)value;
     else if (k == "splitk_target_wgs") ctx->splitk_target_wgs = (int)value;
+    else if (k == "layer2_cplx") ctx->layer2_cplx = value != 0.0;
     else if (k == "layer2_reg") ctx->layer2_reg = (int)value;
     else if (k == "eig64_pingpong") ctx->eig64_pingpong = value != 0.0;
     else if (k == "gemm_timing") {

@@ -27,6 +27,9 @@ struct Layer2Params {
     int KA, KAp, NE, NEp;
     int ldz, lda, ldw;               // LDS row strides (doubles)
     int dbg;                         // development: 1 skip gather, 2 skip MFMA, 4 skip scatter
+    // complex128 (planar): imaginary planes, the physical index handled by this launch, accumulate into out
+    const double* Zi = nullptr; const double* Ai = nullptr; double* out_i = nullptr;
+    int s_sel = 0, accumulate = 0;
 };
 
 // KT = KAp/16 = NEp/16 (square case: contracted and open leg pairs have the same padded size), 512 threads = 8 waves
@@ -274,6 +277,144 @@ __global__ __launch_bounds__(64 * KT) void layer2_reg_kernel(Layer2Params p) {
     }
 }
 
+// complex128 variant of the register-resident kernel (planar data, one physical index s per launch so that the two planes of
+// Z and of the site slice a[.,s,.] fit in LDS together; launches s > 0 accumulate into the output):
+//   W = Z a_s            Wr = Zr Ar - Zi Ai          Wi = Zr Ai + Zi Ar
+//   O += W^T conj(a_s)   Or += Wr Ar + Wi Ai         Oi += Wi Ar - Wr Ai
+// four real FP64 MFMAs per complex tile step, operands negated on the fly where a product is subtracted.
+template <int KT>
+__global__ __launch_bounds__(64 * KT) void layer2_c_kernel(Layer2Params p) {
+    constexpr int KAp = 16 * KT, NEp = 16 * KT, NTH = 64 * KT;
+    constexpr int NZ = (KAp * KAp + NTH - 1) / NTH;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int ldz = KAp + 1, lda = NEp + 1;
+    double* Zr = smem;
+    double* Zi = Zr + KAp * ldz;
+    double* Ar = Zi + KAp * ldz;
+    double* Ai = Ar + KAp * lda;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int lr = lane & 15, lk = lane >> 4;
+    const int tot = 2 * KAp * (ldz + lda);
+    for (int q = tid; q < tot; q += NTH) smem[q] = 0.0;
+    __syncthreads();
+    {
+        const int na = p.KA * p.NE;
+        for (int q = tid; q < na; q += NTH) {
+            const int e = q % p.NE, kk = q / p.NE;
+            const size_t src = ((size_t)kk * p.p + p.s_sel) * p.NE + e;
+            Ar[kk * lda + e] = p.A[src]; Ai[kk * lda + e] = p.Ai[src];
+        }
+    }
+    long long zoff[NZ]; int zdst[NZ];
+    const int nz = p.KA * p.KA;
+#pragma unroll
+    for (int j = 0; j < NZ; ++j) {
+        const int e = tid + NTH * j;
+        if (e < nz) {
+            const int c2b = e % p.D2; int r = e / p.D2;
+            const int c2k = r % p.D2; r /= p.D2;
+            const int c1b = r % p.D1; const int c1k = r / p.D1;
+            zoff[j] = c1k * p.zs_c1k + c1b * p.zs_c1b + c2k * p.zs_c2k + c2b * p.zs_c2b;
+            zdst[j] = (c1b * p.D2 + c2b) * ldz + (c1k * p.D2 + c2k);
+        } else { zoff[j] = 0; zdst[j] = -1; }
+    }
+    long long ooff[KT][4]; bool ook[KT][4];
+#pragma unroll
+    for (int n = 0; n < KT; ++n) {
+        const int E = n * 16 + lr;
+        const long long ob = (long long)(E / p.E2) * p.os_e1b + (long long)(E % p.E2) * p.os_e2b;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int e = wid * 16 + lk + 4 * r;
+            ook[n][r] = E < p.NE && e < p.NE;
+            ooff[n][r] = (long long)(e / p.E2) * p.os_e1k + (long long)(e % p.E2) * p.os_e2k + ob;
+        }
+    }
+    const long long npair = (long long)p.nx * p.ny;
+    double zr[NZ], zi[NZ];
+    {
+        const long long q = blockIdx.x;
+        if (q < npair) {
+            const long long zo = (q / p.ny) * p.zs_x + (q % p.ny) * p.zs_y;
+#pragma unroll
+            for (int j = 0; j < NZ; ++j) if (zdst[j] >= 0) { zr[j] = p.Z[zo + zoff[j]]; zi[j] = p.Zi[zo + zoff[j]]; }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NZ; ++j) if (zdst[j] >= 0) { Zr[zdst[j]] = zr[j]; Zi[zdst[j]] = zi[j]; }
+
+    for (long long q = blockIdx.x; q < npair; q += gridDim.x) {
+        __syncthreads();
+        const long long qn = q + gridDim.x;
+        if (qn < npair) {
+            const long long zo = (qn / p.ny) * p.zs_x + (qn % p.ny) * p.zs_y;
+#pragma unroll
+            for (int j = 0; j < NZ; ++j) if (zdst[j] >= 0) { zr[j] = p.Z[zo + zoff[j]]; zi[j] = p.Zi[zo + zoff[j]]; }
+        }
+        d4 wr[KT], wi[KT], accr[KT], acci[KT];
+#pragma unroll
+        for (int n = 0; n < KT; ++n) { wr[n] = (d4){0., 0., 0., 0.}; wi[n] = wr[n]; accr[n] = wr[n]; acci[n] = wr[n]; }
+#pragma unroll
+        for (int k0 = 0; k0 < KAp; k0 += 4) {
+            const double br = Ar[(lk + k0) * lda + wid * 16 + lr], bi = Ai[(lk + k0) * lda + wid * 16 + lr];
+#pragma unroll
+            for (int j = 0; j < KT; ++j) {
+                const double ar = Zr[(j * 16 + lr) * ldz + lk + k0], ai = Zi[(j * 16 + lr) * ldz + lk + k0];
+                wr[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, br, wr[j], 0, 0, 0);
+                wr[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(-ai, bi, wr[j], 0, 0, 0);
+                wi[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, bi, wi[j], 0, 0, 0);
+                wi[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, br, wi[j], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < KT; ++j) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double a_r = wr[j][r], a_i = wi[j][r];
+                const int row = (j * 16 + 4 * r + lk) * lda + lr;
+#pragma unroll
+                for (int n = 0; n < KT; ++n) {
+                    const double Br = Ar[row + n * 16], Bi = Ai[row + n * 16];
+                    accr[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_r, Br, accr[n], 0, 0, 0);
+                    accr[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_i, Bi, accr[n], 0, 0, 0);
+                    acci[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_i, Br, acci[n], 0, 0, 0);
+                    acci[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a_r, Bi, acci[n], 0, 0, 0);
+                }
+            }
+        }
+        const long long oo = (q / p.ny) * p.os_x + (q % p.ny) * p.os_y;
+#pragma unroll
+        for (int n = 0; n < KT; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (ook[n][r]) {
+                    const long long o = oo + ooff[n][r];
+                    if (p.accumulate) { p.out[o] += accr[n][r]; p.out_i[o] += acci[n][r]; }
+                    else { p.out[o] = accr[n][r]; p.out_i[o] = acci[n][r]; }
+                }
+        __syncthreads();
+        if (qn < npair) {
+#pragma unroll
+            for (int j = 0; j < NZ; ++j) if (zdst[j] >= 0) { Zr[zdst[j]] = zr[j]; Zi[zdst[j]] = zi[j]; }
+        }
+    }
+}
+
+template <int KT>
+int launch_layer2_c(ctm_ctx* ctx, const Layer2Params& p) {
+    const size_t lds_bytes = sizeof(double) * 2 * (size_t)(16 * KT) * (2 * 16 * KT + 2);
+    static std::once_flag attr_once;
+    std::call_once(attr_once, [] { (void)hipFuncSetAttribute((const void*)layer2_c_kernel<KT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
+    const long long npair = (long long)p.nx * p.ny;
+    const int per_cu = std::max(1, std::min(8, (int)((150 * 1024) / lds_bytes)));
+    const int grid = (int)std::min<long long>(npair, 256LL * per_cu * 2);
+    hipLaunchKernelGGL(layer2_c_kernel<KT>, dim3(grid), dim3(64 * KT), lds_bytes, ctx->stream, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { ctx->set_error(std::string("layer2 launch: ") + hipGetErrorString(e)); return CTM_ERR_HIP; }
+    return CTM_OK;
+}
+
 template <int KT>
 int launch_layer2_reg(ctm_ctx* ctx, const Layer2Params& p) {
     const size_t lds_bytes = sizeof(double) * (size_t)p.KAp * (p.ldz + p.lda);
@@ -359,16 +500,20 @@ int dev_layer2(ctm_ctx* ctx, const std::string& iz, const DT& Z, const std::stri
     if (lds_bytes > 150 * 1024) { ctx->set_error("layer2: LDS budget"); return CTM_ERR_UNSUPPORTED; }
     ArenaScope scope(ctx);
     // site tensor image [c1][c2][s][e1][e2]
+    const bool cx = (A.q != nullptr);
+    if (cx && !(Z.q && out->q)) { ctx->set_error("layer2: complex operands need two planes"); return CTM_ERR_BADARG; }
     double* Ap;
-    CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)A.numel(), (void**)&Ap));
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)A.numel() * (cx ? 2 : 1), (void**)&Ap));
     {
         long long dims[5]; int perm[5];
         for (int i = 0; i < 5; ++i) dims[i] = A.dims[i];
         perm[0] = (int)ia.find(ck[0]); perm[1] = (int)ia.find(ck[1]); perm[2] = 0; perm[3] = (int)ia.find(ek[0]); perm[4] = (int)ia.find(ek[1]);
         CTM_TRY(permute_f64(ctx, A.p, Ap, 5, dims, perm));
+        if (cx) CTM_TRY(permute_f64(ctx, A.q, Ap + A.numel(), 5, dims, perm));
     }
     p.A = Ap;
     p.Z = Z.p;
+    if (cx) { p.Ai = Ap + A.numel(); p.Zi = Z.q; }
     p.zs_x = stride_of(iz, Z, sp[0]); p.zs_y = stride_of(iz, Z, sp[1]);
     p.nx = (int)Z.dims[iz.find(sp[0])]; p.ny = (int)Z.dims[iz.find(sp[1])];
     p.zs_c1k = stride_of(iz, Z, ck[0]); p.zs_c1b = stride_of(iz, Z, cb[0]);
@@ -388,15 +533,26 @@ int dev_layer2(ctm_ctx* ctx, const std::string& iz, const DT& Z, const std::stri
         // allocate OUTSIDE this function's scope: caller-visible result must survive -> use the caller's arena position
         ctx->set_error("layer2: output buffer must be provided"); return CTM_ERR_BADARG;
     }
-    p.out = O.p;
+    p.out = O.p; p.out_i = out->q;
     p.os_x = stride_of(io, O, sp[0]); p.os_y = stride_of(io, O, sp[1]);
     p.os_e1k = stride_of(io, O, ek[0]); p.os_e1b = stride_of(io, O, eb[0]);
     p.os_e2k = stride_of(io, O, ek[1]); p.os_e2b = stride_of(io, O, eb[1]);
     p.dbg = ctx->layer2_dbg;
     const long long npair = (long long)p.nx * p.ny;
-    const double fl = 2.0 * npair * p.p * ((double)p.KA * p.KA * p.NE + (double)p.KA * p.NE * p.NE);
+    const double fl = 2.0 * npair * p.p * ((double)p.KA * p.KA * p.NE + (double)p.KA * p.NE * p.NE) * (cx ? 4.0 : 1.0);
     const int ev = timing_begin(ctx);
-    int st;
+    int st = CTM_OK;
+    if (cx) {
+        for (int s_ = 0; s_ < p.p && st == CTM_OK; ++s_) {
+            p.s_sel = s_; p.accumulate = s_ > 0;
+            switch (p.KAp / 16) {
+                case 1: st = launch_layer2_c<1>(ctx, p); break;
+                case 2: st = launch_layer2_c<2>(ctx, p); break;
+                case 3: st = launch_layer2_c<3>(ctx, p); break;
+                default: st = launch_layer2_c<4>(ctx, p); break;
+            }
+        }
+    } else
     if (ctx->layer2_reg >= 0 && p.KAp / 16 >= ctx->layer2_reg) {
         switch (p.KAp / 16) {
             case 1: st = launch_layer2_reg<1>(ctx, p); break;
@@ -415,6 +571,6 @@ int dev_layer2(ctm_ctx* ctx, const std::string& iz, const DT& Z, const std::stri
     CTM_TRY(st);
     ctx->layer2_flops += fl;
     ctx->layer2_calls += 1;
-    out->dims = O.dims;
+    out->dims = O.dims; out->cj = false;
     return CTM_OK;
 }

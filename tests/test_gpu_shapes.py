@@ -9,16 +9,17 @@ from helpers import dev, relerr
 pytestmark = pytest.mark.gpu
 
 
+@pytest.mark.parametrize("cplx", [False, True], ids=["f64", "c128"])
 @pytest.mark.parametrize("D,chi", [(2, 5), (3, 7), (4, 6), (5, 9), (6, 8), (7, 5), (8, 6)])
-def test_corners_and_absorb_all_bond_dims(eng, D, chi):
+def test_corners_and_absorb_all_bond_dims(eng, D, chi, cplx):
     """c2x2 (4 corners, closed + open), the C4v corner and one absorb per direction for every D (fused kernel
     variants KT=1..4 incl. zero padding 25->32, 36->48, 49->64) vs the oracle."""
     from oracle import ctm_oracle as O, c4v_oracle as O4
     rng = np.random.default_rng(100 * D + chi)
-    a = rng.standard_normal((2, D, D, D, D))
-    C = rng.standard_normal((chi, chi))
-    Ts = {(0, -1): rng.standard_normal((chi, D * D, chi)), (-1, 0): rng.standard_normal((chi, chi, D * D)),
-          (0, 1): rng.standard_normal((D * D, chi, chi)), (1, 0): rng.standard_normal((chi, D * D, chi))}
+    rnd = (lambda *s_: rng.standard_normal(s_) + 1j * rng.standard_normal(s_)) if cplx else (lambda *s_: rng.standard_normal(s_))
+    a = rnd(2, D, D, D, D)
+    C = rnd(chi, chi)
+    Ts = {(0, -1): rnd(chi, D * D, chi), (-1, 0): rnd(chi, chi, D * D), (0, 1): rnd(D * D, chi, chi), (1, 0): rnd(chi, D * D, chi)}
     for cid in range(4):
         sp = O._CORNER[cid]
         T1, T2 = Ts[sp['T1']], Ts[sp['T2']]
@@ -28,16 +29,16 @@ def test_corners_and_absorb_all_bond_dims(eng, D, chi):
         if D <= 4:
             refo = O.c2x2_sl(cid, C, T1, T2, a, open_=True)
             assert relerr(eng.c2x2(cid, dev(C), dev(T1), dev(T2), dev(a), open_=True), refo) < 1e-12
-    Tc = rng.standard_normal((chi, chi, D * D))
+    Tc = rnd(chi, chi, D * D)
     assert relerr(eng.c2x2_c4v(dev(a), dev(C), dev(Tc)), O4.c2x2_sl(a, C, Tc)) < 1e-12
     # absorb: random projectors
     sites = {(0, 0): a}
     ost = O.State(sites, lX=1, lY=1)
     env = O.Env(chi)
-    for v in [(-1, -1), (1, -1), (1, 1), (-1, 1)]: env.C[((0, 0), v)] = rng.standard_normal((chi, chi))
+    for v in [(-1, -1), (1, -1), (1, 1), (-1, 1)]: env.C[((0, 0), v)] = rnd(chi, chi)
     for v, t in Ts.items(): env.T[((0, 0), v)] = t
     n = chi * D * D
-    P = {(0, 0): rng.standard_normal((n, chi))}; Pt = {(0, 0): rng.standard_normal((n, chi))}
+    P = {(0, 0): rnd(n, chi)}; Pt = {(0, 0): rnd(n, chi)}
     from ctm.generic import ctmrg
     from ipeps.ipeps import IPEPS
     from ctm.generic.env import ENV
