@@ -207,14 +207,19 @@ void proj_scale(const TruncOut& to, int kc, double reltol, std::vector<double>* 
 }
 
 // out (n x kc) = opA(cA) * ( opB(cB) * rows^T[^H] ) * diag(scale)   with rows = k x n row factors (kc leading ones used)
-int corner_chain_times_rowsT(ctm_ctx* ctx, int n, int k, int kc, const DT& cA, bool tA, const DT& cB, bool tB, const double* rows,
+// Only the first `ncol` columns carry a non-zero scale (S/S[0] > reltol is a prefix of the descending spectrum): the others
+// are exact zeros of the result (as in the reference, ctm_projectors.py:266-283) and are not computed.
+int corner_chain_times_rowsT(ctm_ctx* ctx, int n, int k, int kc, int ncol, const DT& cA, bool tA, const DT& cB, bool tB, const double* rows,
                              bool conj_rows, const double* d_scale, const DT& out) {
     ArenaScope scope(ctx);
+    CTM_TRY(fill_f64(ctx, out.p, (size_t)n * kc * (out.q ? 2 : 1), 0.0));      // planes are adjacent
+    if (out.q && out.q != out.p + (size_t)n * kc) CTM_TRY(fill_f64(ctx, out.q, (size_t)n * kc, 0.0));
+    if (ncol <= 0) return CTM_OK;
     DT t1;
-    CTM_TRY(alloc_dt(ctx, {n, kc}, &t1));
+    CTM_TRY(alloc_dt(ctx, {n, ncol}, &t1));
     XM r; r.re = rows; r.im = ctx->cplx ? rows + (size_t)k * n : nullptr; r.ld = n; r.t = true; r.c = conj_rows;
-    CTM_TRY(xgemm(ctx, n, kc, n, xm(cB, n, tB), r, t1.p, t1.q, kc));
-    return xgemm(ctx, n, kc, n, xm(cA, n, tA), xm(t1, kc, false), out.p, out.q, kc, d_scale);
+    CTM_TRY(xgemm(ctx, n, ncol, n, xm(cB, n, tB), r, t1.p, t1.q, ncol));
+    return xgemm(ctx, n, ncol, n, xm(cA, n, tA), xm(t1, ncol, false), out.p, out.q, kc, d_scale);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -422,9 +427,11 @@ int ctm_svdvals(ctm_ctx* ctx, const double* M, int n, double* S) {
 
 namespace {
 // shared tail of the projector constructions: scale vector from the kept spectrum
-int upload_scale(ctm_ctx* ctx, const TruncOut& to, int kc, double reltol, double* dScale, double* S_out) {
+int upload_scale(ctm_ctx* ctx, const TruncOut& to, int kc, double reltol, double* dScale, double* S_out, int* ncol) {
     std::vector<double> Sh, sc;
     proj_scale(to, kc, reltol, &Sh, &sc);
+    *ncol = 0;
+    for (int i = 0; i < kc; ++i) if (sc[i] != 0.0) *ncol = i + 1;
     CTM_HIP_CHECK(ctx, hipMemcpyAsync(dScale, sc.data(), sizeof(double) * kc, hipMemcpyHostToDevice, ctx->stream));
     if (S_out) CTM_HIP_CHECK(ctx, hipMemcpyAsync(S_out, Sh.data(), sizeof(double) * kc, hipMemcpyHostToDevice, ctx->stream));
     CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));     // host vectors go out of scope
@@ -457,13 +464,18 @@ int ctm_projectors(ctm_ctx* ctx, const double* R, const double* Rt, int n, int c
     TruncOut to;
     { PhaseTimer pt(ctx, CTM_T_SVD); CTM_TRY(svd_rows(ctx, tM, n, chi, cfg, Ut, Vt, dS, &to)); }
     PhaseTimer pt(ctx, CTM_T_PROJ);
-    CTM_TRY(upload_scale(ctx, to, kc, cfg.svd_reltol, dScale, S_out));
+    int ncol;
+    CTM_TRY(upload_scale(ctx, to, kc, cfg.svd_reltol, dScale, S_out, &ncol));
     // P = R conj(U) diag(S_sqrt),  Pt = Rt V diag(S_sqrt)   (:283); with row factors Ut = U^H, Vt = V^H:
-    // conj(U) = Ut^T (plain transpose), V = Vt^H -> NT GEMMs + fused column scale
+    // conj(U) = Ut^T (plain transpose), V = Vt^H -> NT GEMMs + fused column scale; zero-scale columns are not computed
     const size_t kn = (size_t)k * n;
     XM u{Ut, ctx->cplx ? Ut + kn : nullptr, n, true, false}, v{Vt, ctx->cplx ? Vt + kn : nullptr, n, true, true};
-    CTM_TRY(xgemm(ctx, n, kc, n, xm(tR, n, false), u, tP.p, tP.q, kc, dScale));
-    CTM_TRY(xgemm(ctx, n, kc, n, xm(tRt, n, false), v, tPt.p, tPt.q, kc, dScale));
+    CTM_TRY(fill_f64(ctx, tP.p, (size_t)n * kc * (tP.q ? 2 : 1), 0.0));
+    CTM_TRY(fill_f64(ctx, tPt.p, (size_t)n * kc * (tPt.q ? 2 : 1), 0.0));
+    if (ncol > 0) {
+        CTM_TRY(xgemm(ctx, n, ncol, n, xm(tR, n, false), u, tP.p, tP.q, kc, dScale));
+        CTM_TRY(xgemm(ctx, n, ncol, n, xm(tRt, n, false), v, tPt.p, tPt.q, kc, dScale));
+    }
     CTM_TRY(io.finish());
     CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     return CTM_OK;
@@ -514,10 +526,11 @@ int ctm_projectors_4x4_ws(ctm_ctx* ctx, int dir, const double* const* t, int chi
     TruncOut to;
     { PhaseTimer pt(ctx, CTM_T_SVD); CTM_TRY(svd_rows_op(ctx, op, chi, cfg, Ut, Vt, dS, &to)); }
     PhaseTimer pt(ctx, CTM_T_PROJ);
-    CTM_TRY(upload_scale(ctx, to, kc, cfg.svd_reltol, dScale, S_out));
+    int ncol;
+    CTM_TRY(upload_scale(ctx, to, kc, cfg.svd_reltol, dScale, S_out, &ncol));
     // P = R conj(U) S^-1/2 = opA(cA) opB(cB) Ut^T ... ; Pt = Rt V S^-1/2 = opC(cC) opD(cD) Vt^H ...
-    CTM_TRY(corner_chain_times_rowsT(ctx, (int)n, k, kc, c[0], tr[0], c[1], tr[1], Ut, false, dScale, tP));
-    CTM_TRY(corner_chain_times_rowsT(ctx, (int)n, k, kc, c[2], tr[2], c[3], tr[3], Vt, true, dScale, tPt));
+    CTM_TRY(corner_chain_times_rowsT(ctx, (int)n, k, kc, ncol, c[0], tr[0], c[1], tr[1], Ut, false, dScale, tP));
+    CTM_TRY(corner_chain_times_rowsT(ctx, (int)n, k, kc, ncol, c[2], tr[2], c[3], tr[3], Vt, true, dScale, tPt));
     CTM_TRY(io.finish());
     CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     return CTM_OK;
