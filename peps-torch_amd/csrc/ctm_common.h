@@ -55,7 +55,10 @@ struct ctm_ctx {
     bool si_enable = true;
     int si_min_n = 512, si_max_iter = 40, si_last_iters = 0, si_rr_sweeps = 40, si_last_rank = 0;
     double si_tol = 2e-14;
+    double rank_tol = 5e-13;             // numerical-rank threshold of the leading-k solvers (relative to s_0)
     long si_hits = 0, si_fallbacks = 0, si_total_iters = 0, si_warm_starts = 0;
+    // block Golub-Kahan-Lanczos for spectra that do not collapse inside a small block (svd_lanczos)
+    bool lz_enable = true; int lz_min_k = 48; double lz_switch_steps = 6.0; double lz_last_resid = 1.0; long lz_hits = 0, lz_total_steps = 0;
     int last_sweeps = 0;
     long total_sweeps = 0, jacobi_calls = 0;
     double last_offnorm = 0;

@@ -111,6 +111,10 @@ int ctm_set_option(ctm_ctx* ctx, const char* key, double value) {
     else if (k == "gemm_fast") ctx->gemm_fast = value != 0.0;
     else if (k == "splitk_max_tiles") ctx->splitk_max_tiles = (int)value;
     else if (k == "splitk_target_wgs") ctx->splitk_target_wgs = (int)value;
+    else if (k == "rank_tol") ctx->rank_tol = value;
+    else if (k == "lz_enable") ctx->lz_enable = value != 0.0;
+    else if (k == "lz_min_k") ctx->lz_min_k = (int)value;
+    else if (k == "lz_switch_steps") ctx->lz_switch_steps = value;
     else if (k == "layer2_cplx") ctx->layer2_cplx = value != 0.0;
     else if (k == "layer2_reg") ctx->layer2_reg = (int)value;
     else if (k == "eig64_pingpong") ctx->eig64_pingpong = value != 0.0;
@@ -136,6 +140,8 @@ int ctm_get_stat(ctm_ctx* ctx, const char* key, double* value) {
     else if (k == "si_total_iters") *value = (double)ctx->si_total_iters;
     else if (k == "si_last_rank") *value = (double)ctx->si_last_rank;
     else if (k == "si_warm_starts") *value = (double)ctx->si_warm_starts;
+    else if (k == "lz_hits") *value = (double)ctx->lz_hits;
+    else if (k == "lz_total_steps") *value = (double)ctx->lz_total_steps;
     else if (k == "gemm_flops") *value = ctx->gemm_flops;
     else if (k == "gemm_calls") *value = (double)ctx->gemm_calls;
     else if (k == "layer2_flops") *value = ctx->layer2_flops;
@@ -164,7 +170,7 @@ int ctm_gemm_intervals(ctm_ctx* ctx, double* out, long long capacity, long long*
 
 int ctm_timers(ctm_ctx* ctx, double* out8, int reset) {
     for (int i = 0; i < CTM_T_COUNT; ++i) { if (out8) out8[i] = ctx->timers[i]; if (reset) ctx->timers[i] = 0.0; }
-    if (reset) { ctx->gemm_flops = 0; ctx->gemm_calls = 0; ctx->layer2_flops = 0; ctx->layer2_calls = 0; ctx->total_sweeps = 0; ctx->jacobi_calls = 0; ctx->si_hits = 0; ctx->si_fallbacks = 0; ctx->si_total_iters = 0; ctx->si_warm_starts = 0; }
+    if (reset) { ctx->gemm_flops = 0; ctx->gemm_calls = 0; ctx->layer2_flops = 0; ctx->layer2_calls = 0; ctx->total_sweeps = 0; ctx->jacobi_calls = 0; ctx->si_hits = 0; ctx->si_fallbacks = 0; ctx->si_total_iters = 0; ctx->si_warm_starts = 0; ctx->lz_hits = 0; ctx->lz_total_steps = 0; }
     return CTM_OK;
 }
 
