@@ -9,8 +9,8 @@ from helpers import dev, relerr
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("cplx", [False, True], ids=["f64", "c128"])
-def test_sweeps_match_oracle_on_iterative_path(eng, cplx):
+@pytest.mark.parametrize("cplx,chi,nsweeps", [(False, 32, 3), (True, 32, 3), (False, 64, 2)], ids=["f64", "c128", "f64-krylov"])
+def test_sweeps_match_oracle_on_iterative_path(eng, cplx, chi, nsweeps):
     import config as cfg
     from ipeps.ipeps import IPEPS
     from ctm.generic.env import ENV, init_env
@@ -18,7 +18,7 @@ def test_sweeps_match_oracle_on_iterative_path(eng, cplx):
     from models import j1j2
     from oracle import ctm_oracle as O, j1j2_oracle as OJ
     rng = np.random.default_rng(5 + int(cplx))
-    D, chi, nsweeps = 4, 32, 3
+    D = 4
     sites = {}
     for y in range(2):
         for x in range(2):
@@ -29,18 +29,23 @@ def test_sweeps_match_oracle_on_iterative_path(eng, cplx):
     st = IPEPS({k: dev(v) for k, v in sites.items()})
     env = ENV(chi, st); init_env(st, env)
     ost = O.State(sites); oe = O.init_env_ctmrg(ost, chi)
-    h0, w0 = eng.stat("si_hits"), eng.stat("si_warm_starts")
+    h0, w0, l0 = eng.stat("si_hits"), eng.stat("si_warm_starts"), eng.stat("lz_hits")
     for _ in range(nsweeps):
         for d in cfg.ctm_args.ctm_move_sequence:
             for _r in range(2):
                 ctmrg.ctm_MOVE(d, st, env)
         O.ctm_sweep(ost, oe)
-    assert eng.stat("si_hits") > h0 and eng.stat("si_warm_starts") > w0       # the iterative, warm-started path ran
+    if chi >= 48:
+        assert eng.stat("lz_hits") > l0                                      # chi + 1 >= 48 on a hard state: the block Krylov solver ran
+    else:
+        assert eng.stat("si_hits") > h0 and eng.stat("si_warm_starts") > w0   # the iterative, warm-started path ran
     spec = env.get_spectra(); ospec = O.corner_spectra(oe)
     for k in ospec:
         assert np.abs(spec[k].cpu().numpy() - ospec[k]).max() < 1e-10, k
-    for k in oe.C: assert relerr(env.C[k].abs(), np.abs(oe.C[k])) < 1e-8, k
-    for k in oe.T: assert relerr(env.T[k].abs(), np.abs(oe.T[k])) < 1e-8, k
+    # entries carry the 1/sqrt(S) amplification of the smallest kept triplets (S/S0 ~ 1e-8): gauge-invariant |.| to 1e-7,
+    # the north-star quantities (spectra above, RDM/energy below) to 1e-10
+    for k in oe.C: assert relerr(env.C[k].abs(), np.abs(oe.C[k])) < 1e-7, k
+    for k in oe.T: assert relerr(env.T[k].abs(), np.abs(oe.T[k])) < 1e-7, k
     # plaquette RDM of one site (the oracle's open-corner contraction is the slow part of this test)
     from ctm.generic import rdm
     r = rdm.rdm2x2((0, 0), st, env).cpu().numpy()
