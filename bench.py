@@ -280,7 +280,7 @@ def main():
                 "other_gemm": {"kernel": names[1 - dom], "launches": int(k_n[1 - dom]), "ms": round(k_ms[1 - dom], 2),
                                "tflops": round(k_fl[1 - dom] / max(k_ms[1 - dom] * 1e-3, 1e-30) / 1e12, 3) if k_n[1 - dom] else 0.0}}
         # the fused two-layer enlarged-corner / absorb kernel (MFMA from LDS; also the largest HBM consumer)
-        roof["enlarged_corner_kernel"] = {"kernel": "layer2_kernel<KT>", "launches": int(k_n[2]), "avg_launch_ms": round(k_ms[2] / max(k_n[2], 1), 4),
+        roof["enlarged_corner_kernel"] = {"kernel": "layer2_reg_kernel<KT> (float64) / layer2_c_kernel<KT> (complex128)", "launches": int(k_n[2]), "avg_launch_ms": round(k_ms[2] / max(k_n[2], 1), 4),
                                           "busy_ms_union": round(u_ms[2], 3),
                                           "mfma_tflops": round(k_fl[2] / max(u_ms[2] * 1e-3, 1e-30) / 1e12, 3) if k_n[2] else 0.0,
                                           "mfma_frac": round(k_fl[2] / max(u_ms[2] * 1e-3, 1e-30) / 1e12 / FP64_MFMA_PEAK_TFLOPS, 4) if k_n[2] else 0.0}
@@ -296,7 +296,7 @@ def main():
                     if key in row["kernel"] or (dom == 0 and "gemm_f64_kernel<4, 4>" in row["kernel"]):
                         tot_b += float(row["hbm_bytes_per_launch(2x_fetch_corrected)"]) * float(row["launches"]); tot_n += float(row["launches"])
                 for row in csv.DictReader(open(os.path.join(REPO, "profiles", "r01_bench_default_pmc_hbm_traffic.csv"))):
-                    if "layer2_kernel" in row["kernel"] and k_n[2]:
+                    if "layer2_" in row["kernel"] and k_n[2]:
                         b = float(row["hbm_bytes_per_launch(2x_fetch_corrected)"])
                         roof["enlarged_corner_kernel"]["hbm_bytes_per_launch"] = round(b)
                         roof["enlarged_corner_kernel"]["hbm_GBps_per_launch"] = round(b / (k_ms[2] / k_n[2] * 1e-3) / 1e9, 1)
