@@ -885,7 +885,9 @@ int svd_iter(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* Ut, double
         std::fill(h.begin(), h.end(), 0.0);
     }
     if (kw > 0) {
-        p = std::min(p_full, std::max(64, ((kw + 16 + 63) / 64) * 64));
+        // a FULL warm basis (the previous decomposition had at least k significant triplets) starts with the full block, so a
+        // nearly converged basis is recognised by the first residual checks instead of triggering the block-growth logic
+        p = (kw >= k) ? p_full : std::min(p_full, std::max(64, ((kw + 16 + 63) / 64) * 64));
         kw = std::min(kw, p - 8);
         CTM_TRY(copy2d(ctx, op.warm, n, XB, ld, kw, n));
         double* Rn = XB + (size_t)kw * ld;
@@ -945,6 +947,10 @@ int svd_iter(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* Ut, double
             if (worst <= resid_tol(ctx, n) * s0) { *converged = true; break; }
             // a block whose residual contracts slowly (slowly decaying tail): predict the remaining half steps from the
             // observed contraction and hand over to the block Krylov solver when many are left
+            if (want_krylov && ctx->lz_enable && k >= ctx->lz_min_k && !exhausted && warm && it == 1 && worst > 1e-9 * s0) {
+                // a warm basis that is not close (environment still changing) on a full-rank problem: block Krylov straight away
+                *want_krylov = true; ctx->si_last_iters = it; ctx->si_total_iters += it; return CTM_OK;
+            }
             if (want_krylov && ctx->lz_enable && k >= ctx->lz_min_k && !exhausted && worst_prev > 0.0 && worst < worst_prev) {
                 const double rate = worst / worst_prev, need = std::log(resid_tol(ctx, n) * s0 / worst) / std::log(rate);
                 if (need > ctx->lz_switch_steps) { *want_krylov = true; ctx->si_last_iters = it; ctx->si_total_iters += it; return CTM_OK; }
