@@ -48,11 +48,15 @@ const char* ctm_last_error(ctm_ctx* ctx);
 const char* ctm_version(void);
 int ctm_sync(ctm_ctx* ctx);
 int ctm_trim(ctm_ctx* ctx);   /* release the context's workspace arena (regrown on demand); call between engine calls */
-int ctm_set_option(ctm_ctx* ctx, const char* key, double value);   /* "jacobi_tol","jacobi_max_sweeps","jacobi_block","jacobi_inner_sweeps","jacobi_verbose",
-                                                                      "si_enable","si_min_n","si_max_iter","si_tol","si_rr_sweeps","use_layer2","gemm_fast","gemm_timing","profile" */
-int ctm_get_stat(ctm_ctx* ctx, const char* key, double* value);    /* "last_sweeps","last_offnorm","total_sweeps","jacobi_calls","si_hits","si_fallbacks","si_total_iters",
-                                                                      "si_last_rank","si_warm_starts","gemm_flops","gemm_calls","layer2_flops","layer2_calls","arena_high",
-                                                                      "k_ms0|1","k_flops0|1","k_calls0|1" */
+int ctm_set_option(ctm_ctx* ctx, const char* key, double value);
+/*   truncation:  "jacobi_tol","jacobi_max_sweeps","jacobi_block","jacobi_inner_sweeps","jacobi_verbose","eig64_pingpong",
+ *                "si_enable","si_min_n","si_max_iter","si_tol","si_rr_sweeps","rank_tol","lz_enable","lz_min_k","lz_switch_steps"
+ *   kernels:     "use_layer2","layer2_reg","layer2_cplx","gemm_fast","splitk_max_tiles","splitk_target_wgs"
+ *   measurement: "gemm_timing","profile"                                                                                      */
+int ctm_get_stat(ctm_ctx* ctx, const char* key, double* value);
+/*   "last_sweeps","last_offnorm","total_sweeps","jacobi_calls","si_hits","si_fallbacks","si_total_iters","si_last_iters",
+ *   "si_last_rank","si_warm_starts","lz_hits","lz_total_steps","gemm_flops","gemm_calls","layer2_flops","layer2_calls",
+ *   "arena_high","k_ms0|1|2","k_flops0|1|2","k_calls0|1|2"                                                                   */
 int ctm_timers(ctm_ctx* ctx, double* out8, int reset);             /* corners,halves,svd,proj,absorb,norm,rdm,eig (s) */
 /* GEMM launches timed with HIP events while the option "gemm_timing" is on: quadruples (kind, start_ms, end_ms, flops) on a
  * process-wide clock (kind 0 = 128x128-tile GEMM kernels, 1 = 64x64-tile GEMM kernel, 2 = fused two-layer kernel).  out may be NULL to query *count (launches). */
