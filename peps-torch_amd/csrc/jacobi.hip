@@ -1186,8 +1186,9 @@ int matop_apply_c(ctm_ctx* ctx, const MatOp& op, bool adjoint, const double* B, 
 }
 
 // leading-k triplets of a complex operator: the iteration of svd_iter() on panel rows
-int svd_iter_c(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* Ut, double* Vt, bool* converged) {
+int svd_iter_c(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* Ut, double* Vt, bool* converged, bool* want_krylov = nullptr) {
     *converged = false;
+    if (want_krylov) *want_krylov = false;
     const int n = op.n;
     int p_full = k + std::max(32, k / 2);
     p_full = ((p_full + 63) / 64) * 64;
@@ -1214,7 +1215,7 @@ int svd_iter_c(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* Ut, doub
         std::fill(h.begin(), h.end(), 0.0);
     }
     if (kw > 0) {
-        p = std::min(p_full, std::max(64, ((kw + 16 + 63) / 64) * 64));
+        p = (kw >= k) ? p_full : std::min(p_full, std::max(64, ((kw + 16 + 63) / 64) * 64));
         kw = std::min(kw, p - 8);
         const int pr = p - kw;
         ArenaScope ws(ctx);
@@ -1239,6 +1240,7 @@ int svd_iter_c(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* Ut, doub
     int side = 0;              // 0: C = B M^H (B = rows v^H, produces s u^H) ; 1: C = B M (B = rows u^H, produces s v^H)
     double s0 = 0.0;
     int rank = 0, kk = k;
+    double worst_prev = 0.0;
     const double rank_tol = ctx->rank_tol;      // singular values below rank_tol * s_0 are rounding noise: never required to converge, returned as zeros
     const int max_half = 2 * ctx->si_max_iter;
     int it = 0;
@@ -1257,6 +1259,7 @@ int svd_iter_c(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* Ut, doub
             for (int i = 0; i < p; ++i) rank += (h[i] > rank_tol * s0);
             const bool exhausted = rank <= p - 8;
             if (!exhausted && p < p_full) {
+                if (want_krylov && ctx->lz_enable && k >= ctx->lz_min_k) { *want_krylov = true; ctx->si_last_iters = it; ctx->si_total_iters += it; return CTM_OK; }
                 const int pn = std::min(p_full, 2 * p);
                 hipLaunchKernelGGL(hash_fill_kernel, dim3(1024), dim3(256), 0, ctx->stream, cur + (size_t)2 * p * ld, 2 * (pn - p), n, ld,
                                    0x9876543ULL + (unsigned long long)pn);
@@ -1269,6 +1272,14 @@ int svd_iter_c(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* Ut, doub
             for (int i = 0; i < kk; ++i) worst = std::max(worst, hr[idx[i]]);
             if (ctx->jacobi_verbose) fprintf(stderr, "[si-c] n=%d p=%d half-step %d  rank=%d  max resid/s0 = %.3e\n", n, p, it, rank, worst / std::max(s0, 1e-300));
             if (worst <= resid_tol(ctx, n) * s0) { *converged = true; break; }
+            if (want_krylov && ctx->lz_enable && k >= ctx->lz_min_k && !exhausted) {        // same hand-over rules as svd_iter()
+                bool sw = warm && it == 1 && worst > 1e-9 * s0;
+                if (!sw && worst_prev > 0.0 && worst < worst_prev)
+                    sw = std::log(resid_tol(ctx, n) * s0 / worst) / std::log(worst / worst_prev) > ctx->lz_switch_steps;
+                else if (!sw && worst_prev > 0.0 && it >= 6) sw = true;
+                if (sw) { *want_krylov = true; ctx->si_last_iters = it; ctx->si_total_iters += it; return CTM_OK; }
+            }
+            worst_prev = worst;
         }
         int st;
         std::vector<double> hh;
@@ -1536,6 +1547,272 @@ int svd_lanczos(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* Ut, dou
     return CTM_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// complex128 block Golub-Kahan-Lanczos (planar data): the algorithm of svd_lanczos() with ^T -> ^H.  Row bases hold u^H, v^H.
+// ---------------------------------------------------------------------------------------------
+// Cholesky factor of a 64 x 64 Hermitian Gram matrix (planar) and the inverse of its lower factor
+__global__ __launch_bounds__(256) void chol64_inv_c_kernel(const double* Gr, const double* Gi, double* Lr, double* Li, double* status) {
+    constexpr int M = 64;
+    __shared__ double Ar[M][M + 1], Ai[M][M + 1];
+    __shared__ double Xr[M][M + 1], Xi[M][M + 1];
+    __shared__ double piv_min;
+    const int tid = threadIdx.x;
+    for (int q = tid; q < M * M; q += 256) {
+        const int i = q >> 6, c = q & 63;
+        Ar[i][c] = Gr[q]; Ai[i][c] = (i == c) ? 0.0 : Gi[q];
+        Xr[i][c] = (i == c) ? 1.0 : 0.0; Xi[i][c] = 0.0;
+    }
+    if (tid == 0) piv_min = 1e300;
+    __syncthreads();
+    for (int j = 0; j < M; ++j) {
+        const double d = Ar[j][j];
+        if (tid == 0) piv_min = fmin(piv_min, d);
+        const double l = sqrt(fmax(d, 1e-300));
+        __syncthreads();
+        if (tid < M) {
+            if (tid == j) { Ar[j][j] = l; Ai[j][j] = 0.0; }
+            else if (tid > j) { Ar[tid][j] /= l; Ai[tid][j] /= l; }
+        }
+        __syncthreads();
+        for (int q = tid; q < M * M; q += 256) {            // A[i][c] -= A[i][j] conj(A[c][j])   (lower triangle)
+            const int i = q >> 6, c = q & 63;
+            if (c > j && i >= c) {
+                const double xr = Ar[i][j], xi = Ai[i][j], yr = Ar[c][j], yi = Ai[c][j];
+                Ar[i][c] -= xr * yr + xi * yi;
+                Ai[i][c] -= xi * yr - xr * yi;
+            }
+        }
+        __syncthreads();
+    }
+    if (tid < M) {                                            // L X = I, one column per thread
+        const int c = tid;
+        for (int i = c; i < M; ++i) {
+            double ar = (i == c) ? 1.0 : 0.0, ai = 0.0;
+            for (int t = c; t < i; ++t) {
+                ar -= Ar[i][t] * Xr[t][c] - Ai[i][t] * Xi[t][c];
+                ai -= Ar[i][t] * Xi[t][c] + Ai[i][t] * Xr[t][c];
+            }
+            Xr[i][c] = ar / Ar[i][i]; Xi[i][c] = ai / Ar[i][i];
+        }
+    }
+    __syncthreads();
+    for (int q = tid; q < M * M; q += 256) { const int i = q >> 6, c = q & 63; Lr[q] = (c <= i) ? Xr[i][c] : 0.0; Li[q] = (c <= i) ? Xi[i][c] : 0.0; }
+    if (tid == 0) status[0] = piv_min;
+}
+
+struct CRows { double* re; double* im; };      // planar complex row block (rows x n, leading dimension n)
+
+// rows of W (64 x n complex) -> orthonormal rows: unit-norm scaling + two Cholesky-QR passes; *ok = false on near dependence
+int orthonormalise_block_c(ctm_ctx* ctx, CRows W, int n, double* norms, double* inv, double* min_norm, double* max_norm, bool* ok) {
+    const int rows = 64;
+    std::vector<double> h(rows);
+    CTM_TRY(row_norms_c128(ctx, W.re, W.im, rows, n, n, norms));
+    CTM_HIP_CHECK(ctx, hipMemcpyAsync(h.data(), norms, sizeof(double) * rows, hipMemcpyDeviceToHost, ctx->stream));
+    CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    *min_norm = *std::min_element(h.begin(), h.end());
+    *max_norm = *std::max_element(h.begin(), h.end());
+    *ok = *min_norm > 0.0;
+    if (!*ok) return CTM_OK;
+    hipLaunchKernelGGL(inv_or_zero_kernel, dim3(1), dim3(256), 0, ctx->stream, norms, inv, rows);
+    hipLaunchKernelGGL(scale_rows_kernel, dim3(1024), dim3(256), 0, ctx->stream, W.re, rows, n, (long long)n, inv);
+    hipLaunchKernelGGL(scale_rows_kernel, dim3(1024), dim3(256), 0, ctx->stream, W.im, rows, n, (long long)n, inv);
+    ArenaScope scope(ctx);
+    // near-dependent rows (e.g. the first power step of a random block): one-sided complex Jacobi in the panel layout
+    auto jacobi_fallback = [&]() -> int {
+        double *P, *Tp; int* d_idx;
+        CTM_TRY(arena_alloc(ctx, sizeof(double) * 2 * (size_t)rows * n, (void**)&P));
+        CTM_TRY(arena_alloc(ctx, sizeof(double) * 2 * (size_t)rows * n, (void**)&Tp));
+        CTM_TRY(arena_alloc(ctx, sizeof(int) * 2 * rows, (void**)&d_idx));
+        hipLaunchKernelGGL(planar_to_panel_kernel, dim3(2048), dim3(256), 0, ctx->stream, (const double*)W.re, (const double*)W.im, (long long)n, rows, n, P, (long long)n, 0);
+        std::vector<double> hh; int st;
+        const double fro = host_fro(ctx, P, 2 * rows, n, n, norms, hh, &st);
+        CTM_TRY(st);
+        CTM_TRY(jacobi_rows(ctx, P, 2 * rows, n, n, n, 2 * BC, 0, fro, ctx->si_rr_sweeps, true));
+        std::vector<int> idx(rows); std::iota(idx.begin(), idx.end(), 0);
+        CTM_TRY(panel_gather(ctx, P, n, idx, rows, n, Tp, d_idx));
+        CTM_HIP_CHECK(ctx, hipMemcpyAsync(W.re, Tp, sizeof(double) * (size_t)rows * n, hipMemcpyDeviceToDevice, ctx->stream));
+        CTM_HIP_CHECK(ctx, hipMemcpyAsync(W.im, Tp + (size_t)rows * n, sizeof(double) * (size_t)rows * n, hipMemcpyDeviceToDevice, ctx->stream));
+        CTM_TRY(row_norms_c128(ctx, W.re, W.im, rows, n, n, norms));
+        hipLaunchKernelGGL(inv_or_zero_kernel, dim3(1), dim3(256), 0, ctx->stream, norms, inv, rows);
+        hipLaunchKernelGGL(scale_rows_kernel, dim3(1024), dim3(256), 0, ctx->stream, W.re, rows, n, (long long)n, inv);
+        hipLaunchKernelGGL(scale_rows_kernel, dim3(1024), dim3(256), 0, ctx->stream, W.im, rows, n, (long long)n, inv);
+        return CTM_OK;
+    };
+    double *G, *Li, *T;
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * 2 * 64 * 64, (void**)&G));
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * 2 * 64 * 64, (void**)&Li));
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * 2 * (size_t)rows * n, (void**)&T));
+    double* status = ctx->d_scratch + 16;
+    for (int pass = 0; pass < 2; ++pass) {
+        XM w{W.re, W.im, n, false, false}, wh{W.re, W.im, n, true, true};
+        CTM_TRY(xgemm(ctx, 64, 64, n, w, wh, G, G + 4096, 64));                       // G = W W^H
+        hipLaunchKernelGGL(chol64_inv_c_kernel, dim3(1), dim3(256), 0, ctx->stream, (const double*)G, (const double*)(G + 4096), Li, Li + 4096, status);
+        CTM_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_scratch + 16, status, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        if (!(ctx->h_scratch[16] > (pass == 0 ? 1e-10 : 0.5))) return jacobi_fallback();
+        XM l{Li, Li + 4096, 64, false, false};
+        CTM_TRY(xgemm(ctx, 64, n, 64, l, w, T, T + (size_t)rows * n, n));             // W <- L^-1 W
+        CTM_HIP_CHECK(ctx, hipMemcpyAsync(W.re, T, sizeof(double) * (size_t)rows * n, hipMemcpyDeviceToDevice, ctx->stream));
+        CTM_HIP_CHECK(ctx, hipMemcpyAsync(W.im, T + (size_t)rows * n, sizeof(double) * (size_t)rows * n, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    return CTM_OK;
+}
+
+// W (b x n) -= (W B^H) B for the orthonormal planar row basis B (m rows, planes `bplane` apart); twice
+int project_out_c(ctm_ctx* ctx, CRows W, int b, int n, const double* Bre, const double* Bim, int m, double* G, double* T) {
+    if (m <= 0) return CTM_OK;
+    for (int rep = 0; rep < 2; ++rep) {
+        XM w{W.re, W.im, n, false, false}, bh{Bre, Bim, n, true, true}, bb{Bre, Bim, n, false, false};
+        CTM_TRY(xgemm(ctx, b, m, n, w, bh, G, G + (size_t)b * m, m));
+        XM g{G, G + (size_t)b * m, m, false, false};
+        CTM_TRY(xgemm(ctx, b, n, m, g, bb, T, T + (size_t)b * n, n));
+        hipLaunchKernelGGL(sub_inplace_kernel, dim3(1024), dim3(256), 0, ctx->stream, W.re, (const double*)T, (size_t)b * n);
+        hipLaunchKernelGGL(sub_inplace_kernel, dim3(1024), dim3(256), 0, ctx->stream, W.im, (const double*)(T + (size_t)b * n), (size_t)b * n);
+    }
+    return CTM_OK;
+}
+
+// C = B M (adjoint == false) or B M^H on planar complex rows
+int matop_apply_planar(ctm_ctx* ctx, const MatOp& op, bool adjoint, const double* Bre, const double* Bim, int rows, double* Cre, double* Cim) {
+    const int n = op.n;
+    XM b{Bre, Bim, n, false, false};
+    if (op.M) { XM m{op.M, op.Mi, n, adjoint, adjoint}; return xgemm(ctx, rows, n, n, b, m, Cre, Cim, n); }
+    ArenaScope scope(ctx);
+    double *t1, *t2;
+    const size_t rn = (size_t)rows * n;
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * 2 * rn, (void**)&t1));
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * 2 * rn, (void**)&t2));
+    auto f = [&](int i, bool t, bool c) { XM x{op.c[i], op.ci[i], n, t, c}; return x; };
+    XM x1{t1, t1 + rn, n, false, false}, x2{t2, t2 + rn, n, false, false};
+    if (!adjoint) {   // B opB(cB)^T opA(cA)^T opC(cC) opD(cD)
+        CTM_TRY(xgemm(ctx, rows, n, n, b, f(1, !op.t[1], false), t1, t1 + rn, n));
+        CTM_TRY(xgemm(ctx, rows, n, n, x1, f(0, !op.t[0], false), t2, t2 + rn, n));
+        CTM_TRY(xgemm(ctx, rows, n, n, x2, f(2, op.t[2], false), t1, t1 + rn, n));
+        return xgemm(ctx, rows, n, n, x1, f(3, op.t[3], false), Cre, Cim, n);
+    }
+    // B opD(cD)^H opC(cC)^H conj(opA(cA)) conj(opB(cB))
+    CTM_TRY(xgemm(ctx, rows, n, n, b, f(3, !op.t[3], true), t1, t1 + rn, n));
+    CTM_TRY(xgemm(ctx, rows, n, n, x1, f(2, !op.t[2], true), t2, t2 + rn, n));
+    CTM_TRY(xgemm(ctx, rows, n, n, x2, f(0, op.t[0], true), t1, t1 + rn, n));
+    return xgemm(ctx, rows, n, n, x1, f(1, op.t[1], true), Cre, Cim, n);
+}
+
+int svd_lanczos_c(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* Ut, double* Vt, bool* converged) {
+    *converged = false;
+    const int n = op.n, b = 64;
+    const int jmin = (k + b - 1) / b + 1;
+    const int jmax = std::min((n / 2) / b, (6 * k) / b + 8);
+    if (jmax < jmin + 1) return CTM_OK;
+    ArenaScope scope(ctx);
+    const size_t rows_max = (size_t)jmax * b, bn = (size_t)b * n;
+    // planar bases: re plane [rows][n], im plane at +plane
+    const size_t planeU = rows_max * n, planeV = (rows_max + b) * n;
+    double *Uall, *Vall, *Zraw, *G, *T2, *norms, *inv;
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * 2 * planeU, (void**)&Uall));
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * 2 * planeV, (void**)&Vall));
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * 2 * planeU, (void**)&Zraw));
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * 2 * (size_t)b * (rows_max + b), (void**)&G));
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * 2 * bn, (void**)&T2));
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * std::max<size_t>(rows_max, 1024), (void**)&norms));
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * std::max<size_t>(rows_max, 1024), (void**)&inv));
+    auto Ur = [&](int j) { CRows r{Uall + (size_t)j * bn, Uall + planeU + (size_t)j * bn}; return r; };
+    auto Vr = [&](int j) { CRows r{Vall + (size_t)j * bn, Vall + planeV + (size_t)j * bn}; return r; };
+    auto Zr = [&](int j) { CRows r{Zraw + (size_t)j * bn, Zraw + planeU + (size_t)j * bn}; return r; };
+    double mn, mx, s0 = 0.0;
+    bool ok;
+    hipLaunchKernelGGL(hash_fill_kernel, dim3(1024), dim3(256), 0, ctx->stream, Vall, b, n, (long long)n, 0x51f15eedULL);
+    hipLaunchKernelGGL(hash_fill_kernel, dim3(1024), dim3(256), 0, ctx->stream, Vall + planeV, b, n, (long long)n, 0x0dd5eedULL);
+    CTM_TRY(orthonormalise_block_c(ctx, Vr(0), n, norms, inv, &mn, &mx, &ok));
+    if (!ok) return CTM_OK;
+    int applications = 0;
+    for (int j = 0; j < jmax; ++j) {
+        const CRows Uj = Ur(j), Vj = Vr(j), Vn = Vr(j + 1), Zj = Zr(j);
+        CTM_TRY(matop_apply_planar(ctx, op, true, Vj.re, Vj.im, b, Uj.re, Uj.im)); applications += b;
+        CTM_TRY(project_out_c(ctx, Uj, b, n, Uall, Uall + planeU, j * b, G, T2));
+        CTM_TRY(orthonormalise_block_c(ctx, Uj, n, norms, inv, &mn, &mx, &ok));
+        s0 = std::max(s0, mx);
+        if (!ok || mn <= 1e-13 * s0) { if (ctx->jacobi_verbose) fprintf(stderr, "[lz-c] n=%d breakdown at step %d (U)\n", n, j); return CTM_OK; }
+        CTM_TRY(matop_apply_planar(ctx, op, false, Uj.re, Uj.im, b, Zj.re, Zj.im)); applications += b;
+        CTM_HIP_CHECK(ctx, hipMemcpyAsync(Vn.re, Zj.re, sizeof(double) * bn, hipMemcpyDeviceToDevice, ctx->stream));
+        CTM_HIP_CHECK(ctx, hipMemcpyAsync(Vn.im, Zj.im, sizeof(double) * bn, hipMemcpyDeviceToDevice, ctx->stream));
+        CTM_TRY(project_out_c(ctx, Vn, b, n, Vall, Vall + planeV, (j + 1) * b, G, T2));
+        CTM_TRY(orthonormalise_block_c(ctx, Vn, n, norms, inv, &mn, &mx, &ok));
+        if (!ok || mn <= 1e-13 * s0) { if (ctx->jacobi_verbose) fprintf(stderr, "[lz-c] n=%d breakdown at step %d (V)\n", n, j); return CTM_OK; }
+        const int m = (j + 1) * b;
+        const int jfirst = std::max(jmin, (4 * k + b - 1) / b);
+        if ((j + 1 < jfirst || ((j + 1 - jfirst) & 1)) && j + 1 < jmax) continue;
+        ArenaScope rs(ctx);
+        const int kq = std::min(k, m);
+        const size_t mm = (size_t)m * m, mb = (size_t)m * b, km = (size_t)kq * m, kb = (size_t)kq * b;
+        double *T, *E, *Ss, *Xt, *Yt, *XE, *rn;
+        CTM_TRY(arena_alloc(ctx, sizeof(double) * 2 * mm, (void**)&T));
+        CTM_TRY(arena_alloc(ctx, sizeof(double) * 2 * mb, (void**)&E));
+        CTM_TRY(arena_alloc(ctx, sizeof(double) * m, (void**)&Ss));
+        CTM_TRY(arena_alloc(ctx, sizeof(double) * 2 * km, (void**)&Xt));
+        CTM_TRY(arena_alloc(ctx, sizeof(double) * 2 * km, (void**)&Yt));
+        CTM_TRY(arena_alloc(ctx, sizeof(double) * 2 * kb, (void**)&XE));
+        CTM_TRY(arena_alloc(ctx, sizeof(double) * std::max(kq, 1), (void**)&rn));
+        XM z{Zraw, Zraw + planeU, n, false, false}, vh{Vall, Vall + planeV, n, true, true}, vnh{Vn.re, Vn.im, n, true, true};
+        CTM_TRY(xgemm(ctx, m, m, n, z, vh, T, T + mm, m));                           // T = (U_all M) V_all^H
+        CTM_TRY(xgemm(ctx, m, b, n, z, vnh, E, E + mb, b));                          // E = (U_all M) V_{j+1}^H
+        CTM_TRY(svd_full_c(ctx, T, T + mm, m, kq, Ss, Xt, Yt));                      // T = Xt^H diag(Ss) Yt
+        XM x{Xt, Xt + km, m, false, false}, e{E, E + mb, b, false, false};
+        CTM_TRY(xgemm(ctx, kq, b, m, x, e, XE, XE + kb, b));
+        CTM_TRY(row_norms_c128(ctx, XE, XE + kb, kq, b, b, rn));
+        std::vector<double> hr(kq), hs(kq);
+        CTM_HIP_CHECK(ctx, hipMemcpyAsync(hr.data(), rn, sizeof(double) * kq, hipMemcpyDeviceToHost, ctx->stream));
+        CTM_HIP_CHECK(ctx, hipMemcpyAsync(hs.data(), Ss, sizeof(double) * kq, hipMemcpyDeviceToHost, ctx->stream));
+        CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        int kv = 0;
+        while (kv < kq && hs[kv] > ctx->rank_tol * hs[0]) ++kv;
+        const double est = *std::max_element(hr.begin(), hr.begin() + std::max(kv, 1));
+        if (ctx->jacobi_verbose) fprintf(stderr, "[lz-c] n=%d step %d basis %d  s0=%.3e  residual estimate/s0 = %.3e\n", n, j + 1, m, hs[0], est / hs[0]);
+        if (kq < k || (est > resid_tol(ctx, n) * hs[0] && j + 1 < jmax)) continue;
+        // Ritz triplets (rows u^H, v^H) and the check of both relations with the operator
+        const size_t kn = (size_t)k * n;
+        XM y{Yt, Yt + km, m, false, false}, ua{Uall, Uall + planeU, n, false, false}, va{Vall, Vall + planeV, n, false, false};
+        CTM_TRY(xgemm(ctx, k, n, m, x, ua, Ut, Ut + kn, n));
+        CTM_TRY(xgemm(ctx, k, n, m, y, va, Vt, Vt + kn, n));
+        CTM_TRY(reorth_rows_c(ctx, Ut, k, n, 1));
+        CTM_TRY(reorth_rows_c(ctx, Vt, k, n, 1));
+        double *C1, *res;
+        CTM_TRY(arena_alloc(ctx, sizeof(double) * 2 * kn, (void**)&C1));
+        CTM_TRY(arena_alloc(ctx, sizeof(double) * 2 * k, (void**)&res));
+        double worst = 0.0;
+        std::vector<double> r1(2 * k);
+        for (int rel = 0; rel < 2; ++rel) {        // rel 0: Ut M = S Vt ; rel 1: Vt M^H = S Ut
+            const double* src = rel == 0 ? Ut : Vt; const double* dst = rel == 0 ? Vt : Ut;
+            CTM_TRY(matop_apply_planar(ctx, op, rel == 1, src, src + kn, k, C1, C1 + kn)); applications += k;
+            hipLaunchKernelGGL(resid_rows_kernel, dim3((k + 3) / 4), dim3(256), 0, ctx->stream, C1, (long long)n, dst, (long long)n, Ss, k, n, res);
+            hipLaunchKernelGGL(resid_rows_kernel, dim3((k + 3) / 4), dim3(256), 0, ctx->stream, C1 + kn, (long long)n, dst + kn, (long long)n, Ss, k, n, res + k);
+            CTM_HIP_CHECK(ctx, hipMemcpyAsync(r1.data(), res, sizeof(double) * 2 * k, hipMemcpyDeviceToHost, ctx->stream));
+            CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+            for (int i = 0; i < std::max(kv, 1); ++i) worst = std::max(worst, std::sqrt(r1[i] * r1[i] + r1[k + i] * r1[k + i]));
+        }
+        if (ctx->jacobi_verbose) fprintf(stderr, "[lz-c] n=%d verified residual/s0 = %.3e after %d row applications\n", n, worst / hs[0], applications);
+        ctx->lz_last_resid = worst / hs[0];
+        if (worst > resid_tol(ctx, n) * hs[0] && worst <= 1e-11 * hs[0] && est <= resid_tol(ctx, n) * hs[0]) {
+            ctx->lz_hits += 1; ctx->lz_total_steps += j + 1;
+            return CTM_OK;          // the caller polishes with a warm-started subspace pass
+        }
+        if (worst <= resid_tol(ctx, n) * hs[0]) {
+            CTM_HIP_CHECK(ctx, hipMemcpyAsync(S, Ss, sizeof(double) * k, hipMemcpyDeviceToDevice, ctx->stream));
+            if (kv < k) {
+                CTM_TRY(fill_f64(ctx, S + kv, (size_t)(k - kv), 0.0));
+                for (int pl = 0; pl < 2; ++pl) {
+                    CTM_TRY(fill_f64(ctx, Ut + pl * kn + (size_t)kv * n, (size_t)(k - kv) * n, 0.0));
+                    CTM_TRY(fill_f64(ctx, Vt + pl * kn + (size_t)kv * n, (size_t)(k - kv) * n, 0.0));
+                }
+            }
+            CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+            *converged = true;
+            ctx->lz_hits += 1; ctx->lz_total_steps += j + 1;
+            return CTM_OK;
+        }
+    }
+    return CTM_OK;
+}
+
 }  // namespace
 
 int jacobi_svd_top_op(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* Ut, double* Vt) {
@@ -1548,9 +1825,24 @@ int jacobi_svd_top_op(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* U
     };
     if (op.Mi || op.ci[0]) {        // complex128
         if (Ut && Vt && ctx->si_enable && k < n && n >= ctx->si_min_n) {
-            bool ok = false;
-            CTM_TRY(svd_iter_c(ctx, op, k, S, Ut, Vt, &ok));
+            bool ok = false, krylov = false;
+            CTM_TRY(svd_iter_c(ctx, op, k, S, Ut, Vt, &ok, &krylov));
             if (ok) { ctx->si_hits += 1; return keep_warm(); }
+            if (krylov) {
+                ctx->lz_last_resid = 1.0;
+                CTM_TRY(svd_lanczos_c(ctx, op, k, S, Ut, Vt, &ok));
+                if (ok) return keep_warm();
+                MatOp op2 = op;
+                ArenaScope ws(ctx);
+                if (ctx->lz_last_resid <= 1e-11) {
+                    double* w2;
+                    CTM_TRY(arena_alloc(ctx, sizeof(double) * 2 * (size_t)k * n, (void**)&w2));
+                    CTM_HIP_CHECK(ctx, hipMemcpyAsync(w2, Vt, sizeof(double) * 2 * (size_t)k * n, hipMemcpyDeviceToDevice, ctx->stream));
+                    op2.warm = w2;
+                }
+                CTM_TRY(svd_iter_c(ctx, op2, k, S, Ut, Vt, &ok, nullptr));
+                if (ok) { ctx->si_hits += 1; return keep_warm(); }
+            }
             ctx->si_fallbacks += 1;
         }
         if (op.M) { CTM_TRY(svd_full_c(ctx, op.M, op.Mi, n, k, S, Ut, Vt)); return keep_warm(); }

@@ -9,7 +9,8 @@ from helpers import dev, relerr
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("cplx,chi,nsweeps", [(False, 32, 3), (True, 32, 3), (False, 64, 2)], ids=["f64", "c128", "f64-krylov"])
+@pytest.mark.parametrize("cplx,chi,nsweeps", [(False, 32, 3), (True, 32, 3), (False, 64, 2), (True, 64, 1)],
+                         ids=["f64", "c128", "f64-krylov", "c128-krylov"])
 def test_sweeps_match_oracle_on_iterative_path(eng, cplx, chi, nsweeps):
     import config as cfg
     from ipeps.ipeps import IPEPS

@@ -212,18 +212,20 @@ def test_projector_method_4x2(eng, name, chi):
             cfg.ctm_args.projector_method = '4X4'
 
 
-def test_slowly_decaying_tail_uses_block_krylov(eng):
+@pytest.mark.parametrize("cplx", [False, True], ids=["f64", "c128"])
+def test_slowly_decaying_tail_uses_block_krylov(eng, cplx):
     """A spectrum with a fast head and a long, slowly decaying tail (what entangled states give): the subspace iteration
     hands over to the block Golub-Kahan-Lanczos solver; same triplets as LAPACK."""
     rng = np.random.default_rng(31)
     n, chi = 1536, 64
-    Q1, _ = np.linalg.qr(rng.standard_normal((n, n))); Q2, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    rnd = (lambda: rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))) if cplx else (lambda: rng.standard_normal((n, n)))
+    Q1, _ = np.linalg.qr(rnd()); Q2, _ = np.linalg.qr(rnd())
     i = np.arange(n)
     sv = np.sort(np.where(i < 30, 0.6 ** i, 1e-6 / (1.0 + 0.02 * (i - 30))))[::-1]
-    M = (Q1 * sv) @ Q2.T
+    M = (Q1 * sv) @ Q2.conj().T
     h0 = eng.stat("lz_hits")
     U, S, V = (t.cpu().numpy() for t in eng.truncated_svd(dev(M), chi, eng.cfg(keep_multiplets=False)))
     assert eng.stat("lz_hits") == h0 + 1
     assert np.abs(S - sv[:chi]).max() < 1e-13
-    assert np.abs(M @ V - U * S).max() < 1e-12 and np.abs(U.T @ M - S[:, None] * V.T).max() < 1e-12
-    assert np.abs(U.T @ U - np.eye(chi)).max() < 1e-12 and np.abs(V.T @ V - np.eye(chi)).max() < 1e-12
+    assert np.abs(M @ V - U * S).max() < 1e-12 and np.abs(U.conj().T @ M - S[:, None] * V.conj().T).max() < 1e-12
+    assert np.abs(U.conj().T @ U - np.eye(chi)).max() < 1e-12 and np.abs(V.conj().T @ V - np.eye(chi)).max() < 1e-12
