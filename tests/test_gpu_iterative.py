@@ -9,7 +9,7 @@ from helpers import dev, relerr
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("cplx,chi,nsweeps", [(False, 32, 3), (True, 32, 3), (False, 64, 2), (True, 64, 1)],
+@pytest.mark.parametrize("cplx,chi,nsweeps", [(False, 32, 3), (True, 32, 2), (False, 64, 1), (True, 64, 1)],
                          ids=["f64", "c128", "f64-krylov", "c128-krylov"])
 def test_sweeps_match_oracle_on_iterative_path(eng, cplx, chi, nsweeps):
     import config as cfg
