@@ -247,6 +247,19 @@ def main():
     k_fl = [eng.stat("k_flops0"), eng.stat("k_flops1"), eng.stat("k_flops2")]
     k_n = [eng.stat("k_calls0"), eng.stat("k_calls1"), eng.stat("k_calls2")]
     eng.set_option("gemm_timing", 0)
+    # reference pass for the kernel-quality figure: ONE more sweep with the units issued serially on one stream (nothing
+    # co-scheduled), outside the timed region -- per-launch rates of the same kernels without sharing the chip
+    serial = None
+    if world == 1 and kind != "c4v" and not args.serial_units:
+        cfg.ctm_args.concurrent_units = False
+        eng.set_option("gemm_timing", 1)
+        step(); fence()
+        s_ms = [eng.stat("k_ms0"), eng.stat("k_ms1"), eng.stat("k_ms2")]
+        s_fl = [eng.stat("k_flops0"), eng.stat("k_flops1"), eng.stat("k_flops2")]
+        s_n = [eng.stat("k_calls0"), eng.stat("k_calls1"), eng.stat("k_calls2")]
+        eng.set_option("gemm_timing", 0)
+        cfg.ctm_args.concurrent_units = True
+        serial = (s_ms, s_fl, s_n)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -284,6 +297,14 @@ def main():
                                           "busy_ms_union": round(u_ms[2], 3),
                                           "mfma_tflops": round(k_fl[2] / max(u_ms[2] * 1e-3, 1e-30) / 1e12, 3) if k_n[2] else 0.0,
                                           "mfma_frac": round(k_fl[2] / max(u_ms[2] * 1e-3, 1e-30) / 1e12 / FP64_MFMA_PEAK_TFLOPS, 4) if k_n[2] else 0.0}
+        if serial is not None:
+            s_ms, s_fl, s_n = serial
+            tf = lambda i: round(s_fl[i] / max(s_ms[i] * 1e-3, 1e-30) / 1e12, 3) if s_n[i] else 0.0
+            roof["serial_pass"] = {"note": "one extra sweep after the timed region, units issued serially on one stream (no co-scheduling)",
+                                   "kernel": names[dom], "achieved": tf(dom), "frac": round(tf(dom) / FP64_MFMA_PEAK_TFLOPS, 4),
+                                   "avg_launch_ms": round(s_ms[dom] / max(s_n[dom], 1), 5), "launches": int(s_n[dom]),
+                                   "other_gemm_tflops": tf(1 - dom), "enlarged_corner_kernel_tflops": tf(2),
+                                   "enlarged_corner_kernel_frac": round(tf(2) / FP64_MFMA_PEAK_TFLOPS, 4)}
         # HBM traffic of the dominant kernel family from the committed PMC pass of this same command (bench.py cannot attach
         # counters to itself); null when the profile is for another workload
         try:
