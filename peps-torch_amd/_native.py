@@ -150,11 +150,21 @@ class Engine:
         out = [_chk_t(t, "tensor", dt) for t in tensors]
         return out[0] if len(out) == 1 else out
 
+    def close(self):
+        """Destroy the native contexts of this engine and of its workers (idempotent)."""
+        for w in getattr(self, "workers", []):
+            w.close()
+        self.workers = []
+        for h in getattr(self, "_handles", {}).values():
+            try:
+                self.lib.ctm_destroy(h)
+            except Exception:
+                pass
+        self._handles = {}
+
     def __del__(self):
         try:
-            for h in getattr(self, "_handles", {}).values():
-                self.lib.ctm_destroy(h)
-            self._handles = {}
+            self.close()
         except Exception:
             pass
 
@@ -451,6 +461,25 @@ class Engine:
 
 
 _engines = {}
+
+
+def _shutdown():
+    """Release every native context while the HIP runtime is still alive (interpreter exit order is otherwise arbitrary)."""
+    try:
+        import units
+        units.shutdown()
+    except Exception:
+        pass
+    for e in list(_engines.values()):
+        try:
+            e.close()
+        except Exception:
+            pass
+    _engines.clear()
+
+
+import atexit
+atexit.register(_shutdown)
 
 
 def engine(device=None):

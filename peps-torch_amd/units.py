@@ -74,3 +74,11 @@ def pool_for(engine, nunits, n, is_complex):
         if key not in _pools:
             _pools[key] = UnitPool(engine, nw)
         return _pools[key]
+
+
+def shutdown():
+    """Stop the worker threads (their engines are owned and closed by the main engine)."""
+    with _lock:
+        for pool in _pools.values():
+            pool.pool.shutdown(wait=True)
+        _pools.clear()
