@@ -65,9 +65,21 @@ class J1J2():
         RDMs are independent: with torch.distributed each rank evaluates its sites and the partial sums
         are all-reduced."""
         coords = list(state.sites.keys())
+        mine = parallel.my_units(coords)
+        # the plaquette RDMs of my sites are independent: overlap them on streams when the open halves are small enough
+        pool = None
+        if len(mine) > 1 and getattr(cfg.ctm_args, "concurrent_units", True):
+            import units
+            from backend import get_engine
+            a = state.site(mine[0])
+            n = env.chi * a.shape[1] ** 2
+            # rdm2x2 workspace: n^2 (p^4 + 2 p^2 + 4) elements, times 3 for the arena's slab-growth overshoot
+            est = 3.0 * n * n * (a.shape[0] ** 4 + 2 * a.shape[0] ** 2 + 4) * a.element_size()
+            pool = units.pool_for(get_engine(), len(mine), n, a.is_complex(), est_bytes=est)
+        rdms = pool.map(lambda c: rdm.rdm2x2(c, state, env), mine) if pool is not None else [rdm.rdm2x2(c, state, env) for c in mine]
         e = 0.
-        for coord in parallel.my_units(coords):
-            r = rdm.rdm2x2(coord, state, env).cpu()
+        for coord, r in zip(mine, rdms):
+            r = r.cpu()
             e += float(_cast_to_real(torch.einsum('ijklabcd,ijklabcd', r, self.get_hp(coord).to(r.dtype))))
         e = parallel.allreduce_sum_scalar(e, state.device)
         return torch.as_tensor(e / len(coords), dtype=torch.float64)

@@ -59,13 +59,14 @@ _pools = {}
 _lock = threading.Lock()
 
 
-def pool_for(engine, nunits, n, is_complex):
+def pool_for(engine, nunits, n, is_complex, est_bytes=None):
     """UnitPool sized for `nunits` concurrent units of fused dimension n, or None when concurrency is off / pointless
-    (stand-in engines, a single unit, or not enough HBM for one workspace arena per unit)."""
+    (stand-in engines, a single unit, or not enough HBM for one workspace arena per unit).  est_bytes overrides the
+    per-unit workspace estimate of a sweep unit."""
     if nunits < 2 or not hasattr(engine, "spawn_worker"):
         return None
     total = torch.cuda.get_device_properties(engine.device).total_memory
-    est = 14.0 * n * n * 8 * (2 if is_complex else 1)            # peak workspace of one unit (corners, products, work)
+    est = est_bytes if est_bytes is not None else 14.0 * n * n * 8 * (2 if is_complex else 1)   # corners, products, work
     nw = int(min(nunits, max(1, (0.5 * total) // max(est, 1.0))))
     if nw < 2:
         return None
