@@ -46,8 +46,8 @@ def synth_sites(kind, D, seed=1, dtype="f64"):
                 sites[(x, y)] = A / np.abs(A).max()
         return sites
     if kind == "c4v":
-        from oracle.j1j2_oracle import make_c4v_symm_A1
-        A = make_c4v_symm_A1(rng.random((2, D, D, D, D)))
+        from groups.pg import make_c4v_symm                      # the host layer's own symmetriser (reference groups/pg.py:27-63)
+        A = make_c4v_symm(torch.from_numpy(rng.random((2, D, D, D, D)))).numpy()
         return {(0, 0): A / np.abs(A).max()}
     sites = {}
     for y in range(2):
