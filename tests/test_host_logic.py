@@ -122,3 +122,41 @@ def test_error_conventions(cpu_cfg):
     cfg.ctm_args.ctm_env_init_type = old
     e2 = env.extend(6)
     assert e2.C[((0, 0), (-1, -1))].shape == (6, 6) and e2.T[((0, 0), (0, 1))].shape == (4, 6, 6)
+
+
+@pytest.mark.parametrize("name", ["generic_D2_chi8_f64", "generic_D2_chi8_c128"])
+def test_move_variants_on_host_layer(cpu_cfg, name):
+    """projector_method '4X2', ctm_absorb_normalization '2', the ctm_force_dl flag and partially open rdm2x2 through the
+    host layer (engine double) vs the oracle; invalid settings raise the reference's exception types."""
+    from ipeps.ipeps import IPEPS
+    from ctm.generic.env import ENV, init_env
+    from ctm.generic import ctmrg, rdm
+    from oracle import ctm_oracle as O
+    cfg = cpu_cfg
+    g = golden(name)
+    sites = sites_from(g)
+    for method, norm in (("4X2", "inf"), ("4X4", "2")):
+        st = IPEPS({k: torch.from_numpy(v.copy()) for k, v in sites.items()})
+        env = ENV(8, st); init_env(st, env)
+        ost = O.State(sites); oe = O.init_env_ctmrg(ost, 8)
+        cfg.ctm_args.projector_method, cfg.ctm_args.ctm_absorb_normalization, cfg.ctm_args.ctm_force_dl = method, norm, True
+        try:
+            for d in cfg.ctm_args.ctm_move_sequence:
+                ctmrg.ctm_MOVE(d, st, env)
+                O.ctm_move(d, ost, oe, norm_type=norm, projector_method=method)
+        finally:
+            cfg.ctm_args.projector_method, cfg.ctm_args.ctm_absorb_normalization, cfg.ctm_args.ctm_force_dl = "4X4", "inf", False
+        for k in oe.C: assert np.abs(np.abs(env.C[k].numpy()) - np.abs(oe.C[k])).max() < 1e-9, (method, norm, k)
+        for k in oe.T: assert np.abs(np.abs(env.T[k].numpy()) - np.abs(oe.T[k])).max() < 1e-9, (method, norm, k)
+    full = rdm.rdm2x2((0, 0), st, env).numpy()
+    part = rdm.rdm2x2((0, 0), st, env, open_sites=[0, 3]).numpy()
+    ref = np.einsum("aijdeijh->adeh", full)
+    assert np.abs(part - ref / np.trace(ref.reshape(4, 4))).max() < 1e-13
+    with pytest.raises(ValueError):
+        rdm.rdm2x2((0, 0), st, env, open_sites=[0, 5])
+    cfg.ctm_args.projector_method = "4X3"
+    try:
+        with pytest.raises(ValueError):
+            ctmrg.ctm_MOVE((0, -1), st, env)
+    finally:
+        cfg.ctm_args.projector_method = "4X4"
