@@ -76,7 +76,8 @@ struct ctm_ctx {
     bool use_layer2 = true;
     bool gemm_fast = true;
     int splitk_max_tiles = 256, splitk_target_wgs = 1024;   // split-K of skinny GEMMs: when few output tiles, how many workgroups to aim for
-    bool eig64_pingpong = true;         // one-barrier-per-round LDS eigensolver for 64 x 64 pair Grams
+    bool eig64_pingpong = true;
+    int eig64_bpt = 2;                  // 2x2 blocks per thread of the 64 x 64 LDS eigensolver (1, 2, 4 -> 1024, 512, 256 threads)         // one-barrier-per-round LDS eigensolver for 64 x 64 pair Grams
     bool layer2_cplx = true;            // fused kernel for complex128 operands too
     int layer2_dbg = 0;
     int layer2_reg = 1;                 // register-resident fused kernel for KT = KAp/16 >= this value (-1: never)

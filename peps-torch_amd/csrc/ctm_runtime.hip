@@ -117,6 +117,7 @@ int ctm_set_option(ctm_ctx* ctx, const char* key, double value) {
     else if (k == "lz_switch_steps") ctx->lz_switch_steps = value;
     else if (k == "layer2_cplx") ctx->layer2_cplx = value != 0.0;
     else if (k == "layer2_reg") ctx->layer2_reg = (int)value;
+    else if (k == "eig64_bpt") ctx->eig64_bpt = (int)value;
     else if (k == "eig64_pingpong") ctx->eig64_pingpong = value != 0.0;
     else if (k == "gemm_timing") {
         gemm_timing_drain(ctx);

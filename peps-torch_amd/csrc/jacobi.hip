@@ -259,8 +259,9 @@ __device__ __forceinline__ void jacobi_cs(double a, double b, double g, double t
     }
 }
 
-__global__ __launch_bounds__(1024) void small_eig64_kernel(SmallEigParams p) {
-    constexpr int M = 64, H = 32, NTH = 1024;
+template <int BPT>     // 2x2 blocks per thread: 1024 / BPT threads per workgroup
+__global__ __launch_bounds__(1024 / BPT) void small_eig64_kernel(SmallEigParams p) {
+    constexpr int M = 64, H = 32, NTH = 1024 / BPT, NW = NTH / 64, KS = H / BPT, EPT = (M * M) / NTH;
     __shared__ double Wb[2][M][M + 1];
     __shared__ double Jm[M][M + 1];
     __shared__ double red[16];
@@ -271,20 +272,22 @@ __global__ __launch_bounds__(1024) void small_eig64_kernel(SmallEigParams p) {
     const double* G = p.G + (size_t)blockIdx.x * M * M;
     double* Jout = p.J + (size_t)blockIdx.x * M * M;
     {
-        double acc[4] = {0.0, 0.0, 0.0, 0.0};
+        double acc[EPT];
+#pragma unroll
+        for (int u = 0; u < EPT; ++u) acc[u] = 0.0;
         for (int s = 0; s < p.nsplit; ++s) {
             const double* Gs = G + (size_t)s * p.split_stride;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) acc[u] += Gs[tid + u * NTH];
+            for (int u = 0; u < EPT; ++u) acc[u] += Gs[tid + u * NTH];
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { const int q = tid + u * NTH, r = q >> 6, c = q & 63; Wb[0][r][c] = acc[u]; Jm[r][c] = (r == c) ? 1.0 : 0.0; }
+        for (int u = 0; u < EPT; ++u) { const int q = tid + u * NTH, r = q >> 6, c = q & 63; Wb[0][r][c] = acc[u]; Jm[r][c] = (r == c) ? 1.0 : 0.0; }
     }
     __syncthreads();
     {
         double srel = 0.0, sabs = 0.0;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < EPT; ++u) {
             const int q = tid + u * NTH, r = q >> 6, c = q & 63;
             if (r < c) {
                 const double g = fabs(Wb[0][r][c]), a = Wb[0][r][r], b = Wb[0][c][c];
@@ -300,7 +303,7 @@ __global__ __launch_bounds__(1024) void small_eig64_kernel(SmallEigParams p) {
         __syncthreads();
         if (tid == 0) {
             double v = 0.0;
-            for (int w = 0; w < 16; ++w) v = fmax(v, red[w]);
+            for (int w = 0; w < NW; ++w) v = fmax(v, red[w]);
             atomicMax(p.stat_rel, (unsigned long long)__double_as_longlong(v));
             red[0] = v;
         }
@@ -311,7 +314,7 @@ __global__ __launch_bounds__(1024) void small_eig64_kernel(SmallEigParams p) {
         __syncthreads();
         if (tid == 0) {
             double v = 0.0;
-            for (int w = 0; w < 16; ++w) v = fmax(v, red[w]);
+            for (int w = 0; w < NW; ++w) v = fmax(v, red[w]);
             atomicMax(p.stat_abs, (unsigned long long)__double_as_longlong(v));
         }
         if (srel <= p.tol) { if (tid == 0) p.flags[blockIdx.x] = 0; return; }
@@ -327,31 +330,41 @@ __global__ __launch_bounds__(1024) void small_eig64_kernel(SmallEigParams p) {
     }
     if (tid == 0) rot_flag = 0;
     __syncthreads();
-    const int k2 = tid & 31, k1 = tid >> 5;
+    const int k2 = tid & 31, kb = tid >> 5;          // column pair; first of the BPT row pairs kb, kb + KS, ...
     int par = 0;
     for (int sweep = 0; sweep < p.max_sweeps; ++sweep) {
         for (int r = 0; r < M - 1; ++r) {
             const double (*S)[M + 1] = Wb[par];
             double (*D)[M + 1] = Wb[par ^ 1];
-            const int p1 = pair_tab[r][k1][0], q1 = pair_tab[r][k1][1], p2 = pair_tab[r][k2][0], q2 = pair_tab[r][k2][1];
+            const int p2 = pair_tab[r][k2][0], q2 = pair_tab[r][k2][1];
             const double a2 = S[p2][p2], d2 = S[q2][q2], g2 = S[p2][q2];
-            const double b00 = S[p1][p2], b01 = S[p1][q2], b10 = S[q1][p2], b11 = S[q1][q2];
-            const double jp0 = Jm[k1][p2], jq0 = Jm[k1][q2], jp1 = Jm[k1 + 32][p2], jq1 = Jm[k1 + 32][q2];
+            int p1[BPT], q1[BPT];
+            double b00[BPT], b01[BPT], b10[BPT], b11[BPT], jp0[BPT], jq0[BPT], jp1[BPT], jq1[BPT];
+#pragma unroll
+            for (int u = 0; u < BPT; ++u) {
+                const int k1 = kb + u * KS;
+                p1[u] = pair_tab[r][k1][0]; q1[u] = pair_tab[r][k1][1];
+                b00[u] = S[p1[u]][p2]; b01[u] = S[p1[u]][q2]; b10[u] = S[q1[u]][p2]; b11[u] = S[q1[u]][q2];
+                jp0[u] = Jm[k1][p2]; jq0[u] = Jm[k1][q2]; jp1[u] = Jm[k1 + 32][p2]; jq1[u] = Jm[k1 + 32][q2];
+            }
             double c2, s2; bool r2;
             jacobi_cs(a2, d2, g2, p.tol, p.tau2, c2, s2, r2);
-            // the rotation of row pair k1 is the one the lane with k2 == k1 of this half-wave just computed
-            const int src = (tid & 32) | k1;
-            const double c1 = __shfl(c2, src, 64), s1 = __shfl(s2, src, 64);
-            const bool r1 = r2 && (k1 == k2);
-            const double t00 = c2 * b00 - s2 * b01, t01 = s2 * b00 + c2 * b01;
-            const double t10 = c2 * b10 - s2 * b11, t11 = s2 * b10 + c2 * b11;
-            D[p1][p2] = c1 * t00 - s1 * t10; D[p1][q2] = c1 * t01 - s1 * t11;
-            D[q1][p2] = s1 * t00 + c1 * t10; D[q1][q2] = s1 * t01 + c1 * t11;
-            if (r2) {
-                Jm[k1][p2] = c2 * jp0 - s2 * jq0; Jm[k1][q2] = s2 * jp0 + c2 * jq0;
-                Jm[k1 + 32][p2] = c2 * jp1 - s2 * jq1; Jm[k1 + 32][q2] = s2 * jp1 + c2 * jq1;
+#pragma unroll
+            for (int u = 0; u < BPT; ++u) {
+                const int k1 = kb + u * KS;
+                // the rotation of row pair k1 is the one the lane with k2 == k1 of this half-wave just computed
+                const int src = (tid & 32) | k1;
+                const double c1 = __shfl(c2, src, 64), s1 = __shfl(s2, src, 64);
+                const double t00 = c2 * b00[u] - s2 * b01[u], t01 = s2 * b00[u] + c2 * b01[u];
+                const double t10 = c2 * b10[u] - s2 * b11[u], t11 = s2 * b10[u] + c2 * b11[u];
+                D[p1[u]][p2] = c1 * t00 - s1 * t10; D[p1[u]][q2] = c1 * t01 - s1 * t11;
+                D[q1[u]][p2] = s1 * t00 + c1 * t10; D[q1[u]][q2] = s1 * t01 + c1 * t11;
+                if (r2) {
+                    Jm[k1][p2] = c2 * jp0[u] - s2 * jq0[u]; Jm[k1][q2] = s2 * jp0[u] + c2 * jq0[u];
+                    Jm[k1 + 32][p2] = c2 * jp1[u] - s2 * jq1[u]; Jm[k1 + 32][q2] = s2 * jp1[u] + c2 * jq1[u];
+                }
+                if (r2 && k1 == k2) rot_flag = 1;
             }
-            if (r1) rot_flag = 1;
             par ^= 1;
             __syncthreads();
         }
@@ -370,7 +383,7 @@ __global__ __launch_bounds__(1024) void small_eig64_kernel(SmallEigParams p) {
     }
     __syncthreads();
 #pragma unroll
-    for (int u = 0; u < 4; ++u) { const int q = tid + u * NTH, r = q >> 6, c = q & 63; Jout[r * M + rank_of[c]] = Jm[r][c]; }
+    for (int u = 0; u < EPT; ++u) { const int q = tid + u * NTH, r = q >> 6, c = q & 63; Jout[r * M + rank_of[c]] = Jm[r][c]; }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -646,7 +659,11 @@ int jacobi_rows(ctm_ctx* ctx, double* X, int R, long long ld, int Cg, int Ctot, 
             sp.G = G; sp.nsplit = T->nsplit; sp.split_stride = (long long)pairs * m * m; sp.J = J; sp.m = m; sp.tol = ctx->jacobi_tol * 0.1; sp.max_sweeps = (pairs == 1) ? 12 : ctx->jacobi_inner_sweeps;
             sp.tau2 = tau2; sp.stat_rel = stat; sp.stat_abs = stat + 1; sp.flags = flags;
             if (cplx) hipLaunchKernelGGL(small_eig_c_kernel, dim3(pairs), dim3(256), 0, ctx->stream, sp);
-            else if (m == 64 && ctx->eig64_pingpong) hipLaunchKernelGGL(small_eig64_kernel, dim3(pairs), dim3(1024), 0, ctx->stream, sp);
+            else if (m == 64 && ctx->eig64_pingpong) {
+                if (ctx->eig64_bpt == 4) hipLaunchKernelGGL(small_eig64_kernel<4>, dim3(pairs), dim3(256), 0, ctx->stream, sp);
+                else if (ctx->eig64_bpt == 2) hipLaunchKernelGGL(small_eig64_kernel<2>, dim3(pairs), dim3(512), 0, ctx->stream, sp);
+                else hipLaunchKernelGGL(small_eig64_kernel<1>, dim3(pairs), dim3(1024), 0, ctx->stream, sp);
+            }
             else hipLaunchKernelGGL(small_eig_kernel, dim3(pairs), dim3(m > 32 ? 1024 : 256), 0, ctx->stream, sp);
             GemmDesc a;
             a.M = m; a.N = Ctot; a.K = m;
