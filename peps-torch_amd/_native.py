@@ -16,6 +16,8 @@ _ERRNAMES = {1: "bad argument", 2: "shape mismatch", 3: "no convergence", 4: "HI
 LU, RU, RD, LD = 0, 1, 2, 3
 UP, LEFT, DOWN, RIGHT = 0, 1, 2, 3
 DIR_INDEX = {(0, -1): UP, (-1, 0): LEFT, (0, 1): DOWN, (1, 0): RIGHT}
+# leg of the anchor site a[s,u,l,d,r] that lies on the cut truncated by a move (UP: l, LEFT: d, DOWN: r, RIGHT: u)
+CUT_LEG = {UP: 2, LEFT: 3, DOWN: 4, RIGHT: 1}
 
 
 class NativeError(RuntimeError):
@@ -330,9 +332,8 @@ class Engine:
         ts, arr, ad = self._pack16(tensors16)
         chi = ts[0].shape[0]
         d = DIR_INDEX[direction] if isinstance(direction, tuple) else direction
-        # all four corners of a half share the fused dimension n = chi * D^2 for uniform D
-        a0 = ts[3].shape
-        n = chi * a0[1] ** 2
+        # the halves are square in the truncated bond n = chi * D_cut^2 (bond dimensions may differ between directions)
+        n = chi * ts[3].shape[CUT_LEG[d]] ** 2
         R, Rt = self.empty(n, n), self.empty(n, n)
         self._ck(self.lib.ctm_halves(self.h, d, arr, chi, ad, _ptr(R), _ptr(Rt)), "halves")
         return R, Rt
@@ -359,7 +360,7 @@ class Engine:
         ts, arr, ad = self._pack16(tensors16)
         d = DIR_INDEX[direction] if isinstance(direction, tuple) else direction
         chi_env = ts[0].shape[0]
-        n = chi_env * ts[3].shape[1] ** 2
+        n = chi_env * ts[3].shape[CUT_LEG[d]] ** 2
         kc = min(chi, n)
         P, Pt, S = self.empty(n, kc), self.empty(n, kc), self.empty_real(kc)
         cfg = cfg or self.default_cfg

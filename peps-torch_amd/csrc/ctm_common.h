@@ -187,6 +187,7 @@ struct MatOp {
     const double* c[4] = {nullptr, nullptr, nullptr, nullptr};
     const double* ci[4] = {nullptr, nullptr, nullptr, nullptr};      // imaginary planes of the corners (complex128)
     bool t[4] = {false, false, false, false};
+    int mid[2] = {0, 0};      // inner dimensions of R = opA(cA) opB(cB) (n x mid0 x n) and Rt (n x mid1 x n); 0 means n
     // optional warm start (in/out): k x n row basis (planar for complex128) of the right singular vectors of a nearby
     // operator; rows the caller does not have are zero.  Overwritten with this decomposition's right row factor.
     double* warm = nullptr;

@@ -209,17 +209,18 @@ void proj_scale(const TruncOut& to, int kc, double reltol, std::vector<double>* 
 // out (n x kc) = opA(cA) * ( opB(cB) * rows^T[^H] ) * diag(scale)   with rows = k x n row factors (kc leading ones used)
 // Only the first `ncol` columns carry a non-zero scale (S/S[0] > reltol is a prefix of the descending spectrum): the others
 // are exact zeros of the result (as in the reference, ctm_projectors.py:266-283) and are not computed.
-int corner_chain_times_rowsT(ctm_ctx* ctx, int n, int k, int kc, int ncol, const DT& cA, bool tA, const DT& cB, bool tB, const double* rows,
+int corner_chain_times_rowsT(ctm_ctx* ctx, int n, int mid, int k, int kc, int ncol, const DT& cA, bool tA, const DT& cB, bool tB, const double* rows,
                              bool conj_rows, const double* d_scale, const DT& out) {
+    // opA(cA) is n x mid, opB(cB) is mid x n (stored transposed when the flag is set)
     ArenaScope scope(ctx);
     CTM_TRY(fill_f64(ctx, out.p, (size_t)n * kc * (out.q ? 2 : 1), 0.0));      // planes are adjacent
     if (out.q && out.q != out.p + (size_t)n * kc) CTM_TRY(fill_f64(ctx, out.q, (size_t)n * kc, 0.0));
     if (ncol <= 0) return CTM_OK;
     DT t1;
-    CTM_TRY(alloc_dt(ctx, {n, ncol}, &t1));
+    CTM_TRY(alloc_dt(ctx, {mid, ncol}, &t1));
     XM r; r.re = rows; r.im = ctx->cplx ? rows + (size_t)k * n : nullptr; r.ld = n; r.t = true; r.c = conj_rows;
-    CTM_TRY(xgemm(ctx, n, ncol, n, xm(cB, n, tB), r, t1.p, t1.q, ncol));
-    return xgemm(ctx, n, ncol, n, xm(cA, n, tA), xm(t1, ncol, false), out.p, out.q, kc, d_scale);
+    CTM_TRY(xgemm(ctx, mid, ncol, n, xm(cB, tB ? mid : n, tB), r, t1.p, t1.q, ncol));
+    return xgemm(ctx, n, ncol, mid, xm(cA, tA ? n : mid, tA), xm(t1, ncol, false), out.p, out.q, kc, d_scale);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -499,8 +500,15 @@ int ctm_projectors_4x4_ws(ctm_ctx* ctx, int dir, const double* const* t, int chi
         cid[2 * h] = hs.cA; cid[2 * h + 1] = hs.cB; tr[2 * h] = hs.tA != 0; tr[2 * h + 1] = hs.tB != 0;
     }
     for (int i = 0; i < 4; ++i) corner_dims(cid[i], chi, adims4x5 + 5 * i, &d0[i], &d1[i]);
-    const long long n = d0[0];
-    for (int i = 0; i < 4; ++i) if (d0[i] != n || d1[i] != n) { ctx->set_error("projectors_4x4: non-uniform bond dimensions are not supported on the fused path"); return CTM_ERR_UNSUPPORTED; }
+    // R = opA(c0) opB(c1): (n x mid0)(mid0 x n) ; Rt = opC(c2) opD(c3): (n x mid1)(mid1 x n).  The truncated bond n must be
+    // the same on both halves (bond dimensions may differ between the lattice directions, not along one cut).
+    auto rows_of = [&](int i) { return tr[i] ? d1[i] : d0[i]; };
+    auto cols_of = [&](int i) { return tr[i] ? d0[i] : d1[i]; };
+    const long long n = rows_of(0), mid0 = cols_of(0), mid1 = cols_of(2);
+    if (rows_of(1) != mid0 || cols_of(1) != n || rows_of(2) != n || rows_of(3) != mid1 || cols_of(3) != n) {
+        ctx->set_error("projectors_4x4: the four enlarged corners do not chain to square halves (bond dimensions differ along one cut)");
+        return CTM_ERR_UNSUPPORTED;
+    }
     const int k = (chi < n) ? chi + 1 : (int)n, kc = std::min(chi, (int)n), cz = ctx->cplx ? 2 : 1;
     DT tP, tPt;
     CTM_TRY(io.out(P, (size_t)n * kc, &tP));
@@ -522,6 +530,7 @@ int ctm_projectors_4x4_ws(ctm_ctx* ctx, int dir, const double* const* t, int chi
     CTM_TRY(arena_alloc(ctx, sizeof(double) * kc, (void**)&dScale));
     MatOp op; op.n = (int)n;
     for (int i = 0; i < 4; ++i) { op.c[i] = c[i].p; op.ci[i] = c[i].q; op.t[i] = tr[i]; }
+    op.mid[0] = (int)mid0; op.mid[1] = (int)mid1;
     op.warm = basis;
     TruncOut to;
     { PhaseTimer pt(ctx, CTM_T_SVD); CTM_TRY(svd_rows_op(ctx, op, chi, cfg, Ut, Vt, dS, &to)); }
@@ -529,8 +538,8 @@ int ctm_projectors_4x4_ws(ctm_ctx* ctx, int dir, const double* const* t, int chi
     int ncol;
     CTM_TRY(upload_scale(ctx, to, kc, cfg.svd_reltol, dScale, S_out, &ncol));
     // P = R conj(U) S^-1/2 = opA(cA) opB(cB) Ut^T ... ; Pt = Rt V S^-1/2 = opC(cC) opD(cD) Vt^H ...
-    CTM_TRY(corner_chain_times_rowsT(ctx, (int)n, k, kc, ncol, c[0], tr[0], c[1], tr[1], Ut, false, dScale, tP));
-    CTM_TRY(corner_chain_times_rowsT(ctx, (int)n, k, kc, ncol, c[2], tr[2], c[3], tr[3], Vt, true, dScale, tPt));
+    CTM_TRY(corner_chain_times_rowsT(ctx, (int)n, (int)mid0, k, kc, ncol, c[0], tr[0], c[1], tr[1], Ut, false, dScale, tP));
+    CTM_TRY(corner_chain_times_rowsT(ctx, (int)n, (int)mid1, k, kc, ncol, c[2], tr[2], c[3], tr[3], Vt, true, dScale, tPt));
     CTM_TRY(io.finish());
     CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     return CTM_OK;

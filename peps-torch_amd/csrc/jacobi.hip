@@ -829,9 +829,10 @@ int svd_full(ctm_ctx* ctx, const double* M, int n, int k, double* S, double* Ut,
 }
 
 // Y (p x n, ldy) = X (p x n, ldx) * op(Z) for a dense n x n matrix Z (row-major): op = 'N' or 'T'
-int rows_times(ctm_ctx* ctx, const double* X, long long ldx, int p, int n, const double* Z, bool transZ, double* Y, long long ldy) {
-    GemmDesc g; g.M = p; g.N = n; g.K = n; g.A = X; g.sam = ldx; g.sak = 1; g.B = Z;
-    if (transZ) { g.sbk = 1; g.sbn = n; } else { g.sbk = n; g.sbn = 1; }
+int rows_times(ctm_ctx* ctx, const double* X, long long ldx, int p, int kin, int nout, const double* Z, bool transZ, double* Y, long long ldy) {
+    // Y (p x nout) = X (p x kin) op(Z); Z is stored kin x nout (transZ == false) or nout x kin (transZ == true)
+    GemmDesc g; g.M = p; g.N = nout; g.K = kin; g.A = X; g.sam = ldx; g.sak = 1; g.B = Z;
+    if (transZ) { g.sbk = 1; g.sbn = kin; } else { g.sbk = nout; g.sbn = 1; }
     g.C = Y; g.ldc = ldy;
     return gemm_f64(ctx, g);
 }
@@ -839,23 +840,24 @@ int rows_times(ctm_ctx* ctx, const double* X, long long ldx, int p, int n, const
 // C = B * M (transpose == false) or B * M^T (transpose == true) for the operator M of `op`
 int matop_apply(ctm_ctx* ctx, const MatOp& op, bool transpose, const double* B, long long ldb, int p, double* C, long long ldc) {
     const int n = op.n;
-    if (op.M) return rows_times(ctx, B, ldb, p, n, op.M, transpose, C, ldc);
-    // implicit M = R^T Rt,  R = opA(cA) opB(cB),  Rt = opC(cC) opD(cD)
+    if (op.M) return rows_times(ctx, B, ldb, p, n, n, op.M, transpose, C, ldc);
+    // implicit M = R^T Rt,  R = opA(cA) opB(cB) (n x m0 x n),  Rt = opC(cC) opD(cD) (n x m1 x n)
+    const int m0 = op.mid[0] ? op.mid[0] : n, m1 = op.mid[1] ? op.mid[1] : n, mw = std::max(n, std::max(m0, m1));
     ArenaScope scope(ctx);
     double *t1, *t2;
-    CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)p * n, (void**)&t1));
-    CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)p * n, (void**)&t2));
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)p * mw, (void**)&t1));
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)p * mw, (void**)&t2));
     if (!transpose) {   // B R^T Rt = ((B opB(cB)^T) opA(cA)^T) opC(cC) opD(cD)
-        CTM_TRY(rows_times(ctx, B, ldb, p, n, op.c[1], !op.t[1], t1, n));
-        CTM_TRY(rows_times(ctx, t1, n, p, n, op.c[0], !op.t[0], t2, n));
-        CTM_TRY(rows_times(ctx, t2, n, p, n, op.c[2], op.t[2], t1, n));
-        return rows_times(ctx, t1, n, p, n, op.c[3], op.t[3], C, ldc);
+        CTM_TRY(rows_times(ctx, B, ldb, p, n, m0, op.c[1], !op.t[1], t1, m0));
+        CTM_TRY(rows_times(ctx, t1, m0, p, m0, n, op.c[0], !op.t[0], t2, n));
+        CTM_TRY(rows_times(ctx, t2, n, p, n, m1, op.c[2], op.t[2], t1, m1));
+        return rows_times(ctx, t1, m1, p, m1, n, op.c[3], op.t[3], C, ldc);
     }
     // B Rt^T R = ((B opD(cD)^T) opC(cC)^T) opA(cA) opB(cB)
-    CTM_TRY(rows_times(ctx, B, ldb, p, n, op.c[3], !op.t[3], t1, n));
-    CTM_TRY(rows_times(ctx, t1, n, p, n, op.c[2], !op.t[2], t2, n));
-    CTM_TRY(rows_times(ctx, t2, n, p, n, op.c[0], op.t[0], t1, n));
-    return rows_times(ctx, t1, n, p, n, op.c[1], op.t[1], C, ldc);
+    CTM_TRY(rows_times(ctx, B, ldb, p, n, m1, op.c[3], !op.t[3], t1, m1));
+    CTM_TRY(rows_times(ctx, t1, m1, p, m1, n, op.c[2], !op.t[2], t2, n));
+    CTM_TRY(rows_times(ctx, t2, n, p, n, m0, op.c[0], op.t[0], t1, m0));
+    return rows_times(ctx, t1, m0, p, m0, n, op.c[1], op.t[1], C, ldc);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1167,39 +1169,41 @@ int svd_full_c(ctm_ctx* ctx, const double* Mr, const double* Mi, int n, int k, d
 
 // Y (R real panel rows x n) = X * op(Z),  Z planar n x n complex, op in {N, T, C = conj, H = conj transpose};
 // scratch: R x n doubles for i*X.   (x + iy)(zr + i zi):  Y = X op(Zr) +- (iX) op(Zi)
-int rows_times_c(ctm_ctx* ctx, const double* X, long long ldx, int R, int n, const double* Zr, const double* Zi, bool trans, bool conj,
+int rows_times_c(ctm_ctx* ctx, const double* X, long long ldx, int R, int kin, int nout, const double* Zr, const double* Zi, bool trans, bool conj,
                  double* Y, long long ldy, double* scratch) {
-    const size_t tot = (size_t)R * n;
+    // Z stored kin x nout (trans == false) or nout x kin (trans == true)
+    const size_t tot = (size_t)R * kin;
     hipLaunchKernelGGL(panel_times_i_kernel, dim3((int)std::min<size_t>((tot + 255) / 256, 2048)), dim3(256), 0, ctx->stream, X, ldx, scratch,
-                       (long long)n, R, n);
-    GemmDesc g; g.M = R; g.N = n; g.K = n; g.A = X; g.sam = ldx; g.sak = 1; g.B = Zr;
-    if (trans) { g.sbk = 1; g.sbn = n; } else { g.sbk = n; g.sbn = 1; }
+                       (long long)kin, R, kin);
+    GemmDesc g; g.M = R; g.N = nout; g.K = kin; g.A = X; g.sam = ldx; g.sak = 1; g.B = Zr;
+    if (trans) { g.sbk = 1; g.sbn = kin; } else { g.sbk = nout; g.sbn = 1; }
     g.C = Y; g.ldc = ldy;
     CTM_TRY(gemm_f64(ctx, g));
-    g.A = scratch; g.sam = n; g.B = Zi; g.alpha = conj ? -1.0 : 1.0; g.beta = 1.0;
+    g.A = scratch; g.sam = kin; g.B = Zi; g.alpha = conj ? -1.0 : 1.0; g.beta = 1.0;
     return gemm_f64(ctx, g);
 }
 
 // C = B * M (adjoint == false) or B * M^H (adjoint == true), B and C in panel layout
 int matop_apply_c(ctm_ctx* ctx, const MatOp& op, bool adjoint, const double* B, long long ldb, int R, double* C, long long ldc) {
     const int n = op.n;
+    const int m0 = op.mid[0] ? op.mid[0] : n, m1 = op.mid[1] ? op.mid[1] : n, mw = std::max(n, std::max(m0, m1));
     ArenaScope scope(ctx);
     double *t1, *t2, *sc;
-    CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)R * n, (void**)&sc));
-    if (op.M) return rows_times_c(ctx, B, ldb, R, n, op.M, op.Mi, adjoint, adjoint, C, ldc, sc);
-    CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)R * n, (void**)&t1));
-    CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)R * n, (void**)&t2));
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)R * mw, (void**)&sc));
+    if (op.M) return rows_times_c(ctx, B, ldb, R, n, n, op.M, op.Mi, adjoint, adjoint, C, ldc, sc);
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)R * mw, (void**)&t1));
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)R * mw, (void**)&t2));
     if (!adjoint) {   // B R^T Rt = ((B opB(cB)^T) opA(cA)^T) opC(cC) opD(cD)       (plain transposes, ctm_projectors.py:263)
-        CTM_TRY(rows_times_c(ctx, B, ldb, R, n, op.c[1], op.ci[1], !op.t[1], false, t1, n, sc));
-        CTM_TRY(rows_times_c(ctx, t1, n, R, n, op.c[0], op.ci[0], !op.t[0], false, t2, n, sc));
-        CTM_TRY(rows_times_c(ctx, t2, n, R, n, op.c[2], op.ci[2], op.t[2], false, t1, n, sc));
-        return rows_times_c(ctx, t1, n, R, n, op.c[3], op.ci[3], op.t[3], false, C, ldc, sc);
+        CTM_TRY(rows_times_c(ctx, B, ldb, R, n, m0, op.c[1], op.ci[1], !op.t[1], false, t1, m0, sc));
+        CTM_TRY(rows_times_c(ctx, t1, m0, R, m0, n, op.c[0], op.ci[0], !op.t[0], false, t2, n, sc));
+        CTM_TRY(rows_times_c(ctx, t2, n, R, n, m1, op.c[2], op.ci[2], op.t[2], false, t1, m1, sc));
+        return rows_times_c(ctx, t1, m1, R, m1, n, op.c[3], op.ci[3], op.t[3], false, C, ldc, sc);
     }
     // B M^H = B opD(cD)^H opC(cC)^H conj(opA(cA)) conj(opB(cB))
-    CTM_TRY(rows_times_c(ctx, B, ldb, R, n, op.c[3], op.ci[3], !op.t[3], true, t1, n, sc));
-    CTM_TRY(rows_times_c(ctx, t1, n, R, n, op.c[2], op.ci[2], !op.t[2], true, t2, n, sc));
-    CTM_TRY(rows_times_c(ctx, t2, n, R, n, op.c[0], op.ci[0], op.t[0], true, t1, n, sc));
-    return rows_times_c(ctx, t1, n, R, n, op.c[1], op.ci[1], op.t[1], true, C, ldc, sc);
+    CTM_TRY(rows_times_c(ctx, B, ldb, R, n, m1, op.c[3], op.ci[3], !op.t[3], true, t1, m1, sc));
+    CTM_TRY(rows_times_c(ctx, t1, m1, R, m1, n, op.c[2], op.ci[2], !op.t[2], true, t2, n, sc));
+    CTM_TRY(rows_times_c(ctx, t2, n, R, n, m0, op.c[0], op.ci[0], op.t[0], true, t1, m0, sc));
+    return rows_times_c(ctx, t1, m0, R, m0, n, op.c[1], op.ci[1], op.t[1], true, C, ldc, sc);
 }
 
 // leading-k triplets of a complex operator: the iteration of svd_iter() on panel rows
@@ -1694,24 +1698,27 @@ int matop_apply_planar(ctm_ctx* ctx, const MatOp& op, bool adjoint, const double
     const int n = op.n;
     XM b{Bre, Bim, n, false, false};
     if (op.M) { XM m{op.M, op.Mi, n, adjoint, adjoint}; return xgemm(ctx, rows, n, n, b, m, Cre, Cim, n); }
+    const int m0 = op.mid[0] ? op.mid[0] : n, m1 = op.mid[1] ? op.mid[1] : n, mw = std::max(n, std::max(m0, m1));
     ArenaScope scope(ctx);
     double *t1, *t2;
-    const size_t rn = (size_t)rows * n;
+    const size_t rn = (size_t)rows * mw;
     CTM_TRY(arena_alloc(ctx, sizeof(double) * 2 * rn, (void**)&t1));
     CTM_TRY(arena_alloc(ctx, sizeof(double) * 2 * rn, (void**)&t2));
-    auto f = [&](int i, bool t, bool c) { XM x{op.c[i], op.ci[i], n, t, c}; return x; };
-    XM x1{t1, t1 + rn, n, false, false}, x2{t2, t2 + rn, n, false, false};
+    // factor i as the (kin x nout) right operand: stored kin x nout when !t (ld = nout), nout x kin when t (ld = kin)
+    auto f = [&](int i, bool t, bool c, int kin, int nout) { XM x{op.c[i], op.ci[i], t ? kin : nout, t, c}; return x; };
+    auto x1 = [&](int ld) { XM x{t1, t1 + rn, ld, false, false}; return x; };
+    auto x2 = [&](int ld) { XM x{t2, t2 + rn, ld, false, false}; return x; };
     if (!adjoint) {   // B opB(cB)^T opA(cA)^T opC(cC) opD(cD)
-        CTM_TRY(xgemm(ctx, rows, n, n, b, f(1, !op.t[1], false), t1, t1 + rn, n));
-        CTM_TRY(xgemm(ctx, rows, n, n, x1, f(0, !op.t[0], false), t2, t2 + rn, n));
-        CTM_TRY(xgemm(ctx, rows, n, n, x2, f(2, op.t[2], false), t1, t1 + rn, n));
-        return xgemm(ctx, rows, n, n, x1, f(3, op.t[3], false), Cre, Cim, n);
+        CTM_TRY(xgemm(ctx, rows, m0, n, b, f(1, !op.t[1], false, n, m0), t1, t1 + rn, m0));
+        CTM_TRY(xgemm(ctx, rows, n, m0, x1(m0), f(0, !op.t[0], false, m0, n), t2, t2 + rn, n));
+        CTM_TRY(xgemm(ctx, rows, m1, n, x2(n), f(2, op.t[2], false, n, m1), t1, t1 + rn, m1));
+        return xgemm(ctx, rows, n, m1, x1(m1), f(3, op.t[3], false, m1, n), Cre, Cim, n);
     }
     // B opD(cD)^H opC(cC)^H conj(opA(cA)) conj(opB(cB))
-    CTM_TRY(xgemm(ctx, rows, n, n, b, f(3, !op.t[3], true), t1, t1 + rn, n));
-    CTM_TRY(xgemm(ctx, rows, n, n, x1, f(2, !op.t[2], true), t2, t2 + rn, n));
-    CTM_TRY(xgemm(ctx, rows, n, n, x2, f(0, op.t[0], true), t1, t1 + rn, n));
-    return xgemm(ctx, rows, n, n, x1, f(1, op.t[1], true), Cre, Cim, n);
+    CTM_TRY(xgemm(ctx, rows, m1, n, b, f(3, !op.t[3], true, n, m1), t1, t1 + rn, m1));
+    CTM_TRY(xgemm(ctx, rows, n, m1, x1(m1), f(2, !op.t[2], true, m1, n), t2, t2 + rn, n));
+    CTM_TRY(xgemm(ctx, rows, m0, n, x2(n), f(0, op.t[0], true, n, m0), t1, t1 + rn, m0));
+    return xgemm(ctx, rows, n, m0, x1(m0), f(1, op.t[1], true, m0, n), Cre, Cim, n);
 }
 
 int svd_lanczos_c(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* Ut, double* Vt, bool* converged) {
@@ -1869,10 +1876,11 @@ int jacobi_svd_top_op(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* U
         CTM_TRY(arena_alloc(ctx, sizeof(double) * 2 * nn, (void**)&R));
         CTM_TRY(arena_alloc(ctx, sizeof(double) * 2 * nn, (void**)&Rt));
         CTM_TRY(arena_alloc(ctx, sizeof(double) * 2 * nn, (void**)&M));
-        XM a{op.c[0], op.ci[0], n, op.t[0], false}, b{op.c[1], op.ci[1], n, op.t[1], false};
-        XM c{op.c[2], op.ci[2], n, op.t[2], false}, d{op.c[3], op.ci[3], n, op.t[3], false};
-        CTM_TRY(xgemm(ctx, n, n, n, a, b, R, R + nn, n));
-        CTM_TRY(xgemm(ctx, n, n, n, c, d, Rt, Rt + nn, n));
+        const int m0 = op.mid[0] ? op.mid[0] : n, m1 = op.mid[1] ? op.mid[1] : n;
+        XM a{op.c[0], op.ci[0], op.t[0] ? n : m0, op.t[0], false}, b{op.c[1], op.ci[1], op.t[1] ? m0 : n, op.t[1], false};
+        XM c{op.c[2], op.ci[2], op.t[2] ? n : m1, op.t[2], false}, d{op.c[3], op.ci[3], op.t[3] ? m1 : n, op.t[3], false};
+        CTM_TRY(xgemm(ctx, n, n, m0, a, b, R, R + nn, n));
+        CTM_TRY(xgemm(ctx, n, n, m1, c, d, Rt, Rt + nn, n));
         XM rT{R, R + nn, n, true, false}, rt{Rt, Rt + nn, n, false, false};
         CTM_TRY(xgemm(ctx, n, n, n, rT, rt, M, M + nn, n));
         CTM_TRY(svd_full_c(ctx, M, M + nn, n, k, S, Ut, Vt));

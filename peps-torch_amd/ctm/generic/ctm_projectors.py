@@ -24,7 +24,7 @@ def ctm_get_projectors_4x4(direction, coord, state, env, ctm_args=cfg.ctm_args, 
         basis = None
         if getattr(ctm_args, "projector_warm_start", True) and hasattr(eng, "warm_basis"):
             a = t16[3]
-            n = env.chi * a.shape[1] ** 2
+            n = env.chi * a.shape[{(0, -1): 2, (-1, 0): 3, (0, 1): 4, (1, 0): 1}[direction]] ** 2     # truncated bond chi * D_cut^2
             ws = env.__dict__.setdefault("_warm", {})
             key = (direction, coord)
             k = env.chi + 1 if env.chi < n else n

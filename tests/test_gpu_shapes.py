@@ -229,3 +229,43 @@ def test_slowly_decaying_tail_uses_block_krylov(eng, cplx):
     assert np.abs(S - sv[:chi]).max() < 1e-13
     assert np.abs(M @ V - U * S).max() < 1e-12 and np.abs(U.conj().T @ M - S[:, None] * V.conj().T).max() < 1e-12
     assert np.abs(U.conj().T @ U - np.eye(chi)).max() < 1e-12 and np.abs(V.conj().T @ V - np.eye(chi)).max() < 1e-12
+
+
+@pytest.mark.parametrize("Dv,Dh,chi", [(3, 2, 6), (2, 3, 7), (4, 3, 48)])
+def test_direction_dependent_bond_dimensions(eng, Dv, Dh, chi):
+    """Vertical and horizontal bonds of different dimension (rectangular enlarged corners, square halves): one full sweep,
+    fused and explicit projector routes, vs the oracle.  (4,3,48): n = 768 / 432, the implicit-operator iteration."""
+    import config as cfg
+    from ipeps.ipeps import IPEPS
+    from ctm.generic.env import ENV, init_env
+    from ctm.generic import ctmrg
+    from ctm.generic.ctm_components import _halves_t
+    from oracle import ctm_oracle as O
+    rng = np.random.default_rng(7 * Dv + Dh)
+    sites = {(x, y): rng.random((2, Dv, Dh, Dv, Dh)) - 0.3 for y in range(2) for x in range(2)}
+    sites = {k: v / np.abs(v).max() for k, v in sites.items()}
+    st = IPEPS({k: dev(v) for k, v in sites.items()})
+    env = ENV(chi, st); init_env(st, env)
+    ost = O.State(sites); oe = O.init_env_ctmrg(ost, chi)
+    for k in oe.C: assert relerr(env.C[k], oe.C[k]) < 1e-12
+    for k in oe.T: assert relerr(env.T[k], oe.T[k]) < 1e-12
+    for d in cfg.ctm_args.ctm_move_sequence:
+        # same environment on both sides at the start of every direction (moves fix the gauge only up to signs)
+        env.C = {k: dev(v) for k, v in oe.C.items()}; env.T = {k: dev(v) for k, v in oe.T.items()}
+        env.__dict__.pop("_warm", None)
+        t16 = _halves_t(d, (0, 0), st, env)
+        R, Rt = eng.halves(d, t16)
+        Ro, Rto = O.halves(d, (0, 0), ost, oe)
+        assert relerr(R, Ro) < 1e-11 and relerr(Rt, Rto) < 1e-11
+        P, Pt, S = eng.projectors(R, Rt, chi, return_S=True)
+        P2, Pt2, S2 = eng.projectors_4x4(d, t16, chi, return_S=True)
+        Po, Pto, So = O.projectors_from_matrices(Ro, Rto, chi, return_S=True)
+        assert relerr(S, So) < 1e-11 and relerr(S2, So) < 1e-11
+        assert relerr(P2 @ Pt2.t(), Po @ Pto.T) < 1e-6 and relerr(P @ Pt.t(), Po @ Pto.T) < 1e-6
+        for _r in range(2):
+            ctmrg.ctm_MOVE(d, st, env)
+            O.ctm_move(d, ost, oe)
+    for k in oe.C: assert relerr(env.C[k].abs(), np.abs(oe.C[k])) < 1e-7, k
+    for k in oe.T: assert relerr(env.T[k].abs(), np.abs(oe.T[k])) < 1e-7, k
+    spec = env.get_spectra(); ospec = O.corner_spectra(oe)
+    for k in ospec: assert np.abs(spec[k].cpu().numpy() - ospec[k]).max() < 1e-9, k
