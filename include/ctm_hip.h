@@ -68,6 +68,13 @@ int ctm_gemm_intervals(ctm_ctx* ctx, double* out, long long capacity_doubles, lo
 int ctm_gemm(ctm_ctx* ctx, int transA, int transB, int M, int N, int K, double alpha, const double* A, long long lda,
              const double* B, long long ldb, double beta, double* C, long long ldc);
 int ctm_permute(ctm_ctx* ctx, const double* in, double* out, int nd, const long long* dims, const int* perm);
+/* Generic tensor-network contraction "i0,i1,...->o" (single-letter indices, evaluated left to right; a consecutive (a, conj a)
+ * pair of identical 5-index site operands goes through the fused two-layer kernel): the engine behind tn_interface.contract /
+ * einsum (tn_interface.py:3-27), used by the host layer for the observables outside the fixed CTM networks (e.g. the
+ * transfer-matrix correlators of ctm/generic/corrf.py).  dims holds the extents of all operands back to back; conj[i] != 0
+ * reads operand i conjugated (CTM_C128).  out has the extents of the output indices. */
+int ctm_einsum(ctm_ctx* ctx, const char* expr, int ntensors, const double* const* tensors, const int* ndims, const long long* dims,
+               const int* conj, double* out);
 /* x /= max|x| (ord_inf=1, ctmrg.py:210-230) ; scale_out (device or NULL) receives the norm */
 int ctm_normalize_inf(ctm_ctx* ctx, double* x, long long n);
 

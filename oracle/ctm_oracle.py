@@ -483,3 +483,61 @@ def rdm1x2(coord, state, env, sym_pos_def=False):
                    optimize=True)
     r = np.einsum('iXYfst,iXYfuv->sutv', up, lo, optimize=True)
     return sym_pos_def_rdm(r, sym_pos_def)
+
+
+# ----------------------------------------------------------------------------------
+# transfer-matrix correlators (ctm/generic/corrf.py:10-103,234-276,364-670,980-1067)
+# ----------------------------------------------------------------------------------
+_EDGE_SPEC = {
+    UP: (((-1, -1), UP, (1, -1)), "ax,xby,yc->abc"),          # corrf.py:43-56
+    LEFT: (((-1, -1), LEFT, (-1, 1)), "xa,xyb,yc->abc"),      # :57-73
+    DOWN: (((-1, 1), DOWN, (1, 1)), "ax,bxy,cy->abc"),        # :74-84
+    RIGHT: (((1, -1), RIGHT, (1, 1)), "ax,xby,yc->abc"),      # :85-101
+}
+# (T1, T2) and the network over (T1, edge, A, T2) with the double-layer site A[u,l,d,r] (corrf.py:449-667)
+_TM_SPEC = {
+    UP: ((LEFT, RIGHT), "axl,xdy,bldr,cry->abc"),
+    LEFT: ((UP, DOWN), "aux,xry,ubdr,dcy->abc"),
+    DOWN: ((LEFT, RIGHT), "xal,xuy,ulbr,yrc->abc"),
+    RIGHT: ((UP, DOWN), "xua,xly,uldb,dyc->abc"),
+}
+
+
+def get_edge(coord, direction, state, env):
+    c = state.vertexToSite(coord)
+    (c1, t, c2), expr = _EDGE_SPEC[direction]
+    return seq_einsum(expr, env.C[(c, c1)], env.T[(c, t)], env.C[(c, c2)])
+
+
+def apply_edge(coord, direction, state, env, vec):
+    return np.tensordot(vec, get_edge(coord, direction, state, env), ([0, 1, 2], [0, 1, 2]))
+
+
+def apply_TM_1sO(coord, direction, state, env, edge, op=None):
+    """corrf.py:364-670 (no MPO index): A = a^+ op a with the ket layer carrying op (get_aXa, :408-421)."""
+    c = state.vertexToSite(coord)
+    a = state.site(c)
+    ket = a if op is None else np.einsum('mefgh,mn->nefgh', a, op)
+    d = a.shape
+    A = np.einsum('nefgh,nabcd->eafbgchd', ket, a.conj()).reshape(d[1] ** 2, d[2] ** 2, d[3] ** 2, d[4] ** 2)
+    (v1, v2), expr = _TM_SPEC[direction]
+    return seq_einsum(expr, env.T[(c, v1)], edge, A, env.T[(c, v2)])
+
+
+def corrf_1sO1sO(coord, direction, state, env, op1, get_op2, dist):
+    """corrf.py:980-1067: <O1(0) O2(r)>, r = 1..dist+1, with the reference's running normalisation."""
+    c0 = coord
+    rev = (-direction[0], -direction[1])
+    E0 = get_edge(c0, rev, state, env)
+    E1 = apply_TM_1sO(c0, direction, state, env, E0, op=op1)
+    E0 = apply_TM_1sO(c0, direction, state, env, E0)
+    out = np.empty(dist + 1, dtype=E0.dtype)
+    for r in range(dist + 1):
+        c0 = (c0[0] + direction[0], c0[1] + direction[1])
+        E12 = apply_TM_1sO(c0, direction, state, env, E1, op=get_op2(r))
+        E0 = apply_TM_1sO(c0, direction, state, env, E0)
+        E1 = apply_TM_1sO(c0, direction, state, env, E1)
+        out[r] = apply_edge(c0, direction, state, env, E12) / apply_edge(c0, direction, state, env, E0)
+        m = np.abs(E0).max()
+        E0 = E0 / m; E1 = E1 / m
+    return out

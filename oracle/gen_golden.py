@@ -334,7 +334,7 @@ def rvb_case():
     print(f"  rvb ok: E={E:.14f} after {len(hist)} sweeps; zeros in spec: {(spec == 0).sum()}")
 
 
-def file_state_case(name, fname, tiling, chi, j1, j2, E_pub, tol_pub):
+def file_state_case(name, fname, tiling, chi, j1, j2, E_pub, tol_pub, j3=0.0, h_uni=(0., 0., 0.)):
     """G3/G4: the golden-value states of examples/j1j2/ctmrg_j1j2.py:244-266."""
     set_dtype(False)
     if tiling == "BIPARTITE":
@@ -347,24 +347,36 @@ def file_state_case(name, fname, tiling, chi, j1, j2, E_pub, tol_pub):
             return (vx, 0)
     st = read_ipeps(os.path.join('/root/reference/test-input', fname), vertexToSite=lattice_to_site)
     sites = {k: t2n(v) for k, v in st.sites.items()}
-    model = j1j2.J1J2(j1=j1, j2=j2)
     env = ENV(chi, st); init_env(st, env)
     cfg.ctm_args.ctm_max_iter = 40
     env, hist, *_ = ctmrg.run(st, env, conv_check=ctmrg_conv_specC)
     nsw = len(hist['conv_crit'])
-    rd = [t2n(rdm.rdm2x2_legacy(c, st, env)) for c in st.sites]
-    E = OJ.energy_per_site(rd, j1, j2)
+    # reference energy: models/j1j2.py:223-247 with rdm2x2_legacy standing in for rdm2x2 (opt_einsum is not installed here)
+    from ctm.generic import corrf as ref_corrf
+    rmodel = j1j2.J1J2(j1=j1, j2=j2, j3=j3, h_uni=list(h_uni))
+    E = 0.0
+    for c in st.sites:
+        E = E + torch.einsum('ijklabcd,ijklabcd', rdm.rdm2x2_legacy(c, st, env), rmodel.get_hp(c))
+        if abs(j3) > 0:
+            E = E + j3 * j1j2.eval_nnnn_per_site((0, 0), st, env, rmodel.obs_ops)
+    E = float(torch.real(E)) / len(st.sites)
     ost = O.State(sites, lX=st.lX, lY=st.lY, vertexToSite=lattice_to_site)
     oe = O.init_env_ctmrg(ost, chi)
     for _ in range(nsw): O.ctm_sweep(ost, oe)
-    Eo = OJ.energy_per_site([O.rdm2x2(c, ost, oe) for c in ost.sites], j1, j2)
+    Eo = 0.0
+    ocorr = lambda cc, d, o1, g2, dist: O.corrf_1sO1sO(cc, d, ost, oe, o1, g2, dist)
+    for c in ost.sites:
+        Eo += np.einsum('ijklabcd,ijklabcd', O.rdm2x2(c, ost, oe), OJ.get_hp(j1, j2, h_uni=h_uni, coord=c))
+        if abs(j3) > 0:
+            Eo += j3 * OJ.eval_nnnn_per_site(ocorr, (0, 0))
+    Eo = float(np.real(Eo)) / len(ost.sites)
     print(f"  {name}: {nsw} sweeps E_ref={E:.14f} E_oracle={Eo:.14f} published={E_pub}")
     assert abs(E - Eo) < 1e-10
     if E_pub is not None:
         assert abs(E - E_pub) < tol_pub, (E, E_pub)
     out = {f"site_{k[0]}_{k[1]}": v for k, v in sites.items()}
     out.update(energy=np.array(E), nsweeps=np.array(nsw), lX=np.array(st.lX), lY=np.array(st.lY),
-               tiling=np.array(tiling), chi=np.array(chi), j1=np.array(j1), j2=np.array(j2))
+               tiling=np.array(tiling), chi=np.array(chi), j1=np.array(j1), j2=np.array(j2), j3=np.array(j3), h_uni=np.array(h_uni))
     spec = {k: t2n(v) for k, v in env.get_spectra().items()}
     for (c, v), s in spec.items():
         out[f"spec_{c[0]}_{c[1]}_{v[0]}_{v[1]}"] = s
@@ -397,6 +409,30 @@ def variants_check():
             for k in oe.T: close(np.abs(t2n(env.T[k])), np.abs(oe.T[k]), 1e-8, f"{name} {method} norm={norm} T{k}")
             print("variant ok:", name, method, norm)
     cfg.ctm_args.projector_method, cfg.ctm_args.ctm_absorb_normalization = "4X4", "inf"
+    # transfer-matrix correlators (ctm/generic/corrf.py): edges, one transfer step with an operator, <Sz Sz>(r) -- on the
+    # reference's environment after two sweeps, all four directions
+    from ctm.generic import corrf as ref_corrf
+    I2, sz, sp, sm = OJ.su2_ops(2)
+    for name, cx in (("generic_D2_chi8_f64", False), ("generic_D2_chi8_c128", True)):
+        g = np.load(os.path.join(GOLD, name + ".npz"))
+        sites = {tuple(int(v) for v in k.split('_')[1:]): g[k] for k in g.files if k.startswith('site_')}
+        set_dtype(cx)
+        st = IPEPS({k: torch.from_numpy(v.copy()) for k, v in sites.items()})
+        env = ENV(8, st); init_env(st, env)
+        for _ in range(2):
+            for d in [(0, -1), (-1, 0), (0, 1), (1, 0)]:
+                for _r in range(2): ctmrg.ctm_MOVE(d, st, env)
+        ost = O.State(sites); oe = O.Env(8)
+        oe.C = {k: t2n(v) for k, v in env.C.items()}; oe.T = {k: t2n(v) for k, v in env.T.items()}
+        tt = lambda a: torch.from_numpy(a).to(st.dtype)
+        for d in [(0, -1), (-1, 0), (0, 1), (1, 0)]:
+            for c in [(0, 0), (1, 1)]:
+                Eo = O.get_edge(c, d, ost, oe)
+                close(t2n(ref_corrf.get_edge(c, d, st, env)), Eo, 1e-13, f"{name} edge {d}")
+                close(t2n(ref_corrf.apply_TM_1sO(c, d, st, env, tt(Eo), op=tt(sp))), O.apply_TM_1sO(c, d, ost, oe, Eo, op=sp.astype(Eo.dtype)), 1e-13, f"{name} TM {d}")
+                close(t2n(ref_corrf.corrf_1sO1sO(c, d, st, env, tt(sz), lambda r: tt(sz), 3)),
+                      O.corrf_1sO1sO(c, d, ost, oe, sz.astype(Eo.dtype), lambda r: sz.astype(Eo.dtype), 3), 1e-12, f"{name} corrf {d}")
+        print("corrf ok:", name)
 
 
 if __name__ == "__main__":
@@ -417,4 +453,6 @@ if __name__ == "__main__":
     if "files" in which:
         file_state_case("twosite_D2_chi32", "gesdd-D2-chi50-j20.55-run0-iRND2x1_state.json", "2SITE", 32, 1.0, 0.55,
                         -0.4434603770143078, 1e-6)
+        file_state_case("bipartite_D3_chi32", "BIPARTITE_j2_0_j3_1250_h_39000_D_3_chi_32_seed_100_state.json", "BIPARTITE", 32, 1.0, 0.0,
+                        -1.3896897615463615, 1e-6, j3=0.125, h_uni=(3.9, 0., 0.))
     print("golden vectors written to", GOLD)

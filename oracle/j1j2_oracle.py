@@ -37,14 +37,27 @@ def SS(m=2, xyz=(1., 1., 1.)):
     return xyz[0] * np.einsum(k, sz, sz) + 0.5 * xyz[1] * np.einsum(k, sp, sm) + 0.5 * xyz[2] * np.einsum(k, sm, sp)
 
 
-def get_hp(j1=1.0, j2=0.0, m=2):
-    """J1J2.get_hp (models/j1j2.py:130-141) for hz_stag = h_uni = 0, delta_zz = 1."""
+def get_hp(j1=1.0, j2=0.0, m=2, hz_stag=0.0, h_uni=(0., 0., 0.), coord=(0, 0)):
+    """J1J2.get_hp (models/j1j2.py:97-141), delta_zz = 1: the plaquette operator whose expectation value is E/site."""
+    I, sz, sp, sm = su2_ops(m)
     ss = SS(m)
     id2 = np.eye(m * m).reshape(m, m, m, m)
+    id3 = np.eye(m ** 3).reshape(m, m, m, m, m, m)
     h = np.einsum('ijab,klcd->ijklabcd', ss, id2)
     hp = 0.5 * j1 * (h + h.transpose(0, 2, 1, 3, 4, 6, 5, 7) + h.transpose(2, 3, 0, 1, 6, 7, 4, 5)
                      + h.transpose(3, 1, 2, 0, 7, 5, 6, 4)) \
         + j2 * (h.transpose(0, 3, 2, 1, 4, 7, 6, 5) + h.transpose(2, 1, 0, 3, 6, 5, 4, 7))
+    if hz_stag != 0.0:
+        hz = np.einsum('ia,jklbcd->ijklabcd', sz, id3)                                            # :122-123
+        hp = hp - 0.25 * hz_stag * ((-1) ** (coord[0] + coord[1])) * (
+            hz - hz.transpose(3, 0, 1, 2, 7, 4, 5, 6) - hz.transpose(2, 3, 0, 1, 6, 7, 4, 5) + hz.transpose(1, 2, 3, 0, 5, 6, 7, 4))
+    if any(abs(x) > 0 for x in h_uni):
+        # S = (S^z, S^x, S^y) (groups/su2.py:49-62): h_uni . S on one site, spread over the four sites of the plaquette (:124-141)
+        sx, sy = 0.5 * (sp + sm), -0.5j * (sp - sm)
+        h1 = h_uni[0] * sz + h_uni[1] * sx + h_uni[2] * sy
+        if np.abs(h1.imag).max() == 0: h1 = h1.real
+        hu = np.einsum('ia,jklbcd->ijklabcd', h1, id3)
+        hp = hp + 0.25 * (hu + hu.transpose(2, 3, 0, 1, 6, 7, 4, 5) + hu.transpose(3, 0, 1, 2, 7, 4, 5, 6) + hu.transpose(1, 2, 3, 0, 5, 6, 7, 4))
     return hp
 
 
@@ -53,6 +66,15 @@ def energy_per_site(rdms, j1=1.0, j2=0.0):
     hp = get_hp(j1, j2)
     e = sum(np.einsum('ijklabcd,ijklabcd', r, hp) for r in rdms)
     return float(np.real(e)) / len(rdms)
+
+
+def eval_nnnn_per_site(corrf_1sO1sO, coord=(0, 0)):
+    """eval_nnnn_per_site (models/j1j2.py:27-44): third-neighbour S.S along x and y from the distance-2 two-point functions;
+    `corrf_1sO1sO(coord, direction, op1, get_op2, dist)` is the correlator routine bound to a state and its environment."""
+    I, sz, sp, sm = su2_ops(2)
+    f = lambda d, o1, o2: corrf_1sO1sO(coord, d, o1, (lambda r: o2), 2)[1]
+    return (f((1, 0), sz, sz) + f((0, 1), sz, sz)
+            + 0.5 * (f((1, 0), sp, sm) + f((0, 1), sp, sm) + f((1, 0), sm, sp) + f((0, 1), sm, sp)))
 
 
 def energy_1x1_lowmem(rdm_nn, rdm_nnn, j1=1.0, j2=0.0):

@@ -44,6 +44,7 @@ _SIGS = {
                  C.c_void_p, C.c_longlong, C.c_double, C.c_void_p, C.c_longlong],
     "ctm_permute": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_longlong), C.POINTER(C.c_int)],
     "ctm_normalize_inf": [C.c_void_p, C.c_void_p, C.c_longlong],
+    "ctm_einsum": [C.c_void_p, C.c_char_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_longlong), C.POINTER(C.c_int), C.c_void_p],
     "ctm_truncated_svd": [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(TruncCfg), C.c_void_p, C.c_void_p, C.c_void_p],
     "ctm_truncated_eigh": [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(TruncCfg), C.c_void_p, C.c_void_p],
     "ctm_svdvals": [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p],
@@ -268,6 +269,27 @@ class Engine:
         dims = (C.c_longlong * nd)(*x.shape)
         pm = (C.c_int * nd)(*perm)
         self._ck(self.lib.ctm_permute(self.h, _ptr(x), _ptr(out), nd, dims, pm), "permute")
+        return out
+
+    def einsum(self, expr, *tensors, conj=()):
+        """Native contraction of "i0,i1,...->o" (left to right); conj: indices of the operands read conjugated."""
+        ts = self._bind(*tensors)
+        ts = ts if isinstance(ts, list) else [ts]
+        lhs, o = expr.split("->")
+        ins = lhs.split(",")
+        ext = {}
+        for idx, t in zip(ins, ts):
+            if len(idx) != t.dim():
+                raise NativeError(f"einsum: operand '{idx}' has rank {t.dim()}")
+            for ch, n in zip(idx, t.shape):
+                ext[ch] = n
+        out = self.empty(*[ext[ch] for ch in o])
+        arr = (C.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+        nd = (C.c_int * len(ts))(*[t.dim() for t in ts])
+        flat = [n for t in ts for n in t.shape]
+        dims = (C.c_longlong * len(flat))(*flat)
+        cj = (C.c_int * len(ts))(*[1 if i in conj else 0 for i in range(len(ts))])
+        self._ck(self.lib.ctm_einsum(self.h, expr.encode(), len(ts), arr, nd, dims, cj, _ptr(out)), "einsum")
         return out
 
     def normalize_inf_(self, x):

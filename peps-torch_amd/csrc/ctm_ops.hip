@@ -308,6 +308,46 @@ const AbsorbSpec kAbsorb[4] = {
 // =================================================================================================
 extern "C" {
 
+int ctm_einsum(ctm_ctx* ctx, const char* expr, int ntensors, const double* const* tensors, const int* ndims, const long long* dims,
+               const int* conj, double* out) {
+    if (!expr || ntensors < 2 || ntensors > 16) { ctx->set_error("einsum: 2..16 operands"); return CTM_ERR_BADARG; }
+    const std::string e(expr);
+    const size_t arrow = e.find("->");
+    if (arrow == std::string::npos) { ctx->set_error("einsum: explicit output indices required"); return CTM_ERR_BADARG; }
+    ArenaScope scope(ctx);
+    IO io(ctx);
+    std::vector<DT> ops(ntensors);
+    std::vector<std::string> ins;
+    { const std::string lhs = e.substr(0, arrow); size_t s0 = 0; while (true) { size_t c = lhs.find(',', s0); ins.push_back(lhs.substr(s0, c == std::string::npos ? c : c - s0)); if (c == std::string::npos) break; s0 = c + 1; } }
+    if ((int)ins.size() != ntensors) { ctx->set_error("einsum: operand count does not match the expression"); return CTM_ERR_BADARG; }
+    std::map<char, long long> ext;
+    const long long* dp = dims;
+    for (int i = 0; i < ntensors; ++i) {
+        if (ndims[i] != (int)ins[i].size() || ndims[i] > CTM_MAXD) { ctx->set_error("einsum: rank of operand " + std::to_string(i)); return CTM_ERR_SHAPE; }
+        std::vector<long long> d(dp, dp + ndims[i]);
+        for (int a = 0; a < ndims[i]; ++a) {
+            auto it = ext.find(ins[i][a]);
+            if (it != ext.end() && it->second != d[a]) { ctx->set_error(std::string("einsum: extent mismatch on index ") + ins[i][a]); return CTM_ERR_SHAPE; }
+            ext[ins[i][a]] = d[a];
+        }
+        dp += ndims[i];
+        // identical device pointers share one marshalled copy so that the fused (a, conj a) detection still sees one tensor
+        int same = -1;
+        for (int j = 0; j < i; ++j) if (tensors[j] == tensors[i] && ops[j].numel() == [&] { long long n = 1; for (auto v : d) n *= v; return n; }()) { same = j; break; }
+        if (same >= 0) { ops[i] = ops[same]; ops[i].dims = d; ops[i].cj = false; }
+        else CTM_TRY(io.in(tensors[i], d, &ops[i]));
+        if (conj && conj[i]) ops[i] = ops[i].conj();
+    }
+    const std::string o = e.substr(arrow + 2);
+    size_t on = 1;
+    for (char ch : o) { auto it = ext.find(ch); if (it == ext.end()) { ctx->set_error("einsum: unknown output index"); return CTM_ERR_BADARG; } on *= (size_t)it->second; }
+    DT res;
+    CTM_TRY(io.out(out, on, &res));
+    ArenaScope work(ctx);
+    CTM_TRY(dev_network(ctx, e, ops, &res));
+    return io.finish();
+}
+
 int ctm_c2x2(ctm_ctx* ctx, int corner, int open, const double* C, const double* T1, const double* T2, const double* a,
              int chi, const int* adims, double* out) {
     if (corner < 0 || corner > 3) { ctx->set_error("c2x2: bad corner"); return CTM_ERR_BADARG; }

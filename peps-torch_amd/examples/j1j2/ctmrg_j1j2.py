@@ -15,7 +15,10 @@ from models import j1j2
 parser = cfg.get_args_parser()
 parser.add_argument("--j1", type=float, default=1.)
 parser.add_argument("--j2", type=float, default=0.)
+parser.add_argument("--j3", type=float, default=0.)
+parser.add_argument("--lmbd", type=float, default=0.)
 parser.add_argument("--hz_stag", type=float, default=0.)
+parser.add_argument("--h_uni", nargs=3, type=float, default=[0, 0, 0], help="uniform field, components h^z, h^x, h^y")
 parser.add_argument("--delta_zz", type=float, default=1.)
 parser.add_argument("--tiling", default="BIPARTITE", help="BIPARTITE, 1SITE, 2SITE, 4SITE, 8SITE")
 parser.add_argument("--top_freq", type=int, default=-1)
@@ -39,7 +42,7 @@ def main(args=None):
     torch.manual_seed(args.seed)
     if args.tiling not in TILINGS:
         raise ValueError("Invalid tiling: " + str(args.tiling))
-    model = j1j2.J1J2(j1=args.j1, j2=args.j2, hz_stag=args.hz_stag, delta_zz=args.delta_zz)
+    model = j1j2.J1J2(j1=args.j1, j2=args.j2, j3=args.j3, lmbd=args.lmbd, hz_stag=args.hz_stag, delta_zz=args.delta_zz, h_uni=args.h_uni)
     lattice_to_site = TILINGS[args.tiling]
     energy_f = model.energy_2x2_1site_BP if args.tiling == "1SITE" else model.energy_per_site
     eval_obs_f = model.eval_obs_1site_BP if args.tiling == "1SITE" else model.eval_obs

@@ -13,14 +13,22 @@ from ctm.one_site_c4v import rdm_c4v
 import parallel
 
 
+def eval_nnnn_per_site(coord, state, env, obs_ops):
+    """Third-neighbour S.S along x and y from the distance-2 two-point functions (reference models/j1j2.py:27-44)."""
+    from ctm.generic import corrf
+    f = lambda d, o1, o2: corrf.corrf_1sO1sO(coord, d, state, env, obs_ops[o1], (lambda r: obs_ops[o2]), 2)[1]
+    return (f((1, 0), "sz", "sz") + f((0, 1), "sz", "sz")
+            + 0.5 * (f((1, 0), "sp", "sm") + f((0, 1), "sp", "sm") + f((1, 0), "sm", "sp") + f((0, 1), "sm", "sp")))
+
+
 def _cast_to_real(t):
     return t.real if t.is_complex() else t
 
 
 class J1J2():
     def __init__(self, j1=1.0, j2=0, j3=0, hz_stag=0.0, delta_zz=1.0, lmbd=0, h_uni=[0, 0, 0], global_args=cfg.global_args):
-        if j3 != 0 or lmbd != 0:
-            raise NotImplementedError("j3 / chiral terms need RDMs outside the 2x2 hot path")
+        if lmbd != 0:
+            raise NotImplementedError("the chiral term is not implemented")
         self.dtype = global_args.torch_dtype
         self.device = 'cpu'
         self.phys_dim = 2
@@ -81,6 +89,8 @@ class J1J2():
         for coord, r in zip(mine, rdms):
             r = r.cpu()
             e += float(_cast_to_real(torch.einsum('ijklabcd,ijklabcd', r, self.get_hp(coord).to(r.dtype))))
+            if abs(self.j3) > 0:      # the reference evaluates this term at (0,0) for every site of the cell (models/j1j2.py:243-244)
+                e += float(_cast_to_real(self.j3 * eval_nnnn_per_site((0, 0), state, env, self.obs_ops)))
         e = parallel.allreduce_sum_scalar(e, state.device)
         return torch.as_tensor(e / len(coords), dtype=torch.float64)
 

@@ -26,7 +26,10 @@ def mm(m1, m2):
 
 
 def einsum(op, *ts):
-    raise NotImplementedError("use the native contraction entry points (ctm.generic.*); generic einsum is not on the hot path")
+    """Explicit-output einsum ("ab,bc->ac") on the native contraction executor (left-to-right pairwise GEMMs)."""
+    if "->" not in op:
+        raise ValueError("einsum: explicit output indices required")
+    return get_engine().einsum(op, *[t.contiguous() for t in ts])
 
 
 def view(t, *args):

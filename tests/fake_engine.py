@@ -35,6 +35,10 @@ class FakeEngine:
         a, b = _n(A), _n(B)
         return _t(alpha * ((a.T if transA else a) @ (b.T if transB else b)))
 
+    def einsum(self, expr, *tensors, conj=()):
+        ops = [(_n(t).conj() if i in conj else _n(t)) for i, t in enumerate(tensors)]
+        return _t(O.seq_einsum(expr, *ops))
+
     def permute(self, x, perm):
         return x.permute(*perm).contiguous()
 

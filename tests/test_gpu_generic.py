@@ -135,3 +135,25 @@ def test_rdm2x2_partially_open(case, eng):
         ref = np.einsum(expr, full)
         ref = ref / np.trace(ref.reshape(int(np.sqrt(ref.size)), -1))
         assert relerr(rdm.rdm2x2((0, 0), st, env, open_sites=os_), ref) < 1e-11, os_
+
+
+def test_transfer_matrix_correlators(case, eng):
+    """ctm/generic/corrf.py: edges, one transfer step with an operator, <Sz Sz>(r) and <S+ S->(r) in all four directions
+    on the native einsum vs the oracle (itself pinned against the reference by `gen_golden.py variants`)."""
+    from ctm.generic import corrf
+    from oracle import ctm_oracle as O, j1j2_oracle as OJ
+    st, env = device_state_env(case["sites"], case["C"], case["T"], case["chi"])
+    ost, oe = oracle_state_env(case["sites"], case["C"], case["T"], case["chi"])
+    I2, sz, sp, sm = OJ.su2_ops(2)
+    dt = next(iter(case["sites"].values())).dtype
+    tt = lambda a: dev(a.astype(dt))
+    for dn, d in DIRS.items():
+        for c in [(0, 0), (1, 1)]:
+            Eo = O.get_edge(c, d, ost, oe)
+            assert relerr(corrf.get_edge(c, d, st, env), Eo) < 1e-13
+            assert relerr(corrf.apply_TM_1sO(c, d, st, env, dev(Eo), op=tt(sp)), O.apply_TM_1sO(c, d, ost, oe, Eo, op=sp.astype(dt))) < 1e-12
+            assert relerr(corrf.apply_TM_1sO(c, d, st, env, dev(Eo)), O.apply_TM_1sO(c, d, ost, oe, Eo)) < 1e-12
+            for o1, o2 in ((sz, sz), (sp, sm)):
+                cr = corrf.corrf_1sO1sO(c, d, st, env, tt(o1), lambda r: tt(o2), 3).cpu().numpy()
+                cro = O.corrf_1sO1sO(c, d, ost, oe, o1.astype(dt), lambda r: o2.astype(dt), 3)
+                assert np.abs(cr - cro).max() < 1e-11, (dn, c)

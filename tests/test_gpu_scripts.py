@@ -42,3 +42,21 @@ def test_ctmrg_j1j2_c4v_script_rvb(tmp_path):
     vals = _run("ctmrg_j1j2_c4v.py", ["--instate", f, "--chi", "16", "--bond_dim", "3", "--j2", "0.5", "--CTMARGS_ctm_max_iter", "200",
                                       "--GLOBALARGS_device", "cuda:0", "--out_prefix", str(tmp_path / "o")])
     assert abs(vals[0] - (-0.47684229)) < 1e-8
+
+
+def test_ctmrg_j1j2_script_bipartite_golden(tmp_path):
+    """examples/j1j2/ctmrg_j1j2.py:248-257 of the reference: BIPARTITE D=3 chi=32, j3=0.125, h_uni=[3.9,0,0] ->
+    E = -1.3896897615463615 (tol 1e-6): field terms in the plaquette operator + the j3 term from the native distance-2
+    transfer-matrix correlators."""
+    from ipeps.ipeps import IPEPS, write_ipeps
+    g = golden("bipartite_D3_chi32")
+    st = IPEPS({(0, 0): torch.from_numpy(g["site_0_0"]), (1, 0): torch.from_numpy(g["site_1_0"])}, lX=2, lY=1)
+    f = str(tmp_path / "bipartite.json")
+    write_ipeps(st, f)
+    vals = _run("ctmrg_j1j2.py", ["--instate", f, "--tiling", "BIPARTITE", "--chi", "32", "--bond_dim", "3", "--j3", "0.125",
+                                  "--h_uni", "3.9", "0", "0", "--CTMARGS_ctm_max_iter", "100", "--GLOBALARGS_device", "cuda:0",
+                                  "--out_prefix", str(tmp_path / "o")])
+    assert abs(vals[0] - (-1.3896897615463615)) < 1e-6
+    # FINAL observables of the published line (m, m_A, m_B, ...): first four values
+    for v, ref in zip(vals[1:4], (0.4884474386344192, 0.48844697363007333, 0.4884479036387651)):
+        assert abs(v - ref) < 1e-6

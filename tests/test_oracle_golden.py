@@ -114,3 +114,24 @@ def test_two_site_golden_state_energy():
     e = OJ.energy_per_site([O.rdm2x2(c, ost, oe) for c in ost.sites], 1.0, 0.55)
     assert abs(e - (-0.4434603770143078)) < 1e-6
     assert abs(e - float(g["energy"])) < 1e-10
+
+
+def test_bipartite_golden_state_energy_with_j3_and_field():
+    """examples/j1j2/ctmrg_j1j2.py:248-257: BIPARTITE D=3 chi=32, j3=0.125, h_uni=[3.9,0,0] -> E = -1.3896897615463615
+    (tol 1e-6); the j3 term comes from the distance-2 transfer-matrix correlators (models/j1j2.py:27-44)."""
+    g = golden("bipartite_D3_chi32")
+    sites = sites_from(g)
+    v2s = lambda c: ((((c[0] + abs(c[0]) * 2) % 2) + abs(c[1])) % 2, 0)
+    ost = O.State(sites, lX=int(g["lX"]), lY=int(g["lY"]), vertexToSite=v2s)
+    oe = O.init_env_ctmrg(ost, 32)
+    for _ in range(int(g["nsweeps"])):
+        O.ctm_sweep(ost, oe)
+    h_uni = tuple(float(x) for x in g["h_uni"]); j3 = float(g["j3"])
+    corr = lambda c, d, o1, g2, dist: O.corrf_1sO1sO(c, d, ost, oe, o1, g2, dist)
+    e = 0.0
+    for c in ost.sites:
+        e += np.einsum('ijklabcd,ijklabcd', O.rdm2x2(c, ost, oe), OJ.get_hp(1.0, 0.0, h_uni=h_uni, coord=c))
+        e += j3 * OJ.eval_nnnn_per_site(corr, (0, 0))
+    e = float(np.real(e)) / len(ost.sites)
+    assert abs(e - (-1.3896897615463615)) < 1e-6
+    assert abs(e - float(g["energy"])) < 1e-10
