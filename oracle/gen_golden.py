@@ -383,6 +383,36 @@ def file_state_case(name, fname, tiling, chi, j1, j2, E_pub, tol_pub, j3=0.0, h_
     np.savez_compressed(os.path.join(GOLD, name + ".npz"), **out)
 
 
+def aklt_case():
+    """G5: AKLT S=2 states of examples/akltS2/ctmrg_akltS2.py:166-221,224-279 (E < 1e-12, magnetisations < 1e-12): parsed
+    site tensors + the reference's converged energy (RDMs through mode='dl': opt_einsum is not installed here)."""
+    from models import akltS2
+    set_dtype(False)
+    bip = lambda c: ((((c[0] + abs(c[0]) * 2) % 2) + abs(c[1])) % 2, 0)
+    for name, fname, v2s in (("aklt_S2_2x1", "AKLT-S2_2x1_biLat.in", bip), ("aklt_S2_2x2", "AKLT-S2_2x2_ABCD.in", None)):
+        st = read_ipeps(os.path.join('/root/reference/test-input', fname), vertexToSite=v2s)
+        sites = {k: t2n(v) for k, v in st.sites.items()}
+        model = akltS2.AKLTS2()
+        env = ENV(32, st); init_env(st, env)
+        cfg.ctm_args.ctm_max_iter = 30
+        env, hist, *_ = ctmrg.run(st, env, conv_check=ctmrg_conv_specC)
+        nsw = len(hist['conv_crit'])
+        E = 0.0
+        for c in st.sites:
+            E = E + torch.einsum('ijab,ijab', rdm.rdm2x1(c, st, env, mode='dl'), model.h) + torch.einsum('ijab,ijab', rdm.rdm1x2(c, st, env, mode='dl'), model.h)
+        E = float(torch.real(E)) / len(st.sites)
+        ost = O.State(sites, lX=st.lX, lY=st.lY, vertexToSite=v2s)
+        oe = O.init_env_ctmrg(ost, 32)
+        for _ in range(nsw): O.ctm_sweep(ost, oe)
+        h = t2n(model.h)
+        Eo = sum(np.einsum('ijab,ijab', O.rdm2x1(c, ost, oe), h) + np.einsum('ijab,ijab', O.rdm1x2(c, ost, oe), h) for c in ost.sites) / len(ost.sites)
+        print(f"  {name}: {nsw} sweeps E_ref={E:.3e} E_oracle={float(np.real(Eo)):.3e} (reference test: E < 1e-12)")
+        assert abs(E) < 1e-12 and abs(Eo) < 1e-12
+        out = {f"site_{k[0]}_{k[1]}": v for k, v in sites.items()}
+        out.update(energy=np.array(E), nsweeps=np.array(nsw), lX=np.array(st.lX), lY=np.array(st.lY), h=h)
+        np.savez_compressed(os.path.join(GOLD, name + ".npz"), **out)
+
+
 def variants_check():
     """Pins the oracle's non-default variants against the real reference (no vectors stored: assertions only):
     projector_method='4X2' (ctm_projectors.py:66-136) and ctm_absorb_normalization='2' (ctmrg.py:210-230), two sweeps
@@ -436,7 +466,9 @@ def variants_check():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["decomp", "generic", "c4v", "rvb", "files", "variants"]
+    which = sys.argv[1:] or ["decomp", "generic", "c4v", "rvb", "files", "variants", "aklt"]
+    if "aklt" in which:
+        aklt_case()
     if "variants" in which:
         variants_check()
     if "decomp" in which:

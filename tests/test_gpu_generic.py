@@ -157,3 +157,29 @@ def test_transfer_matrix_correlators(case, eng):
                 cr = corrf.corrf_1sO1sO(c, d, st, env, tt(o1), lambda r: tt(o2), 3).cpu().numpy()
                 cro = O.corrf_1sO1sO(c, d, ost, oe, o1.astype(dt), lambda r: o2.astype(dt), 3)
                 assert np.abs(cr - cro).max() < 1e-11, (dn, c)
+
+
+@pytest.mark.parametrize("name", ["aklt_S2_2x1", "aklt_S2_2x2"])
+def test_aklt_S2_known_answer(eng, name):
+    """examples/akltS2/ctmrg_akltS2.py:166-221,224-279 of the reference: AKLT S=2 (p=5, D=2), chi=32: E/site < 1e-12 and
+    every on-site magnetisation < 1e-12, through ctmrg.run with the corner-spectrum convergence check."""
+    import config as cfg
+    from ipeps.ipeps import IPEPS
+    from ctm.generic.env import ENV, init_env, ctmrg_conv_specC
+    from ctm.generic import ctmrg
+    from models import akltS2
+    g = golden(name)
+    sites = sites_from(g)
+    v2s = (lambda c: ((((c[0] + abs(c[0]) * 2) % 2) + abs(c[1])) % 2, 0)) if name.endswith("2x1") else None
+    st = IPEPS({k: dev(v) for k, v in sites.items()}, vertexToSite=v2s, lX=int(g["lX"]), lY=int(g["lY"]))
+    env = ENV(32, st); init_env(st, env)
+    cfg.ctm_args.ctm_max_iter = 30
+    env, hist, *_ = ctmrg.run(st, env, conv_check=ctmrg_conv_specC)
+    cfg.ctm_args.ctm_max_iter = 50
+    assert len(hist['conv_crit']) == int(g["nsweeps"])
+    m = akltS2.AKLTS2()
+    assert abs(float(m.energy_2x1_1x2(st, env))) < 1e-12
+    vals, labels = m.eval_obs(st, env)
+    obs = dict(zip(labels, vals))
+    for c in st.sites:
+        assert abs(obs[f"m{c}"]) < 1e-12

@@ -135,3 +135,19 @@ def test_bipartite_golden_state_energy_with_j3_and_field():
     e = float(np.real(e)) / len(ost.sites)
     assert abs(e - (-1.3896897615463615)) < 1e-6
     assert abs(e - float(g["energy"])) < 1e-10
+
+
+@pytest.mark.parametrize("name", ["aklt_S2_2x1", "aklt_S2_2x2"])
+def test_aklt_S2_energy_is_zero(name):
+    """examples/akltS2/ctmrg_akltS2.py:166-221,224-279: the AKLT S=2 state is the exact ground state of the projector
+    Hamiltonian, E/site < 1e-12 (physical dimension 5; energy from rdm2x1 / rdm1x2)."""
+    g = golden(name)
+    sites = sites_from(g)
+    v2s = (lambda c: ((((c[0] + abs(c[0]) * 2) % 2) + abs(c[1])) % 2, 0)) if name.endswith("2x1") else None
+    ost = O.State(sites, lX=int(g["lX"]), lY=int(g["lY"]), vertexToSite=v2s)
+    oe = O.init_env_ctmrg(ost, 32)
+    for _ in range(int(g["nsweeps"])):
+        O.ctm_sweep(ost, oe)
+    h = g["h"]
+    e = sum(np.einsum('ijab,ijab', O.rdm2x1(c, ost, oe), h) + np.einsum('ijab,ijab', O.rdm1x2(c, ost, oe), h) for c in ost.sites) / len(ost.sites)
+    assert abs(e) < 1e-12
