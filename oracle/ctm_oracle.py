@@ -541,3 +541,28 @@ def corrf_1sO1sO(coord, direction, state, env, op1, get_op2, dist):
         m = np.abs(E0).max()
         E0 = E0 / m; E1 = E1 / m
     return out
+
+
+def get_Top_spec(n, coord, direction, state, env):
+    """transferops.py:119-207: leading n eigenvalues (modulus-descending, |lambda_0| = 1) of the width-0 transfer operator,
+    ARPACK on a matrix-free operator built from lX (lY) transfer steps."""
+    from scipy.sparse.linalg import LinearOperator, eigs
+    c = state.vertexToSite(coord)
+    leg = {(0, -1): 1, (-1, 0): 2, (0, 1): 3, (1, 0): 4}[(-direction[0], -direction[1])]
+    ad = state.site(c).shape[leg]
+    chi = env.chi
+    N = state.lX if direction in (LEFT, RIGHT) else state.lY
+    dt = next(iter(env.T.values())).dtype
+
+    def mv(v):
+        V = np.asarray(v, dtype=dt).reshape(chi, ad * ad, chi)
+        c0 = coord
+        for _ in range(N):
+            V = apply_TM_1sO(c0, direction, state, env, V)
+            c0 = (c0[0] + direction[0], c0[1] + direction[1])
+        return V.reshape(-1)
+
+    dim = chi * ad * ad * chi
+    vals = eigs(LinearOperator((dim, dim), matvec=mv, dtype=dt), k=n, return_eigenvectors=False)
+    vals = vals[np.argsort(np.abs(vals))[::-1]]
+    return vals / np.abs(vals[0])

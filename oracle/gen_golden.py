@@ -462,7 +462,12 @@ def variants_check():
                 close(t2n(ref_corrf.apply_TM_1sO(c, d, st, env, tt(Eo), op=tt(sp))), O.apply_TM_1sO(c, d, ost, oe, Eo, op=sp.astype(Eo.dtype)), 1e-13, f"{name} TM {d}")
                 close(t2n(ref_corrf.corrf_1sO1sO(c, d, st, env, tt(sz), lambda r: tt(sz), 3)),
                       O.corrf_1sO1sO(c, d, ost, oe, sz.astype(Eo.dtype), lambda r: sz.astype(Eo.dtype), 3), 1e-12, f"{name} corrf {d}")
-        print("corrf ok:", name)
+        # leading eigenvalues of the width-0 transfer operator (ctm/generic/transferops.py:119-207)
+        from ctm.generic import transferops as ref_top
+        for d in [(1, 0), (0, 1)]:
+            L = t2n(ref_top.get_Top_spec(4, (0, 0), d, st, env))
+            close(np.abs(L[:, 0] + 1j * L[:, 1]), np.abs(O.get_Top_spec(4, (0, 0), d, ost, oe)), 1e-10, f"{name} Top spec {d}")
+        print("corrf + transfer-operator spectrum ok:", name)
 
 
 if __name__ == "__main__":

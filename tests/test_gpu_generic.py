@@ -183,3 +183,16 @@ def test_aklt_S2_known_answer(eng, name):
     obs = dict(zip(labels, vals))
     for c in st.sites:
         assert abs(obs[f"m{c}"]) < 1e-12
+
+
+def test_transfer_operator_spectrum(case, eng):
+    """transferops.get_Top_spec: ARPACK on the host over native transfer steps vs the oracle (moduli: complex pairs may swap)."""
+    from ctm.generic import transferops
+    from oracle import ctm_oracle as O
+    st, env = device_state_env(case["sites"], case["C"], case["T"], case["chi"])
+    ost, oe = oracle_state_env(case["sites"], case["C"], case["T"], case["chi"])
+    for d in [(1, 0), (0, -1)]:
+        L = transferops.get_Top_spec(4, (0, 0), d, st, env).cpu().numpy()
+        Lo = O.get_Top_spec(4, (0, 0), d, ost, oe)
+        assert np.abs(np.abs(L[:, 0] + 1j * L[:, 1]) - np.abs(Lo)).max() < 1e-9
+        assert abs(L[0, 0] - 1.0) < 1e-12
