@@ -4,6 +4,12 @@ from backend import get_engine
 from ctm.generic.ctm_components import _halves, _halves_t, _HALVES, _corner
 
 
+# The reference switches between LAPACK gesdd, ARPACK, PROPACK and randomised SVD (ctm_projectors.py:225-255); here every
+# choice lands on the same engine (leading-chi iteration / block Krylov / full Jacobi chosen by the spectrum, full-SVD
+# semantics), so the names are accepted as synonyms.  'AF' (arrayfire) has no counterpart.
+SVD_METHODS = ['DEFAULT', 'GESDD', 'GESDD_CPU', 'ARP', 'PROPACK', 'RSVD', 'RSVD_CUSTOM', 'QR']
+
+
 def _trunc_cfg(eng, ctm_args):
     return eng.cfg(svd_reltol=ctm_args.projector_svd_reltol, eps_multiplet=ctm_args.projector_eps_multiplet,
                    multiplet_abstol=ctm_args.projector_multiplet_abstol, keep_multiplets=True)
@@ -13,7 +19,7 @@ def ctm_get_projectors_4x4(direction, coord, state, env, ctm_args=cfg.ctm_args, 
                            diagnostics=None):
     if direction not in [(0, -1), (-1, 0), (0, 1), (1, 0)]:
         raise ValueError("Invalid direction: " + str(direction))
-    if ctm_args.projector_svd_method not in ['DEFAULT', 'GESDD']:
+    if ctm_args.projector_svd_method not in SVD_METHODS:
         raise ValueError(f"Projector svd method \"{ctm_args.projector_svd_method}\" not implemented")
     eng = get_engine()
     if hasattr(eng, "projectors_4x4"):
@@ -59,7 +65,7 @@ def ctm_get_projectors_from_matrices(R, Rt, chi, ctm_args=cfg.ctm_args, global_a
     """M = R^T Rt ; U S V^T = M (leading chi) ; P = R conj(U) S^-1/2 , Pt = Rt V S^-1/2."""
     assert R.shape == Rt.shape
     assert len(R.shape) == 2
-    if ctm_args.projector_svd_method not in ['DEFAULT', 'GESDD']:
+    if ctm_args.projector_svd_method not in SVD_METHODS:
         raise ValueError(f"Projector svd method \"{ctm_args.projector_svd_method}\" not implemented")
     eng = get_engine()
     return eng.projectors(R, Rt, chi, _trunc_cfg(eng, ctm_args))
