@@ -115,6 +115,13 @@ int ctm_projectors_4x4_ws(ctm_ctx* ctx, int dir, const double* const* tensors16,
  * tensors10 = C1,T1,T,T2,C2,A,P2,Pt2,P1,Pt1 */
 int ctm_absorb(ctm_ctx* ctx, int dir, const double* const* tensors10, int chi, const int* adims, int normalize,
                double* nC1, double* nC2, double* nT);
+/* Same with different dimensions of the incoming environment (chi_in: C, T and the row blocks of the projectors) and of the
+ * truncated bond (chi_out: projector columns).  nT is (chi_out, D^2, chi_out)-shaped per direction; nC1 and nC2 have one new and
+ * one old leg: new leg first for nC1 of UP/LEFT/RIGHT and nC2 of LEFT, second otherwise (the output index order of the
+ * reference's contractions, ctmrg.py:351-374 etc.).  Used by the host layer to run a move on the non-zero block of an
+ * environment whose trailing singular values were masked (chi_eff < chi). */
+int ctm_absorb_x(ctm_ctx* ctx, int dir, const double* const* tensors10, int chi_in, int chi_out, const int* adims, int normalize,
+                 double* nC1, double* nC2, double* nT);
 
 /* ---- one-site C4v move (ctm/one_site_c4v/ctmrg_c4v.py:325-463; ctm_components_c4v.py:52-130) ---------- */
 int ctm_c2x2_c4v(ctm_ctx* ctx, int open, const double* a, const double* C, const double* T, int chi, int p, int D,

@@ -54,6 +54,7 @@ _SIGS = {
     "ctm_projectors_4x4": [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_int), C.POINTER(TruncCfg), C.c_void_p, C.c_void_p, C.c_void_p],
     "ctm_projectors_4x4_ws": [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_int), C.POINTER(TruncCfg), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
     "ctm_absorb": [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_int), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p],
+    "ctm_absorb_x": [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p],
     "ctm_c2x2_c4v": [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p],
     "ctm_move_c4v": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(TruncCfg),
                      C.c_void_p, C.c_void_p, C.c_void_p],
@@ -395,17 +396,25 @@ class Engine:
                                                 _ptr(basis) if basis is not None else None), "projectors_4x4")
         return (P, Pt, S) if return_S else (P, Pt)
 
+    # axis of the NEW (truncated) bond in nC1 / nC2 per direction (output index order of the absorb contractions)
+    NEW_AXIS = {UP: (0, 1), LEFT: (0, 0), DOWN: (1, 1), RIGHT: (0, 1)}
+
     def absorb(self, direction, tensors10, normalize=True):
+        """nC1, nC2, nT of one site.  The environment tensors may be smaller (chi_in) than the truncated bond (chi_out =
+        projector columns): nC1 / nC2 then come back as chi_out x chi_in (or transposed, see NEW_AXIS)."""
         ts = self._bind(*tensors10)
         arr = (C.c_void_p * 10)(*[t.data_ptr() for t in ts])
         A = ts[5]
-        chi = ts[0].shape[0]
+        chi_in = ts[0].shape[0]
+        chi_out = ts[6].shape[1]
         d = DIR_INDEX[direction] if isinstance(direction, tuple) else direction
         out_leg = (3, 4, 1, 2)[d]
         D2 = A.shape[out_leg] ** 2
-        shapes = {UP: (chi, D2, chi), LEFT: (chi, chi, D2), DOWN: (D2, chi, chi), RIGHT: (chi, D2, chi)}
-        nC1, nC2, nT = self.empty(chi, chi), self.empty(chi, chi), self.empty(*shapes[d])
-        self._ck(self.lib.ctm_absorb(self.h, d, arr, chi, self._adims(A), int(normalize), _ptr(nC1), _ptr(nC2), _ptr(nT)), "absorb")
+        shapes = {UP: (chi_out, D2, chi_out), LEFT: (chi_out, chi_out, D2), DOWN: (D2, chi_out, chi_out), RIGHT: (chi_out, D2, chi_out)}
+        cs = lambda new_axis: (chi_out, chi_in) if new_axis == 0 else (chi_in, chi_out)
+        n1, n2 = self.NEW_AXIS[d]
+        nC1, nC2, nT = self.empty(*cs(n1)), self.empty(*cs(n2)), self.empty(*shapes[d])
+        self._ck(self.lib.ctm_absorb_x(self.h, d, arr, chi_in, chi_out, self._adims(A), int(normalize), _ptr(nC1), _ptr(nC2), _ptr(nT)), "absorb")
         return nC1, nC2, nT
 
     # ---- C4v ------------------------------------------------------------------------------------------

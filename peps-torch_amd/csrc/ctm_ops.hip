@@ -587,10 +587,16 @@ int ctm_projectors_4x4_ws(ctm_ctx* ctx, int dir, const double* const* t, int chi
 
 int ctm_absorb(ctm_ctx* ctx, int dir, const double* const* t, int chi, const int* ad, int normalize, double* nC1,
                double* nC2, double* nT) {
+    return ctm_absorb_x(ctx, dir, t, chi, chi, ad, normalize, nC1, nC2, nT);
+}
+
+int ctm_absorb_x(ctm_ctx* ctx, int dir, const double* const* t, int chi_in, int chi_out, const int* ad, int normalize, double* nC1,
+                 double* nC2, double* nT) {
     if (dir < 0 || dir > 3) { ctx->set_error("absorb: bad direction"); return CTM_ERR_BADARG; }
     const AbsorbSpec& sp = kAbsorb[dir];
+    // X: environment dimension of the incoming tensors; Y: dimension of the truncated (new) bond = columns of the projectors.
     // D^2 extents of the T tensors follow the site legs they attach to (uniform D assumed per leg pair)
-    const long long X = chi, Dt = ad[sp.t_leg], Dpt2 = ad[sp.pt2_leg], Dp1 = ad[sp.p1_leg];
+    const long long X = chi_in, Y = chi_out, Dt = ad[sp.t_leg], Dpt2 = ad[sp.pt2_leg], Dp1 = ad[sp.p1_leg];
     // T1 carries the D^2 leg shared with Pt1, T2 the one shared with P2
     const long long Dt1 = Dp1 /* neighbour projector leg == this site's leg on that side */, Dt2 = Dpt2;
     auto d3 = [&](int axis, long long D2) { std::vector<long long> d; for (int a = 0; a < 3; ++a) d.push_back(a == axis ? D2 : X); return d; };
@@ -605,17 +611,17 @@ int ctm_absorb(ctm_ctx* ctx, int dir, const double* const* t, int chi, const int
         DT tC1, tT1, tT, tT2, tC2, tA, tP2, tPt2, tP1, tPt1;
         CTM_TRY(io.in(t[0], {X, X}, &tC1));
         CTM_TRY(io.in(t[1], d3(sp.t1_axis, Dt1 * Dt1), &tT1));
-        CTM_TRY(io.in(t[2], t_view(sp.t_axis, chi, Dt), &tT));
+        CTM_TRY(io.in(t[2], t_view(sp.t_axis, chi_in, Dt), &tT));
         CTM_TRY(io.in(t[3], d3(sp.t2_axis, Dt2 * Dt2), &tT2));
         CTM_TRY(io.in(t[4], {X, X}, &tC2));
         CTM_TRY(io.in(t[5], {ad[0], ad[1], ad[2], ad[3], ad[4]}, &tA));
-        CTM_TRY(io.in(t[6], {X, Dt2 * Dt2, X}, &tP2));
-        CTM_TRY(io.in(t[7], {X, Dpt2, Dpt2, X}, &tPt2));
-        CTM_TRY(io.in(t[8], {X, Dp1, Dp1, X}, &tP1));
-        CTM_TRY(io.in(t[9], {X, Dt1 * Dt1, X}, &tPt1));
-        CTM_TRY(io.out(nC1, (size_t)(X * X), &r1));
-        CTM_TRY(io.out(nC2, (size_t)(X * X), &r2));
-        CTM_TRY(io.out(nT, (size_t)(X * X * D2out), &r3));
+        CTM_TRY(io.in(t[6], {X, Dt2 * Dt2, Y}, &tP2));
+        CTM_TRY(io.in(t[7], {X, Dpt2, Dpt2, Y}, &tPt2));
+        CTM_TRY(io.in(t[8], {X, Dp1, Dp1, Y}, &tP1));
+        CTM_TRY(io.in(t[9], {X, Dt1 * Dt1, Y}, &tPt1));
+        CTM_TRY(io.out(nC1, (size_t)(X * Y), &r1));          // one new (Y) and one old (X) leg; which is first follows the spec
+        CTM_TRY(io.out(nC2, (size_t)(X * Y), &r2));
+        CTM_TRY(io.out(nT, (size_t)(Y * Y * D2out), &r3));
         ArenaScope work(ctx);
         CTM_TRY(dev_seq_einsum(ctx, sp.nC1, {tPt1, tC1, tT1}, &r1));
         CTM_TRY(dev_seq_einsum(ctx, sp.nC2, {tC2, tT2, tP2}, &r2));
@@ -625,9 +631,9 @@ int ctm_absorb(ctm_ctx* ctx, int dir, const double* const* t, int chi, const int
     if (normalize) {
         PhaseTimer pt(ctx, CTM_T_NORM);
         const int kind = (normalize == 2) ? 2 : 1;
-        CTM_TRY(normalize_dt(ctx, r1.view({X * X}), kind));
-        CTM_TRY(normalize_dt(ctx, r2.view({X * X}), kind));
-        CTM_TRY(normalize_dt(ctx, r3.view({X * X * D2out}), kind));
+        CTM_TRY(normalize_dt(ctx, r1.view({X * Y}), kind));
+        CTM_TRY(normalize_dt(ctx, r2.view({X * Y}), kind));
+        CTM_TRY(normalize_dt(ctx, r3.view({Y * Y * D2out}), kind));
     }
     return io.finish();
 }

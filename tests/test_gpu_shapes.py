@@ -269,3 +269,34 @@ def test_direction_dependent_bond_dimensions(eng, Dv, Dh, chi):
     for k in oe.T: assert relerr(env.T[k].abs(), np.abs(oe.T[k])) < 1e-7, k
     spec = env.get_spectra(); ospec = O.corner_spectra(oe)
     for k in ospec: assert np.abs(spec[k].cpu().numpy() - ospec[k]).max() < 1e-9, k
+
+
+@pytest.mark.parametrize("name,chi", [("generic_D2_chi8_f64", 8), ("generic_D2_chi8_c128", 8)])
+@pytest.mark.parametrize("chi_out", [5, 12])
+def test_absorb_with_different_environment_and_projector_dimensions(eng, name, chi, chi_out):
+    """ctm_absorb_x: incoming tensors of dimension chi_in, projectors with chi_out columns (a growing or shrinking
+    environment), every direction, against the oracle's absorb on the same operands."""
+    from helpers import sites_from, env_from, device_state_env, oracle_state_env, DIRS
+    from conftest import golden
+    from ctm.generic import ctmrg
+    from oracle import ctm_oracle as O
+    g = golden(name)
+    sites = sites_from(g); C, T = env_from(g, "warm_")
+    st, env = device_state_env(sites, C, T, chi)
+    ost, oe = oracle_state_env(sites, C, T, chi)
+    rng = np.random.default_rng(11)
+    cplx = next(iter(sites.values())).dtype.kind == 'c'
+    for d in DIRS.values():
+        P, Pt = {}, {}
+        for c, a in sites.items():
+            leg = {(0, -1): 2, (-1, 0): 3, (0, 1): 4, (1, 0): 1}[d]
+            n = chi * a.shape[leg] ** 2
+            mk = lambda: (rng.standard_normal((n, chi_out)) + (1j * rng.standard_normal((n, chi_out)) if cplx else 0))
+            P[c], Pt[c] = mk(), mk()
+        dP, dPt = {c: dev(v) for c, v in P.items()}, {c: dev(v) for c, v in Pt.items()}
+        for c in sites:
+            got = ctmrg._absorb(d, c, st, env, dP, dPt, None, normalize=False)
+            want = O.absorb_truncate(d, c, ost, oe, P, Pt)
+            for x, y in zip(got, want):
+                assert tuple(x.shape) == y.shape
+                assert relerr(x, y) < 1e-12
