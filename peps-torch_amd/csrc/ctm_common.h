@@ -75,6 +75,7 @@ struct ctm_ctx {
     long layer2_calls = 0;
     bool use_layer2 = true;
     bool gemm_fast = true;
+    bool gemm_split_rem = true;   // split a 128 q + r (r <= 64) dimension into a vectorised part and a strip
     int splitk_max_tiles = 256, splitk_target_wgs = 1024;   // split-K of skinny GEMMs: when few output tiles, how many workgroups to aim for
     bool eig64_pingpong = true;
     int eig64_bpt = 2;                  // 2x2 blocks per thread of the 64 x 64 LDS eigensolver (1, 2, 4 -> 1024, 512, 256 threads)         // one-barrier-per-round LDS eigensolver for 64 x 64 pair Grams

@@ -317,9 +317,37 @@ __global__ void splitk_reduce_kernel(const double* __restrict__ part, int nsplit
 
 }  // namespace
 
+// operands of a plain GEMM the vectorised 128x128 kernel can take (apart from M, N being multiples of 128)
+static bool fast_operands(const ctm_ctx* ctx, const GemmDesc& d) {
+    const bool ak = d.sak == 1, amf = d.sam == 1, bnf = d.sbn == 1, bkf = d.sbk == 1;
+    return ctx->gemm_fast && !d.offs && d.splitB_dim == 0 && d.splitA >= d.M && d.splitC >= d.M && !d.skip_flags && d.K % 16 == 0 &&
+           (ak || amf) && (bnf || bkf) && (((uintptr_t)d.A | (uintptr_t)d.B) & 15) == 0 && ((ak ? d.sam : d.sak) % 2 == 0) &&
+           ((bnf ? d.sbk : d.sbn) % 2 == 0) && (d.strideA % 2 == 0) && (d.strideB % 2 == 0);
+}
+
 int gemm_f64(ctm_ctx* ctx, const GemmDesc& d) {
     if (d.M <= 0 || d.N <= 0 || d.batch <= 0) return CTM_OK;
     if (d.K <= 0) { ctx->set_error("gemm: K<=0"); return CTM_ERR_BADARG; }
+    // A block of chi+1 (or any 128 q + r, r <= 64) vectors times an n x n corner: the 128-row tiling would pay a whole extra
+    // tile row for the r remainder rows (M = 257: 5.2 ms instead of 2.3 ms at n = 16384).  Split it into the multiple of
+    // 128 (vectorised kernel) and an r-row strip (HBM-streaming split-K path); same for a remainder in N.
+    if (ctx->gemm_split_rem && d.batch == 1 && d.K >= 1024 && fast_operands(ctx, d)) {
+        const int rm = d.M % 128, rn = d.N % 128;
+        if (d.M > 128 && rm > 0 && rm <= 64 && rn == 0 && (long long)d.N * d.K >= (1ll << 22)) {
+            GemmDesc a = d, b = d;
+            a.M = d.M - rm; a.splitA = a.splitC = a.M;
+            b.M = rm; b.A = d.A + (long long)a.M * d.sam; b.C = d.C + (long long)a.M * d.ldc; b.splitA = b.splitC = rm;
+            int st = gemm_f64(ctx, a);
+            return st != CTM_OK ? st : gemm_f64(ctx, b);
+        }
+        if (d.N > 128 && rn > 0 && rn <= 64 && rm == 0 && (long long)d.M * d.K >= (1ll << 22)) {
+            GemmDesc a = d, b = d;
+            a.N = d.N - rn;
+            b.N = rn; b.B = d.B + (long long)a.N * d.sbn; b.C = d.C + a.N; if (d.colscale) b.colscale = d.colscale + a.N;
+            int st = gemm_f64(ctx, a);
+            return st != CTM_OK ? st : gemm_f64(ctx, b);
+        }
+    }
     ArenaScope split_scope(ctx);      // split-K partials live only until the (stream-ordered) reduce kernel
     GemmParams p;
     p.M = d.M; p.N = d.N; p.K = d.K;
@@ -334,7 +362,19 @@ int gemm_f64(ctm_ctx* ctx, const GemmDesc& d) {
     p.skip_flags = d.skip_flags;
     p.ksplit = 1; p.klen = 0; p.split_stride = 0;
     const long long tiles128 = (long long)((d.M + 127) / 128) * ((d.N + 127) / 128) * d.batch;
-    const bool small = (d.M <= 64 || d.N <= 64 || tiles128 < 200);
+    // medium-skinny products (a few hundred rows or columns against a long K): the vectorised kernel with K split so that the
+    // workgroup count is a multiple of the 256 CUs (384 tiles run as long as 512; 128 tiles leave half the chip idle).  The
+    // K split is expressed as a batch over K slices (strides klen*sak, klen*sbk) writing partial products.
+    int fast_ks = 0;
+    if (d.batch == 1 && d.M % 128 == 0 && d.N % 128 == 0 && tiles128 >= 32 && tiles128 < 1024 && d.K >= 2048 && fast_operands(ctx, d)) {
+        double best = 1e30;
+        for (int ks : {1, 2, 3, 4, 6, 8}) {
+            if (d.K % (16 * ks) != 0 || d.K / ks < 1024) continue;
+            const double cost = (double)((tiles128 * ks + 255) / 256) / ks * (ks > 1 ? 1.05 : 1.0);   // 5 %: partials + reduce pass
+            if (cost < best - 1e-9) { best = cost; fast_ks = ks; }
+        }
+    }
+    const bool small = !fast_ks && (d.M <= 64 || d.N <= 64 || tiles128 < 200);
     const int BM = small ? 64 : 128, BN = small ? 64 : 128;
     p.tilesM = (d.M + BM - 1) / BM;
     p.tilesN = (d.N + BN - 1) / BN;
@@ -347,7 +387,14 @@ int gemm_f64(ctm_ctx* ctx, const GemmDesc& d) {
     // once and are HBM-latency bound with one workgroup per CU: aim for ~4 workgroups per CU there, ~2 otherwise
     const bool strip = (d.M <= 64 || d.N <= 64);
     const int max_tiles = strip ? ctx->splitk_max_tiles : 127, target = strip ? ctx->splitk_target_wgs : 512;
-    if (d.batch == 1 && !d.offs && d.splitB_dim == 0 && d.splitA >= d.M && d.splitC >= d.M && ntile <= max_tiles && d.K >= 1024) {
+    if (fast_ks > 1) {
+        if (arena_alloc(ctx, sizeof(double) * (size_t)fast_ks * d.M * d.N, (void**)&part) != CTM_OK) return CTM_ERR_NOMEM;
+        p.K = d.K / fast_ks;
+        p.strideA = (long long)p.K * d.sak; p.strideB = (long long)p.K * d.sbk; p.strideC = (long long)d.M * d.N;
+        p.split_stride = p.strideC;
+        p.C = part; p.ldc = d.N; p.alpha = 1.0; p.beta = 0.0; p.colscale = nullptr;
+        grid.z = (unsigned)fast_ks;
+    } else if (d.batch == 1 && !d.offs && d.splitB_dim == 0 && d.splitA >= d.M && d.splitC >= d.M && ntile <= max_tiles && d.K >= 1024) {
         // partial products cost ks*M*N doubles: tiny outputs (reductions over a huge K) may split much further
         const int ks_cap = ((long long)d.M * d.N <= 4096) ? 256 : 16;
         int ks = std::min(ks_cap, std::min(target / std::max(ntile, 1), d.K / 256));
@@ -372,10 +419,8 @@ int gemm_f64(ctm_ctx* ctx, const GemmDesc& d) {
         (void)hipEventRecord(ctx->ev_pool[e0], ctx->stream);
     }
     const bool ak = d.sak == 1, amf = d.sam == 1, bnf = d.sbn == 1, bkf = d.sbk == 1;
-    const bool fast = ctx->gemm_fast && !small && !part && !d.offs && d.splitB_dim == 0 && d.splitA >= d.M && d.splitC >= d.M && !d.skip_flags &&
-                      d.M % 128 == 0 && d.N % 128 == 0 && d.K % 16 == 0 && (ak || amf) && (bnf || bkf) &&
-                      (((uintptr_t)d.A | (uintptr_t)d.B) & 15) == 0 && ((ak ? d.sam : d.sak) % 2 == 0) && ((bnf ? d.sbk : d.sbn) % 2 == 0) &&
-                      (d.strideA % 2 == 0) && (d.strideB % 2 == 0);
+    const bool fast = fast_ks > 0 || (!small && !part && d.M % 128 == 0 && d.N % 128 == 0 && fast_operands(ctx, d));
+    (void)amf; (void)bkf;
     if (fast) {
         if (ak && bnf) hipLaunchKernelGGL((gemm_f64_fast_kernel<true, true>), grid, dim3(256), 0, ctx->stream, p);
         else if (ak && !bnf) hipLaunchKernelGGL((gemm_f64_fast_kernel<true, false>), grid, dim3(256), 0, ctx->stream, p);
@@ -390,7 +435,7 @@ int gemm_f64(ctm_ctx* ctx, const GemmDesc& d) {
     if (part) {
         const long long tot = (long long)d.M * d.N;
         int blocks = (int)std::min<long long>((tot + 255) / 256, 2048);
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, ctx->stream, (const double*)part, p.ksplit, p.split_stride, d.C,
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, ctx->stream, (const double*)part, fast_ks > 1 ? fast_ks : p.ksplit, p.split_stride, d.C,
                            d.M, d.N, d.ldc, d.alpha, d.beta, d.colscale);
     }
     const double fl = 2.0 * d.M * d.N * (double)d.K * d.batch;

@@ -10,7 +10,10 @@ def dev(x):
     return torch.from_numpy(np.ascontiguousarray(x)).cuda()
 
 
-@pytest.mark.parametrize("M,N,K", [(16, 16, 4), (64, 64, 64), (128, 128, 128), (130, 70, 33), (257, 129, 515), (8, 300, 17), (512, 384, 1024), (1, 1, 1)])
+@pytest.mark.parametrize("M,N,K", [(16, 16, 4), (64, 64, 64), (128, 128, 128), (130, 70, 33), (257, 129, 515), (8, 300, 17), (512, 384, 1024), (1, 1, 1),
+                                   # K split of the vectorised kernel (few 128x128 tiles, long K); 128 q + r rows / columns split into
+                                   # a vectorised part and a strip
+                                   (128, 4096, 2048), (384, 2048, 4096), (257, 2048, 2048), (4096, 300, 1024), (300, 2048, 2048)])
 @pytest.mark.parametrize("tA", [False, True])
 @pytest.mark.parametrize("tB", [False, True])
 def test_gemm(eng, M, N, K, tA, tB):
