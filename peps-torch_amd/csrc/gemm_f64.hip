@@ -301,6 +301,121 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_fast_kernel(GemmParams p) {
         }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Strip kernel: C (M x N, M <= 64) = A (M x K, k-contiguous rows) * B, with B a large K x N operand that is read exactly
+// once -- a block of <= 64 vectors times an n x n enlarged corner in the block power / block Krylov iterations.  At
+// M <= 32 this is HBM-bound (2.15 GB of corner per pass at n = 16384), so the kernel is built to stream: no LDS, no
+// barriers; every wave loads its operands straight from global memory in MFMA operand layout with 16-byte loads and
+// keeps one 16-deep K block in flight behind the one it is multiplying.
+//   * a wave owns all TM*16 rows x 32 columns; a 16-deep K block is contracted by 4 MFMAs per tile whose k index is
+//     k = 2*(lane>>4) + t for t = 0, 1 and 8 + 2*(lane>>4) + t - 2 for t = 2, 3 (t = instruction): a lane's A operands are two
+//     16-byte loads, each covering with the 4 lanes of its row 64 contiguous bytes;
+//   * BNF (B n-contiguous, K x N row major): a lane loads the double2 B[k][c0 + 2*(lane&15) .. +1] of its four rows k(t);
+//     element 0 feeds column tile 0, element 1 column tile 1 (columns interleaved), so 16 lanes cover 256 contiguous
+//     bytes of a B row, the 4 waves of a workgroup 1 KB, and the partial results are stored as double2;
+//   * !BNF (B k-contiguous, stored N x K): same pattern as A, column tile j = columns c0 + 16 j + (lane&15);
+//   * K is split over blockIdx.y (ks slices) into partial products that the fixed-order reduce kernel sums (deterministic).
+// ---------------------------------------------------------------------------------------------------------
+struct StripParams {
+    int M, N, K;
+    const double* A; long long sam;
+    const double* B; long long ldb;          // BNF: row stride of K x N ; !BNF: row stride of N x K
+    double* P;                               // partials [ks][M][N]
+    int klen;
+};
+
+typedef double d4v __attribute__((ext_vector_type(4)));
+
+template <int TM, bool BNF>
+__global__ __launch_bounds__(256) void gemm_strip_kernel(StripParams p) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int lr = lane & 15, lk = lane >> 4;
+    const int c0 = (blockIdx.x * 4 + wid) * 32;
+    if (c0 >= p.N) return;
+    const long long kbeg = (long long)blockIdx.y * p.klen;
+    const int nblk = (int)((std::min<long long>(p.K, kbeg + p.klen) - kbeg) / 16);
+    if (nblk <= 0) return;
+
+    // k index of MFMA instruction t in a 16-deep block: k = 2*lk + t (t = 0, 1), 8 + 2*lk + (t - 2) (t = 2, 3): each 16-byte
+    // load of a k-contiguous operand then covers 64 contiguous bytes per row across the 4 lanes of that row
+    const double* ap[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) ap[i] = p.A + (long long)std::min(i * 16 + lr, p.M - 1) * p.sam + kbeg + 2 * lk;
+    const double* bp[2];
+    if (BNF) { bp[0] = p.B + (kbeg + 2 * lk) * p.ldb + c0 + 2 * lr; bp[1] = nullptr; }
+    else     { bp[0] = p.B + (long long)(c0 + lr) * p.ldb + kbeg + 2 * lk; bp[1] = bp[0] + 16 * p.ldb; }
+    const long long bstep = BNF ? 16 * p.ldb : 16;
+
+    d4 acc[TM][2];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) { acc[i][0] = (d4){0., 0., 0., 0.}; acc[i][1] = (d4){0., 0., 0., 0.}; }
+    // two register sets: the loads of block t+1 are in flight while block t is multiplied (a third set measured no faster
+    // at <= 32 rows and slower at 64 rows, where it costs a wave of occupancy)
+    d2 a0[TM][2], a1[TM][2];
+    d2 bn0[4], bn1[4];         // BNF: rows of instruction t = 0..3
+    d2 bt0[2][2], bt1[2][2];   // !BNF: [column tile j][low / high half of the block]
+
+    auto load = [&](d2 (*a)[2], d2* bn, d2 (*bt)[2]) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) { a[i][0] = *(const d2*)ap[i]; a[i][1] = *(const d2*)(ap[i] + 8); ap[i] += 16; }
+        if (BNF) {
+            bn[0] = __builtin_nontemporal_load((const d2*)bp[0]);
+            bn[1] = __builtin_nontemporal_load((const d2*)(bp[0] + p.ldb));
+            bn[2] = __builtin_nontemporal_load((const d2*)(bp[0] + 8 * p.ldb));
+            bn[3] = __builtin_nontemporal_load((const d2*)(bp[0] + 9 * p.ldb));
+            bp[0] += bstep;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                bt[j][0] = __builtin_nontemporal_load((const d2*)bp[j]);
+                bt[j][1] = __builtin_nontemporal_load((const d2*)(bp[j] + 8));
+                bp[j] += bstep;
+            }
+        }
+    };
+    auto compute = [&](const d2 (*a)[2], const d2* bn, const d2 (*bt)[2]) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const double av = a[i][t >> 1][t & 1];
+                acc[i][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, BNF ? bn[t][0] : bt[0][t >> 1][t & 1], acc[i][0], 0, 0, 0);
+                acc[i][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, BNF ? bn[t][1] : bt[1][t >> 1][t & 1], acc[i][1], 0, 0, 0);
+            }
+    };
+    load(a0, bn0, bt0);
+    int kt = 0;
+    for (; kt + 2 <= nblk; kt += 2) {
+        load(a1, bn1, bt1);
+        compute(a0, bn0, bt0);
+        if (kt + 2 < nblk) load(a0, bn0, bt0);
+        compute(a1, bn1, bt1);
+    }
+    if (kt < nblk) compute(a0, bn0, bt0);
+
+    double* P = p.P + (long long)blockIdx.y * p.M * p.N;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = i * 16 + lk + 4 * r;
+            if (m >= p.M) continue;
+            double* row = P + (long long)m * p.N + c0;
+            if (BNF) *(d2*)(row + 2 * lr) = (d2){acc[i][0][r], acc[i][1][r]};
+            else { row[lr] = acc[i][0][r]; row[16 + lr] = acc[i][1][r]; }
+        }
+}
+
+template <bool BNF>
+void launch_strip(int tm, dim3 grid, hipStream_t st, const StripParams& sp) {
+    switch (tm) {
+        case 1: hipLaunchKernelGGL((gemm_strip_kernel<1, BNF>), grid, dim3(256), 0, st, sp); break;
+        case 2: hipLaunchKernelGGL((gemm_strip_kernel<2, BNF>), grid, dim3(256), 0, st, sp); break;
+        case 3: hipLaunchKernelGGL((gemm_strip_kernel<3, BNF>), grid, dim3(256), 0, st, sp); break;
+        default: hipLaunchKernelGGL((gemm_strip_kernel<4, BNF>), grid, dim3(256), 0, st, sp); break;
+    }
+}
+
 __global__ void splitk_reduce_kernel(const double* __restrict__ part, int nsplit, long long stride, double* __restrict__ C, int M, int N,
                                      long long ldc, double alpha, double beta, const double* __restrict__ colscale) {
     const long long tot = (long long)M * N;
@@ -328,6 +443,9 @@ static bool fast_operands(const ctm_ctx* ctx, const GemmDesc& d) {
 int gemm_f64(ctm_ctx* ctx, const GemmDesc& d) {
     if (d.M <= 0 || d.N <= 0 || d.batch <= 0) return CTM_OK;
     if (d.K <= 0) { ctx->set_error("gemm: K<=0"); return CTM_ERR_BADARG; }
+    if (ctx->gemm_log)
+        fprintf(stderr, "GEMM M=%d N=%d K=%d batch=%d sam=%lld sak=%lld sbk=%lld sbn=%lld offs=%d seg=%d\n", d.M, d.N, d.K, d.batch, d.sam, d.sak, d.sbk,
+                d.sbn, d.offs ? 1 : 0, (d.splitA < d.M || d.splitC < d.M || d.splitB_dim) ? 1 : 0);
     // A block of chi+1 (or any 128 q + r, r <= 64) vectors times an n x n corner: the 128-row tiling would pay a whole extra
     // tile row for the r remainder rows (M = 257: 5.2 ms instead of 2.3 ms at n = 16384).  Split it into the multiple of
     // 128 (vectorised kernel) and an r-row strip (HBM-streaming split-K path); same for a remainder in N.
@@ -349,6 +467,33 @@ int gemm_f64(ctm_ctx* ctx, const GemmDesc& d) {
         }
     }
     ArenaScope split_scope(ctx);      // split-K partials live only until the (stream-ordered) reduce kernel
+    // a block of <= 64 k-contiguous rows times a big operand that is read once: the streaming strip kernel
+    if (ctx->gemm_strip && d.M <= 64 && d.batch == 1 && !d.offs && d.splitB_dim == 0 && d.splitA >= d.M && d.splitC >= d.M && !d.skip_flags &&
+        d.sak == 1 && (d.sbn == 1 || d.sbk == 1) && d.K % 16 == 0 && d.N % 32 == 0 && d.K >= 1024 && (long long)d.N * d.K >= (1ll << 22) &&
+        (((uintptr_t)d.A | (uintptr_t)d.B) & 15) == 0 && d.sam % 2 == 0 && (d.sbn == 1 ? d.sbk : d.sbn) % 2 == 0) {
+        const bool bnf = d.sbn == 1;
+        const int gx = (d.N / 32 + 3) / 4;
+        int ks = std::max(1, std::min(std::min((ctx->strip_target_wgs + gx - 1) / gx, d.K / 256), 64));
+        int klen = (((d.K + ks - 1) / ks) + 15) / 16 * 16;
+        ks = (d.K + klen - 1) / klen;
+        double* part;
+        if (arena_alloc(ctx, sizeof(double) * (size_t)ks * d.M * d.N, (void**)&part) != CTM_OK) return CTM_ERR_NOMEM;
+        StripParams sp;
+        sp.M = d.M; sp.N = d.N; sp.K = d.K; sp.A = d.A; sp.sam = d.sam; sp.B = d.B; sp.ldb = bnf ? d.sbk : d.sbn; sp.P = part; sp.klen = klen;
+        int e0 = timing_begin(ctx);
+        if (bnf) launch_strip<true>((d.M + 15) / 16, dim3(gx, ks), ctx->stream, sp);
+        else launch_strip<false>((d.M + 15) / 16, dim3(gx, ks), ctx->stream, sp);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) { ctx->set_error(std::string("strip gemm launch: ") + hipGetErrorString(e)); return CTM_ERR_HIP; }
+        const long long tot = (long long)d.M * d.N;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)std::min<long long>((tot + 255) / 256, 2048)), dim3(256), 0, ctx->stream,
+                           (const double*)part, ks, tot, d.C, d.M, d.N, d.ldc, d.alpha, d.beta, d.colscale);
+        const double fl = 2.0 * d.M * d.N * (double)d.K;
+        timing_end(ctx, e0, 1, fl);
+        ctx->gemm_flops += fl;
+        ctx->gemm_calls += 1;
+        return CTM_OK;
+    }
     GemmParams p;
     p.M = d.M; p.N = d.N; p.K = d.K;
     p.A = d.A; p.sam = d.sam; p.sak = d.sak;

@@ -13,7 +13,9 @@ def dev(x):
 @pytest.mark.parametrize("M,N,K", [(16, 16, 4), (64, 64, 64), (128, 128, 128), (130, 70, 33), (257, 129, 515), (8, 300, 17), (512, 384, 1024), (1, 1, 1),
                                    # K split of the vectorised kernel (few 128x128 tiles, long K); 128 q + r rows / columns split into
                                    # a vectorised part and a strip
-                                   (128, 4096, 2048), (384, 2048, 4096), (257, 2048, 2048), (4096, 300, 1024), (300, 2048, 2048)])
+                                   (128, 4096, 2048), (384, 2048, 4096), (257, 2048, 2048), (4096, 300, 1024), (300, 2048, 2048),
+                                   # streaming strip kernel (<= 64 rows times a big operand read once), every row-tile count, odd K split
+                                   (32, 4096, 1024), (64, 2048, 2048), (17, 2048, 2064), (1, 4096, 1024), (48, 2080, 2048), (33, 6400, 1040)])
 @pytest.mark.parametrize("tA", [False, True])
 @pytest.mark.parametrize("tB", [False, True])
 def test_gemm(eng, M, N, K, tA, tB):
