@@ -62,6 +62,27 @@ int dev_einsum2(ctm_ctx* ctx, const std::string& ia_, const DT& A_, const std::s
     for (char ch : fA) if (fB.find(ch) != std::string::npos) { ctx->set_error("einsum2: batch index unsupported"); return CTM_ERR_UNSUPPORTED; }
     if (cA.empty()) { ctx->set_error("einsum2: outer product unsupported"); return CTM_ERR_UNSUPPORTED; }
 
+    // The requested output order is the natural one (free of A, free of B) up to a permutation INSIDE each group, and the
+    // result is bigger than the operands: permute the (small) operands so that the GEMM writes the requested layout directly
+    // instead of permuting the (large) result afterwards.
+    if (ctx->einsum_in_relayout && io != fA + fB && io.size() == fA.size() + fB.size()) {
+        const std::string ga = io.substr(0, fA.size()), gb = io.substr(fA.size());
+        auto is_perm = [](std::string a, std::string b) { std::sort(a.begin(), a.end()); std::sort(b.begin(), b.end()); return a == b; };
+        long long mn = 1;
+        for (char ch : fA) mn *= dim_of(ia, A, ch);
+        for (char ch : fB) mn *= dim_of(ib, B, ch);
+        if (is_perm(ga, fA) && is_perm(gb, fB) && A.numel() + B.numel() <= mn) {
+            const bool a_fits = (ia == ga + cA || ia == cA + ga), b_fits_a = (ib == cA + gb || ib == gb + cA);
+            const bool a_fits_b = (ia == ga + cB || ia == cB + ga), b_fits = (ib == cB + gb || ib == gb + cB);
+            // contraction-index order: the one that leaves the larger operand untouched if possible
+            std::string kord = cA;
+            if (!(a_fits && b_fits_a) && ((a_fits_b && b_fits) || (!a_fits && b_fits && B.numel() >= A.numel()))) kord = cB;
+            if (!(ia == ga + kord || ia == kord + ga)) { DT An; const std::string to = ga + kord; CTM_TRY(relayout(ctx, ia, A, to, &An)); A = An; ia = to; }
+            if (!(ib == kord + gb || ib == gb + kord)) { DT Bn; const std::string to = kord + gb; CTM_TRY(relayout(ctx, ib, B, to, &Bn)); B = Bn; ib = to; }
+            cA = kord; cB = kord; fA = ga; fB = gb;
+        }
+    }
+
     bool A_ok = is_prefix(ia, cA) || is_suffix(ia, cA);
     bool B_ok = is_prefix(ib, cB) || is_suffix(ib, cB);
     std::string korder;
@@ -165,6 +186,20 @@ int dev_network(ctm_ctx* ctx, const std::string& expr, const std::vector<DT>& op
         std::string nidx;
         for (char ch : zidx + ins[i]) if (need.find(ch) != std::string::npos && nidx.find(ch) == std::string::npos) nidx += ch;
         zidx = nidx;
+    }
+    // The fused kernel gathers, per spectator pair (x,y), the block of the four site-contracted indices: it wants those to be
+    // the fast-running ones.  If the natural order ends on a spectator index (e.g. LD corner "xlL"+"dDy", every absorb
+    // "bcd"+"ije"), move the spectators of the last operand's group to the front of that group -- the GEMM that produces Z
+    // then writes 64-double runs per (x,y) instead of one element per cache line (dev_einsum2 permutes the small operand).
+    if (ctx->z_spectators_first && k >= 2 && zidx.size() == 6) {
+        auto is_site = [&](char ch) { return ins[k].find(ch) != std::string::npos || ins[k + 1].find(ch) != std::string::npos; };
+        if (!is_site(zidx.back())) {
+            size_t g0 = zidx.size();                   // start of the group contributed by the last prefix operand
+            while (g0 > 0 && ins[k - 1].find(zidx[g0 - 1]) != std::string::npos) --g0;
+            std::string head = zidx.substr(0, g0), spect, site;
+            for (char ch : zidx.substr(g0)) (is_site(ch) ? site : spect) += ch;
+            if (!site.empty()) zidx = head + spect + site;
+        }
     }
     DT Z;
     if (k == 1) Z = ops[0];

@@ -75,6 +75,8 @@ struct ctm_ctx {
     long layer2_calls = 0;
     bool use_layer2 = true;
     bool gemm_fast = true;
+    bool einsum_in_relayout = true, z_spectators_first = true;   // layout of the fused two-layer kernel's input (contract.hip)
+    bool ld_swap = false;          // LD corner: contract T2 before T1 (layout of the two-layer kernel's input)
     bool gemm_log = false;        // debug: print every GEMM shape to stderr
     bool gemm_strip = true;       // streaming kernel for <= 64 rows times a big operand
     int strip_target_wgs = 1024;

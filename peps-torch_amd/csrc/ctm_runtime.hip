@@ -109,6 +109,9 @@ int ctm_set_option(ctm_ctx* ctx, const char* key, double value) {
     else if (k == "use_layer2") ctx->use_layer2 = value != 0.0;
     else if (k == "layer2_dbg") ctx->layer2_dbg = (int)value;
     else if (k == "gemm_fast") ctx->gemm_fast = value != 0.0;
+    else if (k == "einsum_in_relayout") ctx->einsum_in_relayout = value != 0.0;
+    else if (k == "z_spectators_first") ctx->z_spectators_first = value != 0.0;
+    else if (k == "ld_swap") ctx->ld_swap = value != 0.0;
     else if (k == "gemm_log") ctx->gemm_log = value != 0.0;
     else if (k == "gemm_strip") ctx->gemm_strip = value != 0.0;
     else if (k == "strip_target_wgs") ctx->strip_target_wgs = (int)value;

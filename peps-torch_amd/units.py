@@ -10,6 +10,7 @@ event, so each phase is bracketed by full cross-stream barriers (which also make
 cached blocks safe: tensors are only released at phase boundaries)."""
 import threading
 from concurrent.futures import ThreadPoolExecutor
+import os
 import torch
 import backend
 
@@ -68,6 +69,7 @@ def pool_for(engine, nunits, n, is_complex, est_bytes=None):
     total = torch.cuda.get_device_properties(engine.device).total_memory
     est = est_bytes if est_bytes is not None else 14.0 * n * n * 8 * (2 if is_complex else 1)   # corners, products, work
     nw = int(min(nunits, max(1, (0.5 * total) // max(est, 1.0))))
+    nw = min(nw, int(os.environ.get("CTM_MAX_CONCURRENT_UNITS", nw)))       # experiment knob
     if nw < 2:
         return None
     key = (engine.device.index, nw)
