@@ -209,6 +209,16 @@ void proj_scale(const TruncOut& to, int kc, double reltol, std::vector<double>* 
 // out (n x kc) = opA(cA) * ( opB(cB) * rows^T[^H] ) * diag(scale)   with rows = k x n row factors (kc leading ones used)
 // Only the first `ncol` columns carry a non-zero scale (S/S[0] > reltol is a prefix of the descending spectrum): the others
 // are exact zeros of the result (as in the reference, ctm_projectors.py:266-283) and are not computed.
+// out (n x ldo, first ncol columns) = in^T (in: ncol x n) with column j scaled by scale[j]
+__global__ void transpose_scale_kernel(const double* __restrict__ in, int ncol, int n, double* __restrict__ out, long long ldo,
+                                       const double* __restrict__ scale) {
+    const long long tot = (long long)n * ncol;
+    for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < tot; q += (long long)gridDim.x * blockDim.x) {
+        const long long i = q / ncol; const int j = (int)(q - i * ncol);
+        out[i * ldo + j] = in[(long long)j * n + i] * (scale ? scale[j] : 1.0);
+    }
+}
+
 int corner_chain_times_rowsT(ctm_ctx* ctx, int n, int mid, int k, int kc, int ncol, const DT& cA, bool tA, const DT& cB, bool tB, const double* rows,
                              bool conj_rows, const double* d_scale, const DT& out) {
     // opA(cA) is n x mid, opB(cB) is mid x n (stored transposed when the flag is set)
@@ -216,6 +226,27 @@ int corner_chain_times_rowsT(ctm_ctx* ctx, int n, int mid, int k, int kc, int nc
     CTM_TRY(fill_f64(ctx, out.p, (size_t)n * kc * (out.q ? 2 : 1), 0.0));      // planes are adjacent
     if (out.q && out.q != out.p + (size_t)n * kc) CTM_TRY(fill_f64(ctx, out.q, (size_t)n * kc, 0.0));
     if (ncol <= 0) return CTM_OK;
+    if (!ctx->cplx && ncol <= 64 && ctx->chain_as_strips) {
+        // few significant columns: keep them as ROWS so that both corner passes are (ncol x n)(n x n) strips -- the streaming
+        // kernel reads each corner once at HBM speed -- and transpose the small result at the end
+        //   t1^T (ncol x mid) = rows opB(cB)^T ;  out^T (ncol x n) = t1^T opA(cA)^T
+        double *t1t, *ot;
+        CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)ncol * mid, (void**)&t1t));
+        CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)ncol * n, (void**)&ot));
+        auto pass = [&](const double* X, int kin, int nout, const DT& Z, bool transZ, double* Y) {
+            // Y (ncol x nout) = X (ncol x kin) op(Z); Z stored kin x nout (transZ == false) or nout x kin
+            GemmDesc g; g.M = ncol; g.N = nout; g.K = kin; g.A = X; g.sam = kin; g.sak = 1; g.B = Z.p;
+            if (transZ) { g.sbk = 1; g.sbn = kin; } else { g.sbk = nout; g.sbn = 1; }
+            g.C = Y; g.ldc = nout;
+            return gemm_f64(ctx, g);
+        };
+        CTM_TRY(pass(rows, n, mid, cB, !tB, t1t));
+        CTM_TRY(pass(t1t, mid, n, cA, !tA, ot));
+        const long long tot = (long long)n * ncol;
+        hipLaunchKernelGGL(transpose_scale_kernel, dim3((int)std::min<long long>((tot + 255) / 256, 2048)), dim3(256), 0, ctx->stream,
+                           (const double*)ot, ncol, n, out.p, (long long)kc, d_scale);
+        return CTM_OK;
+    }
     DT t1;
     CTM_TRY(alloc_dt(ctx, {mid, ncol}, &t1));
     XM r; r.re = rows; r.im = ctx->cplx ? rows + (size_t)k * n : nullptr; r.ld = n; r.t = true; r.c = conj_rows;

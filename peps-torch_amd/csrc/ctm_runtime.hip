@@ -111,6 +111,7 @@ int ctm_set_option(ctm_ctx* ctx, const char* key, double value) {
     else if (k == "gemm_fast") ctx->gemm_fast = value != 0.0;
     else if (k == "einsum_in_relayout") ctx->einsum_in_relayout = value != 0.0;
     else if (k == "z_spectators_first") ctx->z_spectators_first = value != 0.0;
+    else if (k == "chain_as_strips") ctx->chain_as_strips = value != 0.0;
     else if (k == "ld_swap") ctx->ld_swap = value != 0.0;
     else if (k == "gemm_log") ctx->gemm_log = value != 0.0;
     else if (k == "gemm_strip") ctx->gemm_strip = value != 0.0;
