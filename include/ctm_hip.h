@@ -50,13 +50,13 @@ int ctm_sync(ctm_ctx* ctx);
 int ctm_trim(ctm_ctx* ctx);   /* release the context's workspace arena (regrown on demand); call between engine calls */
 int ctm_set_option(ctm_ctx* ctx, const char* key, double value);
 /*   truncation:  "jacobi_tol","jacobi_max_sweeps","jacobi_block","jacobi_inner_sweeps","jacobi_verbose","eig64_pingpong",
- *                "si_enable","si_min_n","si_max_iter","si_tol","si_rr_sweeps","rank_tol","lz_enable","lz_min_k","lz_switch_steps"
+ *                "si_enable","si_min_n","si_max_iter","si_tol","si_rr_sweeps","si_warm_skip_calls","rank_tol","lz_enable","lz_min_k","lz_switch_steps"
  *   kernels:     "use_layer2","layer2_reg","layer2_cplx","gemm_fast","gemm_strip","strip_target_wgs","gemm_split_rem",
  *                "splitk_max_tiles","splitk_target_wgs","einsum_in_relayout","z_spectators_first","chain_as_strips","gemm_log"
  *   measurement: "gemm_timing","profile"                                                                                      */
 int ctm_get_stat(ctm_ctx* ctx, const char* key, double* value);
 /*   "last_sweeps","last_offnorm","total_sweeps","jacobi_calls","si_hits","si_fallbacks","si_total_iters","si_last_iters",
- *   "si_last_rank","si_warm_starts","lz_hits","lz_total_steps","gemm_flops","gemm_calls","layer2_flops","layer2_calls",
+ *   "si_last_rank","si_warm_starts","si_warm_skips","lz_hits","lz_total_steps","gemm_flops","gemm_calls","layer2_flops","layer2_calls",
  *   "arena_high","k_ms0|1|2","k_flops0|1|2","k_calls0|1|2"                                                                   */
 int ctm_timers(ctm_ctx* ctx, double* out8, int reset);             /* corners,halves,svd,proj,absorb,norm,rdm,eig (s) */
 /* GEMM launches timed with HIP events while the option "gemm_timing" is on: quadruples (kind, start_ms, end_ms, flops) on a
@@ -105,8 +105,8 @@ int ctm_projectors(ctm_ctx* ctx, const double* R, const double* Rt, int n, int c
  * decomposition).  tensors16 / adims4x5 as for ctm_halves. */
 int ctm_projectors_4x4(ctm_ctx* ctx, int dir, const double* const* tensors16, int chi, const int* adims4x5,
                        const ctm_trunc_cfg* cfg, double* P, double* Pt, double* S);
-/* Same, warm started: `basis` is an opaque caller-owned device workspace of min(chi+1,n) * n doubles (twice that for
- * CTM_C128), zero-filled before the first call and passed again for the same (direction, site) on later sweeps.  It carries
+/* Same, warm started: `basis` is an opaque caller-owned device workspace of (min(chi+1,n) + 1) * n doubles (CTM_C128:
+ * (2 min(chi+1,n) + 1) * n; the last row is a header the engine keeps its start-up policy in), zero-filled before the first call and passed again for the same (direction, site) on later sweeps.  It carries
  * the right singular row basis of the previous call: the leading-chi iteration starts from it instead of a random block
  * (the result is residual-verified either way, so a stale or zero basis only costs iterations).  basis == NULL: cold. */
 int ctm_projectors_4x4_ws(ctm_ctx* ctx, int dir, const double* const* tensors16, int chi, const int* adims4x5,

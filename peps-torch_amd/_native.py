@@ -375,7 +375,7 @@ class Engine:
     def warm_basis(self, chi, n, dtype):
         """Zero-filled warm-start workspace for projectors_4x4(..., basis=) of one (direction, site) unit."""
         k = chi + 1 if chi < n else n
-        return torch.zeros((2 if dtype.is_complex else 1) * k, n, dtype=torch.float64, device=self.device)
+        return torch.zeros((2 if dtype.is_complex else 1) * k + 1, n, dtype=torch.float64, device=self.device)   # + header row
 
     def projectors_4x4(self, direction, tensors16, chi, cfg=None, return_S=False, basis=None):
         """Fused corners -> implicit R^T Rt -> leading-chi triplets -> P, Pt (never forms the n x n halves).
@@ -390,7 +390,7 @@ class Engine:
         if basis is not None:
             k = chi + 1 if chi < n else n
             if not (basis.is_cuda and basis.dtype == torch.float64 and basis.is_contiguous()
-                    and tuple(basis.shape) == ((2 if ts[0].dtype.is_complex else 1) * k, n)):
+                    and tuple(basis.shape) == ((2 if ts[0].dtype.is_complex else 1) * k + 1, n)):
                 raise NativeError("projectors_4x4: basis must come from warm_basis(chi, n, dtype)")
         self._ck(self.lib.ctm_projectors_4x4_ws(self.h, d, arr, chi, ad, C.byref(cfg), _ptr(P), _ptr(Pt), _ptr(S),
                                                 _ptr(basis) if basis is not None else None), "projectors_4x4")

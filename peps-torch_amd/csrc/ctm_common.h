@@ -54,6 +54,8 @@ struct ctm_ctx {
     // leading-k block power iteration (svd_iter): enabled for n >= si_min_n, residual tolerance relative to s_0
     bool si_enable = true;
     int si_min_n = 512, si_max_iter = 40, si_last_iters = 0, si_rr_sweeps = 40, si_last_rank = 0;
+    int si_warm_skip_calls = 3;   // after a hopeless warm start (residual > 1e-6 s0): calls of that workspace that start cold
+    long si_warm_skips = 0;
     double si_tol = 2e-14;
     double rank_tol = 5e-13;             // numerical-rank threshold of the leading-k solvers (relative to s_0)
     long si_hits = 0, si_fallbacks = 0, si_total_iters = 0, si_warm_starts = 0;
@@ -198,6 +200,7 @@ struct MatOp {
     // optional warm start (in/out): k x n row basis (planar for complex128) of the right singular vectors of a nearby
     // operator; rows the caller does not have are zero.  Overwritten with this decomposition's right row factor.
     double* warm = nullptr;
+    double* warm_hdr = nullptr;   // optional n-double header row of the warm workspace: [0] = calls left to skip the warm start
 };
 // complex128 operators: Ut, Vt are planar (re plane k x n, then im plane), rows = u_k^H, v_k^H
 int jacobi_svd_top_op(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* Ut, double* Vt);

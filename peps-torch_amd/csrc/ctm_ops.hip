@@ -612,6 +612,7 @@ int ctm_projectors_4x4_ws(ctm_ctx* ctx, int dir, const double* const* t, int chi
     for (int i = 0; i < 4; ++i) { op.c[i] = c[i].p; op.ci[i] = c[i].q; op.t[i] = tr[i]; }
     op.mid[0] = (int)mid0; op.mid[1] = (int)mid1;
     op.warm = basis;
+    op.warm_hdr = basis ? basis + (size_t)cz * k * n : nullptr;      // header row behind the basis (see ctm_hip.h)
     TruncOut to;
     { PhaseTimer pt(ctx, CTM_T_SVD); CTM_TRY(svd_rows_op(ctx, op, chi, cfg, Ut, Vt, dS, &to)); }
     PhaseTimer pt(ctx, CTM_T_PROJ);

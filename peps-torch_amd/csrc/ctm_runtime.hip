@@ -113,6 +113,7 @@ int ctm_set_option(ctm_ctx* ctx, const char* key, double value) {
     else if (k == "z_spectators_first") ctx->z_spectators_first = value != 0.0;
     else if (k == "chain_as_strips") ctx->chain_as_strips = value != 0.0;
     else if (k == "ld_swap") ctx->ld_swap = value != 0.0;
+    else if (k == "si_warm_skip_calls") ctx->si_warm_skip_calls = (int)value;
     else if (k == "gemm_log") ctx->gemm_log = value != 0.0;
     else if (k == "gemm_strip") ctx->gemm_strip = value != 0.0;
     else if (k == "strip_target_wgs") ctx->strip_target_wgs = (int)value;
@@ -148,6 +149,7 @@ int ctm_get_stat(ctm_ctx* ctx, const char* key, double* value) {
     else if (k == "si_last_iters") *value = (double)ctx->si_last_iters;
     else if (k == "si_total_iters") *value = (double)ctx->si_total_iters;
     else if (k == "si_last_rank") *value = (double)ctx->si_last_rank;
+    else if (k == "si_warm_skips") *value = (double)ctx->si_warm_skips;
     else if (k == "si_warm_starts") *value = (double)ctx->si_warm_starts;
     else if (k == "lz_hits") *value = (double)ctx->lz_hits;
     else if (k == "lz_total_steps") *value = (double)ctx->lz_total_steps;

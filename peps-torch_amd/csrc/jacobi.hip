@@ -897,11 +897,16 @@ int svd_iter(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* Ut, double
     // pseudo-random basis (need not be orthonormal)
     int kw = 0;
     if (op.warm) {
+        double hdr = 0.0;
         CTM_TRY(row_norms(ctx, op.warm, k, n, n, norms));
         CTM_HIP_CHECK(ctx, hipMemcpyAsync(h.data(), norms, sizeof(double) * std::min(k, p_full), hipMemcpyDeviceToHost, ctx->stream));
+        if (op.warm_hdr) CTM_HIP_CHECK(ctx, hipMemcpyAsync(&hdr, op.warm_hdr, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
         while (kw < std::min(k, p_full) && std::fabs(h[kw] - 1.0) < 1e-6) ++kw;
         std::fill(h.begin(), h.end(), 0.0);
+        // the last warm start of this workspace was hopeless (residual O(s0): the gauge of the environment legs keeps
+        // changing between sweeps): do not pay for a full-block probe again for a few calls
+        if (hdr >= 1.0 && want_krylov) { kw = 0; CTM_TRY(fill_f64(ctx, op.warm_hdr, 1, hdr - 1.0)); ctx->si_warm_skips += 1; }
     }
     if (kw > 0) {
         // a FULL warm basis (the previous decomposition had at least k significant triplets) starts with the full block, so a
@@ -968,6 +973,7 @@ int svd_iter(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* Ut, double
             // observed contraction and hand over to the block Krylov solver when many are left
             if (want_krylov && ctx->lz_enable && k >= ctx->lz_min_k && !exhausted && warm && it == 1 && worst > 1e-9 * s0) {
                 // a warm basis that is not close (environment still changing) on a full-rank problem: block Krylov straight away
+                if (op.warm_hdr && worst > 1e-6 * s0) CTM_TRY(fill_f64(ctx, op.warm_hdr, 1, (double)ctx->si_warm_skip_calls));
                 *want_krylov = true; ctx->si_last_iters = it; ctx->si_total_iters += it; return CTM_OK;
             }
             if (want_krylov && ctx->lz_enable && k >= ctx->lz_min_k && !exhausted && worst_prev > 0.0 && worst < worst_prev) {
@@ -1229,11 +1235,14 @@ int svd_iter_c(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* Ut, doub
     int kw = 0;
     const size_t wkn = (size_t)k * n;
     if (op.warm) {
+        double hdr = 0.0;
         CTM_TRY(row_norms_c128(ctx, op.warm, op.warm + wkn, std::min(k, p_full), n, n, norms));
         CTM_HIP_CHECK(ctx, hipMemcpyAsync(h.data(), norms, sizeof(double) * std::min(k, p_full), hipMemcpyDeviceToHost, ctx->stream));
+        if (op.warm_hdr) CTM_HIP_CHECK(ctx, hipMemcpyAsync(&hdr, op.warm_hdr, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
         while (kw < std::min(k, p_full) && std::fabs(h[kw] - 1.0) < 1e-6) ++kw;
         std::fill(h.begin(), h.end(), 0.0);
+        if (hdr >= 1.0 && want_krylov) { kw = 0; CTM_TRY(fill_f64(ctx, op.warm_hdr, 1, hdr - 1.0)); ctx->si_warm_skips += 1; }   // see svd_iter()
     }
     if (kw > 0) {
         p = (kw >= k) ? p_full : std::min(p_full, std::max(64, ((kw + 16 + 63) / 64) * 64));
@@ -1295,6 +1304,7 @@ int svd_iter_c(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* Ut, doub
             if (worst <= resid_tol(ctx, n) * s0) { *converged = true; break; }
             if (want_krylov && ctx->lz_enable && k >= ctx->lz_min_k && !exhausted) {        // same hand-over rules as svd_iter()
                 bool sw = warm && it == 1 && worst > 1e-9 * s0;
+                if (sw && op.warm_hdr && worst > 1e-6 * s0) CTM_TRY(fill_f64(ctx, op.warm_hdr, 1, (double)ctx->si_warm_skip_calls));
                 if (!sw && worst_prev > 0.0 && worst < worst_prev)
                     sw = std::log(resid_tol(ctx, n) * s0 / worst) / std::log(worst / worst_prev) > ctx->lz_switch_steps;
                 else if (!sw && worst_prev > 0.0 && it >= 6) sw = true;

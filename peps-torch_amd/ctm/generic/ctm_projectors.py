@@ -35,7 +35,7 @@ def ctm_get_projectors_4x4(direction, coord, state, env, ctm_args=cfg.ctm_args, 
             key = (direction, coord)
             k = env.chi + 1 if env.chi < n else n
             b = ws.get(key)
-            if b is None or b.shape[1] != n or b.shape[0] != (2 if a.dtype.is_complex else 1) * k or b.device != a.device:
+            if b is None or b.shape[1] != n or b.shape[0] != (2 if a.dtype.is_complex else 1) * k + 1 or b.device != a.device:
                 b = ws[key] = eng.warm_basis(env.chi, n, a.dtype)
             basis = b
         return eng.projectors_4x4(direction, t16, env.chi, _trunc_cfg(eng, ctm_args), basis=basis)
