@@ -31,7 +31,7 @@ def _worker(rank, world, port, out_dir, name):
     st = IPEPS({k: torch.from_numpy(v.copy()) for k, v in sites_from(g).items()})
     env = ENV(8, st)
     init_env(st, env)
-    assert parallel.is_distributed() and len(parallel.my_units(list(st.sites))) == 2
+    assert parallel.is_distributed() and len(parallel.my_units(list(st.sites))) == len([i for i in range(4) if i % world == rank])
     for _ in range(2):
         for d in cfg.ctm_args.ctm_move_sequence:
             for _r in range(2):
@@ -44,14 +44,19 @@ def _worker(rank, world, port, out_dir, name):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("name", ["generic_D2_chi8_f64", "generic_D2_chi8_c128"])
-def test_sharded_move_equals_single_process(tmp_path, name):
+# world 2: two sites per rank (one stacked all-gather per phase); world 3: uneven ownership (per-site broadcasts);
+# world 5: more ranks than sites (rank 4 owns nothing -- the 8-GPU case of a 4-site cell)
+@pytest.mark.parametrize("name,world", [("generic_D2_chi8_f64", 2), ("generic_D2_chi8_c128", 2), ("generic_D2_chi8_f64", 3),
+                                        ("generic_D2_chi8_c128", 5)])
+def test_sharded_move_equals_single_process(tmp_path, name, world):
     import socket
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    mp.spawn(_worker, args=(2, port, str(tmp_path), name), nprocs=2, join=True)
-    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
-    for k in r0.files:
-        assert np.array_equal(r0[k], r1[k]), k          # replicated env identical on both ranks
+    mp.spawn(_worker, args=(world, port, str(tmp_path), name), nprocs=world, join=True)
+    r0 = np.load(tmp_path / "rank0.npz")
+    for r in range(1, world):
+        r1 = np.load(tmp_path / f"rank{r}.npz")
+        for k in r0.files:
+            assert np.array_equal(r0[k], r1[k]), (r, k)          # replicated env identical on all ranks
     # single-process oracle reference
     from conftest import golden
     from helpers_cpu import sites_from
