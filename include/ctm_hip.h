@@ -56,7 +56,7 @@ int ctm_set_option(ctm_ctx* ctx, const char* key, double value);
  *   measurement: "gemm_timing","profile"                                                                                      */
 int ctm_get_stat(ctm_ctx* ctx, const char* key, double* value);
 /*   "last_sweeps","last_offnorm","total_sweeps","jacobi_calls","si_hits","si_fallbacks","si_total_iters","si_last_iters",
- *   "si_last_rank","si_warm_starts","si_warm_skips","lz_hits","lz_total_steps","gemm_flops","gemm_calls","layer2_flops","layer2_calls",
+ *   "si_last_rank","si_warm_starts","si_warm_skips","corner_cache_hits","lz_hits","lz_total_steps","gemm_flops","gemm_calls","layer2_flops","layer2_calls",
  *   "arena_high","k_ms0|1|2","k_flops0|1|2","k_calls0|1|2"                                                                   */
 int ctm_timers(ctm_ctx* ctx, double* out8, int reset);             /* corners,halves,svd,proj,absorb,norm,rdm,eig (s) */
 /* GEMM launches timed with HIP events while the option "gemm_timing" is on: quadruples (kind, start_ms, end_ms, flops) on a
@@ -111,6 +111,16 @@ int ctm_projectors_4x4(ctm_ctx* ctx, int dir, const double* const* tensors16, in
  * (the result is residual-verified either way, so a stale or zero basis only costs iterations).  basis == NULL: cold. */
 int ctm_projectors_4x4_ws(ctm_ctx* ctx, int dir, const double* const* tensors16, int chi, const int* adims4x5,
                           const ctm_trunc_cfg* cfg, double* P, double* Pt, double* S, double* basis);
+/* Same with caller-kept enlarged corners.  corner_buf: NULL, or four device buffers (NULL entries allowed) of n0*n1 doubles
+ * (twice that for CTM_C128; 16-byte aligned; engine-internal layout, opaque) for the four corners in tensors16 order;
+ * corner_valid[i] != 0: buffer i holds that corner as computed by an earlier call from the SAME (C, T1, T2, a) -- it is used
+ * as it is; otherwise the corner is computed into the buffer.  An enlarged corner only depends on its own corner matrix and
+ * two T tensors, and a directional move replaces two corner matrices and one T per site (ctmrg.py:302-319): the corners of
+ * the opposite side stay valid, i.e. half of the reference's corner contractions (ctm_components.py:10-265 rebuilds all
+ * four in every move) are repeats.  The host layer keeps the buffers with the environment and checks tensor identity. */
+int ctm_projectors_4x4_cc(ctm_ctx* ctx, int dir, const double* const* tensors16, int chi, const int* adims4x5,
+                          const ctm_trunc_cfg* cfg, double* P, double* Pt, double* S, double* basis,
+                          double* const* corner_buf, const int* corner_valid);
 /* absorb_truncate_CTM_MOVE_<DIR>_c (ctmrg.py:343-438,459-564,585-680,701-804), 'sl' mode, followed by
  * move_normalize_c (ctmrg.py:210-230): normalize = 0 none, 1 'inf' (max-abs), 2 vector 2-norm.
  * tensors10 = C1,T1,T,T2,C2,A,P2,Pt2,P1,Pt1 */

@@ -53,6 +53,8 @@ _SIGS = {
     "ctm_projectors": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(TruncCfg), C.c_void_p, C.c_void_p, C.c_void_p],
     "ctm_projectors_4x4": [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_int), C.POINTER(TruncCfg), C.c_void_p, C.c_void_p, C.c_void_p],
     "ctm_projectors_4x4_ws": [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_int), C.POINTER(TruncCfg), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
+    "ctm_projectors_4x4_cc": [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_int), C.POINTER(TruncCfg), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                              C.POINTER(C.c_void_p), C.POINTER(C.c_int)],
     "ctm_absorb": [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_int), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p],
     "ctm_absorb_x": [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p],
     "ctm_c2x2_c4v": [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p],
@@ -377,9 +379,17 @@ class Engine:
         k = chi + 1 if chi < n else n
         return torch.zeros((2 if dtype.is_complex else 1) * k + 1, n, dtype=torch.float64, device=self.device)   # + header row
 
-    def projectors_4x4(self, direction, tensors16, chi, cfg=None, return_S=False, basis=None):
+    def corner_numel(self, corner, C_, a):
+        """Doubles of an opaque corner buffer for projectors_4x4(corners=...): n0 * n1 (twice that for complex128)."""
+        chi = C_.shape[0]
+        leg0 = (3, 2, 1, 1)[corner]; leg1 = (4, 3, 2, 4)[corner]
+        return chi * a.shape[leg0] ** 2 * chi * a.shape[leg1] ** 2 * (2 if C_.dtype.is_complex else 1)
+
+    def projectors_4x4(self, direction, tensors16, chi, cfg=None, return_S=False, basis=None, corners=None):
         """Fused corners -> implicit R^T Rt -> leading-chi triplets -> P, Pt (never forms the n x n halves).
-        basis: optional warm-start workspace (see warm_basis), updated in place."""
+        basis: optional warm-start workspace (see warm_basis), updated in place.
+        corners: optional list of four (buffer, valid) pairs -- float64 device buffers of corner_numel() doubles kept by the
+        caller; valid=True: the buffer holds that enlarged corner from an earlier call with the same input tensors."""
         ts, arr, ad = self._pack16(tensors16)
         d = DIR_INDEX[direction] if isinstance(direction, tuple) else direction
         chi_env = ts[0].shape[0]
@@ -392,8 +402,15 @@ class Engine:
             if not (basis.is_cuda and basis.dtype == torch.float64 and basis.is_contiguous()
                     and tuple(basis.shape) == ((2 if ts[0].dtype.is_complex else 1) * k + 1, n)):
                 raise NativeError("projectors_4x4: basis must come from warm_basis(chi, n, dtype)")
-        self._ck(self.lib.ctm_projectors_4x4_ws(self.h, d, arr, chi, ad, C.byref(cfg), _ptr(P), _ptr(Pt), _ptr(S),
-                                                _ptr(basis) if basis is not None else None), "projectors_4x4")
+        cb = cv = None
+        if corners is not None:
+            for buf, _ in corners:
+                if buf is not None and not (buf.is_cuda and buf.dtype == torch.float64 and buf.is_contiguous()):
+                    raise NativeError("projectors_4x4: corner buffers must be contiguous float64 device tensors")
+            cb = (C.c_void_p * 4)(*[(_ptr(buf) if buf is not None else None) for buf, _ in corners])
+            cv = (C.c_int * 4)(*[int(bool(v)) for _, v in corners])
+        self._ck(self.lib.ctm_projectors_4x4_cc(self.h, d, arr, chi, ad, C.byref(cfg), _ptr(P), _ptr(Pt), _ptr(S),
+                                                _ptr(basis) if basis is not None else None, cb, cv), "projectors_4x4")
         return (P, Pt, S) if return_S else (P, Pt)
 
     # axis of the NEW (truncated) bond in nC1 / nC2 per direction (output index order of the absorb contractions)

@@ -56,6 +56,7 @@ struct ctm_ctx {
     int si_min_n = 512, si_max_iter = 40, si_last_iters = 0, si_rr_sweeps = 40, si_last_rank = 0;
     int si_warm_skip_calls = 3;   // after a hopeless warm start (residual > 1e-6 s0): calls of that workspace that start cold
     long si_warm_skips = 0;
+    long corner_cache_hits = 0;
     double si_tol = 2e-14;
     double rank_tol = 5e-13;             // numerical-rank threshold of the leading-k solvers (relative to s_0)
     long si_hits = 0, si_fallbacks = 0, si_total_iters = 0, si_warm_starts = 0;

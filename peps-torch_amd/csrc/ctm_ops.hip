@@ -569,6 +569,11 @@ int ctm_projectors_4x4(ctm_ctx* ctx, int dir, const double* const* t, int chi, c
 
 int ctm_projectors_4x4_ws(ctm_ctx* ctx, int dir, const double* const* t, int chi, const int* adims4x5, const ctm_trunc_cfg* cfg_,
                           double* P, double* Pt, double* S_out, double* basis) {
+    return ctm_projectors_4x4_cc(ctx, dir, t, chi, adims4x5, cfg_, P, Pt, S_out, basis, nullptr, nullptr);
+}
+
+int ctm_projectors_4x4_cc(ctm_ctx* ctx, int dir, const double* const* t, int chi, const int* adims4x5, const ctm_trunc_cfg* cfg_,
+                          double* P, double* Pt, double* S_out, double* basis, double* const* corner_buf, const int* corner_valid) {
     const ctm_trunc_cfg cfg = cfg_ ? *cfg_ : kDefaultCfg;
     if (dir < 0 || dir > 3) { ctx->set_error("projectors_4x4: bad direction"); return CTM_ERR_BADARG; }
     ArenaScope scope(ctx);
@@ -596,7 +601,16 @@ int ctm_projectors_4x4_ws(ctm_ctx* ctx, int dir, const double* const* t, int chi
     {
         PhaseTimer pt(ctx, CTM_T_CORNERS);
         for (int i = 0; i < 4; ++i) {
-            CTM_TRY(alloc_dt(ctx, {d0[i], d1[i]}, &c[i]));
+            // caller-owned corner buffers (opaque, engine-internal layout): a valid one is used as it is, an invalid one is
+            // (re)computed in place for the caller to keep -- an enlarged corner only changes when one of ITS three
+            // environment tensors does, i.e. two of the four corner types survive every directional move
+            double* ext = corner_buf ? corner_buf[i] : nullptr;
+            if (ext) {
+                if (((uintptr_t)ext & 15) != 0) { ctx->set_error("projectors_4x4: corner buffers must be 16-byte aligned"); return CTM_ERR_BADARG; }
+                c[i].p = ext; c[i].q = ctx->cplx ? ext + d0[i] * d1[i] : nullptr; c[i].dims = {d0[i], d1[i]}; c[i].cj = false;
+                if (corner_valid && corner_valid[i]) { ctx->corner_cache_hits += 1; continue; }
+            } else
+                CTM_TRY(alloc_dt(ctx, {d0[i], d1[i]}, &c[i]));
             ArenaScope s2(ctx);
             CornerIn ci;
             CTM_TRY(corner_in(io, t + 4 * i, chi, adims4x5 + 5 * i, cid[i], &ci));

@@ -150,6 +150,7 @@ int ctm_get_stat(ctm_ctx* ctx, const char* key, double* value) {
     else if (k == "si_total_iters") *value = (double)ctx->si_total_iters;
     else if (k == "si_last_rank") *value = (double)ctx->si_last_rank;
     else if (k == "si_warm_skips") *value = (double)ctx->si_warm_skips;
+    else if (k == "corner_cache_hits") *value = (double)ctx->corner_cache_hits;
     else if (k == "si_warm_starts") *value = (double)ctx->si_warm_starts;
     else if (k == "lz_hits") *value = (double)ctx->lz_hits;
     else if (k == "lz_total_steps") *value = (double)ctx->lz_total_steps;

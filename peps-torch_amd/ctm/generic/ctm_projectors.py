@@ -38,9 +38,46 @@ def ctm_get_projectors_4x4(direction, coord, state, env, ctm_args=cfg.ctm_args, 
             if b is None or b.shape[1] != n or b.shape[0] != (2 if a.dtype.is_complex else 1) * k + 1 or b.device != a.device:
                 b = ws[key] = eng.warm_basis(env.chi, n, a.dtype)
             basis = b
-        return eng.projectors_4x4(direction, t16, env.chi, _trunc_cfg(eng, ctm_args), basis=basis)
+        corners, fresh = _cached_corners(eng, direction, coord, state, env, t16, ctm_args)
+        out = eng.projectors_4x4(direction, t16, env.chi, _trunc_cfg(eng, ctm_args), basis=basis, corners=corners)
+        for key, entry in fresh:                  # only after the call succeeded: the buffers now hold these corners
+            env.__dict__["_corner_cache"][key] = entry
+        return out
     R, Rt = _halves(direction, coord, state, env)
     return ctm_get_projectors_from_matrices(R, Rt, env.chi, ctm_args, global_args, diagnostics=diagnostics)
+
+
+def _cached_corners(eng, direction, coord, state, env, t16, ctm_args):
+    """Enlarged corners kept with the environment.  A corner depends on (C, T1, T2, a) of ITS site only, and a move rebinds
+    two corner matrices and one T per site (ctmrg.py:302-319): the two corner types of the opposite side are the same
+    tensors in the next move.  The reference rebuilds all four in every move (ctm_components.py:10-265); here a corner is
+    rebuilt only when one of its inputs is a different (or in-place modified) tensor object.  Returns ([(buffer, valid)] * 4,
+    [(key, entry)] to store after the call) or (None, []) when caching is off or the 4 x Nsites buffers do not fit."""
+    import torch
+    if not getattr(ctm_args, "corner_cache", True) or not hasattr(eng, "corner_numel"):
+        return None, []
+    a0 = t16[3]
+    nsites = len(state.sites)
+    sizes = [eng.corner_numel(c, t16[4 * i], t16[4 * i + 3]) for i, (c, _) in enumerate(_HALVES[direction])]
+    total = torch.cuda.get_device_properties(a0.device).total_memory
+    if 4 * nsites * max(sizes) * 8 > 0.35 * total:
+        return None, []
+    cache = env.__dict__.setdefault("_corner_cache", {})
+    corners, fresh = [], []
+    for i, (c, sh) in enumerate(_HALVES[direction]):
+        ins = tuple(t16[4 * i:4 * i + 4])
+        key = (c, state.vertexToSite((coord[0] + sh[0], coord[1] + sh[1])))
+        e = cache.get(key)
+        ok = (e is not None and e[2] == sizes[i] and all(x is y and x._version == v for x, y, v in zip(ins, e[0], e[1])))
+        if ok:
+            corners.append((e[3], True))
+            continue
+        buf = e[3] if (e is not None and e[2] == sizes[i] and e[3].device == a0.device) else \
+            torch.empty(sizes[i], dtype=torch.float64, device=a0.device)
+        cache.pop(key, None)                      # the buffer is about to be overwritten
+        corners.append((buf, False))
+        fresh.append((key, (ins, tuple(x._version for x in ins), sizes[i], buf)))
+    return corners, fresh
 
 
 # plain transposes applied to the corner next to the cut in each half (ctm_projectors.py:113-131): (R, Rt) per direction

@@ -196,3 +196,41 @@ def test_transfer_operator_spectrum(case, eng):
         Lo = O.get_Top_spec(4, (0, 0), d, ost, oe)
         assert np.abs(np.abs(L[:, 0] + 1j * L[:, 1]) - np.abs(Lo)).max() < 1e-9
         assert abs(L[0, 0] - 1.0) < 1e-12
+
+
+def test_corner_cache_gives_identical_sweeps_and_hits(eng):
+    """Enlarged corners kept with the environment (half of them survive every move): the environment after two sweeps is
+    bit-identical to the one computed with the cache off, in-place modification of an environment tensor invalidates."""
+    import copy
+    import config as cfg
+    from helpers import sites_from
+    from ipeps.ipeps import IPEPS
+    from ctm.generic.env import ENV, init_env
+    from ctm.generic import ctmrg
+    g = golden("generic_D3_chi18_f64")
+    sites = sites_from(g)
+    envs = []
+    for use in (True, False):
+        st = IPEPS({k: dev(v) for k, v in sites.items()})
+        env = ENV(18, st); init_env(st, env)
+        args = copy.deepcopy(cfg.ctm_args); args.corner_cache = use; args.projector_warm_start = False
+        h0 = eng.stat("corner_cache_hits")
+        for _ in range(2):
+            for d in args.ctm_move_sequence:
+                for _r in range(2):
+                    ctmrg.ctm_MOVE(d, st, env, ctm_args=args)
+        hits = eng.stat("corner_cache_hits") - h0
+        # 16 moves x 4 units x 4 corners = 256 corner uses; all but the first move find half of them in the cache
+        assert hits == (15 * 8 if use else 0), hits
+        envs.append(env)
+    for k in envs[0].C: assert torch.equal(envs[0].C[k], envs[1].C[k]), k
+    for k in envs[0].T: assert torch.equal(envs[0].T[k], envs[1].T[k]), k
+    # in-place change of one T tensor: the two corner types that contain it are rebuilt at that site
+    env = envs[0]
+    st = IPEPS({k: dev(v) for k, v in sites.items()})
+    args = copy.deepcopy(cfg.ctm_args); args.projector_warm_start = False
+    k0 = next(iter(env.T))
+    env.T[k0].mul_(1.0)
+    h0 = eng.stat("corner_cache_hits")
+    ctmrg.ctm_MOVE((0, -1), st, env, ctm_args=args)
+    assert eng.stat("corner_cache_hits") - h0 < 8
