@@ -37,6 +37,22 @@ class ENV():
                 for vec in [(-1, -1), (-1, 1), (1, -1), (1, 1)]:
                     self.C[(coord, vec)] = torch.empty((chi, chi), **o)
 
+    def __deepcopy__(self, memo):
+        # engine-side caches attached by the move (warm-start bases, enlarged corners: tens of GB at large chi) are not part
+        # of the environment's value
+        import copy
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            if k not in ("_warm", "_corner_cache"):
+                new.__dict__[k] = copy.deepcopy(v, memo)
+        return new
+
+    def drop_caches(self):
+        """Release the warm-start bases and cached enlarged corners kept with this environment (they are rebuilt on demand)."""
+        self.__dict__.pop("_warm", None)
+        self.__dict__.pop("_corner_cache", None)
+
     def __str__(self):
         s = f"ENV chi={self.chi}\n"
         for cr, t in self.C.items(): s += f"C({cr[0]} {cr[1]}): {t.size()}\n"
