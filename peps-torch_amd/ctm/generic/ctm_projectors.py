@@ -60,7 +60,9 @@ def _cached_corners(eng, direction, coord, state, env, t16, ctm_args):
     nsites = len(state.sites)
     sizes = [eng.corner_numel(c, t16[4 * i], t16[4 * i + 3]) for i, (c, _) in enumerate(_HALVES[direction])]
     total = torch.cuda.get_device_properties(a0.device).total_memory
-    if 4 * nsites * max(sizes) * 8 > 0.35 * total:
+    # the corners of the unit being computed live in these buffers instead of the workspace arena, so the extra footprint is
+    # 4 (Nsites - 1) corners
+    if 4 * nsites * max(sizes) * 8 > 0.6 * total:
         return None, []
     cache = env.__dict__.setdefault("_corner_cache", {})
     corners, fresh = [], []

@@ -58,8 +58,13 @@ def rdm2x2(coord, state, env, open_sites=[0, 1, 2, 3], unroll=[], checkpoint_unr
         a = t[3]
         n = env.chi * a.shape[1] ** 2
         need = n * n * (a.shape[0] ** 4 + 2 * a.shape[0] ** 2 + 4) * a.element_size()
-        if need > 0.15 * torch.cuda.get_device_properties(a.device).total_memory:
+        total = torch.cuda.get_device_properties(a.device).total_memory
+        if need > 0.15 * total:
             eng.trim(workers_only=True)
+            # ... and the enlarged corners cached with the environment (rebuilt by the next move) when both would not fit
+            cache = env.__dict__.get("_corner_cache")
+            if cache and need + sum(e[2] for e in cache.values()) * 8 > 0.7 * total:
+                env.__dict__.pop("_corner_cache", None)
     raw = eng.rdm2x2(t)
     if open_sites != [0, 1, 2, 3]:
         # fewer open sites = partial trace of the full plaquette RDM over the closed ones (rdm.py:1306-1360 contracts
