@@ -39,10 +39,15 @@ def ctm_get_projectors_4x4(direction, coord, state, env, ctm_args=cfg.ctm_args, 
                 b = ws[key] = eng.warm_basis(env.chi, n, a.dtype)
             basis = b
         corners, fresh = _cached_corners(eng, direction, coord, state, env, t16, ctm_args)
-        out = eng.projectors_4x4(direction, t16, env.chi, _trunc_cfg(eng, ctm_args), basis=basis, corners=corners)
+        P, Pt, S = eng.projectors_4x4(direction, t16, env.chi, _trunc_cfg(eng, ctm_args), return_S=True, basis=basis, corners=corners)
         for key, entry in fresh:                  # only after the call succeeded: the buffers now hold these corners
             env.__dict__["_corner_cache"][key] = entry
-        return out
+        ncol = env.__dict__.get("_ncol")
+        if ncol is not None:
+            # projector columns are scaled by rsqrt(S) where S/S[0] > projector_svd_reltol and are exact zeros elsewhere
+            # (ctm_projectors.py:266-270); S is descending, so the non-zero columns are a prefix: its length
+            ncol[(direction, state.vertexToSite(coord))] = int((S > ctm_args.projector_svd_reltol * S[0]).sum())
+        return P, Pt
     R, Rt = _halves(direction, coord, state, env)
     return ctm_get_projectors_from_matrices(R, Rt, env.chi, ctm_args, global_args, diagnostics=diagnostics)
 

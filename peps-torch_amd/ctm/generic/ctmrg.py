@@ -78,8 +78,37 @@ def _absorb_tensors(direction, coord, state, env, P, Pt):
             state.site(coord), P[c], Pt[c], P[nb], Pt[nb])
 
 
+# axis of the new (truncated) bond in nC1, nC2 and the two such axes of nT per direction (absorb output layouts)
+_NEW_AX = {(0, -1): (0, 1, (0, 2)), (-1, 0): (0, 0, (0, 1)), (0, 1): (1, 1, (1, 2)), (1, 0): (0, 1, (0, 2))}
+
+
 def _absorb(direction, coord, state, env, P, Pt, ctm_args, normalize=False):
-    return get_engine().absorb(direction, _absorb_tensors(direction, coord, state, env, P, Pt), normalize=normalize)
+    eng = get_engine()
+    tens = _absorb_tensors(direction, coord, state, env, P, Pt)
+    ncol = env.__dict__.get("_ncol")
+    if ncol:
+        # Columns of the projectors beyond the last S/S[0] > projector_svd_reltol are exact zeros, so the rows / columns of
+        # nC1, nC2, nT they produce are exact zeros too: absorb with the non-zero prefix only and pad.  (The reference multiplies
+        # the zeros through, ctmrg.py:351-425.)  Same numbers; pays when the truncation leaves many masked columns.
+        chi = env.chi
+        _, sh = _ABS[direction]
+        c = state.vertexToSite(coord)
+        nb = state.vertexToSite((coord[0] + sh[0], coord[1] + sh[1]))
+        y = max(ncol.get((direction, c), chi), ncol.get((direction, nb), chi))
+        yc = min(chi, max(16, (y + 15) // 16 * 16))
+        if 2 * yc <= chi and all(t.shape[1] == chi for t in tens[6:10]):
+            tens = tens[:6] + tuple(t[:, :yc].contiguous() for t in tens[6:10])
+            nC1, nC2, nT = eng.absorb(direction, tens, normalize=normalize)
+            a1, a2, aT = _NEW_AX[direction]
+
+            def pad(x, axes):
+                shape = list(x.shape)
+                for ax in axes: shape[ax] = chi
+                out = torch.zeros(shape, dtype=x.dtype, device=x.device)
+                out[tuple(slice(0, x.shape[i]) for i in range(x.dim()))] = x
+                return out
+            return pad(nC1, (a1,)), pad(nC2, (a2,)), pad(nT, aT)
+    return eng.absorb(direction, tens, normalize=normalize)
 
 
 def absorb_truncate_CTM_MOVE_UP(coord, state, env, P, Pt, ctm_args=cfg.ctm_args): return _absorb((0, -1), coord, state, env, P, Pt, ctm_args)
@@ -106,6 +135,13 @@ def ctm_MOVE(direction, state, env, ctm_args=cfg.ctm_args, global_args=cfg.globa
     coords = list(state.sites.keys())
     mine = parallel.my_units(coords)
     chi = env.chi
+    # number of non-zero projector columns per site of THIS move (filled by the fused projector path; single process only)
+    # (worth its host-side bookkeeping where an absorb takes milliseconds: n >= absorb_skip_min_n)
+    if getattr(ctm_args, "absorb_skip_zero_columns", True) and not parallel.is_distributed() and ctm_args.projector_method == '4X4' \
+            and max(_proj_rows(direction, c, state, chi) for c in coords) >= getattr(ctm_args, "absorb_skip_min_n", 8192):
+        env.__dict__["_ncol"] = {}
+    else:
+        env.__dict__.pop("_ncol", None)
     like = next(iter(env.C.values()))
 
     # my units of a phase are independent: issue them concurrently (own context + stream each) when that pays

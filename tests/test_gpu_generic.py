@@ -234,3 +234,30 @@ def test_corner_cache_gives_identical_sweeps_and_hits(eng):
     h0 = eng.stat("corner_cache_hits")
     ctmrg.ctm_MOVE((0, -1), st, env, ctm_args=args)
     assert eng.stat("corner_cache_hits") - h0 < 8
+
+
+def test_absorb_of_nonzero_projector_prefix_is_identical(eng):
+    """Masked projector columns (S/S[0] <= projector_svd_reltol) are exact zeros: absorbing only the non-zero prefix and
+    padding gives the same environment, bit for bit, as multiplying the zeros through like the reference does."""
+    import copy
+    import config as cfg
+    from ipeps.ipeps import IPEPS
+    from ctm.generic.env import ENV, init_env
+    from ctm.generic import ctmrg
+    rng = np.random.default_rng(12)
+    sites = {(x, y): rng.random((2, 3, 3, 3, 3)) for x in range(2) for y in range(2)}      # positive tensors: low-rank environment
+    envs, used = [], []
+    for use in (True, False):
+        st = IPEPS({k: dev(v / np.abs(v).max()) for k, v in sites.items()})
+        env = ENV(48, st); init_env(st, env)
+        args = copy.deepcopy(cfg.ctm_args); args.absorb_skip_zero_columns = use; args.absorb_skip_min_n = 0
+        for _ in range(3):
+            for d in args.ctm_move_sequence:
+                for _r in range(2):
+                    ctmrg.ctm_MOVE(d, st, env, ctm_args=args)
+        envs.append(env)
+        nc = env.__dict__.get("_ncol")
+        used.append(bool(nc) and max(nc.values()) <= 24)
+    assert used == [True, False]                     # the compact path really ran (<= chi/2 significant columns)
+    for k in envs[0].C: assert torch.equal(envs[0].C[k], envs[1].C[k]), k
+    for k in envs[0].T: assert torch.equal(envs[0].T[k], envs[1].T[k]), k
