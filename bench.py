@@ -339,6 +339,16 @@ def main():
                        "power_iter_hits": int(eng.stat("si_hits")), "power_iter_fallbacks_to_full": int(eng.stat("si_fallbacks")),
                        "avg_half_steps": round(eng.stat("si_total_iters") / max(eng.stat("si_hits") + eng.stat("si_fallbacks"), 1), 2)},
                "phase_s": {k: round(v, 4) for k, v in eng.timers().items()}}
+        if kind != "c4v":
+            # what the engine could exploit on THIS state (caveat): numerical rank of the truncation and
+            # the number of projector columns above projector_svd_reltol, out of chi
+            nc = env.__dict__.get("_ncol") or {}
+            wr = [w.stat("si_last_rank") for w in getattr(eng, "workers", [])]
+            out["state"] = {"chi": chi, "numerical_rank_of_truncated_operator": int(max(wr + [eng.stat("si_last_rank") - sum(wr)])),
+                            "nonzero_projector_columns": (max(nc.values()) if nc else None),
+                            "corner_cache_hits": int(eng.stat("corner_cache_hits")),
+                            "note": "positive random tensors give a numerically low-rank environment; see --signed for the full-rank extreme"
+                                    if not args.signed else "signed random tensors: full-rank spectrum"}
         if not args.no_cpu_baseline and world == 1:
             try:
                 out["cpu_baseline"] = cpu_baseline(kind, D, chi, sites)
