@@ -417,8 +417,31 @@ void launch_strip(int tm, dim3 grid, hipStream_t st, const StripParams& sp) {
 }
 
 __global__ void splitk_reduce_kernel(const double* __restrict__ part, int nsplit, long long stride, double* __restrict__ C, int M, int N,
-                                     long long ldc, double alpha, double beta, const double* __restrict__ colscale) {
+                                     long long ldc, double alpha, double beta, const double* __restrict__ colscale, int vec) {
+    // sum of the K-slice partials in a fixed order (deterministic).  Two adjacent elements per thread (16-byte loads when N is
+    // even) and four slices in flight per step: the partials of a strip GEMM are tens of MB, this kernel is pure HBM streaming.
     const long long tot = (long long)M * N;
+    if (vec && (N & 1) == 0 && (stride & 1) == 0) {
+        const long long half = tot >> 1;
+        for (long long h = (long long)blockIdx.x * blockDim.x + threadIdx.x; h < half; h += (long long)gridDim.x * blockDim.x) {
+            const long long q = 2 * h;
+            d2 v = (d2){0.0, 0.0};
+            int s = 0;
+            for (; s + 4 <= nsplit; s += 4) {
+                const d2 a = *(const d2*)(part + (long long)s * stride + q), b = *(const d2*)(part + (long long)(s + 1) * stride + q);
+                const d2 c = *(const d2*)(part + (long long)(s + 2) * stride + q), d = *(const d2*)(part + (long long)(s + 3) * stride + q);
+                v = (((v + a) + b) + c) + d;
+            }
+            for (; s < nsplit; ++s) v += *(const d2*)(part + (long long)s * stride + q);
+            const long long m = q / N, n = q - m * N;
+            v *= alpha;
+            if (colscale) { v[0] *= colscale[n]; v[1] *= colscale[n + 1]; }
+            double* c = C + m * ldc + n;
+            if (beta != 0.0) { v[0] += beta * c[0]; v[1] += beta * c[1]; }
+            c[0] = v[0]; c[1] = v[1];
+        }
+        return;
+    }
     for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < tot; q += (long long)gridDim.x * blockDim.x) {
         double v = 0.0;
         for (int s = 0; s < nsplit; ++s) v += part[s * stride + q];
@@ -473,7 +496,9 @@ int gemm_f64(ctm_ctx* ctx, const GemmDesc& d) {
         (((uintptr_t)d.A | (uintptr_t)d.B) & 15) == 0 && d.sam % 2 == 0 && (d.sbn == 1 ? d.sbk : d.sbn) % 2 == 0) {
         const bool bnf = d.sbn == 1;
         const int gx = (d.N / 32 + 3) / 4;
-        int ks = std::max(1, std::min(std::min((ctx->strip_target_wgs + gx - 1) / gx, d.K / 256), 64));
+        // 49..64 rows are MFMA bound with 2 waves per SIMD resident: half the K slices (half the partials) keep the chip as busy
+        const int target = d.M > 48 ? ctx->strip_target_wgs / 2 : ctx->strip_target_wgs;
+        int ks = std::max(1, std::min(std::min((target + gx - 1) / gx, d.K / 256), 64));
         int klen = (((d.K + ks - 1) / ks) + 15) / 16 * 16;
         ks = (d.K + klen - 1) / klen;
         double* part;
@@ -487,7 +512,7 @@ int gemm_f64(ctm_ctx* ctx, const GemmDesc& d) {
         if (e != hipSuccess) { ctx->set_error(std::string("strip gemm launch: ") + hipGetErrorString(e)); return CTM_ERR_HIP; }
         const long long tot = (long long)d.M * d.N;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)std::min<long long>((tot + 255) / 256, 2048)), dim3(256), 0, ctx->stream,
-                           (const double*)part, ks, tot, d.C, d.M, d.N, d.ldc, d.alpha, d.beta, d.colscale);
+                           (const double*)part, ks, tot, d.C, d.M, d.N, d.ldc, d.alpha, d.beta, d.colscale, ctx->splitk_reduce_vec);
         const double fl = 2.0 * d.M * d.N * (double)d.K;
         timing_end(ctx, e0, 1, fl);
         ctx->gemm_flops += fl;
@@ -581,7 +606,7 @@ int gemm_f64(ctm_ctx* ctx, const GemmDesc& d) {
         const long long tot = (long long)d.M * d.N;
         int blocks = (int)std::min<long long>((tot + 255) / 256, 2048);
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, ctx->stream, (const double*)part, fast_ks > 1 ? fast_ks : p.ksplit, p.split_stride, d.C,
-                           d.M, d.N, d.ldc, d.alpha, d.beta, d.colscale);
+                           d.M, d.N, d.ldc, d.alpha, d.beta, d.colscale, ctx->splitk_reduce_vec);
     }
     const double fl = 2.0 * d.M * d.N * (double)d.K * d.batch;
     if (e1 >= 0) {

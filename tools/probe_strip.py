@@ -3,6 +3,8 @@ import sys, os, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "peps-torch_amd"))
 import torch, _native
 eng = _native.engine()
+for kv in os.environ.get('OPTS','').split(','):
+    if kv: eng.set_option(kv.split('=')[0], float(kv.split('=')[1]))
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
 B = torch.randn(n, n, dtype=torch.float64, device="cuda")
 for b in [int(x) for x in (sys.argv[2].split(",") if len(sys.argv) > 2 else "8,16,32,48,64,96,128,257".split(","))]:
