@@ -135,9 +135,9 @@ def ctm_MOVE(direction, state, env, ctm_args=cfg.ctm_args, global_args=cfg.globa
     coords = list(state.sites.keys())
     mine = parallel.my_units(coords)
     chi = env.chi
-    # number of non-zero projector columns per site of THIS move (filled by the fused projector path; single process only)
+    # number of non-zero projector columns per site of THIS move (filled by the fused projector path)
     # (worth its host-side bookkeeping where an absorb takes milliseconds: n >= absorb_skip_min_n)
-    if getattr(ctm_args, "absorb_skip_zero_columns", True) and not parallel.is_distributed() and ctm_args.projector_method == '4X4' \
+    if getattr(ctm_args, "absorb_skip_zero_columns", True) and ctm_args.projector_method == '4X4' \
             and max(_proj_rows(direction, c, state, chi) for c in coords) >= getattr(ctm_args, "absorb_skip_min_n", 8192):
         env.__dict__["_ncol"] = {}
     else:
@@ -165,6 +165,10 @@ def ctm_MOVE(direction, state, env, ctm_args=cfg.ctm_args, global_args=cfg.globa
             shp[coord] = (R_n, min(chi, R_n))
         P = parallel.exchange(P, coords, shp, like)
         Pt = parallel.exchange(Pt, coords, shp, like)
+        if env.__dict__.get("_ncol") is not None:
+            # every rank needs the count of non-zero projector columns of every site: read it off the gathered projectors
+            # (the non-zero columns are a prefix)
+            env.__dict__["_ncol"] = {(direction, state.vertexToSite(c)): int((P[c] != 0).any(0).sum()) for c in coords}
 
     # phase B: absorb + normalise my sites
     new = dict(zip(mine, _each(lambda c: _absorb(direction, c, state, env, P, Pt, ctm_args, normalize=norm_kind), mine)))
