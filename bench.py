@@ -243,9 +243,10 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     ivals = eng.gemm_intervals()
-    k_ms = [eng.stat("k_ms0"), eng.stat("k_ms1"), eng.stat("k_ms2")]
-    k_fl = [eng.stat("k_flops0"), eng.stat("k_flops1"), eng.stat("k_flops2")]
-    k_n = [eng.stat("k_calls0"), eng.stat("k_calls1"), eng.stat("k_calls2")]
+    KK = range(4)
+    k_ms = [eng.stat(f"k_ms{i}") for i in KK]
+    k_fl = [eng.stat(f"k_flops{i}") for i in KK]
+    k_n = [eng.stat(f"k_calls{i}") for i in KK]
     eng.set_option("gemm_timing", 0)
     # reference pass for the kernel-quality figure: ONE more sweep with the units issued serially on one stream (nothing
     # co-scheduled), outside the timed region -- per-launch rates of the same kernels without sharing the chip
@@ -254,20 +255,21 @@ def main():
         cfg.ctm_args.concurrent_units = False
         eng.set_option("gemm_timing", 1)
         step(); fence()
-        s_ms = [eng.stat("k_ms0"), eng.stat("k_ms1"), eng.stat("k_ms2")]
-        s_fl = [eng.stat("k_flops0"), eng.stat("k_flops1"), eng.stat("k_flops2")]
-        s_n = [eng.stat("k_calls0"), eng.stat("k_calls1"), eng.stat("k_calls2")]
+        serial = ([eng.stat(f"k_ms{i}") for i in KK], [eng.stat(f"k_flops{i}") for i in KK], [eng.stat(f"k_calls{i}") for i in KK])
         eng.set_option("gemm_timing", 0)
         cfg.ctm_args.concurrent_units = True
-        serial = (s_ms, s_fl, s_n)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
     if rank == 0:
-        dom = 0 if k_ms[0] >= k_ms[1] else 1
-        names = ["gemm_f64_fast_kernel / gemm_f64_kernel<4,4> (128x128 tile)", "gemm_f64_kernel<2,2> (64x64 tile)"]
+        # instrumented kernel classes (csrc: timing_end kinds).  Class 3 (streaming strip kernel) is HBM-bound: the engine
+        # reports its ALGORITHMIC BYTES (the big operand read once + the block in and out) where the others report flops.
+        CLS = {0: ("gemm_f64_fast_kernel / gemm_f64_kernel<4,4> (128x128 tile)", "mfma", "gemm_f64_fast_kernel"),
+               1: ("gemm_f64_kernel<2,2> (64x64 tile: small, segmented and batched products)", "mfma", "gemm_f64_kernel<2, 2>"),
+               2: ("layer2_reg_kernel<KT> (float64) / layer2_c_kernel<KT> (complex128): fused two-layer enlarged-corner kernel", "mfma", "layer2_"),
+               3: ("gemm_strip_kernel<TM,BNF>: <= 64-row block times an n x n corner, streamed once", "hbm", "gemm_strip_kernel")}
         # Independent units run on concurrent streams, so launches of the kernel overlap: the time the chip spends on
         # them is the UNION of their [start, end] intervals (equal to the sum of durations when nothing overlaps).
         def union_ms(kind):
@@ -280,51 +282,56 @@ def main():
                 else:
                     cur_b = max(cur_b, b)
             return tot + ((cur_b - cur_a) if cur_b is not None else 0.0)
-        u_ms = [union_ms(0), union_ms(1), union_ms(2)]
-        ach = k_fl[dom] / max(u_ms[dom] * 1e-3, 1e-30) / 1e12 if k_n[dom] else 0.0
-        per_launch = (k_fl[dom] / max(k_n[dom], 1)) / max(k_ms[dom] / max(k_n[dom], 1) * 1e-3, 1e-30) / 1e12 if k_n[dom] else 0.0
-        roof = {"bound": "mfma", "kernel": names[dom], "achieved": round(ach, 3), "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(ach / FP64_MFMA_PEAK_TFLOPS, 4), "traffic": None,
-                "launches": int(k_n[dom]), "avg_launch_ms": round(k_ms[dom] / max(k_n[dom], 1), 5),
-                "busy_ms_union": round(u_ms[dom], 3), "sum_launch_ms": round(k_ms[dom], 3),
-                "per_launch_tflops_while_sharing_the_chip": round(per_launch, 3),
+        u_ms = [union_ms(i) for i in KK]
+        HBM_PEAK_GBPS = 8000.0
+
+        def rate(work, ms, bound):              # TFLOP/s or GB/s
+            return work / max(ms * 1e-3, 1e-30) / (1e12 if bound == "mfma" else 1e9)
+
+        def describe(i, kms, kfl, kn, ums=None):
+            name, bound, _ = CLS[i]
+            peak = FP64_MFMA_PEAK_TFLOPS if bound == "mfma" else HBM_PEAK_GBPS
+            busy = ums[i] if ums is not None else kms[i]
+            ach = rate(kfl[i], busy, bound) if kn[i] else 0.0
+            d = {"kernel": name, "bound": bound, "achieved": round(ach, 3), "peak": peak, "unit": "TFLOP/s" if bound == "mfma" else "GB/s",
+                 "frac": round(ach / peak, 4), "launches": int(kn[i]), "avg_launch_ms": round(kms[i] / max(kn[i], 1), 5),
+                 "sum_launch_ms": round(kms[i], 3)}
+            if ums is not None:
+                d["busy_ms_union"] = round(ums[i], 3)
+            return d
+        # the dominant kernel = the class the chip spends most time on
+        dom = max((0, 2, 3), key=lambda i: u_ms[i])
+        roof = describe(dom, k_ms, k_fl, k_n, u_ms)
+        roof = {"bound": roof.pop("bound"), **roof, "traffic": None,
+                "per_launch_rate_while_sharing_the_chip": round(rate(k_fl[dom], k_ms[dom], CLS[dom][1]), 3) if k_n[dom] else 0.0,
                 "concurrent_streams": max(1, len(getattr(eng, "workers", []))),
-                "gemm_time_share": round((u_ms[0] + u_ms[1]) * 1e-3 / dt, 4),
-                "other_gemm": {"kernel": names[1 - dom], "launches": int(k_n[1 - dom]), "ms": round(k_ms[1 - dom], 2),
-                               "tflops": round(k_fl[1 - dom] / max(k_ms[1 - dom] * 1e-3, 1e-30) / 1e12, 3) if k_n[1 - dom] else 0.0}}
-        # the fused two-layer enlarged-corner / absorb kernel (MFMA from LDS; also the largest HBM consumer)
-        roof["enlarged_corner_kernel"] = {"kernel": "layer2_reg_kernel<KT> (float64) / layer2_c_kernel<KT> (complex128)", "launches": int(k_n[2]), "avg_launch_ms": round(k_ms[2] / max(k_n[2], 1), 4),
-                                          "busy_ms_union": round(u_ms[2], 3),
-                                          "mfma_tflops": round(k_fl[2] / max(u_ms[2] * 1e-3, 1e-30) / 1e12, 3) if k_n[2] else 0.0,
-                                          "mfma_frac": round(k_fl[2] / max(u_ms[2] * 1e-3, 1e-30) / 1e12 / FP64_MFMA_PEAK_TFLOPS, 4) if k_n[2] else 0.0}
+                "time_share_of_sweep": round(u_ms[dom] * 1e-3 / dt, 4),
+                "algorithmic_work_per_launch": ("2*M*N*K flop of each product" if dom in (0, 1) else
+                                                "2 * p * chi_x * chi_y * (D^2)^2 * 2 D^2 flop per launch (both layers)" if dom == 2 else
+                                                "8 * (K*N + M*K + M*N) bytes: the n x n corner read once, the <=64-row block in and out"),
+                "other_kernels": {str(i): describe(i, k_ms, k_fl, k_n, u_ms) for i in KK if i != dom and k_n[i]}}
         if serial is not None:
             s_ms, s_fl, s_n = serial
-            tf = lambda i: round(s_fl[i] / max(s_ms[i] * 1e-3, 1e-30) / 1e12, 3) if s_n[i] else 0.0
-            roof["serial_pass"] = {"note": "one extra sweep after the timed region, units issued serially on one stream (no co-scheduling)",
-                                   "kernel": names[dom], "achieved": tf(dom), "frac": round(tf(dom) / FP64_MFMA_PEAK_TFLOPS, 4),
-                                   "avg_launch_ms": round(s_ms[dom] / max(s_n[dom], 1), 5), "launches": int(s_n[dom]),
-                                   "other_gemm_tflops": tf(1 - dom), "enlarged_corner_kernel_tflops": tf(2),
-                                   "enlarged_corner_kernel_frac": round(tf(2) / FP64_MFMA_PEAK_TFLOPS, 4)}
+            roof["serial_pass"] = {"note": "one extra sweep after the timed region, units issued serially on one stream (no co-scheduling): kernel quality without sharing the chip",
+                                   **{("dominant" if i == dom else str(i)): describe(i, s_ms, s_fl, s_n) for i in KK if s_n[i]}}
         # HBM traffic of the dominant kernel family from the committed PMC pass of this same command (bench.py cannot attach
         # counters to itself); null when the profile is for another workload
         try:
             import csv
             prof = json.load(open(os.path.join(REPO, "profiles", "r01_bench_default.json")))
-            if prof["config"]["workload"] == args.config and world == 1:
-                key = "gemm_f64_fast_kernel" if dom == 0 else "gemm_f64_kernel<2, 2>"
-                tot_b = tot_n = 0.0
-                for row in csv.DictReader(open(os.path.join(REPO, "profiles", "r01_bench_default_pmc_hbm_traffic.csv"))):
-                    if key in row["kernel"] or (dom == 0 and "gemm_f64_kernel<4, 4>" in row["kernel"]):
-                        tot_b += float(row["hbm_bytes_per_launch(2x_fetch_corrected)"]) * float(row["launches"]); tot_n += float(row["launches"])
-                for row in csv.DictReader(open(os.path.join(REPO, "profiles", "r01_bench_default_pmc_hbm_traffic.csv"))):
-                    if "layer2_" in row["kernel"] and k_n[2]:
-                        b = float(row["hbm_bytes_per_launch(2x_fetch_corrected)"])
-                        roof["enlarged_corner_kernel"]["hbm_bytes_per_launch"] = round(b)
-                        roof["enlarged_corner_kernel"]["hbm_GBps_per_launch"] = round(b / (k_ms[2] / k_n[2] * 1e-3) / 1e9, 1)
-                        roof["enlarged_corner_kernel"]["hbm_frac_of_8TBps"] = round(b / (k_ms[2] / k_n[2] * 1e-3) / 8e12, 4)
-                if tot_n:
-                    roof["traffic"] = round(tot_b / tot_n)
-                    roof["traffic_source"] = "profiles/r01_bench_default_pmc_hbm_traffic.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, bytes per launch)"
+            if prof["config"]["workload"] == args.config and world == 1 and not args.signed:
+                rows = list(csv.DictReader(open(os.path.join(REPO, "profiles", "r01_bench_default_pmc_hbm_traffic.csv"))))
+
+                def pmc(key):
+                    tb = tn = 0.0
+                    for row in rows:
+                        if key in row["kernel"]:
+                            tb += float(row["hbm_bytes_per_launch(2x_fetch_corrected)"]) * float(row["launches"]); tn += float(row["launches"])
+                    return round(tb / tn) if tn else None
+                roof["traffic"] = pmc(CLS[dom][2])
+                roof["traffic_source"] = "profiles/r01_bench_default_pmc_hbm_traffic.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, average HBM bytes per launch)"
+                for i, dsc in roof["other_kernels"].items():
+                    dsc["traffic"] = pmc(CLS[int(i)][2])
         except Exception:
             pass
         out = {"metric": "ctm_sweeps_per_sec", "value": steps / dt, "unit": "sweeps/s", "n_gpus": world, "steps": steps,

@@ -57,10 +57,12 @@ int ctm_set_option(ctm_ctx* ctx, const char* key, double value);
 int ctm_get_stat(ctm_ctx* ctx, const char* key, double* value);
 /*   "last_sweeps","last_offnorm","total_sweeps","jacobi_calls","si_hits","si_fallbacks","si_total_iters","si_last_iters",
  *   "si_last_rank","si_warm_starts","si_warm_skips","corner_cache_hits","lz_hits","lz_total_steps","gemm_flops","gemm_calls","layer2_flops","layer2_calls",
- *   "arena_high","k_ms0|1|2","k_flops0|1|2","k_calls0|1|2"                                                                   */
+ *   "arena_high","k_ms0..3","k_flops0..3","k_calls0..3"                                                                   */
 int ctm_timers(ctm_ctx* ctx, double* out8, int reset);             /* corners,halves,svd,proj,absorb,norm,rdm,eig (s) */
 /* GEMM launches timed with HIP events while the option "gemm_timing" is on: quadruples (kind, start_ms, end_ms, flops) on a
- * process-wide clock (kind 0 = 128x128-tile GEMM kernels, 1 = 64x64-tile GEMM kernel, 2 = fused two-layer kernel).  out may be NULL to query *count (launches). */
+ * process-wide clock (kind 0 = 128x128-tile GEMM kernels, 1 = 64x64-tile GEMM kernel, 2 = fused two-layer kernel, 3 = streaming
+ * strip kernel, whose fourth value is its ALGORITHMIC BYTES instead of flops: it is HBM-bound).  out may be NULL to query
+ * *count (launches).  The same classes index the stats "k_ms<c>", "k_flops<c>", "k_calls<c>". */
 int ctm_gemm_intervals(ctm_ctx* ctx, double* out, long long capacity_doubles, long long* count);
 
 /* ---- primitives (replace tn_interface.py:3-27 contract/mm/permute) ------------------------------ */

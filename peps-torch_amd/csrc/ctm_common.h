@@ -101,8 +101,10 @@ struct ctm_ctx {
     std::vector<PendingEv> ev_pending;
     int ev_next = 0;
     std::vector<double> intervals;       // (kind, start_ms, end_ms, flops) per timed GEMM launch, process-wide clock
-    double k_ms[3] = {0, 0, 0}, k_flops[3] = {0, 0, 0};      // kind 2 = fused two-layer kernel (layer2.hip)
-    long k_calls[3] = {0, 0, 0};
+    // per kernel class: 0 = 128-tile GEMMs, 1 = other GEMMs, 2 = fused two-layer kernel (layer2.hip), 3 = streaming strip kernel
+    // (k_flops[3] holds ALGORITHMIC BYTES: that kernel is HBM-bound)
+    double k_ms[4] = {0, 0, 0, 0}, k_flops[4] = {0, 0, 0, 0};
+    long k_calls[4] = {0, 0, 0, 0};
     bool cplx = false;                   // CTM_C128 context: every tensor pointer of the C-ABI is interleaved complex128
     void set_error(const std::string& s) { last_error = s; }
 };

@@ -134,7 +134,7 @@ int ctm_set_option(ctm_ctx* ctx, const char* key, double value) {
         gemm_timing_drain(ctx);
         ctx->gemm_timing = value != 0.0;
         if (ctx->gemm_timing) { gemm_timing_base(ctx); ctx->intervals.clear(); }
-        for (int i = 0; i < 3; ++i) { ctx->k_ms[i] = 0; ctx->k_flops[i] = 0; ctx->k_calls[i] = 0; }
+        for (int i = 0; i < 4; ++i) { ctx->k_ms[i] = 0; ctx->k_flops[i] = 0; ctx->k_calls[i] = 0; }
     }
     else { ctx->set_error("unknown option " + k); return CTM_ERR_BADARG; }
     return CTM_OK;
@@ -164,7 +164,7 @@ int ctm_get_stat(ctm_ctx* ctx, const char* key, double* value) {
     else if (k.rfind("k_", 0) == 0 && k.size() >= 5) {      // k_ms0, k_ms1, k_flops0, k_flops1, k_calls0, k_calls1
         gemm_timing_drain(ctx);
         const int i = k.back() - '0';
-        if (i < 0 || i > 2) { ctx->set_error("unknown stat " + k); return CTM_ERR_BADARG; }
+        if (i < 0 || i > 3) { ctx->set_error("unknown stat " + k); return CTM_ERR_BADARG; }
         if (k.compare(0, 4, "k_ms") == 0) *value = ctx->k_ms[i];
         else if (k.compare(0, 7, "k_flops") == 0) *value = ctx->k_flops[i];
         else if (k.compare(0, 7, "k_calls") == 0) *value = (double)ctx->k_calls[i];

@@ -514,7 +514,7 @@ int gemm_f64(ctm_ctx* ctx, const GemmDesc& d) {
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)std::min<long long>((tot + 255) / 256, 2048)), dim3(256), 0, ctx->stream,
                            (const double*)part, ks, tot, d.C, d.M, d.N, d.ldc, d.alpha, d.beta, d.colscale, ctx->splitk_reduce_vec);
         const double fl = 2.0 * d.M * d.N * (double)d.K;
-        timing_end(ctx, e0, 1, fl);
+        timing_end(ctx, e0, 3, 8.0 * ((double)d.K * d.N + (double)d.M * d.K + (double)d.M * d.N));   // class 3 reports algorithmic BYTES
         ctx->gemm_flops += fl;
         ctx->gemm_calls += 1;
         return CTM_OK;

@@ -72,7 +72,7 @@ def pool_for(engine, nunits, n, is_complex, est_bytes=None):
     if n >= 8192:
         # kernels of this size fill the chip on their own: two units in flight hide the launch gaps and host synchronisations
         # just as well as four (measured 1.228 vs 1.231 s/sweep at n = 16384) with half the workspace and less co-scheduling
-        nw = min(nw, 2)
+        nw = min(nw, int(os.environ.get("CTM_LARGE_N_UNITS", 2)))
     nw = min(nw, int(os.environ.get("CTM_MAX_CONCURRENT_UNITS", nw)))       # experiment knob
     if nw < 2:
         return None
