@@ -26,6 +26,11 @@ _ABS = {
     (0, 1): (((-1, 1), (-1, 0), (0, 1), (1, 0), (1, 1)), (-1, 0)),
     (1, 0): (((1, 1), (0, 1), (1, 0), (0, -1), (1, -1)), (0, 1)),
 }
+# Ownership of the projector units when sharded over ranks: window `c` of a move goes to the round-robin owner of the site
+# c + shift.  A move leaves the two enlarged corners on its far side unchanged; with these shifts (default move sequence
+# UP, LEFT, DOWN, RIGHT) the window that needs them in the NEXT move is computed by the rank that built them, so the corner
+# cache hits across ranks as it does in one process (8 of 16 corner contractions per move).
+_OWNER_SHIFT = {(0, -1): (0, 0), (-1, 0): (1, 0), (0, 1): (1, -1), (1, 0): (0, -1)}
 # where the new tensors go (ctmrg.py:302-309)
 _REL = {(0, -1): ((1, -1), (-1, -1)), (-1, 0): ((-1, -1), (-1, 1)), (0, 1): ((-1, 1), (1, 1)), (1, 0): ((1, 1), (1, -1))}
 
@@ -154,17 +159,21 @@ def ctm_MOVE(direction, state, env, ctm_args=cfg.ctm_args, global_args=cfg.globa
         return pool.map(fn, items) if pool is not None else [fn(it) for it in items]
 
     # phase A: projectors of my sites from the old env
+    ownersA, mineA = None, mine
+    if parallel.is_distributed():
+        ownersA = parallel.owners_shifted(coords, state.vertexToSite, _OWNER_SHIFT[direction])
+        mineA = [c for c, o in zip(coords, ownersA) if o == parallel.world()[0]]
     P, Pt = {}, {}
-    for coord, (p_, pt_) in zip(mine, _each(lambda c: get_projectors(direction, c, state, env, ctm_args, global_args,
-                                                                             diagnostics=diagnostics), mine)):
+    for coord, (p_, pt_) in zip(mineA, _each(lambda c: get_projectors(direction, c, state, env, ctm_args, global_args,
+                                                                              diagnostics=diagnostics), mineA)):
         P[coord], Pt[coord] = p_, pt_
     if parallel.is_distributed():
         shp = {}
         for coord in coords:
             R_n = _proj_rows(direction, coord, state, chi)
             shp[coord] = (R_n, min(chi, R_n))
-        P = parallel.exchange(P, coords, shp, like)
-        Pt = parallel.exchange(Pt, coords, shp, like)
+        P = parallel.exchange(P, coords, shp, like, owners=ownersA)
+        Pt = parallel.exchange(Pt, coords, shp, like, owners=ownersA)
         if env.__dict__.get("_ncol") is not None:
             # every rank needs the count of non-zero projector columns of every site: read it off the gathered projectors
             # (the non-zero columns are a prefix)

@@ -38,10 +38,20 @@ def my_units(items):
     return [x for i, x in enumerate(items) if owner_of(i, n) == rank]
 
 
-def exchange(local, keys, shapes, like):
+def owners_shifted(coords, vertex_to_site, shift):
+    """Owner rank of every unit when unit `c` is given to the round-robin owner of the site at c + shift.  Used by the
+    projector phase: with the per-direction shifts of ctmrg._OWNER_SHIFT the two enlarged corners a window can reuse from the
+    previous move (corner cache) were computed on the SAME rank."""
+    _, n = world()
+    idx = {c: i for i, c in enumerate(coords)}
+    return [owner_of(idx[vertex_to_site((c[0] + shift[0], c[1] + shift[1]))], n) for c in coords]
+
+
+def exchange(local, keys, shapes, like, owners=None):
     """All ranks end up with `{key: tensor}` for every key of `keys` (ordered list, identical on all
     ranks); `local` holds the entries this rank computed; `shapes[key]` is known to every rank (it
-    follows from chi and the bond dimensions), `like` supplies dtype/device.  When all tensors of the
+    follows from chi and the bond dimensions), `like` supplies dtype/device, `owners[i]` (default i mod ranks) is the rank that
+    computed keys[i].  When all tensors of the
     exchange have one shape and every rank owns the same number of them (uniform-D cell, #sites a
     multiple of #ranks) they travel as ONE all_gather of a stacked buffer (few, large messages: xGMI
     is point-to-point, per-link bound); otherwise per-key broadcasts from the owner."""
@@ -49,7 +59,8 @@ def exchange(local, keys, shapes, like):
         return dict(local)
     rank, n = world()
     out = dict(local)
-    owned = [[k for i, k in enumerate(keys) if owner_of(i, n) == r] for r in range(n)]
+    own = owners if owners is not None else [owner_of(i, n) for i in range(len(keys))]
+    owned = [[k for i, k in enumerate(keys) if own[i] == r] for r in range(n)]
     uniform = len({len(o) for o in owned}) == 1 and len({tuple(shapes[k]) for k in keys}) == 1 and len(owned[0]) > 0
     cx = like.dtype.is_complex       # RCCL has no complex type: complex128 travels as its (re,im) float64 view
     if uniform:
@@ -64,7 +75,7 @@ def exchange(local, keys, shapes, like):
                 out[k] = buf[j]
         return out
     for i, k in enumerate(keys):
-        src = owner_of(i, n)
+        src = own[i]
         t = local[k].contiguous() if src == rank else torch.empty(tuple(shapes[k]), dtype=like.dtype, device=like.device)
         dist.broadcast(torch.view_as_real(t) if cx else t, src)
         out[k] = t
