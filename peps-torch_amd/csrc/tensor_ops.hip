@@ -134,14 +134,26 @@ __global__ void copy2d_kernel(const double* src, long long lds, double* dst, lon
 
 // one wave per row: sum of squares (scaled two-pass not needed: inputs are max-abs normalised O(1))
 __global__ void row_norms_kernel(const double* __restrict__ x, int rows, int cols, long long ld, double* out) {
-    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
-    const int nw = (gridDim.x * blockDim.x) >> 6;
-    for (int r = wave; r < rows; r += nw) {
-        double s = 0.0;
+    // one WORKGROUP per row (grid-stride over rows): a row of the truncation blocks is n = 10^3..10^4.5 doubles and there are
+    // only tens of rows, so one wave per row left the chip idle and serialised ~n/64 dependent loads.  Four independent
+    // accumulators per thread, fixed reduction order (deterministic).
+    __shared__ double red[4];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    for (int r = blockIdx.x; r < rows; r += gridDim.x) {
         const double* p = x + (long long)r * ld;
-        for (int c = lane; c < cols; c += 64) s += p[c] * p[c];
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        int c = threadIdx.x;
+        for (; c + 768 < cols; c += 1024) {
+            const double a = p[c], b = p[c + 256], d = p[c + 512], e = p[c + 768];
+            s0 += a * a; s1 += b * b; s2 += d * d; s3 += e * e;
+        }
+        for (; c < cols; c += 256) { const double a = p[c]; s0 += a * a; }
+        double s = (s0 + s1) + (s2 + s3);
         for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-        if (lane == 0) out[r] = sqrt(s);
+        if (lane == 0) red[wid] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) out[r] = sqrt((red[0] + red[1]) + (red[2] + red[3]));
+        __syncthreads();
     }
 }
 
@@ -374,8 +386,8 @@ int copy2d(ctm_ctx* ctx, const double* src, long long lds, double* dst, long lon
 }
 
 int row_norms(ctm_ctx* ctx, const double* x, int rows, int cols, long long ld, double* d_out) {
-    int blocks = (rows + 3) / 4; if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(row_norms_kernel, dim3(blocks), dim3(TB), 0, ctx->stream, x, rows, cols, ld, d_out);
+    const int blocks = std::max(1, std::min(rows, 4096));           // one 256-thread workgroup per row
+    hipLaunchKernelGGL(row_norms_kernel, dim3(blocks), dim3(256), 0, ctx->stream, x, rows, cols, ld, d_out);
     LAUNCH_CHECK(ctx, "row_norms");
     return CTM_OK;
 }
@@ -461,7 +473,7 @@ int norm2_f64(ctm_ctx* ctx, const double* x, size_t n, double* tmp, double* d_ou
     const int rows = (int)(n / cols);
     const size_t rem = n - (size_t)rows * cols;
     int nr = rows;
-    if (rows > 0) hipLaunchKernelGGL(row_norms_kernel, dim3(std::max(1, std::min((rows + 3) / 4, 2048))), dim3(256), 0, ctx->stream, x, rows, cols, (long long)cols, tmp);
+    if (rows > 0) hipLaunchKernelGGL(row_norms_kernel, dim3(std::max(1, std::min(rows, 4096))), dim3(256), 0, ctx->stream, x, rows, cols, (long long)cols, tmp);
     if (rem > 0) { hipLaunchKernelGGL(row_norms_kernel, dim3(1), dim3(256), 0, ctx->stream, x + (size_t)rows * cols, 1, (int)rem, (long long)rem, tmp + rows); ++nr; }
     hipLaunchKernelGGL(norm_of_norms_kernel, dim3(1), dim3(64), 0, ctx->stream, (const double*)tmp, nr, d_out);
     return CTM_OK;
