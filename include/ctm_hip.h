@@ -49,8 +49,8 @@ const char* ctm_version(void);
 int ctm_sync(ctm_ctx* ctx);
 int ctm_trim(ctm_ctx* ctx);   /* release the context's workspace arena (regrown on demand); call between engine calls */
 int ctm_set_option(ctm_ctx* ctx, const char* key, double value);
-/*   truncation:  "jacobi_tol","jacobi_max_sweeps","jacobi_block","jacobi_inner_sweeps","jacobi_verbose","eig64_pingpong",
- *                "si_enable","si_min_n","si_max_iter","si_tol","si_rr_sweeps","si_warm_skip_calls","rank_tol","lz_enable","lz_min_k","lz_switch_steps"
+/*   truncation:  "jacobi_tol","jacobi_max_sweeps","jacobi_block","jacobi_inner_sweeps","jacobi_inner_sweeps_many","jacobi_verbose","eig64_pingpong",
+ *                "si_enable","si_min_n","si_max_iter","si_tol","si_rr_sweeps","si_warm_skip_calls","si_block32","rank_tol","lz_enable","lz_min_k","lz_switch_steps"
  *   kernels:     "use_layer2","layer2_reg","layer2_cplx","gemm_fast","gemm_strip","strip_target_wgs","gemm_split_rem",
  *                "splitk_max_tiles","splitk_target_wgs","einsum_in_relayout","z_spectators_first","chain_as_strips","gemm_log"
  *   measurement: "gemm_timing","profile"                                                                                      */

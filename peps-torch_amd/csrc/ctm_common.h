@@ -49,7 +49,8 @@ struct ctm_ctx {
     int jacobi_block = 32;
     int jacobi_max_sweeps = 30;
     double jacobi_tol = 1e-14;
-    int jacobi_inner_sweeps = 2;
+    int jacobi_inner_sweeps = 2;        // inner sweeps of the LDS eigensolver per visit of a pair (2 or 3 pairs per round)
+    int jacobi_inner_sweeps_many = 1;   // ... when a round has >= 4 pairs (dense small SVDs, full-block Rayleigh-Ritz): measured faster
     int jacobi_verbose = 0;
     // leading-k block power iteration (svd_iter): enabled for n >= si_min_n, residual tolerance relative to s_0
     bool si_enable = true;

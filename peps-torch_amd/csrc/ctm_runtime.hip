@@ -99,6 +99,7 @@ int ctm_set_option(ctm_ctx* ctx, const char* key, double value) {
     else if (k == "jacobi_max_sweeps") ctx->jacobi_max_sweeps = (int)value;
     else if (k == "jacobi_block") ctx->jacobi_block = (int)value;
     else if (k == "jacobi_inner_sweeps") ctx->jacobi_inner_sweeps = (int)value;
+    else if (k == "jacobi_inner_sweeps_many") ctx->jacobi_inner_sweeps_many = (int)value;
     else if (k == "jacobi_verbose") ctx->jacobi_verbose = (int)value;
     else if (k == "si_enable") ctx->si_enable = value != 0.0;
     else if (k == "si_min_n") ctx->si_min_n = (int)value;
