@@ -1,0 +1,35 @@
+"""GPU: the site-sharded move on two ranks (one process per rank, gloo, both ranks on this one GPU) against one process --
+at n = 8192, where the corner cache, the cache-aware unit ownership and the masked-column absorb are all active.  The
+environments must agree exactly (same kernels, same operands; sharding only decides who computes which unit)."""
+import json, os, subprocess, sys
+import pytest
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(tmp, nranks, port):
+    out = os.path.join(tmp, f"d{nranks}.json")
+    env = dict(os.environ, CTM_BENCH_ONE_DEVICE="1", CTM_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    tool = os.path.join(REPO, "tools", "check_dist_gpu.py")
+    if nranks == 1:
+        cmd = [sys.executable, tool, out]
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nranks}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), tool, out]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return json.load(open(out))
+
+
+def test_two_ranks_on_one_gpu_equal_one_process(tmp_path):
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    a = _run(str(tmp_path), 1, port)
+    b = _run(str(tmp_path), 2, port)
+    assert b["ncol"] and max(b["ncol"].values()) <= 64            # the masked-column absorb was active on the ranks
+    for k in a:
+        if k in ("checksum", "ncol"):
+            continue
+        assert a[k] == b[k], k
+    assert a["checksum"] == b["checksum"]
