@@ -172,8 +172,28 @@ def ctm_MOVE(direction, state, env, ctm_args=cfg.ctm_args, global_args=cfg.globa
         for coord in coords:
             R_n = _proj_rows(direction, coord, state, chi)
             shp[coord] = (R_n, min(chi, R_n))
-        P = parallel.exchange(P, coords, shp, like, owners=ownersA)
-        Pt = parallel.exchange(Pt, coords, shp, like, owners=ownersA)
+        w = None
+        if env.__dict__.get("_ncol") is not None and len({s_ for s_ in shp.values()}) == 1:
+            # only the non-zero prefix of the projector columns travels: agree on its (rounded) width first
+            nc = env.__dict__["_ncol"]
+            w = parallel.allreduce_max_int(max([nc.get((direction, state.vertexToSite(c)), chi) for c in mineA] + [0]), like.device)
+            w = min(chi, max(16, (w + 15) // 16 * 16))
+            if 2 * w > chi:
+                w = None
+        if w is not None:
+            shw = {c: (shp[c][0], w) for c in coords}
+            Pw = parallel.exchange({c: P[c][:, :w].contiguous() for c in mineA}, coords, shw, like, owners=ownersA)
+            Ptw = parallel.exchange({c: Pt[c][:, :w].contiguous() for c in mineA}, coords, shw, like, owners=ownersA)
+
+            def widen(x, c):
+                full = torch.zeros(shp[c], dtype=x.dtype, device=x.device)
+                full[:, :w] = x
+                return full
+            P = {c: widen(Pw[c], c) for c in coords}
+            Pt = {c: widen(Ptw[c], c) for c in coords}
+        else:
+            P = parallel.exchange(P, coords, shp, like, owners=ownersA)
+            Pt = parallel.exchange(Pt, coords, shp, like, owners=ownersA)
         if env.__dict__.get("_ncol") is not None:
             # every rank needs the count of non-zero projector columns of every site: read it off the gathered projectors
             # (the non-zero columns are a prefix)

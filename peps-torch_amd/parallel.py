@@ -88,3 +88,11 @@ def allreduce_sum_scalar(x, device):
     t = torch.tensor([float(x)], dtype=torch.float64, device=device)
     dist.all_reduce(t)
     return float(t.item())
+
+
+def allreduce_max_int(x, device):
+    if not is_distributed():
+        return int(x)
+    t = torch.tensor([int(x)], dtype=torch.int64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return int(t.item())
