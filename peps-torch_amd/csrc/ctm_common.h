@@ -54,7 +54,7 @@ struct ctm_ctx {
     int jacobi_verbose = 0;
     // leading-k block power iteration (svd_iter): enabled for n >= si_min_n, residual tolerance relative to s_0
     bool si_enable = true;
-    int si_min_n = 512, si_max_iter = 40, si_last_iters = 0, si_rr_sweeps = 40, si_last_rank = 0;
+    int si_min_n = 256, si_max_iter = 40, si_last_iters = 0, si_rr_sweeps = 40, si_last_rank = 0;
     bool si_block32 = true;       // warm start with numerical rank <= 24: 32-row block
     int si_warm_skip_calls = 3;   // after a hopeless warm start (residual > 1e-6 s0): calls of that workspace that start cold
     long si_warm_skips = 0;

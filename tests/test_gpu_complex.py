@@ -46,7 +46,7 @@ def test_truncated_svd_c128_full(eng, n, chi):
 
 
 def test_truncated_svd_c128_iterative(eng):
-    """n >= 512: leading-chi triplets by the complex block power iteration (residual-verified)."""
+    """n >= 256 (si_min_n): leading-chi triplets by the complex block power iteration (residual-verified)."""
     rng = np.random.default_rng(5)
     n, chi = 640, 24
     Q1, _ = np.linalg.qr(crand(rng, n, n)); Q2, _ = np.linalg.qr(crand(rng, n, n))

@@ -1,4 +1,4 @@
-"""GPU: the production configuration of the truncation (n >= 512: implicit-operator block power iteration, warm started
+"""GPU: the production configuration of the truncation (n >= 256 (si_min_n): implicit-operator block power iteration, warm started
 from the previous sweep, four site-units on concurrent streams) against the numpy oracle (LAPACK gesdd on the explicit
 M = R^T Rt) over several full sweeps, on states with a non-trivial spectrum (signed random tensors, f64 and c128)."""
 import numpy as np
