@@ -82,7 +82,6 @@ struct ctm_ctx {
     bool gemm_fast = true;
     bool einsum_in_relayout = true, z_spectators_first = true;   // layout of the fused two-layer kernel's input (contract.hip)
     bool chain_as_strips = true;  // projector columns (<= 64) kept as rows through the two corner passes
-    bool ld_swap = false;          // LD corner: contract T2 before T1 (layout of the two-layer kernel's input)
     int splitk_reduce_vec = 1;
     bool gemm_log = false;        // debug: print every GEMM shape to stderr
     bool gemm_strip = true;       // streaming kernel for <= 64 rows times a big operand

@@ -287,15 +287,6 @@ int corner_impl(ctm_ctx* ctx, int corner, int open, const DT& C, const DT& T1, c
         e = e.substr(0, ar + 2) + o.substr(o.size() - 2) + o.substr(0, o.size() - 2);
         return dev_network(ctx, e, {tC, tT1, tT2, tA, tA.conj()}, res);
     }
-    if (corner == CTM_LD && ctx->ld_swap) {
-        // LD in table order gives the intermediate Z[x,lL,dD,y] with the SPECTATOR index y contiguous: the fused two-layer kernel
-        // then gathers every element of an (x,y) block from its own cache line (1.9 ms of 4.9 ms at D=8 chi=256).  Contracting T2
-        // first gives Z[dD,y,x,lL] -- 64 contiguous doubles per (x,y,dD) -- like the other three corners.
-        std::string e(open ? sp.open : sp.closed);            // "ab,xalL,dDby,..." -> "ab,dDby,xalL,..."
-        const size_t c1 = e.find(','), c2 = e.find(',', c1 + 1), c3 = e.find(',', c2 + 1);
-        e = e.substr(0, c1 + 1) + e.substr(c2 + 1, c3 - c2) + e.substr(c1 + 1, c2 - c1 - 1) + e.substr(c3);
-        return dev_network(ctx, e, {tC, tT2, tT1, tA, tA.conj()}, res);
-    }
     return dev_network(ctx, open ? sp.open : sp.closed, {tC, tT1, tT2, tA, tA.conj()}, res);
 }
 
