@@ -174,7 +174,9 @@ def main():
     args = ap.parse_args()
     kind, D, chi, dtype = CONFIGS[args.config]
     steps = args.steps if args.steps is not None else (20 if kind == "c4v" else 2)
-    warmup = args.warmup if args.warmup is not None else (3 if kind == "c4v" else 1)
+    # untimed warm-up: ceil(chi / D^2) sweeps, the number after which the environment from the CTMRG init has filled its chi
+    # (reference ctmrg.py:81)
+    warmup = args.warmup if args.warmup is not None else (3 if kind == "c4v" else -(-chi // (D * D)))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
