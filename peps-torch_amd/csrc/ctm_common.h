@@ -85,7 +85,7 @@ struct ctm_ctx {
     int splitk_reduce_vec = 1;
     bool gemm_log = false;        // debug: print every GEMM shape to stderr
     bool gemm_strip = true;       // streaming kernel for <= 64 rows times a big operand
-    int strip_target_wgs = 1024;
+    int strip_target_wgs = 512;   // K slices x column tiles of the strip kernel: fewer slices = fewer partials (measured 512 <= 1024, 256)
     bool gemm_split_rem = true;   // split a 128 q + r (r <= 64) dimension into a vectorised part and a strip
     int splitk_max_tiles = 256, splitk_target_wgs = 1024;   // split-K of skinny GEMMs: when few output tiles, how many workgroups to aim for
     bool eig64_pingpong = true;

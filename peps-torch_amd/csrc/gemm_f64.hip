@@ -496,8 +496,8 @@ int gemm_f64(ctm_ctx* ctx, const GemmDesc& d) {
         (((uintptr_t)d.A | (uintptr_t)d.B) & 15) == 0 && d.sam % 2 == 0 && (d.sbn == 1 ? d.sbk : d.sbn) % 2 == 0) {
         const bool bnf = d.sbn == 1;
         const int gx = (d.N / 32 + 3) / 4;
-        // 49..64 rows are MFMA bound with 2 waves per SIMD resident: half the K slices (half the partials) keep the chip as busy
-        const int target = d.M > 48 ? ctx->strip_target_wgs / 2 : ctx->strip_target_wgs;
+        // big operands (>= 1 GB): fewer K slices, fewer partials; smaller ones need the extra workgroups to fill the chip
+        const int target = ((long long)d.N * d.K >= (1ll << 27)) ? ctx->strip_target_wgs : 2 * ctx->strip_target_wgs;
         int ks = std::max(1, std::min(std::min((target + gx - 1) / gx, d.K / 256), 64));
         int klen = (((d.K + ks - 1) / ks) + 15) / 16 * 16;
         ks = (d.K + klen - 1) / klen;
