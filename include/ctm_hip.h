@@ -85,8 +85,18 @@ int ctm_normalize_inf(ctm_ctx* ctx, double* x, long long n);
 /* M is n x n; U,V are n x chi (row-major), S is chi.  Columns beyond the last complete multiplet are zeroed. */
 int ctm_truncated_svd(ctm_ctx* ctx, const double* M, int n, int chi, const ctm_trunc_cfg* cfg, double* U, double* S,
                       double* V);
+/* Same, warm started from the decomposition of a nearby matrix: `basis` as for ctm_projectors_4x4_ws ((min(chi+1,n) + 1) * n
+ * doubles, CTM_C128 (2 min(chi+1,n) + 1) * n; zero-filled before the first call, passed again for the next matrix of the
+ * sequence).  The result does not depend on the basis (residual-verified, and a full block started from it is not accepted
+ * before its guard rows have seen the operator three times); only the work does. */
+int ctm_truncated_svd_ws(ctm_ctx* ctx, const double* M, int n, int chi, const ctm_trunc_cfg* cfg, double* U, double* S,
+                         double* V, double* basis);
 /* A symmetric (lower triangle referenced); D (chi, signed, ordered by |D| descending), U n x chi */
 int ctm_truncated_eigh(ctm_ctx* ctx, const double* A, int n, int chi, const ctm_trunc_cfg* cfg, double* D, double* U);
+/* SVD of a real SYMMETRIC matrix through its eigendecomposition (linalg/svd_symeig.py:12-34 SVDSYMEIG.forward and
+ * linalg/custom_svd.py:143-208 truncated_svd_symeig): A = U D U^T ordered by |D| descending, S = |D|, V = U sign(D);
+ * U, V n x min(chi,n), S min(chi,n); chi = n gives the full decomposition; cfg NULL: no multiplet back-off.  CTM_F64 only. */
+int ctm_svd_symeig(ctm_ctx* ctx, const double* A, int n, int chi, const ctm_trunc_cfg* cfg, double* U, double* S, double* V);
 /* singular values of an n x n matrix, descending (ENV.get_spectra, env.py:204-209) */
 int ctm_svdvals(ctm_ctx* ctx, const double* M, int n, double* S);
 

@@ -248,6 +248,25 @@ def truncated_eig_sym(M, chi, abs_tol=1.0e-14, keep_multiplets=False, eps_multip
     return D[:k], U[:, :k]
 
 
+def truncated_svd_symeig(M, chi, abs_tol=1.0e-14, keep_multiplets=False, eps_multiplet=1.0e-12):
+    """svd_symeig.py:12-34 (SVDSYMEIG.forward: eigh -> order by |D| descending -> S = |D|, V = U sign(D)) followed by the
+    truncation of custom_svd.py:143-208.  torch.symeig (ascending, lower triangle) is restated with LAPACK eigh; the
+    reference function itself cannot run on a current torch (torch.symeig was removed), so this restatement is pinned through
+    its defining identities M = U S V^T, V = U sign(D) and through truncated_eig_sym (tests/test_oracle_golden.py)."""
+    D, U = np.linalg.eigh(M)
+    p = np.argsort(-np.abs(D), kind='stable')
+    D, U = D[p], U[:, p]
+    S, V = np.abs(D), U * np.sign(D)[None, :]
+    if keep_multiplets and chi < S.shape[0]:
+        chi_new = multiplet_chi(S, chi, eps_multiplet, abs_tol)
+        St = S[:chi].copy(); St[chi_new + 1:] = 0.
+        Ut = U[:, :chi].copy(); Ut[:, chi_new + 1:] = 0.
+        Vt = V[:, :chi].copy(); Vt[:, chi_new + 1:] = 0.
+        return Ut, St, Vt
+    k = min(chi, S.shape[0])
+    return U[:, :k], S[:k], V[:, :k]
+
+
 # ----------------------------------------------------------------------------------
 # projectors (ctm/generic/ctm_projectors.py:142-293)
 # ----------------------------------------------------------------------------------

@@ -470,8 +470,41 @@ def variants_check():
         print("corrf + transfer-operator spectrum ok:", name)
 
 
+def input_files_case():
+    """a18: the reference's own test-input DATA files (legacy "entries" format with aux_seq, "1D" format, multi-site cells with a
+    pattern) copied as fixtures, next to the arrays the REFERENCE's read_ipeps / read_ipeps_c4v parse from them."""
+    import shutil
+    set_dtype(False)
+    src = '/root/reference/test-input'
+    dst = os.path.join(GOLD, 'test-input')
+    os.makedirs(dst, exist_ok=True)
+    files = ["RVB_1x1.in", "RVB_2x1_AB.in", "RVB_2x2_ABCD.in", "VBS_1x2_AB_D2.in", "AKLT-S2_2x1_biLat.in", "AKLT-S2_2x2_ABCD.in",
+             "gesdd-D2-chi50-j20.55-run0-iRND2x1_state.json", "BIPARTITE_j2_0_j3_1250_h_39000_D_3_chi_32_seed_100_state.json"]
+    out = {}
+    for f in files:
+        shutil.copyfile(os.path.join(src, f), os.path.join(dst, f))
+        os.chmod(os.path.join(dst, f), 0o644)
+        st = read_ipeps(os.path.join(src, f))
+        tag = f.replace('.', '_').replace('-', '_')
+        out[f"{tag}__lXlY"] = np.array([st.lX, st.lY])
+        for c, t in st.sites.items():
+            out[f"{tag}__site_{c[0]}_{c[1]}"] = t2n(t)
+        # the tiling the file's own pattern (or the default PBC) defines, probed on a window around the origin
+        win = [(x, y) for y in range(-3, 4) for x in range(-3, 4)]
+        out[f"{tag}__v2s"] = np.array([st.vertexToSite(v) for v in win])
+        for asq in ([0, 1, 2, 3], [3, 0, 1, 2]):
+            st2 = read_ipeps(os.path.join(src, f), aux_seq=asq)
+            out[f"{tag}__aux{''.join(map(str, asq))}"] = t2n(next(iter(st2.sites.values())))
+    s4 = read_ipeps_c4v(os.path.join(src, "RVB_1x1.in"))
+    out["RVB_1x1_in__c4v_site"] = t2n(s4.site())
+    np.savez_compressed(os.path.join(GOLD, "test_input_parsed.npz"), **out)
+    print("  input files: copied", len(files), "reference data files and the arrays the reference parses from them")
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["decomp", "generic", "c4v", "rvb", "files", "variants", "aklt"]
+    which = sys.argv[1:] or ["decomp", "generic", "c4v", "rvb", "files", "variants", "aklt", "inputs"]
+    if "inputs" in which:
+        input_files_case()
     if "aklt" in which:
         aklt_case()
     if "variants" in which:

@@ -46,7 +46,9 @@ _SIGS = {
     "ctm_normalize_inf": [C.c_void_p, C.c_void_p, C.c_longlong],
     "ctm_einsum": [C.c_void_p, C.c_char_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_longlong), C.POINTER(C.c_int), C.c_void_p],
     "ctm_truncated_svd": [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(TruncCfg), C.c_void_p, C.c_void_p, C.c_void_p],
+    "ctm_truncated_svd_ws": [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(TruncCfg), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
     "ctm_truncated_eigh": [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(TruncCfg), C.c_void_p, C.c_void_p],
+    "ctm_svd_symeig": [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(TruncCfg), C.c_void_p, C.c_void_p, C.c_void_p],
     "ctm_svdvals": [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p],
     "ctm_c2x2": [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_void_p],
     "ctm_halves": [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_int), C.c_void_p, C.c_void_p],
@@ -152,6 +154,13 @@ class Engine:
     def _bind(self, *tensors):
         """Select the native context for the dtype of the tensor arguments and validate them."""
         dt = tensors[0].dtype if isinstance(tensors[0], torch.Tensor) else None
+        # the native contexts (arena, stream, kernels) live on self.device: make it the calling thread's current HIP device and
+        # refuse tensors of another GPU instead of launching on device-A pointers from device B
+        if torch.cuda.current_device() != self.device.index:
+            torch.cuda.set_device(self.device)
+        for t in tensors:
+            if isinstance(t, torch.Tensor) and t.is_cuda and t.device != self.device:
+                raise NativeError(f"tensor on {t.device} passed to the engine of {self.device}: use _native.engine(tensor.device)")
         self._bind_dtype(dt)
         out = [_chk_t(t, "tensor", dt) for t in tensors]
         return out[0] if len(out) == 1 else out
@@ -301,7 +310,8 @@ class Engine:
         return x
 
     # ---- truncation -----------------------------------------------------------------------------
-    def truncated_svd(self, M, chi, cfg=None):
+    def truncated_svd(self, M, chi, cfg=None, basis=None):
+        """basis: optional warm-start workspace from warm_basis(chi, n, dtype), updated in place (sequence of nearby matrices)."""
         M = self._bind(M)
         n = M.shape[0]
         if M.dim() != 2 or M.shape[1] != n:
@@ -309,7 +319,13 @@ class Engine:
         kc = min(chi, n)
         U, S, V = self.empty(n, kc), self.empty_real(kc), self.empty(n, kc)
         cfg = cfg or self.default_cfg
-        self._ck(self.lib.ctm_truncated_svd(self.h, _ptr(M), n, chi, C.byref(cfg), _ptr(U), _ptr(S), _ptr(V)), "truncated_svd")
+        if basis is not None:
+            k = chi + 1 if chi < n else n
+            if not (basis.is_cuda and basis.dtype == torch.float64 and basis.is_contiguous()
+                    and tuple(basis.shape) == ((2 if M.dtype.is_complex else 1) * k + 1, n)):
+                raise NativeError("truncated_svd: basis must come from warm_basis(chi, n, dtype)")
+        self._ck(self.lib.ctm_truncated_svd_ws(self.h, _ptr(M), n, chi, C.byref(cfg), _ptr(U), _ptr(S), _ptr(V),
+                                               _ptr(basis) if basis is not None else None), "truncated_svd")
         return U, S, V
 
     def truncated_eigh(self, A, chi, cfg=None):
@@ -320,6 +336,17 @@ class Engine:
         cfg = cfg or self.cfg(eps_multiplet=1e-12)
         self._ck(self.lib.ctm_truncated_eigh(self.h, _ptr(A), n, chi, C.byref(cfg), _ptr(D), _ptr(U)), "truncated_eigh")
         return D, U
+
+    def svd_symeig(self, A, chi=None, cfg=None):
+        """SVD of a real symmetric matrix from its eigendecomposition: U, S = |D|, V = U sign(D), ordered by |D| descending."""
+        A = self._bind(A)
+        n = A.shape[0]
+        chi = n if chi is None else chi
+        kc = min(chi, n)
+        U, S, V = self.empty(n, kc), self.empty_real(kc), self.empty(n, kc)
+        cfg = cfg or self.cfg(eps_multiplet=1e-12, keep_multiplets=False)
+        self._ck(self.lib.ctm_svd_symeig(self.h, _ptr(A), n, chi, C.byref(cfg), _ptr(U), _ptr(S), _ptr(V)), "svd_symeig")
+        return U, S, V
 
     def svdvals(self, M):
         M = self._bind(M)
@@ -535,7 +562,13 @@ def engine(device=None):
     """Process-wide engine per device (created lazily)."""
     if not torch.cuda.is_available():
         raise NativeError("no HIP device visible: the CTM engine runs only on the GPU (no CPU fallback)")
-    idx = torch.cuda.current_device() if device is None else torch.device(device).index or 0
+    if device is None:
+        idx = torch.cuda.current_device()
+    else:
+        d = torch.device(device)
+        if d.type != "cuda":
+            raise NativeError(f"the CTM engine runs only on HIP devices, not on '{device}'")
+        idx = d.index if d.index is not None else torch.cuda.current_device()
     if idx not in _engines:
         _engines[idx] = Engine(torch.device("cuda", idx))
     return _engines[idx]

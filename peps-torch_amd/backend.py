@@ -27,4 +27,7 @@ def get_engine():
     if _override is not None:
         return _override
     import _native
-    return _native.engine()
+    import config as cfg
+    dev = str(getattr(cfg.global_args, "device", "") or "")
+    # the engine of the device the host layer was configured for (--GLOBALARGS_device cuda:N), else of the current device
+    return _native.engine(dev) if dev.startswith("cuda") else _native.engine()

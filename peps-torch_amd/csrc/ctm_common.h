@@ -21,6 +21,17 @@
         }                                                                               \
     } while (0)
 
+// kernel launch on the context's stream with the launch error checked (a failed launch must not come back as CTM_OK)
+#define CTM_LAUNCH(ctx, kernel, grid, block, shmem, ...)                                              \
+    do {                                                                                              \
+        hipLaunchKernelGGL(kernel, grid, block, shmem, (ctx)->stream, __VA_ARGS__);                   \
+        hipError_t _le = hipGetLastError();                                                           \
+        if (_le != hipSuccess) {                                                                      \
+            (ctx)->set_error(std::string("launch of " #kernel ": ") + hipGetErrorString(_le));        \
+            return CTM_ERR_HIP;                                                                       \
+        }                                                                                             \
+    } while (0)
+
 #define CTM_TRY(expr)                        \
     do {                                     \
         int _s = (expr);                     \
@@ -56,7 +67,7 @@ struct ctm_ctx {
     bool si_enable = true;
     int si_min_n = 256, si_max_iter = 40, si_last_iters = 0, si_rr_sweeps = 40, si_last_rank = 0;
     bool si_block32 = true;       // warm start with numerical rank <= 24: 32-row block
-    int si_warm_skip_calls = 3;   // after a hopeless warm start (residual > 1e-6 s0): calls of that workspace that start cold
+    int si_warm_skip_calls = 12;  // upper bound on the calls of a unit that start cold after its warm probe went to the Krylov solver
     long si_warm_skips = 0;
     long corner_cache_hits = 0;
     double si_tol = 2e-14;
@@ -64,6 +75,11 @@ struct ctm_ctx {
     long si_hits = 0, si_fallbacks = 0, si_total_iters = 0, si_warm_starts = 0;
     // block Golub-Kahan-Lanczos for spectra that do not collapse inside a small block (svd_lanczos)
     bool lz_enable = true; int lz_min_k = 48; double lz_switch_steps = 6.0; double lz_last_resid = 1.0; long lz_hits = 0, lz_total_steps = 0;
+    int lz_first = 0;                   // > 0: first Ritz extraction after this many block steps (development); 0: policy of svd_lanczos
+    int lz_stride = 0;                  // > 0: fixed distance between Ritz extractions (development); 0: predicted from the residual estimate
+    double lz_first_factor = 3.25;      // cold default: first extraction when the basis holds this many times k rows
+    bool lz_verify_op = false;          // additionally check both relations of the Ritz triplets with operator applications (debug / tests)
+    long lz_extractions = 0; double lz_last_est = 0.0; int lz_last_steps = 0;
     int last_sweeps = 0;
     long total_sweeps = 0, jacobi_calls = 0;
     double last_offnorm = 0;

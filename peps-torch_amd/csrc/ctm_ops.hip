@@ -178,8 +178,8 @@ int svd_rows_op(ctm_ctx* ctx, const MatOp& op, int chi, const ctm_trunc_cfg& cfg
     if (cfg.fix_signs) {
         const int kf = std::min(k, chi);
         const size_t kn = (size_t)k * n;
-        if (ctx->cplx) hipLaunchKernelGGL(fix_phase_rows_c_kernel, dim3(kf), dim3(256), 0, ctx->stream, Ut, Ut + kn, Vt, Vt + kn, kf, n);
-        else hipLaunchKernelGGL(fix_signs_rows_kernel, dim3(kf), dim3(256), 0, ctx->stream, Ut, Vt, kf, n);
+        if (ctx->cplx) CTM_LAUNCH(ctx, fix_phase_rows_c_kernel, dim3(kf), dim3(256), 0, Ut, Ut + kn, Vt, Vt + kn, kf, n);
+        else CTM_LAUNCH(ctx, fix_signs_rows_kernel, dim3(kf), dim3(256), 0, Ut, Vt, kf, n);
     }
     const int kc = std::min(chi, n);
     to->keep_last = kc - 1;
@@ -187,15 +187,18 @@ int svd_rows_op(ctm_ctx* ctx, const MatOp& op, int chi, const ctm_trunc_cfg& cfg
     return CTM_OK;
 }
 
-int svd_rows(ctm_ctx* ctx, const DT& M, int n, int chi, const ctm_trunc_cfg& cfg, double* Ut, double* Vt, double* dS, TruncOut* to) {
+int svd_rows(ctm_ctx* ctx, const DT& M, int n, int chi, const ctm_trunc_cfg& cfg, double* Ut, double* Vt, double* dS, TruncOut* to,
+             double* basis = nullptr) {
     MatOp op; op.n = n; op.M = M.p; op.Mi = M.q;
+    if (basis) { const int k = (chi < n) ? chi + 1 : n; op.warm = basis; op.warm_hdr = basis + (size_t)(ctx->cplx ? 2 : 1) * k * n; }
     return svd_rows_op(ctx, op, chi, cfg, Ut, Vt, dS, to);
 }
 
 // U (n x kc) = (rows 0..kc of the k x n row factor)^H with the columns beyond keep_last zeroed; planar in complex contexts
-void rows_to_cols(ctm_ctx* ctx, const double* rows, int k, int n, int kc, int keep_last, const DT& out) {
-    hipLaunchKernelGGL(rows_to_cols_kernel, dim3(1024), dim3(256), 0, ctx->stream, rows, n, kc, keep_last, out.p, 1.0);
-    if (out.q) hipLaunchKernelGGL(rows_to_cols_kernel, dim3(1024), dim3(256), 0, ctx->stream, rows + (size_t)k * n, n, kc, keep_last, out.q, -1.0);
+int rows_to_cols(ctm_ctx* ctx, const double* rows, int k, int n, int kc, int keep_last, const DT& out) {
+    CTM_LAUNCH(ctx, rows_to_cols_kernel, dim3(1024), dim3(256), 0, rows, n, kc, keep_last, out.p, 1.0);
+    if (out.q) CTM_LAUNCH(ctx, rows_to_cols_kernel, dim3(1024), dim3(256), 0, rows + (size_t)k * n, n, kc, keep_last, out.q, -1.0);
+    return CTM_OK;
 }
 
 // S_sqrt = rsqrt(S) where S/S[0] > reltol (ctm_projectors.py:266-270), zero beyond the kept multiplets
@@ -243,7 +246,7 @@ int corner_chain_times_rowsT(ctm_ctx* ctx, int n, int mid, int k, int kc, int nc
         CTM_TRY(pass(rows, n, mid, cB, !tB, t1t));
         CTM_TRY(pass(t1t, mid, n, cA, !tA, ot));
         const long long tot = (long long)n * ncol;
-        hipLaunchKernelGGL(transpose_scale_kernel, dim3((int)std::min<long long>((tot + 255) / 256, 2048)), dim3(256), 0, ctx->stream,
+        CTM_LAUNCH(ctx, transpose_scale_kernel, dim3((int)std::min<long long>((tot + 255) / 256, 2048)), dim3(256), 0,
                            (const double*)ot, ncol, n, out.p, (long long)kc, d_scale);
         return CTM_OK;
     }
@@ -430,6 +433,11 @@ int ctm_halves(ctm_ctx* ctx, int dir, const double* const* t, int chi, const int
 }
 
 int ctm_truncated_svd(ctm_ctx* ctx, const double* M, int n, int chi, const ctm_trunc_cfg* cfg_, double* U, double* S, double* V) {
+    return ctm_truncated_svd_ws(ctx, M, n, chi, cfg_, U, S, V, nullptr);
+}
+
+int ctm_truncated_svd_ws(ctm_ctx* ctx, const double* M, int n, int chi, const ctm_trunc_cfg* cfg_, double* U, double* S, double* V,
+                         double* basis) {
     const ctm_trunc_cfg cfg = cfg_ ? *cfg_ : kDefaultCfg;
     if (chi < 1 || n < 1) { ctx->set_error("truncated_svd: bad dims"); return CTM_ERR_BADARG; }
     PhaseTimer pt(ctx, CTM_T_SVD);
@@ -445,12 +453,12 @@ int ctm_truncated_svd(ctm_ctx* ctx, const double* M, int n, int chi, const ctm_t
     CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)k * n * cz, (void**)&Vt));
     CTM_TRY(arena_alloc(ctx, sizeof(double) * k, (void**)&dS));
     TruncOut to;
-    CTM_TRY(svd_rows(ctx, tM, n, chi, cfg, Ut, Vt, dS, &to));
+    CTM_TRY(svd_rows(ctx, tM, n, chi, cfg, Ut, Vt, dS, &to, basis));
     std::vector<double> Sh(kc);
     for (int i = 0; i < kc; ++i) Sh[i] = (i <= to.keep_last) ? to.S[i] : 0.0;
     CTM_HIP_CHECK(ctx, hipMemcpyAsync(S, Sh.data(), sizeof(double) * kc, hipMemcpyHostToDevice, ctx->stream));
-    rows_to_cols(ctx, Ut, k, n, kc, to.keep_last, tU);
-    rows_to_cols(ctx, Vt, k, n, kc, to.keep_last, tV);
+    CTM_TRY(rows_to_cols(ctx, Ut, k, n, kc, to.keep_last, tU));
+    CTM_TRY(rows_to_cols(ctx, Vt, k, n, kc, to.keep_last, tV));
     CTM_TRY(io.finish());
     CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     return CTM_OK;
@@ -483,11 +491,41 @@ int truncated_eigh_impl(ctm_ctx* ctx, const double* A, int n, int chi, const ctm
     std::vector<double> Do(kc);
     for (int i = 0; i < kc; ++i) Do[i] = (i <= keep_last) ? Dh[i] : 0.0;
     CTM_HIP_CHECK(ctx, hipMemcpyAsync(D, Do.data(), sizeof(double) * kc, hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(rows_to_cols_kernel, dim3(1024), dim3(256), 0, ctx->stream, Ut, n, kc, keep_last, U, 1.0);
+    CTM_LAUNCH(ctx, rows_to_cols_kernel, dim3(1024), dim3(256), 0, Ut, n, kc, keep_last, U, 1.0);
     CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     return CTM_OK;
 }
 }  // namespace
+
+// svd_symeig (linalg/svd_symeig.py:12-34): V[:, j] = U[:, j] sign(D[j]), S[j] = |D[j]|  (sign(0) = 0 as torch.sign)
+__global__ void symeig_to_svd_kernel(const double* __restrict__ U, const double* __restrict__ D, int n, int kc, double* __restrict__ V,
+                                     double* __restrict__ S) {
+    const size_t tot = (size_t)n * kc;
+    for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < tot; q += (size_t)gridDim.x * blockDim.x) {
+        const int j = (int)(q % kc);
+        const double d = D[j];
+        V[q] = U[q] * (d > 0.0 ? 1.0 : (d < 0.0 ? -1.0 : 0.0));
+        if (q < (size_t)kc) S[q] = fabs(D[q]);
+    }
+}
+
+int ctm_svd_symeig(ctm_ctx* ctx, const double* A, int n, int chi, const ctm_trunc_cfg* cfg_, double* U, double* S, double* V) {
+    ctm_trunc_cfg cfg = cfg_ ? *cfg_ : kDefaultCfg;
+    if (!cfg_) { cfg.eps_multiplet = 1.0e-12; cfg.keep_multiplets = 0; }
+    if (chi < 1 || n < 1) { ctx->set_error("svd_symeig: bad dims"); return CTM_ERR_BADARG; }
+    if (ctx->cplx) { ctx->set_error("svd_symeig: real symmetric matrices only (the reference uses torch.symeig)"); return CTM_ERR_UNSUPPORTED; }
+    ArenaScope scope(ctx);
+    const int kc = std::min(chi, n);
+    double* D;
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * kc, (void**)&D));
+    CTM_TRY(truncated_eigh_impl(ctx, A, n, chi, &cfg, D, U, nullptr));
+    const size_t tot = (size_t)n * kc;
+    CTM_LAUNCH(ctx, symeig_to_svd_kernel, dim3((int)std::min<size_t>((tot + 255) / 256, 2048)), dim3(256), 0,
+                       (const double*)U, (const double*)D, n, kc, V, S);
+    CTM_HIP_CHECK(ctx, hipGetLastError());
+    CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return CTM_OK;
+}
 
 int ctm_svdvals(ctm_ctx* ctx, const double* M, int n, double* S) {
     ArenaScope scope(ctx);

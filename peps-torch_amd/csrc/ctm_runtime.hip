@@ -126,6 +126,10 @@ int ctm_set_option(ctm_ctx* ctx, const char* key, double value) {
     else if (k == "lz_enable") ctx->lz_enable = value != 0.0;
     else if (k == "lz_min_k") ctx->lz_min_k = (int)value;
     else if (k == "lz_switch_steps") ctx->lz_switch_steps = value;
+    else if (k == "lz_first") ctx->lz_first = (int)value;
+    else if (k == "lz_stride") ctx->lz_stride = (int)value;
+    else if (k == "lz_first_factor") ctx->lz_first_factor = value;
+    else if (k == "lz_verify_op") ctx->lz_verify_op = value != 0.0;
     else if (k == "layer2_cplx") ctx->layer2_cplx = value != 0.0;
     else if (k == "layer2_reg") ctx->layer2_reg = (int)value;
     else if (k == "eig64_bpt") ctx->eig64_bpt = (int)value;
@@ -156,6 +160,9 @@ int ctm_get_stat(ctm_ctx* ctx, const char* key, double* value) {
     else if (k == "si_warm_starts") *value = (double)ctx->si_warm_starts;
     else if (k == "lz_hits") *value = (double)ctx->lz_hits;
     else if (k == "lz_total_steps") *value = (double)ctx->lz_total_steps;
+    else if (k == "lz_extractions") *value = (double)ctx->lz_extractions;
+    else if (k == "lz_last_est") *value = ctx->lz_last_est;
+    else if (k == "lz_last_steps") *value = (double)ctx->lz_last_steps;
     else if (k == "gemm_flops") *value = ctx->gemm_flops;
     else if (k == "gemm_calls") *value = (double)ctx->gemm_calls;
     else if (k == "layer2_flops") *value = ctx->layer2_flops;
@@ -184,7 +191,7 @@ int ctm_gemm_intervals(ctm_ctx* ctx, double* out, long long capacity, long long*
 
 int ctm_timers(ctm_ctx* ctx, double* out8, int reset) {
     for (int i = 0; i < CTM_T_COUNT; ++i) { if (out8) out8[i] = ctx->timers[i]; if (reset) ctx->timers[i] = 0.0; }
-    if (reset) { ctx->gemm_flops = 0; ctx->gemm_calls = 0; ctx->layer2_flops = 0; ctx->layer2_calls = 0; ctx->total_sweeps = 0; ctx->jacobi_calls = 0; ctx->si_hits = 0; ctx->si_fallbacks = 0; ctx->si_total_iters = 0; ctx->si_warm_starts = 0; ctx->lz_hits = 0; ctx->lz_total_steps = 0; }
+    if (reset) { ctx->gemm_flops = 0; ctx->gemm_calls = 0; ctx->layer2_flops = 0; ctx->layer2_calls = 0; ctx->total_sweeps = 0; ctx->jacobi_calls = 0; ctx->si_hits = 0; ctx->si_fallbacks = 0; ctx->si_total_iters = 0; ctx->si_warm_starts = 0; ctx->lz_hits = 0; ctx->lz_total_steps = 0; ctx->lz_extractions = 0; }
     return CTM_OK;
 }
 

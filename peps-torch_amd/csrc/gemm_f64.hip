@@ -511,7 +511,7 @@ int gemm_f64(ctm_ctx* ctx, const GemmDesc& d) {
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) { ctx->set_error(std::string("strip gemm launch: ") + hipGetErrorString(e)); return CTM_ERR_HIP; }
         const long long tot = (long long)d.M * d.N;
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)std::min<long long>((tot + 255) / 256, 2048)), dim3(256), 0, ctx->stream,
+        CTM_LAUNCH(ctx, splitk_reduce_kernel, dim3((int)std::min<long long>((tot + 255) / 256, 2048)), dim3(256), 0,
                            (const double*)part, ks, tot, d.C, d.M, d.N, d.ldc, d.alpha, d.beta, d.colscale, ctx->splitk_reduce_vec);
         const double fl = 2.0 * d.M * d.N * (double)d.K;
         timing_end(ctx, e0, 3, 8.0 * ((double)d.K * d.N + (double)d.M * d.K + (double)d.M * d.N));   // class 3 reports algorithmic BYTES
@@ -592,20 +592,20 @@ int gemm_f64(ctm_ctx* ctx, const GemmDesc& d) {
     const bool fast = fast_ks > 0 || (!small && !part && d.M % 128 == 0 && d.N % 128 == 0 && fast_operands(ctx, d));
     (void)amf; (void)bkf;
     if (fast) {
-        if (ak && bnf) hipLaunchKernelGGL((gemm_f64_fast_kernel<true, true>), grid, dim3(256), 0, ctx->stream, p);
-        else if (ak && !bnf) hipLaunchKernelGGL((gemm_f64_fast_kernel<true, false>), grid, dim3(256), 0, ctx->stream, p);
-        else if (!ak && bnf) hipLaunchKernelGGL((gemm_f64_fast_kernel<false, true>), grid, dim3(256), 0, ctx->stream, p);
-        else hipLaunchKernelGGL((gemm_f64_fast_kernel<false, false>), grid, dim3(256), 0, ctx->stream, p);
+        if (ak && bnf) CTM_LAUNCH(ctx, (gemm_f64_fast_kernel<true, true>), grid, dim3(256), 0, p);
+        else if (ak && !bnf) CTM_LAUNCH(ctx, (gemm_f64_fast_kernel<true, false>), grid, dim3(256), 0, p);
+        else if (!ak && bnf) CTM_LAUNCH(ctx, (gemm_f64_fast_kernel<false, true>), grid, dim3(256), 0, p);
+        else CTM_LAUNCH(ctx, (gemm_f64_fast_kernel<false, false>), grid, dim3(256), 0, p);
     } else if (small)
-        hipLaunchKernelGGL((gemm_f64_kernel<2, 2>), grid, dim3(256), 0, ctx->stream, p);
+        CTM_LAUNCH(ctx, (gemm_f64_kernel<2, 2>), grid, dim3(256), 0, p);
     else
-        hipLaunchKernelGGL((gemm_f64_kernel<4, 4>), grid, dim3(256), 0, ctx->stream, p);
+        CTM_LAUNCH(ctx, (gemm_f64_kernel<4, 4>), grid, dim3(256), 0, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { ctx->set_error(std::string("gemm launch: ") + hipGetErrorString(e)); return CTM_ERR_HIP; }
     if (part) {
         const long long tot = (long long)d.M * d.N;
         int blocks = (int)std::min<long long>((tot + 255) / 256, 2048);
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, ctx->stream, (const double*)part, fast_ks > 1 ? fast_ks : p.ksplit, p.split_stride, d.C,
+        CTM_LAUNCH(ctx, splitk_reduce_kernel, dim3(blocks), dim3(256), 0, (const double*)part, fast_ks > 1 ? fast_ks : p.ksplit, p.split_stride, d.C,
                            d.M, d.N, d.ldc, d.alpha, d.beta, d.colscale, ctx->splitk_reduce_vec);
     }
     const double fl = 2.0 * d.M * d.N * (double)d.K * d.batch;

@@ -658,13 +658,13 @@ int jacobi_rows(ctm_ctx* ctx, double* X, int R, long long ld, int Cg, int Ctot, 
             SmallEigParams sp;
             sp.G = G; sp.nsplit = T->nsplit; sp.split_stride = (long long)pairs * m * m; sp.J = J; sp.m = m; sp.tol = ctx->jacobi_tol * 0.1; sp.max_sweeps = (pairs == 1) ? 12 : (pairs >= 4 ? ctx->jacobi_inner_sweeps_many : ctx->jacobi_inner_sweeps);
             sp.tau2 = tau2; sp.stat_rel = stat; sp.stat_abs = stat + 1; sp.flags = flags;
-            if (cplx) hipLaunchKernelGGL(small_eig_c_kernel, dim3(pairs), dim3(256), 0, ctx->stream, sp);
+            if (cplx) CTM_LAUNCH(ctx, small_eig_c_kernel, dim3(pairs), dim3(256), 0, sp);
             else if (m == 64 && ctx->eig64_pingpong) {
-                if (ctx->eig64_bpt == 4) hipLaunchKernelGGL(small_eig64_kernel<4>, dim3(pairs), dim3(256), 0, ctx->stream, sp);
-                else if (ctx->eig64_bpt == 2) hipLaunchKernelGGL(small_eig64_kernel<2>, dim3(pairs), dim3(512), 0, ctx->stream, sp);
-                else hipLaunchKernelGGL(small_eig64_kernel<1>, dim3(pairs), dim3(1024), 0, ctx->stream, sp);
+                if (ctx->eig64_bpt == 4) CTM_LAUNCH(ctx, small_eig64_kernel<4>, dim3(pairs), dim3(256), 0, sp);
+                else if (ctx->eig64_bpt == 2) CTM_LAUNCH(ctx, small_eig64_kernel<2>, dim3(pairs), dim3(512), 0, sp);
+                else CTM_LAUNCH(ctx, small_eig64_kernel<1>, dim3(pairs), dim3(1024), 0, sp);
             }
-            else hipLaunchKernelGGL(small_eig_kernel, dim3(pairs), dim3(m > 32 ? 1024 : 256), 0, ctx->stream, sp);
+            else CTM_LAUNCH(ctx, small_eig_kernel, dim3(pairs), dim3(m > 32 ? 1024 : 256), 0, sp);
             GemmDesc a;
             a.M = m; a.N = Ctot; a.K = m;
             a.A = J; a.sam = 1; a.sak = m;                       // J^T
@@ -793,7 +793,7 @@ int svd_full(ctm_ctx* ctx, const double* M, int n, int k, double* S, double* Ut,
     CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)np * ld, (void**)&X));
     CTM_TRY(arena_alloc(ctx, sizeof(double) * np, (void**)&norms));
     CTM_TRY(arena_alloc(ctx, sizeof(int) * np, (void**)&d_idx));
-    hipLaunchKernelGGL(fill_wq_kernel, dim3(2048), dim3(256), 0, ctx->stream, M, n, n, (long long)n, X, np, ld, with_q ? 1 : 0);
+    CTM_LAUNCH(ctx, fill_wq_kernel, dim3(2048), dim3(256), 0, M, n, n, (long long)n, X, np, ld, with_q ? 1 : 0);
     std::vector<double> h;
     int st;
     const double fro = host_fro(ctx, X, np, n, ld, norms, h, &st);
@@ -821,8 +821,8 @@ int svd_full(ctm_ctx* ctx, const double* M, int n, int k, double* S, double* Ut,
         GemmDesc g; g.M = k; g.N = n; g.K = n; g.A = Ut; g.sam = n; g.sak = 1; g.B = M; g.sbk = n; g.sbn = 1; g.C = Vt; g.ldc = n;
         CTM_TRY(gemm_f64(ctx, g));
         CTM_TRY(row_norms(ctx, Vt, k, n, n, S));
-        hipLaunchKernelGGL(inv_or_zero_kernel, dim3((k + 255) / 256), dim3(256), 0, ctx->stream, S, inv, k);
-        hipLaunchKernelGGL(scale_rows_kernel, dim3(1024), dim3(256), 0, ctx->stream, Vt, k, n, (long long)n, inv);
+        CTM_LAUNCH(ctx, inv_or_zero_kernel, dim3((k + 255) / 256), dim3(256), 0, S, inv, k);
+        CTM_LAUNCH(ctx, scale_rows_kernel, dim3(1024), dim3(256), 0, Vt, k, n, (long long)n, inv);
         CTM_TRY(reorth_rows(ctx, Vt, k, n, n, 2));
     }
     return CTM_OK;
@@ -858,6 +858,14 @@ int matop_apply(ctm_ctx* ctx, const MatOp& op, bool transpose, const double* B, 
     CTM_TRY(rows_times(ctx, t1, m1, p, m1, n, op.c[2], !op.t[2], t2, n));
     CTM_TRY(rows_times(ctx, t2, n, p, n, m0, op.c[0], op.t[0], t1, m0));
     return rows_times(ctx, t1, m0, p, m0, n, op.c[1], op.t[1], C, ldc);
+}
+
+// Calls of a unit that start cold after its full-block warm probe (two half steps on k + k/2 rows) was handed to the Krylov solver
+// with relative residual r.  A probe is only kept below r = 1e-9; the environment of a converging run contracts by a factor
+// of a few per sweep and a unit is visited twice per sweep, so the next probe is scheduled for when it could succeed.
+inline int warm_skip_calls(const ctm_ctx* ctx, double r) {
+    const int need = (int)std::ceil(2.0 * std::log(std::max(r, 1e-9) / 1e-9) / std::log(5.0)) - 1;
+    return std::max(1, std::min(ctx->si_warm_skip_calls, need));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -919,7 +927,7 @@ int svd_iter(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* Ut, double
         CTM_TRY(copy2d(ctx, op.warm, n, XB, ld, kw, n));
         double* Rn = XB + (size_t)kw * ld;
         const int pr = p - kw;
-        hipLaunchKernelGGL(hash_fill_kernel, dim3(1024), dim3(256), 0, ctx->stream, Rn, pr, n, ld, 0x1234567ULL);
+        CTM_LAUNCH(ctx, hash_fill_kernel, dim3(1024), dim3(256), 0, Rn, pr, n, ld, 0x1234567ULL);
         ArenaScope ws(ctx);
         double* Gw;
         CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)pr * kw, (void**)&Gw));
@@ -929,7 +937,7 @@ int svd_iter(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* Ut, double
         g2.alpha = -1.0; g2.beta = 1.0;
         CTM_TRY(gemm_f64(ctx, g2));                                  // R -= G V
     } else
-        hipLaunchKernelGGL(hash_fill_kernel, dim3(1024), dim3(256), 0, ctx->stream, XB, p, n, ld, 0x1234567ULL);
+        CTM_LAUNCH(ctx, hash_fill_kernel, dim3(1024), dim3(256), 0, XB, p, n, ld, 0x1234567ULL);
     const bool warm = kw > 0;
     double* cur = XB;          // columns [0,n) of `cur` hold the current basis B (p x n)
     double* nxt = XA;
@@ -948,7 +956,7 @@ int svd_iter(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* Ut, double
         if (have_prev) {
             // residual of the relation that is NOT exact by construction: |C_i - s_i A_i| with A = previous normalised rows,
             // which sit in cur[:, n:2n] (companion of the previous half step, rotated along)
-            hipLaunchKernelGGL(resid_rows_kernel, dim3((p + 3) / 4), dim3(256), 0, ctx->stream, nxt, ld, cur + n, ld, sprev, p, n, res);
+            CTM_LAUNCH(ctx, resid_rows_kernel, dim3((p + 3) / 4), dim3(256), 0, nxt, ld, cur + n, ld, sprev, p, n, res);
             CTM_HIP_CHECK(ctx, hipMemcpyAsync(hr.data(), res, sizeof(double) * p, hipMemcpyDeviceToHost, ctx->stream));
             CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
             std::vector<int> idx(p); std::iota(idx.begin(), idx.end(), 0);
@@ -961,7 +969,7 @@ int svd_iter(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* Ut, double
                 if (want_krylov && ctx->lz_enable && k >= ctx->lz_min_k) { *want_krylov = true; ctx->si_last_iters = it; ctx->si_total_iters += it; return CTM_OK; }
                 // grow the block: fresh pseudo-random rows appended to the current basis
                 const int pn = std::min(p_full, 2 * p);
-                hipLaunchKernelGGL(hash_fill_kernel, dim3(1024), dim3(256), 0, ctx->stream, cur + (size_t)p * ld, pn - p, n, ld,
+                CTM_LAUNCH(ctx, hash_fill_kernel, dim3(1024), dim3(256), 0, cur + (size_t)p * ld, pn - p, n, ld,
                                    0x9876543ULL + (unsigned long long)pn);
                 if (ctx->jacobi_verbose) fprintf(stderr, "[si] n=%d grow block %d -> %d (rank so far %d)\n", n, p, pn, rank);
                 p = pn; have_prev = false;
@@ -971,12 +979,19 @@ int svd_iter(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* Ut, double
             double worst = 0.0;
             for (int i = 0; i < kk; ++i) worst = std::max(worst, hr[idx[i]]);
             if (ctx->jacobi_verbose) fprintf(stderr, "[si] n=%d p=%d half-step %d  rank=%d  max resid/s0 = %.3e\n", n, p, it, rank, worst / std::max(s0, 1e-300));
-            if (worst <= resid_tol(ctx, n) * s0) { *converged = true; break; }
+            // The residual test certifies that the sorted Ritz triplets ARE singular triplets; that they are the LARGEST ones rests on
+            // the guard rows of the block.  When the block exhausts the numerical rank, any direction the start did not contain shows up
+            // as one more Ritz value above the noise floor after a single application (and must then converge too).  A full block from
+            // a warm start carries guard rows that have seen the operator once: a new direction of size sigma_k .. sqrt(n) sigma_k would
+            // still hide among them, so such a start is not accepted before the guard rows have had three half steps.
+            const bool sound = !warm || exhausted || it >= 3;
+            if (sound && worst <= resid_tol(ctx, n) * s0) { *converged = true; break; }
             // a block whose residual contracts slowly (slowly decaying tail): predict the remaining half steps from the
             // observed contraction and hand over to the block Krylov solver when many are left
             if (want_krylov && ctx->lz_enable && k >= ctx->lz_min_k && !exhausted && warm && it == 1 && worst > 1e-9 * s0) {
-                // a warm basis that is not close (environment still changing) on a full-rank problem: block Krylov straight away
-                if (op.warm_hdr && worst > 1e-6 * s0) CTM_TRY(fill_f64(ctx, op.warm_hdr, 1, (double)ctx->si_warm_skip_calls));
+                // a warm basis that is not close (environment still changing) on a full-rank problem: block Krylov straight away,
+                // and the next calls of this unit do not pay for the full-block probe again (see warm_skip_calls())
+                if (op.warm_hdr) CTM_TRY(fill_f64(ctx, op.warm_hdr, 1, (double)warm_skip_calls(ctx, worst / s0)));
                 *want_krylov = true; ctx->si_last_iters = it; ctx->si_total_iters += it; return CTM_OK;
             }
             if (want_krylov && ctx->lz_enable && k >= ctx->lz_min_k && !exhausted && worst_prev > 0.0 && worst < worst_prev) {
@@ -999,8 +1014,8 @@ int svd_iter(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* Ut, double
         CTM_HIP_CHECK(ctx, hipMemcpyAsync(sprev, norms, sizeof(double) * p, hipMemcpyDeviceToDevice, ctx->stream));
         CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
         s0 = *std::max_element(h.begin(), h.begin() + p);
-        hipLaunchKernelGGL(inv_or_zero_kernel, dim3((p + 255) / 256), dim3(256), 0, ctx->stream, norms, inv, p);
-        hipLaunchKernelGGL(scale_rows_kernel, dim3(1024), dim3(256), 0, ctx->stream, nxt, p, n, ld, inv);
+        CTM_LAUNCH(ctx, inv_or_zero_kernel, dim3((p + 255) / 256), dim3(256), 0, norms, inv, p);
+        CTM_LAUNCH(ctx, scale_rows_kernel, dim3(1024), dim3(256), 0, nxt, p, n, ld, inv);
         // now: nxt[:, 0:n] = new orthonormal basis A (left if side==0), nxt[:, n:2n] = rotated B, s = h
         have_prev = true;
         std::swap(cur, nxt);
@@ -1110,8 +1125,8 @@ int panel_gather(ctm_ctx* ctx, const double* X, long long ld, const std::vector<
 }
 
 int scale_planar_rows(ctm_ctx* ctx, double* V, int k, int n, const double* inv) {
-    hipLaunchKernelGGL(scale_rows_kernel, dim3(1024), dim3(256), 0, ctx->stream, V, k, n, (long long)n, inv);
-    hipLaunchKernelGGL(scale_rows_kernel, dim3(1024), dim3(256), 0, ctx->stream, V + (size_t)k * n, k, n, (long long)n, inv);
+    CTM_LAUNCH(ctx, scale_rows_kernel, dim3(1024), dim3(256), 0, V, k, n, (long long)n, inv);
+    CTM_LAUNCH(ctx, scale_rows_kernel, dim3(1024), dim3(256), 0, V + (size_t)k * n, k, n, (long long)n, inv);
     return CTM_OK;
 }
 
@@ -1143,7 +1158,7 @@ int svd_full_c(ctm_ctx* ctx, const double* Mr, const double* Mi, int n, int k, d
     CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)2 * np * ld, (void**)&X));
     CTM_TRY(arena_alloc(ctx, sizeof(double) * 2 * np, (void**)&norms));
     CTM_TRY(arena_alloc(ctx, sizeof(int) * 2 * np, (void**)&d_idx));
-    hipLaunchKernelGGL(fill_wq_c_kernel, dim3(2048), dim3(256), 0, ctx->stream, Mr, Mi, n, X, np, ld, with_q ? 1 : 0);
+    CTM_LAUNCH(ctx, fill_wq_c_kernel, dim3(2048), dim3(256), 0, Mr, Mi, n, X, np, ld, with_q ? 1 : 0);
     std::vector<double> h;
     int st;
     const double fro = host_fro(ctx, X, 2 * np, n, ld, norms, h, &st);
@@ -1169,7 +1184,7 @@ int svd_full_c(ctm_ctx* ctx, const double* Mr, const double* Mi, int n, int k, d
         XM u{Ut, Ut + kn, n, false, false}, m{Mr, Mi, n, false, false};
         CTM_TRY(xgemm(ctx, k, n, n, u, m, Vt, Vt + kn, n));
         CTM_TRY(row_norms_c128(ctx, Vt, Vt + kn, k, n, n, S));
-        hipLaunchKernelGGL(inv_or_zero_kernel, dim3((k + 255) / 256), dim3(256), 0, ctx->stream, S, inv, k);
+        CTM_LAUNCH(ctx, inv_or_zero_kernel, dim3((k + 255) / 256), dim3(256), 0, S, inv, k);
         CTM_TRY(scale_planar_rows(ctx, Vt, k, n, inv));
         CTM_TRY(reorth_rows_c(ctx, Vt, k, n, 2));
     }
@@ -1182,7 +1197,7 @@ int rows_times_c(ctm_ctx* ctx, const double* X, long long ldx, int R, int kin, i
                  double* Y, long long ldy, double* scratch) {
     // Z stored kin x nout (trans == false) or nout x kin (trans == true)
     const size_t tot = (size_t)R * kin;
-    hipLaunchKernelGGL(panel_times_i_kernel, dim3((int)std::min<size_t>((tot + 255) / 256, 2048)), dim3(256), 0, ctx->stream, X, ldx, scratch,
+    CTM_LAUNCH(ctx, panel_times_i_kernel, dim3((int)std::min<size_t>((tot + 255) / 256, 2048)), dim3(256), 0, X, ldx, scratch,
                        (long long)kin, R, kin);
     GemmDesc g; g.M = R; g.N = nout; g.K = kin; g.A = X; g.sam = ldx; g.sak = 1; g.B = Zr;
     if (trans) { g.sbk = 1; g.sbn = kin; } else { g.sbk = nout; g.sbn = 1; }
@@ -1257,16 +1272,16 @@ int svd_iter_c(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* Ut, doub
         CTM_TRY(arena_alloc(ctx, sizeof(double) * 2 * rn, (void**)&Rn));
         CTM_TRY(arena_alloc(ctx, sizeof(double) * 2 * (size_t)pr * kw, (void**)&Gw));
         CTM_TRY(arena_alloc(ctx, sizeof(double) * 2 * rn, (void**)&Tw));
-        hipLaunchKernelGGL(hash_fill_kernel, dim3(1024), dim3(256), 0, ctx->stream, Rn, 2 * pr, n, (long long)n, 0x1234567ULL);
+        CTM_LAUNCH(ctx, hash_fill_kernel, dim3(1024), dim3(256), 0, Rn, 2 * pr, n, (long long)n, 0x1234567ULL);
         XM r{Rn, Rn + rn, n, false, false}, vh{op.warm, op.warm + wkn, n, true, true}, v{op.warm, op.warm + wkn, n, false, false};
         CTM_TRY(xgemm(ctx, pr, kw, n, r, vh, Gw, Gw + (size_t)pr * kw, kw));            // G = R V^H
         XM g{Gw, Gw + (size_t)pr * kw, kw, false, false};
         CTM_TRY(xgemm(ctx, pr, n, kw, g, v, Tw, Tw + rn, n));                             // T = G V
-        hipLaunchKernelGGL(sub_inplace_kernel, dim3(2048), dim3(256), 0, ctx->stream, Rn, Tw, 2 * rn);
-        hipLaunchKernelGGL(planar_to_panel_kernel, dim3(2048), dim3(256), 0, ctx->stream, op.warm, op.warm + wkn, (long long)n, kw, n, XB, ld, 0);
-        hipLaunchKernelGGL(planar_to_panel_kernel, dim3(2048), dim3(256), 0, ctx->stream, Rn, Rn + rn, (long long)n, pr, n, XB, ld, kw);
+        CTM_LAUNCH(ctx, sub_inplace_kernel, dim3(2048), dim3(256), 0, Rn, Tw, 2 * rn);
+        CTM_LAUNCH(ctx, planar_to_panel_kernel, dim3(2048), dim3(256), 0, op.warm, op.warm + wkn, (long long)n, kw, n, XB, ld, 0);
+        CTM_LAUNCH(ctx, planar_to_panel_kernel, dim3(2048), dim3(256), 0, Rn, Rn + rn, (long long)n, pr, n, XB, ld, kw);
     } else
-        hipLaunchKernelGGL(hash_fill_kernel, dim3(1024), dim3(256), 0, ctx->stream, XB, 2 * p, n, ld, 0x1234567ULL);
+        CTM_LAUNCH(ctx, hash_fill_kernel, dim3(1024), dim3(256), 0, XB, 2 * p, n, ld, 0x1234567ULL);
     const bool warm = kw > 0;
     double* cur = XB; double* nxt = XA;
     bool have_prev = false;
@@ -1282,7 +1297,7 @@ int svd_iter_c(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* Ut, doub
         CTM_TRY(matop_apply_c(ctx, op, side == 0, cur, ld, R, nxt, ld));
         CTM_TRY(copy2d(ctx, cur, ld, nxt + n, ld, R, n));
         if (have_prev) {
-            hipLaunchKernelGGL(resid_rows_kernel, dim3((R + 3) / 4), dim3(256), 0, ctx->stream, nxt, ld, cur + n, ld, nc, R, n, res);
+            CTM_LAUNCH(ctx, resid_rows_kernel, dim3((R + 3) / 4), dim3(256), 0, nxt, ld, cur + n, ld, nc, R, n, res);
             CTM_HIP_CHECK(ctx, hipMemcpyAsync(tmp.data(), res, sizeof(double) * R, hipMemcpyDeviceToHost, ctx->stream));
             CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
             for (int cr = 0; cr < p; ++cr) { const int rr = crow_re(cr); hr[cr] = std::sqrt(tmp[rr] * tmp[rr] + tmp[rr + BC] * tmp[rr + BC]); }
@@ -1294,7 +1309,7 @@ int svd_iter_c(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* Ut, doub
             if (!exhausted && p < p_full) {
                 if (want_krylov && ctx->lz_enable && k >= ctx->lz_min_k) { *want_krylov = true; ctx->si_last_iters = it; ctx->si_total_iters += it; return CTM_OK; }
                 const int pn = std::min(p_full, 2 * p);
-                hipLaunchKernelGGL(hash_fill_kernel, dim3(1024), dim3(256), 0, ctx->stream, cur + (size_t)2 * p * ld, 2 * (pn - p), n, ld,
+                CTM_LAUNCH(ctx, hash_fill_kernel, dim3(1024), dim3(256), 0, cur + (size_t)2 * p * ld, 2 * (pn - p), n, ld,
                                    0x9876543ULL + (unsigned long long)pn);
                 if (ctx->jacobi_verbose) fprintf(stderr, "[si-c] n=%d grow block %d -> %d (rank so far %d)\n", n, p, pn, rank);
                 p = pn; have_prev = false;
@@ -1304,10 +1319,11 @@ int svd_iter_c(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* Ut, doub
             double worst = 0.0;
             for (int i = 0; i < kk; ++i) worst = std::max(worst, hr[idx[i]]);
             if (ctx->jacobi_verbose) fprintf(stderr, "[si-c] n=%d p=%d half-step %d  rank=%d  max resid/s0 = %.3e\n", n, p, it, rank, worst / std::max(s0, 1e-300));
-            if (worst <= resid_tol(ctx, n) * s0) { *converged = true; break; }
+            const bool sound = !warm || exhausted || it >= 3;        // see svd_iter()
+            if (sound && worst <= resid_tol(ctx, n) * s0) { *converged = true; break; }
             if (want_krylov && ctx->lz_enable && k >= ctx->lz_min_k && !exhausted) {        // same hand-over rules as svd_iter()
                 bool sw = warm && it == 1 && worst > 1e-9 * s0;
-                if (sw && op.warm_hdr && worst > 1e-6 * s0) CTM_TRY(fill_f64(ctx, op.warm_hdr, 1, (double)ctx->si_warm_skip_calls));
+                if (sw && op.warm_hdr) CTM_TRY(fill_f64(ctx, op.warm_hdr, 1, (double)warm_skip_calls(ctx, worst / s0)));
                 if (!sw && worst_prev > 0.0 && worst < worst_prev)
                     sw = std::log(resid_tol(ctx, n) * s0 / worst) / std::log(worst / worst_prev) > ctx->lz_switch_steps;
                 else if (!sw && worst_prev > 0.0 && it >= 6) sw = true;
@@ -1321,14 +1337,14 @@ int svd_iter_c(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* Ut, doub
         CTM_TRY(st);
         CTM_TRY(jacobi_rows(ctx, nxt, R, ld, n, (int)ld, 2 * BC, std::min(k, p - 1), fro, (have_prev || warm) ? ctx->si_rr_sweeps : std::min(3, ctx->si_rr_sweeps), true));
         CTM_TRY(row_norms(ctx, nxt, R, n, ld, norms));
-        hipLaunchKernelGGL(panel_combine_kernel, dim3((R + 255) / 256), dim3(256), 0, ctx->stream, norms, nc, R);
+        CTM_LAUNCH(ctx, panel_combine_kernel, dim3((R + 255) / 256), dim3(256), 0, norms, nc, R);
         CTM_HIP_CHECK(ctx, hipMemcpyAsync(tmp.data(), nc, sizeof(double) * R, hipMemcpyDeviceToHost, ctx->stream));
         CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
         h.assign(p_full, 0.0);
         for (int cr = 0; cr < p; ++cr) h[cr] = tmp[crow_re(cr)];
         s0 = *std::max_element(h.begin(), h.begin() + p);
-        hipLaunchKernelGGL(inv_or_zero_kernel, dim3((R + 255) / 256), dim3(256), 0, ctx->stream, nc, inv, R);
-        hipLaunchKernelGGL(scale_rows_kernel, dim3(1024), dim3(256), 0, ctx->stream, nxt, R, n, ld, inv);
+        CTM_LAUNCH(ctx, inv_or_zero_kernel, dim3((R + 255) / 256), dim3(256), 0, nc, inv, R);
+        CTM_LAUNCH(ctx, scale_rows_kernel, dim3(1024), dim3(256), 0, nxt, R, n, ld, inv);
         have_prev = true;
         std::swap(cur, nxt);
         side ^= 1;
@@ -1423,8 +1439,8 @@ int orthonormalise_block(ctm_ctx* ctx, double* W, int rows, int n, double* norms
     CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     *min_norm = *std::min_element(h.begin(), h.end());
     *max_norm = *std::max_element(h.begin(), h.end());
-    hipLaunchKernelGGL(inv_or_zero_kernel, dim3((rows + 255) / 256), dim3(256), 0, ctx->stream, norms, inv, rows);
-    hipLaunchKernelGGL(scale_rows_kernel, dim3(1024), dim3(256), 0, ctx->stream, W, rows, n, (long long)n, inv);
+    CTM_LAUNCH(ctx, inv_or_zero_kernel, dim3((rows + 255) / 256), dim3(256), 0, norms, inv, rows);
+    CTM_LAUNCH(ctx, scale_rows_kernel, dim3(1024), dim3(256), 0, W, rows, n, (long long)n, inv);
     bool ok = (rows == 64) && (*min_norm > 0.0);
     if (ok) {
         ArenaScope scope(ctx);
@@ -1435,7 +1451,7 @@ int orthonormalise_block(ctm_ctx* ctx, double* W, int rows, int n, double* norms
         for (int pass = 0; pass < 2 && ok; ++pass) {
             GemmDesc g; g.M = 64; g.N = 64; g.K = n; g.A = W; g.sam = n; g.sak = 1; g.B = W; g.sbk = 1; g.sbn = n; g.C = G; g.ldc = 64;
             CTM_TRY(gemm_f64(ctx, g));
-            hipLaunchKernelGGL(chol64_inv_kernel, dim3(1), dim3(256), 0, ctx->stream, (const double*)G, Li, status);
+            CTM_LAUNCH(ctx, chol64_inv_kernel, dim3(1), dim3(256), 0, (const double*)G, Li, status);
             CTM_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_scratch + 16, status, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
             CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
             if (!(ctx->h_scratch[16] > (pass == 0 ? 1e-10 : 0.5))) { ok = false; break; }      // unit rows: pivots in (0, 1]
@@ -1450,8 +1466,8 @@ int orthonormalise_block(ctm_ctx* ctx, double* W, int rows, int n, double* norms
     CTM_TRY(st);
     CTM_TRY(jacobi_rows(ctx, W, rows, n, n, n, 32, 0, fro, ctx->si_rr_sweeps));
     CTM_TRY(row_norms(ctx, W, rows, n, n, norms));
-    hipLaunchKernelGGL(inv_or_zero_kernel, dim3((rows + 255) / 256), dim3(256), 0, ctx->stream, norms, inv, rows);
-    hipLaunchKernelGGL(scale_rows_kernel, dim3(1024), dim3(256), 0, ctx->stream, W, rows, n, (long long)n, inv);
+    CTM_LAUNCH(ctx, inv_or_zero_kernel, dim3((rows + 255) / 256), dim3(256), 0, norms, inv, rows);
+    CTM_LAUNCH(ctx, scale_rows_kernel, dim3(1024), dim3(256), 0, W, rows, n, (long long)n, inv);
     return CTM_OK;
 }
 
@@ -1468,6 +1484,10 @@ int project_out(ctm_ctx* ctx, double* W, int b, int n, const double* B, int m, d
     return CTM_OK;
 }
 
+// memory of a unit between sweeps (header row of its warm workspace, doubles): [0] calls left that skip the warm probe (svd_iter),
+// [1] block steps of the last accepted Krylov solve, [2] its residual estimate / s_0
+enum { HDR_SKIP = 0, HDR_STEPS = 1, HDR_EST = 2, HDR_WORDS = 3 };
+
 int svd_lanczos(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* Ut, double* Vt, bool* converged) {
     *converged = false;
     const int n = op.n, b = 64;
@@ -1475,16 +1495,37 @@ int svd_lanczos(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* Ut, dou
     int jmax = std::min((n / 2) / b, (6 * k) / b + 8);
     if (jmax < jmin + 1) return CTM_OK;
     ArenaScope scope(ctx);
-    double *Uall, *Vall, *Zraw, *G, *norms, *inv;
+    double *Uall, *Vall, *Zraw, *Wraw, *G, *norms, *inv;
     const size_t rows_max = (size_t)jmax * b;
     CTM_TRY(arena_alloc(ctx, sizeof(double) * rows_max * n, (void**)&Uall));
     CTM_TRY(arena_alloc(ctx, sizeof(double) * (rows_max + b) * n, (void**)&Vall));
-    CTM_TRY(arena_alloc(ctx, sizeof(double) * rows_max * n, (void**)&Zraw));
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * rows_max * n, (void**)&Zraw));         // raw products U_j M
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * rows_max * n, (void**)&Wraw));         // raw products V_j M^T
     CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)b * (rows_max + b), (void**)&G));
     CTM_TRY(arena_alloc(ctx, sizeof(double) * std::max<size_t>(rows_max, 1024), (void**)&norms));
     CTM_TRY(arena_alloc(ctx, sizeof(double) * std::max<size_t>(rows_max, 1024), (void**)&inv));
+    const double tol = resid_tol(ctx, n);
+    // When to look: a Ritz extraction (dense SVD of the m x m projected matrix) costs as much as 6-8 block steps, so it is
+    // scheduled, not repeated.  The operator of a unit changes slowly from sweep to sweep: the step count that was
+    // accepted last time is tried first (one less when it passed with orders of magnitude to spare); cold, the first look
+    // comes when the basis holds lz_first_factor * k rows; after a failed look the next one is placed where the observed (or a
+    // typical) contraction of the residual estimate predicts convergence.
+    double hdr[HDR_WORDS] = {0.0, 0.0, 0.0};
+    if (op.warm_hdr) {
+        CTM_HIP_CHECK(ctx, hipMemcpyAsync(hdr, op.warm_hdr, sizeof(hdr), hipMemcpyDeviceToHost, ctx->stream));
+        CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    int jnext;
+    if (ctx->lz_first > 0) jnext = ctx->lz_first;
+    else if (hdr[HDR_STEPS] >= jmin && hdr[HDR_STEPS] <= jmax && hdr[HDR_EST] > 0.0)
+        // the estimate falls by a factor 7-17 per block step (measured, D = 6 and 8): one step less when it passed with more than
+        // that to spare, one more when it passed narrowly (a failed look costs five steps)
+        jnext = (int)hdr[HDR_STEPS] + (hdr[HDR_EST] <= tol / 30.0 ? -1 : (hdr[HDR_EST] > tol / 3.0 ? 1 : 0));
+    else jnext = (int)std::ceil(ctx->lz_first_factor * k / b);
+    jnext = std::max(jmin, std::min(jnext, jmax));
+    double est_prev = 0.0; int steps_prev = 0;
     double mn, mx, s0 = 0.0;
-    hipLaunchKernelGGL(hash_fill_kernel, dim3(1024), dim3(256), 0, ctx->stream, Vall, b, n, (long long)n, 0x51f15eedULL);
+    CTM_LAUNCH(ctx, hash_fill_kernel, dim3(1024), dim3(256), 0, Vall, b, n, (long long)n, 0x51f15eedULL);
     CTM_TRY(orthonormalise_block(ctx, Vall, b, n, norms, inv, &mn, &mx));
     int applications = 0;
     for (int j = 0; j < jmax; ++j) {
@@ -1492,8 +1533,10 @@ int svd_lanczos(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* Ut, dou
         double* Vj = Vall + (size_t)j * b * n;
         double* Vn = Vall + (size_t)(j + 1) * b * n;
         double* Zj = Zraw + (size_t)j * b * n;
+        double* Wj = Wraw + (size_t)j * b * n;
         // U_j
-        CTM_TRY(matop_apply(ctx, op, true, Vj, n, b, Uj, n)); applications += b;
+        CTM_TRY(matop_apply(ctx, op, true, Vj, n, b, Wj, n)); applications += b;
+        CTM_HIP_CHECK(ctx, hipMemcpyAsync(Uj, Wj, sizeof(double) * (size_t)b * n, hipMemcpyDeviceToDevice, ctx->stream));
         CTM_TRY(project_out(ctx, Uj, b, n, Uall, j * b, G));
         CTM_TRY(orthonormalise_block(ctx, Uj, b, n, norms, inv, &mn, &mx));
         s0 = std::max(s0, mx);
@@ -1504,9 +1547,8 @@ int svd_lanczos(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* Ut, dou
         CTM_TRY(project_out(ctx, Vn, b, n, Vall, (j + 1) * b, G));
         CTM_TRY(orthonormalise_block(ctx, Vn, b, n, norms, inv, &mn, &mx));
         if (mn <= 1e-13 * s0) { if (ctx->jacobi_verbose) fprintf(stderr, "[lz] n=%d breakdown at step %d (V)\n", n, j); return CTM_OK; }
-        const int m = (j + 1) * b;
-        const int jfirst = std::max(jmin, (4 * k + b - 1) / b);                        // empirically the basis needs ~4-5 k rows
-        if ((j + 1 < jfirst || ((j + 1 - jfirst) & 1)) && j + 1 < jmax) continue;        // Ritz extraction every other step from there
+        const int steps = j + 1, m = steps * b;
+        if (steps < jnext && steps < jmax) continue;
         // ---- small problem T = (U_all M) V_all^T  (m x m),  coupling E = (U_all M) V_{j+1}^T  (m x b)
         ArenaScope rs(ctx);
         double *T, *E, *Ss, *Xt, *Yt, *XE, *rn;
@@ -1526,6 +1568,7 @@ int svd_lanczos(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* Ut, dou
         const int st = svd_full(ctx, T, m, kq, Ss, Xt, Yt);                      // rows of Xt / Yt: x_i^T, y_i^T
         ctx->si_enable = save;
         CTM_TRY(st);
+        ctx->lz_extractions += 1;
         GemmDesc gx; gx.M = kq; gx.N = b; gx.K = m; gx.A = Xt; gx.sam = m; gx.sak = 1; gx.B = E; gx.sbk = b; gx.sbn = 1; gx.C = XE; gx.ldc = b;
         CTM_TRY(gemm_f64(ctx, gx));
         CTM_TRY(row_norms(ctx, XE, kq, b, b, rn));
@@ -1536,47 +1579,85 @@ int svd_lanczos(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* Ut, dou
         int kv = 0;                                   // Ritz values above the noise floor: the only ones that can (and must) converge
         while (kv < kq && hs[kv] > ctx->rank_tol * hs[0]) ++kv;
         const double est = *std::max_element(hr.begin(), hr.begin() + std::max(kv, 1));
-        if (ctx->jacobi_verbose) fprintf(stderr, "[lz] n=%d step %d basis %d  s0=%.3e  residual estimate/s0 = %.3e\n", n, j + 1, m, hs[0], est / hs[0]);
-        if (kq < k || (est > resid_tol(ctx, n) * hs[0] && j + 1 < jmax)) continue;
-        // ---- Ritz triplets and the rigorous check of both relations with the operator
+        if (ctx->jacobi_verbose) fprintf(stderr, "[lz] n=%d step %d basis %d  s0=%.3e  residual estimate/s0 = %.3e\n", n, steps, m, hs[0], est / hs[0]);
+        if (kq < k || (est > tol * hs[0] && steps < jmax)) {
+            // place the next look where the residual estimate is predicted to pass (geometric contraction per block step)
+            double rate = 0.15;
+            if (est_prev > 0.0 && est < est_prev) rate = std::min(0.6, std::max(1e-3, std::pow(est / est_prev, 1.0 / (steps - steps_prev))));
+            int need = (kq < k) ? jmin - steps : (int)std::ceil(std::log(0.5 * tol * hs[0] / est) / std::log(rate));
+            need = std::max(1, std::min(need, 4));
+            if (ctx->lz_stride > 0) need = ctx->lz_stride;
+            jnext = std::min(jmax, steps + need);
+            est_prev = est; steps_prev = steps;
+            continue;
+        }
+        // ---- Ritz triplets.  Both relations are then checked on the triplets as they will be returned (after the
+        // re-orthonormalisation), without further operator applications: u_i = sum_r X'[i,r] U_r, so u_i M = sum_r X'[i,r] (U_r M),
+        // and the products U_r M, V_r M^T of every basis row are the ones the recurrence was built from (stored raw).
         GemmDesc gu; gu.M = k; gu.N = n; gu.K = m; gu.A = Xt; gu.sam = m; gu.sak = 1; gu.B = Uall; gu.sbk = n; gu.sbn = 1; gu.C = Ut; gu.ldc = n;
         CTM_TRY(gemm_f64(ctx, gu));
         GemmDesc gv = gu; gv.A = Yt; gv.B = Vall; gv.C = Vt;
         CTM_TRY(gemm_f64(ctx, gv));
         CTM_TRY(reorth_rows(ctx, Ut, k, n, n, 1));
         CTM_TRY(reorth_rows(ctx, Vt, k, n, n, 1));
-        double *C1, *res;
+        double *C1, *res, *Xc;
         CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)k * n, (void**)&C1));
         CTM_TRY(arena_alloc(ctx, sizeof(double) * k, (void**)&res));
-        double worst = 0.0;
+        CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)k * m, (void**)&Xc));
+        double worst = 0.0, worst_op = 0.0;
         std::vector<double> r1(k);
         for (int rel = 0; rel < 2; ++rel) {        // rel 0: Ut M = S Vt ; rel 1: Vt M^T = S Ut
-            CTM_TRY(matop_apply(ctx, op, rel == 1, rel == 0 ? Ut : Vt, n, k, C1, n)); applications += k;
-            hipLaunchKernelGGL(resid_rows_kernel, dim3((k + 3) / 4), dim3(256), 0, ctx->stream, C1, (long long)n, rel == 0 ? Vt : Ut, (long long)n, Ss, k, n, res);
+            const double* F = rel == 0 ? Ut : Vt; const double* Bs = rel == 0 ? Uall : Vall; const double* Pr = rel == 0 ? Zraw : Wraw;
+            GemmDesc gc; gc.M = k; gc.N = m; gc.K = n; gc.A = F; gc.sam = n; gc.sak = 1; gc.B = Bs; gc.sbk = 1; gc.sbn = n; gc.C = Xc; gc.ldc = m;
+            CTM_TRY(gemm_f64(ctx, gc));                                              // coordinates of the returned rows in the basis
+            GemmDesc gp; gp.M = k; gp.N = n; gp.K = m; gp.A = Xc; gp.sam = m; gp.sak = 1; gp.B = Pr; gp.sbk = n; gp.sbn = 1; gp.C = C1; gp.ldc = n;
+            CTM_TRY(gemm_f64(ctx, gp));
+            CTM_LAUNCH(ctx, resid_rows_kernel, dim3((k + 3) / 4), dim3(256), 0, C1, (long long)n, rel == 0 ? Vt : Ut, (long long)n, Ss, k, n, res);
             CTM_HIP_CHECK(ctx, hipMemcpyAsync(r1.data(), res, sizeof(double) * k, hipMemcpyDeviceToHost, ctx->stream));
             CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
             worst = std::max(worst, *std::max_element(r1.begin(), r1.begin() + std::max(kv, 1)));
+            if (ctx->lz_verify_op) {
+                CTM_TRY(matop_apply(ctx, op, rel == 1, F, n, k, C1, n)); applications += k;
+                CTM_LAUNCH(ctx, resid_rows_kernel, dim3((k + 3) / 4), dim3(256), 0, C1, (long long)n, rel == 0 ? Vt : Ut, (long long)n, Ss, k, n, res);
+                CTM_HIP_CHECK(ctx, hipMemcpyAsync(r1.data(), res, sizeof(double) * k, hipMemcpyDeviceToHost, ctx->stream));
+                CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+                worst_op = std::max(worst_op, *std::max_element(r1.begin(), r1.begin() + std::max(kv, 1)));
+            }
         }
-        if (ctx->jacobi_verbose) fprintf(stderr, "[lz] n=%d verified residual/s0 = %.3e after %d row applications\n", n, worst / hs[0], applications);
+        if (ctx->jacobi_verbose) {
+            fprintf(stderr, "[lz] n=%d verified residual/s0 = %.3e after %d row applications", n, worst / hs[0], applications);
+            if (ctx->lz_verify_op) fprintf(stderr, "  (with operator applications: %.3e)", worst_op / hs[0]);
+            fprintf(stderr, "\n");
+        }
+        if (ctx->lz_verify_op) worst = std::max(worst, worst_op);
         ctx->lz_last_resid = worst / hs[0];
-        if (worst > resid_tol(ctx, n) * hs[0] && worst <= 1e-11 * hs[0] && est <= resid_tol(ctx, n) * hs[0]) {
+        ctx->lz_last_est = est / hs[0]; ctx->lz_last_steps = steps;
+        if (worst > tol * hs[0] && worst <= 1e-11 * hs[0] && est <= tol * hs[0]) {
             // the Krylov recurrence has converged but the long linear combinations left the Ritz vectors a few ulps short of the
             // acceptance threshold: the caller polishes them with a warm-started subspace step
-            ctx->lz_hits += 1; ctx->lz_total_steps += j + 1;
+            ctx->lz_hits += 1; ctx->lz_total_steps += steps;
             return CTM_OK;
         }
-        if (worst <= resid_tol(ctx, n) * hs[0]) {
+        if (worst <= tol * hs[0]) {
             CTM_HIP_CHECK(ctx, hipMemcpyAsync(S, Ss, sizeof(double) * k, hipMemcpyDeviceToDevice, ctx->stream));
             if (kv < k) {                             // triplets in the noise floor are reported as exact zeros (as svd_iter does)
                 CTM_TRY(fill_f64(ctx, S + kv, (size_t)(k - kv), 0.0));
                 CTM_TRY(fill_f64(ctx, Ut + (size_t)kv * n, (size_t)(k - kv) * n, 0.0));
                 CTM_TRY(fill_f64(ctx, Vt + (size_t)kv * n, (size_t)(k - kv) * n, 0.0));
             }
+            if (op.warm_hdr) {
+                CTM_TRY(fill_f64(ctx, op.warm_hdr + HDR_STEPS, 1, (double)steps));
+                CTM_TRY(fill_f64(ctx, op.warm_hdr + HDR_EST, 1, std::max(est / hs[0], 1e-300)));
+            }
             CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
             *converged = true;
-            ctx->lz_hits += 1; ctx->lz_total_steps += j + 1;
+            ctx->lz_hits += 1; ctx->lz_total_steps += steps;
             return CTM_OK;
         }
+        // estimate passed, verification did not (rounding beyond the polishing range): more basis does not help
+        if (steps >= jmax) break;
+        jnext = std::min(jmax, steps + 2);
+        est_prev = 0.0;
     }
     return CTM_OK;
 }
@@ -1647,9 +1728,9 @@ int orthonormalise_block_c(ctm_ctx* ctx, CRows W, int n, double* norms, double* 
     *max_norm = *std::max_element(h.begin(), h.end());
     *ok = *min_norm > 0.0;
     if (!*ok) return CTM_OK;
-    hipLaunchKernelGGL(inv_or_zero_kernel, dim3(1), dim3(256), 0, ctx->stream, norms, inv, rows);
-    hipLaunchKernelGGL(scale_rows_kernel, dim3(1024), dim3(256), 0, ctx->stream, W.re, rows, n, (long long)n, inv);
-    hipLaunchKernelGGL(scale_rows_kernel, dim3(1024), dim3(256), 0, ctx->stream, W.im, rows, n, (long long)n, inv);
+    CTM_LAUNCH(ctx, inv_or_zero_kernel, dim3(1), dim3(256), 0, norms, inv, rows);
+    CTM_LAUNCH(ctx, scale_rows_kernel, dim3(1024), dim3(256), 0, W.re, rows, n, (long long)n, inv);
+    CTM_LAUNCH(ctx, scale_rows_kernel, dim3(1024), dim3(256), 0, W.im, rows, n, (long long)n, inv);
     ArenaScope scope(ctx);
     // near-dependent rows (e.g. the first power step of a random block): one-sided complex Jacobi in the panel layout
     auto jacobi_fallback = [&]() -> int {
@@ -1657,7 +1738,7 @@ int orthonormalise_block_c(ctm_ctx* ctx, CRows W, int n, double* norms, double* 
         CTM_TRY(arena_alloc(ctx, sizeof(double) * 2 * (size_t)rows * n, (void**)&P));
         CTM_TRY(arena_alloc(ctx, sizeof(double) * 2 * (size_t)rows * n, (void**)&Tp));
         CTM_TRY(arena_alloc(ctx, sizeof(int) * 2 * rows, (void**)&d_idx));
-        hipLaunchKernelGGL(planar_to_panel_kernel, dim3(2048), dim3(256), 0, ctx->stream, (const double*)W.re, (const double*)W.im, (long long)n, rows, n, P, (long long)n, 0);
+        CTM_LAUNCH(ctx, planar_to_panel_kernel, dim3(2048), dim3(256), 0, (const double*)W.re, (const double*)W.im, (long long)n, rows, n, P, (long long)n, 0);
         std::vector<double> hh; int st;
         const double fro = host_fro(ctx, P, 2 * rows, n, n, norms, hh, &st);
         CTM_TRY(st);
@@ -1667,9 +1748,9 @@ int orthonormalise_block_c(ctm_ctx* ctx, CRows W, int n, double* norms, double* 
         CTM_HIP_CHECK(ctx, hipMemcpyAsync(W.re, Tp, sizeof(double) * (size_t)rows * n, hipMemcpyDeviceToDevice, ctx->stream));
         CTM_HIP_CHECK(ctx, hipMemcpyAsync(W.im, Tp + (size_t)rows * n, sizeof(double) * (size_t)rows * n, hipMemcpyDeviceToDevice, ctx->stream));
         CTM_TRY(row_norms_c128(ctx, W.re, W.im, rows, n, n, norms));
-        hipLaunchKernelGGL(inv_or_zero_kernel, dim3(1), dim3(256), 0, ctx->stream, norms, inv, rows);
-        hipLaunchKernelGGL(scale_rows_kernel, dim3(1024), dim3(256), 0, ctx->stream, W.re, rows, n, (long long)n, inv);
-        hipLaunchKernelGGL(scale_rows_kernel, dim3(1024), dim3(256), 0, ctx->stream, W.im, rows, n, (long long)n, inv);
+        CTM_LAUNCH(ctx, inv_or_zero_kernel, dim3(1), dim3(256), 0, norms, inv, rows);
+        CTM_LAUNCH(ctx, scale_rows_kernel, dim3(1024), dim3(256), 0, W.re, rows, n, (long long)n, inv);
+        CTM_LAUNCH(ctx, scale_rows_kernel, dim3(1024), dim3(256), 0, W.im, rows, n, (long long)n, inv);
         return CTM_OK;
     };
     double *G, *Li, *T;
@@ -1680,7 +1761,7 @@ int orthonormalise_block_c(ctm_ctx* ctx, CRows W, int n, double* norms, double* 
     for (int pass = 0; pass < 2; ++pass) {
         XM w{W.re, W.im, n, false, false}, wh{W.re, W.im, n, true, true};
         CTM_TRY(xgemm(ctx, 64, 64, n, w, wh, G, G + 4096, 64));                       // G = W W^H
-        hipLaunchKernelGGL(chol64_inv_c_kernel, dim3(1), dim3(256), 0, ctx->stream, (const double*)G, (const double*)(G + 4096), Li, Li + 4096, status);
+        CTM_LAUNCH(ctx, chol64_inv_c_kernel, dim3(1), dim3(256), 0, (const double*)G, (const double*)(G + 4096), Li, Li + 4096, status);
         CTM_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_scratch + 16, status, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
         if (!(ctx->h_scratch[16] > (pass == 0 ? 1e-10 : 0.5))) return jacobi_fallback();
@@ -1700,8 +1781,8 @@ int project_out_c(ctm_ctx* ctx, CRows W, int b, int n, const double* Bre, const 
         CTM_TRY(xgemm(ctx, b, m, n, w, bh, G, G + (size_t)b * m, m));
         XM g{G, G + (size_t)b * m, m, false, false};
         CTM_TRY(xgemm(ctx, b, n, m, g, bb, T, T + (size_t)b * n, n));
-        hipLaunchKernelGGL(sub_inplace_kernel, dim3(1024), dim3(256), 0, ctx->stream, W.re, (const double*)T, (size_t)b * n);
-        hipLaunchKernelGGL(sub_inplace_kernel, dim3(1024), dim3(256), 0, ctx->stream, W.im, (const double*)(T + (size_t)b * n), (size_t)b * n);
+        CTM_LAUNCH(ctx, sub_inplace_kernel, dim3(1024), dim3(256), 0, W.re, (const double*)T, (size_t)b * n);
+        CTM_LAUNCH(ctx, sub_inplace_kernel, dim3(1024), dim3(256), 0, W.im, (const double*)(T + (size_t)b * n), (size_t)b * n);
     }
     return CTM_OK;
 }
@@ -1757,8 +1838,8 @@ int svd_lanczos_c(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* Ut, d
     auto Zr = [&](int j) { CRows r{Zraw + (size_t)j * bn, Zraw + planeU + (size_t)j * bn}; return r; };
     double mn, mx, s0 = 0.0;
     bool ok;
-    hipLaunchKernelGGL(hash_fill_kernel, dim3(1024), dim3(256), 0, ctx->stream, Vall, b, n, (long long)n, 0x51f15eedULL);
-    hipLaunchKernelGGL(hash_fill_kernel, dim3(1024), dim3(256), 0, ctx->stream, Vall + planeV, b, n, (long long)n, 0x0dd5eedULL);
+    CTM_LAUNCH(ctx, hash_fill_kernel, dim3(1024), dim3(256), 0, Vall, b, n, (long long)n, 0x51f15eedULL);
+    CTM_LAUNCH(ctx, hash_fill_kernel, dim3(1024), dim3(256), 0, Vall + planeV, b, n, (long long)n, 0x0dd5eedULL);
     CTM_TRY(orthonormalise_block_c(ctx, Vr(0), n, norms, inv, &mn, &mx, &ok));
     if (!ok) return CTM_OK;
     int applications = 0;
@@ -1820,8 +1901,8 @@ int svd_lanczos_c(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* Ut, d
         for (int rel = 0; rel < 2; ++rel) {        // rel 0: Ut M = S Vt ; rel 1: Vt M^H = S Ut
             const double* src = rel == 0 ? Ut : Vt; const double* dst = rel == 0 ? Vt : Ut;
             CTM_TRY(matop_apply_planar(ctx, op, rel == 1, src, src + kn, k, C1, C1 + kn)); applications += k;
-            hipLaunchKernelGGL(resid_rows_kernel, dim3((k + 3) / 4), dim3(256), 0, ctx->stream, C1, (long long)n, dst, (long long)n, Ss, k, n, res);
-            hipLaunchKernelGGL(resid_rows_kernel, dim3((k + 3) / 4), dim3(256), 0, ctx->stream, C1 + kn, (long long)n, dst + kn, (long long)n, Ss, k, n, res + k);
+            CTM_LAUNCH(ctx, resid_rows_kernel, dim3((k + 3) / 4), dim3(256), 0, C1, (long long)n, dst, (long long)n, Ss, k, n, res);
+            CTM_LAUNCH(ctx, resid_rows_kernel, dim3((k + 3) / 4), dim3(256), 0, C1 + kn, (long long)n, dst + kn, (long long)n, Ss, k, n, res + k);
             CTM_HIP_CHECK(ctx, hipMemcpyAsync(r1.data(), res, sizeof(double) * 2 * k, hipMemcpyDeviceToHost, ctx->stream));
             CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
             for (int i = 0; i < std::max(kv, 1); ++i) worst = std::max(worst, std::sqrt(r1[i] * r1[i] + r1[k + i] * r1[k + i]));
@@ -1901,7 +1982,22 @@ int jacobi_svd_top_op(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* U
     }
     if (Ut && Vt && ctx->si_enable && k < n && n >= ctx->si_min_n) {
         bool ok = false, krylov = false;
-        CTM_TRY(svd_iter(ctx, op, k, S, Ut, Vt, &ok, &krylov));
+        MatOp op1 = op;
+        if (op.warm_hdr && ctx->lz_enable && k >= ctx->lz_min_k) {
+            // a unit whose last solve needed the Krylov solver and whose warm probe is not due yet goes there directly (no
+            // 64-row rank probe either); if that should fail the regular path below starts cold
+            double hdr[HDR_WORDS];
+            CTM_HIP_CHECK(ctx, hipMemcpyAsync(hdr, op.warm_hdr, sizeof(hdr), hipMemcpyDeviceToHost, ctx->stream));
+            CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+            if (hdr[HDR_SKIP] >= 1.0 && hdr[HDR_STEPS] >= 1.0) {
+                CTM_TRY(fill_f64(ctx, op.warm_hdr, 1, hdr[HDR_SKIP] - 1.0)); ctx->si_warm_skips += 1;
+                ctx->lz_last_resid = 1.0;
+                CTM_TRY(svd_lanczos(ctx, op, k, S, Ut, Vt, &ok));
+                if (ok) return keep_warm();
+                op1.warm = nullptr; op1.warm_hdr = nullptr;
+            }
+        }
+        CTM_TRY(svd_iter(ctx, op1, k, S, Ut, Vt, &ok, &krylov));
         if (ok) { ctx->si_hits += 1; return keep_warm(); }
         if (krylov) {
             ctx->lz_last_resid = 1.0;
@@ -2002,7 +2098,7 @@ int jacobi_eigh_top(ctm_ctx* ctx, const double* A, int n, int k, double* D, doub
     CTM_TRY(st);
     const double shift = fro * 1.0009765625 + 1e-300;
     CTM_TRY(symmetrize_lower(ctx, A, As, n, shift));
-    hipLaunchKernelGGL(fill_wq_kernel, dim3(2048), dim3(256), 0, ctx->stream, As, n, n, (long long)n, X, np, ld, 1);
+    CTM_LAUNCH(ctx, fill_wq_kernel, dim3(2048), dim3(256), 0, As, n, n, (long long)n, X, np, ld, 1);
     CTM_TRY(jacobi_rows(ctx, X, np, ld, n, (int)ld, b, 0, shift * std::sqrt((double)n), ctx->jacobi_max_sweeps));
     CTM_TRY(row_norms(ctx, X, np, n, ld, norms));
     h.resize(np);

@@ -409,7 +409,7 @@ int launch_layer2_c(ctm_ctx* ctx, const Layer2Params& p) {
     const long long npair = (long long)p.nx * p.ny;
     const int per_cu = std::max(1, std::min(8, (int)((150 * 1024) / lds_bytes)));
     const int grid = (int)std::min<long long>(npair, 256LL * per_cu * 2);
-    hipLaunchKernelGGL(layer2_c_kernel<KT>, dim3(grid), dim3(64 * KT), lds_bytes, ctx->stream, p);
+    CTM_LAUNCH(ctx, layer2_c_kernel<KT>, dim3(grid), dim3(64 * KT), lds_bytes, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { ctx->set_error(std::string("layer2 launch: ") + hipGetErrorString(e)); return CTM_ERR_HIP; }
     return CTM_OK;
@@ -423,7 +423,7 @@ int launch_layer2_reg(ctm_ctx* ctx, const Layer2Params& p) {
     const long long npair = (long long)p.nx * p.ny;
     const int per_cu = std::max(1, std::min(8, (int)((150 * 1024) / lds_bytes)));
     const int grid = (int)std::min<long long>(npair, 256LL * per_cu * 2);
-    hipLaunchKernelGGL(layer2_reg_kernel<KT>, dim3(grid), dim3(64 * KT), lds_bytes, ctx->stream, p);
+    CTM_LAUNCH(ctx, layer2_reg_kernel<KT>, dim3(grid), dim3(64 * KT), lds_bytes, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { ctx->set_error(std::string("layer2 launch: ") + hipGetErrorString(e)); return CTM_ERR_HIP; }
     return CTM_OK;
@@ -436,7 +436,7 @@ int launch_layer2(ctm_ctx* ctx, const Layer2Params& p, size_t lds_bytes) {
     const long long npair = (long long)p.nx * p.ny;
     const int per_cu = (lds_bytes <= 40 * 1024) ? 3 : (lds_bytes <= 76 * 1024 ? 2 : 1);
     const int grid = (int)std::min<long long>(npair, 256LL * per_cu * 2);
-    hipLaunchKernelGGL(layer2_kernel<KT>, dim3(grid), dim3(512), lds_bytes, ctx->stream, p);
+    CTM_LAUNCH(ctx, layer2_kernel<KT>, dim3(grid), dim3(512), lds_bytes, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { ctx->set_error(std::string("layer2 launch: ") + hipGetErrorString(e)); return CTM_ERR_HIP; }
     return CTM_OK;

@@ -338,14 +338,14 @@ int permute_f64(ctm_ctx* ctx, const double* in, double* out, int nd, const long 
         t.tiles_o = (t.No + 31) / 32; t.tiles_i = (t.Ni + 31) / 32;
         const long long ntile = t.nbatch * t.tiles_o * t.tiles_i;
         const int grid = (int)(ntile > 16384 ? 16384 : ntile);
-        hipLaunchKernelGGL(permute_tiled_kernel, dim3(grid), dim3(256), 0, ctx->stream, in, out, t);
+        CTM_LAUNCH(ctx, permute_tiled_kernel, dim3(grid), dim3(256), 0, in, out, t);
         LAUNCH_CHECK(ctx, "permute_tiled");
         return CTM_OK;
     }
     PermDesc d;
     d.nd = m; d.total = total;
     for (int a = 0; a < CTM_MAXD; ++a) { d.odims[a] = a < m ? od[a] : 1; d.istr[a] = a < m ? os_in[a] : 0; }
-    hipLaunchKernelGGL(permute_generic_kernel, dim3(nblocks(total)), dim3(TB), 0, ctx->stream, in, out, d);
+    CTM_LAUNCH(ctx, permute_generic_kernel, dim3(nblocks(total)), dim3(TB), 0, in, out, d);
     LAUNCH_CHECK(ctx, "permute_generic");
     return CTM_OK;
 }
@@ -353,33 +353,33 @@ int permute_f64(ctm_ctx* ctx, const double* in, double* out, int nd, const long 
 int absmax_f64(ctm_ctx* ctx, const double* x, size_t n, double* d_out) {
     hipError_t e = hipMemsetAsync(d_out, 0, sizeof(double), ctx->stream);
     if (e != hipSuccess) { ctx->set_error("absmax memset"); return CTM_ERR_HIP; }
-    hipLaunchKernelGGL(absmax_kernel, dim3(nblocks(n, TB * 8)), dim3(TB), 0, ctx->stream, x, n, (unsigned long long*)d_out);
+    CTM_LAUNCH(ctx, absmax_kernel, dim3(nblocks(n, TB * 8)), dim3(TB), 0, x, n, (unsigned long long*)d_out);
     LAUNCH_CHECK(ctx, "absmax");
     return CTM_OK;
 }
 
 int div_by_device_scalar(ctm_ctx* ctx, double* x, size_t n, const double* d_s, int use_abs) {
-    hipLaunchKernelGGL(div_scalar_kernel, dim3(nblocks(n, TB * 4)), dim3(TB), 0, ctx->stream, x, n, d_s, use_abs);
+    CTM_LAUNCH(ctx, div_scalar_kernel, dim3(nblocks(n, TB * 4)), dim3(TB), 0, x, n, d_s, use_abs);
     LAUNCH_CHECK(ctx, "div_scalar");
     return CTM_OK;
 }
 
 int fill_f64(ctm_ctx* ctx, double* x, size_t n, double v) {
     if (n == 0) return CTM_OK;
-    hipLaunchKernelGGL(fill_kernel, dim3(nblocks(n, TB * 4)), dim3(TB), 0, ctx->stream, x, n, v);
+    CTM_LAUNCH(ctx, fill_kernel, dim3(nblocks(n, TB * 4)), dim3(TB), 0, x, n, v);
     LAUNCH_CHECK(ctx, "fill");
     return CTM_OK;
 }
 
 int set_identity(ctm_ctx* ctx, double* x, int n, long long ld) {
-    hipLaunchKernelGGL(identity_kernel, dim3(nblocks((size_t)n * n, TB * 4)), dim3(TB), 0, ctx->stream, x, n, ld);
+    CTM_LAUNCH(ctx, identity_kernel, dim3(nblocks((size_t)n * n, TB * 4)), dim3(TB), 0, x, n, ld);
     LAUNCH_CHECK(ctx, "identity");
     return CTM_OK;
 }
 
 int copy2d(ctm_ctx* ctx, const double* src, long long lds, double* dst, long long ldd, int rows, int cols) {
     if (rows <= 0 || cols <= 0) return CTM_OK;
-    hipLaunchKernelGGL(copy2d_kernel, dim3(nblocks((size_t)rows * cols, TB * 4)), dim3(TB), 0, ctx->stream, src, lds, dst,
+    CTM_LAUNCH(ctx, copy2d_kernel, dim3(nblocks((size_t)rows * cols, TB * 4)), dim3(TB), 0, src, lds, dst,
                        ldd, rows, cols);
     LAUNCH_CHECK(ctx, "copy2d");
     return CTM_OK;
@@ -387,14 +387,14 @@ int copy2d(ctm_ctx* ctx, const double* src, long long lds, double* dst, long lon
 
 int row_norms(ctm_ctx* ctx, const double* x, int rows, int cols, long long ld, double* d_out) {
     const int blocks = std::max(1, std::min(rows, 4096));           // one 256-thread workgroup per row
-    hipLaunchKernelGGL(row_norms_kernel, dim3(blocks), dim3(256), 0, ctx->stream, x, rows, cols, ld, d_out);
+    CTM_LAUNCH(ctx, row_norms_kernel, dim3(blocks), dim3(256), 0, x, rows, cols, ld, d_out);
     LAUNCH_CHECK(ctx, "row_norms");
     return CTM_OK;
 }
 
 int row_dots(ctm_ctx* ctx, const double* x, const double* y, int rows, int cols, long long ld, double* d_out) {
     int blocks = (rows + 3) / 4; if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(row_dots_kernel, dim3(blocks), dim3(TB), 0, ctx->stream, x, y, rows, cols, ld, d_out);
+    CTM_LAUNCH(ctx, row_dots_kernel, dim3(blocks), dim3(TB), 0, x, y, rows, cols, ld, d_out);
     LAUNCH_CHECK(ctx, "row_dots");
     return CTM_OK;
 }
@@ -402,38 +402,38 @@ int row_dots(ctm_ctx* ctx, const double* x, const double* y, int rows, int cols,
 int gather_rows(ctm_ctx* ctx, const double* src, long long lds, const int* d_idx, int nrows, int cols, double* dst,
                 long long ldd, const double* d_rowscale) {
     if (nrows <= 0) return CTM_OK;
-    hipLaunchKernelGGL(gather_rows_kernel, dim3(nblocks((size_t)nrows * cols, TB * 4)), dim3(TB), 0, ctx->stream, src, lds,
+    CTM_LAUNCH(ctx, gather_rows_kernel, dim3(nblocks((size_t)nrows * cols, TB * 4)), dim3(TB), 0, src, lds,
                        d_idx, nrows, cols, dst, ldd, d_rowscale);
     LAUNCH_CHECK(ctx, "gather_rows");
     return CTM_OK;
 }
 
 int symmetrize_lower(ctm_ctx* ctx, const double* a, double* out, int n, double shift) {
-    hipLaunchKernelGGL(symmetrize_lower_kernel, dim3(nblocks((size_t)n * n, TB * 4)), dim3(TB), 0, ctx->stream, a, out, n, shift);
+    CTM_LAUNCH(ctx, symmetrize_lower_kernel, dim3(nblocks((size_t)n * n, TB * 4)), dim3(TB), 0, a, out, n, shift);
     LAUNCH_CHECK(ctx, "symmetrize_lower");
     return CTM_OK;
 }
 
 int add_transposed01(ctm_ctx* ctx, double* t, int d0, int d2) {
-    hipLaunchKernelGGL(symm01_kernel, dim3(nblocks((size_t)d0 * d0 * d2, TB * 4)), dim3(TB), 0, ctx->stream, t, d0, d2);
+    CTM_LAUNCH(ctx, symm01_kernel, dim3(nblocks((size_t)d0 * d0 * d2, TB * 4)), dim3(TB), 0, t, d0, d2);
     LAUNCH_CHECK(ctx, "symm01");
     return CTM_OK;
 }
 
 int tril_correction(ctm_ctx* ctx, double* E, int k) {
-    hipLaunchKernelGGL(tril_corr_kernel, dim3(nblocks((size_t)k * k)), dim3(TB), 0, ctx->stream, E, k);
+    CTM_LAUNCH(ctx, tril_corr_kernel, dim3(nblocks((size_t)k * k)), dim3(TB), 0, E, k);
     LAUNCH_CHECK(ctx, "tril_corr");
     return CTM_OK;
 }
 
 int diag_to_matrix(ctm_ctx* ctx, const double* d, double* out, int n) {
-    hipLaunchKernelGGL(diag_kernel, dim3(nblocks((size_t)n * n)), dim3(TB), 0, ctx->stream, d, out, n);
+    CTM_LAUNCH(ctx, diag_kernel, dim3(nblocks((size_t)n * n)), dim3(TB), 0, d, out, n);
     LAUNCH_CHECK(ctx, "diag");
     return CTM_OK;
 }
 
 int trace_partial(ctm_ctx* ctx, const double* in, double* out, long long n2, int p) {
-    hipLaunchKernelGGL(trace_partial_kernel, dim3(nblocks((size_t)n2)), dim3(TB), 0, ctx->stream, in, out, n2, p);
+    CTM_LAUNCH(ctx, trace_partial_kernel, dim3(nblocks((size_t)n2)), dim3(TB), 0, in, out, n2, p);
     LAUNCH_CHECK(ctx, "trace_partial");
     return CTM_OK;
 }
@@ -441,29 +441,29 @@ int trace_partial(ctm_ctx* ctx, const double* in, double* out, long long n2, int
 int deinterleave_c128(ctm_ctx* ctx, const double* z, double* re, double* im, size_t n) {
     if (n == 0) return CTM_OK;
     int blocks = (int)std::min<size_t>((n + 255) / 256, 4096);
-    hipLaunchKernelGGL(deinterleave_kernel, dim3(blocks), dim3(256), 0, ctx->stream, (const double2*)z, re, im, n);
+    CTM_LAUNCH(ctx, deinterleave_kernel, dim3(blocks), dim3(256), 0, (const double2*)z, re, im, n);
     return CTM_OK;
 }
 int interleave_c128(ctm_ctx* ctx, const double* re, const double* im, double* z, size_t n) {
     if (n == 0) return CTM_OK;
     int blocks = (int)std::min<size_t>((n + 255) / 256, 4096);
-    hipLaunchKernelGGL(interleave_kernel, dim3(blocks), dim3(256), 0, ctx->stream, re, im, (double2*)z, n);
+    CTM_LAUNCH(ctx, interleave_kernel, dim3(blocks), dim3(256), 0, re, im, (double2*)z, n);
     return CTM_OK;
 }
 int absmax_c128(ctm_ctx* ctx, const double* re, const double* im, size_t n, double* d_out) {
     CTM_HIP_CHECK(ctx, hipMemsetAsync(d_out, 0, sizeof(double), ctx->stream));
     int blocks = (int)std::min<size_t>((n + 255) / 256, 2048);
-    hipLaunchKernelGGL(absmax2_c_kernel, dim3(blocks), dim3(256), 0, ctx->stream, re, im, n, (unsigned long long*)d_out);
-    hipLaunchKernelGGL(sqrt_inplace_kernel, dim3(1), dim3(1), 0, ctx->stream, d_out);
+    CTM_LAUNCH(ctx, absmax2_c_kernel, dim3(blocks), dim3(256), 0, re, im, n, (unsigned long long*)d_out);
+    CTM_LAUNCH(ctx, sqrt_inplace_kernel, dim3(1), dim3(1), 0, d_out);
     return CTM_OK;
 }
 int row_norms_c128(ctm_ctx* ctx, const double* re, const double* im, int rows, int cols, long long ld, double* d_out) {
-    hipLaunchKernelGGL(row_norms_c_kernel, dim3(std::max(1, std::min((rows + 3) / 4, 2048))), dim3(256), 0, ctx->stream, re, im, rows, cols, ld, d_out);
+    CTM_LAUNCH(ctx, row_norms_c_kernel, dim3(std::max(1, std::min((rows + 3) / 4, 2048))), dim3(256), 0, re, im, rows, cols, ld, d_out);
     return CTM_OK;
 }
 int tril_correction_c128(ctm_ctx* ctx, double* Er, double* Ei, int k) {
     const size_t tot = (size_t)k * k;
-    hipLaunchKernelGGL(tril_corr_c_kernel, dim3((int)std::min<size_t>((tot + 255) / 256, 2048)), dim3(256), 0, ctx->stream, Er, Ei, k);
+    CTM_LAUNCH(ctx, tril_corr_c_kernel, dim3((int)std::min<size_t>((tot + 255) / 256, 2048)), dim3(256), 0, Er, Ei, k);
     return CTM_OK;
 }
 // Frobenius (vector 2-) norm of x (n doubles; for planar complex data pass both planes as one array of 2n) -> d_out;
@@ -473,8 +473,8 @@ int norm2_f64(ctm_ctx* ctx, const double* x, size_t n, double* tmp, double* d_ou
     const int rows = (int)(n / cols);
     const size_t rem = n - (size_t)rows * cols;
     int nr = rows;
-    if (rows > 0) hipLaunchKernelGGL(row_norms_kernel, dim3(std::max(1, std::min(rows, 4096))), dim3(256), 0, ctx->stream, x, rows, cols, (long long)cols, tmp);
-    if (rem > 0) { hipLaunchKernelGGL(row_norms_kernel, dim3(1), dim3(256), 0, ctx->stream, x + (size_t)rows * cols, 1, (int)rem, (long long)rem, tmp + rows); ++nr; }
-    hipLaunchKernelGGL(norm_of_norms_kernel, dim3(1), dim3(64), 0, ctx->stream, (const double*)tmp, nr, d_out);
+    if (rows > 0) CTM_LAUNCH(ctx, row_norms_kernel, dim3(std::max(1, std::min(rows, 4096))), dim3(256), 0, x, rows, cols, (long long)cols, tmp);
+    if (rem > 0) { CTM_LAUNCH(ctx, row_norms_kernel, dim3(1), dim3(256), 0, x + (size_t)rows * cols, 1, (int)rem, (long long)rem, tmp + rows); ++nr; }
+    CTM_LAUNCH(ctx, norm_of_norms_kernel, dim3(1), dim3(64), 0, (const double*)tmp, nr, d_out);
     return CTM_OK;
 }

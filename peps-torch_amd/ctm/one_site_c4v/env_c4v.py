@@ -103,3 +103,19 @@ def init_from_ipeps_pbc(state, env, verbosity=0):
     T = torch.zeros((env.chi, env.chi, D2), dtype=env.dtype, device=env.device)
     T[:m, :m, :] = t2[:m, :m, :]
     env.T[env.keyT] = T
+
+
+def compute_multiplets(env, eps_multiplet_gap=1.0e-10):
+    """Sizes of the groups of (numerically) degenerate |eigenvalues| of the corner matrix, in descending order
+    (reference env_c4v.py:401-417): a group ends where the gap to the next value exceeds eps_multiplet_gap."""
+    eng = get_engine()
+    C = env.C[env.keyC]
+    D, _ = eng.truncated_eigh(C, env.chi, eng.cfg(keep_multiplets=False))     # ordered by |D| descending
+    d = torch.cat([D.abs(), torch.zeros(1, dtype=D.dtype, device=D.device)]).cpu()
+    m, l = [], 0
+    for i in range(env.chi):
+        l += 1
+        if d[i] - d[i + 1] > eps_multiplet_gap:
+            m.append(l)
+            l = 0
+    return m

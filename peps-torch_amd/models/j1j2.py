@@ -25,11 +25,22 @@ def _cast_to_real(t):
     return t.real if t.is_complex() else t
 
 
+def _cyclic_shift_4(m, dtype):
+    """P4[s0' s1' s2' s3'; s0 s1 s2 s3] = swap(2,3) swap(1,2) swap(0,1) as an operator on four spins (out; in)."""
+    def swap(i, j):
+        S = torch.zeros([m] * 8, dtype=dtype)
+        for idx in itertools.product(range(m), repeat=4):
+            o = list(idx); o[i], o[j] = o[j], o[i]
+            S[tuple(o) + tuple(idx)] = 1
+        return S.reshape(m ** 4, m ** 4)
+    return (swap(2, 3) @ swap(1, 2) @ swap(0, 1)).reshape([m] * 8)
+
+
 class J1J2():
     def __init__(self, j1=1.0, j2=0, j3=0, hz_stag=0.0, delta_zz=1.0, lmbd=0, h_uni=[0, 0, 0], global_args=cfg.global_args):
-        if lmbd != 0:
-            raise NotImplementedError("the chiral term is not implemented")
         self.dtype = global_args.torch_dtype
+        if lmbd != 0 and not torch.zeros(1, dtype=self.dtype).is_complex():
+            raise AssertionError("Invalid dtype: Lambda requires complex numbers")        # models/j1j2.py:97-98
         self.device = 'cpu'
         self.phys_dim = 2
         self.j1, self.j2, self.j3, self.lmbd, self.hz_stag, self.delta_zz = j1, j2, j3, lmbd, hz_stag, delta_zz
@@ -62,6 +73,15 @@ class J1J2():
             return hp
         self.get_hp = get_hp
         self.hp_rot = torch.einsum('xj,yk,ixylauvd,ub,vc->ijklabcd', rot, rot, self.get_hp((0, 0)), rot, rot).contiguous()
+        # scalar-chirality term i (P4 - P4^dagger) of the plaquette (models/j1j2.py:147-175): P4 moves the spin of site q to
+        # site q+1 around the plaquette; the RDM orders the sites s0 s1 / s2 s3, the cycle runs s0 -> s1 -> s3 -> s2
+        self.chiral_term = self.chiral_term_rot = self.hp_chiral_rot = 0 * s2.I_N(N=4)
+        if self.phys_dim == 2 and self.lmbd != 0:
+            P4 = _cyclic_shift_4(self.phys_dim, self.dtype)
+            ch = 1.0j * (P4 - P4.reshape(16, 16).t().reshape([2] * 8))
+            self.chiral_term = ch.permute(0, 1, 3, 2, 4, 5, 7, 6)
+            self.chiral_term_rot = torch.einsum('xj,yk,ixylauvd,ub,vc->ijklabcd', rot, rot, self.chiral_term, rot, rot).contiguous()
+            self.hp_chiral_rot = self.lmbd * self.chiral_term_rot
         self.obs_ops = self.get_obs_ops()
 
     def get_obs_ops(self):
@@ -101,7 +121,12 @@ class J1J2():
     def energy_2x2_1site_BP(self, state, env):
         assert self.h_uni[:2].norm() == 0
         r = rdm.rdm2x2((0, 0), state, env).cpu()
-        return _cast_to_real(torch.einsum('ijklabcd,ijklabcd', r, self.hp_rot))
+        e = torch.einsum('ijklabcd,ijklabcd', r, self.hp_rot.to(r.dtype))
+        if abs(self.lmbd) > 0:
+            e = e + torch.einsum('ijklabcd,ijklabcd', r, self.hp_chiral_rot.to(r.dtype))
+        if abs(self.j3) > 0:                                                   # models/j1j2.py:216-218
+            e = e + self.j3 * eval_nnnn_per_site((0, 0), state, env, self.obs_ops)
+        return _cast_to_real(e)
 
     def _eval_obs(self, state, env, ss):
         obs = {"avg_m": 0.}

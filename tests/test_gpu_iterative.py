@@ -54,3 +54,52 @@ def test_sweeps_match_oracle_on_iterative_path(eng, cplx, chi, nsweeps):
     assert np.abs(r - ro).max() < 1e-10, np.abs(r - ro).max()
     eo = OJ.energy_per_site([ro], 1.0, 0.5); e = OJ.energy_per_site([r], 1.0, 0.5)
     assert abs(e - eo) < 1e-10 * max(abs(eo), 1e-3), (e, eo)
+
+
+def _svd_matrix(n, s, seed):
+    rng = np.random.default_rng(seed)
+    U, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    V, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    return U, V, (U * s) @ V.T
+
+
+@pytest.mark.parametrize("factor", [3.0, 40.0])
+def test_warm_start_finds_a_new_leading_direction(eng, factor):
+    """Between two calls the operator gains a singular direction ORTHOGONAL to the warm basis and larger than the smallest kept
+    value.  Every triplet of the warm basis is still an exact singular triplet of the new matrix (residual zero), so a residual
+    test alone would accept the old leading chi at the first check; the engine must still return the new direction
+    (a full warm block is not accepted before its guard rows have had three half steps)."""
+    import torch
+    n, chi = 1024, 64
+    s = 0.9 ** np.arange(n)
+    U, V, M1 = _svd_matrix(n, s, 11)
+    s2 = s.copy()
+    s2[200] = factor * s[chi]                                   # a direction that was far down the spectrum, now inside the kept range
+    M2 = (U * s2) @ V.T
+    basis = eng.warm_basis(chi, n, torch.float64)
+    cfg = eng.cfg(keep_multiplets=False)
+    _, S1, _ = eng.truncated_svd(dev(M1), chi, cfg, basis=basis)
+    assert np.abs(S1.cpu().numpy() - s[:chi]).max() < 1e-12
+    U2, S2, V2 = (t.cpu().numpy() for t in eng.truncated_svd(dev(M2), chi, cfg, basis=basis))
+    exact = np.sort(s2)[::-1][:chi]
+    assert np.abs(S2 - exact).max() < 1e-12, "the new singular direction was missed by the warm-started solve"
+    assert np.abs(U2.T @ M2 @ V2 - np.diag(S2)).max() < 1e-12
+    # third call, unchanged matrix: the warm start is now exact and must reproduce the same values
+    _, S3, _ = eng.truncated_svd(dev(M2), chi, cfg, basis=basis)
+    assert np.abs(S3.cpu().numpy() - exact).max() < 1e-12
+
+
+def test_values_below_the_numerical_rank_are_returned_as_zeros(eng):
+    """Documented deviation of ctm_truncated_svd from truncated_svd_gesdd: the leading-k solver does not resolve
+    singular values below rank_tol = 5e-13 s_0 and returns them as exact zeros, where LAPACK returns numbers of that size
+    (themselves only accurate to eps s_0).  Everything above the threshold is exact, and whatever is zeroed is below it."""
+    n, chi = 600, 40
+    s = np.zeros(n)
+    s[:20] = 10.0 ** (-np.arange(20) * 0.5)                    # 1 ... 3e-10
+    s[20:30] = 10.0 ** (-13.0 - 0.3 * np.arange(10))           # 1e-13 ... 2e-16: below the numerical rank
+    _, _, M = _svd_matrix(n, s, 5)
+    S = eng.truncated_svd(dev(M), chi, eng.cfg(keep_multiplets=False))[1].cpu().numpy()
+    ex = np.linalg.svd(M, compute_uv=False)[:chi]
+    assert np.abs(S[:20] - ex[:20]).max() < 1e-14
+    assert (S[S < 5e-13] == 0).all() and ex[S == 0].max() < 5e-13
+    assert np.abs(S - ex).max() < 5e-13

@@ -111,3 +111,38 @@ def test_svdvals(eng):
     C = rng.standard_normal((18, 18))
     S = eng.svdvals(dev(C)).cpu().numpy()
     assert np.abs(S - np.linalg.svd(C, compute_uv=False)).max() < 1e-13 * S[0]
+
+
+@pytest.mark.parametrize("n,chi", [(24, 24), (81, 20), (300, 300), (768, 48)])
+def test_svd_symeig(eng, n, chi):
+    """ctm_svd_symeig (reference linalg/svd_symeig.py:12-34, custom_svd.py:143-208) vs the oracle restatement."""
+    from oracle import ctm_oracle as O
+    rng = np.random.default_rng(n + 7)
+    Q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    lam = np.exp(-0.07 * np.arange(n)) * np.where(rng.random(n) < 0.4, -1.0, 1.0)
+    H = (Q * lam) @ Q.T
+    H = 0.5 * (H + H.T)
+    U, S, V = (t.cpu().numpy() for t in eng.svd_symeig(dev(H), chi))
+    Uo, So, Vo = O.truncated_svd_symeig(H, chi)
+    assert np.abs(S - So).max() < 1e-13 and (np.diff(S) <= 0).all()
+    # V = U sign(D) exactly, column by column
+    sg = np.sign(np.sum(U * V, axis=0))
+    assert np.array_equal(V, U * sg[None, :])
+    assert np.array_equal(sg, np.sign(np.sum(Uo * Vo, axis=0)))                # the eigenvalue signs
+    assert np.abs(U.T @ U - np.eye(chi)).max() < 1e-12
+    assert np.abs(H @ V - U * S[None, :]).max() < 1e-12                         # M v = s u  (M symmetric: M u sign = s u)
+    if chi == n:
+        assert np.linalg.norm(H - (U * S) @ V.T) < S[0] * n * n * 1e-14          # svd_symeig.py:88
+
+
+def test_truncated_svd_symeig_host_wrapper(eng):
+    from linalg.custom_svd import truncated_svd_symeig
+    from linalg.svd_symeig import SVDSYMEIG
+    from conftest import golden
+    H = golden("decomp")["eig_H"]
+    for nm, ch in (("a", 4), ("b", 6)):
+        U, S, V = (t.cpu().numpy() for t in truncated_svd_symeig(dev(H), ch, keep_multiplets=True, eps_multiplet=1e-12))
+        D = golden("decomp")[f"eig_{nm}_D"]
+        assert np.abs(S - np.abs(D)).max() < 1e-13 and ((S == 0) == (D == 0)).all()
+    U, S, V = (t.cpu().numpy() for t in SVDSYMEIG.apply(dev(H)))
+    assert np.linalg.norm(H - (U * S) @ V.T) < S[0] * H.shape[0] ** 2 * 1e-14

@@ -160,3 +160,44 @@ def test_move_variants_on_host_layer(cpu_cfg, name):
             ctmrg.ctm_MOVE((0, -1), st, env)
     finally:
         cfg.ctm_args.projector_method = "4X4"
+
+
+REF_INPUTS = ["RVB_1x1.in", "RVB_2x1_AB.in", "RVB_2x2_ABCD.in", "VBS_1x2_AB_D2.in", "AKLT-S2_2x1_biLat.in", "AKLT-S2_2x2_ABCD.in",
+              "gesdd-D2-chi50-j20.55-run0-iRND2x1_state.json", "BIPARTITE_j2_0_j3_1250_h_39000_D_3_chi_32_seed_100_state.json"]
+
+
+@pytest.mark.parametrize("fname", REF_INPUTS)
+def test_read_ipeps_parses_the_reference_data_files(fname, cpu_cfg):
+    """The reference's own test-input files (legacy "entries" format, "1D" format, cells with a pattern) are committed as data
+    under tests/golden/test-input; read_ipeps must reproduce the arrays, cell size, tiling and aux_seq handling that the
+    REFERENCE's parser gives on them (oracle/gen_golden.py inputs; reference ipeps/ipeps.py:339-441, tensor_io.py:52-87)."""
+    from ipeps.ipeps import read_ipeps
+    from conftest import REPO
+    g = golden("test_input_parsed")
+    path = os.path.join(REPO, "tests", "golden", "test-input", fname)
+    tag = fname.replace('.', '_').replace('-', '_')
+    st = read_ipeps(path)
+    assert [st.lX, st.lY] == list(g[f"{tag}__lXlY"])
+    keys = [k for k in g.files if k.startswith(f"{tag}__site_")]
+    assert len(keys) == len(st.sites)
+    for k in keys:
+        c = tuple(int(v) for v in k.split("__site_")[1].split("_"))
+        ref = g[k]
+        assert tuple(st.sites[c].shape) == ref.shape and np.array_equal(st.sites[c].cpu().numpy(), ref), (fname, c)
+    win = [(x, y) for y in range(-3, 4) for x in range(-3, 4)]
+    assert np.array_equal(np.array([st.vertexToSite(v) for v in win]), g[f"{tag}__v2s"])
+    for asq in ([0, 1, 2, 3], [3, 0, 1, 2]):
+        st2 = read_ipeps(path, aux_seq=asq)
+        assert np.array_equal(next(iter(st2.sites.values())).cpu().numpy(), g[f"{tag}__aux{''.join(map(str, asq))}"])
+
+
+def test_read_ipeps_c4v_on_the_reference_rvb_file(cpu_cfg):
+    """BASELINE configs[0] reads test-input/RVB_1x1.in: D = 3 single-site state in the legacy format."""
+    from ipeps.ipeps_c4v import read_ipeps_c4v
+    from conftest import REPO
+    g = golden("test_input_parsed")
+    st = read_ipeps_c4v(os.path.join(REPO, "tests", "golden", "test-input", "RVB_1x1.in"))
+    assert tuple(st.site().shape) == (2, 3, 3, 3, 3)
+    assert np.array_equal(st.site().cpu().numpy(), g["RVB_1x1_in__c4v_site"])
+    # the fixture of the published RVB anchor was generated from this very file
+    assert np.array_equal(st.site().cpu().numpy(), golden("rvb_c4v")["site"])

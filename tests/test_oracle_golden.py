@@ -151,3 +151,21 @@ def test_aklt_S2_energy_is_zero(name):
     h = g["h"]
     e = sum(np.einsum('ijab,ijab', O.rdm2x1(c, ost, oe), h) + np.einsum('ijab,ijab', O.rdm1x2(c, ost, oe), h) for c in ost.sites) / len(ost.sites)
     assert abs(e) < 1e-12
+
+
+def test_oracle_svd_symeig_identities():
+    """truncated_svd_symeig restates linalg/svd_symeig.py:12-34 + custom_svd.py:143-208; the reference function needs torch.symeig
+    (removed from torch), so the restatement is pinned by the reference's own assertion (svd_symeig.py:88: |M - U S V^T| <
+    S0 m^2 1e-14) and by its relation to truncated_eig_sym, which IS pinned against the reference (decomp.npz)."""
+    from oracle import ctm_oracle as O
+    g = golden("decomp")
+    H = g["eig_H"]
+    m = H.shape[0]
+    U, S, V = O.truncated_svd_symeig(H, m)
+    assert np.linalg.norm(H - (U * S) @ V.T) < S[0] * m * m * 1e-14
+    assert (np.diff(S) <= 0).all()
+    D, Ue = O.truncated_eig_sym(H, m)
+    assert np.array_equal(S, np.abs(D)) and np.array_equal(U, Ue) and np.array_equal(V, Ue * np.sign(D)[None, :])
+    for nm, ch in (("a", 4), ("b", 6)):             # the multiplet back-off cases of the eig golden
+        Ut, St, Vt = O.truncated_svd_symeig(H, ch, keep_multiplets=True, eps_multiplet=1e-12)
+        assert np.abs(St - np.abs(g[f"eig_{nm}_D"])).max() < 1e-13 and ((St == 0) == (g[f"eig_{nm}_D"] == 0)).all()
