@@ -62,7 +62,23 @@ def gemm_macs_per_unit(D, chi, p=2):
     return 3 * chi ** 3 * D ** 6 + 8 * chi ** 3 * D ** 4 + 8 * chi ** 3 * D ** 2 + 10 * p * chi ** 2 * D ** 6
 
 
-def cpu_baseline(kind, D, chi, sites, budget_s=25.0):
+def _cpu_env(O, ost, chi, env_np, sites):
+    """Environment for the CPU leg: the tensors the GPU run ended with (downloaded), i.e. the same environment the timed sweeps
+    worked on -- dense LAPACK/BLAS does the same work on any environment, but the comparison should not rest on that."""
+    env = O.init_env_ctmrg(ost, chi)
+    if env_np is not None:
+        C, T = env_np
+        for k in env.C: env.C[k] = np.ascontiguousarray(C[k])
+        for k in env.T: env.T[k] = np.ascontiguousarray(T[k])
+        return env, "environment of the timed GPU run"
+    rng = np.random.default_rng(7)
+    cx = np.iscomplexobj(sites[(0, 0)])
+    for k in env.C: env.C[k] = rng.random(env.C[k].shape) + (1j * rng.random(env.C[k].shape) if cx else 0.0)
+    for k in env.T: env.T[k] = rng.random(env.T[k].shape) + (1j * rng.random(env.T[k].shape) if cx else 0.0)
+    return env, "dense random environment"
+
+
+def cpu_baseline(kind, D, chi, sites, env_np=None, budget_s=25.0):
     """numpy oracle on the host cores: time ONE unit (site (0,0), UP move: halves -> projectors -> absorb) of
     the generic sweep -- or ONE C4v sweep -- and extrapolate to sweeps/s.  Bounded sample."""
     from oracle import ctm_oracle as O, c4v_oracle as O4
@@ -85,14 +101,9 @@ def cpu_baseline(kind, D, chi, sites, budget_s=25.0):
         return {"value": 1.0 / dt, "unit": "sweeps/s", "cores": threads, "kind": "port",
                 "sample": f"{n} full C4v sweeps of the numpy oracle (LAPACK eigh), {os.cpu_count()} host cpus"}
     ost = O.State(sites)
-    env = O.init_env_ctmrg(ost, chi)
+    env, env_what = _cpu_env(O, ost, chi, env_np, sites)
     if chi * D * D > 6000:
-        return cpu_baseline_large(O, ost, env, D, chi, threads)
-    # make the environment dense with the cheapest possible warm-up: random dense env of the right shapes
-    rng = np.random.default_rng(7)
-    cx = np.iscomplexobj(sites[(0, 0)])
-    for k in env.C: env.C[k] = rng.random(env.C[k].shape) + (1j * rng.random(env.C[k].shape) if cx else 0.0)
-    for k in env.T: env.T[k] = rng.random(env.T[k].shape) + (1j * rng.random(env.T[k].shape) if cx else 0.0)
+        return cpu_baseline_large(O, ost, env, D, chi, threads, env_what)
     t0 = time.perf_counter()
     P, Pt = O.get_projectors_4x4(O.UP, (0, 0), ost, env)
     Pd = {c: P for c in ost.sites}; Ptd = {c: Pt for c in ost.sites}
@@ -100,10 +111,10 @@ def cpu_baseline(kind, D, chi, sites, budget_s=25.0):
     dt = time.perf_counter() - t0
     return {"value": 1.0 / (32 * dt), "unit": "sweeps/s", "cores": threads, "kind": "port",
             "sample": f"1 of the 32 (site,direction) units of one sweep (numpy oracle: 4 corners, 2 halves, M, LAPACK gesdd, "
-                      f"projectors, absorb) = {dt:.2f} s, extrapolated x32; {os.cpu_count()} host cpus"}
+                      f"projectors, absorb) on the {env_what} = {dt:.2f} s, extrapolated x32; {os.cpu_count()} host cpus"}
 
 
-def energy_parity(dev, dtype="f64", D=3, chi=36, nsweeps=3):
+def energy_parity(dev, dtype="f64", D=3, chi=36, nsweeps=3, signed=False):
     """rdm2x2 energy (J1-J2, j2 = 0.5) after `nsweeps` sweeps from the CTMRG init: native engine vs the numpy oracle on the SAME
     synthetic state, at a size the oracle finishes in seconds (the second half of BASELINE.json's metric)."""
     import config as cfg
@@ -113,6 +124,9 @@ def energy_parity(dev, dtype="f64", D=3, chi=36, nsweeps=3):
     from ctm.generic import ctmrg
     from models import j1j2
     sites = synth_sites("generic", D, seed=3, dtype=dtype)
+    if signed:
+        sites = {k: (2.0 * v - (1.0 + 1.0j if np.iscomplexobj(v) else 1.0)) for k, v in sites.items()}
+        sites = {k: v / np.abs(v).max() for k, v in sites.items()}
     st = IPEPS({k: torch.from_numpy(v).to(dev) for k, v in sites.items()})
     env = ENV(chi, st); init_env(st, env)
     for _ in range(nsweeps):
@@ -126,20 +140,18 @@ def energy_parity(dev, dtype="f64", D=3, chi=36, nsweeps=3):
         O.ctm_sweep(ost, oe)
     eo = OJ.energy_per_site([O.rdm2x2(c, ost, oe) for c in ost.sites], 1.0, 0.5)
     ospec = O.corner_spectra(oe)
-    return {"workload": f"generic 2x2 D={D} chi={chi} {dtype}, {nsweeps} sweeps from the CTMRG init, J1-J2 j2=0.5", "energy_native": e,
+    return {"workload": f"generic 2x2 D={D} chi={chi} {dtype}{' signed' if signed else ''}, {nsweeps} sweeps from the CTMRG init, J1-J2 j2=0.5", "energy_native": e,
             "energy_oracle": float(eo), "rel_err": abs(e - eo) / max(abs(eo), 1e-300),
             "max_abs_err_corner_spectra": float(max(np.abs(spec[k] - ospec[k]).max() for k in ospec)), "tolerance": 1e-10}
 
 
-def cpu_baseline_large(O, ost, env, D, chi, threads):
+def cpu_baseline_large(O, ost, env, D, chi, threads, env_what="dense random environment"):
     """n = chi D^2 > 6000: one full unit on the CPU takes many minutes (LAPACK gesdd of an n x n matrix), so the unit is
     assembled from bounded pieces: the four enlarged corners and the absorb are timed at full size with the oracle, ONE
     n x n x n product is timed and counted three times (two halves + M = R^T Rt), and the SVD is timed at n_s = 4096 and
     scaled by (n / n_s)^3."""
     rng = np.random.default_rng(7)
     cx = np.iscomplexobj(next(iter(ost.sites.values())))
-    for k in env.C: env.C[k] = rng.random(env.C[k].shape) + (1j * rng.random(env.C[k].shape) if cx else 0.0)
-    for k in env.T: env.T[k] = rng.random(env.T[k].shape) + (1j * rng.random(env.T[k].shape) if cx else 0.0)
     n = chi * D * D
     t0 = time.perf_counter()
     cs = [O.c2x2(cid, (0, 0), ost, env) for cid in range(4)]
@@ -154,62 +166,67 @@ def cpu_baseline_large(O, ost, env, D, chi, threads):
     t0 = time.perf_counter(); O.absorb_truncate(O.UP, (0, 0), ost, env, Pd, Pd); t_abs = time.perf_counter() - t0
     dt = t_corners + 3 * t_gemm + t_svd + t_proj + t_abs
     return {"value": 1.0 / (32 * dt), "unit": "sweeps/s", "cores": threads, "kind": "port",
-            "sample": f"one (site,direction) unit of the numpy oracle assembled from bounded pieces: 4 corners {t_corners:.1f} s + 3 x (n^3 GEMM "
+            "sample": f"one (site,direction) unit of the numpy oracle on the {env_what}, assembled from bounded pieces: 4 corners {t_corners:.1f} s + 3 x (n^3 GEMM "
                       f"{t_gemm:.1f} s) + gesdd at n_s=4096 {t_svd_s:.1f} s scaled by (n/n_s)^3 = {t_svd:.0f} s + projector GEMMs {t_proj:.1f} s + "
                       f"absorb {t_abs:.1f} s = {dt:.0f} s/unit, x32 units/sweep (extrapolated); {os.cpu_count()} host cpus"}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=None)
-    ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--config", default=DEFAULT_CONFIG, choices=sorted(CONFIGS))
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--profile", action="store_true", help="per-phase host timers (adds stream syncs)")
-    ap.add_argument("--opt", action="append", default=[], help="engine option key=value (development)")
-    ap.add_argument("--signed", action="store_true", help="development: A ~ U(-1,1) instead of the reference's U[0,1) (flatter spectra)")
-    ap.add_argument("--serial-units", action="store_true", help="do not overlap the independent site-units of a move on streams")
-    ap.add_argument("--cold-start", action="store_true", help="no warm start of the leading-chi iteration")
-    args = ap.parse_args()
-    kind, D, chi, dtype = CONFIGS[args.config]
-    steps = args.steps if args.steps is not None else (20 if kind == "c4v" else 2)
-    # untimed warm-up: ceil(chi / D^2) sweeps, the number after which the environment from the CTMRG init has filled its chi
-    # (reference ctmrg.py:81)
-    warmup = args.warmup if args.warmup is not None else (3 if kind == "c4v" else -(-chi // (D * D)))
+def _union_ms(ivals, kind):
+    """Independent units run on concurrent streams, so launches overlap: the time the chip spends on a kernel class is the UNION
+    of the [start, end] intervals of its launches (equal to the sum of durations when nothing overlaps)."""
+    iv = sorted((a, b) for k_, a, b, _ in ivals if int(k_) == kind)
+    tot, cur_a, cur_b = 0.0, None, None
+    for a, b in iv:
+        if cur_b is None or a > cur_b:
+            if cur_b is not None: tot += cur_b - cur_a
+            cur_a, cur_b = a, b
+        else:
+            cur_b = max(cur_b, b)
+    return tot + ((cur_b - cur_a) if cur_b is not None else 0.0)
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the engine has no CPU path")
-    if os.environ.get("CTM_BENCH_ONE_DEVICE"):      # development hook: several ranks on ONE GPU (gloo), to exercise the sharded path
-        local = 0
-    torch.cuda.set_device(local)
-    import torch.distributed as dist
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(os.environ.get("CTM_BENCH_BACKEND", "nccl"), rank=rank, world_size=world)
-    if args.gpus != world and rank == 0 and world > 1:
-        print(f"# note: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
 
+HBM_PEAK_GBPS = 8000.0
+# instrumented kernel classes (csrc: timing_end kinds).  Class 3 (streaming strip / row-block kernels) reports ALGORITHMIC BYTES
+# (the big operand read once + the row block in and out) AND is priced against HBM; the others report flops.
+CLS = {0: ("gemm_f64_fast_kernel / gemm_f64_kernel<4,4> (128x128 tile)", "mfma", "gemm_f64_fast_kernel"),
+       1: ("gemm_f64_kernel<2,2> (64x64 tile: small, segmented and batched products)", "mfma", "gemm_f64_kernel<2, 2>"),
+       2: ("layer2_reg_kernel<KT> (float64) / layer2_c_kernel<KT> (complex128): fused two-layer enlarged-corner kernel", "mfma", "layer2_"),
+       3: ("gemm_rows_kernel<TM<=2,BNF> (gemm_strip_kernel): <= 32-row block times an n x n corner, streamed once", "hbm", "gemm_rows_kernel"),
+       4: ("gemm_rows_kernel<TM>=3,BNF>: 33..64-row block times an n x n corner (16 flop per byte of the corner)", "mfma", "gemm_rows_kernel")}
+
+
+def _rate(work, ms, bound):              # TFLOP/s or GB/s
+    return work / max(ms * 1e-3, 1e-30) / (1e12 if bound == "mfma" else 1e9)
+
+
+def _describe(i, kms, kfl, kn, ums=None):
+    """frac = plain per-launch figure: total algorithmic work / SUM of the launch durations (what rocprofv3's per-kernel
+    average confirms); frac_union = the same work / union of the launch intervals (what the chip delivered on that class while
+    units share it)."""
+    name, bound, _ = CLS[i]
+    peak = FP64_MFMA_PEAK_TFLOPS if bound == "mfma" else HBM_PEAK_GBPS
+    ach = _rate(kfl[i], kms[i], bound) if kn[i] else 0.0
+    d = {"kernel": name, "bound": bound, "achieved": round(ach, 3), "peak": peak, "unit": "TFLOP/s" if bound == "mfma" else "GB/s",
+         "frac": round(ach / peak, 4), "launches": int(kn[i]), "avg_launch_ms": round(kms[i] / max(kn[i], 1), 5),
+         "sum_launch_ms": round(kms[i], 3)}
+    if ums is not None and kn[i]:
+        d["busy_ms_union"] = round(ums[i], 3)
+        d["achieved_union"] = round(_rate(kfl[i], ums[i], bound), 3)
+        d["frac_union"] = round(d["achieved_union"] / peak, 4)
+    return d
+
+
+def run_workload(args, eng, dev, kind, D, chi, dtype, signed, steps, warmup, world, rank, dist):
+    """Build the synthetic state, warm up, time `steps` sweeps; returns (dict for the JSON line, sites, state, env)."""
     import config as cfg
-    cfg.global_args.device = f"cuda:{local}"
-    cfg.ctm_args.concurrent_units = not args.serial_units
-    cfg.ctm_args.projector_warm_start = not args.cold_start
-    import _native
     from ipeps.ipeps import IPEPS
     from ipeps.ipeps_c4v import IPEPS_C4V
     from ctm.generic.env import ENV, init_env
     from ctm.generic import ctmrg
     from ctm.one_site_c4v.env_c4v import ENV_C4V, init_env as init_env_c4v
     from ctm.one_site_c4v import ctmrg_c4v
-    eng = _native.engine()
-    for kv in args.opt:
-        k_, v_ = kv.split("="); eng.set_option(k_, float(v_))
-    dev = torch.device("cuda", local)
     sites = synth_sites(kind, D, dtype=dtype)
-    if args.signed:
+    if signed:
         sites = {k: (2.0 * v - (1.0 + 1.0j if np.iscomplexobj(v) else 1.0)) for k, v in sites.items()}
         sites = {k: v / np.abs(v).max() for k, v in sites.items()}
     if kind == "c4v":
@@ -245,15 +262,25 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     ivals = eng.gemm_intervals()
-    KK = range(4)
+    KK = range(5)
     k_ms = [eng.stat(f"k_ms{i}") for i in KK]
     k_fl = [eng.stat(f"k_flops{i}") for i in KK]
     k_n = [eng.stat(f"k_calls{i}") for i in KK]
+    phase = eng.timers()
+    absorb_bytes, absorb_calls = eng.stat("absorb_bytes"), eng.stat("absorb_calls")
+    svd = {"decompositions": int(eng.stat("jacobi_calls")),
+           "avg_jacobi_sweeps": round(eng.stat("total_sweeps") / max(eng.stat("jacobi_calls"), 1), 2),
+           "power_iter_hits": int(eng.stat("si_hits")), "power_iter_fallbacks_to_full": int(eng.stat("si_fallbacks")),
+           "block_krylov_solves": int(eng.stat("lz_hits")),
+           "avg_block_krylov_steps": round(eng.stat("lz_total_steps") / max(eng.stat("lz_hits"), 1), 2),
+           "ritz_extractions": int(eng.stat("lz_extractions"))}
     eng.set_option("gemm_timing", 0)
+    if args.profile:
+        eng.set_option("profile", 0)
     # reference pass for the kernel-quality figure: ONE more sweep with the units issued serially on one stream (nothing
     # co-scheduled), outside the timed region -- per-launch rates of the same kernels without sharing the chip
     serial = None
-    if world == 1 and kind != "c4v" and not args.serial_units:
+    if world == 1 and kind != "c4v" and not args.serial_units and not args.no_serial_pass:
         cfg.ctm_args.concurrent_units = False
         eng.set_option("gemm_timing", 1)
         step(); fence()
@@ -264,107 +291,187 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    u_ms = [_union_ms(ivals, i) for i in KK]
+    # the dominant kernel = the class the chip spends most time on (sum of its launch durations)
+    dom = max((0, 2, 3, 4), key=lambda i: k_ms[i])
+    roof = _describe(dom, k_ms, k_fl, k_n, u_ms)
+    roof = {"bound": roof.pop("bound"), **roof, "traffic": None,
+            "concurrent_streams": max(1, len(getattr(eng, "workers", []))),
+            "time_share_of_sweep": round(u_ms[dom] * 1e-3 / dt, 4),
+            "algorithmic_work_per_launch": ("2*M*N*K flop of each product" if dom in (0, 1) else
+                                            "2 * p * chi_x * chi_y * (D^2)^2 * 2 D^2 flop per launch (both layers)" if dom == 2 else
+                                            "2*M*N*K flop: M <= 64 rows times the N x K corner" if dom == 4 else
+                                            "8 * (K*N + M*K + M*N) bytes: the n x n corner read once, the <=64-row block in and out"),
+            "other_kernels": {str(i): _describe(i, k_ms, k_fl, k_n, u_ms) for i in KK if i != dom and k_n[i]}}
+    if serial is not None:
+        s_ms, s_fl, s_n = serial
+        roof["serial_pass"] = {"note": "one extra sweep after the timed region, units issued serially on one stream (no co-scheduling): kernel quality without sharing the chip",
+                               **{("dominant" if i == dom else str(i)): _describe(i, s_ms, s_fl, s_n) for i in KK if s_n[i]}}
+    # north_star: achieved HBM GB/s on the absorb step = algorithmic bytes of the absorb calls (operands read once, results written
+    # once) / device time of the absorb phase (HIP events on the engines' streams, summed over streams)
+    if absorb_calls and phase.get("absorb", 0.0) > 0:
+        roof["absorb_step"] = {"bound": "hbm", "calls": int(absorb_calls), "algorithmic_bytes_per_call": round(absorb_bytes / absorb_calls),
+                               "device_ms_per_call": round(1e3 * phase["absorb"] / absorb_calls, 4),
+                               "achieved": round(absorb_bytes / phase["absorb"] / 1e9, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                               "frac": round(absorb_bytes / phase["absorb"] / 1e9 / HBM_PEAK_GBPS, 5),
+                               "note": "the absorb is a chain of skinny GEMMs and the fused two-layer kernel over chi^2 D^4-sized intermediates: "
+                                       "its time is set by those kernels (MFMA / latency), not by streaming its O(n chi) operands"}
+    out = {"value": steps / dt, "ms_per_step": 1e3 * dt / steps, "steps": steps, "warmup": warmup, "roofline": roof, "svd": svd,
+           "phase_s": {k: round(v, 4) for k, v in phase.items()},
+           "phase_s_note": "device time per phase from HIP events on the engines' streams, summed over concurrent streams (not wall time)"}
+    if kind != "c4v":
+        # what the engine could exploit on THIS state: numerical rank of the truncation and the number of projector columns above
+        # projector_svd_reltol, out of chi
+        nc = env.__dict__.get("_ncol") or {}
+        S = [float((s_ > 1e-8 * s_[0]).sum()) for s_ in (v for v in env.get_spectra().values())]
+        out["state"] = {"chi": chi, "signed": bool(signed),
+                        "corner_values_above_1e-8": int(min(S)) if S else None,
+                        "nonzero_projector_columns": (max(nc.values()) if nc else chi),
+                        "corner_cache_hits": int(eng.stat("corner_cache_hits")),
+                        "note": ("signed random tensors A ~ U(-1,1): full-rank environment (all chi projector columns significant), "
+                                 "block-Krylov truncation on every unit") if signed else
+                                ("positive random tensors A ~ U[0,1) (the state SURVEY 8d prescribes): numerically low-rank environment, "
+                                 "see the full_rank block for the same shape on a full-rank state")}
+    return out, dom, sites, state, env
+
+
+def traffic_from_profile(args, world, dom, signed):
+    """HBM traffic of the kernel families from the committed PMC pass of this same command (bench.py cannot attach counters to
+    itself); None when no profile of this workload is committed."""
+    try:
+        import csv
+        tag = "signed" if signed else "default"
+        prof = json.load(open(os.path.join(REPO, "profiles", f"r02_bench_{tag}.json")))
+        if prof["config"]["workload"] != args.config or world != 1:
+            return None
+        rows = list(csv.DictReader(open(os.path.join(REPO, "profiles", f"r02_bench_{tag}_pmc_hbm_traffic.csv"))))
+
+        def pmc(key):
+            tb = tn = 0.0
+            for row in rows:
+                if key in row["kernel"]:
+                    tb += float(row["hbm_bytes_per_launch(2x_fetch_corrected)"]) * float(row["launches"]); tn += float(row["launches"])
+            return round(tb / tn) if tn else None
+        return {"dominant": pmc(CLS[dom][2]), "others": {str(i): pmc(CLS[i][2]) for i in CLS if i != dom},
+                "source": f"profiles/r02_bench_{tag}_pmc_hbm_traffic.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, average HBM bytes per launch)"}
+    except Exception:
+        return None
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: re-execute under torch.distributed.run with N ranks on this node (one per
+    GPU, RCCL), which is exactly what the driver's own command line does."""
+    import socket, subprocess
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0)); port = s_.getsockname()[1]
+    ngpu = torch.cuda.device_count()
+    if ngpu < n and not os.environ.get("CTM_BENCH_ONE_DEVICE"):
+        raise SystemExit(f"bench.py --gpus {n}: only {ngpu} GPU(s) visible on this node")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ); env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--config", default=DEFAULT_CONFIG, choices=sorted(CONFIGS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile", action="store_true", help="per-phase HOST timers (adds stream syncs; phase_s is event-based without it)")
+    ap.add_argument("--opt", action="append", default=[], help="engine option key=value (development)")
+    ap.add_argument("--signed", action="store_true", help="time ONLY the full-rank state A ~ U(-1,1) (as `value`)")
+    ap.add_argument("--no-full-rank", action="store_true", help="skip the second (full-rank) block of the default run")
+    ap.add_argument("--no-serial-pass", action="store_true", help="skip the extra serially issued sweep behind roofline.serial_pass")
+    ap.add_argument("--serial-units", action="store_true", help="do not overlap the independent site-units of a move on streams")
+    ap.add_argument("--cold-start", action="store_true", help="no warm start of the leading-chi iteration")
+    args = ap.parse_args()
+    kind, D, chi, dtype = CONFIGS[args.config]
+    steps = args.steps if args.steps is not None else (20 if kind == "c4v" else 2)
+    # untimed warm-up: ceil(chi / D^2) sweeps, the number after which the environment from the CTMRG init has filled its chi
+    # (SURVEY 8d; reference ctmrg.py:81)
+    warmup = args.warmup if args.warmup is not None else (3 if kind == "c4v" else -(-chi // (D * D)))
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the engine has no CPU path")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args.gpus)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    if os.environ.get("CTM_BENCH_ONE_DEVICE"):      # development hook: several ranks on ONE GPU (gloo), to exercise the sharded path
+        local = 0
+    torch.cuda.set_device(local)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(os.environ.get("CTM_BENCH_BACKEND", "nccl"), rank=rank, world_size=world)
+
+    import config as cfg
+    cfg.global_args.device = f"cuda:{local}"
+    cfg.ctm_args.concurrent_units = not args.serial_units
+    cfg.ctm_args.projector_warm_start = not args.cold_start
+    import _native
+    eng = _native.engine()
+    for kv in args.opt:
+        k_, v_ = kv.split("="); eng.set_option(k_, float(v_))
+    dev = torch.device("cuda", local)
+
+    primary_signed = bool(args.signed)
+    res, dom, sites, state, env = run_workload(args, eng, dev, kind, D, chi, dtype, primary_signed, steps, warmup, world, rank, dist)
+    tr = traffic_from_profile(args, world, dom, primary_signed)
+    if tr:
+        res["roofline"]["traffic"] = tr["dominant"]; res["roofline"]["traffic_source"] = tr["source"]
+        for i, dsc in res["roofline"]["other_kernels"].items():
+            dsc["traffic"] = tr["others"].get(i)
+    full = None
+    if kind != "c4v" and not primary_signed and not args.no_full_rank:
+        # second required block: the SAME shape on a full-rank state (the workload real iPEPS produce lies between the two)
+        env_np = None
+        if rank == 0 and not args.no_cpu_baseline and world == 1:
+            env_np = ({k: v.cpu().numpy() for k, v in env.C.items()}, {k: v.cpu().numpy() for k, v in env.T.items()})
+        del state, env
+        import gc; gc.collect(); torch.cuda.empty_cache()
+        full, fdom, fsites, fstate, fenv = run_workload(args, eng, dev, kind, D, chi, dtype, True, steps, warmup, world, rank, dist)
+        ftr = traffic_from_profile(args, world, fdom, True)
+        if ftr:
+            full["roofline"]["traffic"] = ftr["dominant"]; full["roofline"]["traffic_source"] = ftr["source"]
+        del fstate, fenv
+        gc.collect(); torch.cuda.empty_cache()
+    else:
+        env_np = None
+        if kind != "c4v" and rank == 0 and not args.no_cpu_baseline and world == 1:
+            env_np = ({k: v.cpu().numpy() for k, v in env.C.items()}, {k: v.cpu().numpy() for k, v in env.T.items()})
 
     if rank == 0:
-        # instrumented kernel classes (csrc: timing_end kinds).  Class 3 (streaming strip kernel) is HBM-bound: the engine
-        # reports its ALGORITHMIC BYTES (the big operand read once + the block in and out) where the others report flops.
-        CLS = {0: ("gemm_f64_fast_kernel / gemm_f64_kernel<4,4> (128x128 tile)", "mfma", "gemm_f64_fast_kernel"),
-               1: ("gemm_f64_kernel<2,2> (64x64 tile: small, segmented and batched products)", "mfma", "gemm_f64_kernel<2, 2>"),
-               2: ("layer2_reg_kernel<KT> (float64) / layer2_c_kernel<KT> (complex128): fused two-layer enlarged-corner kernel", "mfma", "layer2_"),
-               3: ("gemm_strip_kernel<TM,BNF>: <= 64-row block times an n x n corner, streamed once", "hbm", "gemm_strip_kernel")}
-        # Independent units run on concurrent streams, so launches of the kernel overlap: the time the chip spends on
-        # them is the UNION of their [start, end] intervals (equal to the sum of durations when nothing overlaps).
-        def union_ms(kind):
-            iv = sorted((a, b) for k_, a, b, _ in ivals if int(k_) == kind)
-            tot, cur_a, cur_b = 0.0, None, None
-            for a, b in iv:
-                if cur_b is None or a > cur_b:
-                    if cur_b is not None: tot += cur_b - cur_a
-                    cur_a, cur_b = a, b
-                else:
-                    cur_b = max(cur_b, b)
-            return tot + ((cur_b - cur_a) if cur_b is not None else 0.0)
-        u_ms = [union_ms(i) for i in KK]
-        HBM_PEAK_GBPS = 8000.0
-
-        def rate(work, ms, bound):              # TFLOP/s or GB/s
-            return work / max(ms * 1e-3, 1e-30) / (1e12 if bound == "mfma" else 1e9)
-
-        def describe(i, kms, kfl, kn, ums=None):
-            name, bound, _ = CLS[i]
-            peak = FP64_MFMA_PEAK_TFLOPS if bound == "mfma" else HBM_PEAK_GBPS
-            busy = ums[i] if ums is not None else kms[i]
-            ach = rate(kfl[i], busy, bound) if kn[i] else 0.0
-            d = {"kernel": name, "bound": bound, "achieved": round(ach, 3), "peak": peak, "unit": "TFLOP/s" if bound == "mfma" else "GB/s",
-                 "frac": round(ach / peak, 4), "launches": int(kn[i]), "avg_launch_ms": round(kms[i] / max(kn[i], 1), 5),
-                 "sum_launch_ms": round(kms[i], 3)}
-            if ums is not None:
-                d["busy_ms_union"] = round(ums[i], 3)
-            return d
-        # the dominant kernel = the class the chip spends most time on
-        dom = max((0, 2, 3), key=lambda i: u_ms[i])
-        roof = describe(dom, k_ms, k_fl, k_n, u_ms)
-        roof = {"bound": roof.pop("bound"), **roof, "traffic": None,
-                "per_launch_rate_while_sharing_the_chip": round(rate(k_fl[dom], k_ms[dom], CLS[dom][1]), 3) if k_n[dom] else 0.0,
-                "concurrent_streams": max(1, len(getattr(eng, "workers", []))),
-                "time_share_of_sweep": round(u_ms[dom] * 1e-3 / dt, 4),
-                "algorithmic_work_per_launch": ("2*M*N*K flop of each product" if dom in (0, 1) else
-                                                "2 * p * chi_x * chi_y * (D^2)^2 * 2 D^2 flop per launch (both layers)" if dom == 2 else
-                                                "8 * (K*N + M*K + M*N) bytes: the n x n corner read once, the <=64-row block in and out"),
-                "other_kernels": {str(i): describe(i, k_ms, k_fl, k_n, u_ms) for i in KK if i != dom and k_n[i]}}
-        if serial is not None:
-            s_ms, s_fl, s_n = serial
-            roof["serial_pass"] = {"note": "one extra sweep after the timed region, units issued serially on one stream (no co-scheduling): kernel quality without sharing the chip",
-                                   **{("dominant" if i == dom else str(i)): describe(i, s_ms, s_fl, s_n) for i in KK if s_n[i]}}
-        # HBM traffic of the dominant kernel family from the committed PMC pass of this same command (bench.py cannot attach
-        # counters to itself); null when the profile is for another workload
-        try:
-            import csv
-            prof = json.load(open(os.path.join(REPO, "profiles", "r01_bench_default.json")))
-            if prof["config"]["workload"] == args.config and world == 1 and not args.signed:
-                rows = list(csv.DictReader(open(os.path.join(REPO, "profiles", "r01_bench_default_pmc_hbm_traffic.csv"))))
-
-                def pmc(key):
-                    tb = tn = 0.0
-                    for row in rows:
-                        if key in row["kernel"]:
-                            tb += float(row["hbm_bytes_per_launch(2x_fetch_corrected)"]) * float(row["launches"]); tn += float(row["launches"])
-                    return round(tb / tn) if tn else None
-                roof["traffic"] = pmc(CLS[dom][2])
-                roof["traffic_source"] = "profiles/r01_bench_default_pmc_hbm_traffic.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, average HBM bytes per launch)"
-                for i, dsc in roof["other_kernels"].items():
-                    dsc["traffic"] = pmc(CLS[int(i)][2])
-        except Exception:
-            pass
-        out = {"metric": "ctm_sweeps_per_sec", "value": steps / dt, "unit": "sweeps/s", "n_gpus": world, "steps": steps,
-               "warmup": warmup, "ms_per_step": 1e3 * dt / steps, "higher_is_better": True, "scaling": "strong",
+        out = {"metric": "ctm_sweeps_per_sec", "value": res["value"], "unit": "sweeps/s", "n_gpus": world, "steps": steps,
+               "warmup": warmup, "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": "strong",
                "vs_baseline": None, "dtype": dtype, "data": "synthetic",
                "config": {"workload": args.config, "variant": kind, "D": D, "chi": chi, "n": chi * D * D,
+                          "state": "A ~ U(-1,1) (full rank)" if primary_signed else "A ~ U[0,1) (reference scripts, SURVEY 8d)",
                           "unit_cell": "1x1 C4v" if kind == "c4v" else "2x2 (4 sites, 32 units/sweep)",
                           "parallelism": f"site-sharded x{world}" if world > 1 else "single GPU"},
-               "roofline": roof,
-               "svd": {"decompositions": int(eng.stat("jacobi_calls")),
-                       "avg_jacobi_sweeps": round(eng.stat("total_sweeps") / max(eng.stat("jacobi_calls"), 1), 2),
-                       "power_iter_hits": int(eng.stat("si_hits")), "power_iter_fallbacks_to_full": int(eng.stat("si_fallbacks")),
-                       "avg_half_steps": round(eng.stat("si_total_iters") / max(eng.stat("si_hits") + eng.stat("si_fallbacks"), 1), 2)},
-               "phase_s": {k: round(v, 4) for k, v in eng.timers().items()}}
-        if kind != "c4v":
-            # what the engine could exploit on THIS state (caveat): numerical rank of the truncation and
-            # the number of projector columns above projector_svd_reltol, out of chi
-            nc = env.__dict__.get("_ncol") or {}
-            wr = [w.stat("si_last_rank") for w in getattr(eng, "workers", [])]
-            out["state"] = {"chi": chi, "numerical_rank_of_truncated_operator": int(max(wr + [eng.stat("si_last_rank") - sum(wr)])),
-                            "nonzero_projector_columns": (max(nc.values()) if nc else None),
-                            "corner_cache_hits": int(eng.stat("corner_cache_hits")),
-                            "note": "positive random tensors give a numerically low-rank environment; see --signed for the full-rank extreme"
-                                    if not args.signed else "signed random tensors: full-rank spectrum"}
+               "roofline": res["roofline"], "svd": res["svd"], "phase_s": res["phase_s"], "phase_s_note": res["phase_s_note"]}
+        if "state" in res:
+            out["state"] = res["state"]
+        if full is not None:
+            out["full_rank"] = {"metric": "ctm_sweeps_per_sec", "value": full["value"], "unit": "sweeps/s", "ms_per_step": full["ms_per_step"],
+                                "steps": full["steps"], "warmup": full["warmup"],
+                                "config": {"workload": args.config, "state": "A ~ U(-1,1), A /= max|A| (signed random tensors)", "n": chi * D * D},
+                                "state": full["state"], "roofline": full["roofline"], "svd": full["svd"], "phase_s": full["phase_s"]}
         if not args.no_cpu_baseline and world == 1:
             try:
-                out["cpu_baseline"] = cpu_baseline(kind, D, chi, sites)
+                out["cpu_baseline"] = cpu_baseline(kind, D, chi, sites, env_np)
             except Exception as e:                      # the baseline is reporting only
                 out["cpu_baseline"] = {"error": repr(e)}
             try:
                 out["energy_parity"] = energy_parity(dev, dtype)
+                if full is not None:
+                    out["full_rank"]["energy_parity"] = energy_parity(dev, dtype, signed=True)
             except Exception as e:
                 out["energy_parity"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)

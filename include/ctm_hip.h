@@ -61,7 +61,8 @@ int ctm_get_stat(ctm_ctx* ctx, const char* key, double* value);
 int ctm_timers(ctm_ctx* ctx, double* out8, int reset);             /* corners,halves,svd,proj,absorb,norm,rdm,eig (s) */
 /* GEMM launches timed with HIP events while the option "gemm_timing" is on: quadruples (kind, start_ms, end_ms, flops) on a
  * process-wide clock (kind 0 = 128x128-tile GEMM kernels, 1 = 64x64-tile GEMM kernel, 2 = fused two-layer kernel, 3 = streaming
- * strip kernel, whose fourth value is its ALGORITHMIC BYTES instead of flops: it is HBM-bound).  out may be NULL to query
+ * row-block kernels with <= 32 rows, whose fourth value is the ALGORITHMIC BYTES instead of flops: HBM-bound; 4 = the same kernels
+ * with 33..64 rows: MFMA-bound, flops).  out may be NULL to query
  * *count (launches).  The same classes index the stats "k_ms<c>", "k_flops<c>", "k_calls<c>". */
 int ctm_gemm_intervals(ctm_ctx* ctx, double* out, long long capacity_doubles, long long* count);
 
@@ -160,6 +161,14 @@ int ctm_move_c4v_ws(ctm_ctx* ctx, const double* a, const double* C, const double
 /* rdm2x2: tensors16 = (C,T1,T2,a) for LU(coord), RU(coord+x), RD(coord+x+y), LD(coord+y); out p^8 raw
  * (un-normalised, index order s0 s1 s2 s3 s0' s1' s2' s3'); symmetrisation/normalisation is host-side. */
 int ctm_rdm2x2(ctm_ctx* ctx, const double* const* tensors16, int chi, const int* adims4x5, double* out);
+/* One part of the same contraction: only the lower-half slices cl in [lo0, lo1), cl = (s2 t2) p^2 + (s3 t3) (p^4 in all; s2 is
+ * the site coord+y, s3 the site coord+x+y), are built; out receives the raw block R[(s0 t0 s1 t1), lo0:lo1] (p^4 x (lo1 - lo0),
+ * row-major).  The blocks of all ranges put side by side give R[s0 t0 s1 t1 ; s2 t2 s3 t3], whose permutation
+ * (0,2,4,6,1,3,5,7) is ctm_rdm2x2's output.  Peak workspace
+ * n^2 (2 p^2 + 1 + lo1 - lo0) elements instead of n^2 (p^4 + 2 p^2 + 1): the unit that is sharded over the GPUs of a rank group
+ * (models/j1j2.py:238-240 loops over sites; SURVEY 8e splits a site's RDM over a GPU pair) or looped over on one GPU when the
+ * open halves do not fit (D = 8, chi = 384, complex128). */
+int ctm_rdm2x2_part(ctm_ctx* ctx, const double* const* tensors16, int chi, const int* adims4x5, int lo0, int lo1, double* out);
 /* rdm1x1 / rdm2x1 / rdm1x2 through the open-corner route; tensor lists documented in INTEGRATION.md */
 int ctm_rdm1x1(ctm_ctx* ctx, const double* const* tensors9 /* C1,C2,C3,C4,T1,T2,T3,T4,a */, int chi, const int* adims,
                double* out /* p^2 */);

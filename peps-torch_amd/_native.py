@@ -65,6 +65,7 @@ _SIGS = {
     "ctm_move_c4v_ws": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(TruncCfg),
                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
     "ctm_rdm2x2": [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_int), C.c_void_p],
+    "ctm_rdm2x2_part": [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_void_p],
     "ctm_rdm1x1": [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_int), C.c_void_p],
     "ctm_rdm2x1": [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_int), C.c_void_p],
     "ctm_rdm1x2": [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_int), C.c_void_p],
@@ -503,6 +504,20 @@ class Engine:
         out = self.empty(*([p] * 8))
         self._ck(self.lib.ctm_rdm2x2(self.h, arr, ts[0].shape[0], ad, _ptr(out)), "rdm2x2")
         return out
+
+    def rdm2x2_part(self, tensors16, lo0, lo1):
+        """Raw block R[(s0 t0 s1 t1), lo0:lo1] of the plaquette contraction (lower-half slices lo0..lo1-1 of p^4)."""
+        ts, arr, ad = self._pack16(tensors16)
+        p = ts[3].shape[0]
+        out = self.empty(p ** 4, lo1 - lo0)
+        self._ck(self.lib.ctm_rdm2x2_part(self.h, arr, ts[0].shape[0], ad, int(lo0), int(lo1), _ptr(out)), "rdm2x2_part")
+        return out
+
+    @staticmethod
+    def rdm2x2_from_parts(R, p):
+        """R[s0 t0 s1 t1 ; s2 t2 s3 t3] (p^4 x p^4, the parts side by side; s2 = site coord+y, s3 = coord+x+y)
+        -> rdm[s0 s1 s2 s3 ; t0 t1 t2 t3] (rdm.py:1581-1588)."""
+        return R.reshape([p] * 8).permute(0, 2, 4, 6, 1, 3, 5, 7).contiguous()
 
     def rdm1x1(self, tensors9):
         ts = self._bind(*tensors9)

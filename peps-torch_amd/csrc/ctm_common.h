@@ -94,6 +94,8 @@ struct ctm_ctx {
     long gemm_calls = 0;
     double layer2_flops = 0;
     long layer2_calls = 0;
+    double absorb_bytes = 0;            // algorithmic HBM bytes of the absorb calls (operands read once, results written once)
+    long absorb_calls = 0;
     bool use_layer2 = true;
     bool gemm_fast = true;
     bool einsum_in_relayout = true, z_spectators_first = true;   // layout of the fused two-layer kernel's input (contract.hip)
@@ -102,6 +104,8 @@ struct ctm_ctx {
     bool gemm_log = false;        // debug: print every GEMM shape to stderr
     bool gemm_strip = true;       // streaming kernel for <= 64 rows times a big operand
     int strip_target_wgs = 512;   // K slices x column tiles of the strip kernel: fewer slices = fewer partials (measured 512 <= 1024, 256)
+    int rows_kernel_min_m = 1, rows_kernel_min_m_kc = 1;   // LDS-tiled row-block kernel from this many rows (n-contiguous / k-contiguous big operand)
+    int rows_target_wgs = 768;    // its workgroup count (column tiles x K slices): three per CU
     bool gemm_split_rem = true;   // split a 128 q + r (r <= 64) dimension into a vectorised part and a strip
     int splitk_max_tiles = 256, splitk_target_wgs = 1024;   // split-K of skinny GEMMs: when few output tiles, how many workgroups to aim for
     bool eig64_pingpong = true;
@@ -119,8 +123,9 @@ struct ctm_ctx {
     std::vector<double> intervals;       // (kind, start_ms, end_ms, flops) per timed GEMM launch, process-wide clock
     // per kernel class: 0 = 128-tile GEMMs, 1 = other GEMMs, 2 = fused two-layer kernel (layer2.hip), 3 = streaming strip kernel
     // (k_flops[3] holds ALGORITHMIC BYTES: that kernel is HBM-bound)
-    double k_ms[4] = {0, 0, 0, 0}, k_flops[4] = {0, 0, 0, 0};
-    long k_calls[4] = {0, 0, 0, 0};
+    // 4 = the same row-block products with 33..64 rows: MFMA-bound (16 flop per byte of the big operand), k_flops[4] holds flops
+    double k_ms[5] = {0, 0, 0, 0, 0}, k_flops[5] = {0, 0, 0, 0, 0};
+    long k_calls[5] = {0, 0, 0, 0, 0};
     bool cplx = false;                   // CTM_C128 context: every tensor pointer of the C-ABI is interleaved complex128
     void set_error(const std::string& s) { last_error = s; }
 };
@@ -133,16 +138,24 @@ struct ArenaScope {
     ~ArenaScope() { c->arena.cur = cur; c->arena.top = top; }
 };
 
+// event pair around a launch on ctx->stream while "gemm_timing" is on: begin returns the slot (or -1), end files it under `kind`
+int timing_begin(ctm_ctx* ctx);
+void timing_end(ctm_ctx* ctx, int e0, int kind, double flops);
+constexpr int CTM_KIND_PHASE0 = 16;      // timing kinds >= this are phases: kind - CTM_KIND_PHASE0 indexes ctm_ctx::timers
+
+// Phase time of the engine's stream.  "profile": host wall time with stream syncs on both sides (development).  "gemm_timing":
+// a HIP-event pair on the stream, no synchronisation -- the phase's device time, accumulated when the events are drained.
 struct PhaseTimer {
-    ctm_ctx* c; int id; std::chrono::high_resolution_clock::time_point t0;
+    ctm_ctx* c; int id; int e0 = -1; std::chrono::high_resolution_clock::time_point t0;
     PhaseTimer(ctm_ctx* ctx, int i) : c(ctx), id(i) {
         if (c->profile) { (void)hipStreamSynchronize(c->stream); t0 = std::chrono::high_resolution_clock::now(); }
+        else if (c->gemm_timing) e0 = timing_begin(c);
     }
     ~PhaseTimer() {
         if (c->profile) {
             (void)hipStreamSynchronize(c->stream);
             c->timers[id] += std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - t0).count();
-        }
+        } else if (e0 >= 0) timing_end(c, e0, CTM_KIND_PHASE0 + id, 0.0);
     }
 };
 
@@ -173,10 +186,6 @@ struct GemmDesc {
 int gemm_f64(ctm_ctx* ctx, const GemmDesc& d);
 void gemm_timing_drain(ctm_ctx* ctx);
 void gemm_timing_base(ctm_ctx* ctx);
-// event pair around a launch on ctx->stream while "gemm_timing" is on: begin returns the slot (or -1), end files it under `kind`
-int timing_begin(ctm_ctx* ctx);
-void timing_end(ctm_ctx* ctx, int e0, int kind, double flops);
-
 // ---- elementwise / layout kernels (tensor_ops.hip) -----------------------------------------
 #define CTM_MAXD 8
 int permute_f64(ctm_ctx* ctx, const double* in, double* out, int nd, const long long* dims, const int* perm);

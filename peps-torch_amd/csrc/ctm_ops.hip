@@ -690,6 +690,12 @@ int ctm_absorb_x(ctm_ctx* ctx, int dir, const double* const* t, int chi_in, int 
     ArenaScope scope(ctx);
     IO io(ctx);
     DT r1, r2, r3;
+    {   // algorithmic bytes: four projector blocks, three T tensors, two corners and the site read once, the three results written once
+        const double el = ctx->cplx ? 16.0 : 8.0;
+        ctx->absorb_bytes += el * ((double)X * Y * (2.0 * Dt1 * Dt1 + Dpt2 * Dpt2 + Dp1 * Dp1) + (double)X * X * (Dt1 * Dt1 + Dt * Dt + Dt2 * Dt2 + 2.0)
+                                   + (double)ad[0] * ad[1] * ad[2] * ad[3] * ad[4] + 2.0 * X * Y + (double)Y * Y * D2out);
+        ctx->absorb_calls += 1;
+    }
     {
         PhaseTimer pt(ctx, CTM_T_ABSORB);
         DT tC1, tT1, tT, tT2, tC2, tA, tP2, tPt2, tP1, tPt1;
@@ -771,6 +777,10 @@ int ctm_move_c4v_ws(ctm_ctx* ctx, const double* a, const double* C, const double
 
 // ---- RDMs ------------------------------------------------------------------------------------------
 int ctm_rdm2x2(ctm_ctx* ctx, const double* const* t, int chi, const int* ad4, double* out) {
+    return ctm_rdm2x2_part(ctx, t, chi, ad4, 0, -1, out);
+}
+
+int ctm_rdm2x2_part(ctm_ctx* ctx, const double* const* t, int chi, const int* ad4, int lo0, int lo1, double* out) {
     // rdm.py:1390-1588.  The reference holds the four open corners (n^2 p^2 each) and the two open halves (n^2 p^4 each) at
     // once; here the physical legs are unrolled: the lower half is kept as p^4 slices L[(s2 t2 s3 t3)] (n x n), the upper
     // half is produced one slice U[(s0 t0 s1 t1)] at a time and reduced against all of L immediately, so the peak is
@@ -784,11 +794,17 @@ int ctm_rdm2x2(ctm_ctx* ctx, const double* const* t, int chi, const int* ad4, do
     const long long A = n0[0], ku = n1[0], B = n1[1], kl = n1[3];
     if (n0[1] != ku || n0[3] != A || n0[2] != B || n1[2] != kl) { ctx->set_error("rdm2x2: corner dimensions do not chain"); return CTM_ERR_SHAPE; }
     const long long AB = A * B;
-    const long long Pu = pp[0] * pp[0] * pp[1] * pp[1], Pl = pp[3] * pp[3] * pp[2] * pp[2];
+    const long long Pu = pp[0] * pp[0] * pp[1] * pp[1], Pl_all = pp[3] * pp[3] * pp[2] * pp[2];
     if (AB >= (1LL << 31)) { ctx->set_error("rdm2x2: n^2 exceeds the GEMM K range"); return CTM_ERR_UNSUPPORTED; }
+    // partial evaluation: only the lower-half slices cl in [lo0, lo1) (cl = (s3 t3) * p2^2 + (s2 t2)) are built and the raw block
+    // R[(s0 t0 s1 t1), lo0:lo1] is returned -- the unit of work that is sharded over a group of GPUs or looped over on one
+    // GPU when n^2 p^4 elements do not fit (peak n^2 (2 p^2 + 1 + (lo1 - lo0)) elements)
+    const bool partial = lo1 >= 0;
+    if (partial && (lo0 < 0 || lo1 <= lo0 || lo1 > Pl_all)) { ctx->set_error("rdm2x2_part: bad slice range"); return CTM_ERR_BADARG; }
+    const long long L0 = partial ? lo0 : 0, Pl = partial ? (lo1 - lo0) : Pl_all;
     DT r, R, Lall;
     CTM_TRY(io.out(out, (size_t)(Pu * Pl), &r));
-    CTM_TRY(alloc_dt(ctx, {Pu, Pl}, &R));
+    if (partial) R = r; else CTM_TRY(alloc_dt(ctx, {Pu, Pl}, &R));
     CTM_TRY(alloc_dt(ctx, {Pl, AB}, &Lall));
     auto slice = [&](const DT& c, long long idx, long long rows, long long cols) {     // (s,t) slice of a [p][p][rows][cols] corner
         DT v = c.view({rows, cols});
@@ -811,7 +827,8 @@ int ctm_rdm2x2(ctm_ctx* ctx, const double* const* t, int chi, const int* ad4, do
         for (long long i3 = 0; i3 < pp[3] * pp[3]; ++i3)
             for (long long i2 = 0; i2 < pp[2] * pp[2]; ++i2) {
                 const DT x = slice(c3, i3, A, kl), y = slice(c2, i2, B, kl);
-                const long long cl = i3 * pp[2] * pp[2] + i2;
+                const long long cl = i3 * pp[2] * pp[2] + i2 - L0;
+                if (cl < 0 || cl >= Pl) continue;
                 CTM_TRY(xgemm(ctx, (int)A, (int)B, (int)kl, xm(x, kl, false), xm(y, kl, true), Lall.p + cl * AB,
                               Lall.q ? Lall.q + cl * AB : nullptr, B));
             }
@@ -831,6 +848,7 @@ int ctm_rdm2x2(ctm_ctx* ctx, const double* const* t, int chi, const int* ad4, do
                 CTM_TRY(xgemm(ctx, 1, (int)Pl, (int)AB, u, l, R.p + cu * Pl, R.q ? R.q + cu * Pl : nullptr, Pl));
             }
     }
+    if (partial) return io.finish();
     // R[s0 t0 s1 t1 ; s2 t2 s3 t3] -> rdm[s0 s1 s2 s3 ; t0 t1 t2 t3]                                               (:1581-1588)
     long long dims[8] = {pp[0], pp[0], pp[1], pp[1], pp[3], pp[3], pp[2], pp[2]};
     int perm[8] = {0, 2, 4, 6, 1, 3, 5, 7};

@@ -120,6 +120,9 @@ int ctm_set_option(ctm_ctx* ctx, const char* key, double value) {
     else if (k == "gemm_strip") ctx->gemm_strip = value != 0.0;
     else if (k == "strip_target_wgs") ctx->strip_target_wgs = (int)value;
     else if (k == "gemm_split_rem") ctx->gemm_split_rem = value != 0.0;
+    else if (k == "rows_kernel_min_m") ctx->rows_kernel_min_m = (int)value;
+    else if (k == "rows_kernel_min_m_kc") ctx->rows_kernel_min_m_kc = (int)value;
+    else if (k == "rows_target_wgs") ctx->rows_target_wgs = (int)value;
     else if (k == "splitk_max_tiles") ctx->splitk_max_tiles = (int)value;
     else if (k == "splitk_target_wgs") ctx->splitk_target_wgs = (int)value;
     else if (k == "rank_tol") ctx->rank_tol = value;
@@ -138,7 +141,7 @@ int ctm_set_option(ctm_ctx* ctx, const char* key, double value) {
         gemm_timing_drain(ctx);
         ctx->gemm_timing = value != 0.0;
         if (ctx->gemm_timing) { gemm_timing_base(ctx); ctx->intervals.clear(); }
-        for (int i = 0; i < 4; ++i) { ctx->k_ms[i] = 0; ctx->k_flops[i] = 0; ctx->k_calls[i] = 0; }
+        for (int i = 0; i < 5; ++i) { ctx->k_ms[i] = 0; ctx->k_flops[i] = 0; ctx->k_calls[i] = 0; }
     }
     else { ctx->set_error("unknown option " + k); return CTM_ERR_BADARG; }
     return CTM_OK;
@@ -168,10 +171,12 @@ int ctm_get_stat(ctm_ctx* ctx, const char* key, double* value) {
     else if (k == "layer2_flops") *value = ctx->layer2_flops;
     else if (k == "layer2_calls") *value = (double)ctx->layer2_calls;
     else if (k == "arena_high") *value = (double)ctx->arena.high;
+    else if (k == "absorb_bytes") *value = ctx->absorb_bytes;
+    else if (k == "absorb_calls") *value = (double)ctx->absorb_calls;
     else if (k.rfind("k_", 0) == 0 && k.size() >= 5) {      // k_ms0, k_ms1, k_flops0, k_flops1, k_calls0, k_calls1
         gemm_timing_drain(ctx);
         const int i = k.back() - '0';
-        if (i < 0 || i > 3) { ctx->set_error("unknown stat " + k); return CTM_ERR_BADARG; }
+        if (i < 0 || i > 4) { ctx->set_error("unknown stat " + k); return CTM_ERR_BADARG; }
         if (k.compare(0, 4, "k_ms") == 0) *value = ctx->k_ms[i];
         else if (k.compare(0, 7, "k_flops") == 0) *value = ctx->k_flops[i];
         else if (k.compare(0, 7, "k_calls") == 0) *value = (double)ctx->k_calls[i];
@@ -190,8 +195,9 @@ int ctm_gemm_intervals(ctm_ctx* ctx, double* out, long long capacity, long long*
 }
 
 int ctm_timers(ctm_ctx* ctx, double* out8, int reset) {
+    gemm_timing_drain(ctx);       // event-timed phases are accumulated when their events are read
     for (int i = 0; i < CTM_T_COUNT; ++i) { if (out8) out8[i] = ctx->timers[i]; if (reset) ctx->timers[i] = 0.0; }
-    if (reset) { ctx->gemm_flops = 0; ctx->gemm_calls = 0; ctx->layer2_flops = 0; ctx->layer2_calls = 0; ctx->total_sweeps = 0; ctx->jacobi_calls = 0; ctx->si_hits = 0; ctx->si_fallbacks = 0; ctx->si_total_iters = 0; ctx->si_warm_starts = 0; ctx->lz_hits = 0; ctx->lz_total_steps = 0; ctx->lz_extractions = 0; }
+    if (reset) { ctx->gemm_flops = 0; ctx->gemm_calls = 0; ctx->layer2_flops = 0; ctx->layer2_calls = 0; ctx->total_sweeps = 0; ctx->jacobi_calls = 0; ctx->si_hits = 0; ctx->si_fallbacks = 0; ctx->si_total_iters = 0; ctx->si_warm_starts = 0; ctx->lz_hits = 0; ctx->lz_total_steps = 0; ctx->lz_extractions = 0; ctx->absorb_bytes = 0; ctx->absorb_calls = 0; }
     return CTM_OK;
 }
 

@@ -406,6 +406,113 @@ __global__ __launch_bounds__(256) void gemm_strip_kernel(StripParams p) {
         }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Row-block kernel: the same product (<= 64 k-contiguous rows times a big operand read once, K split into partials) for the
+// MFMA-bound block sizes (33..64 rows: 16 flop per byte of the big operand).  There the LDS-free strip kernel is limited by
+// what it re-reads through L1/L2: each of its waves loads the whole A block for its 32 columns (A traffic = 2x the B stream)
+// and holds one K block in flight.  Here the workgroup shares one A tile: tile = all rows x 128 columns x 16 k, A and B
+// staged global -> VGPR -> LDS with 16-byte loads into a k-major image (one ds_read_b64 per MFMA operand), double buffered,
+// one barrier per K tile; wave w owns the rows x 32 columns block w.  50 KB of LDS and ~120 VGPRs: three workgroups per CU
+// keep three K tiles of the stream in flight per CU.
+// ---------------------------------------------------------------------------------------------------------
+template <int TMW, bool BNF>
+__global__ __launch_bounds__(256, 3) void gemm_rows_kernel(StripParams p) {
+    constexpr int BM = 16 * TMW, BN = 128, LDA = BM + PAD, LDB = BN + PAD;
+    constexpr int NA = (BM * BK / 2 + 255) / 256;                 // d2 loads of A per thread per K tile (1 or 2)
+    __shared__ __attribute__((aligned(16))) double smem[2 * BK * LDA + 2 * BK * LDB];
+    double* As = smem;
+    double* Bs = smem + 2 * BK * LDA;
+    const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
+    const int n0 = blockIdx.x * BN;
+    const long long kbeg = (long long)blockIdx.y * p.klen;
+    const int nk = (int)((std::min<long long>(p.K, kbeg + p.klen) - kbeg) / BK);
+    if (nk <= 0) return;
+
+    const double* ap[NA]; int a_lds[NA]; bool a_on[NA];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int u = tid + 256 * i, row = u >> 3, kp = u & 7;
+        a_on[i] = row < BM;
+        ap[i] = p.A + (long long)std::min(row, p.M - 1) * p.sam + kbeg + 2 * kp;
+        a_lds[i] = (2 * kp) * LDA + row;
+    }
+    const double* bp[4]; int b_lds[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int u = tid + 256 * i;
+        if (BNF) { const int kk = u >> 6, np = u & 63; bp[i] = p.B + (kbeg + kk) * p.ldb + n0 + 2 * np; b_lds[i] = kk * LDB + 2 * np; }
+        else     { const int col = u >> 3, kp = u & 7; bp[i] = p.B + (long long)(n0 + col) * p.ldb + kbeg + 2 * kp; b_lds[i] = (2 * kp) * LDB + col; }
+    }
+    const long long b_step = BNF ? (long long)BK * p.ldb : BK;
+
+    d4 acc[TMW][2];
+#pragma unroll
+    for (int i = 0; i < TMW; ++i) { acc[i][0] = (d4){0., 0., 0., 0.}; acc[i][1] = (d4){0., 0., 0., 0.}; }
+    d2 ra[NA], rb[4];
+    auto load_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) { if (a_on[i]) ra[i] = *(const d2*)ap[i]; ap[i] += BK; }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { rb[i] = __builtin_nontemporal_load((const d2*)bp[i]); bp[i] += b_step; }
+    };
+    auto store_tile = [&](int buf) {
+        double* as = As + buf * BK * LDA;
+        double* bs = Bs + buf * BK * LDB;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) if (a_on[i]) { as[a_lds[i]] = ra[i][0]; as[a_lds[i] + LDA] = ra[i][1]; }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (BNF) *(d2*)(bs + b_lds[i]) = rb[i];
+            else { bs[b_lds[i]] = rb[i][0]; bs[b_lds[i] + LDB] = rb[i][1]; }
+        }
+    };
+    load_tile();
+    store_tile(0);
+    __syncthreads();
+    const int lr = lane & 15, lk = lane >> 4;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) load_tile();
+        const double* as = As + buf * BK * LDA + lr;
+        const double* bs = Bs + buf * BK * LDB + wn * 32 + lr;
+#pragma unroll
+        for (int k4 = 0; k4 < BK / 4; ++k4) {
+            double af[TMW], bf[2];
+            const int kr = k4 * 4 + lk;
+#pragma unroll
+            for (int i = 0; i < TMW; ++i) af[i] = as[kr * LDA + i * 16];
+            bf[0] = bs[kr * LDB]; bf[1] = bs[kr * LDB + 16];
+#pragma unroll
+            for (int i = 0; i < TMW; ++i) {
+                acc[i][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[0], acc[i][0], 0, 0, 0);
+                acc[i][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[1], acc[i][1], 0, 0, 0);
+            }
+        }
+        if (kt + 1 < nk) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+    double* P = p.P + (long long)blockIdx.y * p.M * p.N;
+#pragma unroll
+    for (int i = 0; i < TMW; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = i * 16 + lk + 4 * r;
+            if (m >= p.M) continue;
+            double* row = P + (long long)m * p.N + n0 + wn * 32;
+            row[lr] = acc[i][0][r]; row[16 + lr] = acc[i][1][r];
+        }
+}
+
+template <bool BNF>
+void launch_rows(int tm, dim3 grid, hipStream_t st, const StripParams& sp) {
+    switch (tm) {
+        case 1: hipLaunchKernelGGL((gemm_rows_kernel<1, BNF>), grid, dim3(256), 0, st, sp); break;
+        case 2: hipLaunchKernelGGL((gemm_rows_kernel<2, BNF>), grid, dim3(256), 0, st, sp); break;
+        case 3: hipLaunchKernelGGL((gemm_rows_kernel<3, BNF>), grid, dim3(256), 0, st, sp); break;
+        default: hipLaunchKernelGGL((gemm_rows_kernel<4, BNF>), grid, dim3(256), 0, st, sp); break;
+    }
+}
+
 template <bool BNF>
 void launch_strip(int tm, dim3 grid, hipStream_t st, const StripParams& sp) {
     switch (tm) {
@@ -474,7 +581,7 @@ int gemm_f64(ctm_ctx* ctx, const GemmDesc& d) {
     // 128 (vectorised kernel) and an r-row strip (HBM-streaming split-K path); same for a remainder in N.
     if (ctx->gemm_split_rem && d.batch == 1 && d.K >= 1024 && fast_operands(ctx, d)) {
         const int rm = d.M % 128, rn = d.N % 128;
-        if (d.M > 128 && rm > 0 && rm <= 64 && rn == 0 && (long long)d.N * d.K >= (1ll << 22)) {
+        if (d.M > 128 && rm > 0 && rm <= 64 && (rn == 0 || (d.N > 128 && rn <= 64)) && (long long)d.N * d.K >= (1ll << 22)) {   // (an N remainder is split off by the recursion)
             GemmDesc a = d, b = d;
             a.M = d.M - rm; a.splitA = a.splitC = a.M;
             b.M = rm; b.A = d.A + (long long)a.M * d.sam; b.C = d.C + (long long)a.M * d.ldc; b.splitA = b.splitC = rm;
@@ -496,8 +603,11 @@ int gemm_f64(ctm_ctx* ctx, const GemmDesc& d) {
         (((uintptr_t)d.A | (uintptr_t)d.B) & 15) == 0 && d.sam % 2 == 0 && (d.sbn == 1 ? d.sbk : d.sbn) % 2 == 0) {
         const bool bnf = d.sbn == 1;
         const int gx = (d.N / 32 + 3) / 4;
+        // MFMA-bound block sizes go to the LDS-tiled row-block kernel (same partial-sum interface, 128-column workgroups)
+        const bool rows_kernel = d.M >= (bnf ? ctx->rows_kernel_min_m : ctx->rows_kernel_min_m_kc) && d.N % 128 == 0;
         // big operands (>= 1 GB): fewer K slices, fewer partials; smaller ones need the extra workgroups to fill the chip
-        const int target = ((long long)d.N * d.K >= (1ll << 27)) ? ctx->strip_target_wgs : 2 * ctx->strip_target_wgs;
+        int target = ((long long)d.N * d.K >= (1ll << 27)) ? ctx->strip_target_wgs : 2 * ctx->strip_target_wgs;
+        if (rows_kernel) target = ctx->rows_target_wgs;
         int ks = std::max(1, std::min(std::min((target + gx - 1) / gx, d.K / 256), 64));
         int klen = (((d.K + ks - 1) / ks) + 15) / 16 * 16;
         ks = (d.K + klen - 1) / klen;
@@ -506,7 +616,11 @@ int gemm_f64(ctm_ctx* ctx, const GemmDesc& d) {
         StripParams sp;
         sp.M = d.M; sp.N = d.N; sp.K = d.K; sp.A = d.A; sp.sam = d.sam; sp.B = d.B; sp.ldb = bnf ? d.sbk : d.sbn; sp.P = part; sp.klen = klen;
         int e0 = timing_begin(ctx);
-        if (bnf) launch_strip<true>((d.M + 15) / 16, dim3(gx, ks), ctx->stream, sp);
+        if (rows_kernel) {
+            if (bnf) launch_rows<true>((d.M + 15) / 16, dim3(d.N / 128, ks), ctx->stream, sp);
+            else launch_rows<false>((d.M + 15) / 16, dim3(d.N / 128, ks), ctx->stream, sp);
+        }
+        else if (bnf) launch_strip<true>((d.M + 15) / 16, dim3(gx, ks), ctx->stream, sp);
         else launch_strip<false>((d.M + 15) / 16, dim3(gx, ks), ctx->stream, sp);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) { ctx->set_error(std::string("strip gemm launch: ") + hipGetErrorString(e)); return CTM_ERR_HIP; }
@@ -514,7 +628,9 @@ int gemm_f64(ctm_ctx* ctx, const GemmDesc& d) {
         CTM_LAUNCH(ctx, splitk_reduce_kernel, dim3((int)std::min<long long>((tot + 255) / 256, 2048)), dim3(256), 0,
                            (const double*)part, ks, tot, d.C, d.M, d.N, d.ldc, d.alpha, d.beta, d.colscale, ctx->splitk_reduce_vec);
         const double fl = 2.0 * d.M * d.N * (double)d.K;
-        timing_end(ctx, e0, 3, 8.0 * ((double)d.K * d.N + (double)d.M * d.K + (double)d.M * d.N));   // class 3 reports algorithmic BYTES
+        // class 3 (<= 32 rows: HBM-bound) reports algorithmic BYTES, class 4 (33..64 rows: MFMA-bound) flops
+        if (d.M <= 32) timing_end(ctx, e0, 3, 8.0 * ((double)d.K * d.N + (double)d.M * d.K + (double)d.M * d.N));
+        else timing_end(ctx, e0, 4, fl);
         ctx->gemm_flops += fl;
         ctx->gemm_calls += 1;
         return CTM_OK;
@@ -671,6 +787,7 @@ void gemm_timing_drain(ctm_ctx* ctx) {
     for (auto& pe : ctx->ev_pending) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, ctx->ev_pool[pe.e0], ctx->ev_pool[pe.e1]) == hipSuccess) {
+            if (pe.kind >= CTM_KIND_PHASE0) { ctx->timers[pe.kind - CTM_KIND_PHASE0] += 1e-3 * ms; continue; }
             ctx->k_ms[pe.kind] += ms; ctx->k_flops[pe.kind] += pe.flops; ctx->k_calls[pe.kind] += 1;
             float t0 = 0.f;
             if (g_base_event && hipEventElapsedTime(&t0, g_base_event, ctx->ev_pool[pe.e0]) == hipSuccess && ctx->intervals.size() < (1u << 22)) {

@@ -1394,40 +1394,36 @@ int svd_iter_c(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* Ut, doub
 // ---------------------------------------------------------------------------------------------
 // Cholesky factor of a 64 x 64 Gram matrix and the inverse of its lower factor, one workgroup, everything in LDS:
 // G = L L^T, out = L^-1 (lower triangular, row-major); status[0] = smallest pivot met (<= 0: not positive definite).
-__global__ __launch_bounds__(256) void chol64_inv_kernel(const double* G, double* Linv, double* status) {
+__global__ __launch_bounds__(64) void chol64_inv_kernel(const double* G, double* Linv, double* status) {
+    // ONE wave, thread i owns row i of L (kept in LDS, row stride 65: a column access by the wave is conflict free, a pivot-row
+    // access is a broadcast).  Left-looking factorisation: every thread recomputes the pivot itself, so a column costs one
+    // barrier; then L X = I by forward substitution, thread c owning column c of X.
     constexpr int M = 64;
-    __shared__ double A[M][M + 1];
+    __shared__ double L[M][M + 1];
     __shared__ double X[M][M + 1];
-    __shared__ double piv_min;
-    const int tid = threadIdx.x;
-    for (int q = tid; q < M * M; q += 256) { A[q >> 6][q & 63] = G[q]; X[q >> 6][q & 63] = ((q >> 6) == (q & 63)) ? 1.0 : 0.0; }
-    if (tid == 0) piv_min = 1e300;
+    const int i = threadIdx.x;
+    for (int c = 0; c < M; ++c) L[i][c] = G[c * M + i];          // G is symmetric: column i read as row i, coalesced
     __syncthreads();
+    double pmin = 1e300;
     for (int j = 0; j < M; ++j) {
-        const double d = A[j][j];
-        if (tid == 0) piv_min = fmin(piv_min, d);
-        const double l = sqrt(fmax(d, 1e-300));
-        __syncthreads();
-        if (tid < M) { if (tid == j) A[j][j] = l; else if (tid > j) A[tid][j] = A[tid][j] / l; }
-        __syncthreads();
-        for (int q = tid; q < M * M; q += 256) {            // trailing update (lower triangle incl. diagonal)
-            const int i = q >> 6, c = q & 63;
-            if (c > j && i >= c) A[i][c] -= A[i][j] * A[c][j];
-        }
+        double dot = 0.0, pd = 0.0;
+        for (int t = 0; t < j; ++t) { const double ljt = L[j][t]; dot += L[i][t] * ljt; pd += ljt * ljt; }
+        const double p = L[j][j] - pd;
+        pmin = fmin(pmin, p);
+        const double l = sqrt(fmax(p, 1e-300));
+        const double v = (i == j) ? l : (L[i][j] - dot) / l;
+        __syncthreads();                                          // everybody has read the old L[j][j]
+        if (i >= j) L[i][j] = v;
         __syncthreads();
     }
-    // forward substitution L X = I, one column of X per thread (columns are independent)
-    if (tid < M) {
-        const int c = tid;
-        for (int i = c; i < M; ++i) {
-            double acc = (i == c) ? 1.0 : 0.0;
-            for (int t = c; t < i; ++t) acc -= A[i][t] * X[t][c];
-            X[i][c] = acc / A[i][i];
-        }
+    const int c = i;
+    for (int r = 0; r < M; ++r) {
+        double acc = (r == c) ? 1.0 : 0.0;
+        for (int t = c; t < r; ++t) acc -= L[r][t] * X[t][c];
+        X[r][c] = (r >= c) ? acc / L[r][r] : 0.0;
     }
-    __syncthreads();
-    for (int q = tid; q < M * M; q += 256) { const int i = q >> 6, c = q & 63; Linv[q] = (c <= i) ? X[i][c] : 0.0; }
-    if (tid == 0) status[0] = piv_min;
+    for (int r = 0; r < M; ++r) Linv[r * M + c] = X[r][c];
+    if (i == 0) status[0] = pmin;
 }
 
 // rows of W (64 x n) -> orthonormal rows spanning the same space: unit-norm scaling + two Cholesky-QR passes
@@ -1451,7 +1447,7 @@ int orthonormalise_block(ctm_ctx* ctx, double* W, int rows, int n, double* norms
         for (int pass = 0; pass < 2 && ok; ++pass) {
             GemmDesc g; g.M = 64; g.N = 64; g.K = n; g.A = W; g.sam = n; g.sak = 1; g.B = W; g.sbk = 1; g.sbn = n; g.C = G; g.ldc = 64;
             CTM_TRY(gemm_f64(ctx, g));
-            CTM_LAUNCH(ctx, chol64_inv_kernel, dim3(1), dim3(256), 0, (const double*)G, Li, status);
+            CTM_LAUNCH(ctx, chol64_inv_kernel, dim3(1), dim3(64), 0, (const double*)G, Li, status);
             CTM_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_scratch + 16, status, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
             CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
             if (!(ctx->h_scratch[16] > (pass == 0 ? 1e-10 : 0.5))) { ok = false; break; }      // unit rows: pivots in (0, 1]

@@ -65,7 +65,7 @@ def rdm2x2(coord, state, env, open_sites=[0, 1, 2, 3], unroll=[], checkpoint_unr
             cache = env.__dict__.get("_corner_cache")
             if cache and need + sum(e[2] for e in cache.values()) * 8 > 0.7 * total:
                 env.__dict__.pop("_corner_cache", None)
-    raw = eng.rdm2x2(t)
+    raw = _rdm2x2_raw(eng, t, env)
     if open_sites != [0, 1, 2, 3]:
         # fewer open sites = partial trace of the full plaquette RDM over the closed ones (rdm.py:1306-1360 contracts
         # their physical legs inside the corners; same numbers, the native kernel always opens all four)
@@ -76,6 +76,46 @@ def rdm2x2(coord, state, env, open_sites=[0, 1, 2, 3], unroll=[], checkpoint_unr
         keep = [ket[i] for i in open_sites] + [bra[i] for i in open_sites]
         raw = torch.einsum("".join(ket + bra) + "->" + "".join(keep), raw).contiguous()
     return _sym_pos_def_rdm(raw, sym_pos_def=sym_pos_def, verbosity=verbosity, who="rdm2x2")
+
+
+def _rdm2x2_raw(eng, t, env, group=None):
+    """Raw plaquette RDM.  The contraction is a sum over p^4 independent lower-half slices (ctm_rdm2x2_part): they are
+      * looped over in chunks on one GPU when the open halves (n^2 (p^4 + 2 p^2 + 1) elements) do not fit in free HBM
+        (D = 8, chi = 384, complex128: 241 GB at once, 126 GB in chunks of four slices), and
+      * shared among the ranks of `group` (parallel.site_group: the GPUs assigned to this site when there are more ranks than
+        sites) with one all-reduce of the p^8 numbers."""
+    import parallel
+    a = t[3]
+    p = a.shape[0]
+    members = group if group is not None else [parallel.world()[0]]
+    me = members.index(parallel.world()[0])
+    if not hasattr(eng, "rdm2x2_part"):
+        return eng.rdm2x2(t)
+    n = env.chi * a.shape[1] ** 2
+    el = a.element_size()
+    P4 = p ** 4
+    chunk = P4
+    if a.is_cuda:
+        free, _ = torch.cuda.mem_get_info(a.device)
+        arena = sum(getattr(e, "stat", lambda k: 0)("arena_high") for e in [eng]) if hasattr(eng, "stat") else 0
+        budget = 0.85 * (free + arena)                          # the engine's own arena is reused
+        while chunk > 1 and 1.15 * n * n * (2 * p * p + 1 + chunk) * el > budget:
+            chunk //= 2
+    nparts = -(-P4 // chunk)
+    if nparts == 1 and len(members) == 1:
+        return eng.rdm2x2(t)
+    if len(members) > 1:                                       # at least one part per member
+        while nparts < len(members) and chunk > 1:
+            chunk //= 2; nparts = -(-P4 // chunk)
+    R = torch.zeros(P4, P4, dtype=a.dtype, device=a.device)
+    for i in range(nparts):
+        if i % len(members) != me:
+            continue
+        lo0, lo1 = i * chunk, min(P4, (i + 1) * chunk)
+        R[:, lo0:lo1] = eng.rdm2x2_part(t, lo0, lo1)
+    if len(members) > 1:
+        R = parallel.allreduce_sum_group(R, members)
+    return eng.rdm2x2_from_parts(R, p)
 
 
 rdm2x2_legacy = lambda coord, state, env, sym_pos_def=False, verbosity=0: rdm2x2(coord, state, env, sym_pos_def=sym_pos_def)

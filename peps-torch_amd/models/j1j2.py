@@ -93,6 +93,9 @@ class J1J2():
         RDMs are independent: with torch.distributed each rank evaluates its sites and the partial sums
         are all-reduced."""
         coords = list(state.sites.keys())
+        groups = parallel.site_groups(len(coords))
+        if any(len(g) > 1 for g in groups):
+            return self._energy_per_site_grouped(state, env, coords, groups)
         mine = parallel.my_units(coords)
         # the plaquette RDMs of my sites are independent: overlap them on streams when the open halves are small enough
         pool = None
@@ -111,6 +114,31 @@ class J1J2():
             e += float(_cast_to_real(torch.einsum('ijklabcd,ijklabcd', r, self.get_hp(coord).to(r.dtype))))
             if abs(self.j3) > 0:      # the reference evaluates this term at (0,0) for every site of the cell (models/j1j2.py:243-244)
                 e += float(_cast_to_real(self.j3 * eval_nnnn_per_site((0, 0), state, env, self.obs_ops)))
+        e = parallel.allreduce_sum_scalar(e, state.device)
+        return torch.as_tensor(e / len(coords), dtype=torch.float64)
+
+    def _energy_per_site_grouped(self, state, env, coords, groups):
+        """More ranks than sites (e.g. 8 GPUs on a 4-site cell): the ranks {r : r mod Nsites == i} share the plaquette RDM of
+        site i (p^4 lower-half slices split among them, one all-reduce of p^8 numbers inside the group); the group's first rank
+        adds tr(rho h_p) to the energy, which is then summed over all ranks."""
+        from backend import get_engine
+        from ctm.generic.ctm_components import _corner_t, LU, RU, RD, LD
+        parallel.prepare_groups(groups)
+        rank = parallel.world()[0]
+        eng = get_engine()
+        e = 0.
+        for coord, members in zip(coords, groups):
+            if rank not in members:
+                continue
+            x, y = coord
+            t = _corner_t(LU, (x, y), state, env) + _corner_t(RU, (x + 1, y), state, env) \
+                + _corner_t(RD, (x + 1, y + 1), state, env) + _corner_t(LD, (x, y + 1), state, env)
+            raw = rdm._rdm2x2_raw(eng, t, env, group=members)
+            if rank == members[0]:
+                r = rdm._sym_pos_def_rdm(raw, who="rdm2x2").cpu()
+                e += float(_cast_to_real(torch.einsum('ijklabcd,ijklabcd', r, self.get_hp(coord).to(r.dtype))))
+                if abs(self.j3) > 0:
+                    e += float(_cast_to_real(self.j3 * eval_nnnn_per_site((0, 0), state, env, self.obs_ops)))
         e = parallel.allreduce_sum_scalar(e, state.device)
         return torch.as_tensor(e / len(coords), dtype=torch.float64)
 

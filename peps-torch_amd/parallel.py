@@ -38,6 +38,44 @@ def my_units(items):
     return [x for i, x in enumerate(items) if owner_of(i, n) == rank]
 
 
+def site_groups(nitems):
+    """Ranks that work on each of `nitems` independent items (per-site RDMs).  Up to one rank per item: round-robin owners
+    (one-member groups).  MORE ranks than items (8 GPUs, 4-site cell: SURVEY 8e): item i gets the ranks {r : r mod nitems == i},
+    which share its contraction (rdm._rdm2x2_raw splits the p^4 lower-half slices among them)."""
+    _, n = world()
+    if n <= nitems:
+        return [[owner_of(i, n)] for i in range(nitems)]
+    return [[r for r in range(n) if r % nitems == i] for i in range(nitems)]
+
+
+_group_cache = {}
+
+
+def _process_group(members):
+    """torch.distributed group of `members` (created collectively: every rank must ask for the same groups in the same order)."""
+    key = tuple(members)
+    if key not in _group_cache:
+        _group_cache[key] = dist.new_group(ranks=list(members))
+    return _group_cache[key]
+
+
+def prepare_groups(groups):
+    """Collective creation of the process groups of `groups` (all ranks call this with the same list)."""
+    if is_distributed():
+        for g in groups:
+            if len(g) > 1:
+                _process_group(g)
+
+
+def allreduce_sum_group(t, members):
+    """Sum of `t` over the ranks in `members` (complex128 travels as its (re,im) float64 view)."""
+    if not is_distributed() or len(members) < 2:
+        return t
+    buf = torch.view_as_real(t.contiguous()) if t.is_complex() else t.contiguous()
+    dist.all_reduce(buf, group=_process_group(members))
+    return torch.view_as_complex(buf) if t.is_complex() else buf
+
+
 def owners_shifted(coords, vertex_to_site, shift):
     """Owner rank of every unit when unit `c` is given to the round-robin owner of the site at c + shift.  Used by the
     projector phase: with the per-direction shifts of ctmrg._OWNER_SHIFT the two enlarged corners a window can reuse from the

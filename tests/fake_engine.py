@@ -101,3 +101,19 @@ class FakeEngine:
         lo = np.einsum('akst,bkuv->abstuv', cs[3], cs[2], optimize=True)
         r = np.einsum('abstuv,abwxyz->stuvwxyz', up, lo, optimize=True)
         return _t(r.transpose(0, 2, 4, 6, 1, 3, 5, 7))
+
+    def rdm2x2_part(self, tensors16, lo0, lo1):
+        """R[(s0 t0 s1 t1), lo0:lo1] of the same contraction (the native ctm_rdm2x2_part)."""
+        cs = []
+        for i, cid in enumerate((O.LU, O.RU, O.RD, O.LD)):
+            cs.append(O.c2x2_sl(cid, *[_n(t) for t in tensors16[4 * i:4 * i + 4]], open_=True))
+        up = np.einsum('akst,kbuv->abstuv', cs[0], cs[1], optimize=True)
+        lo = np.einsum('akst,bkuv->abstuv', cs[3], cs[2], optimize=True)
+        p = up.shape[2]
+        lo = lo.reshape(lo.shape[0], lo.shape[1], p ** 4)[:, :, lo0:lo1]
+        return _t(np.einsum('abstuv,abl->stuvl', up, lo, optimize=True).reshape(p ** 4, lo1 - lo0))
+
+    @staticmethod
+    def rdm2x2_from_parts(R, p):
+        return R.reshape([p] * 8).permute(0, 2, 4, 6, 1, 3, 5, 7).contiguous()
+

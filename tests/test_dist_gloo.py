@@ -46,8 +46,10 @@ def _worker(rank, world, port, out_dir, name):
 
 # world 2: two sites per rank (one stacked all-gather per phase); world 3: uneven ownership (per-site broadcasts);
 # world 5: more ranks than sites (rank 4 owns nothing -- the 8-GPU case of a 4-site cell)
+# world 8: two ranks per site -- in the moves ranks 4-7 own nothing, the plaquette RDM of each site is split over its rank pair
+# (lower-half slices, one all-reduce inside the pair; world 5: only site 0 has a pair)
 @pytest.mark.parametrize("name,world", [("generic_D2_chi8_f64", 2), ("generic_D2_chi8_c128", 2), ("generic_D2_chi8_f64", 3),
-                                        ("generic_D2_chi8_c128", 5)])
+                                        ("generic_D2_chi8_c128", 5), ("generic_D2_chi8_f64", 8)])
 def test_sharded_move_equals_single_process(tmp_path, name, world):
     import socket
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()

@@ -92,14 +92,25 @@ def _check_unit(eng, st, env, chi, coord=(0, 0), direction=UP, torch_svdvals=Fal
     return n
 
 
-@pytest.mark.parametrize("D,chi,signed", [(6, 128, False), (6, 128, True), (8, 256, False)], ids=["D6chi128", "D6chi128-signed", "D8chi256"])
+@pytest.mark.parametrize("D,chi,signed", [(6, 128, False), (6, 128, True), (8, 256, False), (8, 256, True)],
+                         ids=["D6chi128", "D6chi128-signed", "D8chi256", "D8chi256-signed"])
 def test_generic_unit_at_full_size(eng, D, chi, signed):
     from ctm.generic.env import ENV, init_env
     st = _state(D, 3, signed=signed)
     env = ENV(chi, st); init_env(st, env)
-    _sweep(st, env, 2 if D == 6 else 1)
+    lz0 = eng.stat("lz_hits")
+    _sweep(st, env, 2 if (D == 6 or signed) else 1)
+    if signed:
+        # the full-rank regime: the block Krylov solver must have produced the truncations of the sweeps above (n = chi D^2:
+        # 4608 and 16384) -- and the unit checked below goes through it again, on the implicit and on the explicit operator
+        assert eng.stat("lz_hits") > lz0, "signed state did not reach the block Krylov solver"
+        assert int(min((s_ > 1e-8 * s_[0]).sum() for s_ in env.get_spectra().values())) >= chi // 2    # far from the rank-<= 30 of a positive state
+    lz1 = eng.stat("lz_hits")
     n = _check_unit(eng, st, env, chi, torch_svdvals=(D == 6))
+    if signed:
+        assert eng.stat("lz_hits") >= lz1 + 2
     assert n == chi * D * D
+    env.__dict__.pop("_corner_cache", None)
     eng.trim()
 
 
@@ -171,3 +182,103 @@ def test_c4v_move_at_full_size(eng):
     assert float((Dv - w)[kept].abs().max()) < 1e-12 * float(w.abs().max())
     assert float((nT - nT.permute(1, 0, 2)).abs().max()) < 1e-13
     assert abs(float(nT.abs().max()) - 1.0) < 1e-14
+
+
+def _energy_and_rdms(st, env):
+    from ctm.generic import rdm
+    from models import j1j2
+    model = j1j2.J1J2(j1=1.0, j2=0.5)
+    rdms = {c: rdm.rdm2x2(c, st, env) for c in st.sites}
+    return float(model.energy_per_site(st, env)), rdms
+
+
+def test_rdm2x2_and_energy_at_D6_chi128(eng):
+    """rdm2x2 + J1-J2 energy at BASELINE configs[2] size (n = 4608), through invariants: Hermitian, unit trace, positive up to
+    rounding, identical on the four sites of a tiled 1x1 state, unchanged under a -> 2a."""
+    from ctm.generic.env import ENV, init_env
+    from ipeps.ipeps import IPEPS
+    D, chi = 6, 128
+    st = _state(D, 21, tiled=True)
+    env = ENV(chi, st); init_env(st, env)
+    _sweep(st, env, 2)
+    e, rdms = _energy_and_rdms(st, env)
+    r0 = rdms[(0, 0)].reshape(16, 16)
+    for c, r in rdms.items():
+        r = r.reshape(16, 16)
+        assert abs(float(torch.trace(r)) - 1.0) < 1e-13
+        assert float((r - r.T).abs().max()) < 1e-13
+        assert float(torch.linalg.eigvalsh(r.cpu()).min()) > -1e-12
+        assert float((r - r0).abs().max()) < 1e-10, c                 # tiled state: every plaquette is the same
+    st2 = IPEPS({k: 2.0 * v for k, v in st.sites.items()})
+    env2 = ENV(chi, st2); init_env(st2, env2)
+    _sweep(st2, env2, 2)
+    e2, rdms2 = _energy_and_rdms(st2, env2)
+    assert abs(e - e2) < 1e-11 * abs(e)
+    assert float((rdms2[(0, 0)] - rdms[(0, 0)]).abs().max()) < 1e-11
+    assert -2.0 < e < 2.0
+    env.__dict__.pop("_corner_cache", None); env2.__dict__.pop("_corner_cache", None)
+    eng.trim()
+
+
+def test_rdm2x2_and_energy_at_D4_chi64_against_the_oracle(eng):
+    """n = 1024: the native rdm2x2 / energy of every site against the numpy oracle evaluated on the SAME (downloaded) environment
+    after two native sweeps of a signed 4-site state."""
+    from ctm.generic.env import ENV, init_env
+    from oracle import ctm_oracle as O, j1j2_oracle as OJ
+    D, chi = 4, 64
+    st = _state(D, 22, signed=True)
+    env = ENV(chi, st); init_env(st, env)
+    _sweep(st, env, 2)
+    e, rdms = _energy_and_rdms(st, env)
+    ost = O.State({k: v.cpu().numpy() for k, v in st.sites.items()})
+    oe = O.Env(chi)
+    oe.C = {k: v.cpu().numpy() for k, v in env.C.items()}
+    oe.T = {k: v.cpu().numpy() for k, v in env.T.items()}
+    ordm = {c: O.rdm2x2(c, ost, oe) for c in ost.sites}
+    for c in ordm:
+        assert np.abs(rdms[c].cpu().numpy() - ordm[c]).max() < 1e-11, c
+    eo = OJ.energy_per_site([ordm[c] for c in ost.sites], 1.0, 0.5)
+    assert abs(e - eo) < 1e-10 * abs(eo)
+    eng.trim()
+
+
+def test_whole_move_of_the_complex_config_at_full_size(eng):
+    """BASELINE configs[4] (generic D = 8, chi = 384, complex128, n = 24576): ONE whole directional move -- fused projectors of the
+    four sites AND the four complex absorbs -- from the CTMRG init.  Checks: every new tensor has max-abs 1, the move is invariant
+    under a -> 2a, and the absorb on the non-zero projector prefix equals the absorb with all chi columns."""
+    import config as cfg
+    from ctm.generic.env import ENV, init_env
+    from ctm.generic import ctmrg
+    from ipeps.ipeps import IPEPS
+    free, _ = torch.cuda.mem_get_info()
+    if free < 200e9:
+        pytest.skip("needs ~190 GB of free HBM")
+    chi, D = 384, 8
+    st = _state(D, 4, cplx=True)
+
+    def one_move(state, **kw):
+        env = ENV(chi, state); init_env(state, env)
+        old = {k: getattr(cfg.ctm_args, k, None) for k in kw}
+        for k, v in kw.items(): setattr(cfg.ctm_args, k, v)
+        try:
+            ctmrg.ctm_MOVE(UP, state, env)
+        finally:
+            for k, v in old.items(): setattr(cfg.ctm_args, k, v)
+        out = {("C", k): v for k, v in env.C.items() if k[1] in ((1, -1), (-1, -1))}
+        out.update({("T", k): v for k, v in env.T.items() if k[1] == UP})
+        env.__dict__.pop("_corner_cache", None); env.__dict__.pop("_warm", None)
+        return out
+    a = one_move(st)
+    assert len(a) == 12
+    for k, t in a.items():
+        assert t.dtype == torch.complex128 and abs(float(t.abs().max()) - 1.0) < 1e-13, k
+        assert t.shape == ((chi, chi) if k[0] == "C" else (chi, D * D, chi)), k
+    eng.trim(); torch.cuda.empty_cache()
+    b = one_move(st, absorb_skip_zero_columns=False)
+    for k in a:
+        assert torch.equal(a[k], b[k]), k                         # masked-column absorb is bit-identical
+    del b; eng.trim(); torch.cuda.empty_cache()
+    c = one_move(IPEPS({k: 2.0 * v for k, v in st.sites.items()}))
+    for k in a:
+        assert float((a[k] - c[k]).abs().max()) < 1e-12, k
+    eng.trim()

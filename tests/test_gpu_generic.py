@@ -261,3 +261,26 @@ def test_absorb_of_nonzero_projector_prefix_is_identical(eng):
     assert used == [True, False]                     # the compact path really ran (<= chi/2 significant columns)
     for k in envs[0].C: assert torch.equal(envs[0].C[k], envs[1].C[k]), k
     for k in envs[0].T: assert torch.equal(envs[0].T[k], envs[1].T[k]), k
+
+
+def test_rdm2x2_from_parts_equals_the_whole(case, eng):
+    """ctm_rdm2x2_part: the plaquette contraction split over ranges of lower-half slices (what a rank group shares, and what one
+    GPU loops over when the open halves do not fit) reassembles to ctm_rdm2x2 exactly; and the host layer's chunked path gives
+    the same normalised RDM as the reference-pinned golden one."""
+    from ctm.generic import rdm
+    from ctm.generic.ctm_components import _corner_t, LU, RU, RD, LD
+    st, env = device_state_env(case["sites"], case["C"], case["T"], case["chi"])
+    for c in ((0, 0), (1, 1)):
+        x, y = c
+        t = _corner_t(LU, (x, y), st, env) + _corner_t(RU, (x + 1, y), st, env) + _corner_t(RD, (x + 1, y + 1), st, env) \
+            + _corner_t(LD, (x, y + 1), st, env)
+        whole = eng.rdm2x2(t)
+        p = whole.shape[0]
+        for bounds in ([0, 16], [0, 5, 16], [0, 1, 2, 4, 8, 16]):
+            R = torch.cat([eng.rdm2x2_part(t, a, b) for a, b in zip(bounds[:-1], bounds[1:])], dim=1)
+            assert relerr(eng.rdm2x2_from_parts(R, p), whole) < 1e-14, (c, bounds)
+    # forced chunking through the host layer
+    import unittest.mock as mock
+    with mock.patch("torch.cuda.mem_get_info", return_value=(1, 1)), mock.patch.object(type(eng), "stat", lambda self, k: 0):
+        r = rdm.rdm2x2((0, 0), st, env)
+    assert relerr(r, rdm.rdm2x2((0, 0), st, env)) < 1e-14

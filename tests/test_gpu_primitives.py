@@ -146,3 +146,25 @@ def test_truncated_svd_symeig_host_wrapper(eng):
         assert np.abs(S - np.abs(D)).max() < 1e-13 and ((S == 0) == (D == 0)).all()
     U, S, V = (t.cpu().numpy() for t in SVDSYMEIG.apply(dev(H)))
     assert np.linalg.norm(H - (U * S) @ V.T) < S[0] * H.shape[0] ** 2 * 1e-14
+
+
+@pytest.mark.parametrize("rows_kernel", [True, False], ids=["lds-row-block", "streaming-strip"])
+def test_row_block_times_big_operand_kernels(eng, rows_kernel):
+    """The two kernels behind (<= 64 rows) x (big operand): LDS-tiled row-block kernel and LDS-free streaming strip kernel, both
+    operand layouts, against torch's fp64 matmul."""
+    import torch
+    n = 2048
+    g = torch.Generator(device="cuda").manual_seed(3)
+    B = torch.randn(n, n, dtype=torch.float64, device="cuda", generator=g)
+    old = (33, 33)
+    eng.set_option("rows_kernel_min_m", 1 if rows_kernel else 1000)
+    eng.set_option("rows_kernel_min_m_kc", 1 if rows_kernel else 1000)
+    try:
+        for m in (8, 16, 31, 32, 33, 48, 64):
+            A = torch.randn(m, n, dtype=torch.float64, device="cuda", generator=g)
+            for tB in (False, True):
+                C = eng.gemm(A, B, transB=tB)
+                ref = A @ (B.t() if tB else B)
+                assert (C - ref).abs().max().item() < 1e-11 * ref.abs().max().item(), (m, tB)
+    finally:
+        eng.set_option("rows_kernel_min_m", old[0]); eng.set_option("rows_kernel_min_m_kc", old[1])
