@@ -157,6 +157,11 @@ int ctm_move_c4v(ctm_ctx* ctx, const double* a, const double* C, const double* T
 int ctm_move_c4v_ws(ctm_ctx* ctx, const double* a, const double* C, const double* T, int chi, int p, int D,
                     const ctm_trunc_cfg* cfg, double* C_out, double* T_out, double* D_out, double* basis);
 
+/* Same with the normalisation of the new T selectable (_move_normalize_c, ctmrg_c4v.py:182-197): normalize = 1 'inf' (max-abs),
+ * 2 vector 2-norm; C is always divided by |C[0,0]|. */
+int ctm_move_c4v_x(ctm_ctx* ctx, const double* a, const double* C, const double* T, int chi, int p, int D,
+                   const ctm_trunc_cfg* cfg, int normalize, double* C_out, double* T_out, double* D_out, double* basis);
+
 /* ---- RDMs (ctm/generic/rdm.py:1362-1592, 71-302, 304-500, 622-826; one_site_c4v/rdm_c4v.py) ---------- */
 /* rdm2x2: tensors16 = (C,T1,T2,a) for LU(coord), RU(coord+x), RD(coord+x+y), LD(coord+y); out p^8 raw
  * (un-normalised, index order s0 s1 s2 s3 s0' s1' s2' s3'); symmetrisation/normalisation is host-side. */

@@ -38,7 +38,7 @@ def init_env_ctmrg(a, chi):
     return C, T
 
 
-def ctm_move_sl(a, C, T, chi=None, eps_multiplet=1.0e-12, abs_tol=1.0e-14, return_P=False):
+def ctm_move_sl(a, C, T, chi=None, eps_multiplet=1.0e-12, abs_tol=1.0e-14, return_P=False, norm_type='inf'):
     """ctm_MOVE_sl (ctmrg_c4v.py:325-463) with truncated_eig_sym(keep_multiplets=True)
     (ctmrg_c4v.py:49-52: eps_multiplet/abs_tol at their custom_eig.py defaults)."""
     chi = C.shape[0] if chi is None else chi
@@ -54,7 +54,7 @@ def ctm_move_sl(a, C, T, chi=None, eps_multiplet=1.0e-12, abs_tol=1.0e-14, retur
     nT = nT.reshape(chi, chi, D * D)
     nT = 0.5 * (nT + nT.conj().transpose(1, 0, 2))                     # :446
     nC = nC / np.abs(nC[0, 0])                                         # :182-197
-    nT = nT / np.abs(nT).max()
+    nT = nT / (np.abs(nT).max() if norm_type == 'inf' else np.linalg.norm(nT.ravel()))   # vector_norm(ord=inf | 2)
     if return_P:
         return nC, nT, Dv, P
     return nC, nT

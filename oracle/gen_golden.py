@@ -289,6 +289,19 @@ def c4v_case(name, D, chi, seed, complex_=False):
     # T is gauge dependent (signs of eigenvectors): compare |T| and the invariant contraction
     close(np.abs(oT2), np.abs(T2), 1e-8, "c4v move |T|")
     out["move_C"] = C2; out["move_T"] = T2
+    # the same move with ctm_absorb_normalization = '2' (_move_normalize_c, ctmrg_c4v.py:182-197)
+    e3 = env.clone()
+    cfg.ctm_args.ctm_absorb_normalization = '2'
+    try:
+        ctmrg_c4v.ctm_MOVE_sl(st.site(), e3, teig)
+    finally:
+        cfg.ctm_args.ctm_absorb_normalization = 'inf'
+    C3, T3 = t2n(e3.get_C()), t2n(e3.get_T())
+    oC3, oT3 = O4.ctm_move_sl(A, C1, T1, norm_type='2')
+    close(np.diag(oC3), np.diag(C3), 1e-10, "c4v move C (2-norm)")
+    close(np.abs(oT3), np.abs(T3), 1e-8, "c4v move |T| (2-norm)")
+    assert abs(np.linalg.norm(T3.ravel()) - 1.0) < 1e-13
+    out["move2_C"] = C3; out["move2_T"] = T3
     for nm, fr, fo in (("rdm2x1", rdm_c4v.rdm2x1_sl, O4.rdm2x1_sl), ("rdmNN", rdm_c4v.rdm2x2_NN_lowmem_sl, O4.rdm2x2_NN_lowmem_sl),
                        ("rdmNNN", rdm_c4v.rdm2x2_NNN_lowmem_sl, O4.rdm2x2_NNN_lowmem_sl), ("rdm2x2", rdm_c4v.rdm2x2, O4.rdm2x2)):
         r = t2n(fr(st, env, sym_pos_def=True))

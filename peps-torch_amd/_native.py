@@ -64,6 +64,8 @@ _SIGS = {
                      C.c_void_p, C.c_void_p, C.c_void_p],
     "ctm_move_c4v_ws": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(TruncCfg),
                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
+    "ctm_move_c4v_x": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(TruncCfg), C.c_int,
+                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
     "ctm_rdm2x2": [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_int), C.c_void_p],
     "ctm_rdm2x2_part": [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_void_p],
     "ctm_rdm1x1": [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_int), C.c_void_p],
@@ -476,7 +478,7 @@ class Engine:
         k = chi + 1 if chi < n else n
         return torch.zeros(min(n, k + 8), n, dtype=torch.float64, device=self.device)
 
-    def move_c4v(self, a, C_, T, cfg=None, basis=None):
+    def move_c4v(self, a, C_, T, cfg=None, basis=None, normalize=1):
         a, C_, T = self._bind(a, C_, T)
         chi, p, D = C_.shape[0], a.shape[0], a.shape[1]
         nC, nT, Dv = self.empty(chi, chi), self.empty(chi, chi, D * D), self.empty_real(chi)
@@ -486,8 +488,8 @@ class Engine:
             k = chi + 1 if chi < n else n
             if not (basis.is_cuda and basis.dtype == torch.float64 and basis.is_contiguous() and tuple(basis.shape) == (min(n, k + 8), n)):
                 raise NativeError("move_c4v: basis must come from warm_basis_c4v(chi, n)")
-        self._ck(self.lib.ctm_move_c4v_ws(self.h, _ptr(a), _ptr(C_), _ptr(T), chi, p, D, C.byref(cfg), _ptr(nC), _ptr(nT), _ptr(Dv),
-                                          _ptr(basis) if basis is not None else None), "move_c4v")
+        self._ck(self.lib.ctm_move_c4v_x(self.h, _ptr(a), _ptr(C_), _ptr(T), chi, p, D, C.byref(cfg), int(normalize), _ptr(nC), _ptr(nT), _ptr(Dv),
+                                         _ptr(basis) if basis is not None else None), "move_c4v")
         return nC, nT, Dv
 
     def rdm_c4v(self, which, a, C_, T):

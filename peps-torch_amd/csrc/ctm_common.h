@@ -99,6 +99,7 @@ struct ctm_ctx {
     bool use_layer2 = true;
     bool gemm_fast = true;
     bool einsum_in_relayout = true, z_spectators_first = true;   // layout of the fused two-layer kernel's input (contract.hip)
+    bool proj_from_krylov = true; // projectors from the half-way products the block Krylov solver stored (no corner passes after the truncation)
     bool chain_as_strips = true;  // projector columns (<= 64) kept as rows through the two corner passes
     int splitk_reduce_vec = 1;
     bool gemm_log = false;        // debug: print every GEMM shape to stderr
@@ -231,6 +232,12 @@ struct MatOp {
     // operator; rows the caller does not have are zero.  Overwritten with this decomposition's right row factor.
     double* warm = nullptr;
     double* warm_hdr = nullptr;   // optional n-double header row of the warm workspace: [0] = calls left to skip the warm start
+    // optional by-products for the projectors of an implicit operator (float64): when the block Krylov solver produced the
+    // decomposition it also returns u_i^T R^T and v_i^T Rt^T (k x n each) assembled from the half-way products of its own
+    // operator applications, and sets *have_mid -- the caller then needs no further corner passes for P = R conj(U), Pt = Rt V
+    double* out_uR = nullptr;
+    double* out_vRt = nullptr;
+    bool* have_mid = nullptr;
 };
 // complex128 operators: Ut, Vt are planar (re plane k x n, then im plane), rows = u_k^H, v_k^H
 int jacobi_svd_top_op(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* Ut, double* Vt);

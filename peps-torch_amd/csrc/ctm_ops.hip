@@ -12,7 +12,7 @@ namespace {
 // ---------------------------------------------------------------------------------------------
 // fix_svd_signs (svd_gesdd.py:18-26) on row-stored factors: Ut, Vt are k x n; one workgroup per row:
 // argmax of the int64-quantised |U| (first occurrence), then both rows are multiplied by its sign.
-__global__ void fix_signs_rows_kernel(double* Ut, double* Vt, int k, int n) {
+__global__ void fix_signs_rows_kernel(double* Ut, double* Vt, int k, int n, double* X1, double* X2) {
     const int r = blockIdx.x;
     if (r >= k) return;
     double* u = Ut + (size_t)r * n;
@@ -37,6 +37,9 @@ __global__ void fix_signs_rows_kernel(double* Ut, double* Vt, int k, int n) {
     __syncthreads();
     if (sg < 0.0) {
         for (int c = threadIdx.x; c < n; c += blockDim.x) { u[c] = -u[c]; v[c] = -v[c]; }
+        // rows that are linear images of u (X1) and of v (X2) follow the sign of their triplet
+        if (X1) { double* x = X1 + (size_t)r * n; for (int c = threadIdx.x; c < n; c += blockDim.x) x[c] = -x[c]; }
+        if (X2) { double* x = X2 + (size_t)r * n; for (int c = threadIdx.x; c < n; c += blockDim.x) x[c] = -x[c]; }
     }
 }
 
@@ -179,7 +182,10 @@ int svd_rows_op(ctm_ctx* ctx, const MatOp& op, int chi, const ctm_trunc_cfg& cfg
         const int kf = std::min(k, chi);
         const size_t kn = (size_t)k * n;
         if (ctx->cplx) CTM_LAUNCH(ctx, fix_phase_rows_c_kernel, dim3(kf), dim3(256), 0, Ut, Ut + kn, Vt, Vt + kn, kf, n);
-        else CTM_LAUNCH(ctx, fix_signs_rows_kernel, dim3(kf), dim3(256), 0, Ut, Vt, kf, n);
+        else {
+            const bool mids = op.have_mid && *op.have_mid;
+            CTM_LAUNCH(ctx, fix_signs_rows_kernel, dim3(kf), dim3(256), 0, Ut, Vt, kf, n, mids ? op.out_uR : (double*)nullptr, mids ? op.out_vRt : (double*)nullptr);
+        }
     }
     const int kc = std::min(chi, n);
     to->keep_last = kc - 1;
@@ -656,11 +662,32 @@ int ctm_projectors_4x4_cc(ctm_ctx* ctx, int dir, const double* const* t, int chi
     op.mid[0] = (int)mid0; op.mid[1] = (int)mid1;
     op.warm = basis;
     op.warm_hdr = basis ? basis + (size_t)cz * k * n : nullptr;      // header row behind the basis (see ctm_hip.h)
+    bool have_mid = false;
+    if (!ctx->cplx && ctx->proj_from_krylov) {
+        CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)k * n, (void**)&op.out_uR));
+        CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)k * n, (void**)&op.out_vRt));
+        op.have_mid = &have_mid;
+    }
     TruncOut to;
     { PhaseTimer pt(ctx, CTM_T_SVD); CTM_TRY(svd_rows_op(ctx, op, chi, cfg, Ut, Vt, dS, &to)); }
     PhaseTimer pt(ctx, CTM_T_PROJ);
     int ncol;
     CTM_TRY(upload_scale(ctx, to, kc, cfg.svd_reltol, dScale, S_out, &ncol));
+    if (have_mid) {
+        // the block Krylov solver left u_i^T R^T and v_i^T Rt^T (rows, sign-fixed with their triplets): P[:, j] = (R u_j) s_j^-1/2
+        // and Pt[:, j] = (Rt v_j) s_j^-1/2 are their scaled transposes -- no corner passes
+        CTM_TRY(fill_f64(ctx, tP.p, (size_t)n * kc, 0.0));
+        CTM_TRY(fill_f64(ctx, tPt.p, (size_t)n * kc, 0.0));
+        if (ncol > 0) {
+            const long long tot = (long long)n * ncol;
+            const int blocks = (int)std::min<long long>((tot + 255) / 256, 2048);
+            CTM_LAUNCH(ctx, transpose_scale_kernel, dim3(blocks), dim3(256), 0, (const double*)op.out_uR, ncol, (int)n, tP.p, (long long)kc, (const double*)dScale);
+            CTM_LAUNCH(ctx, transpose_scale_kernel, dim3(blocks), dim3(256), 0, (const double*)op.out_vRt, ncol, (int)n, tPt.p, (long long)kc, (const double*)dScale);
+        }
+        CTM_TRY(io.finish());
+        CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        return CTM_OK;
+    }
     // P = R conj(U) S^-1/2 = opA(cA) opB(cB) Ut^T ... ; Pt = Rt V S^-1/2 = opC(cC) opD(cD) Vt^H ...
     CTM_TRY(corner_chain_times_rowsT(ctx, (int)n, (int)mid0, k, kc, ncol, c[0], tr[0], c[1], tr[1], Ut, false, dScale, tP));
     CTM_TRY(corner_chain_times_rowsT(ctx, (int)n, (int)mid1, k, kc, ncol, c[2], tr[2], c[3], tr[3], Vt, true, dScale, tPt));
@@ -751,6 +778,11 @@ int ctm_move_c4v(ctm_ctx* ctx, const double* a, const double* C, const double* T
 
 int ctm_move_c4v_ws(ctm_ctx* ctx, const double* a, const double* C, const double* T, int chi, int p, int D,
                     const ctm_trunc_cfg* cfg_, double* C_out, double* T_out, double* D_out, double* basis) {
+    return ctm_move_c4v_x(ctx, a, C, T, chi, p, D, cfg_, 1, C_out, T_out, D_out, basis);
+}
+
+int ctm_move_c4v_x(ctm_ctx* ctx, const double* a, const double* C, const double* T, int chi, int p, int D,
+                   const ctm_trunc_cfg* cfg_, int normalize, double* C_out, double* T_out, double* D_out, double* basis) {
     ctm_trunc_cfg cfg = cfg_ ? *cfg_ : kDefaultCfg;
     if (!cfg_) cfg.eps_multiplet = 1.0e-12;          // custom_eig.py default used by ctmrg_c4v.py:49-52
     if (ctx->cplx) { ctx->set_error("move_c4v: the one-site C4v move is float64 only in this build"); return CTM_ERR_UNSUPPORTED; }
@@ -769,8 +801,9 @@ int ctm_move_c4v_ws(ctm_ctx* ctx, const double* a, const double* C, const double
     DT res; res.p = T_out;
     CTM_TRY(dev_network(ctx, "xuUi,xelL,suldr,sULDR,edDj->ijrR", {tP, tT, tA, tA, tP}, &res));   // :383-443
     CTM_TRY(add_transposed01(ctx, T_out, chi, D * D));                                 // :446
-    // C /= |C[0,0]| ; T /= max|T|   (:182-197)
+    // C /= |C[0,0]| ; T /= max|T| ('inf') or T /= |T|_2   (_move_normalize_c, :182-197)
     CTM_TRY(div_by_device_scalar(ctx, C_out, (size_t)chi * chi, Dv, 1));
+    if (normalize == 2) { DT tT2(T_out, {(long long)chi * chi * D * D}); return normalize_dt(ctx, tT2, 2); }
     CTM_TRY(ctm_normalize_inf(ctx, T_out, (long long)chi * chi * D * D));
     return CTM_OK;
 }

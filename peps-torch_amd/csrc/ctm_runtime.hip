@@ -113,6 +113,7 @@ int ctm_set_option(ctm_ctx* ctx, const char* key, double value) {
     else if (k == "einsum_in_relayout") ctx->einsum_in_relayout = value != 0.0;
     else if (k == "z_spectators_first") ctx->z_spectators_first = value != 0.0;
     else if (k == "chain_as_strips") ctx->chain_as_strips = value != 0.0;
+    else if (k == "proj_from_krylov") ctx->proj_from_krylov = value != 0.0;
     else if (k == "si_block32") ctx->si_block32 = value != 0.0;
     else if (k == "si_warm_skip_calls") ctx->si_warm_skip_calls = (int)value;
     else if (k == "splitk_reduce_vec") ctx->splitk_reduce_vec = (int)value;

@@ -838,15 +838,18 @@ int rows_times(ctm_ctx* ctx, const double* X, long long ldx, int p, int kin, int
 }
 
 // C = B * M (transpose == false) or B * M^T (transpose == true) for the operator M of `op`
-int matop_apply(ctm_ctx* ctx, const MatOp& op, bool transpose, const double* B, long long ldb, int p, double* C, long long ldc) {
+// mid (optional, p x n, leading dimension n; implicit operators only): receives the half-way product B R^T (transpose == false)
+// or B Rt^T (transpose == true)
+int matop_apply(ctm_ctx* ctx, const MatOp& op, bool transpose, const double* B, long long ldb, int p, double* C, long long ldc,
+                double* mid = nullptr) {
     const int n = op.n;
     if (op.M) return rows_times(ctx, B, ldb, p, n, n, op.M, transpose, C, ldc);
     // implicit M = R^T Rt,  R = opA(cA) opB(cB) (n x m0 x n),  Rt = opC(cC) opD(cD) (n x m1 x n)
     const int m0 = op.mid[0] ? op.mid[0] : n, m1 = op.mid[1] ? op.mid[1] : n, mw = std::max(n, std::max(m0, m1));
     ArenaScope scope(ctx);
-    double *t1, *t2;
+    double *t1, *t2 = mid;
     CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)p * mw, (void**)&t1));
-    CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)p * mw, (void**)&t2));
+    if (!t2) CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)p * mw, (void**)&t2));
     if (!transpose) {   // B R^T Rt = ((B opB(cB)^T) opA(cA)^T) opC(cC) opD(cD)
         CTM_TRY(rows_times(ctx, B, ldb, p, n, m0, op.c[1], !op.t[1], t1, m0));
         CTM_TRY(rows_times(ctx, t1, m0, p, m0, n, op.c[0], !op.t[0], t2, n));
@@ -1497,6 +1500,13 @@ int svd_lanczos(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* Ut, dou
     CTM_TRY(arena_alloc(ctx, sizeof(double) * (rows_max + b) * n, (void**)&Vall));
     CTM_TRY(arena_alloc(ctx, sizeof(double) * rows_max * n, (void**)&Zraw));         // raw products U_j M
     CTM_TRY(arena_alloc(ctx, sizeof(double) * rows_max * n, (void**)&Wraw));         // raw products V_j M^T
+    const bool want_mid = !op.M && op.out_uR && op.out_vRt && op.have_mid;
+    double *URall = nullptr, *VRall = nullptr;                                       // half-way products U_j R^T, V_j Rt^T
+    if (want_mid) {
+        *op.have_mid = false;
+        CTM_TRY(arena_alloc(ctx, sizeof(double) * rows_max * n, (void**)&URall));
+        CTM_TRY(arena_alloc(ctx, sizeof(double) * rows_max * n, (void**)&VRall));
+    }
     CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)b * (rows_max + b), (void**)&G));
     CTM_TRY(arena_alloc(ctx, sizeof(double) * std::max<size_t>(rows_max, 1024), (void**)&norms));
     CTM_TRY(arena_alloc(ctx, sizeof(double) * std::max<size_t>(rows_max, 1024), (void**)&inv));
@@ -1531,14 +1541,14 @@ int svd_lanczos(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* Ut, dou
         double* Zj = Zraw + (size_t)j * b * n;
         double* Wj = Wraw + (size_t)j * b * n;
         // U_j
-        CTM_TRY(matop_apply(ctx, op, true, Vj, n, b, Wj, n)); applications += b;
+        CTM_TRY(matop_apply(ctx, op, true, Vj, n, b, Wj, n, want_mid ? VRall + (size_t)j * b * n : nullptr)); applications += b;
         CTM_HIP_CHECK(ctx, hipMemcpyAsync(Uj, Wj, sizeof(double) * (size_t)b * n, hipMemcpyDeviceToDevice, ctx->stream));
         CTM_TRY(project_out(ctx, Uj, b, n, Uall, j * b, G));
         CTM_TRY(orthonormalise_block(ctx, Uj, b, n, norms, inv, &mn, &mx));
         s0 = std::max(s0, mx);
         if (mn <= 1e-13 * s0) { if (ctx->jacobi_verbose) fprintf(stderr, "[lz] n=%d breakdown at step %d (U)\n", n, j); return CTM_OK; }
         // raw product and V_{j+1}
-        CTM_TRY(matop_apply(ctx, op, false, Uj, n, b, Zj, n)); applications += b;
+        CTM_TRY(matop_apply(ctx, op, false, Uj, n, b, Zj, n, want_mid ? URall + (size_t)j * b * n : nullptr)); applications += b;
         CTM_HIP_CHECK(ctx, hipMemcpyAsync(Vn, Zj, sizeof(double) * (size_t)b * n, hipMemcpyDeviceToDevice, ctx->stream));
         CTM_TRY(project_out(ctx, Vn, b, n, Vall, (j + 1) * b, G));
         CTM_TRY(orthonormalise_block(ctx, Vn, b, n, norms, inv, &mn, &mx));
@@ -1608,6 +1618,10 @@ int svd_lanczos(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* Ut, dou
             CTM_TRY(gemm_f64(ctx, gc));                                              // coordinates of the returned rows in the basis
             GemmDesc gp; gp.M = k; gp.N = n; gp.K = m; gp.A = Xc; gp.sam = m; gp.sak = 1; gp.B = Pr; gp.sbk = n; gp.sbn = 1; gp.C = C1; gp.ldc = n;
             CTM_TRY(gemm_f64(ctx, gp));
+            if (want_mid) {      // the same coordinates give u_i^T R^T (rel 0) and v_i^T Rt^T (rel 1) from the stored half-way products
+                GemmDesc gm = gp; gm.B = rel == 0 ? URall : VRall; gm.C = rel == 0 ? op.out_uR : op.out_vRt;
+                CTM_TRY(gemm_f64(ctx, gm));
+            }
             CTM_LAUNCH(ctx, resid_rows_kernel, dim3((k + 3) / 4), dim3(256), 0, C1, (long long)n, rel == 0 ? Vt : Ut, (long long)n, Ss, k, n, res);
             CTM_HIP_CHECK(ctx, hipMemcpyAsync(r1.data(), res, sizeof(double) * k, hipMemcpyDeviceToHost, ctx->stream));
             CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
@@ -1640,6 +1654,13 @@ int svd_lanczos(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* Ut, dou
                 CTM_TRY(fill_f64(ctx, S + kv, (size_t)(k - kv), 0.0));
                 CTM_TRY(fill_f64(ctx, Ut + (size_t)kv * n, (size_t)(k - kv) * n, 0.0));
                 CTM_TRY(fill_f64(ctx, Vt + (size_t)kv * n, (size_t)(k - kv) * n, 0.0));
+            }
+            if (want_mid) {
+                if (kv < k) {
+                    CTM_TRY(fill_f64(ctx, op.out_uR + (size_t)kv * n, (size_t)(k - kv) * n, 0.0));
+                    CTM_TRY(fill_f64(ctx, op.out_vRt + (size_t)kv * n, (size_t)(k - kv) * n, 0.0));
+                }
+                *op.have_mid = true;
             }
             if (op.warm_hdr) {
                 CTM_TRY(fill_f64(ctx, op.warm_hdr + HDR_STEPS, 1, (double)steps));

@@ -37,8 +37,7 @@ def run(state, env, conv_check=None, ctm_args=cfg.ctm_args, global_args=cfg.glob
 def ctm_MOVE_sl(a, env, f_c2x2_decomp=None, ctm_args=cfg.ctm_args, global_args=cfg.global_args, past_steps_data=None):
     """One C4v move.  `f_c2x2_decomp` is accepted for signature compatibility; the native move always
     uses the truncated symmetric eigendecomposition with keep_multiplets (ctmrg_c4v.py:49-52)."""
-    if ctm_args.ctm_absorb_normalization != 'inf':
-        raise NotImplementedError("ctm_absorb_normalization: only 'inf' is implemented natively")
+    norm_kind = 1 if ctm_args.ctm_absorb_normalization == 'inf' else 2        # anything else is the 2-norm (ctmrg_c4v.py:183-185)
     eng = get_engine()
     cfgT = eng.cfg(eps_multiplet=1.0e-12, multiplet_abstol=1.0e-14, keep_multiplets=True)
     basis = None
@@ -49,7 +48,7 @@ def ctm_MOVE_sl(a, env, f_c2x2_decomp=None, ctm_args=cfg.ctm_args, global_args=c
         k = env.chi + 1 if env.chi < n else n
         if basis is None or tuple(basis.shape) != (min(n, k + 8), n) or basis.device != a.device:
             basis = env.__dict__["_warm"] = eng.warm_basis_c4v(env.chi, n)
-    nC, nT, _D = eng.move_c4v(a, env.C[env.keyC], env.T[env.keyT], cfgT, **({"basis": basis} if basis is not None else {}))
+    nC, nT, _D = eng.move_c4v(a, env.C[env.keyC], env.T[env.keyT], cfgT, normalize=norm_kind, **({"basis": basis} if basis is not None else {}))
     env.C[env.keyC] = nC
     env.T[env.keyT] = nT
 

@@ -245,7 +245,7 @@ def test_rdm2x2_and_energy_at_D4_chi64_against_the_oracle(eng):
 def test_whole_move_of_the_complex_config_at_full_size(eng):
     """BASELINE configs[4] (generic D = 8, chi = 384, complex128, n = 24576): ONE whole directional move -- fused projectors of the
     four sites AND the four complex absorbs -- from the CTMRG init.  Checks: every new tensor has max-abs 1, the move is invariant
-    under a -> 2a, and the absorb on the non-zero projector prefix equals the absorb with all chi columns."""
+    under a -> 2a, and the absorb on the non-zero projector prefix equals the absorb with all chi columns (to rounding)."""
     import config as cfg
     from ctm.generic.env import ENV, init_env
     from ctm.generic import ctmrg
@@ -276,7 +276,8 @@ def test_whole_move_of_the_complex_config_at_full_size(eng):
     eng.trim(); torch.cuda.empty_cache()
     b = one_move(st, absorb_skip_zero_columns=False)
     for k in a:
-        assert torch.equal(a[k], b[k]), k                         # masked-column absorb is bit-identical
+        # same numbers up to the summation order of the differently shaped products (split-K slices follow the shape)
+        assert float((a[k] - b[k]).abs().max()) < 1e-13, k
     del b; eng.trim(); torch.cuda.empty_cache()
     c = one_move(IPEPS({k: 2.0 * v for k, v in st.sites.items()}))
     for k in a:
