@@ -263,6 +263,9 @@ def c4v_case(name, D, chi, seed, complex_=False):
     rng = np.random.default_rng(seed)
     A = rng.random((2, D, D, D, D))
     A = t2n(make_c4v_symm(torch.from_numpy(A)))
+    if complex_:      # the complex C4v ansatz of ipeps_c4v.py:60-66: A1-symmetric real part + i * A2-symmetric imaginary part
+        B = rng.random((2, D, D, D, D)) - 0.5
+        A = A + 1j * t2n(make_c4v_symm(torch.from_numpy(B), irreps=["A2"]))
     A = A / np.abs(A).max()
     st = IPEPS_C4V(torch.from_numpy(A.copy()))
     env = ENV_C4V(chi, st)
@@ -308,7 +311,7 @@ def c4v_case(name, D, chi, seed, complex_=False):
         close(fo(A, C1, T1, sym_pos_def=True), r, 1e-10, f"c4v {nm}")
         out[nm] = r
     model = j1j2.J1J2_C4V_BIPARTITE(j1=1.0, j2=0.5)
-    e_low = float(model.energy_1x1_lowmem(st, env)); e_22 = float(model.energy_1x1(st, env))
+    e_low = float(torch.real(model.energy_1x1_lowmem(st, env))); e_22 = float(torch.real(model.energy_1x1(st, env)))
     close(OJ.energy_1x1_lowmem(out["rdmNN"], out["rdmNNN"], 1.0, 0.5), e_low, 1e-12, "c4v e lowmem")
     close(OJ.energy_1x1(out["rdm2x2"], 1.0, 0.5), e_22, 1e-12, "c4v e 2x2")
     out["e_lowmem"] = np.array(e_low); out["e_2x2"] = np.array(e_22)
@@ -531,6 +534,8 @@ if __name__ == "__main__":
     if "c4v" in which:
         c4v_case("c4v_D2_chi8", 2, 8, 21)
         c4v_case("c4v_D3_chi18", 3, 18, 22)
+        c4v_case("c4v_D2_chi8_c128", 2, 8, 23, complex_=True)
+        c4v_case("c4v_D3_chi18_c128", 3, 18, 24, complex_=True)
     if "rvb" in which:
         rvb_case()
     if "files" in which:

@@ -201,6 +201,8 @@ int gather_rows(ctm_ctx* ctx, const double* src, long long lds, const int* d_idx
                 long long ldd, const double* d_rowscale);
 int symmetrize_lower(ctm_ctx* ctx, const double* a, double* out, int n, double shift);
 int add_transposed01(ctm_ctx* ctx, double* t, int d0, int d2);   // t[i,j,s] = 0.5 (t[i,j,s] + t[j,i,s])
+int hermitize_lower_c128(ctm_ctx* ctx, const double* ar, const double* ai, double* outr, double* outi, int n, double shift);
+int add_conj_transposed01_c128(ctm_ctx* ctx, double* tr, double* ti, int d0, int d2);   // t = 0.5 (t + conj(t)^T(0,1)), planar
 int tril_correction(ctm_ctx* ctx, double* E, int k);             // E -> I - strict_lower(E) - diag(E)/2 with E=G-I
 int diag_to_matrix(ctm_ctx* ctx, const double* d, double* out, int n);
 int trace_partial(ctm_ctx* ctx, const double* in, double* out, long long n2, int p);  // out[ab] = sum_i in[ab,i,i]
@@ -249,5 +251,8 @@ int jacobi_svd_top(ctm_ctx* ctx, const double* M, int n, int k, double* S, doubl
 // Symmetric eigendecomposition (lower triangle of A is referenced), k leading eigenpairs by |lambda|:
 //   D[k] (signed), Ut (k x n, rows = eigenvectors).
 int jacobi_eigh_top(ctm_ctx* ctx, const double* A, int n, int k, double* D, double* Ut, double* warm = nullptr);
+// Hermitian eigendecomposition of a planar complex matrix (lower triangle referenced): D[k] real (signed, by |lambda| descending),
+// Ut planar k x n (re plane, then im plane), rows = u_i^H
+int jacobi_eigh_top_c(ctm_ctx* ctx, const double* Ar, const double* Ai, int n, int k, double* D, double* Ut);
 // singular values only, small matrices (corner spectra)
 int jacobi_svdvals(ctm_ctx* ctx, const double* M, const double* Mi /* nullptr: real */, int n, double* S);

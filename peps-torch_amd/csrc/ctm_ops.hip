@@ -470,34 +470,52 @@ int ctm_truncated_svd_ws(ctm_ctx* ctx, const double* M, int n, int chi, const ct
     return CTM_OK;
 }
 
-namespace { int truncated_eigh_impl(ctm_ctx* ctx, const double* A, int n, int chi, const ctm_trunc_cfg* cfg_, double* D, double* U, double* warm); }
+namespace {
+int truncated_eigh_impl(ctm_ctx* ctx, const double* A, int n, int chi, const ctm_trunc_cfg* cfg_, double* D, double* U, double* warm);
+int eigh_trunc_planar(ctm_ctx* ctx, const DT& A, int n, int chi, const ctm_trunc_cfg& cfg, double* dD, const DT& U, double* warm);
+}
 
 int ctm_truncated_eigh(ctm_ctx* ctx, const double* A, int n, int chi, const ctm_trunc_cfg* cfg_, double* D, double* U) {
     return truncated_eigh_impl(ctx, A, n, chi, cfg_, D, U, nullptr);
 }
 
 namespace {
-int truncated_eigh_impl(ctm_ctx* ctx, const double* A, int n, int chi, const ctm_trunc_cfg* cfg_, double* D, double* U, double* warm) {
-    ctm_trunc_cfg cfg = cfg_ ? *cfg_ : kDefaultCfg;
-    if (!cfg_) { cfg.eps_multiplet = 1.0e-12; }
-    if (chi < 1 || n < 1) { ctx->set_error("truncated_eigh: bad dims"); return CTM_ERR_BADARG; }
-    if (ctx->cplx) { ctx->set_error("truncated_eigh: the symmetric eigensolver (C4v path) is float64 only in this build"); return CTM_ERR_UNSUPPORTED; }
+// truncated_eig_sym (custom_eig.py:7-65) on a planar (real or complex Hermitian) matrix: dD (device, min(chi,n), signed, zeros beyond
+// the last complete multiplet), U (n x min(chi,n), planar in complex contexts, columns beyond the kept multiplets zeroed)
+int eigh_trunc_planar(ctm_ctx* ctx, const DT& A, int n, int chi, const ctm_trunc_cfg& cfg, double* dD, const DT& U, double* warm) {
     PhaseTimer pt(ctx, CTM_T_EIG);
     ArenaScope scope(ctx);
-    const int k = (chi < n) ? chi + 1 : n, kc = std::min(chi, n);
-    double *Ut, *dD;
-    CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)k * n, (void**)&Ut));
-    CTM_TRY(arena_alloc(ctx, sizeof(double) * k, (void**)&dD));
-    CTM_TRY(jacobi_eigh_top(ctx, A, n, k, dD, Ut, warm));
+    const int k = (chi < n) ? chi + 1 : n, kc = std::min(chi, n), cz = A.q ? 2 : 1;
+    double *Ut, *dk;
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)k * n * cz, (void**)&Ut));
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * k, (void**)&dk));
+    if (A.q) CTM_TRY(jacobi_eigh_top_c(ctx, A.p, A.q, n, k, dk, Ut));
+    else CTM_TRY(jacobi_eigh_top(ctx, A.p, n, k, dk, Ut, warm));
     std::vector<double> Dh(k);
-    CTM_HIP_CHECK(ctx, hipMemcpyAsync(Dh.data(), dD, sizeof(double) * k, hipMemcpyDeviceToHost, ctx->stream));
+    CTM_HIP_CHECK(ctx, hipMemcpyAsync(Dh.data(), dk, sizeof(double) * k, hipMemcpyDeviceToHost, ctx->stream));
     CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     int keep_last = kc - 1;
     if (cfg.keep_multiplets && chi < n) keep_last = std::min(kc - 1, multiplet_chi(Dh, chi, cfg.eps_multiplet, cfg.multiplet_abstol));
     std::vector<double> Do(kc);
     for (int i = 0; i < kc; ++i) Do[i] = (i <= keep_last) ? Dh[i] : 0.0;
-    CTM_HIP_CHECK(ctx, hipMemcpyAsync(D, Do.data(), sizeof(double) * kc, hipMemcpyHostToDevice, ctx->stream));
-    CTM_LAUNCH(ctx, rows_to_cols_kernel, dim3(1024), dim3(256), 0, Ut, n, kc, keep_last, U, 1.0);
+    CTM_HIP_CHECK(ctx, hipMemcpyAsync(dD, Do.data(), sizeof(double) * kc, hipMemcpyHostToDevice, ctx->stream));
+    CTM_TRY(rows_to_cols(ctx, Ut, k, n, kc, keep_last, U));       // columns u_i from the rows u_i^H
+    CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return CTM_OK;
+}
+
+int truncated_eigh_impl(ctm_ctx* ctx, const double* A, int n, int chi, const ctm_trunc_cfg* cfg_, double* D, double* U, double* warm) {
+    ctm_trunc_cfg cfg = cfg_ ? *cfg_ : kDefaultCfg;
+    if (!cfg_) { cfg.eps_multiplet = 1.0e-12; }
+    if (chi < 1 || n < 1) { ctx->set_error("truncated_eigh: bad dims"); return CTM_ERR_BADARG; }
+    ArenaScope scope(ctx);
+    IO io(ctx);
+    const int kc = std::min(chi, n);
+    DT tA, tU;
+    CTM_TRY(io.in(A, {n, n}, &tA));
+    CTM_TRY(io.out(U, (size_t)n * kc, &tU));
+    CTM_TRY(eigh_trunc_planar(ctx, tA, n, chi, cfg, D, tU, ctx->cplx ? nullptr : warm));
+    CTM_TRY(io.finish());
     CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     return CTM_OK;
 }
@@ -785,27 +803,39 @@ int ctm_move_c4v_x(ctm_ctx* ctx, const double* a, const double* C, const double*
                    const ctm_trunc_cfg* cfg_, int normalize, double* C_out, double* T_out, double* D_out, double* basis) {
     ctm_trunc_cfg cfg = cfg_ ? *cfg_ : kDefaultCfg;
     if (!cfg_) cfg.eps_multiplet = 1.0e-12;          // custom_eig.py default used by ctmrg_c4v.py:49-52
-    if (ctx->cplx) { ctx->set_error("move_c4v: the one-site C4v move is float64 only in this build"); return CTM_ERR_UNSUPPORTED; }
     const int n = chi * D * D;
     ArenaScope scope(ctx);
-    double *C2X2, *Dv, *P;
-    CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)n * n, (void**)&C2X2));
+    IO io(ctx);
+    DT tA, tC, tT, c2, tP, rC, rT;
+    CTM_TRY(io.in(a, {p, D, D, D, D}, &tA));
+    CTM_TRY(io.in(C, {chi, chi}, &tC));
+    CTM_TRY(io.in(T, {chi, chi, D, D}, &tT));
+    CTM_TRY(io.out(C_out, (size_t)chi * chi, &rC));
+    CTM_TRY(io.out(T_out, (size_t)chi * chi * D * D, &rT));
+    CTM_TRY(alloc_dt(ctx, {n, n}, &c2));
+    CTM_TRY(alloc_dt(ctx, {n, chi}, &tP));
+    double* Dv;
     CTM_TRY(arena_alloc(ctx, sizeof(double) * chi, (void**)&Dv));
-    CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)n * chi, (void**)&P));
-    CTM_TRY(ctm_c2x2_c4v(ctx, 0, a, C, T, chi, p, D, C2X2));
-    CTM_TRY(truncated_eigh_impl(ctx, C2X2, n, chi, &cfg, Dv, P, basis));
+    {   // 1) enlarged corner (ctm_components_c4v.py:52-130)
+        PhaseTimer pt(ctx, CTM_T_CORNERS);
+        CTM_TRY(dev_network(ctx, "xy,cyuU,xelL,suldr,sULDR->edDcrR", {tC, tT, tT, tA, tA.conj()}, &c2));
+    }
+    // 2) projector: truncated (Hermitian) eigendecomposition, D real with sign (ctmrg_c4v.py:49-52, 360-374)
+    CTM_TRY(eigh_trunc_planar(ctx, c2, n, chi, cfg, Dv, tP, ctx->cplx ? nullptr : basis));
     PhaseTimer pt(ctx, CTM_T_ABSORB);
-    CTM_TRY(diag_to_matrix(ctx, Dv, C_out, chi));                                     // ctmrg_c4v.py:374
+    CTM_TRY(diag_to_matrix(ctx, Dv, rC.p, chi));                                       // C = diag(D) (:374), imaginary part zero
+    if (rC.q) CTM_TRY(fill_f64(ctx, rC.q, (size_t)chi * chi, 0.0));
     if (D_out) CTM_HIP_CHECK(ctx, hipMemcpyAsync(D_out, Dv, sizeof(double) * chi, hipMemcpyDeviceToDevice, ctx->stream));
-    DT tP(P, {chi, D, D, chi}), tT(T, {chi, chi, D, D}), tA(a, {p, D, D, D, D});
-    DT res; res.p = T_out;
-    CTM_TRY(dev_network(ctx, "xuUi,xelL,suldr,sULDR,edDj->ijrR", {tP, tT, tA, tA, tP}, &res));   // :383-443
-    CTM_TRY(add_transposed01(ctx, T_out, chi, D * D));                                 // :446
+    // 3) nT = P . T . a . a* . P*, symmetrised with its conjugate transpose in the environment legs (:383-446)
+    DT tPv = tP.view({chi, D, D, chi});
+    DT res = rT.view({chi, chi, D, D});
+    CTM_TRY(dev_network(ctx, "xuUi,xelL,suldr,sULDR,edDj->ijrR", {tPv, tT, tA, tA.conj(), tPv.conj()}, &res));
+    if (rT.q) CTM_TRY(add_conj_transposed01_c128(ctx, rT.p, rT.q, chi, D * D));
+    else CTM_TRY(add_transposed01(ctx, rT.p, chi, D * D));
     // C /= |C[0,0]| ; T /= max|T| ('inf') or T /= |T|_2   (_move_normalize_c, :182-197)
-    CTM_TRY(div_by_device_scalar(ctx, C_out, (size_t)chi * chi, Dv, 1));
-    if (normalize == 2) { DT tT2(T_out, {(long long)chi * chi * D * D}); return normalize_dt(ctx, tT2, 2); }
-    CTM_TRY(ctm_normalize_inf(ctx, T_out, (long long)chi * chi * D * D));
-    return CTM_OK;
+    CTM_TRY(div_by_device_scalar(ctx, rC.p, (size_t)chi * chi, Dv, 1));
+    CTM_TRY(normalize_dt(ctx, rT.view({(long long)chi * chi * D * D}), normalize == 2 ? 2 : 1));
+    return io.finish();
 }
 
 // ---- RDMs ------------------------------------------------------------------------------------------
@@ -949,48 +979,64 @@ int ctm_rdm1x2(ctm_ctx* ctx, const double* const* t, int chi, const int* ad2, do
 }
 
 int ctm_rdm_c4v(ctm_ctx* ctx, int which, const double* a, const double* C, const double* T, int chi, int p, int D, double* out) {
-    if (ctx->cplx) { ctx->set_error("rdm_c4v: float64 only in this build"); return CTM_ERR_UNSUPPORTED; }
+    if (which < 0 || which > 3) { ctx->set_error("rdm_c4v: bad selector"); return CTM_ERR_BADARG; }
     PhaseTimer pt(ctx, CTM_T_RDM);
     ArenaScope scope(ctx);
-    const long long n = (long long)chi * D * D, X = chi, D2 = (long long)D * D;
-    double* c; CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)(n * n * p * p), (void**)&c));
-    { ArenaScope s2(ctx); CTM_TRY(ctm_c2x2_c4v(ctx, 1, a, C, T, chi, p, D, c)); }
-    DT r; r.p = out;
+    IO io(ctx);
+    const long long n = (long long)chi * D * D, X = chi, D2 = (long long)D * D, P = p;
+    DT tA, tC, tT, c, r;
+    CTM_TRY(io.in(a, {P, D, D, D, D}, &tA));
+    CTM_TRY(io.in(C, {X, X}, &tC));
+    CTM_TRY(io.in(T, {X, X, D, D}, &tT));
+    CTM_TRY(io.out(out, (size_t)(which == 3 ? P * P * P * P * P * P * P * P : P * P * P * P), &r));
+    CTM_TRY(alloc_dt(ctx, {n, n, P, P}, &c));
+    {   // open enlarged corner (rdm_c4v.py:13-93)
+        ArenaScope s2(ctx);
+        CTM_TRY(dev_network(ctx, "xy,cyuU,xelL,suldr,tULDR->edDcrRst", {tC, tT, tT, tA, tA.conj()}, &c));
+    }
+    auto perm = [&](const DT& src, const DT& dst, int nd, const long long* dims, const int* pm) -> int {
+        CTM_TRY(permute_f64(ctx, src.p, dst.p, nd, dims, pm));
+        if (src.q) CTM_TRY(permute_f64(ctx, src.q, dst.q, nd, dims, pm));
+        return CTM_OK;
+    };
     if (which == 0) {            // rdm2x1_sl (rdm_c4v.py:530-665)
-        DT c6(c, {X, D2, X, D2, (long long)p, (long long)p}), tC(C, {X, X}), tT(T, {X, X, D2});
+        DT c6 = c.view({X, D2, X, D2, P, P}), tT3 = tT.view({X, X, D2});
         DT c2x1, left;
-        CTM_TRY(dev_einsum2(ctx, "ab", tC, "bcd", tT, "acd", &c2x1));
+        CTM_TRY(dev_einsum2(ctx, "ab", tC, "bcd", tT3, "acd", &c2x1));
         CTM_TRY(dev_einsum2(ctx, "acd", c2x1, "adefst", c6, "cefst", &left));
-        return dev_einsum2(ctx, "cefst", left, "ecfuv", left, "sutv", &r);
+        CTM_TRY(dev_einsum2(ctx, "cefst", left, "ecfuv", left, "sutv", &r));
+        return io.finish();
     }
     if (which == 1 || which == 2) {
-        double* cc; CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)(n * n), (void**)&cc));
-        CTM_TRY(trace_partial(ctx, c, cc, n * n, p));                         // C2x2c = einsum('abii->ab')
-        DT c3(c, {n, n, (long long)p * p}), tcc(cc, {n, n});
+        DT cc;
+        CTM_TRY(alloc_dt(ctx, {n, n}, &cc));
+        CTM_TRY(trace_partial(ctx, c.p, cc.p, n * n, p));                     // C2x2c = einsum('abii->ab')
+        if (c.q) CTM_TRY(trace_partial(ctx, c.q, cc.q, n * n, p));
+        DT c3 = c.view({n, n, P * P});
         DT r3;
         if (which == 1) {        // _rdm2x2_NN_lowmem (rdm_c4v.py:1204-1284)
             DT r1, r2;
-            CTM_TRY(dev_einsum2(ctx, "ab", tcc, "bcs", c3, "acs", &r1));
-            CTM_TRY(dev_einsum2(ctx, "da", tcc, "acs", r1, "dcs", &r2));
+            CTM_TRY(dev_einsum2(ctx, "ab", cc, "bcs", c3, "acs", &r1));
+            CTM_TRY(dev_einsum2(ctx, "da", cc, "acs", r1, "dcs", &r2));
             CTM_TRY(dev_einsum2(ctx, "cdt", c3, "dcs", r2, "ts", &r3));        // [(k0 b0), (k1 b1)]
         } else {                 // _rdm2x2_NNN_lowmem (rdm_c4v.py:1373-1443)
             DT h;
-            CTM_TRY(dev_einsum2(ctx, "ab", tcc, "bcs", c3, "acs", &h));
+            CTM_TRY(dev_einsum2(ctx, "ab", cc, "bcs", c3, "acs", &h));
             CTM_TRY(dev_einsum2(ctx, "acs", h, "cat", h, "st", &r3));
         }
-        long long dims[4] = {p, p, p, p}; int perm[4] = {0, 2, 1, 3};
-        return permute_f64(ctx, r3.p, out, 4, dims, perm);
+        long long dims[4] = {p, p, p, p}; int pm[4] = {0, 2, 1, 3};
+        CTM_TRY(perm(r3, r, 4, dims, pm));
+        return io.finish();
     }
-    if (which == 3) {            // rdm2x2 (rdm_c4v.py:1446-1545)
-        DT c4(c, {n, n, (long long)p, (long long)p});
-        DT up, r8;
-        CTM_TRY(dev_einsum2(ctx, "akst", c4, "kbuv", c4, "abstuv", &up));
-        CTM_TRY(dev_einsum2(ctx, "abstuv", up, "bawxyz", up, "stuvwxyz", &r8));
-        long long dims[8]; for (int i = 0; i < 8; ++i) dims[i] = p;
-        int perm[8] = {0, 2, 6, 4, 1, 3, 7, 5};
-        return permute_f64(ctx, r8.p, out, 8, dims, perm);
-    }
-    ctx->set_error("rdm_c4v: bad selector"); return CTM_ERR_BADARG;
+    // rdm2x2 (rdm_c4v.py:1446-1545)
+    DT c4 = c.view({n, n, P, P});
+    DT up, r8;
+    CTM_TRY(dev_einsum2(ctx, "akst", c4, "kbuv", c4, "abstuv", &up));
+    CTM_TRY(dev_einsum2(ctx, "abstuv", up, "bawxyz", up, "stuvwxyz", &r8));
+    long long dims[8]; for (int i = 0; i < 8; ++i) dims[i] = p;
+    int pm[8] = {0, 2, 6, 4, 1, 3, 7, 5};
+    CTM_TRY(perm(r8, r, 8, dims, pm));
+    return io.finish();
 }
 
 int ctm_init_piece(ctm_ctx* ctx, int kind, const double* a, const int* ad, double* out) {

@@ -1093,6 +1093,10 @@ __global__ void planar_to_panel_kernel(const double* re, const double* im, long 
     }
 }
 
+__global__ void add_inplace_kernel(double* x, const double* y, size_t n) {
+    for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (size_t)gridDim.x * blockDim.x) x[q] += y[q];
+}
+
 __global__ void sub_inplace_kernel(double* x, const double* y, size_t n) {
     for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (size_t)gridDim.x * blockDim.x) x[q] -= y[q];
 }
@@ -2141,3 +2145,93 @@ int jacobi_eigh_top(ctm_ctx* ctx, const double* A, int n, int k, double* D, doub
     CTM_TRY(row_dots(ctx, Y, Ut, k, n, n, D));
     return CTM_OK;
 }
+
+// Complex Hermitian twin of jacobi_eigh_top (eig_sym.py:25-34 on a complex128 matrix: torch.linalg.eigh, lower triangle, ordered
+// by |lambda| descending).  (1) large n, k << n: leading-|lambda| invariant subspace by the complex block iteration on the
+// Hermitian matrix, then a small Hermitian Rayleigh-Ritz; (2) full path: one-sided complex Jacobi on A + shift I (positive
+// definite, so the accumulated unitary holds the eigenvectors and lambda = sigma - shift).
+int jacobi_eigh_top_c(ctm_ctx* ctx, const double* Ar, const double* Ai, int n, int k, double* D, double* Ut) {
+    if (n <= 0 || k <= 0 || k > n) { ctx->set_error("jacobi_eigh_top_c: bad n/k"); return CTM_ERR_BADARG; }
+    ArenaScope scope(ctx);
+    const size_t nn = (size_t)n * n;
+    double* As;
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * 2 * nn, (void**)&As));
+    CTM_TRY(hermitize_lower_c128(ctx, Ar, Ai, As, As + nn, n, 0.0));
+    if (ctx->si_enable && k < n && n >= ctx->si_min_n) {
+        const int kk = std::min(n, k + 8);
+        const size_t kn = (size_t)kk * n;
+        double *S, *Uk, *Vk;
+        CTM_TRY(arena_alloc(ctx, sizeof(double) * kk, (void**)&S));
+        CTM_TRY(arena_alloc(ctx, sizeof(double) * 2 * kn, (void**)&Uk));
+        CTM_TRY(arena_alloc(ctx, sizeof(double) * 2 * kn, (void**)&Vk));
+        bool ok = false;
+        MatOp aop; aop.n = n; aop.M = As; aop.Mi = As + nn;
+        CTM_TRY(svd_iter_c(ctx, aop, kk, S, Uk, Vk, &ok));
+        if (ok) {
+            ctx->si_hits += 1;
+            // T = U A U^H (kk x kk Hermitian; U rows are q_j^H), T w = mu w, eigenvector rows x^H = w^H U
+            double *Y, *T, *Dk, *Th;
+            CTM_TRY(arena_alloc(ctx, sizeof(double) * 2 * kn, (void**)&Y));
+            CTM_TRY(arena_alloc(ctx, sizeof(double) * 2 * (size_t)kk * kk, (void**)&T));
+            CTM_TRY(arena_alloc(ctx, sizeof(double) * kk, (void**)&Dk));
+            CTM_TRY(arena_alloc(ctx, sizeof(double) * 2 * (size_t)kk * kk, (void**)&Th));
+            XM u{Uk, Uk + kn, n, false, false}, a{As, As + nn, n, false, false}, uh{Uk, Uk + kn, n, true, true};
+            CTM_TRY(xgemm(ctx, kk, n, n, u, a, Y, Y + kn, n));
+            XM y{Y, Y + kn, n, false, false};
+            CTM_TRY(xgemm(ctx, kk, kk, n, y, uh, T, T + (size_t)kk * kk, kk));
+            const bool save = ctx->si_enable; ctx->si_enable = false;
+            const int st = jacobi_eigh_top_c(ctx, T, T + (size_t)kk * kk, kk, kk, Dk, Th);
+            ctx->si_enable = save;
+            CTM_TRY(st);
+            XM th{Th, Th + (size_t)kk * kk, kk, false, false};
+            // the leading k rows of Th (ordered by |mu|) times U: planar output with k rows
+            double* tmp;
+            CTM_TRY(arena_alloc(ctx, sizeof(double) * 2 * kn, (void**)&tmp));
+            CTM_TRY(xgemm(ctx, kk, n, kk, th, u, tmp, tmp + kn, n));
+            CTM_HIP_CHECK(ctx, hipMemcpyAsync(Ut, tmp, sizeof(double) * (size_t)k * n, hipMemcpyDeviceToDevice, ctx->stream));
+            CTM_HIP_CHECK(ctx, hipMemcpyAsync(Ut + (size_t)k * n, tmp + kn, sizeof(double) * (size_t)k * n, hipMemcpyDeviceToDevice, ctx->stream));
+            CTM_HIP_CHECK(ctx, hipMemcpyAsync(D, Dk, sizeof(double) * k, hipMemcpyDeviceToDevice, ctx->stream));
+            CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+            return CTM_OK;
+        }
+        ctx->si_fallbacks += 1;
+    }
+    const int np = padded(n, BC);
+    const long long ld = (long long)n + np;
+    double *X, *norms;
+    int* d_idx;
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)2 * np * ld, (void**)&X));
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * 2 * np, (void**)&norms));
+    CTM_TRY(arena_alloc(ctx, sizeof(int) * 2 * np, (void**)&d_idx));
+    std::vector<double> h;
+    int st;
+    const double fro = host_fro(ctx, As, 2 * n, n, n, norms, h, &st);      // both planes: |A|_F >= spectral norm
+    CTM_TRY(st);
+    const double shift = fro * 1.0009765625 + 1e-300;
+    CTM_TRY(hermitize_lower_c128(ctx, Ar, Ai, As, As + nn, n, shift));
+    CTM_LAUNCH(ctx, fill_wq_c_kernel, dim3(2048), dim3(256), 0, (const double*)As, (const double*)(As + nn), n, X, np, ld, 1);
+    CTM_TRY(jacobi_rows(ctx, X, 2 * np, ld, n, (int)ld, 2 * BC, 0, shift * std::sqrt((double)n), ctx->jacobi_max_sweeps, true));
+    std::vector<double> hc;
+    CTM_TRY(panel_row_norms(ctx, X, np, n, ld, norms, hc));
+    std::vector<int> idx;
+    for (int i = 0; i < np; ++i) if (hc[i] > 0.0) idx.push_back(i);
+    if ((int)idx.size() != n) { ctx->set_error("jacobi_eigh_top_c: rank bookkeeping failed"); return CTM_ERR_NOCONV; }
+    std::vector<double> lam(np);
+    for (int i : idx) lam[i] = hc[i] - shift;
+    std::stable_sort(idx.begin(), idx.end(), [&](int a, int c) { return std::fabs(lam[a]) > std::fabs(lam[c]); });
+    CTM_TRY(panel_gather(ctx, X + n, ld, idx, k, n, Ut, d_idx));
+    CTM_TRY(reorth_rows_c(ctx, Ut, k, n, 2));
+    // eigenvalues as Rayleigh quotients Re(u^H A u): rows r = u^H, (r A) . conj(r)
+    const size_t kn = (size_t)k * n;
+    double *Y, *d2;
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * 2 * kn, (void**)&Y));
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * k, (void**)&d2));
+    CTM_TRY(hermitize_lower_c128(ctx, Ar, Ai, As, As + nn, n, 0.0));
+    XM u{Ut, Ut + kn, n, false, false}, a{As, As + nn, n, false, false};
+    CTM_TRY(xgemm(ctx, k, n, n, u, a, Y, Y + kn, n));
+    CTM_TRY(row_dots(ctx, Y, Ut, k, n, n, D));
+    CTM_TRY(row_dots(ctx, Y + kn, Ut + kn, k, n, n, d2));
+    CTM_LAUNCH(ctx, add_inplace_kernel, dim3((k + 255) / 256), dim3(256), 0, D, (const double*)d2, (size_t)k);
+    return CTM_OK;
+}
+

@@ -414,6 +414,40 @@ int symmetrize_lower(ctm_ctx* ctx, const double* a, double* out, int n, double s
     return CTM_OK;
 }
 
+// out = Hermitian matrix whose lower triangle is that of (ar, ai) (planar), + shift on the diagonal; the diagonal is real
+__global__ void hermitize_lower_kernel(const double* ar, const double* ai, double* outr, double* outi, int n, double shift) {
+    const size_t tot = (size_t)n * n;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = i / n, c = i - r * n;
+        if (r >= c) { outr[i] = ar[r * n + c] + (r == c ? shift : 0.0); outi[i] = (r == c) ? 0.0 : ai[r * n + c]; }
+        else { outr[i] = ar[c * n + r]; outi[i] = -ai[c * n + r]; }
+    }
+}
+
+int hermitize_lower_c128(ctm_ctx* ctx, const double* ar, const double* ai, double* outr, double* outi, int n, double shift) {
+    CTM_LAUNCH(ctx, hermitize_lower_kernel, dim3(nblocks((size_t)n * n, TB * 4)), dim3(TB), 0, ar, ai, outr, outi, n, shift);
+    return CTM_OK;
+}
+
+// imaginary plane of t <- 0.5 (t + conj(t)^T(0,1)): antisymmetric average, zero for i == j
+__global__ void asymm01_kernel(double* t, int d0, int d2) {
+    const size_t tot = (size_t)d0 * d0 * d2;
+    for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < tot; q += (size_t)gridDim.x * blockDim.x) {
+        const size_t s = q % d2, ij = q / d2, j = ij % d0, i = ij / d0;
+        if (i < j) {
+            const size_t q2 = (j * (size_t)d0 + i) * d2 + s;
+            const double v = 0.5 * (t[q] - t[q2]);
+            t[q] = v; t[q2] = -v;
+        } else if (i == j) t[q] = 0.0;
+    }
+}
+
+int add_conj_transposed01_c128(ctm_ctx* ctx, double* tr, double* ti, int d0, int d2) {
+    CTM_LAUNCH(ctx, symm01_kernel, dim3(nblocks((size_t)d0 * d0 * d2, TB * 4)), dim3(TB), 0, tr, d0, d2);
+    CTM_LAUNCH(ctx, asymm01_kernel, dim3(nblocks((size_t)d0 * d0 * d2, TB * 4)), dim3(TB), 0, ti, d0, d2);
+    return CTM_OK;
+}
+
 int add_transposed01(ctm_ctx* ctx, double* t, int d0, int d2) {
     CTM_LAUNCH(ctx, symm01_kernel, dim3(nblocks((size_t)d0 * d0 * d2, TB * 4)), dim3(TB), 0, t, d0, d2);
     LAUNCH_CHECK(ctx, "symm01");

@@ -86,7 +86,7 @@ def init_from_ipeps_pbc(state, env, verbosity=0):
     a = state.site()
     D2 = a.size(1) ** 2
     c = eng.init_piece(0, a)                                   # 'mijef,mijab->eafb', /max-abs
-    asym = torch.norm(c.t() - c) / c.abs().max()
+    asym = torch.norm(c.conj().t() - c) / c.abs().max()
     assert asym < 1.0e-8, "a is not symmetric"
     Dv, U = truncated_eig_sym(c, c.size(0))
     m = min(env.chi, D2)
@@ -94,11 +94,11 @@ def init_from_ipeps_pbc(state, env, verbosity=0):
     C[:m, :m] = torch.diag(Dv)[:m, :m]
     env.C[env.keyC] = C
     t = eng.init_piece(5, a)                                   # 'meifg,maibc->eafbgc' -> (D^2, D^2, D^2), /max-abs
-    # 'ai,abs,bj->ijs' as two GEMMs
+    # 'ai,abs,bj->ijs' with conj(U) on the bra leg, as two GEMMs (U^T, then U^H: trans = 2 is the conjugate transpose)
     t1 = eng.gemm(U, t.reshape(D2, D2 * D2), transA=True).reshape(D2, D2, D2)         # [i, b, s]
-    t2 = eng.gemm(U, eng.permute(t1, (1, 0, 2)).reshape(D2, D2 * D2), transA=True)       # [j, (i s)]
+    t2 = eng.gemm(U, eng.permute(t1, (1, 0, 2)).reshape(D2, D2 * D2), transA=(2 if U.is_complex() else True))   # [j, (i s)]
     t2 = eng.permute(t2.reshape(D2, D2, D2), (1, 0, 2))                                 # [i, j, s]
-    asym = (t2 - t2.permute(1, 0, 2)).norm() / t2.abs().max()
+    asym = (t2 - t2.permute(1, 0, 2).conj()).norm() / t2.abs().max()
     assert asym < 1.0e-8, "a is not symmetric"
     T = torch.zeros((env.chi, env.chi, D2), dtype=env.dtype, device=env.device)
     T[:m, :m, :] = t2[:m, :m, :]

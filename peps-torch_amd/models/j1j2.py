@@ -180,25 +180,26 @@ class J1J2():
 class J1J2_C4V_BIPARTITE(J1J2):
     def energy_1x1(self, state, env_c4v, force_cpu=False, **kwargs):
         r = rdm_c4v.rdm2x2(state, env_c4v, sym_pos_def=True).cpu()
-        return _cast_to_real(torch.einsum('ijklabcd,ijklabcd', r, self.hp_rot))
+        return _cast_to_real(torch.einsum('ijklabcd,ijklabcd', r, self.hp_rot.to(r.dtype)))
 
     def energy_1x1_lowmem(self, state, env_c4v, force_cpu=False):
         nn = rdm_c4v.rdm2x2_NN_lowmem_sl(state, env_c4v, sym_pos_def=True).cpu()
-        e = 2.0 * self.j1 * torch.einsum('ijkl,ijkl', nn, self.SS_delta_zz_rot) \
-            - 0.5 * self.hz_stag * torch.einsum('ijkl,ijkl', nn, self.hz_2x1_rot)
+        dt = nn.dtype
+        e = 2.0 * self.j1 * torch.einsum('ijkl,ijkl', nn, self.SS_delta_zz_rot.to(dt)) \
+            - 0.5 * self.hz_stag * torch.einsum('ijkl,ijkl', nn, self.hz_2x1_rot.to(dt))
         if abs(self.h_uni.norm()) > 0:
-            e = e + 0.5 * torch.einsum('ijkl,ijkl', nn, self.huni_2x1_rot)
+            e = e + 0.5 * torch.einsum('ijkl,ijkl', nn, self.huni_2x1_rot.to(dt))
         if abs(self.j2) > 0:
             nnn = rdm_c4v.rdm2x2_NNN_lowmem_sl(state, env_c4v, sym_pos_def=True).cpu()
-            e = e + 2.0 * self.j2 * torch.einsum('ijkl,ijkl', nnn, self.SS)
+            e = e + 2.0 * self.j2 * torch.einsum('ijkl,ijkl', nnn, self.SS.to(dt))
         return _cast_to_real(e)
 
     def eval_obs(self, state, env_c4v, force_cpu=False):
         """<m>, <S^z>, <S^+>, <S^-> and nearest-neighbour S.S from rho_2x1 (models/j1j2.py:710-770)."""
         r2 = rdm_c4v.rdm2x1_sl(state, env_c4v, sym_pos_def=True).cpu()
         r1 = torch.einsum('ijaj->ia', r2)
-        obs = {l: torch.trace(r1 @ op) for l, op in self.obs_ops.items()}
+        obs = {l: torch.trace(r1 @ op.to(r1.dtype)) for l, op in self.obs_ops.items()}
         obs["m"] = sqrt(abs(obs["sz"] ** 2 + obs["sp"] * obs["sm"]))
-        obs["SS2x1"] = _cast_to_real(torch.einsum('ijab,ijab', r2, self.SS_rot))
+        obs["SS2x1"] = _cast_to_real(torch.einsum('ijab,ijab', r2, self.SS_rot.to(r2.dtype)))
         labels = ["m"] + list(self.obs_ops.keys()) + ["SS2x1"]
         return [obs[l] for l in labels], labels

@@ -8,7 +8,7 @@ from helpers import dev, relerr
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=["c4v_D2_chi8", "c4v_D3_chi18"])
+@pytest.fixture(scope="module", params=["c4v_D2_chi8", "c4v_D3_chi18", "c4v_D2_chi8_c128", "c4v_D3_chi18_c128"])
 def case(request):
     return golden(request.param)
 
@@ -69,3 +69,36 @@ def test_rvb_known_answer(eng):
     spec = torch.diagonal(env.get_C()).abs().cpu().numpy()
     assert (spec == 0).sum() == 3
     assert np.abs(np.sort(spec)[::-1] - np.sort(g["spec"])[::-1]).max() < 1e-10
+
+
+def test_c4v_move_with_2norm_normalisation(case, eng):
+    """ctm_absorb_normalization = '2' (_move_normalize_c, ctmrg_c4v.py:182-197): T divided by its vector 2-norm, C by |C[0,0]|."""
+    import config as cfg
+    from ctm.one_site_c4v import ctmrg_c4v
+    st, env = _state_env(case)
+    old = cfg.ctm_args.ctm_absorb_normalization
+    cfg.ctm_args.ctm_absorb_normalization = '2'
+    try:
+        ctmrg_c4v.ctm_MOVE_sl(st.site(), env)
+    finally:
+        cfg.ctm_args.ctm_absorb_normalization = old
+    assert relerr(torch.diagonal(env.get_C()), np.diag(case["move2_C"])) < 1e-10
+    assert relerr(env.get_T().abs(), np.abs(case["move2_T"])) < 1e-8
+    assert abs(float(torch.linalg.vector_norm(env.get_T())) - 1.0) < 1e-13
+
+
+@pytest.mark.parametrize("n,chi", [(96, 24), (300, 300), (640, 40)])
+def test_truncated_eigh_complex_hermitian(eng, n, chi):
+    """ctm_truncated_eigh on a complex128 Hermitian matrix (eig_sym.py:25-34 is dtype generic): eigenvalues by |lambda| descending,
+    signs kept, unitary eigenvectors -- full Jacobi path (n <= 300) and the iterative leading-subspace path (n = 640)."""
+    rng = np.random.default_rng(n)
+    Q, _ = np.linalg.qr(rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n)))
+    lam = np.exp(-0.05 * np.arange(n)) * np.where(rng.random(n) < 0.35, -1.0, 1.0)
+    H = (Q * lam) @ Q.conj().T
+    H = 0.5 * (H + H.conj().T)
+    D, U = (t.cpu().numpy() for t in eng.truncated_eigh(dev(H), chi, eng.cfg(keep_multiplets=False)))
+    w = np.linalg.eigvalsh(H)
+    w = w[np.argsort(-np.abs(w))][:chi]
+    assert D.dtype == np.float64 and np.abs(D - w).max() < 1e-13
+    assert np.abs(U.conj().T @ U - np.eye(chi)).max() < 1e-12
+    assert np.abs(H @ U - U * D[None, :]).max() < 1e-12
