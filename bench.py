@@ -78,7 +78,7 @@ def _cpu_env(O, ost, chi, env_np, sites):
     return env, "dense random environment"
 
 
-def cpu_baseline(kind, D, chi, sites, env_np=None, budget_s=25.0):
+def cpu_baseline(kind, D, chi, sites, env_np=None, budget_s=25.0, svd_n=None):
     """numpy oracle on the host cores: time ONE unit (site (0,0), UP move: halves -> projectors -> absorb) of
     the generic sweep -- or ONE C4v sweep -- and extrapolate to sweeps/s.  Bounded sample."""
     from oracle import ctm_oracle as O, c4v_oracle as O4
@@ -102,7 +102,23 @@ def cpu_baseline(kind, D, chi, sites, env_np=None, budget_s=25.0):
                 "sample": f"{n} full C4v sweeps of the numpy oracle (LAPACK eigh), {os.cpu_count()} host cpus"}
     ost = O.State(sites)
     env, env_what = _cpu_env(O, ost, chi, env_np, sites)
-    if chi * D * D > 6000:
+    n = chi * D * D
+    if not np.iscomplexobj(sites[(0, 0)]):
+        # C++ restatement on threaded OpenBLAS/LAPACK (oracle/cpu_unit.cpp): ONE full unit -- four enlarged corners, R, Rt,
+        # M = R^T Rt (three n^3 dgemm), full dgesdd, projectors, absorb -- measured; only at n > 6000 the dgesdd is measured on
+        # the leading svd_n x svd_n block of M and scaled by (n / svd_n)^3 (a full n = 16384 dgesdd alone takes ~20 minutes)
+        from oracle import cpu_unit
+        nsub = 0 if n <= 6000 else min(n, svd_n or 4096)
+        r = cpu_unit.run_unit(O.UP, (0, 0), ost, env, svd_nsub=nsub)
+        t = dict(r["times"])
+        t_svd = t["svd"] * ((n / nsub) ** 3 if nsub else 1.0)
+        dt = t["corners"] + t["halves"] + t_svd + t["proj"] + t["absorb"]
+        how = "measured" if not nsub else f"dgesdd measured at n_s={nsub} ({t['svd']:.1f} s) and scaled by (n/n_s)^3 = {t_svd:.0f} s, everything else measured at full size"
+        return {"value": 1.0 / (32 * dt), "unit": "sweeps/s", "cores": r["threads"], "kind": "port",
+                "sample": f"1 of the 32 (site,direction) units of one sweep, C++ restatement on OpenBLAS/LAPACK ({r['threads']} threads of "
+                          f"{os.cpu_count()} host cpus) on the {env_what}: 4 corners {t['corners']:.1f} s + R, Rt, M (3 n^3 dgemm) {t['halves']:.1f} s + "
+                          f"dgesdd {t_svd:.1f} s + projectors {t['proj']:.2f} s + absorb {t['absorb']:.1f} s = {dt:.1f} s/unit ({how}), x32 units/sweep"}
+    if n > 6000:
         return cpu_baseline_large(O, ost, env, D, chi, threads, env_what)
     t0 = time.perf_counter()
     P, Pt = O.get_projectors_4x4(O.UP, (0, 0), ost, env)
@@ -380,6 +396,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--config", default=DEFAULT_CONFIG, choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-svd-n", type=int, default=None, help="CPU baseline at n > 6000: size of the dgesdd that is measured (default 4096)")
     ap.add_argument("--profile", action="store_true", help="per-phase HOST timers (adds stream syncs; phase_s is event-based without it)")
     ap.add_argument("--opt", action="append", default=[], help="engine option key=value (development)")
     ap.add_argument("--signed", action="store_true", help="time ONLY the full-rank state A ~ U(-1,1) (as `value`)")
@@ -465,7 +482,7 @@ def main():
                                 "state": full["state"], "roofline": full["roofline"], "svd": full["svd"], "phase_s": full["phase_s"]}
         if not args.no_cpu_baseline and world == 1:
             try:
-                out["cpu_baseline"] = cpu_baseline(kind, D, chi, sites, env_np)
+                out["cpu_baseline"] = cpu_baseline(kind, D, chi, sites, env_np, svd_n=args.cpu_svd_n)
             except Exception as e:                      # the baseline is reporting only
                 out["cpu_baseline"] = {"error": repr(e)}
             try:
