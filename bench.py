@@ -204,11 +204,13 @@ def _union_ms(ivals, kind):
 HBM_PEAK_GBPS = 8000.0
 # instrumented kernel classes (csrc: timing_end kinds).  Class 3 (streaming strip / row-block kernels) reports ALGORITHMIC BYTES
 # (the big operand read once + the row block in and out) AND is priced against HBM; the others report flops.
-CLS = {0: ("gemm_f64_fast_kernel / gemm_f64_kernel<4,4> (128x128 tile)", "mfma", "gemm_f64_fast_kernel"),
-       1: ("gemm_f64_kernel<2,2> (64x64 tile: small, segmented and batched products)", "mfma", "gemm_f64_kernel<2, 2>"),
-       2: ("layer2_reg_kernel<KT> (float64) / layer2_c_kernel<KT> (complex128): fused two-layer enlarged-corner kernel", "mfma", "layer2_"),
-       3: ("gemm_rows_kernel<TM<=2,BNF> (gemm_strip_kernel): <= 32-row block times an n x n corner, streamed once", "hbm", "gemm_rows_kernel"),
-       4: ("gemm_rows_kernel<TM>=3,BNF>: 33..64-row block times an n x n corner (16 flop per byte of the corner)", "mfma", "gemm_rows_kernel")}
+CLS = {0: ("gemm_f64_fast_kernel / gemm_f64_kernel<4,4> (128x128 tile)", "mfma", ("gemm_f64_fast_kernel", "gemm_f64_kernel<4, 4>")),
+       1: ("gemm_f64_kernel<2,2> (64x64 tile: small, segmented and batched products)", "mfma", ("gemm_f64_kernel<2, 2>",)),
+       2: ("layer2_reg_kernel<KT> (float64) / layer2_c_kernel<KT> (complex128): fused two-layer enlarged-corner kernel", "mfma", ("layer2_",)),
+       3: ("gemm_rows_kernel<TM<=2,BNF> (gemm_strip_kernel): <= 32-row block times an n x n corner, streamed once", "hbm",
+           ("gemm_rows_kernel<1,", "gemm_rows_kernel<2,", "gemm_strip_kernel")),
+       4: ("gemm_rows_kernel<TM>=3,BNF>: 33..64-row block times an n x n corner (16 flop per byte of the corner)", "mfma",
+           ("gemm_rows_kernel<3,", "gemm_rows_kernel<4,"))}
 
 
 def _rate(work, ms, bound):              # TFLOP/s or GB/s
@@ -343,6 +345,7 @@ def run_workload(args, eng, dev, kind, D, chi, dtype, signed, steps, warmup, wor
         out["state"] = {"chi": chi, "signed": bool(signed),
                         "corner_values_above_1e-8": int(min(S)) if S else None,
                         "nonzero_projector_columns": (max(nc.values()) if nc else chi),
+                        "effective_rank_much_smaller_than_chi": bool(S and min(S) < 0.25 * chi),
                         "corner_cache_hits": int(eng.stat("corner_cache_hits")),
                         "note": ("signed random tensors A ~ U(-1,1): full-rank environment (all chi projector columns significant), "
                                  "block-Krylov truncation on every unit") if signed else
@@ -362,10 +365,10 @@ def traffic_from_profile(args, world, dom, signed):
             return None
         rows = list(csv.DictReader(open(os.path.join(REPO, "profiles", f"r02_bench_{tag}_pmc_hbm_traffic.csv"))))
 
-        def pmc(key):
+        def pmc(keys):
             tb = tn = 0.0
             for row in rows:
-                if key in row["kernel"]:
+                if any(k_ in row["kernel"] for k_ in keys):
                     tb += float(row["hbm_bytes_per_launch(2x_fetch_corrected)"]) * float(row["launches"]); tn += float(row["launches"])
             return round(tb / tn) if tn else None
         return {"dominant": pmc(CLS[dom][2]), "others": {str(i): pmc(CLS[i][2]) for i in CLS if i != dom},

@@ -201,3 +201,32 @@ def test_read_ipeps_c4v_on_the_reference_rvb_file(cpu_cfg):
     assert np.array_equal(st.site().cpu().numpy(), g["RVB_1x1_in__c4v_site"])
     # the fixture of the published RVB anchor was generated from this very file
     assert np.array_equal(st.site().cpu().numpy(), golden("rvb_c4v")["site"])
+
+
+def test_energy_1site_BP_includes_j3_and_chiral_terms(cpu_cfg):
+    """energy_2x2_1site_BP = tr(rho_2x2 hp_rot) [+ lambda chiral term] + j3 * eval_nnnn_per_site (reference models/j1j2.py:212-221):
+    the j3 and chiral contributions against the oracle's pieces on a golden one-site... (4-site golden state used as a 1x1 tiling of
+    site (0,0))."""
+    from ipeps.ipeps import IPEPS
+    from ctm.generic.env import ENV, init_env
+    from ctm.generic import ctmrg, rdm
+    from models import j1j2
+    from oracle import ctm_oracle as O, j1j2_oracle as OJ
+    g = golden("generic_D2_chi8_f64")
+    A = sites_from(g)[(0, 0)]
+    st = IPEPS({(0, 0): torch.from_numpy(A.copy())})
+    env = ENV(8, st); init_env(st, env)
+    for d in cpu_cfg.ctm_args.ctm_move_sequence:
+        ctmrg.ctm_MOVE(d, st, env)
+    ost = O.State({(0, 0): A}); oe = O.Env(8)
+    oe.C = {k: v.numpy() for k, v in env.C.items()}; oe.T = {k: v.numpy() for k, v in env.T.items()}
+    e0 = float(j1j2.J1J2(j1=1.0, j2=0.3).energy_2x2_1site_BP(st, env))
+    e3 = float(j1j2.J1J2(j1=1.0, j2=0.3, j3=0.7).energy_2x2_1site_BP(st, env))
+    nnnn = OJ.eval_nnnn_per_site(lambda cc, d, o1, g2, dist: O.corrf_1sO1sO(cc, d, ost, oe, o1, g2, dist), (0, 0))
+    assert abs((e3 - e0) - 0.7 * float(np.real(nnnn))) < 1e-12
+    # rotated plaquette term itself against the oracle
+    r = O.rdm2x2((0, 0), ost, oe)
+    assert abs(e0 - OJ.energy_1x1(r, 1.0, 0.3)) < 1e-12
+    # the chiral term needs a complex dtype (models/j1j2.py:97-98)
+    with pytest.raises(AssertionError):
+        j1j2.J1J2(j1=1.0, lmbd=0.5)
