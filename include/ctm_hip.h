@@ -101,6 +101,17 @@ int ctm_svd_symeig(ctm_ctx* ctx, const double* A, int n, int chi, const ctm_trun
 /* singular values of an n x n matrix, descending (ENV.get_spectra, env.py:204-209) */
 int ctm_svdvals(ctm_ctx* ctx, const double* M, int n, double* S);
 
+/* ---- adjoints of the two decompositions (first part of the backward pass; the adjoint of a whole move is not built) ------ */
+/* SVDGESDD.backward (linalg/svd_gesdd.py:209-328): A = U diag(S) V^H with U m x k, V n x k (k <= min(m,n); thin factors get the
+ * (1 - U U^H), (1 - V V^H) terms exactly as the reference), gradients gU, gS, gV (any may be NULL), regularisation eps (the
+ * reference's ad_decomp_reg, relative to S[0]); dA is m x n.  CTM_C128: complex factors / gradients, S and gS real. */
+int ctm_svd_backward(ctm_ctx* ctx, const double* U, const double* S, const double* V, const double* gU, const double* gS,
+                     const double* gV, int m, int n, int k, double eps, double* dA);
+/* SYMEIG.backward (linalg/eig_sym.py:57-75): A = U diag(D) U^H, U n x k; dA = U (diag(gD) + F o (U^H gU)) U^H with
+ * F_ij = x / (x^2 + reg), x = D_j - D_i; gD, gU may be NULL. */
+int ctm_eigh_backward(ctm_ctx* ctx, const double* D, const double* U, const double* gD, const double* gU, int n, int k, double reg,
+                      double* dA);
+
 /* ---- generic directional move units ---------------------------------------------------------------- */
 /* c2x2_{LU,RU,RD,LD}_sl_c (ctm_components.py:372-434,532-586,683-733,832-884).
  * adims = {p,Du,Dl,Dd,Dr}.  out: (chi*Dx^2) x (chi*Dy^2) [x p x p if open]. */

@@ -267,6 +267,50 @@ def truncated_svd_symeig(M, chi, abs_tol=1.0e-14, keep_multiplets=False, eps_mul
     return U[:, :k], S[:k], V[:, :k]
 
 
+def _safe_inverse(x, eps):
+    return x / (x ** 2 + eps)
+
+
+def svd_backward(U, S, V, gU, gS, gV, eps):
+    """SVDGESDD.backward (linalg/svd_gesdd.py:209-328): gradient of A = U diag(S) V^H; thin factors get the (1 - U U^H),
+    (1 - V V^H) terms, complex input the extra imaginary-diagonal term."""
+    m, k = U.shape
+    n = V.shape[0]
+    Uh, Vh = U.conj().T, V.conj().T
+    s0 = S[0]
+    sinv = np.where(np.abs(S) < s0 * eps, 0.0, 1.0 / np.where(S == 0, 1.0, S))            # safe_inverse_2
+    F = _safe_inverse(S[None, :] - S[:, None], s0 * eps); np.fill_diagonal(F, 0.0)
+    G = _safe_inverse(S[None, :] + S[:, None], s0 * eps); np.fill_diagonal(G, 0.0)
+    dA = np.zeros((m, n), dtype=U.dtype)
+    if gS is not None:
+        dA = dA + (U * gS[None, :]) @ Vh
+    if gU is not None:
+        t = U @ ((F + G) * (Uh @ gU - gU.conj().T @ U)) * 0.5
+        if m > k:
+            t = t + (np.eye(m) - U @ Uh) @ (gU * sinv[None, :])
+        dA = dA + t @ Vh
+    if gV is not None:
+        t = ((F - G) * (Vh @ gV - gV.conj().T @ V)) @ Vh * 0.5
+        if n > k:
+            t = t + sinv[:, None] * (gV.conj().T @ (np.eye(n) - V @ Vh))
+        dA = dA + U @ t
+    if np.iscomplexobj(U) and gU is not None:
+        L = 1j * np.imag(np.diag(Uh @ gU)) * sinv
+        dA = dA + (U * L[None, :]) @ Vh
+    return dA
+
+
+def eigh_backward(D, U, gD, gU, reg):
+    """SYMEIG.backward (linalg/eig_sym.py:57-75)."""
+    F = _safe_inverse(D[None, :] - D[:, None], reg); np.fill_diagonal(F, 0.0)
+    mid = np.zeros((U.shape[1], U.shape[1]), dtype=U.dtype)
+    if gD is not None:
+        mid = mid + np.diag(gD)
+    if gU is not None:
+        mid = mid + F * (U.conj().T @ gU)
+    return U @ mid @ U.conj().T
+
+
 # ----------------------------------------------------------------------------------
 # projectors (ctm/generic/ctm_projectors.py:142-293)
 # ----------------------------------------------------------------------------------

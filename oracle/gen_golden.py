@@ -486,6 +486,44 @@ def variants_check():
         print("corrf + transfer-operator spectrum ok:", name)
 
 
+def backward_case():
+    """f4 (first part): the reference's regularised SVD / eig backward (svd_gesdd.py:209-328, eig_sym.py:57-75) on seeded factors
+    and gradients, real and complex, square and thin -- pins oracle.svd_backward / eigh_backward; fixtures for the native kernels."""
+    from linalg.svd_gesdd import SVDGESDD
+    from linalg.eig_sym import SYMEIG
+    out = {}
+    rng = np.random.default_rng(77)
+
+    class Ctx:
+        diagnostics = None
+    for tag, cx, m, n, k in (("sq_f64", False, 24, 24, 24), ("thin_f64", False, 30, 26, 9), ("sq_c128", True, 20, 20, 20), ("thin_c128", True, 28, 22, 7)):
+        A = rng.standard_normal((m, n)) + (1j * rng.standard_normal((m, n)) if cx else 0.0)
+        U, S, Vh = np.linalg.svd(A, full_matrices=False)
+        U, S, V = U[:, :k], S[:k], Vh.conj().T[:, :k]
+        g = lambda r, c: rng.standard_normal((r, c)) + (1j * rng.standard_normal((r, c)) if cx else 0.0)
+        gU, gS, gV = g(m, k), rng.standard_normal(k), g(n, k)
+        eps = 1e-12
+        ctx = Ctx(); ctx.saved_tensors = (torch.from_numpy(U), torch.from_numpy(S), torch.from_numpy(V), torch.tensor(eps, dtype=torch.float64))
+        dA = t2n(SVDGESDD.backward(ctx, torch.from_numpy(gU), torch.from_numpy(gS), torch.from_numpy(gV))[0])
+        close(O.svd_backward(U, S, V, gU, gS, gV, eps), dA, 1e-12, f"svd backward {tag}")
+        for nm, v in (("U", U), ("S", S), ("V", V), ("gU", gU), ("gS", gS), ("gV", gV), ("dA", dA)):
+            out[f"svd_{tag}_{nm}"] = v
+    for tag, cx, n in (("f64", False, 18), ("c128", True, 16)):
+        H = rng.standard_normal((n, n)) + (1j * rng.standard_normal((n, n)) if cx else 0.0)
+        H = 0.5 * (H + H.conj().T)
+        D, U = np.linalg.eigh(H)
+        p = np.argsort(-np.abs(D), kind='stable'); D, U = D[p], U[:, p]
+        gD = rng.standard_normal(n)
+        gU = rng.standard_normal((n, n)) + (1j * rng.standard_normal((n, n)) if cx else 0.0)
+        ctx = Ctx(); ctx.saved_tensors = (torch.from_numpy(D), torch.from_numpy(U), torch.tensor(1e-12, dtype=torch.float64))
+        dA = t2n(SYMEIG.backward(ctx, torch.from_numpy(gD).to(torch.from_numpy(U).dtype) if False else torch.from_numpy(gD), torch.from_numpy(gU))[0])
+        close(O.eigh_backward(D, U, gD, gU, 1e-12), dA, 1e-12, f"eigh backward {tag}")
+        for nm, v in (("D", D), ("U", U), ("gD", gD), ("gU", gU), ("dA", dA)):
+            out[f"eig_{tag}_{nm}"] = v
+    np.savez_compressed(os.path.join(GOLD, "backward.npz"), **out)
+    print("  backward ok: svd (square, thin; f64, c128) and eigh (f64, c128) adjoints pinned against the reference")
+
+
 def input_files_case():
     """a18: the reference's own test-input DATA files (legacy "entries" format with aux_seq, "1D" format, multi-site cells with a
     pattern) copied as fixtures, next to the arrays the REFERENCE's read_ipeps / read_ipeps_c4v parse from them."""
@@ -518,7 +556,9 @@ def input_files_case():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["decomp", "generic", "c4v", "rvb", "files", "variants", "aklt", "inputs"]
+    which = sys.argv[1:] or ["decomp", "generic", "c4v", "rvb", "files", "variants", "aklt", "inputs", "backward"]
+    if "backward" in which:
+        backward_case()
     if "inputs" in which:
         input_files_case()
     if "aklt" in which:

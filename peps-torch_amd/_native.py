@@ -50,6 +50,9 @@ _SIGS = {
     "ctm_truncated_eigh": [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(TruncCfg), C.c_void_p, C.c_void_p],
     "ctm_svd_symeig": [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(TruncCfg), C.c_void_p, C.c_void_p, C.c_void_p],
     "ctm_svdvals": [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p],
+    "ctm_svd_backward": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                         C.c_double, C.c_void_p],
+    "ctm_eigh_backward": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_void_p],
     "ctm_c2x2": [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_void_p],
     "ctm_halves": [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_int), C.c_void_p, C.c_void_p],
     "ctm_projectors": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(TruncCfg), C.c_void_p, C.c_void_p, C.c_void_p],
@@ -350,6 +353,31 @@ class Engine:
         cfg = cfg or self.cfg(eps_multiplet=1e-12, keep_multiplets=False)
         self._ck(self.lib.ctm_svd_symeig(self.h, _ptr(A), n, chi, C.byref(cfg), _ptr(U), _ptr(S), _ptr(V)), "svd_symeig")
         return U, S, V
+
+    def svd_backward(self, U, S, V, gU=None, gS=None, gV=None, eps=1.0e-12):
+        """dA of A = U diag(S) V^H given the gradients on U, S, V (reference SVDGESDD.backward); thin factors allowed."""
+        U, V = self._bind(U, V)
+        m, k = U.shape
+        n = V.shape[0]
+        S = S.contiguous()
+        g = [None if t is None else (t.to(U.dtype) if i != 1 else t.to(torch.float64)).contiguous() for i, t in enumerate((gU, gS, gV))]
+        dA = self.empty(m, n)
+        opt = lambda t: _ptr(t) if t is not None else None
+        self._ck(self.lib.ctm_svd_backward(self.h, _ptr(U), _ptr(S), _ptr(V), opt(g[0]), opt(g[1]), opt(g[2]), m, n, k, float(eps), _ptr(dA)),
+                 "svd_backward")
+        return dA
+
+    def eigh_backward(self, D, U, gD=None, gU=None, reg=1.0e-12):
+        """dA of A = U diag(D) U^H given the gradients on D and U (reference SYMEIG.backward)."""
+        U = self._bind(U)
+        n, k = U.shape
+        D = D.contiguous()
+        gD = None if gD is None else gD.to(torch.float64).contiguous()
+        gU = None if gU is None else gU.to(U.dtype).contiguous()
+        dA = self.empty(n, n)
+        opt = lambda t: _ptr(t) if t is not None else None
+        self._ck(self.lib.ctm_eigh_backward(self.h, _ptr(D), _ptr(U), opt(gD), opt(gU), n, k, float(reg), _ptr(dA)), "eigh_backward")
+        return dA
 
     def svdvals(self, M):
         M = self._bind(M)

@@ -1,0 +1,20 @@
+"""Symmetric / Hermitian eigendecomposition with the reference's regularised backward (linalg/eig_sym.py:13-34 forward, :57-75
+backward) as a torch.autograd.Function on the native engine (forward: native Jacobi eigensolver, ordered by |D| descending;
+backward: ctm_eigh_backward)."""
+import torch
+from backend import get_engine
+
+
+class SYMEIG(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, A, ad_decomp_reg):
+        eng = get_engine()
+        D, U = eng.truncated_eigh(A.detach(), A.shape[0], eng.cfg(keep_multiplets=False))
+        ctx.save_for_backward(D, U)
+        ctx.reg = float(ad_decomp_reg)
+        return D, U
+
+    @staticmethod
+    def backward(ctx, dD, dU):
+        D, U = ctx.saved_tensors
+        return get_engine().eigh_backward(D, U, dD, dU, reg=ctx.reg), None

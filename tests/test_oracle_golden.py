@@ -169,3 +169,17 @@ def test_oracle_svd_symeig_identities():
     for nm, ch in (("a", 4), ("b", 6)):             # the multiplet back-off cases of the eig golden
         Ut, St, Vt = O.truncated_svd_symeig(H, ch, keep_multiplets=True, eps_multiplet=1e-12)
         assert np.abs(St - np.abs(g[f"eig_{nm}_D"])).max() < 1e-13 and ((St == 0) == (g[f"eig_{nm}_D"] == 0)).all()
+
+
+def test_oracle_backward_matches_reference_golden():
+    """oracle.svd_backward / eigh_backward vs the reference's SVDGESDD.backward / SYMEIG.backward outputs (tests/golden/backward.npz,
+    generated by oracle/gen_golden.py backward)."""
+    from oracle import ctm_oracle as O
+    g = golden("backward")
+    for tag in ("sq_f64", "thin_f64", "sq_c128", "thin_c128"):
+        a = {nm: g[f"svd_{tag}_{nm}"] for nm in ("U", "S", "V", "gU", "gS", "gV", "dA")}
+        dA = O.svd_backward(a["U"], a["S"], a["V"], a["gU"], a["gS"], a["gV"], 1e-12)
+        assert np.abs(dA - a["dA"]).max() < 1e-12 * np.abs(a["dA"]).max(), tag
+    for tag in ("f64", "c128"):
+        a = {nm: g[f"eig_{tag}_{nm}"] for nm in ("D", "U", "gD", "gU", "dA")}
+        assert np.abs(O.eigh_backward(a["D"], a["U"], a["gD"], a["gU"], 1e-12) - a["dA"]).max() < 1e-12 * np.abs(a["dA"]).max(), tag
