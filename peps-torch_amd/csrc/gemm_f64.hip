@@ -419,10 +419,6 @@ template <int TMW, bool BNF>
 __global__ __launch_bounds__(256, 3) void gemm_rows_kernel(StripParams p) {
     constexpr int BM = 16 * TMW, BN = 128, LDA = BM + PAD, LDB = BN + PAD;
     constexpr int NA = (BM * BK / 2 + 255) / 256;                 // d2 loads of A per thread per K tile (1 or 2)
-    // bank swizzle: odd k rows of the LDS images store column c at c ^ 16.  An MFMA operand read has its two k rows (lk, lk + 1)
-    // in one 32-lane LDS group; with the swizzle they read different 16-double halves = disjoint halves of the 64 banks, so the
-    // ds_read_b64 operand fetches are conflict free (without it: two-way conflicts on every operand read)
-    constexpr int SWA = (BM % 32 == 0) ? 16 : 0, SWB = 16;
     __shared__ __attribute__((aligned(16))) double smem[2 * BK * LDA + 2 * BK * LDB];
     double* As = smem;
     double* Bs = smem + 2 * BK * LDA;
@@ -432,20 +428,20 @@ __global__ __launch_bounds__(256, 3) void gemm_rows_kernel(StripParams p) {
     const int nk = (int)((std::min<long long>(p.K, kbeg + p.klen) - kbeg) / BK);
     if (nk <= 0) return;
 
-    const double* ap[NA]; int a_lds[NA], a_lds1[NA]; bool a_on[NA];
+    const double* ap[NA]; int a_lds[NA]; bool a_on[NA];
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
         const int u = tid + 256 * i, row = u >> 3, kp = u & 7;
         a_on[i] = row < BM;
         ap[i] = p.A + (long long)std::min(row, p.M - 1) * p.sam + kbeg + 2 * kp;
-        a_lds[i] = (2 * kp) * LDA + row; a_lds1[i] = (2 * kp + 1) * LDA + (row ^ SWA);
+        a_lds[i] = (2 * kp) * LDA + row;
     }
-    const double* bp[4]; int b_lds[4], b_lds1[4];
+    const double* bp[4]; int b_lds[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int u = tid + 256 * i;
-        if (BNF) { const int kk = u >> 6, np = u & 63; bp[i] = p.B + (kbeg + kk) * p.ldb + n0 + 2 * np; b_lds[i] = kk * LDB + ((2 * np) ^ ((kk & 1) ? SWB : 0)); b_lds1[i] = 0; }
-        else     { const int col = u >> 3, kp = u & 7; bp[i] = p.B + (long long)(n0 + col) * p.ldb + kbeg + 2 * kp; b_lds[i] = (2 * kp) * LDB + col; b_lds1[i] = (2 * kp + 1) * LDB + (col ^ SWB); }
+        if (BNF) { const int kk = u >> 6, np = u & 63; bp[i] = p.B + (kbeg + kk) * p.ldb + n0 + 2 * np; b_lds[i] = kk * LDB + 2 * np; }
+        else     { const int col = u >> 3, kp = u & 7; bp[i] = p.B + (long long)(n0 + col) * p.ldb + kbeg + 2 * kp; b_lds[i] = (2 * kp) * LDB + col; }
     }
     const long long b_step = BNF ? (long long)BK * p.ldb : BK;
 
@@ -463,11 +459,11 @@ __global__ __launch_bounds__(256, 3) void gemm_rows_kernel(StripParams p) {
         double* as = As + buf * BK * LDA;
         double* bs = Bs + buf * BK * LDB;
 #pragma unroll
-        for (int i = 0; i < NA; ++i) if (a_on[i]) { as[a_lds[i]] = ra[i][0]; as[a_lds1[i]] = ra[i][1]; }
+        for (int i = 0; i < NA; ++i) if (a_on[i]) { as[a_lds[i]] = ra[i][0]; as[a_lds[i] + LDA] = ra[i][1]; }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             if (BNF) *(d2*)(bs + b_lds[i]) = rb[i];
-            else { bs[b_lds[i]] = rb[i][0]; bs[b_lds1[i]] = rb[i][1]; }
+            else { bs[b_lds[i]] = rb[i][0]; bs[b_lds[i] + LDB] = rb[i][1]; }
         }
     };
     load_tile();
@@ -477,16 +473,15 @@ __global__ __launch_bounds__(256, 3) void gemm_rows_kernel(StripParams p) {
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
         if (kt + 1 < nk) load_tile();
-        const double* as = As + buf * BK * LDA;
-        const double* bs = Bs + buf * BK * LDB;
-        const int swa = (lk & 1) ? SWA : 0, swb = (lk & 1) ? SWB : 0;      // k = 4 k4 + lk: parity of the k row = parity of lk
+        const double* as = As + buf * BK * LDA + lr;
+        const double* bs = Bs + buf * BK * LDB + wn * 32 + lr;
 #pragma unroll
         for (int k4 = 0; k4 < BK / 4; ++k4) {
             double af[TMW], bf[2];
             const int kr = k4 * 4 + lk;
 #pragma unroll
-            for (int i = 0; i < TMW; ++i) af[i] = as[kr * LDA + ((i * 16 + lr) ^ swa)];
-            bf[0] = bs[kr * LDB + ((wn * 32 + lr) ^ swb)]; bf[1] = bs[kr * LDB + ((wn * 32 + 16 + lr) ^ swb)];
+            for (int i = 0; i < TMW; ++i) af[i] = as[kr * LDA + i * 16];
+            bf[0] = bs[kr * LDB]; bf[1] = bs[kr * LDB + 16];
 #pragma unroll
             for (int i = 0; i < TMW; ++i) {
                 acc[i][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[0], acc[i][0], 0, 0, 0);
