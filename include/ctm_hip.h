@@ -7,8 +7,8 @@
  * C-contiguous (row-major, as torch) float64 buffers unless stated otherwise; nothing is
  * retained after a call returns.  In a CTM_C128 context every tensor pointer (declared double* below)
  * addresses interleaved (re,im) complex128 elements exactly as torch stores them, all sizes/dims count
- * complex elements, and singular values / spectra / S outputs stay real; the C4v entry points and
- * ctm_truncated_eigh are float64 only (CTM_ERR_UNSUPPORTED).  Every function returns an int status (CTM_OK == 0) and
+ * complex elements, and singular values / eigenvalues / spectra / S outputs stay real (ctm_svd_symeig is float64 only:
+ * CTM_ERR_UNSUPPORTED in a CTM_C128 context).  Every function returns an int status (CTM_OK == 0) and
  * records a message retrievable with ctm_last_error().  One ctm_ctx is used by one host
  * thread at a time; work is enqueued on the context's HIP stream and the call returns after
  * enqueueing unless it needs a host decision (truncation logic), in which case it syncs.

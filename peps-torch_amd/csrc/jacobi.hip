@@ -1846,10 +1846,11 @@ int svd_lanczos_c(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* Ut, d
     const size_t rows_max = (size_t)jmax * b, bn = (size_t)b * n;
     // planar bases: re plane [rows][n], im plane at +plane
     const size_t planeU = rows_max * n, planeV = (rows_max + b) * n;
-    double *Uall, *Vall, *Zraw, *G, *T2, *norms, *inv;
+    double *Uall, *Vall, *Zraw, *Wraw, *G, *T2, *norms, *inv;
     CTM_TRY(arena_alloc(ctx, sizeof(double) * 2 * planeU, (void**)&Uall));
     CTM_TRY(arena_alloc(ctx, sizeof(double) * 2 * planeV, (void**)&Vall));
-    CTM_TRY(arena_alloc(ctx, sizeof(double) * 2 * planeU, (void**)&Zraw));
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * 2 * planeU, (void**)&Zraw));         // raw products U_j M
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * 2 * planeU, (void**)&Wraw));         // raw products V_j M^H
     CTM_TRY(arena_alloc(ctx, sizeof(double) * 2 * (size_t)b * (rows_max + b), (void**)&G));
     CTM_TRY(arena_alloc(ctx, sizeof(double) * 2 * bn, (void**)&T2));
     CTM_TRY(arena_alloc(ctx, sizeof(double) * std::max<size_t>(rows_max, 1024), (void**)&norms));
@@ -1857,6 +1858,21 @@ int svd_lanczos_c(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* Ut, d
     auto Ur = [&](int j) { CRows r{Uall + (size_t)j * bn, Uall + planeU + (size_t)j * bn}; return r; };
     auto Vr = [&](int j) { CRows r{Vall + (size_t)j * bn, Vall + planeV + (size_t)j * bn}; return r; };
     auto Zr = [&](int j) { CRows r{Zraw + (size_t)j * bn, Zraw + planeU + (size_t)j * bn}; return r; };
+    auto Wr = [&](int j) { CRows r{Wraw + (size_t)j * bn, Wraw + planeU + (size_t)j * bn}; return r; };
+    const double tol = resid_tol(ctx, n);
+    // scheduling of the Ritz extractions: see svd_lanczos()
+    double hdr[HDR_WORDS] = {0.0, 0.0, 0.0};
+    if (op.warm_hdr) {
+        CTM_HIP_CHECK(ctx, hipMemcpyAsync(hdr, op.warm_hdr, sizeof(hdr), hipMemcpyDeviceToHost, ctx->stream));
+        CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    int jnext;
+    if (ctx->lz_first > 0) jnext = ctx->lz_first;
+    else if (hdr[HDR_STEPS] >= jmin && hdr[HDR_STEPS] <= jmax && hdr[HDR_EST] > 0.0)
+        jnext = (int)hdr[HDR_STEPS] + (hdr[HDR_EST] <= tol / 30.0 ? -1 : (hdr[HDR_EST] > tol / 3.0 ? 1 : 0));
+    else jnext = (int)std::ceil(ctx->lz_first_factor * k / b);
+    jnext = std::max(jmin, std::min(jnext, jmax));
+    double est_prev = 0.0; int steps_prev = 0;
     double mn, mx, s0 = 0.0;
     bool ok;
     CTM_LAUNCH(ctx, hash_fill_kernel, dim3(1024), dim3(256), 0, Vall, b, n, (long long)n, 0x51f15eedULL);
@@ -1865,8 +1881,10 @@ int svd_lanczos_c(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* Ut, d
     if (!ok) return CTM_OK;
     int applications = 0;
     for (int j = 0; j < jmax; ++j) {
-        const CRows Uj = Ur(j), Vj = Vr(j), Vn = Vr(j + 1), Zj = Zr(j);
-        CTM_TRY(matop_apply_planar(ctx, op, true, Vj.re, Vj.im, b, Uj.re, Uj.im)); applications += b;
+        const CRows Uj = Ur(j), Vj = Vr(j), Vn = Vr(j + 1), Zj = Zr(j), Wj = Wr(j);
+        CTM_TRY(matop_apply_planar(ctx, op, true, Vj.re, Vj.im, b, Wj.re, Wj.im)); applications += b;
+        CTM_HIP_CHECK(ctx, hipMemcpyAsync(Uj.re, Wj.re, sizeof(double) * bn, hipMemcpyDeviceToDevice, ctx->stream));
+        CTM_HIP_CHECK(ctx, hipMemcpyAsync(Uj.im, Wj.im, sizeof(double) * bn, hipMemcpyDeviceToDevice, ctx->stream));
         CTM_TRY(project_out_c(ctx, Uj, b, n, Uall, Uall + planeU, j * b, G, T2));
         CTM_TRY(orthonormalise_block_c(ctx, Uj, n, norms, inv, &mn, &mx, &ok));
         s0 = std::max(s0, mx);
@@ -1877,9 +1895,8 @@ int svd_lanczos_c(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* Ut, d
         CTM_TRY(project_out_c(ctx, Vn, b, n, Vall, Vall + planeV, (j + 1) * b, G, T2));
         CTM_TRY(orthonormalise_block_c(ctx, Vn, n, norms, inv, &mn, &mx, &ok));
         if (!ok || mn <= 1e-13 * s0) { if (ctx->jacobi_verbose) fprintf(stderr, "[lz-c] n=%d breakdown at step %d (V)\n", n, j); return CTM_OK; }
-        const int m = (j + 1) * b;
-        const int jfirst = std::max(jmin, (4 * k + b - 1) / b);
-        if ((j + 1 < jfirst || ((j + 1 - jfirst) & 1)) && j + 1 < jmax) continue;
+        const int steps = j + 1, m = steps * b;
+        if (steps < jnext && steps < jmax) continue;
         ArenaScope rs(ctx);
         const int kq = std::min(k, m);
         const size_t mm = (size_t)m * m, mb = (size_t)m * b, km = (size_t)kq * m, kb = (size_t)kq * b;
@@ -1895,6 +1912,7 @@ int svd_lanczos_c(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* Ut, d
         CTM_TRY(xgemm(ctx, m, m, n, z, vh, T, T + mm, m));                           // T = (U_all M) V_all^H
         CTM_TRY(xgemm(ctx, m, b, n, z, vnh, E, E + mb, b));                          // E = (U_all M) V_{j+1}^H
         CTM_TRY(svd_full_c(ctx, T, T + mm, m, kq, Ss, Xt, Yt));                      // T = Xt^H diag(Ss) Yt
+        ctx->lz_extractions += 1;
         XM x{Xt, Xt + km, m, false, false}, e{E, E + mb, b, false, false};
         CTM_TRY(xgemm(ctx, kq, b, m, x, e, XE, XE + kb, b));
         CTM_TRY(row_norms_c128(ctx, XE, XE + kb, kq, b, b, rn));
@@ -1905,36 +1923,65 @@ int svd_lanczos_c(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* Ut, d
         int kv = 0;
         while (kv < kq && hs[kv] > ctx->rank_tol * hs[0]) ++kv;
         const double est = *std::max_element(hr.begin(), hr.begin() + std::max(kv, 1));
-        if (ctx->jacobi_verbose) fprintf(stderr, "[lz-c] n=%d step %d basis %d  s0=%.3e  residual estimate/s0 = %.3e\n", n, j + 1, m, hs[0], est / hs[0]);
-        if (kq < k || (est > resid_tol(ctx, n) * hs[0] && j + 1 < jmax)) continue;
-        // Ritz triplets (rows u^H, v^H) and the check of both relations with the operator
+        if (ctx->jacobi_verbose) fprintf(stderr, "[lz-c] n=%d step %d basis %d  s0=%.3e  residual estimate/s0 = %.3e\n", n, steps, m, hs[0], est / hs[0]);
+        if (kq < k || (est > tol * hs[0] && steps < jmax)) {
+            double rate = 0.15;
+            if (est_prev > 0.0 && est < est_prev) rate = std::min(0.6, std::max(1e-3, std::pow(est / est_prev, 1.0 / (steps - steps_prev))));
+            int need = (kq < k) ? jmin - steps : (int)std::ceil(std::log(0.5 * tol * hs[0] / est) / std::log(rate));
+            need = std::max(1, std::min(need, 4));
+            if (ctx->lz_stride > 0) need = ctx->lz_stride;
+            jnext = std::min(jmax, steps + need);
+            est_prev = est; steps_prev = steps;
+            continue;
+        }
+        // Ritz triplets (rows u^H, v^H); both relations checked on the returned rows from the stored raw products (see svd_lanczos())
         const size_t kn = (size_t)k * n;
         XM y{Yt, Yt + km, m, false, false}, ua{Uall, Uall + planeU, n, false, false}, va{Vall, Vall + planeV, n, false, false};
         CTM_TRY(xgemm(ctx, k, n, m, x, ua, Ut, Ut + kn, n));
         CTM_TRY(xgemm(ctx, k, n, m, y, va, Vt, Vt + kn, n));
         CTM_TRY(reorth_rows_c(ctx, Ut, k, n, 1));
         CTM_TRY(reorth_rows_c(ctx, Vt, k, n, 1));
-        double *C1, *res;
+        double *C1, *res, *Xc;
         CTM_TRY(arena_alloc(ctx, sizeof(double) * 2 * kn, (void**)&C1));
         CTM_TRY(arena_alloc(ctx, sizeof(double) * 2 * k, (void**)&res));
-        double worst = 0.0;
+        CTM_TRY(arena_alloc(ctx, sizeof(double) * 2 * (size_t)k * m, (void**)&Xc));
+        double worst = 0.0, worst_op = 0.0;
         std::vector<double> r1(2 * k);
-        for (int rel = 0; rel < 2; ++rel) {        // rel 0: Ut M = S Vt ; rel 1: Vt M^H = S Ut
-            const double* src = rel == 0 ? Ut : Vt; const double* dst = rel == 0 ? Vt : Ut;
-            CTM_TRY(matop_apply_planar(ctx, op, rel == 1, src, src + kn, k, C1, C1 + kn)); applications += k;
+        auto resid = [&](const double* dst, double* acc) -> int {
             CTM_LAUNCH(ctx, resid_rows_kernel, dim3((k + 3) / 4), dim3(256), 0, C1, (long long)n, dst, (long long)n, Ss, k, n, res);
             CTM_LAUNCH(ctx, resid_rows_kernel, dim3((k + 3) / 4), dim3(256), 0, C1 + kn, (long long)n, dst + kn, (long long)n, Ss, k, n, res + k);
             CTM_HIP_CHECK(ctx, hipMemcpyAsync(r1.data(), res, sizeof(double) * 2 * k, hipMemcpyDeviceToHost, ctx->stream));
             CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-            for (int i = 0; i < std::max(kv, 1); ++i) worst = std::max(worst, std::sqrt(r1[i] * r1[i] + r1[k + i] * r1[k + i]));
+            for (int i = 0; i < std::max(kv, 1); ++i) *acc = std::max(*acc, std::sqrt(r1[i] * r1[i] + r1[k + i] * r1[k + i]));
+            return CTM_OK;
+        };
+        for (int rel = 0; rel < 2; ++rel) {        // rel 0: Ut M = S Vt ; rel 1: Vt M^H = S Ut
+            const double* src = rel == 0 ? Ut : Vt; const double* dst = rel == 0 ? Vt : Ut;
+            XM f{src, src + kn, n, false, false};
+            XM bh = rel == 0 ? XM{Uall, Uall + planeU, n, true, true} : XM{Vall, Vall + planeV, n, true, true};
+            XM pr = rel == 0 ? XM{Zraw, Zraw + planeU, n, false, false} : XM{Wraw, Wraw + planeU, n, false, false};
+            CTM_TRY(xgemm(ctx, k, m, n, f, bh, Xc, Xc + (size_t)k * m, m));               // coordinates of the returned rows in the basis
+            XM xc{Xc, Xc + (size_t)k * m, m, false, false};
+            CTM_TRY(xgemm(ctx, k, n, m, xc, pr, C1, C1 + kn, n));
+            CTM_TRY(resid(dst, &worst));
+            if (ctx->lz_verify_op) {
+                CTM_TRY(matop_apply_planar(ctx, op, rel == 1, src, src + kn, k, C1, C1 + kn)); applications += k;
+                CTM_TRY(resid(dst, &worst_op));
+            }
         }
-        if (ctx->jacobi_verbose) fprintf(stderr, "[lz-c] n=%d verified residual/s0 = %.3e after %d row applications\n", n, worst / hs[0], applications);
+        if (ctx->jacobi_verbose) {
+            fprintf(stderr, "[lz-c] n=%d verified residual/s0 = %.3e after %d row applications", n, worst / hs[0], applications);
+            if (ctx->lz_verify_op) fprintf(stderr, "  (with operator applications: %.3e)", worst_op / hs[0]);
+            fprintf(stderr, "\n");
+        }
+        if (ctx->lz_verify_op) worst = std::max(worst, worst_op);
         ctx->lz_last_resid = worst / hs[0];
-        if (worst > resid_tol(ctx, n) * hs[0] && worst <= 1e-11 * hs[0] && est <= resid_tol(ctx, n) * hs[0]) {
-            ctx->lz_hits += 1; ctx->lz_total_steps += j + 1;
+        ctx->lz_last_est = est / hs[0]; ctx->lz_last_steps = steps;
+        if (worst > tol * hs[0] && worst <= 1e-11 * hs[0] && est <= tol * hs[0]) {
+            ctx->lz_hits += 1; ctx->lz_total_steps += steps;
             return CTM_OK;          // the caller polishes with a warm-started subspace pass
         }
-        if (worst <= resid_tol(ctx, n) * hs[0]) {
+        if (worst <= tol * hs[0]) {
             CTM_HIP_CHECK(ctx, hipMemcpyAsync(S, Ss, sizeof(double) * k, hipMemcpyDeviceToDevice, ctx->stream));
             if (kv < k) {
                 CTM_TRY(fill_f64(ctx, S + kv, (size_t)(k - kv), 0.0));
@@ -1943,11 +1990,18 @@ int svd_lanczos_c(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* Ut, d
                     CTM_TRY(fill_f64(ctx, Vt + pl * kn + (size_t)kv * n, (size_t)(k - kv) * n, 0.0));
                 }
             }
+            if (op.warm_hdr) {
+                CTM_TRY(fill_f64(ctx, op.warm_hdr + HDR_STEPS, 1, (double)steps));
+                CTM_TRY(fill_f64(ctx, op.warm_hdr + HDR_EST, 1, std::max(est / hs[0], 1e-300)));
+            }
             CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
             *converged = true;
-            ctx->lz_hits += 1; ctx->lz_total_steps += j + 1;
+            ctx->lz_hits += 1; ctx->lz_total_steps += steps;
             return CTM_OK;
         }
+        if (steps >= jmax) break;
+        jnext = std::min(jmax, steps + 2);
+        est_prev = 0.0;
     }
     return CTM_OK;
 }
@@ -1965,7 +2019,20 @@ int jacobi_svd_top_op(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* U
     if (op.Mi || op.ci[0]) {        // complex128
         if (Ut && Vt && ctx->si_enable && k < n && n >= ctx->si_min_n) {
             bool ok = false, krylov = false;
-            CTM_TRY(svd_iter_c(ctx, op, k, S, Ut, Vt, &ok, &krylov));
+            MatOp op1 = op;
+            if (op.warm_hdr && ctx->lz_enable && k >= ctx->lz_min_k) {      // direct Krylov entry of a full-rank unit, see the real branch below
+                double hdr[HDR_WORDS];
+                CTM_HIP_CHECK(ctx, hipMemcpyAsync(hdr, op.warm_hdr, sizeof(hdr), hipMemcpyDeviceToHost, ctx->stream));
+                CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+                if (hdr[HDR_SKIP] >= 1.0 && hdr[HDR_STEPS] >= 1.0) {
+                    CTM_TRY(fill_f64(ctx, op.warm_hdr, 1, hdr[HDR_SKIP] - 1.0)); ctx->si_warm_skips += 1;
+                    ctx->lz_last_resid = 1.0;
+                    CTM_TRY(svd_lanczos_c(ctx, op, k, S, Ut, Vt, &ok));
+                    if (ok) return keep_warm();
+                    op1.warm = nullptr; op1.warm_hdr = nullptr;
+                }
+            }
+            CTM_TRY(svd_iter_c(ctx, op1, k, S, Ut, Vt, &ok, &krylov));
             if (ok) { ctx->si_hits += 1; return keep_warm(); }
             if (krylov) {
                 ctx->lz_last_resid = 1.0;
