@@ -1413,8 +1413,18 @@ __global__ __launch_bounds__(64) void chol64_inv_kernel(const double* G, double*
     __syncthreads();
     double pmin = 1e300;
     for (int j = 0; j < M; ++j) {
-        double dot = 0.0, pd = 0.0;
-        for (int t = 0; t < j; ++t) { const double ljt = L[j][t]; dot += L[i][t] * ljt; pd += ljt * ljt; }
+        // the LDS reads do not depend on the accumulators: eight iterations' loads are issued together (four accumulator chains)
+        double dot0 = 0.0, dot1 = 0.0, pd0 = 0.0, pd1 = 0.0;
+        int t = 0;
+        for (; t + 8 <= j; t += 8) {
+            double a[8], b[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { a[u] = L[i][t + u]; b[u] = L[j][t + u]; }
+#pragma unroll
+            for (int u = 0; u < 8; u += 2) { dot0 += a[u] * b[u]; dot1 += a[u + 1] * b[u + 1]; pd0 += b[u] * b[u]; pd1 += b[u + 1] * b[u + 1]; }
+        }
+        for (; t < j; ++t) { const double ljt = L[j][t]; dot0 += L[i][t] * ljt; pd0 += ljt * ljt; }
+        const double dot = dot0 + dot1, pd = pd0 + pd1;
         const double p = L[j][j] - pd;
         pmin = fmin(pmin, p);
         const double l = sqrt(fmax(p, 1e-300));
@@ -1424,10 +1434,18 @@ __global__ __launch_bounds__(64) void chol64_inv_kernel(const double* G, double*
         __syncthreads();
     }
     const int c = i;
-    for (int r = 0; r < M; ++r) {
-        double acc = (r == c) ? 1.0 : 0.0;
-        for (int t = c; t < r; ++t) acc -= L[r][t] * X[t][c];
-        X[r][c] = (r >= c) ? acc / L[r][r] : 0.0;
+    for (int r = 0; r < M; ++r) {       // X[t][c] = 0 for t < c: the sum may start at 0 for every thread (uniform trip count)
+        double acc0 = (r == c) ? 1.0 : 0.0, acc1 = 0.0;
+        int t = 0;
+        for (; t + 8 <= r; t += 8) {
+            double a[8], b[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { a[u] = L[r][t + u]; b[u] = X[t + u][c]; }
+#pragma unroll
+            for (int u = 0; u < 8; u += 2) { acc0 -= a[u] * b[u]; acc1 -= a[u + 1] * b[u + 1]; }
+        }
+        for (; t < r; ++t) acc0 -= L[r][t] * X[t][c];
+        X[r][c] = (r >= c) ? (acc0 + acc1) / L[r][r] : 0.0;
     }
     for (int r = 0; r < M; ++r) Linv[r * M + c] = X[r][c];
     if (i == 0) status[0] = pmin;
