@@ -70,12 +70,15 @@ def apply_TM_1sO(coord, direction, state, env, edge, op=None, verbosity=0):
 
 
 def corrf_1sO1sO(coord, direction, state, env, op1, get_op2, dist, rl_0=None, verbosity=0):
-    """<O1(0) O2(r)> for r = 1..dist+1 along `direction` (reference corrf.py:980-1067, same normalisation steps)."""
-    if rl_0 is not None:
-        raise NotImplementedError("corrf_1sO1sO: user-supplied boundary vectors are not supported")
+    """<O1(0) O2(r)> for r = 1..dist+1 along `direction` (reference corrf.py:980-1067, same normalisation steps).
+    rl_0 = (right(c), left(c)): optional functions returning the rank-3 boundary edges at coordinate c (typically leading
+    eigenvectors of the transfer operator) used instead of the corner-T-corner edges."""
+    eng = get_engine()
     c0 = coord
     rev = (-direction[0], -direction[1])
-    E0 = get_edge(c0, rev, state, env)
+    E0 = get_edge(c0, rev, state, env) if rl_0 is None else rl_0[0](c0).contiguous()
+    close = (lambda c, v: apply_edge(c, direction, state, env, v)) if rl_0 is None else \
+        (lambda c, v: eng.einsum("abc,abc->", v.contiguous(), rl_0[1](c).contiguous()))
     E1 = apply_TM_1sO(c0, direction, state, env, E0, op=op1)
     E0 = apply_TM_1sO(c0, direction, state, env, E0)
     corrf = torch.empty(dist + 1, dtype=state.dtype, device=state.device)
@@ -84,7 +87,7 @@ def corrf_1sO1sO(coord, direction, state, env, op1, get_op2, dist, rl_0=None, ve
         E12 = apply_TM_1sO(c0, direction, state, env, E1, op=get_op2(r))
         E0 = apply_TM_1sO(c0, direction, state, env, E0)
         E1 = apply_TM_1sO(c0, direction, state, env, E1)
-        corrf[r] = apply_edge(c0, direction, state, env, E12) / apply_edge(c0, direction, state, env, E0)
+        corrf[r] = close(c0, E12) / close(c0, E0)
         m = E0.abs().max()
         E0 = E0 / m
         E1 = E1 / m

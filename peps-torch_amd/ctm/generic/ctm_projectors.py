@@ -10,6 +10,20 @@ from ctm.generic.ctm_components import _halves, _halves_t, _HALVES, _corner
 SVD_METHODS = ['DEFAULT', 'GESDD', 'GESDD_CPU', 'ARP', 'PROPACK', 'RSVD', 'RSVD_CUSTOM', 'QR']
 
 
+_noted = set()
+
+
+def _note_method(name):
+    """The reference's alternative truncation routes (ARPACK, PROPACK, randomised, QR) are names for ONE native engine here; say
+    so once instead of aliasing silently."""
+    if name not in ('DEFAULT', 'GESDD', 'GESDD_CPU') and name not in _noted:
+        _noted.add(name)
+        import warnings
+        warnings.warn(f"projector_svd_method={name}: executed by the native truncation engine (leading-chi iteration / block "
+                      "Krylov / full Jacobi chosen by the spectrum, full-SVD semantics); the reference's method-specific "
+                      "parameters are not used", stacklevel=3)
+
+
 def _trunc_cfg(eng, ctm_args):
     return eng.cfg(svd_reltol=ctm_args.projector_svd_reltol, eps_multiplet=ctm_args.projector_eps_multiplet,
                    multiplet_abstol=ctm_args.projector_multiplet_abstol, keep_multiplets=True)
@@ -21,6 +35,7 @@ def ctm_get_projectors_4x4(direction, coord, state, env, ctm_args=cfg.ctm_args, 
         raise ValueError("Invalid direction: " + str(direction))
     if ctm_args.projector_svd_method not in SVD_METHODS:
         raise ValueError(f"Projector svd method \"{ctm_args.projector_svd_method}\" not implemented")
+    _note_method(ctm_args.projector_svd_method)
     eng = get_engine()
     if hasattr(eng, "projectors_4x4"):
         # fused native path: corners -> implicit M = R^T Rt -> P, Pt (halves never materialised).  The environment

@@ -230,3 +230,24 @@ def test_energy_1site_BP_includes_j3_and_chiral_terms(cpu_cfg):
     # the chiral term needs a complex dtype (models/j1j2.py:97-98)
     with pytest.raises(AssertionError):
         j1j2.J1J2(j1=1.0, lmbd=0.5)
+
+
+def test_corrf_with_user_supplied_boundary_edges(cpu_cfg):
+    """corrf_1sO1sO(..., rl_0=(right, left)) (reference corrf.py:980-1067): with the corner-T-corner edges passed explicitly the
+    result equals the default; with rescaled edges it is unchanged (the ratio E12/E00 is scale invariant)."""
+    from ipeps.ipeps import IPEPS
+    from ctm.generic.env import ENV, init_env
+    from ctm.generic import ctmrg, corrf
+    from oracle import j1j2_oracle as OJ
+    g = golden("generic_D2_chi8_f64")
+    st = IPEPS({k: torch.from_numpy(v.copy()) for k, v in sites_from(g).items()})
+    env = ENV(8, st); init_env(st, env)
+    for d in cpu_cfg.ctm_args.ctm_move_sequence:
+        ctmrg.ctm_MOVE(d, st, env)
+    I, sz, sp, sm = (torch.from_numpy(x) for x in OJ.su2_ops(2))
+    for d in ((1, 0), (0, 1)):
+        rev = (-d[0], -d[1])
+        ref = corrf.corrf_1sO1sO((0, 0), d, st, env, sz, lambda r: sz, 3)
+        rl = (lambda c: corrf.get_edge(c, rev, st, env), lambda c: 2.5 * corrf.get_edge(c, d, st, env))
+        got = corrf.corrf_1sO1sO((0, 0), d, st, env, sz, lambda r: sz, 3, rl_0=rl)
+        assert float((got - ref).abs().max()) < 1e-13
