@@ -239,9 +239,19 @@ __global__ __launch_bounds__(1024) void small_eig_kernel(SmallEigParams p) {
 // m = 64 variant with ONE barrier per round: the matrix ping-pongs between two LDS images, every thread derives the two
 // rotations it needs (row pair k1, column pair k2) itself from the source image -- bitwise identical on all threads that share
 // a pair -- transforms its own 2x2 block into the other image and its two eigenvector rows in place.  1024 threads.
+// round-robin pairing of M = 64 indices: round r (0..62), slot k (0..31) -> the pair (p < q); same schedule as the table the
+// other kernels build, computed instead of read (six LDS byte loads per thread and round less)
+__device__ __forceinline__ void rr_pair64(int r, int k, int& p, int& q) {
+    int a = r + k; a = (a >= 63) ? a - 63 : a;
+    int b = r - k + 63; b = (b >= 63) ? b - 63 : b;
+    if (k == 0) { a = 63; b = r; }
+    p = min(a, b); q = max(a, b);
+}
+
 __device__ __forceinline__ void jacobi_cs(double a, double b, double g, double tol, double tau2, double& c, double& s, bool& rot) {
     c = 1.0; s = 0.0; rot = false;
-    if (g != 0.0 && fabs(g) > tol * fmax(sqrt(fabs(a * b)), tau2)) {
+    // |g| > tol * max(sqrt|a b|, tau2)  <=>  g^2 > tol^2 * max(|a b|, tau2^2): no square root on the critical path
+    if (g != 0.0 && g * g > tol * tol * fmax(fabs(a * b), tau2 * tau2)) {
         const double d = b - a, g2 = 2.0 * g;
         const double hh = d * d + g2 * g2;
         double rh = __builtin_amdgcn_rsq(hh);
@@ -266,7 +276,6 @@ __global__ __launch_bounds__(1024 / BPT) void small_eig64_kernel(SmallEigParams 
     __shared__ double Jm[M][M + 1];
     __shared__ double red[16];
     __shared__ int rot_flag;
-    __shared__ unsigned char pair_tab[M - 1][H][2];
     __shared__ int rank_of[M];
     const int tid = threadIdx.x;
     const double* G = p.G + (size_t)blockIdx.x * M * M;
@@ -320,14 +329,6 @@ __global__ __launch_bounds__(1024 / BPT) void small_eig64_kernel(SmallEigParams 
         if (srel <= p.tol) { if (tid == 0) p.flags[blockIdx.x] = 0; return; }
         if (tid == 0) p.flags[blockIdx.x] = 1;
     }
-    for (int q = tid; q < (M - 1) * H; q += NTH) {
-        const int r = q / H, k = q - r * H;
-        int pi, qi;
-        if (k == 0) { pi = M - 1; qi = r % (M - 1); }
-        else { pi = (r + k) % (M - 1); qi = (r - k + (M - 1)) % (M - 1); }
-        if (pi > qi) { const int t = pi; pi = qi; qi = t; }
-        pair_tab[r][k][0] = (unsigned char)pi; pair_tab[r][k][1] = (unsigned char)qi;
-    }
     if (tid == 0) rot_flag = 0;
     __syncthreads();
     const int k2 = tid & 31, kb = tid >> 5;          // column pair; first of the BPT row pairs kb, kb + KS, ...
@@ -336,14 +337,15 @@ __global__ __launch_bounds__(1024 / BPT) void small_eig64_kernel(SmallEigParams 
         for (int r = 0; r < M - 1; ++r) {
             const double (*S)[M + 1] = Wb[par];
             double (*D)[M + 1] = Wb[par ^ 1];
-            const int p2 = pair_tab[r][k2][0], q2 = pair_tab[r][k2][1];
+            int p2, q2;
+            rr_pair64(r, k2, p2, q2);
             const double a2 = S[p2][p2], d2 = S[q2][q2], g2 = S[p2][q2];
             int p1[BPT], q1[BPT];
             double b00[BPT], b01[BPT], b10[BPT], b11[BPT], jp0[BPT], jq0[BPT], jp1[BPT], jq1[BPT];
 #pragma unroll
             for (int u = 0; u < BPT; ++u) {
                 const int k1 = kb + u * KS;
-                p1[u] = pair_tab[r][k1][0]; q1[u] = pair_tab[r][k1][1];
+                rr_pair64(r, k1, p1[u], q1[u]);
                 b00[u] = S[p1[u]][p2]; b01[u] = S[p1[u]][q2]; b10[u] = S[q1[u]][p2]; b11[u] = S[q1[u]][q2];
                 jp0[u] = Jm[k1][p2]; jq0[u] = Jm[k1][q2]; jp1[u] = Jm[k1 + 32][p2]; jq1[u] = Jm[k1 + 32][q2];
             }

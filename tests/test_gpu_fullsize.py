@@ -283,3 +283,31 @@ def test_whole_move_of_the_complex_config_at_full_size(eng):
     for k in a:
         assert float((a[k] - c[k]).abs().max()) < 1e-12, k
     eng.trim()
+
+
+def test_one_part_of_rdm2x2_of_the_complex_config_at_full_size(eng):
+    """BASELINE configs[4] (n = 24576, complex128): the plaquette RDM does not fit one GPU at once (241 GB of open halves); it is
+    evaluated in parts (ctm_rdm2x2_part: ranges of lower-half slices, shared by a rank group or looped over on one GPU).  One part
+    at full size: the block R[(s0 t0 s1 t1), cl = 0] (lower sites projected on |0><0|) is a Hermitian, positive matrix in
+    (s0 s1),(t0 t1), and it equals the corresponding block computed with a two-slice range."""
+    from ctm.generic.env import ENV, init_env
+    from ctm.generic.ctm_components import _corner_t, LU, RU, RD, LD
+    torch.cuda.empty_cache()
+    free, _ = torch.cuda.mem_get_info()
+    if free < 200e9:
+        pytest.skip("needs ~130 GB of free HBM")
+    chi, D = 384, 8
+    st = _state(D, 4, cplx=True)
+    env = ENV(chi, st); init_env(st, env)
+    t = _corner_t(LU, (0, 0), st, env) + _corner_t(RU, (1, 0), st, env) + _corner_t(RD, (1, 1), st, env) + _corner_t(LD, (0, 1), st, env)
+    r0 = eng.rdm2x2_part(t, 0, 1)                       # (16, 1): [(s0 t0 s1 t1), cl = 0]
+    m = r0.reshape(2, 2, 2, 2).permute(0, 2, 1, 3).reshape(4, 4)            # [(s0 s1), (t0 t1)]
+    tr = torch.trace(m)
+    assert abs(float(tr.imag)) < 1e-12 * abs(float(tr.real)) and float(tr.real) > 0
+    m = m / tr
+    assert float((m - m.conj().T).abs().max()) < 1e-12
+    assert float(torch.linalg.eigvalsh(0.5 * (m + m.conj().T).cpu()).min()) > -1e-12
+    eng.trim(); torch.cuda.empty_cache()
+    r01 = eng.rdm2x2_part(t, 0, 2)
+    assert float((r01[:, :1] - r0).abs().max()) < 1e-12 * float(r0.abs().max())
+    eng.trim()
