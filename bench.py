@@ -274,11 +274,17 @@ def run_workload(args, eng, dev, kind, D, chi, dtype, signed, steps, warmup, wor
     eng.timers(reset=True)
     if args.profile:
         eng.set_option("profile", 1)
+    step_ms = []
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
+        if kind == "c4v":                 # ms-scale steps: per-step wall times (the sync costs ~10 us) for the steady-state figure
+            torch.cuda.synchronize()
+            step_ms.append(time.perf_counter())
     fence()
     dt = time.perf_counter() - t0
+    if step_ms:
+        step_ms = [1e3 * (b - a) for a, b in zip([t0] + step_ms[:-1], step_ms)]
     ivals = eng.gemm_intervals()
     KK = range(5)
     k_ms = [eng.stat(f"k_ms{i}") for i in KK]
@@ -337,6 +343,15 @@ def run_workload(args, eng, dev, kind, D, chi, dtype, signed, steps, warmup, wor
     out = {"value": steps / dt, "ms_per_step": 1e3 * dt / steps, "steps": steps, "warmup": warmup, "roofline": roof, "svd": svd,
            "phase_s": {k: round(v, 4) for k, v in phase.items()},
            "phase_s_note": "device time per phase from HIP events on the engines' streams, summed over concurrent streams (not wall time)"}
+    if step_ms:
+        srt = sorted(step_ms)
+        med = srt[len(srt) // 2]
+        out["steady_state"] = {"ms_per_step_median": round(med, 4), "sweeps_per_sec_at_median": round(1e3 / med, 1),
+                               "ms_per_step_first": round(step_ms[0], 3), "ms_per_step_max": round(srt[-1], 3),
+                               "warm_restarts_accepted": int(eng.stat("eigh_warm_hits")), "warm_restarts_rejected_by_probe": int(eng.stat("eigh_warm_rejects")),
+                               "note": "`value` is the mean over all timed sweeps, including the first ones after the warm-up in which the environment still moves "
+                                       "and the eigensolver iterates from the previous subspace; once the enlarged corner is stationary to the residual "
+                                       "threshold a sweep is one Rayleigh-Ritz in the previous subspace plus a deflated probe for missed directions"}
     if kind != "c4v":
         # what the engine could exploit on THIS state: numerical rank of the truncation and the number of projector columns above
         # projector_svd_reltol, out of chi
@@ -409,7 +424,7 @@ def main():
     ap.add_argument("--cold-start", action="store_true", help="no warm start of the leading-chi iteration")
     args = ap.parse_args()
     kind, D, chi, dtype = CONFIGS[args.config]
-    steps = args.steps if args.steps is not None else (20 if kind == "c4v" else 2)
+    steps = args.steps if args.steps is not None else (100 if kind == "c4v" else 2)
     # untimed warm-up: ceil(chi / D^2) sweeps, the number after which the environment from the CTMRG init has filled its chi
     # (reference ctmrg.py:81)
     warmup = args.warmup if args.warmup is not None else (3 if kind == "c4v" else -(-chi // (D * D)))
@@ -478,6 +493,8 @@ def main():
                "roofline": res["roofline"], "svd": res["svd"], "phase_s": res["phase_s"], "phase_s_note": res["phase_s_note"]}
         if "state" in res:
             out["state"] = res["state"]
+        if "steady_state" in res:
+            out["steady_state"] = res["steady_state"]
         if full is not None:
             out["full_rank"] = {"metric": "ctm_sweeps_per_sec", "value": full["value"], "unit": "sweeps/s", "ms_per_step": full["ms_per_step"],
                                 "steps": full["steps"], "warmup": full["warmup"],

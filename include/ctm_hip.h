@@ -94,6 +94,13 @@ int ctm_truncated_svd_ws(ctm_ctx* ctx, const double* M, int n, int chi, const ct
                          double* V, double* basis);
 /* A symmetric (lower triangle referenced); D (chi, signed, ordered by |D| descending), U n x chi */
 int ctm_truncated_eigh(ctm_ctx* ctx, const double* A, int n, int chi, const ctm_trunc_cfg* cfg, double* D, double* U);
+/* Same for a sequence of nearby matrices (the enlarged corner of consecutive C4v moves): `basis` is an opaque caller-owned device
+ * workspace of min(n, min(chi+1,n) + 8) * n doubles, zero-filled before the first call (CTM_F64; ignored in CTM_C128 contexts).
+ * A restart from the previous invariant subspace is accepted only if (a) every pair of a Rayleigh-Ritz inside it passes the
+ * residual threshold of the cold solver and (b) a block of fresh pseudo-random rows iterated three times on the deflated matrix finds
+ * nothing above the smallest accepted |lambda|; otherwise the regular iteration runs.  The result does not depend on the basis. */
+int ctm_truncated_eigh_ws(ctm_ctx* ctx, const double* A, int n, int chi, const ctm_trunc_cfg* cfg, double* D, double* U,
+                          double* basis);
 /* SVD of a real SYMMETRIC matrix through its eigendecomposition (linalg/svd_symeig.py:12-34 SVDSYMEIG.forward and
  * linalg/custom_svd.py:143-208 truncated_svd_symeig): A = U D U^T ordered by |D| descending, S = |D|, V = U sign(D);
  * U, V n x min(chi,n), S min(chi,n); chi = n gives the full decomposition; cfg NULL: no multiplet back-off.  CTM_F64 only. */

@@ -48,6 +48,7 @@ _SIGS = {
     "ctm_truncated_svd": [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(TruncCfg), C.c_void_p, C.c_void_p, C.c_void_p],
     "ctm_truncated_svd_ws": [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(TruncCfg), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
     "ctm_truncated_eigh": [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(TruncCfg), C.c_void_p, C.c_void_p],
+    "ctm_truncated_eigh_ws": [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(TruncCfg), C.c_void_p, C.c_void_p, C.c_void_p],
     "ctm_svd_symeig": [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(TruncCfg), C.c_void_p, C.c_void_p, C.c_void_p],
     "ctm_svdvals": [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p],
     "ctm_svd_backward": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
@@ -334,13 +335,20 @@ class Engine:
                                                _ptr(basis) if basis is not None else None), "truncated_svd")
         return U, S, V
 
-    def truncated_eigh(self, A, chi, cfg=None):
+    def truncated_eigh(self, A, chi, cfg=None, basis=None):
+        """basis: optional workspace from warm_basis_c4v(chi, n), updated in place (sequence of nearby symmetric matrices)."""
         A = self._bind(A)
         n = A.shape[0]
         kc = min(chi, n)
         D, U = self.empty_real(kc), self.empty(n, kc)
         cfg = cfg or self.cfg(eps_multiplet=1e-12)
-        self._ck(self.lib.ctm_truncated_eigh(self.h, _ptr(A), n, chi, C.byref(cfg), _ptr(D), _ptr(U)), "truncated_eigh")
+        if basis is not None:
+            k = chi + 1 if chi < n else n
+            if not (basis.is_cuda and basis.dtype == torch.float64 and basis.is_contiguous() and tuple(basis.shape) == (min(n, k + 8), n)):
+                raise NativeError("truncated_eigh: basis must come from warm_basis_c4v(chi, n)")
+            self._ck(self.lib.ctm_truncated_eigh_ws(self.h, _ptr(A), n, chi, C.byref(cfg), _ptr(D), _ptr(U), _ptr(basis)), "truncated_eigh")
+        else:
+            self._ck(self.lib.ctm_truncated_eigh(self.h, _ptr(A), n, chi, C.byref(cfg), _ptr(D), _ptr(U)), "truncated_eigh")
         return D, U
 
     def svd_symeig(self, A, chi=None, cfg=None):

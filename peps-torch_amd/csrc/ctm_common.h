@@ -73,6 +73,8 @@ struct ctm_ctx {
     double si_tol = 2e-14;
     double rank_tol = 5e-13;             // numerical-rank threshold of the leading-k solvers (relative to s_0)
     long si_hits = 0, si_fallbacks = 0, si_total_iters = 0, si_warm_starts = 0;
+    int eigh_warm = 1;                 // symmetric problems with a warm basis: Rayleigh-Ritz in the warm subspace + deflated probe first
+    long eigh_warm_hits = 0, eigh_warm_rejects = 0, eigh_probe_calls = 0;
     // block Golub-Kahan-Lanczos for spectra that do not collapse inside a small block (svd_lanczos)
     bool lz_enable = true; int lz_min_k = 48; double lz_switch_steps = 6.0; double lz_last_resid = 1.0; long lz_hits = 0, lz_total_steps = 0;
     int lz_first = 0;                   // > 0: first Ritz extraction after this many block steps (development); 0: policy of svd_lanczos

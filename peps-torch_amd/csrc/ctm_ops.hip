@@ -479,6 +479,10 @@ int ctm_truncated_eigh(ctm_ctx* ctx, const double* A, int n, int chi, const ctm_
     return truncated_eigh_impl(ctx, A, n, chi, cfg_, D, U, nullptr);
 }
 
+int ctm_truncated_eigh_ws(ctm_ctx* ctx, const double* A, int n, int chi, const ctm_trunc_cfg* cfg_, double* D, double* U, double* basis) {
+    return truncated_eigh_impl(ctx, A, n, chi, cfg_, D, U, basis);
+}
+
 namespace {
 // truncated_eig_sym (custom_eig.py:7-65) on a planar (real or complex Hermitian) matrix: dD (device, min(chi,n), signed, zeros beyond
 // the last complete multiplet), U (n x min(chi,n), planar in complex contexts, columns beyond the kept multiplets zeroed)

@@ -1453,6 +1453,64 @@ __global__ __launch_bounds__(64) void chol64_inv_kernel(const double* G, double*
     if (i == 0) status[0] = pmin;
 }
 
+// Rank-revealing companion of chol64_inv_kernel: pivoted Cholesky of a 64 x 64 Gram matrix G = Z Z^T (lazy, left-looking: only the
+// pivot columns are ever formed), stopped at the first pivot below rel * (largest diagonal entry).  Output Mo (64 x 64, row-major):
+// rows k < rank hold row k of L_pp^-1 scattered to the pivot positions, so that Mo Z has orthonormal rows 0..rank-1 (Gram-Schmidt
+// of the pivot rows in pivot order) and zero rows beyond; status[0] = rank.  One wave; thread j owns row j of L.
+__global__ __launch_bounds__(64) void pivchol64_inv_kernel(const double* __restrict__ G, double rel, double* __restrict__ Mo, double* __restrict__ status) {
+    constexpr int M = 64;
+    __shared__ double Lt[M][M];             // Lt[k][j]: entry of ORIGINAL row j in pivot step k (a wave reads a row: conflict free)
+    __shared__ double GX[M][M];             // G during the factorisation, then X = L_pp^-1
+    const int j = threadIdx.x;
+    for (int r = 0; r < M; ++r) GX[r][j] = G[r * M + j];
+    __syncthreads();
+    double d = GX[j][j];
+    bool chosen = false;
+    double d0 = 0.0;
+    int rank = 0, myperm = 0;               // thread k remembers the pivot of step k
+    for (int k = 0; k < M; ++k) {
+        double best = chosen ? -1.0 : d;
+        int who = j;
+        for (int off = 32; off > 0; off >>= 1) {
+            const double ob = __shfl_xor(best, off, 64);
+            const int ow = __shfl_xor(who, off, 64);
+            if (ob > best || (ob == best && ow < who)) { best = ob; who = ow; }
+        }
+        if (k == 0) d0 = best;
+        if (!(best > rel * d0) || !(best > 0.0)) break;           // uniform: every lane holds the same maximum
+        const int p = who;
+        double acc0 = GX[p][j], acc1 = 0.0;                       // G[j][p] (symmetric)
+        int t = 0;
+        for (; t + 4 <= k; t += 4) {
+            const double a0 = Lt[t][j], a1 = Lt[t + 1][j], a2 = Lt[t + 2][j], a3 = Lt[t + 3][j];
+            const double b0 = Lt[t][p], b1 = Lt[t + 1][p], b2 = Lt[t + 2][p], b3 = Lt[t + 3][p];
+            acc0 -= a0 * b0; acc1 -= a1 * b1; acc0 -= a2 * b2; acc1 -= a3 * b3;
+        }
+        for (; t < k; ++t) acc0 -= Lt[t][j] * Lt[t][p];
+        const double lkk = sqrt(best);
+        const double v = (j == p) ? lkk : (chosen ? 0.0 : (acc0 + acc1) / lkk);
+        Lt[k][j] = v;                                             // step k only reads steps < k
+        if (j == p) chosen = true; else if (!chosen) d -= v * v;
+        if (j == k) myperm = p;
+        rank = k + 1;
+        __syncthreads();
+    }
+    // X = L_pp^-1 with L_pp[r][t] = Lt[t][perm[r]] (lower triangular, rank x rank); thread c owns column c of X (stored in GX)
+    const int c = j;
+    for (int r = 0; r < rank; ++r) {
+        const int pr = __shfl(myperm, r, 64);
+        double acc = (r == c) ? 1.0 : 0.0;
+        for (int t = 0; t < r; ++t) acc -= Lt[t][pr] * GX[t][c];
+        GX[r][c] = (r >= c && c < rank) ? acc / Lt[r][pr] : 0.0;
+    }
+    __syncthreads();
+    // Mo[k][perm[t]] = X[k][t]: thread j zeroes column j, then (j < rank) fills column perm[j]
+    for (int k = 0; k < M; ++k) Mo[k * M + j] = 0.0;
+    __syncthreads();
+    if (j < rank) for (int k = 0; k < rank; ++k) Mo[k * M + myperm] = GX[k][j];
+    if (j == 0) status[0] = (double)rank;
+}
+
 // rows of W (64 x n) -> orthonormal rows spanning the same space: unit-norm scaling + two Cholesky-QR passes
 // (W <- L^-1 W with W W^T = L L^T); falls back to the row-Jacobi when a pivot signals near dependence.
 int orthonormalise_block(ctm_ctx* ctx, double* W, int rows, int n, double* norms, double* inv, double* min_norm, double* max_norm) {
@@ -1495,9 +1553,9 @@ int orthonormalise_block(ctm_ctx* ctx, double* W, int rows, int n, double* norms
 }
 
 // W (b x n) -= (W B^T) B for the orthonormal row basis B (m x n); twice ("twice is enough")
-int project_out(ctm_ctx* ctx, double* W, int b, int n, const double* B, int m, double* G) {
+int project_out(ctm_ctx* ctx, double* W, int b, int n, const double* B, int m, double* G, int reps = 2) {
     if (m <= 0) return CTM_OK;
-    for (int rep = 0; rep < 2; ++rep) {
+    for (int rep = 0; rep < reps; ++rep) {
         GemmDesc g1; g1.M = b; g1.N = m; g1.K = n; g1.A = W; g1.sam = n; g1.sak = 1; g1.B = B; g1.sbk = 1; g1.sbn = n; g1.C = G; g1.ldc = m;
         CTM_TRY(gemm_f64(ctx, g1));
         GemmDesc g2; g2.M = b; g2.N = n; g2.K = m; g2.A = G; g2.sam = m; g2.sak = 1; g2.B = B; g2.sbk = n; g2.sbn = 1; g2.C = W; g2.ldc = n;
@@ -2148,6 +2206,148 @@ int jacobi_svdvals(ctm_ctx* ctx, const double* M, const double* Mi, int n, doubl
     return svd_full(ctx, M, n, n, S, nullptr, nullptr);
 }
 
+// Warm restart of the symmetric leading-|lambda| problem when the matrix has (almost) not changed since the previous call -- the
+// regime of a CTM run after its first few sweeps.  `warm` holds kk orthonormal rows (the previous invariant subspace).
+//  (a) Rayleigh-Ritz inside the warm subspace: H = Q A Q^T (kk x kk), dense eigendecomposition, rotate, and the residuals
+//      |q_i A - lambda_i q_i| of ALL kk pairs must pass the same threshold as the cold iteration.
+//  (b) Residuals certify eigenpairs, not that they are the LEADING ones.  A block of 64 fresh pseudo-random rows (a different
+//      seed every call) is iterated three times on the operator deflated by the accepted subspace (orthonormalised in between);
+//      its largest Ritz singular value must not exceed the smallest accepted |lambda|: a direction the warm subspace misses
+//      would show up there exactly as it would among the guard rows of the cold iteration after three applications.
+// Not accepted (either test fails, rows missing, rank deficiency) -> the caller runs the regular iteration.  ~100 small launches
+// instead of four half steps with a 128-row Jacobi each.
+// inv[i] = 1 / x[i] where x[i] > rel * max(x), else 0   (rows <= 64, one wave)
+__global__ __launch_bounds__(64) void inv_rel_kernel(const double* __restrict__ x, double* __restrict__ inv, int rows, double rel) {
+    const int i = threadIdx.x;
+    const double v = (i < rows) ? x[i] : 0.0;
+    double m = v;
+    for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off, 64));
+    if (i < rows) inv[i] = (v > rel * m && v > 0.0) ? 1.0 / v : 0.0;
+}
+
+// symmetric positive semi-definite 64 x 64 G: out[0] = |G|_F (>= lambda_max), out[1] = |G x| after `iters` power steps on a unit
+// vector (<= lambda_max).  One wave, thread i keeps row i in registers.
+__global__ __launch_bounds__(64) void sym64_lmax_kernel(const double* __restrict__ G, int iters, double* __restrict__ out) {
+    __shared__ double x[64];
+    const int i = threadIdx.x;
+    double row[64];
+    double f = 0.0;
+#pragma unroll
+    for (int j = 0; j < 64; ++j) { row[j] = G[i * 64 + j]; f += row[j] * row[j]; }
+    for (int off = 32; off > 0; off >>= 1) f += __shfl_xor(f, off, 64);
+    double xi = 1.0 + 0.37 * (double)((i * 29) % 64) / 64.0;       // generic positive start
+    double nrm = 0.0;
+    for (int it = 0; it <= iters; ++it) {
+        double q = xi * xi;
+        for (int off = 32; off > 0; off >>= 1) q += __shfl_xor(q, off, 64);
+        nrm = sqrt(q);
+        if (it == iters || !(nrm > 0.0)) break;
+        x[i] = xi / nrm;
+        __syncthreads();
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll
+        for (int j = 0; j < 64; j += 4) { a0 += row[j] * x[j]; a1 += row[j + 1] * x[j + 1]; a2 += row[j + 2] * x[j + 2]; a3 += row[j + 3] * x[j + 3]; }
+        xi = (a0 + a1) + (a2 + a3);
+        __syncthreads();
+    }
+    if (i == 0) { out[0] = sqrt(f); out[1] = (iters > 0) ? nrm : 0.0; }
+}
+
+// out[i,:] = sign(d[i]) * q[i,:]  (sign(0) = +1)
+__global__ void signed_rows_kernel(const double* __restrict__ q, const double* __restrict__ d, int rows, int n, double* __restrict__ out) {
+    const size_t tot = (size_t)rows * n;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += (size_t)gridDim.x * blockDim.x)
+        out[e] = (d[e / n] < 0.0) ? -q[e] : q[e];
+}
+
+static int eigh_warm_verify(ctm_ctx* ctx, const double* As, int n, int kk, int k_out, double* warm, double* D, double* Ut, bool* accepted) {
+    *accepted = false;
+    if (kk > n / 4 || kk < 2) return CTM_OK;
+    ArenaScope scope(ctx);
+    const int pb = 64;
+    double *norms, *inv, *Q, *Y, *H, *Dk, *Th, *Q2, *Y2, *res;
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * std::max(kk, pb), (void**)&norms));
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * std::max(kk, pb), (void**)&inv));
+    std::vector<double> h(std::max(kk, pb)), hd(kk);
+    CTM_TRY(row_norms(ctx, warm, kk, n, n, norms));
+    CTM_HIP_CHECK(ctx, hipMemcpyAsync(h.data(), norms, sizeof(double) * kk, hipMemcpyDeviceToHost, ctx->stream));
+    CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < kk; ++i) if (!(std::fabs(h[i] - 1.0) < 1e-6)) return CTM_OK;
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)kk * n, (void**)&Q));
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)kk * n, (void**)&Y));
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)kk * kk, (void**)&H));
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * kk, (void**)&Dk));
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)kk * kk, (void**)&Th));
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)kk * n, (void**)&Q2));
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)kk * n, (void**)&Y2));
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * kk, (void**)&res));
+    CTM_HIP_CHECK(ctx, hipMemcpyAsync(Q, warm, sizeof(double) * (size_t)kk * n, hipMemcpyDeviceToDevice, ctx->stream));
+    CTM_TRY(reorth_rows(ctx, Q, kk, n, n, 1));                       // rounding drift of many restarts
+    CTM_TRY(rows_times(ctx, Q, n, kk, n, n, As, false, Y, n));      // Y = Q A
+    GemmDesc gh; gh.M = kk; gh.N = kk; gh.K = n; gh.A = Y; gh.sam = n; gh.sak = 1; gh.B = Q; gh.sbk = 1; gh.sbn = n; gh.C = H; gh.ldc = kk;
+    CTM_TRY(gemm_f64(ctx, gh));                                      // H = Y Q^T
+    const bool save = ctx->si_enable; ctx->si_enable = false;
+    const int st = jacobi_eigh_top(ctx, H, kk, kk, Dk, Th, nullptr); // rows of Th = eigenvectors, ordered by |lambda|
+    ctx->si_enable = save;
+    CTM_TRY(st);
+    GemmDesc r1; r1.M = kk; r1.N = n; r1.K = kk; r1.A = Th; r1.sam = kk; r1.sak = 1; r1.B = Q; r1.sbk = n; r1.sbn = 1; r1.C = Q2; r1.ldc = n;
+    CTM_TRY(gemm_f64(ctx, r1));
+    GemmDesc r2 = r1; r2.B = Y; r2.C = Y2;
+    CTM_TRY(gemm_f64(ctx, r2));
+    CTM_LAUNCH(ctx, resid_rows_kernel, dim3((kk + 3) / 4), dim3(256), 0, (const double*)Y2, (long long)n, (const double*)Q2, (long long)n,
+               (const double*)Dk, kk, n, res);
+    CTM_HIP_CHECK(ctx, hipMemcpyAsync(h.data(), res, sizeof(double) * kk, hipMemcpyDeviceToHost, ctx->stream));
+    CTM_HIP_CHECK(ctx, hipMemcpyAsync(hd.data(), Dk, sizeof(double) * kk, hipMemcpyDeviceToHost, ctx->stream));
+    CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    const double lam0 = std::fabs(hd[0]), lamk = std::fabs(hd[kk - 1]);
+    const double worst = *std::max_element(h.begin(), h.begin() + kk);
+    if (ctx->jacobi_verbose) fprintf(stderr, "[eigh-warm] n=%d kk=%d  max resid/|l0| = %.3e  |l_kk|/|l0| = %.3e\n", n, kk, worst / std::max(lam0, 1e-300), lamk / std::max(lam0, 1e-300));
+    if (!(lam0 > 0.0) || !(lamk > ctx->rank_tol * lam0) || !(worst <= resid_tol(ctx, n) * lam0)) return CTM_OK;
+    // (b) probe of the deflated operator: Z <- orth(Z A_perp) twice, then the largest singular value of Z A_perp
+    double *Z, *Zn, *G, *G64, *Mo, *bnd;
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)pb * n, (void**)&Z));
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)pb * n, (void**)&Zn));
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)pb * kk, (void**)&G));
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * pb * pb, (void**)&G64));
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * pb * pb, (void**)&Mo));
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * 2, (void**)&bnd));
+    CTM_LAUNCH(ctx, hash_fill_kernel, dim3(256), dim3(256), 0, Z, pb, n, (long long)n, 0x51ED270BULL + 0x9E3779B97F4A7C15ULL * (unsigned long long)(++ctx->eigh_probe_calls));
+    for (int q = 0; q < 3; ++q) {       // the accepted subspace is projected out after every application (its part of a row grows by |l_0 / l_kk| each time)
+        CTM_TRY(rows_times(ctx, Z, n, pb, n, n, As, false, Zn, n));
+        std::swap(Z, Zn);
+        CTM_TRY(project_out(ctx, Z, pb, n, Q2, kk, G, 1));
+        if (q == 2) break;
+        // orthonormal basis of the significant part of the row space: Gram matrix, pivoted Cholesky stopped at 1e-10 of the largest
+        // pivot (rank revealing: the rows of a probe of a fast decaying spectrum are numerically dependent), rows <- L_pp^-1 (pivot rows)
+        GemmDesc go; go.M = pb; go.N = pb; go.K = n; go.A = Z; go.sam = n; go.sak = 1; go.B = Z; go.sbk = 1; go.sbn = n; go.C = G64; go.ldc = pb;
+        CTM_TRY(gemm_f64(ctx, go));
+        CTM_LAUNCH(ctx, pivchol64_inv_kernel, dim3(1), dim3(64), 0, (const double*)G64, 1e-10, Mo, bnd);
+        GemmDesc ga; ga.M = pb; ga.N = n; ga.K = pb; ga.A = Mo; ga.sam = pb; ga.sak = 1; ga.B = Z; ga.sbk = n; ga.sbn = 1; ga.C = Zn; ga.ldc = n;
+        CTM_TRY(gemm_f64(ctx, ga));
+        std::swap(Z, Zn);
+    }
+    // bounds on the largest singular value mu of the last product from its 64 x 64 Gram matrix: (power iteration) <= mu^2 <= |G|_F
+    GemmDesc gg; gg.M = pb; gg.N = pb; gg.K = n; gg.A = Z; gg.sam = n; gg.sak = 1; gg.B = Z; gg.sbk = 1; gg.sbn = n; gg.C = G64; gg.ldc = pb;
+    CTM_TRY(gemm_f64(ctx, gg));
+    CTM_LAUNCH(ctx, sym64_lmax_kernel, dim3(1), dim3(64), 0, (const double*)G64, 64, bnd);
+    CTM_HIP_CHECK(ctx, hipMemcpyAsync(h.data(), bnd, sizeof(double) * 2, hipMemcpyDeviceToHost, ctx->stream));
+    CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    const double mu_hi = std::sqrt(std::max(h[0], 0.0)), mu_lo = std::sqrt(std::max(h[1], 0.0));
+    // the block is orthonormal to ~1e-6 only: same slack in the threshold (8 accepted pairs lie beyond the ones the caller uses)
+    const double thr = lamk * (1.0 + 1e-6) + resid_tol(ctx, n) * lam0;
+    const double mu = (mu_hi <= thr) ? mu_hi : mu_lo * 1.002;        // undecided by the upper bound: the (converged) power estimate
+    if (ctx->jacobi_verbose) fprintf(stderr, "[eigh-warm] probe: largest Ritz value outside / |l_kk| in [%.6f, %.6f]\n", mu_lo / lamk, mu_hi / lamk);
+    if (!(mu <= thr)) { ctx->eigh_warm_rejects += 1; return CTM_OK; }
+    CTM_HIP_CHECK(ctx, hipMemcpyAsync(warm, Q2, sizeof(double) * (size_t)kk * n, hipMemcpyDeviceToDevice, ctx->stream));
+    // the regular iteration keeps the right vectors v_i as the warm basis and returns the left ones, u_i = sign(lambda_i) v_i: same
+    // convention here, so that a run does not change the gauge of its environment legs when it switches between the two paths
+    CTM_LAUNCH(ctx, signed_rows_kernel, dim3(256), dim3(256), 0, (const double*)Q2, (const double*)Dk, k_out, n, Ut);
+    CTM_HIP_CHECK(ctx, hipMemcpyAsync(D, Dk, sizeof(double) * k_out, hipMemcpyDeviceToDevice, ctx->stream));
+    ctx->eigh_warm_hits += 1;
+    *accepted = true;
+    return CTM_OK;
+}
+
 int jacobi_eigh_top(ctm_ctx* ctx, const double* A, int n, int k, double* D, double* Ut, double* warm) {
     if (n <= 0 || k <= 0 || k > n) { ctx->set_error("jacobi_eigh_top: bad n/k"); return CTM_ERR_BADARG; }
     ArenaScope scope(ctx);
@@ -2159,6 +2359,11 @@ int jacobi_eigh_top(ctm_ctx* ctx, const double* A, int n, int k, double* D, doub
     if (ctx->si_enable && k < n && n >= ctx->si_min_n) {
         // a few extra vectors so that a cluster of equal |lambda| with both signs is never cut inside the RR space
         const int kk = std::min(n, k + 8), k_out = k;
+        if (warm && ctx->eigh_warm) {
+            bool accepted = false;
+            CTM_TRY(eigh_warm_verify(ctx, As, n, kk, k_out, warm, D, Ut, &accepted));
+            if (accepted) return CTM_OK;
+        }
         double *S, *Uk, *Vk;
         CTM_TRY(arena_alloc(ctx, sizeof(double) * kk, (void**)&S));
         CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)kk * n, (void**)&Uk));

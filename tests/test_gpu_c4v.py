@@ -102,3 +102,94 @@ def test_truncated_eigh_complex_hermitian(eng, n, chi):
     assert D.dtype == np.float64 and np.abs(D - w).max() < 1e-13
     assert np.abs(U.conj().T @ U - np.eye(chi)).max() < 1e-12
     assert np.abs(H @ U - U * D[None, :]).max() < 1e-12
+
+
+# ---- warm restart of the symmetric truncation (ctm_truncated_eigh_ws): accepted only when residual-verified AND the deflated probe
+# ---- finds nothing above the smallest accepted |lambda| -------------------------------------------------------------------------
+def _sym_with_spectrum(n, lam, seed):
+    g = torch.Generator().manual_seed(seed)
+    Q, _ = torch.linalg.qr(torch.randn(n, n, generator=g, dtype=torch.float64))
+    return (Q * lam) @ Q.T, Q
+
+
+def test_warm_restart_is_accepted_on_a_stationary_matrix_and_changes_nothing(eng):
+    n, chi = 768, 48
+    lam = (0.8 ** torch.arange(n, dtype=torch.float64)) * torch.where(torch.arange(n) % 3 == 1, -1.0, 1.0)     # signs + - + + - + ...
+    A, _ = _sym_with_spectrum(n, lam.double(), 3)
+    A = A.cuda()
+    D0, U0 = eng.truncated_eigh(A, chi)
+    basis = eng.warm_basis_c4v(chi, n)
+    eng.timers(reset=True)
+    outs = [eng.truncated_eigh(A, chi, basis=basis) for _ in range(4)]
+    assert eng.stat("eigh_warm_hits") >= 2                  # first call cold, second from the cold call's subspace, then restarts
+    for D, U in outs:
+        assert float((D - D0).abs().max()) < 1e-13
+        assert float(((A @ U) - U * D).abs().max()) < 1e-12
+        assert float((U.T @ U - torch.eye(chi, device=U.device, dtype=U.dtype)).abs().max()) < 1e-12
+    # same gauge from the regular and the restart path: the columns do not change sign between consecutive calls
+    for (_, Ua), (_, Ub) in zip(outs[:-1], outs[1:]):
+        assert float((Ua - Ub).abs().max()) < 1e-7
+
+
+def test_warm_restart_with_a_missing_leading_direction_is_rejected_by_the_probe(eng):
+    """The warm subspace is exactly invariant (every residual passes) but lacks the 5th eigenvector: only the probe of the deflated
+    matrix can see that; the call must fall back to the regular iteration and return the true leading pairs."""
+    n, chi = 768, 48
+    lam = (0.8 ** torch.arange(n, dtype=torch.float64))
+    A, Q = _sym_with_spectrum(n, lam, 5)
+    kk = chi + 1 + 8
+    cols = [i for i in range(kk + 1) if i != 4]
+    basis = eng.warm_basis_c4v(chi, n)
+    assert tuple(basis.shape) == (kk, n)
+    basis.copy_(Q[:, cols].T.contiguous().cuda())
+    eng.timers(reset=True)
+    D, U = eng.truncated_eigh(A.cuda(), chi, basis=basis)
+    assert eng.stat("eigh_warm_rejects") == 1 and eng.stat("eigh_warm_hits") == 0
+    assert float((D.cpu() - lam[:chi]).abs().max()) < 1e-12
+    assert float((U.cpu().T @ Q[:, :chi]).abs().diagonal()[:30].min()) > 1 - 1e-8      # eigenvalues down to 0.8^29: gaps well above the rounding level
+
+
+def test_warm_restart_on_a_moved_matrix_falls_back_and_stays_exact(eng):
+    n, chi = 512, 32
+    lam = (0.8 ** torch.arange(n, dtype=torch.float64)) * torch.where(torch.arange(n) % 3 == 0, -1.0, 1.0)
+    A, _ = _sym_with_spectrum(n, lam, 7)
+    g = torch.Generator().manual_seed(11)
+    E = torch.randn(n, n, generator=g, dtype=torch.float64); E = 1e-5 * (E + E.T)
+    basis = eng.warm_basis_c4v(chi, n)
+    eng.truncated_eigh(A.cuda(), chi, basis=basis)
+    eng.timers(reset=True)
+    D, U = eng.truncated_eigh((A + E).cuda(), chi, basis=basis)
+    assert eng.stat("eigh_warm_hits") == 0
+    w = torch.linalg.eigvalsh(A + E)
+    w = w[torch.argsort(w.abs(), descending=True)][:chi]
+    assert float((D.cpu() - w).abs().max()) < 1e-12
+    assert float((((A + E).cuda() @ U) - U * D).abs().max()) < 1e-12
+
+
+def test_c4v_run_with_and_without_the_warm_restart_agree(eng):
+    """20 moves of a random C4v state (converges after ~7): the restart path takes over once the enlarged corner is stationary; corner
+    spectrum and energy equal those of the run with the restart switched off."""
+    from ipeps.ipeps_c4v import IPEPS_C4V
+    from ctm.one_site_c4v.env_c4v import ENV_C4V, init_env
+    from ctm.one_site_c4v import ctmrg_c4v
+    from groups.pg import make_c4v_symm
+    from models import j1j2
+    rng = np.random.default_rng(4)
+    a = make_c4v_symm(torch.from_numpy(rng.random((2, 4, 4, 4, 4)))).cuda()
+    res = []
+    for flag in (1, 0):
+        eng.set_option("eigh_warm", flag)
+        try:
+            st = IPEPS_C4V(a.clone())
+            env = ENV_C4V(20, st); init_env(st, env)          # n = 320: above the size below which the dense path is used
+            eng.timers(reset=True)
+            for _ in range(20):
+                ctmrg_c4v.ctm_MOVE_sl(st.site(), env)
+            hits = eng.stat("eigh_warm_hits")
+            e = float(j1j2.J1J2_C4V_BIPARTITE(j1=1.0, j2=0.3).energy_1x1_lowmem(st, env))
+            res.append((hits, torch.diagonal(env.get_C()).clone(), e))
+        finally:
+            eng.set_option("eigh_warm", 1)
+    assert res[0][0] > 0 and res[1][0] == 0
+    assert float((res[0][1] - res[1][1]).abs().max()) < 1e-11
+    assert abs(res[0][2] - res[1][2]) < 1e-11
