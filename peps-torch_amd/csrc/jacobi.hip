@@ -2284,24 +2284,37 @@ static int eigh_warm_verify(ctm_ctx* ctx, const double* As, int n, int kk, int k
     CTM_HIP_CHECK(ctx, hipMemcpyAsync(Q, warm, sizeof(double) * (size_t)kk * n, hipMemcpyDeviceToDevice, ctx->stream));
     CTM_TRY(reorth_rows(ctx, Q, kk, n, n, 1));                       // rounding drift of many restarts
     CTM_TRY(rows_times(ctx, Q, n, kk, n, n, As, false, Y, n));      // Y = Q A
-    GemmDesc gh; gh.M = kk; gh.N = kk; gh.K = n; gh.A = Y; gh.sam = n; gh.sak = 1; gh.B = Q; gh.sbk = 1; gh.sbn = n; gh.C = H; gh.ldc = kk;
-    CTM_TRY(gemm_f64(ctx, gh));                                      // H = Y Q^T
-    const bool save = ctx->si_enable; ctx->si_enable = false;
-    const int st = jacobi_eigh_top(ctx, H, kk, kk, Dk, Th, nullptr); // rows of Th = eigenvectors, ordered by |lambda|
-    ctx->si_enable = save;
-    CTM_TRY(st);
-    GemmDesc r1; r1.M = kk; r1.N = n; r1.K = kk; r1.A = Th; r1.sam = kk; r1.sak = 1; r1.B = Q; r1.sbk = n; r1.sbn = 1; r1.C = Q2; r1.ldc = n;
-    CTM_TRY(gemm_f64(ctx, r1));
-    GemmDesc r2 = r1; r2.B = Y; r2.C = Y2;
-    CTM_TRY(gemm_f64(ctx, r2));
-    CTM_LAUNCH(ctx, resid_rows_kernel, dim3((kk + 3) / 4), dim3(256), 0, (const double*)Y2, (long long)n, (const double*)Q2, (long long)n,
+    // stationary matrix: the previous Ritz vectors ARE the eigenvectors -- Rayleigh quotients d_i = q_i A q_i^T, residuals
+    // |q_i A - d_i q_i|, order by |d| unchanged: nothing to rotate.  Otherwise the Rayleigh-Ritz inside the subspace.
+    CTM_TRY(row_dots(ctx, Y, Q, kk, n, n, Dk));
+    CTM_LAUNCH(ctx, resid_rows_kernel, dim3((kk + 3) / 4), dim3(256), 0, (const double*)Y, (long long)n, (const double*)Q, (long long)n,
                (const double*)Dk, kk, n, res);
     CTM_HIP_CHECK(ctx, hipMemcpyAsync(h.data(), res, sizeof(double) * kk, hipMemcpyDeviceToHost, ctx->stream));
     CTM_HIP_CHECK(ctx, hipMemcpyAsync(hd.data(), Dk, sizeof(double) * kk, hipMemcpyDeviceToHost, ctx->stream));
     CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    bool as_is = *std::max_element(h.begin(), h.begin() + kk) <= resid_tol(ctx, n) * std::fabs(hd[0]);
+    for (int i = 1; i < kk && as_is; ++i) as_is = std::fabs(hd[i]) <= std::fabs(hd[i - 1]);
+    if (as_is) Q2 = Q;
+    else {
+        GemmDesc gh; gh.M = kk; gh.N = kk; gh.K = n; gh.A = Y; gh.sam = n; gh.sak = 1; gh.B = Q; gh.sbk = 1; gh.sbn = n; gh.C = H; gh.ldc = kk;
+        CTM_TRY(gemm_f64(ctx, gh));                                      // H = Y Q^T
+        const bool save = ctx->si_enable; ctx->si_enable = false;
+        const int st = jacobi_eigh_top(ctx, H, kk, kk, Dk, Th, nullptr); // rows of Th = eigenvectors, ordered by |lambda|
+        ctx->si_enable = save;
+        CTM_TRY(st);
+        GemmDesc r1; r1.M = kk; r1.N = n; r1.K = kk; r1.A = Th; r1.sam = kk; r1.sak = 1; r1.B = Q; r1.sbk = n; r1.sbn = 1; r1.C = Q2; r1.ldc = n;
+        CTM_TRY(gemm_f64(ctx, r1));
+        GemmDesc r2 = r1; r2.B = Y; r2.C = Y2;
+        CTM_TRY(gemm_f64(ctx, r2));
+        CTM_LAUNCH(ctx, resid_rows_kernel, dim3((kk + 3) / 4), dim3(256), 0, (const double*)Y2, (long long)n, (const double*)Q2, (long long)n,
+                   (const double*)Dk, kk, n, res);
+        CTM_HIP_CHECK(ctx, hipMemcpyAsync(h.data(), res, sizeof(double) * kk, hipMemcpyDeviceToHost, ctx->stream));
+        CTM_HIP_CHECK(ctx, hipMemcpyAsync(hd.data(), Dk, sizeof(double) * kk, hipMemcpyDeviceToHost, ctx->stream));
+        CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    }
     const double lam0 = std::fabs(hd[0]), lamk = std::fabs(hd[kk - 1]);
     const double worst = *std::max_element(h.begin(), h.begin() + kk);
-    if (ctx->jacobi_verbose) fprintf(stderr, "[eigh-warm] n=%d kk=%d  max resid/|l0| = %.3e  |l_kk|/|l0| = %.3e\n", n, kk, worst / std::max(lam0, 1e-300), lamk / std::max(lam0, 1e-300));
+    if (ctx->jacobi_verbose) fprintf(stderr, "[eigh-warm] n=%d kk=%d%s  max resid/|l0| = %.3e  |l_kk|/|l0| = %.3e\n", n, kk, as_is ? " (vectors kept)" : "", worst / std::max(lam0, 1e-300), lamk / std::max(lam0, 1e-300));
     if (!(lam0 > 0.0) || !(lamk > ctx->rank_tol * lam0) || !(worst <= resid_tol(ctx, n) * lam0)) return CTM_OK;
     // (b) probe of the deflated operator: Z <- orth(Z A_perp) twice, then the largest singular value of Z A_perp
     double *Z, *Zn, *G, *G64, *Mo, *bnd;
