@@ -951,6 +951,7 @@ int svd_iter(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* Ut, double
     double s0 = 0.0;
     int rank = 0, kk = k;
     double worst_prev = 0.0;
+    std::vector<double> worst_hist;       // residual per checked half step (stagnation: see below)
     const double rank_tol = ctx->rank_tol;      // singular values below rank_tol * s_0 are rounding noise: never required to converge, returned as zeros
     const int max_half = 2 * ctx->si_max_iter;
     int it = 0;
@@ -1006,6 +1007,12 @@ int svd_iter(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* Ut, double
                 *want_krylov = true; ctx->si_last_iters = it; ctx->si_total_iters += it; return CTM_OK;      // not contracting at all
             }
             worst_prev = worst;
+            // Stagnation at the rounding floor of the Rayleigh-Ritz (a flat leading spectrum leaves ~50 x the Jacobi tolerance,
+            // above the acceptance threshold): more half steps cannot help, the caller's dense path takes over now rather than
+            // after si_max_iter iterations.
+            worst_hist.push_back(worst);
+            const size_t nh = worst_hist.size();
+            if (nh >= 10 && worst < 1e-10 * s0 && worst > 0.5 * worst_hist[nh - 7]) break;
         }
         // Rayleigh-Ritz to convergence (the bases must be orthonormal for the residual test to certify the triplets);
         // the very first one only orthonormalises a power step of the random start, so it is capped
@@ -1298,6 +1305,7 @@ int svd_iter_c(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* Ut, doub
     double s0 = 0.0;
     int rank = 0, kk = k;
     double worst_prev = 0.0;
+    std::vector<double> worst_hist;       // residual per checked half step (stagnation: see below)
     const double rank_tol = ctx->rank_tol;      // singular values below rank_tol * s_0 are rounding noise: never required to converge, returned as zeros
     const int max_half = 2 * ctx->si_max_iter;
     int it = 0;
@@ -1339,6 +1347,12 @@ int svd_iter_c(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* Ut, doub
                 if (sw) { *want_krylov = true; ctx->si_last_iters = it; ctx->si_total_iters += it; return CTM_OK; }
             }
             worst_prev = worst;
+            // Stagnation at the rounding floor of the Rayleigh-Ritz (a flat leading spectrum leaves ~50 x the Jacobi tolerance,
+            // above the acceptance threshold): more half steps cannot help, the caller's dense path takes over now rather than
+            // after si_max_iter iterations.
+            worst_hist.push_back(worst);
+            const size_t nh = worst_hist.size();
+            if (nh >= 10 && worst < 1e-10 * s0 && worst > 0.5 * worst_hist[nh - 7]) break;
         }
         int st;
         std::vector<double> hh;
