@@ -319,6 +319,39 @@ def c4v_case(name, D, chi, seed, complex_=False):
     print(f"  {name} ok  E_lowmem={e_low:.12f}")
 
 
+def c4v_ad_case(name, base, nmoves=2, j2=0.5, complex_=False):
+    """Gradient of the energy after `nmoves` C4v moves with respect to the on-site tensor, by the reference's autograd
+    (ctmrg_c4v.ctm_MOVE_sl + truncated_eig_sym/SYMEIG.backward + rdm_c4v + J1J2_C4V_BIPARTITE.energy_1x1_lowmem); the
+    environment the moves start from (golden `base`: warm_C, warm_T) is a constant."""
+    set_dtype(complex_)
+    g = np.load(os.path.join(GOLD, base + ".npz"))
+    A = torch.from_numpy(g["site"].copy()).requires_grad_(True)
+    st = IPEPS_C4V(A)
+    chi = g["warm_C"].shape[0]
+    env = ENV_C4V(chi, st)
+    env.C[env.keyC] = torch.from_numpy(g["warm_C"].copy()); env.T[env.keyT] = torch.from_numpy(g["warm_T"].copy())
+    def teig(M, ch):
+        return truncated_eig_sym(M, ch, keep_multiplets=True)
+    for _ in range(nmoves):
+        ctmrg_c4v.ctm_MOVE_sl(st.site(), env, teig)
+    model = j1j2.J1J2_C4V_BIPARTITE(j1=1.0, j2=j2)
+    e = model.energy_1x1_lowmem(st, env)
+    e.backward()
+    out = dict(site=g["site"], C0=g["warm_C"], T0=g["warm_T"], energy=np.array(float(torch.real(e))), grad=t2n(A.grad),
+               C_after=t2n(env.get_C().detach()), nmoves=np.array(nmoves), j2=np.array(j2))
+    # second loss: sum of the squared new corner spectrum after one move (exercises the eigenvalue branch of SYMEIG.backward alone)
+    A2 = torch.from_numpy(g["site"].copy()).requires_grad_(True)
+    st2 = IPEPS_C4V(A2)
+    env2 = ENV_C4V(chi, st2)
+    env2.C[env2.keyC] = torch.from_numpy(g["warm_C"].copy()); env2.T[env2.keyT] = torch.from_numpy(g["warm_T"].copy())
+    ctmrg_c4v.ctm_MOVE_sl(st2.site(), env2, teig)
+    l2 = (torch.diagonal(env2.get_C()).abs() ** 2).sum() + (env2.get_T().abs() ** 2).sum()
+    l2.backward()
+    out["loss_spec"] = np.array(float(l2)); out["grad_spec"] = t2n(A2.grad)
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **out)
+    print(f"  {name} ok  E={float(torch.real(e)):.12f} |grad|={np.linalg.norm(out['grad']):.6e} |grad_spec|={np.linalg.norm(out['grad_spec']):.6e}")
+
+
 def rvb_case():
     """G1/G2: the reference's own known-answer test (examples/j1j2/ctmrg_j1j2_c4v.py:218-260):
     RVB_1x1 D=3 chi=16 j2=0.5 -> E = -0.47684229 +- 1e-8."""
@@ -556,7 +589,7 @@ def input_files_case():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["decomp", "generic", "c4v", "rvb", "files", "variants", "aklt", "inputs", "backward"]
+    which = sys.argv[1:] or ["decomp", "generic", "c4v", "c4v_ad", "rvb", "files", "variants", "aklt", "inputs", "backward"]
     if "backward" in which:
         backward_case()
     if "inputs" in which:
@@ -576,6 +609,10 @@ if __name__ == "__main__":
         c4v_case("c4v_D3_chi18", 3, 18, 22)
         c4v_case("c4v_D2_chi8_c128", 2, 8, 23, complex_=True)
         c4v_case("c4v_D3_chi18_c128", 3, 18, 24, complex_=True)
+    if "c4v_ad" in which:
+        c4v_ad_case("c4v_ad_D2_chi8", "c4v_D2_chi8")
+        c4v_ad_case("c4v_ad_D3_chi18", "c4v_D3_chi18")
+        c4v_ad_case("c4v_ad_D2_chi8_c128", "c4v_D2_chi8_c128", complex_=True)
     if "rvb" in which:
         rvb_case()
     if "files" in which:

@@ -23,11 +23,12 @@ def _cast_to_real(t, fail_on_check=False, warn_on_check=True, imag_eps=1.0e-8, w
 def _sym_pos_def_matrix(rdm, sym_pos_def=False, verbosity=0, who="unknown", **kwargs):
     rdm = 0.5 * (rdm + rdm.conj().t())
     if sym_pos_def:
-        D, U = torch.linalg.eigh(rdm.cpu())            # <= 16 x 16, host
+        D, U = torch.linalg.eigh(rdm.detach().cpu())   # <= 16 x 16, host
         if D.min() < 0:
             log.info(f"{who} max(diag(rdm)) {D.max()} min(diag(rdm)) {D.min()}")
             D = torch.clamp(D, min=0)
-            rdm = (U @ torch.diag(D).to(U.dtype) @ U.conj().t()).to(rdm.device)
+            # the reference overwrites the values under no_grad (rdm.py:44-53): the projection carries no gradient of its own
+            rdm = rdm + ((U @ torch.diag(D).to(U.dtype) @ U.conj().t()).to(rdm.device) - rdm).detach()
     norm = _cast_to_real(rdm.diagonal().sum(), who=who, **kwargs)
     return rdm / norm
 

@@ -7,6 +7,7 @@ import logging
 import torch
 import config as cfg
 from backend import get_engine
+from linalg.native_einsum import einsum, needs_grad
 
 log = logging.getLogger(__name__)
 
@@ -38,6 +39,8 @@ def ctm_MOVE_sl(a, env, f_c2x2_decomp=None, ctm_args=cfg.ctm_args, global_args=c
     """One C4v move.  `f_c2x2_decomp` is accepted for signature compatibility; the native move always
     uses the truncated symmetric eigendecomposition with keep_multiplets (ctmrg_c4v.py:49-52)."""
     norm_kind = 1 if ctm_args.ctm_absorb_normalization == 'inf' else 2        # anything else is the 2-norm (ctmrg_c4v.py:183-185)
+    if needs_grad(a, env.C[env.keyC], env.T[env.keyT]):
+        return _ctm_MOVE_sl_ad(a, env, f_c2x2_decomp, norm_kind, ctm_args)
     eng = get_engine()
     cfgT = eng.cfg(eps_multiplet=1.0e-12, multiplet_abstol=1.0e-14, keep_multiplets=True)
     basis = None
@@ -49,6 +52,43 @@ def ctm_MOVE_sl(a, env, f_c2x2_decomp=None, ctm_args=cfg.ctm_args, global_args=c
         if basis is None or tuple(basis.shape) != (min(n, k + 8), n) or basis.device != a.device:
             basis = env.__dict__["_warm"] = eng.warm_basis_c4v(env.chi, n)
     nC, nT, _D = eng.move_c4v(a, env.C[env.keyC], env.T[env.keyT], cfgT, normalize=norm_kind, **({"basis": basis} if basis is not None else {}))
+    env.C[env.keyC] = nC
+    env.T[env.keyT] = nT
+
+
+def _ctm_MOVE_sl_ad(a, env, f_c2x2_decomp, norm_kind, ctm_args):
+    """The same move as a graph of differentiable native nodes (reference ctmrg_c4v.py:349-463 under torch autograd): enlarged
+    corner (one contraction node) -> FULL symmetric eigendecomposition with the regularised backward, truncated by slicing
+    (custom_eig.py:7-65) -> C = diag(D), T = P.T.a.a*.P* (one contraction node) symmetrised -> scales taken without gradient
+    (`_move_normalize_c`, :182-197).  `fwd_checkpoint_move` recomputes the move in the backward pass like the reference."""
+    from ctm.one_site_c4v.ctm_components_c4v import c2x2_sl
+    from linalg.custom_eig import truncated_eig_sym
+    if f_c2x2_decomp is None:
+        def f_c2x2_decomp(M, chi):
+            return truncated_eig_sym(M, chi, keep_multiplets=True, eps_multiplet=1.0e-12, abs_tol=1.0e-14,
+                                     ad_decomp_reg=ctm_args.ad_decomp_reg)
+    chi = env.chi
+
+    def core(a, C, T):
+        D_ = a.shape[1]
+        C2X2 = c2x2_sl(a, C, T)
+        Dv, P = f_c2x2_decomp(C2X2, chi)
+        nC = torch.diag(Dv.to(a.dtype))
+        Pv = P.reshape(chi, D_, D_, chi)
+        Tv = T.reshape(chi, chi, D_, D_)
+        nT = einsum('xuUi,xelL,suldr,sULDR,edDj->ijrR', Pv, Tv, a, a, Pv, conj=(3, 4)).reshape(chi, chi, D_ * D_)
+        nT = 0.5 * (nT + nT.conj().permute(1, 0, 2))
+        with torch.no_grad():
+            sC = nC[0, 0].abs()
+            sT = nT.abs().max() if norm_kind == 1 else torch.linalg.vector_norm(nT)
+        return nC / sC, nT / sT
+
+    tensors = (a, env.C[env.keyC], env.T[env.keyT])
+    if getattr(ctm_args, "fwd_checkpoint_move", False):
+        from torch.utils.checkpoint import checkpoint
+        nC, nT = checkpoint(core, *tensors, use_reentrant=False)
+    else:
+        nC, nT = core(*tensors)
     env.C[env.keyC] = nC
     env.T[env.keyT] = nT
 

@@ -39,6 +39,15 @@ class FakeEngine:
         ops = [(_n(t).conj() if i in conj else _n(t)) for i, t in enumerate(tensors)]
         return _t(O.seq_einsum(expr, *ops))
 
+    def truncated_eigh(self, A, chi, cfg=None, basis=None):
+        km = True if cfg is None else cfg.keep_multiplets
+        D, U = O.truncated_eig_sym(_n(A), chi, abs_tol=1e-14 if cfg is None else cfg.multiplet_abstol, keep_multiplets=km,
+                                   eps_multiplet=1e-12 if cfg is None else cfg.eps_multiplet)
+        return _t(D), _t(U)
+
+    def eigh_backward(self, D, U, gD=None, gU=None, reg=1.0e-12):
+        return _t(O.eigh_backward(_n(D), _n(U), None if gD is None else _n(gD), None if gU is None else _n(gU), reg))
+
     def permute(self, x, perm):
         return x.permute(*perm).contiguous()
 

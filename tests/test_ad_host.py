@@ -1,0 +1,110 @@
+"""CPU: the host side of the differentiable path -- the adjoint networks that linalg/native_einsum.py builds for a
+contraction node, and the C4v move / RDM / energy graph assembled from such nodes and the SYMEIG node, checked against gradients
+the REFERENCE's autograd produced (tests/golden/c4v_ad_*.npz, written by oracle/gen_golden.py c4v_ad).  The engine is the
+oracle-backed double, so only the graph construction is under test here; tests/test_gpu_ad.py runs the same on the native kernels."""
+import numpy as np
+import pytest
+import torch
+import backend
+from fake_engine import FakeEngine
+from conftest import golden
+
+
+@pytest.fixture()
+def fake():
+    import config as cfg
+    old = cfg.global_args.device
+    cfg.global_args.device = 'cpu'
+    backend.set_engine(FakeEngine())
+    yield cfg
+    backend.set_engine(None)
+    cfg.global_args.device = old
+
+
+NETS = [("ab,bc->ac", [(3, 4), (4, 5)], ()),
+        ("xy,cyuU,xelL,suldr,sULDR->edDcrR", [(3, 3), (3, 3, 2, 2), (3, 3, 2, 2), (2, 2, 2, 2, 2), (2, 2, 2, 2, 2)], (4,)),
+        ("xuUi,xelL,suldr,sULDR,edDj->ijrR", [(3, 2, 2, 3), (3, 3, 2, 2), (2, 2, 2, 2, 2), (2, 2, 2, 2, 2), (3, 2, 2, 3)], (3, 4)),
+        ("abst,bcuv->acstuv", [(4, 4, 2, 2), (4, 4, 2, 2)], ())]
+
+
+@pytest.mark.parametrize("cplx", [False, True])
+@pytest.mark.parametrize("net", NETS, ids=[n[0] for n in NETS])
+def test_adjoint_networks_of_a_contraction_node(fake, net, cplx):
+    from linalg.native_einsum import einsum
+    expr, shapes, conj = net
+    g = torch.Generator().manual_seed(5)
+    dt = torch.complex128 if cplx else torch.float64
+    ops = [torch.randn(*s, generator=g, dtype=dt).requires_grad_(True) for s in shapes]
+    assert torch.autograd.gradcheck(lambda *o: einsum(expr, *o, conj=conj), ops, eps=1e-6, atol=1e-7, rtol=1e-6)
+    # the same tensor in two slots (a and conj(a)): autograd adds the slots' gradients
+    if conj:
+        ref_ops = [o.detach().clone().requires_grad_(True) for o in ops]
+        lhs, out = expr.split("->")
+        tor = torch.einsum(expr, *[(o.conj() if i in conj else o) for i, o in enumerate(ref_ops)])
+        mine = einsum(expr, *ops, conj=conj)
+        w = torch.randn(*mine.shape, generator=g, dtype=dt)
+        (mine * w).sum().abs().backward(); (tor * w).sum().abs().backward()
+        for a, b in zip(ops, ref_ops):
+            assert float((a.grad - b.grad).abs().max()) < 1e-11
+
+
+def test_index_traced_out_alone_is_refused(fake):
+    from linalg.native_einsum import einsum
+    x = torch.randn(3, 3, 2, 2, dtype=torch.float64, requires_grad=True)
+    with pytest.raises((NotImplementedError, Exception)):
+        einsum("abii->ab", x).sum().backward()
+
+
+def _c4v_energy(g, fake_cfg, checkpoint=False):
+    from ipeps.ipeps_c4v import IPEPS_C4V
+    from ctm.one_site_c4v.env_c4v import ENV_C4V
+    from ctm.one_site_c4v import ctmrg_c4v
+    from models import j1j2
+    A = torch.from_numpy(g["site"].copy()).requires_grad_(True)
+    st = IPEPS_C4V(A)
+    env = ENV_C4V(g["C0"].shape[0], st)
+    env.C[env.keyC] = torch.from_numpy(g["C0"].copy()); env.T[env.keyT] = torch.from_numpy(g["T0"].copy())
+    fake_cfg.ctm_args.fwd_checkpoint_move = checkpoint
+    try:
+        for _ in range(int(g["nmoves"])):
+            ctmrg_c4v.ctm_MOVE_sl(st.site(), env)
+    finally:
+        fake_cfg.ctm_args.fwd_checkpoint_move = False
+    e = j1j2.J1J2_C4V_BIPARTITE(j1=1.0, j2=float(g["j2"])).energy_1x1_lowmem(st, env)
+    e.backward()
+    return float(e), A.grad, env
+
+
+@pytest.mark.parametrize("name", ["c4v_ad_D2_chi8", "c4v_ad_D3_chi18", "c4v_ad_D2_chi8_c128"])
+def test_c4v_energy_gradient_equals_the_reference_autograd(fake, name):
+    g = golden(name)
+    e, grad, env = _c4v_energy(g, fake)
+    assert abs(e - float(g["energy"])) < 1e-11
+    assert float(np.abs(np.diag(env.get_C().detach().numpy()) - np.diag(g["C_after"])).max()) < 1e-10
+    ref = g["grad"]
+    assert float(np.abs(grad.numpy() - ref).max()) < 1e-9 * max(1.0, float(np.abs(ref).max()))
+
+
+def test_c4v_gradient_with_checkpointed_moves_is_the_same(fake):
+    g = golden("c4v_ad_D2_chi8")
+    _, g0, _ = _c4v_energy(g, fake)
+    _, g1, _ = _c4v_energy(g, fake, checkpoint=True)
+    assert float((g0 - g1).abs().max()) < 1e-13
+
+
+@pytest.mark.parametrize("name", ["c4v_ad_D2_chi8", "c4v_ad_D2_chi8_c128"])
+def test_c4v_spectrum_loss_gradient(fake, name):
+    """One move, loss = |C'|^2 + |T'|^2: the eigenvalue AND eigenvector branches of SYMEIG.backward with the detached scales."""
+    from ipeps.ipeps_c4v import IPEPS_C4V
+    from ctm.one_site_c4v.env_c4v import ENV_C4V
+    from ctm.one_site_c4v import ctmrg_c4v
+    g = golden(name)
+    A = torch.from_numpy(g["site"].copy()).requires_grad_(True)
+    st = IPEPS_C4V(A)
+    env = ENV_C4V(g["C0"].shape[0], st)
+    env.C[env.keyC] = torch.from_numpy(g["C0"].copy()); env.T[env.keyT] = torch.from_numpy(g["T0"].copy())
+    ctmrg_c4v.ctm_MOVE_sl(st.site(), env)
+    l = (torch.diagonal(env.get_C()).abs() ** 2).sum() + (env.get_T().abs() ** 2).sum()
+    l.backward()
+    assert abs(float(l) - float(g["loss_spec"])) < 1e-10 * float(g["loss_spec"])
+    assert float(np.abs(A.grad.numpy() - g["grad_spec"]).max()) < 1e-8 * float(np.abs(g["grad_spec"]).max())

@@ -1,0 +1,110 @@
+"""GPU: the differentiable C4v path on the native kernels -- every node of the graph runs `ctm_einsum`,
+`ctm_truncated_eigh` or `ctm_eigh_backward`; gradients against the reference's autograd (tests/golden/c4v_ad_*.npz)."""
+import numpy as np
+import pytest
+import torch
+from conftest import golden
+from helpers import dev
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("cplx", [False, True])
+def test_contraction_node_gradients_on_the_engine(eng, cplx):
+    from linalg.native_einsum import einsum
+    g = torch.Generator().manual_seed(9)
+    dt = torch.complex128 if cplx else torch.float64
+    shapes = [(5, 5), (5, 5, 3, 3), (5, 5, 3, 3), (2, 3, 3, 3, 3), (2, 3, 3, 3, 3)]
+    expr, conj = "xy,cyuU,xelL,suldr,sULDR->edDcrR", (4,)
+    ops = [torch.randn(*s, generator=g, dtype=dt).cuda().requires_grad_(True) for s in shapes]
+    ref = [o.detach().clone().requires_grad_(True) for o in ops]
+    mine = einsum(expr, *ops, conj=conj)
+    tor = torch.einsum(expr, *[(o.conj() if i in conj else o) for i, o in enumerate(ref)])
+    assert float((mine - tor).abs().max()) < 1e-12 * float(tor.abs().max())
+    w = torch.randn(*mine.shape, generator=g, dtype=dt).cuda()
+    (mine * w).sum().abs().backward(); (tor * w).sum().abs().backward()
+    for a, b in zip(ops, ref):
+        assert float((a.grad - b.grad).abs().max()) < 1e-11 * float(b.grad.abs().max())
+
+
+def _run(g, checkpoint=False):
+    import config as cfg
+    from ipeps.ipeps_c4v import IPEPS_C4V
+    from ctm.one_site_c4v.env_c4v import ENV_C4V
+    from ctm.one_site_c4v import ctmrg_c4v
+    from models import j1j2
+    A = dev(g["site"]).requires_grad_(True)
+    st = IPEPS_C4V(A)
+    env = ENV_C4V(g["C0"].shape[0], st)
+    env.C[env.keyC] = dev(g["C0"]); env.T[env.keyT] = dev(g["T0"])
+    cfg.ctm_args.fwd_checkpoint_move = checkpoint
+    try:
+        for _ in range(int(g["nmoves"])):
+            ctmrg_c4v.ctm_MOVE_sl(st.site(), env)
+    finally:
+        cfg.ctm_args.fwd_checkpoint_move = False
+    e = j1j2.J1J2_C4V_BIPARTITE(j1=1.0, j2=float(g["j2"])).energy_1x1_lowmem(st, env)
+    e.backward()
+    return float(e.detach()), A.grad.cpu().numpy(), env
+
+
+@pytest.mark.parametrize("name", ["c4v_ad_D2_chi8", "c4v_ad_D3_chi18", "c4v_ad_D2_chi8_c128"])
+def test_c4v_energy_gradient_equals_the_reference_autograd(eng, name):
+    g = golden(name)
+    e, grad, env = _run(g)
+    assert abs(e - float(g["energy"])) < 1e-11
+    ref = g["grad"]
+    assert float(np.abs(grad - ref).max()) < 1e-9 * max(1.0, float(np.abs(ref).max()))
+    _, grad2, _ = _run(g, checkpoint=True)
+    assert float(np.abs(grad - grad2).max()) < 1e-12
+
+
+def test_forward_values_of_the_differentiable_move_equal_the_fused_move(eng):
+    """The graph path and the one-call native move are the same mathematics: C' equal, T' equal up to the eigenvector signs."""
+    from ipeps.ipeps_c4v import IPEPS_C4V
+    from ctm.one_site_c4v.env_c4v import ENV_C4V
+    from ctm.one_site_c4v import ctmrg_c4v
+    g = golden("c4v_ad_D3_chi18")
+    outs = []
+    for rg in (True, False):
+        A = dev(g["site"]).requires_grad_(rg)
+        st = IPEPS_C4V(A)
+        env = ENV_C4V(g["C0"].shape[0], st)
+        env.C[env.keyC] = dev(g["C0"]); env.T[env.keyT] = dev(g["T0"])
+        ctmrg_c4v.ctm_MOVE_sl(st.site(), env)
+        outs.append((torch.diagonal(env.get_C()).detach(), env.get_T().detach().abs()))
+    assert float((outs[0][0] - outs[1][0]).abs().max()) < 1e-11
+    assert float((outs[0][1] - outs[1][1]).abs().max()) < 1e-9
+
+
+def test_gradient_at_a_larger_size_against_finite_differences(eng):
+    """D = 3, chi = 30 (n = 270, the iterative forward solvers are not involved: SYMEIG is the full decomposition): directional
+    derivative of the energy after two moves along a random C4v-symmetric direction, central differences."""
+    from ipeps.ipeps_c4v import IPEPS_C4V
+    from ctm.one_site_c4v.env_c4v import ENV_C4V, init_env
+    from ctm.one_site_c4v import ctmrg_c4v
+    from groups.pg import make_c4v_symm
+    from models import j1j2
+    rng = np.random.default_rng(3)
+    a0 = make_c4v_symm(torch.from_numpy(rng.random((2, 3, 3, 3, 3)))).cuda()
+    da = make_c4v_symm(torch.from_numpy(rng.random((2, 3, 3, 3, 3)) - 0.5)).cuda()
+    st0 = IPEPS_C4V(a0.clone()); env0 = ENV_C4V(30, st0); init_env(st0, env0)
+    for _ in range(6):
+        ctmrg_c4v.ctm_MOVE_sl(st0.site(), env0)
+    C0, T0 = env0.get_C().clone(), env0.get_T().clone()
+    model = j1j2.J1J2_C4V_BIPARTITE(j1=1.0, j2=0.3)
+
+    def energy(a):
+        st = IPEPS_C4V(a); env = ENV_C4V(30, st)
+        env.C[env.keyC] = C0.clone(); env.T[env.keyT] = T0.clone()
+        for _ in range(2):
+            ctmrg_c4v.ctm_MOVE_sl(st.site(), env)
+        return model.energy_1x1_lowmem(st, env)
+
+    a = a0.clone().requires_grad_(True)
+    e = energy(a); e.backward()
+    lin = float((a.grad * da).sum())
+    h = 1e-5
+    with torch.no_grad():
+        fd = (float(energy(a0 + h * da)) - float(energy(a0 - h * da))) / (2 * h)
+    assert abs(lin - fd) < 1e-6 * max(1.0, abs(fd)), (lin, fd)
