@@ -352,6 +352,46 @@ def c4v_ad_case(name, base, nmoves=2, j2=0.5, complex_=False):
     print(f"  {name} ok  E={float(torch.real(e)):.12f} |grad|={np.linalg.norm(out['grad']):.6e} |grad_spec|={np.linalg.norm(out['grad_spec']):.6e}")
 
 
+def generic_ad_case(name, base, complex_=False, moves=((0, -1), (-1, 0), (0, 1), (1, 0)), j2=0.5, projector_method='4X4'):
+    """Gradient of energy_2x2_4site after one move per direction with respect to the four site tensors, by the reference's
+    autograd through ctm_MOVE (halves, truncated_svd_gesdd / SVDGESDD.backward, projectors, absorb) and rdm2x2; the environment the
+    moves start from (golden `base`: warm_*) is a constant."""
+    from helpers_cpu import sites_from, env_from
+    set_dtype(complex_)
+    g = np.load(os.path.join(GOLD, base + ".npz"))
+    sites = {k: torch.from_numpy(v.copy()).requires_grad_(True) for k, v in sites_from(g).items()}
+    st = IPEPS(sites, lX=2, lY=2)
+    C, T = env_from(g, "warm_")
+    chi = next(iter(C.values())).shape[0]
+    env = ENV(chi, st)
+    env.C = {k: torch.from_numpy(v.copy()) for k, v in C.items()}
+    env.T = {k: torch.from_numpy(v.copy()) for k, v in T.items()}
+    old = cfg.ctm_args.projector_method
+    cfg.ctm_args.projector_method = projector_method
+    try:
+        for d in moves:
+            ctmrg.ctm_MOVE(d, st, env)
+    finally:
+        cfg.ctm_args.projector_method = old
+    model = j1j2.J1J2(j1=1.0, j2=j2)
+    # energy_per_site (models/j1j2.py:223-247) with rdm2x2_legacy standing in for rdm2x2 (opt_einsum is not installed here)
+    e = 0.0
+    for c in st.sites:
+        e = e + torch.einsum('ijklabcd,ijklabcd', rdm.rdm2x2_legacy(c, st, env), model.get_hp(c))
+    e = torch.real(e) / len(st.sites)
+    e.backward()
+    out = dict(energy=np.array(float(torch.real(e))), j2=np.array(j2), base=np.array(base), moves=np.array(moves),
+               projector_method=np.array(projector_method))
+    for k, v in sites.items():
+        out[f"grad_{k[0]}_{k[1]}"] = t2n(v.grad)
+    spec = {k: t2n(v) for k, v in env.get_spectra().items()}
+    for (c, v), sv in spec.items():
+        out[f"spec_{c[0]}_{c[1]}_{v[0]}_{v[1]}"] = sv
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **out)
+    gn = np.sqrt(sum(np.linalg.norm(out[k]) ** 2 for k in out if k.startswith("grad_")))
+    print(f"  {name} ok  E={float(torch.real(e)):.12f} |grad|={gn:.6e}")
+
+
 def rvb_case():
     """G1/G2: the reference's own known-answer test (examples/j1j2/ctmrg_j1j2_c4v.py:218-260):
     RVB_1x1 D=3 chi=16 j2=0.5 -> E = -0.47684229 +- 1e-8."""
@@ -589,7 +629,7 @@ def input_files_case():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["decomp", "generic", "c4v", "c4v_ad", "rvb", "files", "variants", "aklt", "inputs", "backward"]
+    which = sys.argv[1:] or ["decomp", "generic", "c4v", "c4v_ad", "generic_ad", "rvb", "files", "variants", "aklt", "inputs", "backward"]
     if "backward" in which:
         backward_case()
     if "inputs" in which:
@@ -613,6 +653,11 @@ if __name__ == "__main__":
         c4v_ad_case("c4v_ad_D2_chi8", "c4v_D2_chi8")
         c4v_ad_case("c4v_ad_D3_chi18", "c4v_D3_chi18")
         c4v_ad_case("c4v_ad_D2_chi8_c128", "c4v_D2_chi8_c128", complex_=True)
+    if "generic_ad" in which:
+        sys.path.insert(0, os.path.join(REPO, "tests"))
+        generic_ad_case("generic_ad_D2_chi8_f64", "generic_D2_chi8_f64")
+        generic_ad_case("generic_ad_D2_chi8_c128", "generic_D2_chi8_c128", complex_=True)
+        generic_ad_case("generic_ad_D2_chi8_f64_4x2", "generic_D2_chi8_f64", moves=((0, -1), (1, 0)), projector_method='4X2')
     if "rvb" in which:
         rvb_case()
     if "files" in which:

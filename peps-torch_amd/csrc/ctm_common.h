@@ -60,6 +60,7 @@ struct ctm_ctx {
     int jacobi_block = 32;
     int jacobi_max_sweeps = 30;
     double jacobi_tol = 1e-14;
+    double svd_null_tol = 1e-11;       // full decomposition: right vectors of s_i <= svd_null_tol s_0 are completed orthonormally (svd_full)
     int jacobi_inner_sweeps = 2;        // inner sweeps of the LDS eigensolver per visit of a pair (2 or 3 pairs per round)
     int jacobi_inner_sweeps_many = 1;   // ... when a round has >= 4 pairs (dense small SVDs, full-block Rayleigh-Ritz): measured faster
     int jacobi_verbose = 0;

@@ -96,6 +96,7 @@ int ctm_sync(ctm_ctx* ctx) {
 int ctm_set_option(ctm_ctx* ctx, const char* key, double value) {
     const std::string k(key ? key : "");
     if (k == "jacobi_tol") ctx->jacobi_tol = value;
+    else if (k == "svd_null_tol") ctx->svd_null_tol = value;
     else if (k == "jacobi_max_sweeps") ctx->jacobi_max_sweeps = (int)value;
     else if (k == "jacobi_block") ctx->jacobi_block = (int)value;
     else if (k == "jacobi_inner_sweeps") ctx->jacobi_inner_sweeps = (int)value;

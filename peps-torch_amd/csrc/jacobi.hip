@@ -825,7 +825,27 @@ int svd_full(ctm_ctx* ctx, const double* M, int n, int k, double* S, double* Ut,
         CTM_TRY(row_norms(ctx, Vt, k, n, n, S));
         CTM_LAUNCH(ctx, inv_or_zero_kernel, dim3((k + 255) / 256), dim3(256), 0, S, inv, k);
         CTM_LAUNCH(ctx, scale_rows_kernel, dim3(1024), dim3(256), 0, Vt, k, n, (long long)n, inv);
-        CTM_TRY(reorth_rows(ctx, Vt, k, n, n, 2));
+        // Rows whose singular value sits at the rounding level of M (s_i <= null_tol s_0): U^T M is noise there and the 1/s scaling
+        // turns it into O(1) garbage that the re-orthonormalisation cannot repair.  Like LAPACK, return an ORTHONORMAL V for a
+        // rank-deficient matrix: those rows become an orthonormal basis of the orthogonal complement of the others (eigenvectors
+        // with eigenvalue 1 of the projector 1 - Vg^T Vg).  The differentiable full decomposition (linalg/svd_gesdd.py) needs it.
+        int kg = k;
+        while (kg > 0 && !(hs[kg - 1] > ctx->svd_null_tol * hs[0])) --kg;
+        if (kg > 0 && kg < k) {
+            CTM_TRY(reorth_rows(ctx, Vt, kg, n, n, 2));
+            double *Pm, *Dn, *Wn;
+            CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)n * n, (void**)&Pm));
+            CTM_TRY(arena_alloc(ctx, sizeof(double) * (k - kg), (void**)&Dn));
+            CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)(k - kg) * n, (void**)&Wn));
+            CTM_TRY(set_identity(ctx, Pm, n, n));
+            GemmDesc gp; gp.M = n; gp.N = n; gp.K = kg; gp.A = Vt; gp.sam = 1; gp.sak = n; gp.B = Vt; gp.sbk = n; gp.sbn = 1; gp.C = Pm; gp.ldc = n;
+            gp.alpha = -1.0; gp.beta = 1.0;
+            CTM_TRY(gemm_f64(ctx, gp));
+            CTM_TRY(jacobi_eigh_top(ctx, Pm, n, k - kg, Dn, Wn, nullptr));
+            CTM_HIP_CHECK(ctx, hipMemcpyAsync(Vt + (size_t)kg * n, Wn, sizeof(double) * (size_t)(k - kg) * n, hipMemcpyDeviceToDevice, ctx->stream));
+            CTM_TRY(reorth_rows(ctx, Vt, k, n, n, 1));
+        } else
+            CTM_TRY(reorth_rows(ctx, Vt, k, n, n, 2));
     }
     return CTM_OK;
 }
@@ -1102,6 +1122,16 @@ __global__ void planar_to_panel_kernel(const double* re, const double* im, long 
     }
 }
 
+// (Pr + i Pi) <- 1 - (Pr + i Pi)
+__global__ void eye_minus_kernel(double* Pr, double* Pi, int n) {
+    const size_t tot = (size_t)n * n;
+    for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < tot; q += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = q / n, c = q - r * n;
+        Pr[q] = (r == c ? 1.0 : 0.0) - Pr[q];
+        Pi[q] = -Pi[q];
+    }
+}
+
 __global__ void add_inplace_kernel(double* x, const double* y, size_t n) {
     for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (size_t)gridDim.x * blockDim.x) x[q] += y[q];
 }
@@ -1202,7 +1232,32 @@ int svd_full_c(ctm_ctx* ctx, const double* Mr, const double* Mi, int n, int k, d
         CTM_TRY(row_norms_c128(ctx, Vt, Vt + kn, k, n, n, S));
         CTM_LAUNCH(ctx, inv_or_zero_kernel, dim3((k + 255) / 256), dim3(256), 0, S, inv, k);
         CTM_TRY(scale_planar_rows(ctx, Vt, k, n, inv));
-        CTM_TRY(reorth_rows_c(ctx, Vt, k, n, 2));
+        // rows at the rounding level of M: orthonormal basis of the complement of the others (see svd_full); rows are v_i^H, so the
+        // projector is 1 - A^H A with A = the good rows
+        int kg = k;
+        while (kg > 0 && !(hs[kg - 1] > ctx->svd_null_tol * hs[0])) --kg;
+        if (kg > 0 && kg < k) {
+            const int kb = k - kg;
+            double *Pr, *Pi, *Dn, *Wn, *Vg;
+            CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)n * n, (void**)&Pr));
+            CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)n * n, (void**)&Pi));
+            CTM_TRY(arena_alloc(ctx, sizeof(double) * kb, (void**)&Dn));
+            CTM_TRY(arena_alloc(ctx, sizeof(double) * 2 * (size_t)kb * n, (void**)&Wn));
+            CTM_TRY(arena_alloc(ctx, sizeof(double) * 2 * (size_t)kg * n, (void**)&Vg));
+            CTM_HIP_CHECK(ctx, hipMemcpyAsync(Vg, Vt, sizeof(double) * (size_t)kg * n, hipMemcpyDeviceToDevice, ctx->stream));
+            CTM_HIP_CHECK(ctx, hipMemcpyAsync(Vg + (size_t)kg * n, Vt + kn, sizeof(double) * (size_t)kg * n, hipMemcpyDeviceToDevice, ctx->stream));
+            CTM_TRY(reorth_rows_c(ctx, Vg, kg, n, 2));
+            XM ah{Vg, Vg + (size_t)kg * n, n, true, true}, a{Vg, Vg + (size_t)kg * n, n, false, false};
+            CTM_TRY(xgemm(ctx, n, n, kg, ah, a, Pr, Pi, n));
+            CTM_LAUNCH(ctx, eye_minus_kernel, dim3(1024), dim3(256), 0, Pr, Pi, n);
+            CTM_TRY(jacobi_eigh_top_c(ctx, Pr, Pi, n, kb, Dn, Wn));
+            CTM_HIP_CHECK(ctx, hipMemcpyAsync(Vt, Vg, sizeof(double) * (size_t)kg * n, hipMemcpyDeviceToDevice, ctx->stream));
+            CTM_HIP_CHECK(ctx, hipMemcpyAsync(Vt + kn, Vg + (size_t)kg * n, sizeof(double) * (size_t)kg * n, hipMemcpyDeviceToDevice, ctx->stream));
+            CTM_HIP_CHECK(ctx, hipMemcpyAsync(Vt + (size_t)kg * n, Wn, sizeof(double) * (size_t)kb * n, hipMemcpyDeviceToDevice, ctx->stream));
+            CTM_HIP_CHECK(ctx, hipMemcpyAsync(Vt + kn + (size_t)kg * n, Wn + (size_t)kb * n, sizeof(double) * (size_t)kb * n, hipMemcpyDeviceToDevice, ctx->stream));
+            CTM_TRY(reorth_rows_c(ctx, Vt, k, n, 1));
+        } else
+            CTM_TRY(reorth_rows_c(ctx, Vt, k, n, 2));
     }
     return CTM_OK;
 }

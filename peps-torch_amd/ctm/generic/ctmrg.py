@@ -136,6 +136,13 @@ def ctm_MOVE(direction, state, env, ctm_args=cfg.ctm_args, global_args=cfg.globa
     if direction not in _ABS:
         raise ValueError("Invalid direction: " + str(direction))
     norm_kind = 1 if ctm_args.ctm_absorb_normalization == 'inf' else 2      # anything else is the 2-norm (ctmrg.py:212-214)
+    from ctm.generic import ctm_ad
+    if ctm_ad.wants_grad(state, env):
+        # a tensor requires grad: the explicit, differentiable route (graph of native contraction / SVD nodes);
+        # single process (the adjoint of the rank exchanges is not built)
+        if parallel.is_distributed():
+            raise NotImplementedError("ctm_MOVE with tensors that require grad is single-process")
+        return ctm_ad.ctm_MOVE(direction, state, env, ctm_args)
     eng = get_engine()
     coords = list(state.sites.keys())
     mine = parallel.my_units(coords)

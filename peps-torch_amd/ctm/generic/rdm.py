@@ -53,6 +53,18 @@ def rdm2x2(coord, state, env, open_sites=[0, 1, 2, 3], unroll=[], checkpoint_unr
     t = _corner_t(LU, (x, y), state, env) + _corner_t(RU, (x + 1, y), state, env) \
         + _corner_t(RD, (x + 1, y + 1), state, env) + _corner_t(LD, (x, y + 1), state, env)
     eng = get_engine()
+    from ctm.generic import ctm_ad
+    if ctm_ad.wants_grad(state, env):
+        # differentiable route: the same contraction as a graph of native contraction nodes
+        raw = ctm_ad.rdm2x2(coord, state, env)
+        if open_sites != [0, 1, 2, 3]:
+            ket, bra = list("abcd"), list("efgh")
+            for i in range(4):
+                if i not in open_sites:
+                    bra[i] = ket[i]
+            keep = [ket[i] for i in open_sites] + [bra[i] for i in open_sites]
+            raw = torch.einsum("".join(ket + bra) + "->" + "".join(keep), raw)
+        return _sym_pos_def_rdm(raw.contiguous(), sym_pos_def=sym_pos_def, verbosity=verbosity, who="rdm2x2")
     if hasattr(eng, "trim"):
         # the open halves need n^2 (p^4 + 2 p^2) elements: at large n give the worker contexts' arenas (concurrent sweep
         # units) back to the device first

@@ -93,6 +93,16 @@ class J1J2():
         RDMs are independent: with torch.distributed each rank evaluates its sites and the partial sums
         are all-reduced."""
         coords = list(state.sites.keys())
+        from ctm.generic import ctm_ad
+        if ctm_ad.wants_grad(state, env):
+            # differentiable route (SURVEY 8 f4): the value stays a graph (no host floats), plaquettes one after the other
+            if abs(self.j3) > 0:
+                raise NotImplementedError("energy_per_site with tensors that require grad: the j3 correlator term is forward only")
+            e = 0.
+            for coord in coords:
+                r = rdm.rdm2x2(coord, state, env).cpu()
+                e = e + _cast_to_real(torch.einsum('ijklabcd,ijklabcd', r, self.get_hp(coord).to(r.dtype)))
+            return e / len(coords)
         groups = parallel.site_groups(len(coords))
         if any(len(g) > 1 for g in groups):
             return self._energy_per_site_grouped(state, env, coords, groups)

@@ -45,6 +45,16 @@ class FakeEngine:
                                    eps_multiplet=1e-12 if cfg is None else cfg.eps_multiplet)
         return _t(D), _t(U)
 
+    def truncated_svd(self, M, chi, cfg=None, basis=None):
+        km = True if cfg is None else cfg.keep_multiplets
+        U, S, V = O.truncated_svd_gesdd(_n(M), chi, abs_tol=1e-14 if cfg is None else cfg.multiplet_abstol, keep_multiplets=km,
+                                        eps_multiplet=1e-8 if cfg is None else cfg.eps_multiplet)
+        return _t(U), _t(S), _t(V)
+
+    def svd_backward(self, U, S, V, gU=None, gS=None, gV=None, eps=1.0e-12):
+        f = lambda x: None if x is None else _n(x)
+        return _t(O.svd_backward(_n(U), _n(S), _n(V), f(gU), f(gS), f(gV), eps))
+
     def eigh_backward(self, D, U, gD=None, gU=None, reg=1.0e-12):
         return _t(O.eigh_backward(_n(D), _n(U), None if gD is None else _n(gD), None if gU is None else _n(gU), reg))
 

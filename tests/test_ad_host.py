@@ -108,3 +108,48 @@ def test_c4v_spectrum_loss_gradient(fake, name):
     l.backward()
     assert abs(float(l) - float(g["loss_spec"])) < 1e-10 * float(g["loss_spec"])
     assert float(np.abs(A.grad.numpy() - g["grad_spec"]).max()) < 1e-8 * float(np.abs(g["grad_spec"]).max())
+
+
+# ---- generic 2x2 cell: one move per direction + energy_2x2_4site, gradients with respect to the four site tensors ---------------
+def _generic_energy(name, fake_cfg, checkpoint=False):
+    from helpers_cpu import sites_from, env_from
+    from ipeps.ipeps import IPEPS
+    from ctm.generic.env import ENV
+    from ctm.generic import ctmrg
+    from models import j1j2
+    g = golden(name)
+    b = golden(str(g["base"]))
+    sites = {k: torch.from_numpy(v.copy()).requires_grad_(True) for k, v in sites_from(b).items()}
+    st = IPEPS(sites, lX=2, lY=2)
+    C, T = env_from(b, "warm_")
+    env = ENV(next(iter(C.values())).shape[0], st)
+    env.C = {k: torch.from_numpy(v.copy()) for k, v in C.items()}
+    env.T = {k: torch.from_numpy(v.copy()) for k, v in T.items()}
+    old = fake_cfg.ctm_args.projector_method
+    fake_cfg.ctm_args.projector_method = str(g["projector_method"])
+    fake_cfg.ctm_args.fwd_checkpoint_move = checkpoint
+    try:
+        for d in g["moves"]:
+            ctmrg.ctm_MOVE(tuple(int(x) for x in d), st, env)
+    finally:
+        fake_cfg.ctm_args.projector_method = old
+        fake_cfg.ctm_args.fwd_checkpoint_move = False
+    e = j1j2.J1J2(j1=1.0, j2=float(g["j2"])).energy_2x2_4site(st, env)
+    e.backward()
+    return g, float(e.detach()), {k: v.grad for k, v in sites.items()}
+
+
+@pytest.mark.parametrize("name", ["generic_ad_D2_chi8_f64", "generic_ad_D2_chi8_c128", "generic_ad_D2_chi8_f64_4x2"])
+def test_generic_energy_gradient_equals_the_reference_autograd(fake, name):
+    g, e, grads = _generic_energy(name, fake)
+    assert abs(e - float(g["energy"])) < 1e-11
+    for k, gr in grads.items():
+        ref = g[f"grad_{k[0]}_{k[1]}"]
+        assert float(np.abs(gr.numpy() - ref).max()) < 1e-9 * max(1.0, float(np.abs(ref).max())), k
+
+
+def test_generic_gradient_with_checkpointed_moves_is_the_same(fake):
+    _, _, g0 = _generic_energy("generic_ad_D2_chi8_f64", fake)
+    _, _, g1 = _generic_energy("generic_ad_D2_chi8_f64", fake, checkpoint=True)
+    for k in g0:
+        assert float((g0[k] - g1[k]).abs().max()) < 1e-13

@@ -168,3 +168,22 @@ def test_row_block_times_big_operand_kernels(eng, rows_kernel):
                 assert (C - ref).abs().max().item() < 1e-11 * ref.abs().max().item(), (m, tB)
     finally:
         eng.set_option("rows_kernel_min_m", old[0]); eng.set_option("rows_kernel_min_m_kc", old[1])
+
+
+@pytest.mark.parametrize("cplx", [False, True])
+def test_full_decomposition_of_a_rank_deficient_matrix_returns_orthonormal_factors(eng, cplx):
+    """chi = n on a matrix of rank n/3 (plus singular values at the rounding level): U and V are complete orthonormal bases, as
+    LAPACK returns them -- the differentiable full decomposition feeds both to the regularised backward."""
+    n, r = 96, 32
+    g = torch.Generator().manual_seed(17)
+    dt = torch.complex128 if cplx else torch.float64
+    A = torch.randn(n, r, generator=g, dtype=dt) * (0.5 ** torch.arange(r, dtype=torch.float64)).to(dt)
+    B = torch.randn(r, n, generator=g, dtype=dt)
+    M = (A @ B).cuda()
+    U, S, V = eng.truncated_svd(M, n, eng.cfg(keep_multiplets=False))
+    I = torch.eye(n, dtype=dt, device=M.device)
+    assert float((U.conj().T @ U - I).abs().max()) < 1e-12
+    assert float((V.conj().T @ V - I).abs().max()) < 1e-12
+    Sref = torch.linalg.svdvals(M.cpu())
+    assert float((S.cpu() - Sref).abs().max()) < 1e-12 * float(Sref[0])
+    assert float((U * S.to(dt) @ V.conj().T - M).abs().max()) < 1e-12 * float(Sref[0])
