@@ -153,3 +153,36 @@ def test_generic_gradient_with_checkpointed_moves_is_the_same(fake):
     _, _, g1 = _generic_energy("generic_ad_D2_chi8_f64", fake, checkpoint=True)
     for k in g0:
         assert float((g0[k] - g1[k]).abs().max()) < 1e-13
+
+
+@pytest.mark.parametrize("which", ["energy_1x1", "SS2x1"])
+def test_c4v_other_rdm_graphs_against_finite_differences(fake, which):
+    """rdm2x2 (energy_1x1) and rdm2x1 (nearest-neighbour S.S of eval_obs) of the C4v network as differentiable graphs: directional
+    derivative along a random C4v-symmetric direction vs central differences (environment fixed)."""
+    from ipeps.ipeps_c4v import IPEPS_C4V
+    from ctm.one_site_c4v.env_c4v import ENV_C4V
+    from ctm.one_site_c4v import rdm_c4v
+    from groups.pg import make_c4v_symm
+    from models import j1j2
+    g = golden("c4v_ad_D2_chi8")
+    model = j1j2.J1J2_C4V_BIPARTITE(j1=1.0, j2=0.4)
+    C0, T0 = torch.from_numpy(g["C0"].copy()), torch.from_numpy(g["T0"].copy())
+
+    def f(a):
+        st = IPEPS_C4V(a)
+        env = ENV_C4V(C0.shape[0], st)
+        env.C[env.keyC] = C0; env.T[env.keyT] = T0
+        if which == "energy_1x1":
+            return model.energy_1x1(st, env)
+        r2 = rdm_c4v.rdm2x1_sl(st, env, sym_pos_def=True)
+        return torch.einsum('ijab,ijab', r2, model.SS_rot.to(r2.dtype))
+
+    a0 = torch.from_numpy(g["site"].copy())
+    rng = np.random.default_rng(8)
+    da = make_c4v_symm(torch.from_numpy(rng.random(a0.shape) - 0.5))
+    a = a0.clone().requires_grad_(True)
+    f(a).backward()
+    lin = float((a.grad * da).sum())
+    h = 1e-6      # the engine double has no fused C4v RDM: the shifted values also go through the graph route
+    fd = (float(f((a0 + h * da).requires_grad_(True)).detach()) - float(f((a0 - h * da).requires_grad_(True)).detach())) / (2 * h)
+    assert abs(lin - fd) < 1e-7 * max(1.0, abs(fd)), (lin, fd)

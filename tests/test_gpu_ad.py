@@ -172,3 +172,35 @@ def test_generic_differentiable_move_equals_the_fused_move(eng):
         spectra.append({k: v.detach() for k, v in env.get_spectra().items()})
     for k in spectra[0]:
         assert float((spectra[0][k] - spectra[1][k]).abs().max()) < 1e-10
+
+
+def test_c4v_rdm_graphs_equal_the_fused_rdms(eng):
+    from ipeps.ipeps_c4v import IPEPS_C4V
+    from ctm.one_site_c4v.env_c4v import ENV_C4V
+    from ctm.one_site_c4v import rdm_c4v
+    g = golden("c4v_ad_D3_chi18")
+    for fn in (rdm_c4v.rdm2x1_sl, rdm_c4v.rdm2x2_NN_lowmem_sl, rdm_c4v.rdm2x2_NNN_lowmem_sl, rdm_c4v.rdm2x2):
+        vals = []
+        for rg in (True, False):
+            st = IPEPS_C4V(dev(g["site"]).requires_grad_(rg))
+            env = ENV_C4V(g["C0"].shape[0], st)
+            env.C[env.keyC] = dev(g["C0"]); env.T[env.keyT] = dev(g["T0"])
+            vals.append(fn(st, env, sym_pos_def=True).detach())
+        assert float((vals[0] - vals[1]).abs().max()) < 1e-12, fn.__name__
+
+
+def test_generic_rdm2x2_graph_equals_the_fused_rdm(eng):
+    from helpers_cpu import sites_from, env_from
+    from ipeps.ipeps import IPEPS
+    from ctm.generic.env import ENV
+    from ctm.generic import rdm
+    b = golden("generic_D2_chi8_c128")
+    vals = []
+    for rg in (True, False):
+        sites = {k: dev(v).requires_grad_(rg) for k, v in sites_from(b).items()}
+        st = IPEPS(sites, lX=2, lY=2)
+        C, T = env_from(b, "warm_")
+        env = ENV(next(iter(C.values())).shape[0], st)
+        env.C = {k: dev(v) for k, v in C.items()}; env.T = {k: dev(v) for k, v in T.items()}
+        vals.append(rdm.rdm2x2((1, 0), st, env).detach())
+    assert float((vals[0] - vals[1]).abs().max()) < 1e-12
