@@ -97,6 +97,8 @@ int ctm_set_option(ctm_ctx* ctx, const char* key, double value) {
     const std::string k(key ? key : "");
     if (k == "jacobi_tol") ctx->jacobi_tol = value;
     else if (k == "svd_null_tol") ctx->svd_null_tol = value;
+    else if (k == "jacobi_tau_relax") ctx->jacobi_tau_relax = (int)value;
+    else if (k == "si_tau_both") ctx->si_tau_both = (int)value;
     else if (k == "jacobi_max_sweeps") ctx->jacobi_max_sweeps = (int)value;
     else if (k == "jacobi_block") ctx->jacobi_block = (int)value;
     else if (k == "jacobi_inner_sweeps") ctx->jacobi_inner_sweeps = (int)value;

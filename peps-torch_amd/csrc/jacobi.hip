@@ -43,10 +43,17 @@ struct SmallEigParams {
     double tol;          // relative off-diagonal tolerance for a rotation
     int max_sweeps;
     double tau2;         // scale floor: a pair (i,j) is measured against max(sqrt(g_ii g_jj), tau2)
+    int tau_both;        // 1: the floor applies only when BOTH rows are below it (g_ii, g_jj < tau2); pairs with a leading row keep full relative accuracy
     unsigned long long* stat_rel;   // max |g_ij| / max(sqrt(g_ii g_jj), tau2)  (bits of a non-negative double)
     unsigned long long* stat_abs;   // max |g_ij| / sqrt(g_ii g_jj) (classical measure, diagnostics only)
     int* flags;          // per pair: 1 if J != I (the apply GEMM skips the others)
 };
+
+// floor of the pair measure: with `both`, a pair that contains a row at or above the floor is measured relative to its own rows only
+__device__ __forceinline__ double tau_floor(double a, double b, double tau2, int both) {
+    return (both && (a >= tau2 || b >= tau2)) ? 0.0 : tau2;
+}
+
 
 // Two-sided cyclic Jacobi on one m x m (m <= 64, even) symmetric matrix per workgroup, everything in LDS.
 // Round-robin ordering: m/2 disjoint rotations per round; per round the rotation parameters are computed by
@@ -94,7 +101,7 @@ __global__ __launch_bounds__(1024) void small_eig_kernel(SmallEigParams p) {
                 const double g = fabs(W[r][c]), a = W[r][r], b = W[c][c];
                 if (g > 0.0) {
                     const double sc = sqrt(fabs(a * b));
-                    srel = fmax(srel, g / fmax(sc, p.tau2));
+                    srel = fmax(srel, g / fmax(sc, tau_floor(a, b, p.tau2, p.tau_both)));
                     if (sc > 0.0) sabs = fmax(sabs, g / sc);
                 }
             }
@@ -152,7 +159,7 @@ __global__ __launch_bounds__(1024) void small_eig_kernel(SmallEigParams p) {
                 const int pi = pair_tab[r][tid][0], qi = pair_tab[r][tid][1];
                 const double a = W[pi][pi], b = W[qi][qi], g = W[pi][qi];
                 double c = 1.0, s = 0.0;
-                if (g != 0.0 && fabs(g) > p.tol * fmax(sqrt(fabs(a * b)), p.tau2)) {
+                if (g != 0.0 && fabs(g) > p.tol * fmax(sqrt(fabs(a * b)), tau_floor(a, b, p.tau2, p.tau_both))) {
                     // tan of the rotation angle: t = 2g / (d + sign(d) hypot(d, 2g)), d = b - a.  Only c^2 + s^2 = 1 has to
                     // hold to machine precision (orthogonality); the angle itself may carry the ~1e-8 error of the
                     // hardware rsq/rcp seeds, so t uses the fast seeds and c = rsqrt(1 + t^2) gets two Newton steps.
@@ -248,8 +255,9 @@ __device__ __forceinline__ void rr_pair64(int r, int k, int& p, int& q) {
     p = min(a, b); q = max(a, b);
 }
 
-__device__ __forceinline__ void jacobi_cs(double a, double b, double g, double tol, double tau2, double& c, double& s, bool& rot) {
+__device__ __forceinline__ void jacobi_cs(double a, double b, double g, double tol, double tau2in, int both, double& c, double& s, bool& rot) {
     c = 1.0; s = 0.0; rot = false;
+    const double tau2 = tau_floor(a, b, tau2in, both);
     // |g| > tol * max(sqrt|a b|, tau2)  <=>  g^2 > tol^2 * max(|a b|, tau2^2): no square root on the critical path
     if (g != 0.0 && g * g > tol * tol * fmax(fabs(a * b), tau2 * tau2)) {
         const double d = b - a, g2 = 2.0 * g;
@@ -302,7 +310,7 @@ __global__ __launch_bounds__(1024 / BPT) void small_eig64_kernel(SmallEigParams 
                 const double g = fabs(Wb[0][r][c]), a = Wb[0][r][r], b = Wb[0][c][c];
                 if (g > 0.0) {
                     const double sc = sqrt(fabs(a * b));
-                    srel = fmax(srel, g / fmax(sc, p.tau2));
+                    srel = fmax(srel, g / fmax(sc, tau_floor(a, b, p.tau2, p.tau_both)));
                     if (sc > 0.0) sabs = fmax(sabs, g / sc);
                 }
             }
@@ -350,7 +358,7 @@ __global__ __launch_bounds__(1024 / BPT) void small_eig64_kernel(SmallEigParams 
                 jp0[u] = Jm[k1][p2]; jq0[u] = Jm[k1][q2]; jp1[u] = Jm[k1 + 32][p2]; jq1[u] = Jm[k1 + 32][q2];
             }
             double c2, s2; bool r2;
-            jacobi_cs(a2, d2, g2, p.tol, p.tau2, c2, s2, r2);
+            jacobi_cs(a2, d2, g2, p.tol, p.tau2, p.tau_both, c2, s2, r2);
 #pragma unroll
             for (int u = 0; u < BPT; ++u) {
                 const int k1 = kb + u * KS;
@@ -442,7 +450,7 @@ __global__ __launch_bounds__(256) void small_eig_c_kernel(SmallEigParams p) {
                 const double g = sqrt(Wr[r][c] * Wr[r][c] + Wi[r][c] * Wi[r][c]), a = Wr[r][r], b = Wr[c][c];
                 if (g > 0.0) {
                     const double sc = sqrt(fabs(a * b));
-                    srel = fmax(srel, g / fmax(sc, p.tau2));
+                    srel = fmax(srel, g / fmax(sc, tau_floor(a, b, p.tau2, p.tau_both)));
                     if (sc > 0.0) sabs = fmax(sabs, g / sc);
                 }
             }
@@ -489,7 +497,7 @@ __global__ __launch_bounds__(256) void small_eig_c_kernel(SmallEigParams p) {
                 const double a = Wr[pi][pi], b = Wr[qi][qi], gr = Wr[pi][qi], gi = Wi[pi][qi];
                 const double g = sqrt(gr * gr + gi * gi);
                 double c = 1.0, s = 0.0, er = 1.0, ei = 0.0;
-                if (g != 0.0 && g > p.tol * fmax(sqrt(fabs(a * b)), p.tau2)) {
+                if (g != 0.0 && g > p.tol * fmax(sqrt(fabs(a * b)), tau_floor(a, b, p.tau2, p.tau_both))) {
                     er = gr / g; ei = gi / g;
                     const double d = b - a, g2 = 2.0 * g;
                     const double h = sqrt(d * d + g2 * g2);
@@ -616,7 +624,8 @@ int get_tables(ctm_ctx* ctx, int nbk, long long ld, int b, int Cg, RRTables** ou
 // its pair and finishes reading it before it writes.
 // ktop > 0: only the ktop largest rows need full relative accuracy -- pairs of smaller rows are measured against
 // tau = (ktop-th largest row norm), which still bounds the spectral norm of the remaining rows by tau(1 + R tol).
-int jacobi_rows(ctm_ctx* ctx, double* X, int R, long long ld, int Cg, int Ctot, int b, int ktop, double fro, int max_sweeps, bool cplx = false) {
+int jacobi_rows(ctm_ctx* ctx, double* X, int R, long long ld, int Cg, int Ctot, int b, int ktop, double fro, int max_sweeps, bool cplx = false,
+                bool tau_both = false) {
     const int nbk = R / b, rounds = nbk - 1, pairs = nbk / 2, m = 2 * b;
     if (cplx && b != 32) { ctx->set_error("jacobi_rows: complex panels are 16 + 16 real rows"); return CTM_ERR_BADARG; }
     RRTables* T;
@@ -634,7 +643,7 @@ int jacobi_rows(ctm_ctx* ctx, double* X, int R, long long ld, int Cg, int Ctot, 
     ctx->last_sweeps = 0;
     for (int sweep = 0; sweep < max_sweeps; ++sweep) {
         double tau2 = floor2;
-        if (ktop > 0 && ktop < (cplx ? R / 2 : R)) {
+        if (ctx->jacobi_tau_relax && ktop > 0 && ktop < (cplx ? R / 2 : R)) {
             CTM_TRY(row_norms(ctx, X, R, Cg, ld, norms));
             CTM_HIP_CHECK(ctx, hipMemcpyAsync(h.data(), norms, sizeof(double) * R, hipMemcpyDeviceToHost, ctx->stream));
             CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
@@ -659,7 +668,7 @@ int jacobi_rows(ctm_ctx* ctx, double* X, int R, long long ld, int Cg, int Ctot, 
             CTM_TRY(gemm_f64(ctx, g));
             SmallEigParams sp;
             sp.G = G; sp.nsplit = T->nsplit; sp.split_stride = (long long)pairs * m * m; sp.J = J; sp.m = m; sp.tol = ctx->jacobi_tol * 0.1; sp.max_sweeps = (pairs == 1) ? 12 : (pairs >= 4 ? ctx->jacobi_inner_sweeps_many : ctx->jacobi_inner_sweeps);
-            sp.tau2 = tau2; sp.stat_rel = stat; sp.stat_abs = stat + 1; sp.flags = flags;
+            sp.tau2 = tau2; sp.tau_both = tau_both ? 1 : 0; sp.stat_rel = stat; sp.stat_abs = stat + 1; sp.flags = flags;
             if (cplx) CTM_LAUNCH(ctx, small_eig_c_kernel, dim3(pairs), dim3(256), 0, sp);
             else if (m == 64 && ctx->eig64_pingpong) {
                 if (ctx->eig64_bpt == 4) CTM_LAUNCH(ctx, small_eig64_kernel<4>, dim3(pairs), dim3(256), 0, sp);
@@ -1039,7 +1048,8 @@ int svd_iter(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* Ut, double
         int st;
         const double fro = host_fro(ctx, nxt, p, n, ld, norms, h, &st);
         CTM_TRY(st);
-        CTM_TRY(jacobi_rows(ctx, nxt, p, ld, n, (int)ld, p == 32 ? 16 : b, std::min(k, p - 1), fro, (have_prev || warm) ? ctx->si_rr_sweeps : std::min(3, ctx->si_rr_sweeps)));
+        CTM_TRY(jacobi_rows(ctx, nxt, p, ld, n, (int)ld, p == 32 ? 16 : b, std::min(k, p - 1), fro, (have_prev || warm) ? ctx->si_rr_sweeps : std::min(3, ctx->si_rr_sweeps),
+                            false, ctx->si_tau_both != 0));
         CTM_TRY(row_norms(ctx, nxt, p, n, ld, norms));
         h.assign(p_full, 0.0);
         CTM_HIP_CHECK(ctx, hipMemcpyAsync(h.data(), norms, sizeof(double) * p, hipMemcpyDeviceToHost, ctx->stream));
@@ -1413,7 +1423,8 @@ int svd_iter_c(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* Ut, doub
         std::vector<double> hh;
         const double fro = host_fro(ctx, nxt, R, n, ld, norms, hh, &st);
         CTM_TRY(st);
-        CTM_TRY(jacobi_rows(ctx, nxt, R, ld, n, (int)ld, 2 * BC, std::min(k, p - 1), fro, (have_prev || warm) ? ctx->si_rr_sweeps : std::min(3, ctx->si_rr_sweeps), true));
+        CTM_TRY(jacobi_rows(ctx, nxt, R, ld, n, (int)ld, 2 * BC, std::min(k, p - 1), fro, (have_prev || warm) ? ctx->si_rr_sweeps : std::min(3, ctx->si_rr_sweeps), true,
+                            ctx->si_tau_both != 0));
         CTM_TRY(row_norms(ctx, nxt, R, n, ld, norms));
         CTM_LAUNCH(ctx, panel_combine_kernel, dim3((R + 255) / 256), dim3(256), 0, norms, nc, R);
         CTM_HIP_CHECK(ctx, hipMemcpyAsync(tmp.data(), nc, sizeof(double) * R, hipMemcpyDeviceToHost, ctx->stream));
