@@ -179,5 +179,46 @@ def rdm2x2(coord, state, env):
     return r.permute(0, 2, 4, 6, 1, 3, 5, 7)
 
 
+def rdm1x1(coord, state, env):
+    """rdm1x1 (rdm.py:71-302): the full one-site environment contracted over the auxiliary legs.  Raw."""
+    c = state.vertexToSite(coord)
+    a = state.site(coord)
+    D = a.shape
+    C1, C2, C3, C4 = env.C[(c, (-1, -1))], env.C[(c, (1, -1))], env.C[(c, (1, 1))], env.C[(c, (-1, 1))]
+    T1 = _split(env.T[(c, (0, -1))], 1, D[1]); T4 = _split(env.T[(c, (-1, 0))], 2, D[2])
+    T3 = _split(env.T[(c, (0, 1))], 0, D[3]); T2 = _split(env.T[(c, (1, 0))], 1, D[4])
+    return einsum('ab,bUVc,ce,eRQf,fg,XYhg,ih,aiLM,sULXR,tVMYQ->st', C1, T1, C2, T2, C3, T3, C4, T4, a, a, conj=(9,))
+
+
+def rdm2x1(coord, state, env):
+    """rdm2x1 (rdm.py:304-500): horizontal pair coord, coord + (1,0); s0 s1 ; s0' s1'.  Raw."""
+    x, y = coord
+    c0, c1 = state.vertexToSite((x, y)), state.vertexToSite((x + 1, y))
+    a0, a1 = state.site((x, y)), state.site((x + 1, y))
+    D0, D1 = a0.shape, a1.shape
+    C1, C4 = env.C[(c0, (-1, -1))], env.C[(c0, (-1, 1))]
+    T1a = _split(env.T[(c0, (0, -1))], 1, D0[1]); T4 = _split(env.T[(c0, (-1, 0))], 2, D0[2]); T3a = _split(env.T[(c0, (0, 1))], 0, D0[3])
+    C2, C3 = env.C[(c1, (1, -1))], env.C[(c1, (1, 1))]
+    T1b = _split(env.T[(c1, (0, -1))], 1, D1[1]); T2 = _split(env.T[(c1, (1, 0))], 1, D1[4]); T3b = _split(env.T[(c1, (0, 1))], 0, D1[3])
+    left = einsum('ab,bUVc,ih,aiLM,XYhg,sULXR,tVMYQ->cRQgst', C1, T1a, C4, T4, T3a, a0, a0, conj=(6,))
+    right = einsum('ce,eRQf,fg,jUVc,XYhg,sULXR,tVMYQ->jLMhst', C2, T2, C3, T1b, T3b, a1, a1, conj=(6,))
+    return einsum('cRQgst,cRQguv->sutv', left, right)
+
+
+def rdm1x2(coord, state, env):
+    """rdm1x2 (rdm.py:622-826): vertical pair coord, coord + (0,1); s0 s1 ; s0' s1'.  Raw."""
+    x, y = coord
+    c0, c1 = state.vertexToSite((x, y)), state.vertexToSite((x, y + 1))
+    a0, a1 = state.site((x, y)), state.site((x, y + 1))
+    D0, D1 = a0.shape, a1.shape
+    C1, C2 = env.C[(c0, (-1, -1))], env.C[(c0, (1, -1))]
+    T1 = _split(env.T[(c0, (0, -1))], 1, D0[1]); T4a = _split(env.T[(c0, (-1, 0))], 2, D0[2]); T2a = _split(env.T[(c0, (1, 0))], 1, D0[4])
+    C4, C3 = env.C[(c1, (-1, 1))], env.C[(c1, (1, 1))]
+    T3 = _split(env.T[(c1, (0, 1))], 0, D1[3]); T4b = _split(env.T[(c1, (-1, 0))], 2, D1[2]); T2b = _split(env.T[(c1, (1, 0))], 1, D1[4])
+    up = einsum('ab,bUVc,ce,aiLM,eRQf,sULXR,tVMYQ->iXYfst', C1, T1, C2, T4a, T2a, a0, a0, conj=(6,))
+    lo = einsum('jh,XYhg,fg,ijLM,eRQf,sULXR,tVMYQ->iUVest', C4, T3, C3, T4b, T2b, a1, a1, conj=(6,))
+    return einsum('iXYfst,iXYfuv->sutv', up, lo)
+
+
 def wants_grad(state, env):
     return needs_grad(*state.sites.values(), *env.C.values(), *env.T.values())

@@ -138,7 +138,9 @@ def rdm1x1(coord, state, env, operator=None, sym_pos_def=False, force_cpu=False,
     c = state.vertexToSite(coord)
     t = (env.C[(c, (-1, -1))], env.C[(c, (1, -1))], env.C[(c, (1, 1))], env.C[(c, (-1, 1))],
          env.T[(c, (0, -1))], env.T[(c, (1, 0))], env.T[(c, (0, 1))], env.T[(c, (-1, 0))], state.site(coord))
-    rdm = _sym_pos_def_rdm(get_engine().rdm1x1(t), sym_pos_def=sym_pos_def, verbosity=verbosity, who="rdm1x1")
+    from ctm.generic import ctm_ad
+    raw = ctm_ad.rdm1x1(coord, state, env) if ctm_ad.wants_grad(state, env) else get_engine().rdm1x1(t)
+    rdm = _sym_pos_def_rdm(raw, sym_pos_def=sym_pos_def, verbosity=verbosity, who="rdm1x1")
     if operator is not None:
         return torch.einsum('ij,ji', rdm, operator.to(rdm.device))
     return rdm
@@ -150,7 +152,9 @@ def rdm2x1(coord, state, env, sym_pos_def=False, force_cpu=False, verbosity=0, m
     c0, c1 = state.vertexToSite((x, y)), state.vertexToSite((x + 1, y))
     t = (env.C[(c0, (-1, -1))], env.T[(c0, (0, -1))], env.T[(c0, (-1, 0))], env.C[(c0, (-1, 1))], env.T[(c0, (0, 1))], state.site((x, y)),
          env.C[(c1, (1, -1))], env.T[(c1, (1, 0))], env.C[(c1, (1, 1))], env.T[(c1, (0, -1))], env.T[(c1, (0, 1))], state.site((x + 1, y)))
-    return _sym_pos_def_rdm(get_engine().rdm2x1(t), sym_pos_def=sym_pos_def, verbosity=verbosity, who="rdm2x1")
+    from ctm.generic import ctm_ad
+    raw = ctm_ad.rdm2x1(coord, state, env) if ctm_ad.wants_grad(state, env) else get_engine().rdm2x1(t)
+    return _sym_pos_def_rdm(raw, sym_pos_def=sym_pos_def, verbosity=verbosity, who="rdm2x1")
 
 
 def rdm1x2(coord, state, env, sym_pos_def=False, force_cpu=False, verbosity=0, mode='sl', **kwargs):
@@ -159,4 +163,6 @@ def rdm1x2(coord, state, env, sym_pos_def=False, force_cpu=False, verbosity=0, m
     c0, c1 = state.vertexToSite((x, y)), state.vertexToSite((x, y + 1))
     t = (env.C[(c0, (-1, -1))], env.T[(c0, (0, -1))], env.C[(c0, (1, -1))], env.T[(c0, (-1, 0))], env.T[(c0, (1, 0))], state.site((x, y)),
          env.C[(c1, (-1, 1))], env.T[(c1, (0, 1))], env.C[(c1, (1, 1))], env.T[(c1, (-1, 0))], env.T[(c1, (1, 0))], state.site((x, y + 1)))
-    return _sym_pos_def_rdm(get_engine().rdm1x2(t), sym_pos_def=sym_pos_def, verbosity=verbosity, who="rdm1x2")
+    from ctm.generic import ctm_ad
+    raw = ctm_ad.rdm1x2(coord, state, env) if ctm_ad.wants_grad(state, env) else get_engine().rdm1x2(t)
+    return _sym_pos_def_rdm(raw, sym_pos_def=sym_pos_def, verbosity=verbosity, who="rdm1x2")

@@ -186,3 +186,44 @@ def test_c4v_other_rdm_graphs_against_finite_differences(fake, which):
     h = 1e-6      # the engine double has no fused C4v RDM: the shifted values also go through the graph route
     fd = (float(f((a0 + h * da).requires_grad_(True)).detach()) - float(f((a0 - h * da).requires_grad_(True)).detach())) / (2 * h)
     assert abs(lin - fd) < 1e-7 * max(1.0, abs(fd)), (lin, fd)
+
+
+@pytest.mark.parametrize("base", ["generic_D2_chi8_f64", "generic_D2_chi8_c128"])
+def test_generic_small_rdm_graphs_values_and_finite_differences(fake, base):
+    """rdm1x1 / rdm2x1 / rdm1x2 as differentiable graphs: values equal the reference's (golden), directional derivative of
+    tr(rho O) with respect to the site tensors vs central differences."""
+    from helpers_cpu import sites_from, env_from
+    from ipeps.ipeps import IPEPS
+    from ctm.generic.env import ENV
+    from ctm.generic import rdm
+    b = golden(base)
+    C, T = env_from(b, "warm_")
+    chi = next(iter(C.values())).shape[0]
+    g = torch.Generator().manual_seed(4)
+
+    def build(sites):
+        st = IPEPS(sites, lX=2, lY=2)
+        env = ENV(chi, st)
+        env.C = {k: torch.from_numpy(v.copy()) for k, v in C.items()}
+        env.T = {k: torch.from_numpy(v.copy()) for k, v in T.items()}
+        return st, env
+
+    s0 = {k: torch.from_numpy(v.copy()) for k, v in sites_from(b).items()}
+    ds = {k: torch.randn(v.shape, generator=g, dtype=torch.float64).to(v.dtype) * 1e-1 for k, v in s0.items()}
+    for fn, key in ((rdm.rdm1x1, "rdm1x1"), (rdm.rdm2x1, "rdm2x1"), (rdm.rdm1x2, "rdm1x2")):
+        sites = {k: v.clone().requires_grad_(True) for k, v in s0.items()}
+        st, env = build(sites)
+        r = fn((0, 0), st, env)
+        assert float(np.abs(r.detach().numpy() - b[key]).max()) < 1e-10, key
+        O = torch.randn(r.shape, generator=g, dtype=torch.float64).to(r.dtype)
+
+        def val(sites_):
+            st_, env_ = build(sites_)
+            return torch.real((fn((0, 0), st_, env_) * O).sum())
+
+        val(sites).backward()
+        lin = sum(float(torch.real((sites[k].grad.conj() * ds[k]).sum())) for k in sites if sites[k].grad is not None)
+        h = 1e-6
+        fd = (float(val({k: (s0[k] + h * ds[k]).requires_grad_(True) for k in s0}).detach())
+              - float(val({k: (s0[k] - h * ds[k]).requires_grad_(True) for k in s0}).detach())) / (2 * h)
+        assert abs(lin - fd) < 1e-6 * max(1.0, abs(fd)), (key, lin, fd)

@@ -204,3 +204,21 @@ def test_generic_rdm2x2_graph_equals_the_fused_rdm(eng):
         env.C = {k: dev(v) for k, v in C.items()}; env.T = {k: dev(v) for k, v in T.items()}
         vals.append(rdm.rdm2x2((1, 0), st, env).detach())
     assert float((vals[0] - vals[1]).abs().max()) < 1e-12
+
+
+def test_generic_small_rdm_graphs_equal_the_fused_rdms(eng):
+    from helpers_cpu import sites_from, env_from
+    from ipeps.ipeps import IPEPS
+    from ctm.generic.env import ENV
+    from ctm.generic import rdm
+    b = golden("generic_D3_chi18_f64")
+    for fn in (rdm.rdm1x1, rdm.rdm2x1, rdm.rdm1x2):
+        vals = []
+        for rg in (True, False):
+            sites = {k: dev(v).requires_grad_(rg) for k, v in sites_from(b).items()}
+            st = IPEPS(sites, lX=2, lY=2)
+            C, T = env_from(b, "warm_")
+            env = ENV(next(iter(C.values())).shape[0], st)
+            env.C = {k: dev(v) for k, v in C.items()}; env.T = {k: dev(v) for k, v in T.items()}
+            vals.append(fn((1, 1), st, env).detach())
+        assert float((vals[0] - vals[1]).abs().max()) < 1e-12, fn.__name__
