@@ -200,7 +200,8 @@ def rdm2x1(coord, state, env):
     T1a = _split(env.T[(c0, (0, -1))], 1, D0[1]); T4 = _split(env.T[(c0, (-1, 0))], 2, D0[2]); T3a = _split(env.T[(c0, (0, 1))], 0, D0[3])
     C2, C3 = env.C[(c1, (1, -1))], env.C[(c1, (1, 1))]
     T1b = _split(env.T[(c1, (0, -1))], 1, D1[1]); T2 = _split(env.T[(c1, (1, 0))], 1, D1[4]); T3b = _split(env.T[(c1, (0, 1))], 0, D1[3])
-    left = einsum('ab,bUVc,ih,aiLM,XYhg,sULXR,tVMYQ->cRQgst', C1, T1a, C4, T4, T3a, a0, a0, conj=(6,))
+    # operand order: every operand shares an index with the running intermediate (the engine contracts left to right, no outer products)
+    left = einsum('ab,bUVc,aiLM,ih,XYhg,sULXR,tVMYQ->cRQgst', C1, T1a, T4, C4, T3a, a0, a0, conj=(6,))
     right = einsum('ce,eRQf,fg,jUVc,XYhg,sULXR,tVMYQ->jLMhst', C2, T2, C3, T1b, T3b, a1, a1, conj=(6,))
     return einsum('cRQgst,cRQguv->sutv', left, right)
 

@@ -222,3 +222,41 @@ def test_generic_small_rdm_graphs_equal_the_fused_rdms(eng):
             env.C = {k: dev(v) for k, v in C.items()}; env.T = {k: dev(v) for k, v in T.items()}
             vals.append(fn((1, 1), st, env).detach())
         assert float((vals[0] - vals[1]).abs().max()) < 1e-12, fn.__name__
+
+
+def test_generic_small_rdm_gradients_on_the_engine(eng):
+    """Backward of the rdm1x1 / rdm2x1 / rdm1x2 graphs on the kernels (every adjoint network must be contractible left to right
+    without an outer product): directional derivative vs central differences."""
+    from helpers_cpu import sites_from, env_from
+    from ipeps.ipeps import IPEPS
+    from ctm.generic.env import ENV
+    from ctm.generic import rdm
+    b = golden("generic_D2_chi8_c128")
+    C, T = env_from(b, "warm_")
+    chi = next(iter(C.values())).shape[0]
+    g = torch.Generator().manual_seed(6)
+
+    def build(sites):
+        st = IPEPS(sites, lX=2, lY=2)
+        env = ENV(chi, st)
+        env.C = {k: dev(v) for k, v in C.items()}; env.T = {k: dev(v) for k, v in T.items()}
+        return st, env
+
+    s0 = {k: dev(v) for k, v in sites_from(b).items()}
+    ds = {k: (torch.randn(v.shape, generator=g, dtype=torch.float64) * 1e-1).to(v.dtype).cuda() for k, v in s0.items()}
+    for fn in (rdm.rdm1x1, rdm.rdm2x1, rdm.rdm1x2):
+        sites = {k: v.clone().requires_grad_(True) for k, v in s0.items()}
+        st, env = build(sites)
+        r = fn((1, 0), st, env)
+        O = torch.randn(r.shape, generator=g, dtype=torch.float64).to(r.dtype).to(r.device)
+
+        def val(sites_):
+            st_, env_ = build(sites_)
+            return torch.real((fn((1, 0), st_, env_) * O).sum())
+
+        val(sites).backward()
+        lin = sum(float(torch.real((sites[k].grad.conj() * ds[k]).sum())) for k in sites if sites[k].grad is not None)
+        h = 1e-6
+        with torch.no_grad():
+            fd = (float(val({k: s0[k] + h * ds[k] for k in s0})) - float(val({k: s0[k] - h * ds[k] for k in s0}))) / (2 * h)
+        assert abs(lin - fd) < 1e-6 * max(1.0, abs(fd)), (fn.__name__, lin, fd)
