@@ -2305,8 +2305,10 @@ __global__ __launch_bounds__(64) void inv_rel_kernel(const double* __restrict__ 
     if (i < rows) inv[i] = (v > rel * m && v > 0.0) ? 1.0 / v : 0.0;
 }
 
-// symmetric positive semi-definite 64 x 64 G: out[0] = |G|_F (>= lambda_max), out[1] = |G x| after `iters` power steps on a unit
-// vector (<= lambda_max).  One wave, thread i keeps row i in registers.
+// symmetric positive semi-definite 64 x 64 G: out[0] = |G|_F (a rigorous upper bound of lambda_max); out[1] = rho + |G x - rho x| for
+// the unit vector x after `iters` power steps, rho = x^T G x -- G has an eigenvalue in [rho - r, rho + r], the largest one once the
+// iteration has turned x towards the leading eigenspace (a cluster or an exact tie at the top only makes r smaller).
+// One wave, thread i keeps row i in registers.
 __global__ __launch_bounds__(64) void sym64_lmax_kernel(const double* __restrict__ G, int iters, double* __restrict__ out) {
     __shared__ double x[64];
     const int i = threadIdx.x;
@@ -2316,21 +2318,29 @@ __global__ __launch_bounds__(64) void sym64_lmax_kernel(const double* __restrict
     for (int j = 0; j < 64; ++j) { row[j] = G[i * 64 + j]; f += row[j] * row[j]; }
     for (int off = 32; off > 0; off >>= 1) f += __shfl_xor(f, off, 64);
     double xi = 1.0 + 0.37 * (double)((i * 29) % 64) / 64.0;       // generic positive start
-    double nrm = 0.0;
+    double est = 0.0;
     for (int it = 0; it <= iters; ++it) {
         double q = xi * xi;
         for (int off = 32; off > 0; off >>= 1) q += __shfl_xor(q, off, 64);
-        nrm = sqrt(q);
-        if (it == iters || !(nrm > 0.0)) break;
-        x[i] = xi / nrm;
+        const double nrm = sqrt(q);
+        if (!(nrm > 0.0)) break;
+        const double xn = xi / nrm;
+        x[i] = xn;
         __syncthreads();
         double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
 #pragma unroll
         for (int j = 0; j < 64; j += 4) { a0 += row[j] * x[j]; a1 += row[j + 1] * x[j + 1]; a2 += row[j + 2] * x[j + 2]; a3 += row[j + 3] * x[j + 3]; }
-        xi = (a0 + a1) + (a2 + a3);
+        xi = (a0 + a1) + (a2 + a3);                             // (G x)_i
         __syncthreads();
+        if (it == iters) {
+            double rho = xn * xi;
+            for (int off = 32; off > 0; off >>= 1) rho += __shfl_xor(rho, off, 64);
+            double r2 = (xi - rho * xn) * (xi - rho * xn);
+            for (int off = 32; off > 0; off >>= 1) r2 += __shfl_xor(r2, off, 64);
+            est = rho + sqrt(r2);
+        }
     }
-    if (i == 0) { out[0] = sqrt(f); out[1] = (iters > 0) ? nrm : 0.0; }
+    if (i == 0) { out[0] = sqrt(f); out[1] = est; }
 }
 
 // out[i,:] = sign(d[i]) * q[i,:]  (sign(0) = +1)
@@ -2419,16 +2429,16 @@ static int eigh_warm_verify(ctm_ctx* ctx, const double* As, int n, int kk, int k
         CTM_TRY(gemm_f64(ctx, ga));
         std::swap(Z, Zn);
     }
-    // bounds on the largest singular value mu of the last product from its 64 x 64 Gram matrix: (power iteration) <= mu^2 <= |G|_F
+    // the largest singular value mu of the last product from its 64 x 64 Gram matrix: mu^2 <= |G|_F, mu^2 ~ rho + r of a power iterate
     GemmDesc gg; gg.M = pb; gg.N = pb; gg.K = n; gg.A = Z; gg.sam = n; gg.sak = 1; gg.B = Z; gg.sbk = 1; gg.sbn = n; gg.C = G64; gg.ldc = pb;
     CTM_TRY(gemm_f64(ctx, gg));
-    CTM_LAUNCH(ctx, sym64_lmax_kernel, dim3(1), dim3(64), 0, (const double*)G64, 64, bnd);
+    CTM_LAUNCH(ctx, sym64_lmax_kernel, dim3(1), dim3(64), 0, (const double*)G64, 96, bnd);
     CTM_HIP_CHECK(ctx, hipMemcpyAsync(h.data(), bnd, sizeof(double) * 2, hipMemcpyDeviceToHost, ctx->stream));
     CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     const double mu_hi = std::sqrt(std::max(h[0], 0.0)), mu_lo = std::sqrt(std::max(h[1], 0.0));
     // the block is orthonormal to ~1e-6 only: same slack in the threshold (8 accepted pairs lie beyond the ones the caller uses)
     const double thr = lamk * (1.0 + 1e-6) + resid_tol(ctx, n) * lam0;
-    const double mu = (mu_hi <= thr) ? mu_hi : mu_lo * 1.002;        // undecided by the upper bound: the (converged) power estimate
+    const double mu = (mu_hi <= thr) ? mu_hi : mu_lo;                // undecided by the Frobenius bound: Rayleigh quotient + residual of the power iterate
     if (ctx->jacobi_verbose) fprintf(stderr, "[eigh-warm] probe: largest Ritz value outside / |l_kk| in [%.6f, %.6f]\n", mu_lo / lamk, mu_hi / lamk);
     if (!(mu <= thr)) { ctx->eigh_warm_rejects += 1; return CTM_OK; }
     CTM_HIP_CHECK(ctx, hipMemcpyAsync(warm, Q2, sizeof(double) * (size_t)kk * n, hipMemcpyDeviceToDevice, ctx->stream));

@@ -211,3 +211,20 @@ def test_iterative_solver_converges_on_a_flat_leading_spectrum(eng, signs):
     assert eng.stat("si_hits") == 1 and eng.stat("si_fallbacks") == 0
     assert float((D.cpu() - lam[:chi]).abs().max()) < 1e-12
     assert float(((A @ U) - U * D).abs().max()) < 1e-12
+
+
+def test_warm_restart_is_accepted_when_the_kept_subspace_cuts_a_degenerate_pair(eng):
+    """The chi + 1 + 8 kept pairs end inside an exactly degenerate pair of eigenvalues (position kk and kk + 1): the probe finds a
+    Ritz value EQUAL to the smallest accepted |lambda| -- a tie, not a missed direction; the restart must still be accepted."""
+    n, chi = 768, 48
+    kk = chi + 1 + 8
+    lam = (0.8 ** torch.arange(n, dtype=torch.float64))
+    lam[kk] = lam[kk - 1]
+    A, _ = _sym_with_spectrum(n, lam, 9)
+    A = A.cuda()
+    basis = eng.warm_basis_c4v(chi, n)
+    eng.timers(reset=True)
+    outs = [eng.truncated_eigh(A, chi, basis=basis) for _ in range(3)]
+    assert eng.stat("eigh_warm_hits") >= 1 and eng.stat("eigh_warm_rejects") == 0
+    for D, U in outs:
+        assert float((D.cpu() - lam[:chi]).abs().max()) < 1e-13
