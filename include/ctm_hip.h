@@ -171,7 +171,9 @@ int ctm_c2x2_c4v(ctm_ctx* ctx, int open, const double* a, const double* C, const
 int ctm_move_c4v(ctm_ctx* ctx, const double* a, const double* C, const double* T, int chi, int p, int D,
                  const ctm_trunc_cfg* cfg, double* C_out, double* T_out, double* D_out /* chi eigenvalues or NULL */);
 /* Same, warm started: `basis` is an opaque caller-owned device workspace of (min(chi+1,n)+8) * n doubles, zero-filled before the
- * first sweep and passed again on every later one (invariant subspace of the previous enlarged corner; see ctm_projectors_4x4_ws). */
+ * first sweep and passed again on every later one (invariant subspace of the previous enlarged corner; see ctm_projectors_4x4_ws).
+ * Once the enlarged corner is stationary a sweep restarts from that subspace (residual test on every kept pair + a deflated probe for
+ * missed directions, see ctm_truncated_eigh_ws) instead of iterating; the returned tensors do not depend on the workspace. */
 int ctm_move_c4v_ws(ctm_ctx* ctx, const double* a, const double* C, const double* T, int chi, int p, int D,
                     const ctm_trunc_cfg* cfg, double* C_out, double* T_out, double* D_out, double* basis);
 
