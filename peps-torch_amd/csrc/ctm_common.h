@@ -61,6 +61,7 @@ struct ctm_ctx {
     int jacobi_max_sweeps = 30;
     double jacobi_tol = 1e-14;
     int si_tau_both = 1;               // Rayleigh-Ritz of the subspace iteration: guard-guard pairs only are measured against the k-th row norm
+    int jacobi_gram_kmin = 256, jacobi_gram_kmin_short = 64;   // pair Gram GEMMs: K is split over workgroups down to this many columns each (rows longer / not longer than 2048)
     int jacobi_tau_relax = 1;          // rows below the k-th largest norm are measured against it (development switch)
     double svd_null_tol = 1e-11;       // full decomposition: right vectors of s_i <= svd_null_tol s_0 are completed orthonormally (svd_full)
     int jacobi_inner_sweeps = 2;        // inner sweeps of the LDS eigensolver per visit of a pair (2 or 3 pairs per round)

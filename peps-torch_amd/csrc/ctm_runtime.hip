@@ -99,6 +99,8 @@ int ctm_set_option(ctm_ctx* ctx, const char* key, double value) {
     else if (k == "svd_null_tol") ctx->svd_null_tol = value;
     else if (k == "jacobi_tau_relax") ctx->jacobi_tau_relax = (int)value;
     else if (k == "si_tau_both") ctx->si_tau_both = (int)value;
+    else if (k == "jacobi_gram_kmin") ctx->jacobi_gram_kmin = (int)value;
+    else if (k == "jacobi_gram_kmin_short") ctx->jacobi_gram_kmin_short = (int)value;
     else if (k == "jacobi_max_sweeps") ctx->jacobi_max_sweeps = (int)value;
     else if (k == "jacobi_block") ctx->jacobi_block = (int)value;
     else if (k == "jacobi_inner_sweeps") ctx->jacobi_inner_sweeps = (int)value;

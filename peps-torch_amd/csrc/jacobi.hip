@@ -577,14 +577,17 @@ std::map<std::string, RRTables>& tables() { static std::map<std::string, RRTable
 std::mutex& tables_mutex() { static std::mutex m; return m; }   // contexts of several host threads share the tables
 
 int get_tables(ctm_ctx* ctx, int nbk, long long ld, int b, int Cg, RRTables** out) {
-    const std::string key = std::to_string(ctx->device) + ":" + std::to_string(nbk) + ":" + std::to_string(ld) + ":" + std::to_string(b) + ":" + std::to_string(Cg);
+    const std::string key = std::to_string(ctx->device) + ":" + std::to_string(nbk) + ":" + std::to_string(ld) + ":" + std::to_string(b) + ":" + std::to_string(Cg) + ":" + std::to_string(ctx->jacobi_gram_kmin) + ":" + std::to_string(ctx->jacobi_gram_kmin_short);
     std::lock_guard<std::mutex> lock(tables_mutex());
     auto& T = tables();
     auto it = T.find(key);
     if (it != T.end()) { *out = &it->second; return CTM_OK; }
     const int rounds = nbk - 1, pairs = nbk / 2, m = 2 * b;
     // split the long K (= Cg) of the pair Grams over enough workgroups to fill the chip (>= ~512 WGs per launch)
-    int nsplit = std::max(1, std::min(512 / std::max(pairs, 1), Cg / 256));
+    // (short rows -- the dense SVD of a Ritz matrix -- are split down to jacobi_gram_kmin_short columns per workgroup: the round is
+    // latency bound and the eigensolver's prologue adds the partial Grams; long rows keep >= 256 columns, their partials are 32 KB each)
+    const int kmin = (Cg <= 2048) ? ctx->jacobi_gram_kmin_short : ctx->jacobi_gram_kmin;
+    int nsplit = std::max(1, std::min(512 / std::max(pairs, 1), Cg / std::max(16, kmin)));
     int klen = (((Cg + nsplit - 1) / nsplit) + 15) / 16 * 16;
     nsplit = (Cg + klen - 1) / klen;
     std::vector<GemmOff> gram((size_t)rounds * pairs * nsplit), app((size_t)rounds * pairs);
