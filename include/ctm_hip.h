@@ -108,7 +108,8 @@ int ctm_svd_symeig(ctm_ctx* ctx, const double* A, int n, int chi, const ctm_trun
 /* singular values of an n x n matrix, descending (ENV.get_spectra, env.py:204-209) */
 int ctm_svdvals(ctm_ctx* ctx, const double* M, int n, double* S);
 
-/* ---- adjoints of the two decompositions (first part of the backward pass; the adjoint of a whole move is not built) ------ */
+/* ---- adjoints of the two decompositions (the adjoint of a whole move is assembled by the host layer from these and from ctm_einsum
+ * nodes: peps-torch_amd/linalg/native_einsum.py, ctm/generic/ctm_ad.py) ------ */
 /* SVDGESDD.backward (linalg/svd_gesdd.py:209-328): A = U diag(S) V^H with U m x k, V n x k (k <= min(m,n); thin factors get the
  * (1 - U U^H), (1 - V V^H) terms exactly as the reference), gradients gU, gS, gV (any may be NULL), regularisation eps (the
  * reference's ad_decomp_reg, relative to S[0]); dA is m x n.  CTM_C128: complex factors / gradients, S and gS real. */

@@ -1,7 +1,8 @@
 // Adjoints of the two decompositions of the chi-truncation (first part): the regularised SVD backward of
 // linalg/svd_gesdd.py:209-328 (SVDGESDD.backward) and the symmetric / Hermitian eigendecomposition backward of
 // linalg/eig_sym.py:57-75 (SYMEIG.backward), restated on the device: every O(n^2 k) term is an FP64-MFMA GEMM, the k x k
-// "F, G" weightings are one small elementwise kernel.  The adjoint of the contractions of a whole move is not built.
+// "F, G" weightings are one small elementwise kernel.  The adjoints of the contractions of a move are ctm_einsum calls issued by
+// the host layer (peps-torch_amd/linalg/native_einsum.py).
 //
 //   dA = U K V^H + (1 - U U^H) gU S^-1 V^H + U S^-1 gV^H (1 - V V^H)
 //   K  = 1/2 (F + G) o (U^H gU - gU^H U) + 1/2 (F - G) o (V^H gV - gV^H V) + diag(gS) + i diag(Im(U^H gU)_ii / s_i)

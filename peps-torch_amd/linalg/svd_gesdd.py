@@ -1,7 +1,7 @@
 """SVD with the reference's regularised backward (linalg/svd_gesdd.py:77-96 forward, :209-328 backward) as a torch.autograd.Function
 whose forward AND backward run on the native engine: forward = full decomposition by the native Jacobi SVD + fix_svd_signs,
 backward = ctm_svd_backward (GEMMs + one elementwise kernel).  This is the decomposition-level part of the backward pass
-(SURVEY 8 f4); the contractions of a CTM move are not differentiable through the engine."""
+(SURVEY 8 f4); the contractions of a move are differentiable nodes of their own (linalg/native_einsum.py, ctm/generic/ctm_ad.py)."""
 import torch
 from backend import get_engine
 
