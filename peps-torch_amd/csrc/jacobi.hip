@@ -2435,7 +2435,7 @@ static int eigh_warm_verify(ctm_ctx* ctx, const double* As, int n, int kk, int k
     // the largest singular value mu of the last product from its 64 x 64 Gram matrix: mu^2 <= |G|_F, mu^2 ~ rho + r of a power iterate
     GemmDesc gg; gg.M = pb; gg.N = pb; gg.K = n; gg.A = Z; gg.sam = n; gg.sak = 1; gg.B = Z; gg.sbk = 1; gg.sbn = n; gg.C = G64; gg.ldc = pb;
     CTM_TRY(gemm_f64(ctx, gg));
-    CTM_LAUNCH(ctx, sym64_lmax_kernel, dim3(1), dim3(64), 0, (const double*)G64, 96, bnd);
+    CTM_LAUNCH(ctx, sym64_lmax_kernel, dim3(1), dim3(64), 0, (const double*)G64, 64, bnd);
     CTM_HIP_CHECK(ctx, hipMemcpyAsync(h.data(), bnd, sizeof(double) * 2, hipMemcpyDeviceToHost, ctx->stream));
     CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     const double mu_hi = std::sqrt(std::max(h[0], 0.0)), mu_lo = std::sqrt(std::max(h[1], 0.0));
