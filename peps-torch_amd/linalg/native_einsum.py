@@ -35,6 +35,9 @@ def _order(target, first, others, ext):
             key = (0 if shares else 1, size)
             if best is None or key < best_size:
                 best, best_size = cand, key
+        if best_size[0] == 1:
+            # nothing left shares an index with the running intermediate: the engine contracts pairwise without outer products
+            raise NotImplementedError("einsum backward: the adjoint network is disconnected (needs an outer product)")
         later = set(target)
         for o in rest:
             if o is not best:
