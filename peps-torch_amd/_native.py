@@ -344,8 +344,9 @@ class Engine:
         cfg = cfg or self.cfg(eps_multiplet=1e-12)
         if basis is not None:
             k = chi + 1 if chi < n else n
-            if not (basis.is_cuda and basis.dtype == torch.float64 and basis.is_contiguous() and tuple(basis.shape) == (min(n, k + 8), n)):
-                raise NativeError("truncated_eigh: basis must come from warm_basis_c4v(chi, n)")
+            if not (basis.is_cuda and basis.dtype == torch.float64 and basis.is_contiguous()
+                    and tuple(basis.shape) == ((2 if A.dtype.is_complex else 1) * min(n, k + 8), n)):
+                raise NativeError("truncated_eigh: basis must come from warm_basis_c4v(chi, n, dtype)")
             self._ck(self.lib.ctm_truncated_eigh_ws(self.h, _ptr(A), n, chi, C.byref(cfg), _ptr(D), _ptr(U), _ptr(basis)), "truncated_eigh")
         else:
             self._ck(self.lib.ctm_truncated_eigh(self.h, _ptr(A), n, chi, C.byref(cfg), _ptr(D), _ptr(U)), "truncated_eigh")
@@ -509,10 +510,11 @@ class Engine:
         self._ck(self.lib.ctm_c2x2_c4v(self.h, int(open_), _ptr(a), _ptr(C_), _ptr(T), chi, p, D, _ptr(out)), "c2x2_c4v")
         return out
 
-    def warm_basis_c4v(self, chi, n):
-        """Zero-filled warm-start workspace for move_c4v(..., basis=)."""
+    def warm_basis_c4v(self, chi, n, dtype=torch.float64):
+        """Zero-filled warm-start workspace for move_c4v / truncated_eigh(..., basis=): (chi + 1 + 8) rows of length n, for complex128
+        matrices the real plane followed by the imaginary plane."""
         k = chi + 1 if chi < n else n
-        return torch.zeros(min(n, k + 8), n, dtype=torch.float64, device=self.device)
+        return torch.zeros((2 if dtype.is_complex else 1) * min(n, k + 8), n, dtype=torch.float64, device=self.device)
 
     def move_c4v(self, a, C_, T, cfg=None, basis=None, normalize=1):
         a, C_, T = self._bind(a, C_, T)
@@ -522,8 +524,9 @@ class Engine:
         if basis is not None:
             n = chi * D * D
             k = chi + 1 if chi < n else n
-            if not (basis.is_cuda and basis.dtype == torch.float64 and basis.is_contiguous() and tuple(basis.shape) == (min(n, k + 8), n)):
-                raise NativeError("move_c4v: basis must come from warm_basis_c4v(chi, n)")
+            if not (basis.is_cuda and basis.dtype == torch.float64 and basis.is_contiguous()
+                    and tuple(basis.shape) == ((2 if a.dtype.is_complex else 1) * min(n, k + 8), n)):
+                raise NativeError("move_c4v: basis must come from warm_basis_c4v(chi, n, dtype)")
         self._ck(self.lib.ctm_move_c4v_x(self.h, _ptr(a), _ptr(C_), _ptr(T), chi, p, D, C.byref(cfg), int(normalize), _ptr(nC), _ptr(nT), _ptr(Dv),
                                          _ptr(basis) if basis is not None else None), "move_c4v")
         return nC, nT, Dv

@@ -259,6 +259,6 @@ int jacobi_svd_top(ctm_ctx* ctx, const double* M, int n, int k, double* S, doubl
 int jacobi_eigh_top(ctm_ctx* ctx, const double* A, int n, int k, double* D, double* Ut, double* warm = nullptr);
 // Hermitian eigendecomposition of a planar complex matrix (lower triangle referenced): D[k] real (signed, by |lambda| descending),
 // Ut planar k x n (re plane, then im plane), rows = u_i^H
-int jacobi_eigh_top_c(ctm_ctx* ctx, const double* Ar, const double* Ai, int n, int k, double* D, double* Ut);
+int jacobi_eigh_top_c(ctm_ctx* ctx, const double* Ar, const double* Ai, int n, int k, double* D, double* Ut, double* warm = nullptr);
 // singular values only, small matrices (corner spectra)
 int jacobi_svdvals(ctm_ctx* ctx, const double* M, const double* Mi /* nullptr: real */, int n, double* S);

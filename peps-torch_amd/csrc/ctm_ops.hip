@@ -493,7 +493,7 @@ int eigh_trunc_planar(ctm_ctx* ctx, const DT& A, int n, int chi, const ctm_trunc
     double *Ut, *dk;
     CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)k * n * cz, (void**)&Ut));
     CTM_TRY(arena_alloc(ctx, sizeof(double) * k, (void**)&dk));
-    if (A.q) CTM_TRY(jacobi_eigh_top_c(ctx, A.p, A.q, n, k, dk, Ut));
+    if (A.q) CTM_TRY(jacobi_eigh_top_c(ctx, A.p, A.q, n, k, dk, Ut, warm));
     else CTM_TRY(jacobi_eigh_top(ctx, A.p, n, k, dk, Ut, warm));
     std::vector<double> Dh(k);
     CTM_HIP_CHECK(ctx, hipMemcpyAsync(Dh.data(), dk, sizeof(double) * k, hipMemcpyDeviceToHost, ctx->stream));
@@ -518,7 +518,7 @@ int truncated_eigh_impl(ctm_ctx* ctx, const double* A, int n, int chi, const ctm
     DT tA, tU;
     CTM_TRY(io.in(A, {n, n}, &tA));
     CTM_TRY(io.out(U, (size_t)n * kc, &tU));
-    CTM_TRY(eigh_trunc_planar(ctx, tA, n, chi, cfg, D, tU, ctx->cplx ? nullptr : warm));
+    CTM_TRY(eigh_trunc_planar(ctx, tA, n, chi, cfg, D, tU, warm));
     CTM_TRY(io.finish());
     CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     return CTM_OK;
@@ -825,7 +825,7 @@ int ctm_move_c4v_x(ctm_ctx* ctx, const double* a, const double* C, const double*
         CTM_TRY(dev_network(ctx, "xy,cyuU,xelL,suldr,sULDR->edDcrR", {tC, tT, tT, tA, tA.conj()}, &c2));
     }
     // 2) projector: truncated (Hermitian) eigendecomposition, D real with sign (ctmrg_c4v.py:49-52, 360-374)
-    CTM_TRY(eigh_trunc_planar(ctx, c2, n, chi, cfg, Dv, tP, ctx->cplx ? nullptr : basis));
+    CTM_TRY(eigh_trunc_planar(ctx, c2, n, chi, cfg, Dv, tP, basis));
     PhaseTimer pt(ctx, CTM_T_ABSORB);
     CTM_TRY(diag_to_matrix(ctx, Dv, rC.p, chi));                                       // C = diag(D) (:374), imaginary part zero
     if (rC.q) CTM_TRY(fill_f64(ctx, rC.q, (size_t)chi * chi, 0.0));

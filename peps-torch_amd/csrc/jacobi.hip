@@ -1263,7 +1263,7 @@ int svd_full_c(ctm_ctx* ctx, const double* Mr, const double* Mi, int n, int k, d
             XM ah{Vg, Vg + (size_t)kg * n, n, true, true}, a{Vg, Vg + (size_t)kg * n, n, false, false};
             CTM_TRY(xgemm(ctx, n, n, kg, ah, a, Pr, Pi, n));
             CTM_LAUNCH(ctx, eye_minus_kernel, dim3(1024), dim3(256), 0, Pr, Pi, n);
-            CTM_TRY(jacobi_eigh_top_c(ctx, Pr, Pi, n, kb, Dn, Wn));
+            CTM_TRY(jacobi_eigh_top_c(ctx, Pr, Pi, n, kb, Dn, Wn, nullptr));
             CTM_HIP_CHECK(ctx, hipMemcpyAsync(Vt, Vg, sizeof(double) * (size_t)kg * n, hipMemcpyDeviceToDevice, ctx->stream));
             CTM_HIP_CHECK(ctx, hipMemcpyAsync(Vt + kn, Vg + (size_t)kg * n, sizeof(double) * (size_t)kg * n, hipMemcpyDeviceToDevice, ctx->stream));
             CTM_HIP_CHECK(ctx, hipMemcpyAsync(Vt + (size_t)kg * n, Wn, sizeof(double) * (size_t)kb * n, hipMemcpyDeviceToDevice, ctx->stream));
@@ -2548,7 +2548,7 @@ int jacobi_eigh_top(ctm_ctx* ctx, const double* A, int n, int k, double* D, doub
 // by |lambda| descending).  (1) large n, k << n: leading-|lambda| invariant subspace by the complex block iteration on the
 // Hermitian matrix, then a small Hermitian Rayleigh-Ritz; (2) full path: one-sided complex Jacobi on A + shift I (positive
 // definite, so the accumulated unitary holds the eigenvectors and lambda = sigma - shift).
-int jacobi_eigh_top_c(ctm_ctx* ctx, const double* Ar, const double* Ai, int n, int k, double* D, double* Ut) {
+int jacobi_eigh_top_c(ctm_ctx* ctx, const double* Ar, const double* Ai, int n, int k, double* D, double* Ut, double* warm) {
     if (n <= 0 || k <= 0 || k > n) { ctx->set_error("jacobi_eigh_top_c: bad n/k"); return CTM_ERR_BADARG; }
     ArenaScope scope(ctx);
     const size_t nn = (size_t)n * n;
@@ -2563,9 +2563,10 @@ int jacobi_eigh_top_c(ctm_ctx* ctx, const double* Ar, const double* Ai, int n, i
         CTM_TRY(arena_alloc(ctx, sizeof(double) * 2 * kn, (void**)&Uk));
         CTM_TRY(arena_alloc(ctx, sizeof(double) * 2 * kn, (void**)&Vk));
         bool ok = false;
-        MatOp aop; aop.n = n; aop.M = As; aop.Mi = As + nn;
+        MatOp aop; aop.n = n; aop.M = As; aop.Mi = As + nn; aop.warm = warm;      // warm: planar (k + 8) x n rows (re plane, im plane) of the previous subspace
         CTM_TRY(svd_iter_c(ctx, aop, kk, S, Uk, Vk, &ok));
         if (ok) {
+            if (warm) CTM_HIP_CHECK(ctx, hipMemcpyAsync(warm, Vk, sizeof(double) * 2 * kn, hipMemcpyDeviceToDevice, ctx->stream));
             ctx->si_hits += 1;
             // T = U A U^H (kk x kk Hermitian; U rows are q_j^H), T w = mu w, eigenvector rows x^H = w^H U
             double *Y, *T, *Dk, *Th;
@@ -2578,7 +2579,7 @@ int jacobi_eigh_top_c(ctm_ctx* ctx, const double* Ar, const double* Ai, int n, i
             XM y{Y, Y + kn, n, false, false};
             CTM_TRY(xgemm(ctx, kk, kk, n, y, uh, T, T + (size_t)kk * kk, kk));
             const bool save = ctx->si_enable; ctx->si_enable = false;
-            const int st = jacobi_eigh_top_c(ctx, T, T + (size_t)kk * kk, kk, kk, Dk, Th);
+            const int st = jacobi_eigh_top_c(ctx, T, T + (size_t)kk * kk, kk, kk, Dk, Th, nullptr);
             ctx->si_enable = save;
             CTM_TRY(st);
             XM th{Th, Th + (size_t)kk * kk, kk, false, false};

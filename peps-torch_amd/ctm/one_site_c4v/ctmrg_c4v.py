@@ -49,8 +49,8 @@ def ctm_MOVE_sl(a, env, f_c2x2_decomp=None, ctm_args=cfg.ctm_args, global_args=c
         n = env.chi * a.shape[1] ** 2
         basis = env.__dict__.get("_warm")
         k = env.chi + 1 if env.chi < n else n
-        if basis is None or tuple(basis.shape) != (min(n, k + 8), n) or basis.device != a.device:
-            basis = env.__dict__["_warm"] = eng.warm_basis_c4v(env.chi, n)
+        if basis is None or tuple(basis.shape) != ((2 if a.is_complex() else 1) * min(n, k + 8), n) or basis.device != a.device:
+            basis = env.__dict__["_warm"] = eng.warm_basis_c4v(env.chi, n, a.dtype)
     nC, nT, _D = eng.move_c4v(a, env.C[env.keyC], env.T[env.keyT], cfgT, normalize=norm_kind, **({"basis": basis} if basis is not None else {}))
     env.C[env.keyC] = nC
     env.T[env.keyT] = nT

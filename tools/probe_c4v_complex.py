@@ -1,0 +1,25 @@
+"""Development probe: ms per C4v move of a complex128 state (A1 + i A2 ansatz), D and chi from argv."""
+import sys, os, time, numpy as np, torch
+R = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, os.path.join(R, "peps-torch_amd"))
+import _native
+from ipeps.ipeps_c4v import IPEPS_C4V
+from ctm.one_site_c4v.env_c4v import ENV_C4V, init_env
+from ctm.one_site_c4v import ctmrg_c4v
+from groups.pg import make_c4v_symm
+eng = _native.engine()
+D, chi, nm = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+for kv in sys.argv[4:]:
+    k_, v_ = kv.split("="); eng.set_option(k_, float(v_))
+rng = np.random.default_rng(2)
+A = make_c4v_symm(torch.from_numpy(rng.random((2, D, D, D, D)))) + 1j * make_c4v_symm(torch.from_numpy(rng.random((2, D, D, D, D)) - 0.5), irreps=["A2"])
+A = (A / A.abs().max()).cuda()
+st = IPEPS_C4V(A); env = ENV_C4V(chi, st); init_env(st, env)
+ts = []
+for i in range(nm):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    ctmrg_c4v.ctm_MOVE_sl(st.site(), env)
+    torch.cuda.synchronize(); ts.append(1e3 * (time.perf_counter() - t0))
+print("ms per move:", " ".join(f"{t:.1f}" for t in ts[:12]), "... median of the last half", f"{sorted(ts[nm//2:])[len(ts[nm//2:])//2]:.2f}", "si_iters", eng.stat("si_total_iters"), "fallbacks", eng.stat("si_fallbacks"))
+d = torch.diagonal(env.get_C()).abs()
+print("C spectrum head/tail", float(d[1]/d[0]), float(d[-1]/d[0]))
