@@ -95,7 +95,8 @@ int ctm_truncated_svd_ws(ctm_ctx* ctx, const double* M, int n, int chi, const ct
 /* A symmetric (lower triangle referenced); D (chi, signed, ordered by |D| descending), U n x chi */
 int ctm_truncated_eigh(ctm_ctx* ctx, const double* A, int n, int chi, const ctm_trunc_cfg* cfg, double* D, double* U);
 /* Same for a sequence of nearby matrices (the enlarged corner of consecutive C4v moves): `basis` is an opaque caller-owned device
- * workspace of min(n, min(chi+1,n) + 8) * n doubles, zero-filled before the first call (CTM_F64; ignored in CTM_C128 contexts).
+ * workspace of min(n, min(chi+1,n) + 8) * n doubles (CTM_C128: twice that, real plane then imaginary plane), zero-filled before the
+ * first call.
  * A restart from the previous invariant subspace is accepted only if (a) every pair of a Rayleigh-Ritz inside it passes the
  * residual threshold of the cold solver and (b) a block of fresh pseudo-random rows iterated three times on the deflated matrix finds
  * nothing above the smallest accepted |lambda|; otherwise the regular iteration runs.  The result does not depend on the basis. */
@@ -171,7 +172,7 @@ int ctm_c2x2_c4v(ctm_ctx* ctx, int open, const double* a, const double* C, const
                  double* out);
 int ctm_move_c4v(ctm_ctx* ctx, const double* a, const double* C, const double* T, int chi, int p, int D,
                  const ctm_trunc_cfg* cfg, double* C_out, double* T_out, double* D_out /* chi eigenvalues or NULL */);
-/* Same, warm started: `basis` is an opaque caller-owned device workspace of (min(chi+1,n)+8) * n doubles, zero-filled before the
+/* Same, warm started: `basis` is an opaque caller-owned device workspace of (min(chi+1,n)+8) * n doubles (CTM_C128: twice that), zero-filled before the
  * first sweep and passed again on every later one (invariant subspace of the previous enlarged corner; see ctm_projectors_4x4_ws).
  * Once the enlarged corner is stationary a sweep restarts from that subspace (residual test on every kept pair + a deflated probe for
  * missed directions, see ctm_truncated_eigh_ws) instead of iterating; the returned tensors do not depend on the workspace. */

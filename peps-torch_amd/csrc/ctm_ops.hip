@@ -484,6 +484,39 @@ int ctm_truncated_eigh_ws(ctm_ctx* ctx, const double* A, int n, int chi, const c
 }
 
 namespace {
+// Complex eigenvectors are defined up to a phase; the solver's phases drift with rounding, and a C4v run whose projector phases
+// drift never sees the same enlarged corner twice (its environment legs are re-gauged every sweep).  Canonical choice per row
+// u^H (planar k x n): the component of largest modulus (first one on ties at the 2^-40 level, like fix_svd_signs) real and positive.
+__global__ __launch_bounds__(256) void canon_phase_rows_kernel(double* __restrict__ re, double* __restrict__ im, int n) {
+    __shared__ double best[256];
+    __shared__ int where[256];
+    double* xr = re + (size_t)blockIdx.x * n;
+    double* xi = im + (size_t)blockIdx.x * n;
+    double b = -1.0; int w = 0;
+    for (int c = threadIdx.x; c < n; c += blockDim.x) {
+        const double m = floor((xr[c] * xr[c] + xi[c] * xi[c]) * 1099511627776.0);
+        if (m > b) { b = m; w = c; }
+    }
+    best[threadIdx.x] = b; where[threadIdx.x] = w;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (threadIdx.x < off) {
+            const double ob = best[threadIdx.x + off]; const int ow = where[threadIdx.x + off];
+            if (ob > best[threadIdx.x] || (ob == best[threadIdx.x] && ow < where[threadIdx.x])) { best[threadIdx.x] = ob; where[threadIdx.x] = ow; }
+        }
+        __syncthreads();
+    }
+    const int c0 = where[0];
+    const double pr = xr[c0], pi = xi[c0], m = sqrt(pr * pr + pi * pi);
+    if (!(m > 0.0)) return;
+    const double cr = pr / m, ci = -pi / m;        // multiply the row by conj(phase)
+    __syncthreads();
+    for (int c = threadIdx.x; c < n; c += blockDim.x) {
+        const double a = xr[c], d = xi[c];
+        xr[c] = a * cr - d * ci; xi[c] = a * ci + d * cr;
+    }
+}
+
 // truncated_eig_sym (custom_eig.py:7-65) on a planar (real or complex Hermitian) matrix: dD (device, min(chi,n), signed, zeros beyond
 // the last complete multiplet), U (n x min(chi,n), planar in complex contexts, columns beyond the kept multiplets zeroed)
 int eigh_trunc_planar(ctm_ctx* ctx, const DT& A, int n, int chi, const ctm_trunc_cfg& cfg, double* dD, const DT& U, double* warm) {
@@ -493,8 +526,10 @@ int eigh_trunc_planar(ctm_ctx* ctx, const DT& A, int n, int chi, const ctm_trunc
     double *Ut, *dk;
     CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)k * n * cz, (void**)&Ut));
     CTM_TRY(arena_alloc(ctx, sizeof(double) * k, (void**)&dk));
-    if (A.q) CTM_TRY(jacobi_eigh_top_c(ctx, A.p, A.q, n, k, dk, Ut, warm));
-    else CTM_TRY(jacobi_eigh_top(ctx, A.p, n, k, dk, Ut, warm));
+    if (A.q) {
+        CTM_TRY(jacobi_eigh_top_c(ctx, A.p, A.q, n, k, dk, Ut, warm));
+        CTM_LAUNCH(ctx, canon_phase_rows_kernel, dim3(k), dim3(256), 0, Ut, Ut + (size_t)k * n, n);
+    } else CTM_TRY(jacobi_eigh_top(ctx, A.p, n, k, dk, Ut, warm));
     std::vector<double> Dh(k);
     CTM_HIP_CHECK(ctx, hipMemcpyAsync(Dh.data(), dk, sizeof(double) * k, hipMemcpyDeviceToHost, ctx->stream));
     CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));

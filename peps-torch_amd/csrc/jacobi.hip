@@ -2347,13 +2347,40 @@ __global__ __launch_bounds__(64) void sym64_lmax_kernel(const double* __restrict
 }
 
 // out[i,:] = sign(d[i]) * q[i,:]  (sign(0) = +1)
-__global__ void signed_rows_kernel(const double* __restrict__ q, const double* __restrict__ d, int rows, int n, double* __restrict__ out) {
+__global__ void signed_rows_kernel(const double* __restrict__ q, const double* __restrict__ d, int dstride, int rows, int n, double* __restrict__ out) {
     const size_t tot = (size_t)rows * n;
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += (size_t)gridDim.x * blockDim.x)
-        out[e] = (d[e / n] < 0.0) ? -q[e] : q[e];
+        out[e] = (d[(e / n) * dstride] < 0.0) ? -q[e] : q[e];
 }
 
-static int eigh_warm_verify(ctm_ctx* ctx, const double* As, int n, int kk, int k_out, double* warm, double* D, double* Ut, bool* accepted) {
+// real embedding of a Hermitian matrix for ROW vectors [x y] <-> x + iy:  [x y] [[Ar, Ai], [-Ai, Ar]] = [Re, Im] of (x + iy)(Ar + i Ai)
+__global__ void embed_herm_kernel(const double* __restrict__ Ar, const double* __restrict__ Ai, int n, double* __restrict__ Ae) {
+    const size_t n2 = 2 * (size_t)n, tot = n2 * n2;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = e / n2, c = e - r * n2;
+        const size_t rr = r % n, cc = c % n;
+        const bool lo = r >= (size_t)n, ri = c >= (size_t)n;
+        Ae[e] = (lo == ri) ? Ar[rr * n + cc] : (lo ? -Ai[rr * n + cc] : Ai[rr * n + cc]);
+    }
+}
+
+// complex rows x + iy (planar: re plane, im plane, k x n each) -> 2k real rows of length 2n: [x y] and [-y x] (the row times i)
+__global__ void embed_rows_kernel(const double* __restrict__ re, const double* __restrict__ im, int k, int n, double* __restrict__ out) {
+    const size_t n2 = 2 * (size_t)n, tot = 2 * (size_t)k * n2;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = e / n2, c = e - r * n2;
+        const size_t i = r >> 1, cc = c % n;
+        const bool second = r & 1, right = c >= (size_t)n;
+        const double x = re[i * n + cc], y = im[i * n + cc];
+        out[e] = second ? (right ? x : -y) : (right ? y : x);
+    }
+}
+
+// `embedded`: As is the real 2n x 2n embedding of a Hermitian matrix and `warm` the embedded rows ([x y] and [-y x] per complex row
+// x + iy) of eigh_warm_verify_c: only the keep-the-vectors route is taken (a rotation inside the doubly degenerate real spectrum
+// would not come back as complex vectors), the workspace is not written and D receives all kk Rayleigh quotients.
+static int eigh_warm_verify(ctm_ctx* ctx, const double* As, int n, int kk, int k_out, double* warm, double* D, double* Ut, bool* accepted,
+                            bool embedded = false) {
     *accepted = false;
     if (kk > n / 4 || kk < 2) return CTM_OK;
     ArenaScope scope(ctx);
@@ -2365,7 +2392,10 @@ static int eigh_warm_verify(ctm_ctx* ctx, const double* As, int n, int kk, int k
     CTM_TRY(row_norms(ctx, warm, kk, n, n, norms));
     CTM_HIP_CHECK(ctx, hipMemcpyAsync(h.data(), norms, sizeof(double) * kk, hipMemcpyDeviceToHost, ctx->stream));
     CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-    for (int i = 0; i < kk; ++i) if (!(std::fabs(h[i] - 1.0) < 1e-6)) return CTM_OK;
+    for (int i = 0; i < kk; ++i) if (!(std::fabs(h[i] - 1.0) < 1e-6)) {
+        if (ctx->jacobi_verbose) fprintf(stderr, "[eigh-warm] n=%d kk=%d: workspace row %d has norm %.3e (no complete previous subspace)\n", n, kk, i, h[i]);
+        return CTM_OK;
+    }
     CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)kk * n, (void**)&Q));
     CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)kk * n, (void**)&Y));
     CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)kk * kk, (void**)&H));
@@ -2385,10 +2415,18 @@ static int eigh_warm_verify(ctm_ctx* ctx, const double* As, int n, int kk, int k
     CTM_HIP_CHECK(ctx, hipMemcpyAsync(h.data(), res, sizeof(double) * kk, hipMemcpyDeviceToHost, ctx->stream));
     CTM_HIP_CHECK(ctx, hipMemcpyAsync(hd.data(), Dk, sizeof(double) * kk, hipMemcpyDeviceToHost, ctx->stream));
     CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-    bool as_is = *std::max_element(h.begin(), h.begin() + kk) <= resid_tol(ctx, n) * std::fabs(hd[0]);
-    for (int i = 1; i < kk && as_is; ++i) as_is = std::fabs(hd[i]) <= std::fabs(hd[i - 1]);
+    // The last kept rows may not be eigenvectors: when the kk-th |lambda| is shared by a pair of opposite sign (or a multiplet) that
+    // the workspace cuts, its last row is a mixture.  `ke` = the leading rows that are (at least the k_out the caller uses plus one);
+    // only those are deflated by the probe and compared with it.
+    int ke = 0;
+    while (ke < kk && h[ke] <= resid_tol(ctx, n) * std::fabs(hd[0])
+           && (ke == 0 || std::fabs(hd[ke]) <= std::fabs(hd[ke - 1]) + 1e-12 * std::fabs(hd[0]))) ++ke;      // ties may sit in either order
+    if (embedded) ke &= ~1;
+    bool as_is = ke >= std::min(kk, k_out + (embedded ? 2 : 1));
     if (as_is) Q2 = Q;
+    else if (embedded) return CTM_OK;
     else {
+        ke = kk;
         GemmDesc gh; gh.M = kk; gh.N = kk; gh.K = n; gh.A = Y; gh.sam = n; gh.sak = 1; gh.B = Q; gh.sbk = 1; gh.sbn = n; gh.C = H; gh.ldc = kk;
         CTM_TRY(gemm_f64(ctx, gh));                                      // H = Y Q^T
         const bool save = ctx->si_enable; ctx->si_enable = false;
@@ -2405,9 +2443,9 @@ static int eigh_warm_verify(ctm_ctx* ctx, const double* As, int n, int kk, int k
         CTM_HIP_CHECK(ctx, hipMemcpyAsync(hd.data(), Dk, sizeof(double) * kk, hipMemcpyDeviceToHost, ctx->stream));
         CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     }
-    const double lam0 = std::fabs(hd[0]), lamk = std::fabs(hd[kk - 1]);
-    const double worst = *std::max_element(h.begin(), h.begin() + kk);
-    if (ctx->jacobi_verbose) fprintf(stderr, "[eigh-warm] n=%d kk=%d%s  max resid/|l0| = %.3e  |l_kk|/|l0| = %.3e\n", n, kk, as_is ? " (vectors kept)" : "", worst / std::max(lam0, 1e-300), lamk / std::max(lam0, 1e-300));
+    const double lam0 = std::fabs(hd[0]), lamk = std::fabs(hd[ke - 1]);
+    const double worst = *std::max_element(h.begin(), h.begin() + ke);
+    if (ctx->jacobi_verbose) fprintf(stderr, "[eigh-warm] n=%d kk=%d%s (%d rows)  max resid/|l0| = %.3e  |l_ke|/|l0| = %.3e\n", n, kk, as_is ? " (vectors kept)" : "", ke, worst / std::max(lam0, 1e-300), lamk / std::max(lam0, 1e-300));
     if (!(lam0 > 0.0) || !(lamk > ctx->rank_tol * lam0) || !(worst <= resid_tol(ctx, n) * lam0)) return CTM_OK;
     // (b) probe of the deflated operator: Z <- orth(Z A_perp) twice, then the largest singular value of Z A_perp
     double *Z, *Zn, *G, *G64, *Mo, *bnd;
@@ -2421,7 +2459,7 @@ static int eigh_warm_verify(ctm_ctx* ctx, const double* As, int n, int kk, int k
     for (int q = 0; q < 3; ++q) {       // the accepted subspace is projected out after every application (its part of a row grows by |l_0 / l_kk| each time)
         CTM_TRY(rows_times(ctx, Z, n, pb, n, n, As, false, Zn, n));
         std::swap(Z, Zn);
-        CTM_TRY(project_out(ctx, Z, pb, n, Q2, kk, G, 1));
+        CTM_TRY(project_out(ctx, Z, pb, n, Q2, ke, G, 1));
         if (q == 2) break;
         // orthonormal basis of the significant part of the row space: Gram matrix, pivoted Cholesky stopped at 1e-10 of the largest
         // pivot (rank revealing: the rows of a probe of a fast decaying spectrum are numerically dependent), rows <- L_pp^-1 (pivot rows)
@@ -2444,13 +2482,44 @@ static int eigh_warm_verify(ctm_ctx* ctx, const double* As, int n, int kk, int k
     const double mu = (mu_hi <= thr) ? mu_hi : mu_lo;                // undecided by the Frobenius bound: Rayleigh quotient + residual of the power iterate
     if (ctx->jacobi_verbose) fprintf(stderr, "[eigh-warm] probe: largest Ritz value outside / |l_kk| in [%.6f, %.6f]\n", mu_lo / lamk, mu_hi / lamk);
     if (!(mu <= thr)) { ctx->eigh_warm_rejects += 1; return CTM_OK; }
-    CTM_HIP_CHECK(ctx, hipMemcpyAsync(warm, Q2, sizeof(double) * (size_t)kk * n, hipMemcpyDeviceToDevice, ctx->stream));
+    if (embedded) {
+        CTM_HIP_CHECK(ctx, hipMemcpyAsync(D, Dk, sizeof(double) * ke, hipMemcpyDeviceToDevice, ctx->stream));
+        ctx->eigh_warm_hits += 1;
+        *accepted = true;
+        return CTM_OK;
+    }
+    if (ke == kk) CTM_HIP_CHECK(ctx, hipMemcpyAsync(warm, Q2, sizeof(double) * (size_t)kk * n, hipMemcpyDeviceToDevice, ctx->stream));
     // the regular iteration keeps the right vectors v_i as the warm basis and returns the left ones, u_i = sign(lambda_i) v_i: same
     // convention here, so that a run does not change the gauge of its environment legs when it switches between the two paths
-    CTM_LAUNCH(ctx, signed_rows_kernel, dim3(256), dim3(256), 0, (const double*)Q2, (const double*)Dk, k_out, n, Ut);
+    CTM_LAUNCH(ctx, signed_rows_kernel, dim3(256), dim3(256), 0, (const double*)Q2, (const double*)Dk, 1, k_out, n, Ut);
     CTM_HIP_CHECK(ctx, hipMemcpyAsync(D, Dk, sizeof(double) * k_out, hipMemcpyDeviceToDevice, ctx->stream));
     ctx->eigh_warm_hits += 1;
     *accepted = true;
+    return CTM_OK;
+}
+
+// Complex Hermitian twin of the warm restart: everything is checked on the real embedding (2n x 2n symmetric, every eigenvalue twice),
+// where the real routine applies unchanged: Rayleigh quotients and residuals of the embedded previous vectors, and the deflated probe
+// (the largest singular value of the deflated operator is the same number in the embedding).  Only the stationary case -- the
+// previous vectors are the eigenvectors -- is taken; they are returned as they are (times sign(lambda), see above).
+static int eigh_warm_verify_c(ctm_ctx* ctx, const double* Asr, const double* Asi, int n, int kk, int k_out, double* warm, double* D, double* Ut,
+                              bool* accepted) {
+    *accepted = false;
+    if (2 * kk > (2 * n) / 4 || kk < 2) return CTM_OK;
+    ArenaScope scope(ctx);
+    const size_t kn = (size_t)kk * n;
+    double *Ae, *Qe, *De;
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * 4 * (size_t)n * n, (void**)&Ae));
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * 4 * kn, (void**)&Qe));
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * 2 * kk, (void**)&De));
+    CTM_LAUNCH(ctx, embed_herm_kernel, dim3(2048), dim3(256), 0, Asr, Asi, n, Ae);
+    CTM_LAUNCH(ctx, embed_rows_kernel, dim3(1024), dim3(256), 0, (const double*)warm, (const double*)(warm + kn), kk, n, Qe);
+    CTM_TRY(eigh_warm_verify(ctx, Ae, 2 * n, 2 * kk, 2 * k_out, Qe, De, nullptr, accepted, true));
+    if (!*accepted) return CTM_OK;
+    const size_t on = (size_t)k_out * n;
+    CTM_LAUNCH(ctx, signed_rows_kernel, dim3(256), dim3(256), 0, (const double*)warm, (const double*)De, 2, k_out, n, Ut);
+    CTM_LAUNCH(ctx, signed_rows_kernel, dim3(256), dim3(256), 0, (const double*)(warm + kn), (const double*)De, 2, k_out, n, Ut + on);
+    CTM_HIP_CHECK(ctx, hipMemcpy2DAsync(D, sizeof(double), De, 2 * sizeof(double), sizeof(double), k_out, hipMemcpyDeviceToDevice, ctx->stream));
     return CTM_OK;
 }
 
@@ -2478,7 +2547,6 @@ int jacobi_eigh_top(ctm_ctx* ctx, const double* A, int n, int k, double* D, doub
         MatOp aop; aop.n = n; aop.M = As; aop.warm = warm;     // warm: (k + 8) x n rows of the previous invariant subspace
         CTM_TRY(svd_iter(ctx, aop, kk, S, Uk, Vk, &ok));
         if (ok) {
-            if (warm) CTM_HIP_CHECK(ctx, hipMemcpyAsync(warm, Vk, sizeof(double) * (size_t)kk * n, hipMemcpyDeviceToDevice, ctx->stream));
             const int k = kk;
             ctx->si_hits += 1;
             // T = U A U^T (k x k, symmetric, diagonal except inside clusters of equal |lambda|)
@@ -2495,9 +2563,13 @@ int jacobi_eigh_top(ctm_ctx* ctx, const double* A, int n, int k, double* D, doub
             const int st = jacobi_eigh_top(ctx, T, k, k, Dk, Th, nullptr);      // full small problem (rows of Th = eigenvectors)
             ctx->si_enable = save;
             CTM_TRY(st);
-            // eigen-pairs of T come ordered by |lambda|: keep the leading k_out
-            GemmDesc r; r.M = k_out; r.N = n; r.K = k; r.A = Th; r.sam = k; r.sak = 1; r.B = Uk; r.sbk = n; r.sbn = 1; r.C = Ut; r.ldc = n;
+            // eigen-pairs of T come ordered by |lambda|: keep the leading k_out.  The workspace keeps ALL kk eigenvectors (after this
+            // Rayleigh-Ritz: inside a cluster of equal |lambda| with both signs the singular vectors of the iteration are mixtures),
+            // as v_i = sign(lambda_i) u_i -- the right vectors the iteration would have kept
+            GemmDesc r; r.M = k; r.N = n; r.K = k; r.A = Th; r.sam = k; r.sak = 1; r.B = Uk; r.sbk = n; r.sbn = 1; r.C = Y; r.ldc = n;
             CTM_TRY(gemm_f64(ctx, r));
+            CTM_HIP_CHECK(ctx, hipMemcpyAsync(Ut, Y, sizeof(double) * (size_t)k_out * n, hipMemcpyDeviceToDevice, ctx->stream));
+            if (warm) CTM_LAUNCH(ctx, signed_rows_kernel, dim3(256), dim3(256), 0, (const double*)Y, (const double*)Dk, 1, k, n, warm);
             CTM_HIP_CHECK(ctx, hipMemcpyAsync(D, Dk, sizeof(double) * k_out, hipMemcpyDeviceToDevice, ctx->stream));
             return CTM_OK;
         }
@@ -2562,11 +2634,15 @@ int jacobi_eigh_top_c(ctm_ctx* ctx, const double* Ar, const double* Ai, int n, i
         CTM_TRY(arena_alloc(ctx, sizeof(double) * kk, (void**)&S));
         CTM_TRY(arena_alloc(ctx, sizeof(double) * 2 * kn, (void**)&Uk));
         CTM_TRY(arena_alloc(ctx, sizeof(double) * 2 * kn, (void**)&Vk));
+        if (warm && ctx->eigh_warm) {
+            bool accepted = false;
+            CTM_TRY(eigh_warm_verify_c(ctx, As, As + nn, n, kk, k, warm, D, Ut, &accepted));
+            if (accepted) return CTM_OK;
+        }
         bool ok = false;
         MatOp aop; aop.n = n; aop.M = As; aop.Mi = As + nn; aop.warm = warm;      // warm: planar (k + 8) x n rows (re plane, im plane) of the previous subspace
         CTM_TRY(svd_iter_c(ctx, aop, kk, S, Uk, Vk, &ok));
         if (ok) {
-            if (warm) CTM_HIP_CHECK(ctx, hipMemcpyAsync(warm, Vk, sizeof(double) * 2 * kn, hipMemcpyDeviceToDevice, ctx->stream));
             ctx->si_hits += 1;
             // T = U A U^H (kk x kk Hermitian; U rows are q_j^H), T w = mu w, eigenvector rows x^H = w^H U
             double *Y, *T, *Dk, *Th;
@@ -2590,6 +2666,10 @@ int jacobi_eigh_top_c(ctm_ctx* ctx, const double* Ar, const double* Ai, int n, i
             CTM_HIP_CHECK(ctx, hipMemcpyAsync(Ut, tmp, sizeof(double) * (size_t)k * n, hipMemcpyDeviceToDevice, ctx->stream));
             CTM_HIP_CHECK(ctx, hipMemcpyAsync(Ut + (size_t)k * n, tmp + kn, sizeof(double) * (size_t)k * n, hipMemcpyDeviceToDevice, ctx->stream));
             CTM_HIP_CHECK(ctx, hipMemcpyAsync(D, Dk, sizeof(double) * k, hipMemcpyDeviceToDevice, ctx->stream));
+            if (warm) {     // all kk eigenvectors after the Rayleigh-Ritz, v_i = sign(lambda_i) u_i (see jacobi_eigh_top)
+                CTM_LAUNCH(ctx, signed_rows_kernel, dim3(256), dim3(256), 0, (const double*)tmp, (const double*)Dk, 1, kk, n, warm);
+                CTM_LAUNCH(ctx, signed_rows_kernel, dim3(256), dim3(256), 0, (const double*)(tmp + kn), (const double*)Dk, 1, kk, n, warm + kn);
+            }
             CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
             return CTM_OK;
         }

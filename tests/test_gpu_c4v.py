@@ -228,3 +228,76 @@ def test_warm_restart_is_accepted_when_the_kept_subspace_cuts_a_degenerate_pair(
     assert eng.stat("eigh_warm_hits") >= 1 and eng.stat("eigh_warm_rejects") == 0
     for D, U in outs:
         assert float((D.cpu() - lam[:chi]).abs().max()) < 1e-13
+
+
+# ---- complex Hermitian restart (real embedding; only the keep-the-vectors route) --------------------------------------------------
+def _herm_with_spectrum(n, lam, seed):
+    g = torch.Generator().manual_seed(seed)
+    Z = torch.randn(n, n, generator=g, dtype=torch.float64) + 1j * torch.randn(n, n, generator=g, dtype=torch.float64)
+    Q, _ = torch.linalg.qr(Z)
+    return (Q * lam.to(torch.complex128)) @ Q.conj().T, Q
+
+
+def test_complex_warm_restart_on_a_stationary_hermitian_matrix(eng):
+    """Spectrum with pairs of equal modulus and opposite sign (as the enlarged corner of the A1 + i A2 ansatz has): the workspace keeps
+    the eigenvectors after the small Rayleigh-Ritz, not the singular vectors of the iteration (mixtures inside such a pair)."""
+    n, chi = 768, 48
+    mod = 0.8 ** (torch.arange(n, dtype=torch.float64) // 2)
+    lam = mod * torch.where(torch.arange(n) % 2 == 0, 1.0, -1.0)           # +m0, -m0, +m1, -m1, ...
+    A, _ = _herm_with_spectrum(n, lam, 21)
+    A = A.cuda()
+    D0, U0 = eng.truncated_eigh(A, chi)
+    basis = eng.warm_basis_c4v(chi, n, A.dtype)
+    eng.timers(reset=True)
+    outs = [eng.truncated_eigh(A, chi, basis=basis) for _ in range(4)]
+    assert eng.stat("eigh_warm_hits") >= 2
+    for D, U in outs:
+        assert float((D.abs() - D0.abs()).abs().max()) < 1e-13
+        assert float(((A @ U) - U * D.to(U.dtype)).abs().max()) < 1e-12
+        assert float((U.conj().T @ U - torch.eye(chi, device=U.device, dtype=U.dtype)).abs().max()) < 1e-12
+    for (_, Ua), (_, Ub) in zip(outs[:-1], outs[1:]):          # canonical phases: the columns do not change between calls
+        assert float((Ua - Ub).abs().max()) < 1e-7
+
+
+def test_complex_warm_restart_with_a_missing_leading_direction_is_rejected(eng):
+    n, chi = 768, 48
+    lam = (0.8 ** torch.arange(n, dtype=torch.float64))
+    A, Q = _herm_with_spectrum(n, lam, 23)
+    kk = chi + 1 + 8
+    cols = [i for i in range(kk + 1) if i != 4]
+    basis = eng.warm_basis_c4v(chi, n, A.dtype)
+    Vh = Q[:, cols].conj().T.contiguous()                      # rows v_i^H
+    basis.copy_(torch.cat([Vh.real, Vh.imag]).cuda())
+    eng.timers(reset=True)
+    D, U = eng.truncated_eigh(A.cuda(), chi, basis=basis)
+    assert eng.stat("eigh_warm_rejects") == 1 and eng.stat("eigh_warm_hits") == 0
+    assert float((D.cpu() - lam[:chi]).abs().max()) < 1e-12
+
+
+def test_complex_c4v_run_with_and_without_the_warm_restart_agree(eng):
+    from ipeps.ipeps_c4v import IPEPS_C4V
+    from ctm.one_site_c4v.env_c4v import ENV_C4V, init_env
+    from ctm.one_site_c4v import ctmrg_c4v
+    from groups.pg import make_c4v_symm
+    from models import j1j2
+    rng = np.random.default_rng(14)
+    a = make_c4v_symm(torch.from_numpy(rng.random((2, 4, 4, 4, 4)))) \
+        + 1j * make_c4v_symm(torch.from_numpy(rng.random((2, 4, 4, 4, 4)) - 0.5), irreps=["A2"])
+    a = (a / a.abs().max()).cuda()
+    res = []
+    for flag in (1, 0):
+        eng.set_option("eigh_warm", flag)
+        try:
+            st = IPEPS_C4V(a.clone())
+            env = ENV_C4V(20, st); init_env(st, env)
+            eng.timers(reset=True)
+            for _ in range(30):
+                ctmrg_c4v.ctm_MOVE_sl(st.site(), env)
+            hits = eng.stat("eigh_warm_hits")
+            e = float(j1j2.J1J2_C4V_BIPARTITE(j1=1.0, j2=0.3).energy_1x1_lowmem(st, env))
+            res.append((hits, torch.diagonal(env.get_C()).clone(), e))
+        finally:
+            eng.set_option("eigh_warm", 1)
+    assert res[0][0] > 0 and res[1][0] == 0
+    assert float((res[0][1] - res[1][1]).abs().max()) < 1e-11
+    assert abs(res[0][2] - res[1][2]) < 1e-11

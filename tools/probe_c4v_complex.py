@@ -23,3 +23,13 @@ for i in range(nm):
 print("ms per move:", " ".join(f"{t:.1f}" for t in ts[:12]), "... median of the last half", f"{sorted(ts[nm//2:])[len(ts[nm//2:])//2]:.2f}", "si_iters", eng.stat("si_total_iters"), "fallbacks", eng.stat("si_fallbacks"))
 d = torch.diagonal(env.get_C()).abs()
 print("C spectrum head/tail", float(d[1]/d[0]), float(d[-1]/d[0]))
+# stationarity of the enlarged corner itself (elementwise) vs of its spectrum (gauge invariant)
+from ctm.one_site_c4v.ctm_components_c4v import c2x2_sl
+prev = None
+for i in range(6):
+    c = c2x2_sl(st.site(), env.get_C(), env.get_T())
+    ev = torch.linalg.eigvalsh(c.cpu())
+    if prev is not None:
+        print(f"sweep +{i}: |dC2x2|/|C2x2| = {float((c - prev[0]).norm() / c.norm()):.3e}   |d spectrum| = {float((ev - prev[1]).abs().max() / ev.abs().max()):.3e}   |dT| = {float((env.get_T() - prev[2]).norm() / prev[2].norm()):.3e}")
+    prev = (c.clone(), ev, env.get_T().clone())
+    ctmrg_c4v.ctm_MOVE_sl(st.site(), env)
