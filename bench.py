@@ -24,6 +24,7 @@ import torch
 CONFIGS = {
     # name: (kind, D, chi, dtype)          BASELINE.json configs[1..4]
     "c4v_D4_chi64": ("c4v", 4, 64, "f64"),
+    "c4v_D4_chi64_c128": ("c4v", 4, 64, "c128"),               # the complex C4v ansatz A1 + i A2 (ipeps_c4v.py:60-66)
     "generic_D4_chi64": ("generic", 4, 64, "f64"),
     "generic_D6_chi128": ("generic", 6, 128, "f64"),
     "generic_D8_chi256": ("generic", 8, 256, "f64"),
@@ -38,6 +39,12 @@ FP64_MFMA_PEAK_TFLOPS = 78.6               # MI355X FP64 matrix peak (v_mfma_f64
 
 def synth_sites(kind, D, seed=1, dtype="f64"):
     rng = np.random.default_rng(seed)
+    if kind == "c4v" and dtype == "c128":
+        from groups.pg import make_c4v_symm
+        A = make_c4v_symm(torch.from_numpy(rng.random((2, D, D, D, D)))) \
+            + 1j * make_c4v_symm(torch.from_numpy(rng.random((2, D, D, D, D)) - 0.5), irreps=["A2"])
+        A = A.numpy()
+        return {(0, 0): A / np.abs(A).max()}
     if dtype == "c128":      # re and im parts each U[0,1)
         sites = {}
         for y in range(2):
