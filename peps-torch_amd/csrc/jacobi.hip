@@ -2313,7 +2313,6 @@ __global__ __launch_bounds__(64) void inv_rel_kernel(const double* __restrict__ 
 // iteration has turned x towards the leading eigenspace (a cluster or an exact tie at the top only makes r smaller).
 // One wave, thread i keeps row i in registers.
 __global__ __launch_bounds__(64) void sym64_lmax_kernel(const double* __restrict__ G, int iters, double* __restrict__ out) {
-    __shared__ double x[64];
     const int i = threadIdx.x;
     double row[64];
     double f = 0.0;
@@ -2328,13 +2327,13 @@ __global__ __launch_bounds__(64) void sym64_lmax_kernel(const double* __restrict
         const double nrm = sqrt(q);
         if (!(nrm > 0.0)) break;
         const double xn = xi / nrm;
-        x[i] = xn;
-        __syncthreads();
         double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
 #pragma unroll
-        for (int j = 0; j < 64; j += 4) { a0 += row[j] * x[j]; a1 += row[j + 1] * x[j + 1]; a2 += row[j + 2] * x[j + 2]; a3 += row[j + 3] * x[j + 3]; }
+        for (int j = 0; j < 64; j += 4) {                       // x_j of lane j by lane broadcast (compile-time lane: v_readlane), no LDS round trip
+            a0 += row[j] * __shfl(xn, j, 64); a1 += row[j + 1] * __shfl(xn, j + 1, 64);
+            a2 += row[j + 2] * __shfl(xn, j + 2, 64); a3 += row[j + 3] * __shfl(xn, j + 3, 64);
+        }
         xi = (a0 + a1) + (a2 + a3);                             // (G x)_i
-        __syncthreads();
         if (it == iters) {
             double rho = xn * xi;
             for (int off = 32; off > 0; off >>= 1) rho += __shfl_xor(rho, off, 64);
@@ -2473,7 +2472,7 @@ static int eigh_warm_verify(ctm_ctx* ctx, const double* As, int n, int kk, int k
     // the largest singular value mu of the last product from its 64 x 64 Gram matrix: mu^2 <= |G|_F, mu^2 ~ rho + r of a power iterate
     GemmDesc gg; gg.M = pb; gg.N = pb; gg.K = n; gg.A = Z; gg.sam = n; gg.sak = 1; gg.B = Z; gg.sbk = 1; gg.sbn = n; gg.C = G64; gg.ldc = pb;
     CTM_TRY(gemm_f64(ctx, gg));
-    CTM_LAUNCH(ctx, sym64_lmax_kernel, dim3(1), dim3(64), 0, (const double*)G64, 64, bnd);
+    CTM_LAUNCH(ctx, sym64_lmax_kernel, dim3(1), dim3(64), 0, (const double*)G64, 48, bnd);
     CTM_HIP_CHECK(ctx, hipMemcpyAsync(h.data(), bnd, sizeof(double) * 2, hipMemcpyDeviceToHost, ctx->stream));
     CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     const double mu_hi = std::sqrt(std::max(h[0], 0.0)), mu_lo = std::sqrt(std::max(h[1], 0.0));
