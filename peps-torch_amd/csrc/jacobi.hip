@@ -1564,10 +1564,12 @@ __global__ __launch_bounds__(64) void pivchol64_inv_kernel(const double* __restr
         const int p = who;
         double acc0 = GX[p][j], acc1 = 0.0;                       // G[j][p] (symmetric)
         int t = 0;
-        for (; t + 4 <= k; t += 4) {
-            const double a0 = Lt[t][j], a1 = Lt[t + 1][j], a2 = Lt[t + 2][j], a3 = Lt[t + 3][j];
-            const double b0 = Lt[t][p], b1 = Lt[t + 1][p], b2 = Lt[t + 2][p], b3 = Lt[t + 3][p];
-            acc0 -= a0 * b0; acc1 -= a1 * b1; acc0 -= a2 * b2; acc1 -= a3 * b3;
+        for (; t + 8 <= k; t += 8) {
+            double a[8], b[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { a[u] = Lt[t + u][j]; b[u] = Lt[t + u][p]; }
+#pragma unroll
+            for (int u = 0; u < 8; u += 2) { acc0 -= a[u] * b[u]; acc1 -= a[u + 1] * b[u + 1]; }
         }
         for (; t < k; ++t) acc0 -= Lt[t][j] * Lt[t][p];
         const double lkk = sqrt(best);
@@ -1582,9 +1584,18 @@ __global__ __launch_bounds__(64) void pivchol64_inv_kernel(const double* __restr
     const int c = j;
     for (int r = 0; r < rank; ++r) {
         const int pr = __shfl(myperm, r, 64);
-        double acc = (r == c) ? 1.0 : 0.0;
-        for (int t = 0; t < r; ++t) acc -= Lt[t][pr] * GX[t][c];
-        GX[r][c] = (r >= c && c < rank) ? acc / Lt[r][pr] : 0.0;
+        // the LDS reads do not depend on the accumulators: eight iterations' loads are issued together (two accumulator chains)
+        double acc0 = (r == c) ? 1.0 : 0.0, acc1 = 0.0;
+        int t = 0;
+        for (; t + 8 <= r; t += 8) {
+            double a[8], b[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { a[u] = Lt[t + u][pr]; b[u] = GX[t + u][c]; }
+#pragma unroll
+            for (int u = 0; u < 8; u += 2) { acc0 -= a[u] * b[u]; acc1 -= a[u + 1] * b[u + 1]; }
+        }
+        for (; t < r; ++t) acc0 -= Lt[t][pr] * GX[t][c];
+        GX[r][c] = (r >= c && c < rank) ? (acc0 + acc1) / Lt[r][pr] : 0.0;
     }
     __syncthreads();
     // Mo[k][perm[t]] = X[k][t]: thread j zeroes column j, then (j < rank) fills column perm[j]
