@@ -118,6 +118,61 @@ def init_env_ctmrg(state, chi):
     return env
 
 
+def init_env_prod(state, chi):
+    """init_prod (ctm/generic/env.py:274-365), 5-leg sites: C = e_00; T of direction vec = partial trace of the neighbour's double
+    layer over all legs but the one pointing back, placed at T[0,:,0] / T[0,0,:] / T[:,0,0]; the (0,-1) one is NOT normalised."""
+    env = Env(chi)
+    spec = {(0, -1): ('miefg,miebg->fb', lambda n: (chi, n, chi), (0, slice(None), 0), False),
+            (-1, 0): ('meifg,meifc->gc', lambda n: (chi, chi, n), (0, 0, slice(None)), True),
+            (0, 1): ('mefig,mafig->ea', lambda n: (n, chi, chi), (slice(None), 0, 0), True),
+            (1, 0): ('mefgi,mebgi->fb', lambda n: (chi, n, chi), (0, slice(None), 0), True)}
+    for coord in state.sites:
+        for vec in ((-1, -1), (1, -1), (1, 1), (-1, 1)):
+            C = np.zeros((chi, chi), dtype=state.site(coord).dtype); C[0, 0] = 1.0
+            env.C[(coord, vec)] = C
+        for vec, (expr, shape, where, normalise) in spec.items():
+            A = state.site((coord[0] + vec[0], coord[1] + vec[1]))
+            a = np.einsum(expr, A, A.conj()).reshape(-1)
+            if normalise:
+                a = a / np.abs(a).max()
+            T = np.zeros(shape(a.size), dtype=A.dtype)
+            T[where] = a
+            env.T[(coord, vec)] = T
+    return env
+
+
+def init_env_obc(state, chi):
+    """init_from_ipeps_obc (ctm/generic/env.py:538-716), 5-leg sites: the outward legs of each layer summed separately, BOTH layers
+    un-conjugated (`einsum('mijef,mklab->eafb', A, A)`), divided by the max-abs, zero padded to chi."""
+    env = Env(chi)
+    cspec = {(-1, -1): 'mijef,mklab->eafb', (1, -1): 'miefj,mkabl->eafb', (1, 1): 'mefij,mabkl->eafb', (-1, 1): 'meijf,maklb->eafb'}
+    tspec = {(0, -1): 'miefg,mkabc->eafbgc', (-1, 0): 'meifg,makbc->eafbgc', (0, 1): 'mefig,mabkc->eafbgc', (1, 0): 'mefgi,mabck->eafbgc'}
+    for coord in state.sites:
+        for vec, expr in cspec.items():
+            A = state.site((coord[0] + vec[0], coord[1] + vec[1]))
+            r = np.einsum(expr, A, A)
+            a = _nrm(r.reshape(r.shape[0] * r.shape[1], r.shape[2] * r.shape[3]))
+            C = np.zeros((chi, chi), dtype=A.dtype)
+            m0, m1 = min(chi, a.shape[0]), min(chi, a.shape[1])
+            C[:m0, :m1] = a[:m0, :m1]
+            env.C[(coord, vec)] = C
+        for vec, expr in tspec.items():
+            A = state.site((coord[0] + vec[0], coord[1] + vec[1]))
+            r = np.einsum(expr, A, A)
+            a = _nrm(r.reshape(r.shape[0] * r.shape[1], r.shape[2] * r.shape[3], r.shape[4] * r.shape[5]))
+            if vec in ((0, -1), (1, 0)):
+                T = np.zeros((chi, a.shape[1], chi), dtype=A.dtype); m0, m2 = min(chi, a.shape[0]), min(chi, a.shape[2])
+                T[:m0, :, :m2] = a[:m0, :, :m2]
+            elif vec == (-1, 0):
+                T = np.zeros((chi, chi, a.shape[2]), dtype=A.dtype); m0, m1 = min(chi, a.shape[0]), min(chi, a.shape[1])
+                T[:m0, :m1, :] = a[:m0, :m1, :]
+            else:
+                T = np.zeros((a.shape[0], chi, chi), dtype=A.dtype); m1, m2 = min(chi, a.shape[1]), min(chi, a.shape[2])
+                T[:, :m1, :m2] = a[:, :m1, :m2]
+            env.T[(coord, vec)] = T
+    return env
+
+
 # ----------------------------------------------------------------------------------
 # enlarged corners  (ctm/generic/ctm_components.py:372-434, 532-586, 683-733, 832-884)
 # ----------------------------------------------------------------------------------

@@ -392,6 +392,33 @@ def generic_ad_case(name, base, complex_=False, moves=((0, -1), (-1, 0), (0, 1),
     print(f"  {name} ok  E={float(torch.real(e)):.12f} |grad|={gn:.6e}")
 
 
+def envinit_case():
+    """init_prod / init_from_ipeps_obc (ctm/generic/env.py:274-365, 538-716) on random 2x2 states, chi below and above D^2."""
+    out = {}
+    for tag, D, chi, cplx, seed in (("f64_D2_chi3", 2, 3, False, 41), ("f64_D2_chi6", 2, 6, False, 42), ("c128_D3_chi7", 3, 7, True, 43)):
+        set_dtype(cplx)
+        sites = rand_state(D, cplx, seed)
+        st = ref_state(sites)
+        ost = O.State(sites)
+        for k, v in sites.items():
+            out[f"{tag}_site_{k[0]}_{k[1]}"] = v
+        for kind, fo in (("PROD", O.init_env_prod), ("CTMRG_OBC", O.init_env_obc)):
+            env = ENV(chi, st)
+            old = cfg.ctm_args.ctm_env_init_type
+            cfg.ctm_args.ctm_env_init_type = kind
+            try:
+                init_env(st, env)
+            finally:
+                cfg.ctm_args.ctm_env_init_type = old
+            C, T = env_to_np(env)
+            oe = fo(ost, chi)
+            for k in C: close(oe.C[k], C[k], 1e-13, f"{kind} C{k}")
+            for k in T: close(oe.T[k], T[k], 1e-13, f"{kind} T{k}")
+            pack_env(f"{tag}_{kind}_", C, T, out)
+    np.savez_compressed(os.path.join(GOLD, "envinit.npz"), **out)
+    print("  envinit ok")
+
+
 def rvb_case():
     """G1/G2: the reference's own known-answer test (examples/j1j2/ctmrg_j1j2_c4v.py:218-260):
     RVB_1x1 D=3 chi=16 j2=0.5 -> E = -0.47684229 +- 1e-8."""
@@ -629,7 +656,7 @@ def input_files_case():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["decomp", "generic", "c4v", "c4v_ad", "generic_ad", "rvb", "files", "variants", "aklt", "inputs", "backward"]
+    which = sys.argv[1:] or ["decomp", "generic", "c4v", "c4v_ad", "generic_ad", "envinit", "rvb", "files", "variants", "aklt", "inputs", "backward"]
     if "backward" in which:
         backward_case()
     if "inputs" in which:
@@ -658,6 +685,8 @@ if __name__ == "__main__":
         generic_ad_case("generic_ad_D2_chi8_f64", "generic_D2_chi8_f64")
         generic_ad_case("generic_ad_D2_chi8_c128", "generic_D2_chi8_c128", complex_=True)
         generic_ad_case("generic_ad_D2_chi8_f64_4x2", "generic_D2_chi8_f64", moves=((0, -1), (1, 0)), projector_method='4X2')
+    if "envinit" in which:
+        envinit_case()
     if "rvb" in which:
         rvb_case()
     if "files" in which:

@@ -116,10 +116,14 @@ class ENV():
 def init_env(state, env, ctm_args=cfg.ctm_args):
     if len(next(iter(state.sites.values())).size()) == 4 and ctm_args.ctm_env_init_type not in ["PROD", "CTMRG_OBC", "RANDOM"]:
         raise RuntimeError("Incompatible ENV initialization")
-    if ctm_args.ctm_env_init_type == 'RANDOM':
+    if ctm_args.ctm_env_init_type == 'PROD':
+        init_prod(state, env, ctm_args.verbosity_initialization)
+    elif ctm_args.ctm_env_init_type == 'RANDOM':
         init_random(env, ctm_args.verbosity_initialization)
     elif ctm_args.ctm_env_init_type == 'CTMRG':
         init_from_ipeps_pbc(state, env, ctm_args.verbosity_initialization)
+    elif ctm_args.ctm_env_init_type == 'CTMRG_OBC':
+        init_from_ipeps_obc(state, env, ctm_args.verbosity_initialization)
     else:
         raise ValueError("Invalid environment initialization: " + str(ctm_args.ctm_env_init_type))
 
@@ -129,6 +133,77 @@ def init_random(env, verbosity=0):
         env.C[key] = torch.rand(t.size(), dtype=env.dtype, device=env.device)
     for key, t in env.T.items():
         env.T[key] = torch.rand(t.size(), dtype=env.dtype, device=env.device)
+
+
+# per T direction: (legs of a[s,u,l,d,r] that stay open in the PROD init / leg traced between the layers, shape builder)
+_PROD_T = {(0, -1): ('miefg,miebg->fb', lambda chi, n: (chi, n, chi), lambda T, a: T.__setitem__((0, slice(None), 0), a), False),
+           (-1, 0): ('meifg,meifc->gc', lambda chi, n: (chi, chi, n), lambda T, a: T.__setitem__((0, 0, slice(None)), a), True),
+           (0, 1): ('mefig,mafig->ea', lambda chi, n: (n, chi, chi), lambda T, a: T.__setitem__((slice(None), 0, 0), a), True),
+           (1, 0): ('mefgi,mebgi->fb', lambda chi, n: (chi, n, chi), lambda T, a: T.__setitem__((0, slice(None), 0), a), True)}
+
+
+def init_prod(state, env, verbosity=0):
+    """env.py:274-365 (5-leg sites): C = e_00; every T holds, in its chi x chi corner (0,0), the double-layer partial trace of the
+    neighbouring site over everything but the leg pointing at `coord`.  As in the reference the T of direction (0,-1) is the only
+    one NOT divided by its max-abs (:297-298 vs :319, :341, :363)."""
+    eng = get_engine()
+    chi = env.chi
+    o = dict(dtype=env.dtype, device=env.device)
+    for key, t in env.C.items():
+        C = torch.zeros(t.size(), **o)
+        C[0, 0] = 1.0
+        env.C[key] = C
+    for coord in state.sites.keys():
+        for vec, (expr, shape, put, normalise) in _PROD_T.items():
+            A = state.site((coord[0] + vec[0], coord[1] + vec[1]))
+            if A.dim() != 5:
+                raise NotImplementedError("init_prod: double-layer (4-leg) sites are not supported by the native engine")
+            a = eng.einsum(expr, A, A, conj=(1,)).reshape(-1)
+            if normalise:
+                a = a / a.abs().max()
+            T = torch.zeros(shape(chi, a.numel()), **o)
+            put(T, a)
+            env.T[(coord, vec)] = T
+
+
+# open boundary: the outward legs of EACH layer are summed separately (contracted with vectors of ones), no conjugation (:538-716)
+_OBC_C = {(-1, -1): ((1, 2), 3, 4), (1, -1): ((1, 4), 2, 3), (1, 1): ((3, 4), 1, 2), (-1, 1): ((2, 3), 1, 4)}
+_OBC_T = {(0, -1): (1, (2, 3, 4)), (-1, 0): (2, (1, 3, 4)), (0, 1): (3, (1, 2, 4)), (1, 0): (4, (1, 2, 3))}
+
+
+def init_from_ipeps_obc(state, env, verbosity=0):
+    """env.py:538-716 (5-leg sites): C and T from the neighbouring site with its outward legs summed out layer by layer
+    (`einsum('mijef,mklab->eafb', A, A)`: both layers un-conjugated, as the reference has it), divided by the max-abs, zero padded."""
+    eng = get_engine()
+    chi = env.chi
+    o = dict(dtype=env.dtype, device=env.device)
+    for coord in state.sites.keys():
+        for vec, (summed, i0, i1) in _OBC_C.items():
+            A = state.site((coord[0] + vec[0], coord[1] + vec[1]))
+            if A.dim() != 5:
+                raise NotImplementedError("init_from_ipeps_obc: double-layer (4-leg) sites are not supported by the native engine")
+            B = A.sum(dim=summed).contiguous()                                  # [m, e, f]
+            a = eng.einsum('mef,mab->eafb', B, B).reshape(A.size(i0) ** 2, A.size(i1) ** 2)
+            a = a / a.abs().max()
+            C = torch.zeros(chi, chi, **o)
+            m0, m1 = min(chi, a.size(0)), min(chi, a.size(1))
+            C[:m0, :m1] = a[:m0, :m1]
+            env.C[(coord, vec)] = C
+        for vec, (summed, (i0, i1, i2)) in _OBC_T.items():
+            A = state.site((coord[0] + vec[0], coord[1] + vec[1]))
+            B = A.sum(dim=summed).contiguous()                                  # [m, e, f, g]
+            a = eng.einsum('mefg,mabc->eafbgc', B, B).reshape(A.size(i0) ** 2, A.size(i1) ** 2, A.size(i2) ** 2)
+            a = a / a.abs().max()
+            if vec in ((0, -1), (1, 0)):
+                T = torch.zeros((chi, a.size(1), chi), **o); m0, m2 = min(chi, a.size(0)), min(chi, a.size(2))
+                T[:m0, :, :m2] = a[:m0, :, :m2]
+            elif vec == (-1, 0):
+                T = torch.zeros((chi, chi, a.size(2)), **o); m0, m1 = min(chi, a.size(0)), min(chi, a.size(1))
+                T[:m0, :m1, :] = a[:m0, :m1, :]
+            else:
+                T = torch.zeros((a.size(0), chi, chi), **o); m1, m2 = min(chi, a.size(1)), min(chi, a.size(2))
+                T[:, :m1, :m2] = a[:, :m1, :m2]
+            env.T[(coord, vec)] = T
 
 
 _C_KIND = {(-1, -1): (0, 3, 4), (1, -1): (1, 2, 3), (1, 1): (2, 1, 2), (-1, 1): (3, 1, 4)}

@@ -284,3 +284,26 @@ def test_rdm2x2_from_parts_equals_the_whole(case, eng):
     with mock.patch("torch.cuda.mem_get_info", return_value=(1, 1)), mock.patch.object(type(eng), "stat", lambda self, k: 0):
         r = rdm.rdm2x2((0, 0), st, env)
     assert relerr(r, rdm.rdm2x2((0, 0), st, env)) < 1e-14
+
+
+@pytest.mark.parametrize("tag,chi", [("f64_D2_chi3", 3), ("f64_D2_chi6", 6), ("c128_D3_chi7", 7)])
+@pytest.mark.parametrize("kind", ["PROD", "CTMRG_OBC"])
+def test_env_init_variants_on_the_engine(eng, tag, chi, kind):
+    """ctm_env_init_type PROD / CTMRG_OBC (reference ctm/generic/env.py:274-365, 538-716) against the reference's own output."""
+    import config as cfg
+    from ipeps.ipeps import IPEPS
+    from ctm.generic.env import ENV, init_env
+    from helpers_cpu import env_from
+    g = golden("envinit")
+    sites = {tuple(int(v) for v in k.split('_')[-2:]): g[k] for k in g.files if k.startswith(tag + "_site_")}
+    st = IPEPS({k: dev(v) for k, v in sites.items()}, lX=2, lY=2)
+    env = ENV(chi, st)
+    old = cfg.ctm_args.ctm_env_init_type
+    cfg.ctm_args.ctm_env_init_type = kind
+    try:
+        init_env(st, env)
+    finally:
+        cfg.ctm_args.ctm_env_init_type = old
+    C, T = env_from(g, f"{tag}_{kind}_")
+    for k in C: assert relerr(env.C[k], C[k]) < 1e-13 or float(np.abs(C[k]).max()) == 0
+    for k in T: assert tuple(env.T[k].shape) == T[k].shape and relerr(env.T[k], T[k]) < 1e-13

@@ -251,3 +251,45 @@ def test_corrf_with_user_supplied_boundary_edges(cpu_cfg):
         rl = (lambda c: corrf.get_edge(c, rev, st, env), lambda c: 2.5 * corrf.get_edge(c, d, st, env))
         got = corrf.corrf_1sO1sO((0, 0), d, st, env, sz, lambda r: sz, 3, rl_0=rl)
         assert float((got - ref).abs().max()) < 1e-13
+
+
+# ---- environment initialisations PROD / CTMRG_OBC (reference ctm/generic/env.py:274-365, 538-716) ---------------------------------
+ENVINIT_CASES = [("f64_D2_chi3", 3), ("f64_D2_chi6", 6), ("c128_D3_chi7", 7)]
+
+
+def _envinit_sites(g, tag):
+    return {tuple(int(v) for v in k.split('_')[-2:]): g[k] for k in g.files if k.startswith(tag + "_site_")}
+
+
+@pytest.mark.parametrize("tag,chi", ENVINIT_CASES)
+@pytest.mark.parametrize("kind", ["PROD", "CTMRG_OBC"])
+def test_env_init_variants_oracle_vs_reference(tag, chi, kind):
+    from oracle import ctm_oracle as O
+    from helpers_cpu import env_from
+    g = golden("envinit")
+    ost = O.State(_envinit_sites(g, tag))
+    oe = (O.init_env_prod if kind == "PROD" else O.init_env_obc)(ost, chi)
+    C, T = env_from(g, f"{tag}_{kind}_")
+    assert len(C) == 16 and len(T) == 16
+    for k in C: assert abs(oe.C[k] - C[k]).max() < 1e-13
+    for k in T: assert oe.T[k].shape == T[k].shape and abs(oe.T[k] - T[k]).max() < 1e-13
+
+
+@pytest.mark.parametrize("tag,chi", ENVINIT_CASES)
+@pytest.mark.parametrize("kind", ["PROD", "CTMRG_OBC"])
+def test_env_init_variants_host_layer(cpu_cfg, tag, chi, kind):
+    from ipeps.ipeps import IPEPS
+    from ctm.generic.env import ENV, init_env
+    from helpers_cpu import env_from
+    g = golden("envinit")
+    st = IPEPS({k: torch.from_numpy(v.copy()) for k, v in _envinit_sites(g, tag).items()}, lX=2, lY=2)
+    env = ENV(chi, st)
+    old = cpu_cfg.ctm_args.ctm_env_init_type
+    cpu_cfg.ctm_args.ctm_env_init_type = kind
+    try:
+        init_env(st, env)
+    finally:
+        cpu_cfg.ctm_args.ctm_env_init_type = old
+    C, T = env_from(g, f"{tag}_{kind}_")
+    for k in C: assert float((env.C[k] - torch.from_numpy(C[k])).abs().max()) < 1e-13
+    for k in T: assert tuple(env.T[k].shape) == T[k].shape and float((env.T[k] - torch.from_numpy(T[k])).abs().max()) < 1e-13
