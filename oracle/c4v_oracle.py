@@ -38,6 +38,32 @@ def init_env_ctmrg(a, chi):
     return C, T
 
 
+def init_env_prod(a, chi):
+    """init_prod (env_c4v.py:215-246): C = e_00, T[0,0,:] = leading eigenvector (by |eigenvalue|) of 'meifj,maibj->eafb' / max-abs."""
+    D = a.shape[1]
+    t = np.einsum('meifj,maibj->eafb', a, a.conj()).reshape(D * D, D * D)
+    t = t / np.abs(t).max()
+    Dv, U = truncated_eig_sym(t, 2)
+    C = np.zeros((chi, chi), dtype=a.dtype); C[0, 0] = 1.0
+    T = np.zeros((chi, chi, D * D), dtype=a.dtype); T[0, 0, :] = U[:, 0]
+    return C, T
+
+
+def init_env_obc(a, chi):
+    """init_from_ipeps_obc (env_c4v.py:315-355): outward legs summed layer by layer (ket and conjugated bra), / max-abs, zero padded."""
+    D = a.shape[1]
+    c = np.einsum('mijef,mklab->eafb', a, a.conj()).reshape(D * D, D * D)
+    c = c / np.abs(c).max()
+    C = np.zeros((chi, chi), dtype=a.dtype)
+    m = min(chi, D * D)
+    C[:m, :m] = c[:m, :m]
+    t = np.einsum('meifg,makbc->eafbgc', a, a.conj()).reshape(D * D, D * D, D * D)
+    t = t / np.abs(t).max()
+    T = np.zeros((chi, chi, D * D), dtype=a.dtype)
+    T[:m, :m, :] = t[:m, :m, :]
+    return C, T
+
+
 def ctm_move_sl(a, C, T, chi=None, eps_multiplet=1.0e-12, abs_tol=1.0e-14, return_P=False, norm_type='inf'):
     """ctm_MOVE_sl (ctmrg_c4v.py:325-463) with truncated_eig_sym(keep_multiplets=True)
     (ctmrg_c4v.py:49-52: eps_multiplet/abs_tol at their custom_eig.py defaults)."""

@@ -415,6 +415,33 @@ def envinit_case():
             for k in C: close(oe.C[k], C[k], 1e-13, f"{kind} C{k}")
             for k in T: close(oe.T[k], T[k], 1e-13, f"{kind} T{k}")
             pack_env(f"{tag}_{kind}_", C, T, out)
+    # one-site C4v variants (ctm/one_site_c4v/env_c4v.py:215-246, 315-355)
+    for tag, D, chi, cplx, seed in (("c4v_f64_D2_chi3", 2, 3, False, 51), ("c4v_f64_D3_chi12", 3, 12, False, 52), ("c4v_c128_D2_chi6", 2, 6, True, 53)):
+        set_dtype(cplx)
+        rng = np.random.default_rng(seed)
+        A = t2n(make_c4v_symm(torch.from_numpy(rng.random((2, D, D, D, D)))))
+        if cplx:
+            A = A + 1j * t2n(make_c4v_symm(torch.from_numpy(rng.random((2, D, D, D, D)) - 0.5), irreps=["A2"]))
+        A = A / np.abs(A).max()
+        out[f"{tag}_site"] = A
+        st4 = IPEPS_C4V(torch.from_numpy(A.copy()))
+        for kind, fo in (("PROD", O4.init_env_prod), ("CTMRG_OBC", O4.init_env_obc)):
+            e4 = ENV_C4V(chi, st4)
+            old = cfg.ctm_args.ctm_env_init_type
+            cfg.ctm_args.ctm_env_init_type = kind
+            try:
+                env_c4v.init_env(st4, e4)
+            finally:
+                cfg.ctm_args.ctm_env_init_type = old
+            C4, T4 = t2n(e4.get_C()), t2n(e4.get_T())
+            oC, oT = fo(A, chi)
+            close(oC, C4, 1e-13, f"c4v {kind} C")
+            if kind == "PROD":       # the leading eigenvector is defined up to a phase
+                ph = np.vdot(oT[0, 0, :], T4[0, 0, :]); ph = ph / abs(ph)
+                close(oT * ph, T4, 1e-12, f"c4v {kind} T")
+            else:
+                close(oT, T4, 1e-13, f"c4v {kind} T")
+            out[f"{tag}_{kind}_C"] = C4; out[f"{tag}_{kind}_T"] = T4
     np.savez_compressed(os.path.join(GOLD, "envinit.npz"), **out)
     print("  envinit ok")
 

@@ -65,10 +65,14 @@ def init_env(state, env, C_and_T=None, ctm_args=cfg.ctm_args):
         env.T[env.keyT] = torch.zeros((env.chi, env.chi, C_and_T[1].size(2)), dtype=env.dtype, device=env.device)
         env.T[env.keyT][:x, :x, :] = C_and_T[1]
         return
-    if ctm_args.ctm_env_init_type == 'RANDOM':
+    if ctm_args.ctm_env_init_type == 'PROD':
+        init_prod(state, env, ctm_args.verbosity_initialization)
+    elif ctm_args.ctm_env_init_type == 'RANDOM':
         init_random(env, ctm_args.verbosity_initialization)
     elif ctm_args.ctm_env_init_type == 'CTMRG':
         init_from_ipeps_pbc(state, env, ctm_args.verbosity_initialization)
+    elif ctm_args.ctm_env_init_type == 'CTMRG_OBC':
+        init_from_ipeps_obc(state, env, ctm_args.verbosity_initialization)
     else:
         raise ValueError("Invalid environment initialization: " + str(ctm_args.ctm_env_init_type))
 
@@ -77,6 +81,51 @@ def init_random(env, verbosity=0):
     c = torch.rand(env.get_C().size(), dtype=env.dtype, device=env.device)
     env.C[env.keyC] = 0.5 * (c + c.conj().t())
     env.T[env.keyT] = torch.rand(env.get_T().size(), dtype=env.dtype, device=env.device)
+
+
+def init_prod(state, env, verbosity=0):
+    """env_c4v.py:215-246 (5-leg site): C = e_00; T[0,0,:] = the leading eigenvector of the double-layer partial trace over the
+    physical, up and down legs ('meifj,maibj->eafb'), which must be unique."""
+    eng = get_engine()
+    A = state.site()
+    if A.dim() != 5:
+        raise NotImplementedError("init_prod: double-layer (4-leg) sites are not supported by the native engine")
+    C = torch.zeros(env.chi, env.chi, dtype=env.dtype, device=env.device)
+    C[0, 0] = 1.0
+    env.C[env.keyC] = C
+    a = eng.einsum('meifj,maibj->eafb', A, A, conj=(1,)).reshape(A.size(1) ** 2, A.size(3) ** 2)
+    a = a / a.abs().max()
+    assert torch.norm(a.conj().t() - a) / a.abs().max() < 1.0e-8, "a is not symmetric"
+    Dv, U = truncated_eig_sym(a, 2)
+    assert torch.abs(Dv[0] - Dv[1]) > 1.0e-8, "Leading eigenvector of T not unique"
+    T = torch.zeros((env.chi, env.chi, A.size(3) ** 2), dtype=env.dtype, device=env.device)
+    T[0, 0, :] = U[:, 0]
+    env.T[env.keyT] = T
+
+
+def init_from_ipeps_obc(state, env, verbosity=0):
+    """env_c4v.py:315-355: C and T from the site with its outward legs summed out in each layer separately (ket and conjugated bra:
+    `einsum('mijef,mklab->eafb', A, A.conj())`), divided by the max-abs, zero padded to chi."""
+    eng = get_engine()
+    A = state.site()
+    if A.dim() != 5:
+        raise RuntimeError("Incompatible ENV_C4V initialization")
+    d = A.size()
+    o = dict(dtype=env.dtype, device=env.device)
+    B = A.sum(dim=(1, 2)).contiguous()                                    # [m, e, f]
+    a = eng.einsum('mef,mab->eafb', B, B, conj=(1,)).reshape(d[3] ** 2, d[4] ** 2)
+    a = a / a.abs().max()
+    C = torch.zeros(env.chi, env.chi, **o)
+    m0, m1 = min(env.chi, d[3] ** 2), min(env.chi, d[4] ** 2)
+    C[:m0, :m1] = a[:m0, :m1]
+    env.C[env.keyC] = C
+    B = A.sum(dim=2).contiguous()                                         # [m, e, f, g]
+    t = eng.einsum('mefg,mabc->eafbgc', B, B, conj=(1,)).reshape(d[1] ** 2, d[3] ** 2, d[4] ** 2)
+    t = t / t.abs().max()
+    T = torch.zeros((env.chi, env.chi, d[4] ** 2), **o)
+    m0, m1 = min(env.chi, d[1] ** 2), min(env.chi, d[3] ** 2)
+    T[:m0, :m1, :] = t[:m0, :m1, :]
+    env.T[env.keyT] = T
 
 
 def init_from_ipeps_pbc(state, env, verbosity=0):

@@ -301,3 +301,27 @@ def test_complex_c4v_run_with_and_without_the_warm_restart_agree(eng):
     assert res[0][0] > 0 and res[1][0] == 0
     assert float((res[0][1] - res[1][1]).abs().max()) < 1e-11
     assert abs(res[0][2] - res[1][2]) < 1e-11
+
+
+@pytest.mark.parametrize("tag,chi", [("c4v_f64_D2_chi3", 3), ("c4v_f64_D3_chi12", 12), ("c4v_c128_D2_chi6", 6)])
+def test_c4v_env_init_prod_and_obc(eng, tag, chi):
+    """ctm_env_init_type PROD / CTMRG_OBC of the C4v environment (env_c4v.py:215-246, 315-355) against the reference's output."""
+    import config as cfg
+    from ipeps.ipeps_c4v import IPEPS_C4V
+    from ctm.one_site_c4v.env_c4v import ENV_C4V, init_env
+    g = golden("envinit")
+    st = IPEPS_C4V(dev(g[f"{tag}_site"]))
+    for kind in ("PROD", "CTMRG_OBC"):
+        env = ENV_C4V(chi, st)
+        old = cfg.ctm_args.ctm_env_init_type
+        cfg.ctm_args.ctm_env_init_type = kind
+        try:
+            init_env(st, env)
+        finally:
+            cfg.ctm_args.ctm_env_init_type = old
+        assert relerr(env.get_C(), g[f"{tag}_{kind}_C"]) < 1e-13
+        T, Tr = env.get_T().cpu().numpy(), g[f"{tag}_{kind}_T"]
+        if kind == "PROD":
+            ph = np.vdot(T[0, 0, :], Tr[0, 0, :]); ph = ph / abs(ph)
+            T = T * ph
+        assert float(np.abs(T - Tr).max()) < 1e-12

@@ -183,3 +183,17 @@ def test_oracle_backward_matches_reference_golden():
     for tag in ("f64", "c128"):
         a = {nm: g[f"eig_{tag}_{nm}"] for nm in ("D", "U", "gD", "gU", "dA")}
         assert np.abs(O.eigh_backward(a["D"], a["U"], a["gD"], a["gU"], 1e-12) - a["dA"]).max() < 1e-12 * np.abs(a["dA"]).max(), tag
+
+
+@pytest.mark.parametrize("tag,chi", [("c4v_f64_D2_chi3", 3), ("c4v_f64_D3_chi12", 12), ("c4v_c128_D2_chi6", 6)])
+def test_c4v_env_init_variants_oracle_vs_reference(tag, chi):
+    """init_prod / init_from_ipeps_obc of the one-site C4v environment (env_c4v.py:215-246, 315-355)."""
+    from oracle import c4v_oracle as O4
+    g = golden("envinit")
+    A = g[f"{tag}_site"]
+    C, T = O4.init_env_obc(A, chi)
+    assert abs(C - g[f"{tag}_CTMRG_OBC_C"]).max() < 1e-13 and abs(T - g[f"{tag}_CTMRG_OBC_T"]).max() < 1e-13
+    C, T = O4.init_env_prod(A, chi)
+    Tr = g[f"{tag}_PROD_T"]
+    ph = np.vdot(T[0, 0, :], Tr[0, 0, :]); ph = ph / abs(ph)                   # eigenvector phase
+    assert abs(C - g[f"{tag}_PROD_C"]).max() < 1e-13 and abs(T * ph - Tr).max() < 1e-12
