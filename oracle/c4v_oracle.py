@@ -97,6 +97,18 @@ def rdm2x1_sl(a, C, T, sym_pos_def=False):
     return sym_pos_def_rdm(r, sym_pos_def)
 
 
+def rdm3x1_sl(a, C, T, sym_pos_def=False):
+    """rdm3x1_sl (rdm_c4v.py:829-994): end sites of a 3x1 strip, middle site traced; s0 s1 ; s0' s1'."""
+    chi, D, p = C.shape[0], a.shape[1], a.shape[0]
+    c6 = c2x2_sl(a, C, T, open_=True).reshape(chi, D * D, chi, D * D, p, p)
+    C2x1 = np.tensordot(C, T, ([1], [0]))
+    left = np.tensordot(C2x1, c6, ([0, 2], [0, 1])).reshape(chi, chi, D, D, p, p)
+    Tv = T.reshape(chi, chi, D, D)
+    mid = seq_einsum('xpgG,xylLst,SULGR,Sulgr,PyuU->PrRpst', Tv, left, a.conj(), a, Tv)
+    r = np.einsum('PrRpst,PprRuv->stuv', mid, left, optimize=True).transpose(0, 2, 1, 3)
+    return sym_pos_def_rdm(r, sym_pos_def)
+
+
 def _nn_pieces(a, C, T):
     n = C.shape[0] * a.shape[1] ** 2
     C2x2 = c2x2_sl(a, C, T, open_=True)

@@ -392,6 +392,26 @@ def generic_ad_case(name, base, complex_=False, moves=((0, -1), (-1, 0), (0, 1),
     print(f"  {name} ok  E={float(torch.real(e)):.12f} |grad|={gn:.6e}")
 
 
+def c4v_j3_case():
+    """rdm3x1_sl and the j3 term of energy_1x1_lowmem (rdm_c4v.py:829-994, models/j1j2.py:672-676) on the warm C4v goldens."""
+    out = {}
+    for base, cplx in (("c4v_D2_chi8", False), ("c4v_D3_chi18", False), ("c4v_D2_chi8_c128", True)):
+        set_dtype(cplx)
+        g = np.load(os.path.join(GOLD, base + ".npz"))
+        A = g["site"]
+        st = IPEPS_C4V(torch.from_numpy(A.copy()))
+        env = ENV_C4V(g["warm_C"].shape[0], st)
+        env.C[env.keyC] = torch.from_numpy(g["warm_C"].copy()); env.T[env.keyT] = torch.from_numpy(g["warm_T"].copy())
+        r = t2n(rdm_c4v.rdm3x1_sl(st, env, sym_pos_def=True))
+        close(O4.rdm3x1_sl(A, g["warm_C"], g["warm_T"], sym_pos_def=True), r, 1e-10, f"rdm3x1_sl {base}")
+        close(t2n(rdm_c4v.rdm3x1(st, env, sym_pos_def=True)), r, 1e-10, f"rdm3x1 (dl) {base}")
+        model = j1j2.J1J2_C4V_BIPARTITE(j1=1.0, j2=0.3, j3=0.2)
+        e = float(torch.real(model.energy_1x1_lowmem(st, env)))
+        out[f"{base}_rdm3x1"] = r; out[f"{base}_e_j3"] = np.array(e)
+    np.savez_compressed(os.path.join(GOLD, "c4v_j3.npz"), **out)
+    print("  c4v_j3 ok")
+
+
 def envinit_case():
     """init_prod / init_from_ipeps_obc (ctm/generic/env.py:274-365, 538-716) on random 2x2 states, chi below and above D^2."""
     out = {}
@@ -683,7 +703,7 @@ def input_files_case():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["decomp", "generic", "c4v", "c4v_ad", "generic_ad", "envinit", "rvb", "files", "variants", "aklt", "inputs", "backward"]
+    which = sys.argv[1:] or ["decomp", "generic", "c4v", "c4v_ad", "generic_ad", "c4v_j3", "envinit", "rvb", "files", "variants", "aklt", "inputs", "backward"]
     if "backward" in which:
         backward_case()
     if "inputs" in which:
@@ -712,6 +732,8 @@ if __name__ == "__main__":
         generic_ad_case("generic_ad_D2_chi8_f64", "generic_D2_chi8_f64")
         generic_ad_case("generic_ad_D2_chi8_c128", "generic_D2_chi8_c128", complex_=True)
         generic_ad_case("generic_ad_D2_chi8_f64_4x2", "generic_D2_chi8_f64", moves=((0, -1), (1, 0)), projector_method='4X2')
+    if "c4v_j3" in which:
+        c4v_j3_case()
     if "envinit" in which:
         envinit_case()
     if "rvb" in which:

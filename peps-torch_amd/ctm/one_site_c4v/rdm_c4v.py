@@ -53,6 +53,26 @@ def _rdm_ad(which, a, C, T):
     return r.permute(0, 2, 6, 4, 1, 3, 7, 5)
 
 
+def rdm3x1_sl(state, env, sym_pos_def=False, force_cpu=False, verbosity=0):
+    """Reduced density matrix of the two END sites of a horizontal 3x1 strip, s0 s1 ; s0' s1' (the middle site is traced): the
+    next-to-next-nearest-neighbour pair of the j3 term (reference rdm_c4v.py:829-994).  Left half = lower-left corner + enlarged
+    upper-left corner with the physical legs of the first site open (as in rdm2x1_sl), one closed column T - a a* - T, and the left
+    half again for the right end (C4v).  Three native contractions; differentiable like the other RDMs."""
+    a, C, T = _parts(state, env)
+    chi, D, p = C.shape[0], a.shape[1], a.shape[0]
+    c6 = _open_c2x2_ad(a, C, T).reshape(chi, D * D, chi, D * D, p, p)
+    C2x1 = einsum('xy,yba->xba', C, T)                                  # [C0, T1, T2]
+    # [b, y, l, L, z]: the two physical legs of the end site fused (z = (s t)) so that no intermediate exceeds the engine's rank limit
+    left = einsum('xba,xaydst->bydst', C2x1, c6).reshape(chi, chi, D, D, p * p)
+    Tv = T.reshape(chi, chi, D, D)
+    mid = einsum('xpgG,xylLz,SULGR,Sulgr,PyuU->PrRpz', Tv, left, a, a, Tv, conj=(2,))
+    r = einsum('PrRpz,PprRw->zw', mid, left).reshape(p, p, p, p)
+    return _sym_pos_def_rdm(r.permute(0, 2, 1, 3).contiguous(), sym_pos_def=sym_pos_def, verbosity=verbosity, who="rdm3x1_sl")
+
+
+rdm3x1 = rdm3x1_sl
+
+
 def _rdm(which, who, state, env, sym_pos_def, verbosity):
     a, C, T = _parts(state, env)
     raw = _rdm_ad(which, a, C, T) if needs_grad(a, C, T) else get_engine().rdm_c4v(which, a, C, T)

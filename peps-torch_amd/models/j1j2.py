@@ -202,6 +202,9 @@ class J1J2_C4V_BIPARTITE(J1J2):
         if abs(self.j2) > 0:
             nnn = rdm_c4v.rdm2x2_NNN_lowmem_sl(state, env_c4v, sym_pos_def=True).cpu()
             e = e + 2.0 * self.j2 * torch.einsum('ijkl,ijkl', nnn, self.SS.to(dt))
+        if abs(self.j3) > 0:                                               # models/j1j2.py:672-676
+            r31 = rdm_c4v.rdm3x1_sl(state, env_c4v, sym_pos_def=True).cpu()
+            e = e + 2.0 * self.j3 * torch.einsum('ijab,ijab', r31, self.SS.to(dt))
         return _cast_to_real(e)
 
     def eval_obs(self, state, env_c4v, force_cpu=False):

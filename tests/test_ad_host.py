@@ -155,7 +155,7 @@ def test_generic_gradient_with_checkpointed_moves_is_the_same(fake):
         assert float((g0[k] - g1[k]).abs().max()) < 1e-13
 
 
-@pytest.mark.parametrize("which", ["energy_1x1", "SS2x1"])
+@pytest.mark.parametrize("which", ["energy_1x1", "SS2x1", "lowmem_j3"])
 def test_c4v_other_rdm_graphs_against_finite_differences(fake, which):
     """rdm2x2 (energy_1x1) and rdm2x1 (nearest-neighbour S.S of eval_obs) of the C4v network as differentiable graphs: directional
     derivative along a random C4v-symmetric direction vs central differences (environment fixed)."""
@@ -174,6 +174,8 @@ def test_c4v_other_rdm_graphs_against_finite_differences(fake, which):
         env.C[env.keyC] = C0; env.T[env.keyT] = T0
         if which == "energy_1x1":
             return model.energy_1x1(st, env)
+        if which == "lowmem_j3":                                    # NN + NNN + the 3x1 pair of the j3 term
+            return j1j2.J1J2_C4V_BIPARTITE(j1=1.0, j2=0.4, j3=0.25).energy_1x1_lowmem(st, env)
         r2 = rdm_c4v.rdm2x1_sl(st, env, sym_pos_def=True)
         return torch.einsum('ijab,ijab', r2, model.SS_rot.to(r2.dtype))
 
@@ -227,3 +229,17 @@ def test_generic_small_rdm_graphs_values_and_finite_differences(fake, base):
         fd = (float(val({k: (s0[k] + h * ds[k]).requires_grad_(True) for k in s0}).detach())
               - float(val({k: (s0[k] - h * ds[k]).requires_grad_(True) for k in s0}).detach())) / (2 * h)
         assert abs(lin - fd) < 1e-6 * max(1.0, abs(fd)), (key, lin, fd)
+
+
+@pytest.mark.parametrize("base", ["c4v_D2_chi8", "c4v_D2_chi8_c128"])
+def test_c4v_rdm3x1_host_layer(fake, base):
+    """rdm3x1_sl (the j3 pair of the C4v model) is three native contractions in the host layer: values against the reference."""
+    from ipeps.ipeps_c4v import IPEPS_C4V
+    from ctm.one_site_c4v.env_c4v import ENV_C4V
+    from ctm.one_site_c4v import rdm_c4v
+    g, j = golden(base), golden("c4v_j3")
+    st = IPEPS_C4V(torch.from_numpy(g["site"].copy()))
+    env = ENV_C4V(g["warm_C"].shape[0], st)
+    env.C[env.keyC] = torch.from_numpy(g["warm_C"].copy()); env.T[env.keyT] = torch.from_numpy(g["warm_T"].copy())
+    r = rdm_c4v.rdm3x1_sl(st, env, sym_pos_def=True)
+    assert float(np.abs(r.numpy() - j[f"{base}_rdm3x1"]).max()) < 1e-10

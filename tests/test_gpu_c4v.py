@@ -325,3 +325,15 @@ def test_c4v_env_init_prod_and_obc(eng, tag, chi):
             ph = np.vdot(T[0, 0, :], Tr[0, 0, :]); ph = ph / abs(ph)
             T = T * ph
         assert float(np.abs(T - Tr).max()) < 1e-12
+
+
+@pytest.mark.parametrize("base", ["c4v_D2_chi8", "c4v_D3_chi18", "c4v_D2_chi8_c128"])
+def test_c4v_rdm3x1_and_the_j3_term(eng, base):
+    """rdm3x1_sl and energy_1x1_lowmem with j3 != 0 (reference rdm_c4v.py:829-994, models/j1j2.py:672-676)."""
+    from ctm.one_site_c4v import rdm_c4v
+    from models import j1j2
+    g, j = golden(base), golden("c4v_j3")
+    st, env = _state_env(g)
+    assert relerr(rdm_c4v.rdm3x1_sl(st, env, sym_pos_def=True), j[f"{base}_rdm3x1"]) < 1e-10
+    e = float(j1j2.J1J2_C4V_BIPARTITE(j1=1.0, j2=0.3, j3=0.2).energy_1x1_lowmem(st, env))
+    assert abs(e - float(j[f"{base}_e_j3"])) < 1e-11

@@ -197,3 +197,10 @@ def test_c4v_env_init_variants_oracle_vs_reference(tag, chi):
     Tr = g[f"{tag}_PROD_T"]
     ph = np.vdot(T[0, 0, :], Tr[0, 0, :]); ph = ph / abs(ph)                   # eigenvector phase
     assert abs(C - g[f"{tag}_PROD_C"]).max() < 1e-13 and abs(T * ph - Tr).max() < 1e-12
+
+
+@pytest.mark.parametrize("base", ["c4v_D2_chi8", "c4v_D3_chi18", "c4v_D2_chi8_c128"])
+def test_c4v_rdm3x1_oracle_vs_reference(base):
+    g, j = golden(base), golden("c4v_j3")
+    r = O4.rdm3x1_sl(g["site"], g["warm_C"], g["warm_T"], sym_pos_def=True)
+    assert abs(r - j[f"{base}_rdm3x1"]).max() < 1e-10
