@@ -408,6 +408,7 @@ def c4v_j3_case():
         model = j1j2.J1J2_C4V_BIPARTITE(j1=1.0, j2=0.3, j3=0.2)
         e = float(torch.real(model.energy_1x1_lowmem(st, env)))
         out[f"{base}_rdm3x1"] = r; out[f"{base}_e_j3"] = np.array(e)
+        out[f"{base}_e1x1_j3"] = np.array(float(torch.real(model.energy_1x1(st, env))))
     np.savez_compressed(os.path.join(GOLD, "c4v_j3.npz"), **out)
     print("  c4v_j3 ok")
 

@@ -190,7 +190,13 @@ class J1J2():
 class J1J2_C4V_BIPARTITE(J1J2):
     def energy_1x1(self, state, env_c4v, force_cpu=False, **kwargs):
         r = rdm_c4v.rdm2x2(state, env_c4v, sym_pos_def=True).cpu()
-        return _cast_to_real(torch.einsum('ijklabcd,ijklabcd', r, self.hp_rot.to(r.dtype)))
+        e = torch.einsum('ijklabcd,ijklabcd', r, self.hp_rot.to(r.dtype))
+        if abs(self.lmbd) > 0:                                             # models/j1j2.py:630-631
+            e = e + torch.einsum('ijklabcd,ijklabcd', r, self.hp_chiral_rot.to(r.dtype))
+        if abs(self.j3) > 0:                                               # :632-636
+            r31 = rdm_c4v.rdm3x1(state, env_c4v, sym_pos_def=True).cpu()
+            e = e + 2.0 * self.j3 * torch.einsum('ijab,ijab', r31, self.SS.to(r.dtype))
+        return _cast_to_real(e)
 
     def energy_1x1_lowmem(self, state, env_c4v, force_cpu=False):
         nn = rdm_c4v.rdm2x2_NN_lowmem_sl(state, env_c4v, sym_pos_def=True).cpu()

@@ -335,5 +335,6 @@ def test_c4v_rdm3x1_and_the_j3_term(eng, base):
     g, j = golden(base), golden("c4v_j3")
     st, env = _state_env(g)
     assert relerr(rdm_c4v.rdm3x1_sl(st, env, sym_pos_def=True), j[f"{base}_rdm3x1"]) < 1e-10
-    e = float(j1j2.J1J2_C4V_BIPARTITE(j1=1.0, j2=0.3, j3=0.2).energy_1x1_lowmem(st, env))
-    assert abs(e - float(j[f"{base}_e_j3"])) < 1e-11
+    model = j1j2.J1J2_C4V_BIPARTITE(j1=1.0, j2=0.3, j3=0.2)
+    assert abs(float(model.energy_1x1_lowmem(st, env)) - float(j[f"{base}_e_j3"])) < 1e-11
+    assert abs(float(model.energy_1x1(st, env)) - float(j[f"{base}_e1x1_j3"])) < 1e-11
