@@ -409,6 +409,8 @@ def c4v_j3_case():
         e = float(torch.real(model.energy_1x1_lowmem(st, env)))
         out[f"{base}_rdm3x1"] = r; out[f"{base}_e_j3"] = np.array(e)
         out[f"{base}_e1x1_j3"] = np.array(float(torch.real(model.energy_1x1(st, env))))
+        vals, labels = model.eval_obs(st, env)
+        out[f"{base}_obs"] = np.array([complex(v) for v in vals]); out[f"{base}_obs_labels"] = np.array(",".join(labels))
     np.savez_compressed(os.path.join(GOLD, "c4v_j3.npz"), **out)
     print("  c4v_j3 ok")
 

@@ -214,11 +214,28 @@ class J1J2_C4V_BIPARTITE(J1J2):
         return _cast_to_real(e)
 
     def eval_obs(self, state, env_c4v, force_cpu=False):
-        """<m>, <S^z>, <S^+>, <S^-> and nearest-neighbour S.S from rho_2x1 (models/j1j2.py:710-770)."""
-        r2 = rdm_c4v.rdm2x1_sl(state, env_c4v, sym_pos_def=True).cpu()
-        r1 = torch.einsum('ijaj->ia', r2)
-        obs = {l: torch.trace(r1 @ op.to(r1.dtype)) for l, op in self.obs_ops.items()}
-        obs["m"] = sqrt(abs(obs["sz"] ** 2 + obs["sp"] * obs["sm"]))
-        obs["SS2x1"] = _cast_to_real(torch.einsum('ijab,ijab', r2, self.SS_rot.to(r2.dtype)))
+        """<m>, <S^z>, <S^+>, <S^->, nearest-neighbour S.S from rho_2x1 and -- as the couplings are switched on -- S.S of the
+        diagonal pair (j2), of the 3x1 pair (j3) and the chiral term (lambda) (models/j1j2.py:710-770, same labels and order)."""
+        obs = dict()
+        with torch.no_grad():
+            if abs(self.j3) > 0:
+                r31 = rdm_c4v.rdm3x1(state, env_c4v).cpu()
+                obs["SS3x1"] = torch.einsum('ijab,ijab', r31, self.SS.to(r31.dtype))
+            if abs(self.lmbd) > 0:
+                r22 = rdm_c4v.rdm2x2(state, env_c4v).cpu()
+                obs["ChiralT"] = torch.einsum('ijklabcd,ijklabcd', r22, self.chiral_term_rot.to(r22.dtype))
+            if abs(self.j2) > 0:
+                rd = rdm_c4v.rdm2x2_NNN_lowmem_sl(state, env_c4v).cpu()
+                obs["SS_nnn"] = torch.einsum('ijab,ijab', rd, self.SS.to(rd.dtype))
+            r2 = rdm_c4v.rdm2x1_sl(state, env_c4v).cpu()
+            obs["SS2x1"] = _cast_to_real(torch.einsum('ijab,ijab', r2, self.SS_rot.to(r2.dtype)))
+            r1 = torch.einsum('ijaj->ia', r2)
+            r1 = r1 / torch.trace(r1)
+            for l, op in self.obs_ops.items():
+                obs[l] = torch.trace(r1 @ op.to(r1.dtype))
+            obs["m"] = sqrt(abs(obs["sz"] ** 2 + obs["sp"] * obs["sm"]))
         labels = ["m"] + list(self.obs_ops.keys()) + ["SS2x1"]
+        if abs(self.j2) > 0: labels += ["SS_nnn"]
+        if abs(self.j3) > 0: labels += ["SS3x1"]
+        if abs(self.lmbd) > 0: labels += ["ChiralT"]
         return [obs[l] for l in labels], labels

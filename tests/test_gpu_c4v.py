@@ -338,3 +338,6 @@ def test_c4v_rdm3x1_and_the_j3_term(eng, base):
     model = j1j2.J1J2_C4V_BIPARTITE(j1=1.0, j2=0.3, j3=0.2)
     assert abs(float(model.energy_1x1_lowmem(st, env)) - float(j[f"{base}_e_j3"])) < 1e-11
     assert abs(float(model.energy_1x1(st, env)) - float(j[f"{base}_e1x1_j3"])) < 1e-11
+    vals, labels = model.eval_obs(st, env)                                 # same labels, same order, same numbers as the reference
+    assert ",".join(labels) == str(j[f"{base}_obs_labels"])
+    assert float(np.abs(np.array([complex(v) for v in vals]) - j[f"{base}_obs"]).max()) < 1e-10
