@@ -171,13 +171,14 @@ class J1J2():
         for coord in state.sites.keys():
             r1 = rdm.rdm1x1(coord, state, env).cpu()
             for label, op in self.obs_ops.items():
-                obs[f"{label}{coord}"] = torch.trace(r1 @ op)
+                obs[f"{label}{coord}"] = torch.trace(r1 @ op.to(r1.dtype))
             obs[f"m{coord}"] = sqrt(abs(obs[f"sz{coord}"] ** 2 + obs[f"sp{coord}"] * obs[f"sm{coord}"]))
             obs["avg_m"] += obs[f"m{coord}"]
         obs["avg_m"] = obs["avg_m"] / len(state.sites.keys())
         for coord in state.sites.keys():
-            obs[f"SS2x1{coord}"] = _cast_to_real(torch.einsum('ijab,ijab', rdm.rdm2x1(coord, state, env).cpu(), ss))
-            obs[f"SS1x2{coord}"] = _cast_to_real(torch.einsum('ijab,ijab', rdm.rdm1x2(coord, state, env).cpu(), ss))
+            r21, r12 = rdm.rdm2x1(coord, state, env).cpu(), rdm.rdm1x2(coord, state, env).cpu()
+            obs[f"SS2x1{coord}"] = _cast_to_real(torch.einsum('ijab,ijab', r21, ss.to(r21.dtype)))
+            obs[f"SS1x2{coord}"] = _cast_to_real(torch.einsum('ijab,ijab', r12, ss.to(r12.dtype)))
         labels = ["avg_m"] + [f"m{c}" for c in state.sites.keys()] \
             + [f"{lc[1]}{lc[0]}" for lc in itertools.product(state.sites.keys(), self.obs_ops.keys())] \
             + [f"SS2x1{c}" for c in state.sites.keys()] + [f"SS1x2{c}" for c in state.sites.keys()]
