@@ -97,6 +97,48 @@ def rdm2x1_sl(a, C, T, sym_pos_def=False):
     return sym_pos_def_rdm(r, sym_pos_def)
 
 
+def rdm1x1(a, C, T, sym_pos_def=False):
+    """rdm1x1 (rdm_c4v.py:168-262)."""
+    chi, D, p = C.shape[0], a.shape[1], a.shape[0]
+    CTC = np.tensordot(np.tensordot(C, T, ([0], [0])), C, ([1], [0]))
+    r = np.tensordot(CTC, T, ([2], [0]))
+    aa = np.einsum('mefgh,nabcd->eafbgchdmn', a, a.conj()).reshape(D * D, D * D, D * D, D * D, p, p)
+    r = np.tensordot(r, aa, ([1, 3], [1, 2]))
+    r = np.tensordot(T, r, ([1, 2], [0, 2]))
+    r = np.tensordot(r, CTC, ([0, 1, 2], [2, 0, 1]))
+    return sym_pos_def_rdm(r, sym_pos_def)
+
+
+def apply_TM_1sO(a, C, T, edge, op=None):
+    """corrf_c4v.apply_TM_1sO (corrf_c4v.py:178-271)."""
+    D, p = a.shape[1], a.shape[0]
+    X = np.eye(p, dtype=a.dtype) if op is None else op
+    A = np.einsum('mefgh,mn,nabcd->eafbgchd', a, X, a.conj()).reshape(D * D, D * D, D * D, D * D)
+    E = np.tensordot(edge, T, ([0], [1]))
+    E = np.tensordot(E, A, ([0, 3], [1, 0]))
+    return np.tensordot(E, T, ([0, 2], [0, 2]))
+
+
+def corrf_1sO1sO(a, C, T, op1, get_op2, dist):
+    """corrf_c4v.corrf_1sO1sO (corrf_c4v.py:593-664) with the C - T - C boundaries."""
+    def edge_scalar(v):
+        S = np.tensordot(v, C, ([0], [0]))
+        S = np.tensordot(S, T, ([0, 2], [2, 1]))
+        return np.tensordot(S, C, ([0, 1], [1, 0]))
+    E0 = np.tensordot(np.tensordot(C, T, ([0], [0])), C, ([1], [0]))
+    E1 = apply_TM_1sO(a, C, T, E0, op1)
+    E0 = apply_TM_1sO(a, C, T, E0)
+    out = np.empty(dist + 1, dtype=a.dtype)
+    for r in range(dist + 1):
+        E12 = apply_TM_1sO(a, C, T, E1, get_op2(r))
+        E0 = apply_TM_1sO(a, C, T, E0)
+        E1 = apply_TM_1sO(a, C, T, E1)
+        out[r] = edge_scalar(E12) / edge_scalar(E0)
+        m = np.abs(E0).max()
+        E0, E1 = E0 / m, E1 / m
+    return out
+
+
 def rdm3x1_sl(a, C, T, sym_pos_def=False):
     """rdm3x1_sl (rdm_c4v.py:829-994): end sites of a 3x1 strip, middle site traced; s0 s1 ; s0' s1'."""
     chi, D, p = C.shape[0], a.shape[1], a.shape[0]

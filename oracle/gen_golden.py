@@ -411,6 +411,29 @@ def c4v_j3_case():
         out[f"{base}_e1x1_j3"] = np.array(float(torch.real(model.energy_1x1(st, env))))
         vals, labels = model.eval_obs(st, env)
         out[f"{base}_obs"] = np.array([complex(v) for v in vals]); out[f"{base}_obs_labels"] = np.array(",".join(labels))
+    # what the reference script prints after FINAL: rho_1x1, spin-spin correlators (plain and canonical), transfer-operator spectrum
+    from ctm.one_site_c4v import corrf_c4v as ref_corrf4, transferops_c4v as ref_top4
+    for base, cplx in (("c4v_D2_chi8", False), ("c4v_D3_chi18", False), ("c4v_D2_chi8_c128", True)):
+        set_dtype(cplx)
+        g = np.load(os.path.join(GOLD, base + ".npz"))
+        A = g["site"]
+        st = IPEPS_C4V(torch.from_numpy(A.copy()))
+        env = ENV_C4V(g["warm_C"].shape[0], st)
+        env.C[env.keyC] = torch.from_numpy(g["warm_C"].copy()); env.T[env.keyT] = torch.from_numpy(g["warm_T"].copy())
+        r11 = t2n(rdm_c4v.rdm1x1(st, env))
+        close(O4.rdm1x1(A, g["warm_C"], g["warm_T"]), r11, 1e-12, f"rdm1x1 {base}")
+        out[f"{base}_rdm1x1"] = r11
+        model = j1j2.J1J2_C4V_BIPARTITE(j1=1.0, j2=0.3)
+        for canon in (False, True):
+            c = model.eval_corrf_SS(st, env, 4, canonical=canon)
+            for k, v in c.items():
+                out[f"{base}_corr{'_canon' if canon else ''}_{k}"] = t2n(v)
+        sz = t2n(model.obs_ops["sz"]).astype(A.dtype)
+        oc = O4.corrf_1sO1sO(A, g["warm_C"], g["warm_T"], sz, lambda r: sz, 3)
+        rc = t2n(ref_corrf4.corrf_1sO1sO(st, env, model.obs_ops["sz"].to(st.site().dtype), lambda r: model.obs_ops["sz"].to(st.site().dtype), 3))
+        close(oc, rc, 1e-11, f"corrf_1sO1sO {base}")
+        out[f"{base}_corr_szsz_plain"] = rc
+        out[f"{base}_top"] = t2n(ref_top4.get_Top_spec_c4v(3, st, env))
     np.savez_compressed(os.path.join(GOLD, "c4v_j3.npz"), **out)
     print("  c4v_j3 ok")
 

@@ -53,6 +53,20 @@ def _rdm_ad(which, a, C, T):
     return r.permute(0, 2, 6, 4, 1, 3, 7, 5)
 
 
+def rdm1x1_sl(state, env, sym_pos_def=False, verbosity=0):
+    """One-site reduced density matrix s ; s' (reference rdm_c4v.py:168-262): C - T - C edge, T, the site with its physical legs
+    open, T, and the edge again; one native contraction."""
+    a, C, T = _parts(state, env)
+    chi, D = C.shape[0], a.shape[1]
+    E = einsum('xa,xbs,bc->asc', C, T, C).reshape(chi, D, D, chi)
+    Tv = T.reshape(chi, chi, D, D)
+    r = einsum('alLc,cydD,muldr,nULDR,pauU,yrRp->mn', E, Tv, a, a, Tv, E, conj=(3,))
+    return _sym_pos_def_rdm(r, sym_pos_def=sym_pos_def, verbosity=verbosity, who="rdm1x1")
+
+
+rdm1x1 = rdm1x1_sl
+
+
 def rdm3x1_sl(state, env, sym_pos_def=False, force_cpu=False, verbosity=0):
     """Reduced density matrix of the two END sites of a horizontal 3x1 strip, s0 s1 ; s0' s1' (the middle site is traced): the
     next-to-next-nearest-neighbour pair of the j3 term (reference rdm_c4v.py:829-994).  Left half = lower-left corner + enlarged

@@ -20,6 +20,9 @@ parser.add_argument("--j2", type=float, default=0.)
 parser.add_argument("--hz_stag", type=float, default=0.)
 parser.add_argument("--delta_zz", type=float, default=1.)
 parser.add_argument("--top_freq", type=int, default=-1)
+parser.add_argument("--corrf_canonical", action='store_true', help="align spin operators with the vector of spontaneous magnetization")
+parser.add_argument("--corrf_r", type=int, default=1, help="maximal correlation function distance")
+parser.add_argument("--top_n", type=int, default=2, help="number of leading eigenvalues of the transfer operator to compute")
 
 
 def main(args=None):
@@ -71,7 +74,28 @@ def main(args=None):
     print(", ".join([f"{len(history['log'])}", f"{e}"] + [f"{v}" for v in obs_values]))
     print(f"TIMINGS ctm: {t_ctm} conv_check: {t_obs}")
     print("FINAL " + ", ".join([f"{e}"] + [f"{v}" for v in obs_values]))
+
+    # additional observables, as the reference script prints them after FINAL (examples/j1j2/ctmrg_j1j2_c4v.py:153-183); the
+    # dimer-dimer correlators (two-site operators in the transfer matrix) are not built
+    corrSS = model.eval_corrf_SS(state, env, args.corrf_r, canonical=args.corrf_canonical)
+    print("\n\nSS r " + " ".join(corrSS.keys()) + f" canonical {args.corrf_canonical}")
+    for i in range(args.corrf_r):
+        print(f"{i} " + " ".join([f"{corrSS[label][i]}" for label in corrSS.keys()]))
+    print("\n\nspectrum(C)")
+    s = get_engine_svdvals(env.C[env.keyC])
+    for i in range(args.chi):
+        print(f"{i} {s[i]}")
+    print("\n\nspectrum(T)")
+    from ctm.one_site_c4v import transferops_c4v
+    l = transferops_c4v.get_Top_spec_c4v(args.top_n, state, env)
+    for i in range(l.size()[0]):
+        print(f"{i} {l[i, 0]} {l[i, 1]}")
     return float(e), obs_values
+
+
+def get_engine_svdvals(C):
+    from backend import get_engine
+    return get_engine().svdvals(C)
 
 
 if __name__ == '__main__':

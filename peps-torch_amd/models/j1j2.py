@@ -214,6 +214,35 @@ class J1J2_C4V_BIPARTITE(J1J2):
             e = e + 2.0 * self.j3 * torch.einsum('ijab,ijab', r31, self.SS.to(dt))
         return _cast_to_real(e)
 
+    def eval_corrf_SS(self, state, env_c4v, dist, canonical=False, rl_0=None):
+        """<S(r).S(0)> and its zz / xx / yy parts for r = 0 .. dist along a row (models/j1j2.py:803-865): transfer-matrix correlators
+        with the sublattice rotation applied to the operator on every second site; `canonical` first rotates the spin operators so
+        that z points along the spontaneous magnetisation read off rho_1x1."""
+        from ctm.one_site_c4v import corrf_c4v
+        dt = state.site().dtype
+        Sop = torch.zeros((3, self.phys_dim, self.phys_dim), dtype=dt, device="cpu")
+        Sop[0] = self.obs_ops["sz"]
+        Sop[1] = 0.5 * (self.obs_ops["sp"] + self.obs_ops["sm"])
+        Sop[2] = -0.5 * (self.obs_ops["sp"] - self.obs_ops["sm"])
+        if canonical:
+            r1 = rdm_c4v.rdm1x1(state, env_c4v).cpu()
+            zpm = [torch.trace(r1 @ self.obs_ops[l].to(r1.dtype)) for l in ("sz", "sp", "sm")]
+            v = torch.stack([zpm[0], 0.5 * (zpm[1] + zpm[2]), 0.5 * (zpm[1] - zpm[2])]).to(dt)
+            v = v / torch.norm(v)
+            R = torch.zeros(3, 3, dtype=dt)
+            R[0, 0], R[0, 1], R[1, 0], R[1, 1], R[2, 2] = v[0], -v[1], v[1], v[0], 1.0
+            Sop = torch.einsum('ab,bij->aij', R.t(), Sop)
+        rot = su2.get_rot_op(self.phys_dim, dtype=dt, device="cpu")
+
+        def bilat(op):
+            op_rot = torch.einsum('ki,kl,lj->ij', rot, op, rot)
+            return lambda r: op_rot if r % 2 == 0 else op
+
+        zz = corrf_c4v.corrf_1sO1sO(state, env_c4v, Sop[0], bilat(Sop[0]), dist, rl_0=rl_0)
+        xx = corrf_c4v.corrf_1sO1sO(state, env_c4v, Sop[1], bilat(Sop[1]), dist, rl_0=rl_0)
+        nyy = corrf_c4v.corrf_1sO1sO(state, env_c4v, Sop[2], bilat(Sop[2]), dist, rl_0=rl_0)
+        return dict({"ss": zz + xx - nyy, "szsz": zz, "sxsx": xx, "sysy": -nyy})
+
     def eval_obs(self, state, env_c4v, force_cpu=False):
         """<m>, <S^z>, <S^+>, <S^->, nearest-neighbour S.S from rho_2x1 and -- as the couplings are switched on -- S.S of the
         diagonal pair (j2), of the 3x1 pair (j3) and the chiral term (lambda) (models/j1j2.py:710-770, same labels and order)."""

@@ -243,3 +243,22 @@ def test_c4v_rdm3x1_host_layer(fake, base):
     env.C[env.keyC] = torch.from_numpy(g["warm_C"].copy()); env.T[env.keyT] = torch.from_numpy(g["warm_T"].copy())
     r = rdm_c4v.rdm3x1_sl(st, env, sym_pos_def=True)
     assert float(np.abs(r.numpy() - j[f"{base}_rdm3x1"]).max()) < 1e-10
+
+
+@pytest.mark.parametrize("base", ["c4v_D2_chi8", "c4v_D2_chi8_c128"])
+def test_c4v_correlators_host_layer(fake, base):
+    """rdm1x1 and eval_corrf_SS (plain and canonical) of the C4v model: host graph of native contractions vs the reference's numbers."""
+    from ipeps.ipeps_c4v import IPEPS_C4V
+    from ctm.one_site_c4v.env_c4v import ENV_C4V
+    from ctm.one_site_c4v import rdm_c4v
+    from models import j1j2
+    g, j = golden(base), golden("c4v_j3")
+    st = IPEPS_C4V(torch.from_numpy(g["site"].copy()))
+    env = ENV_C4V(g["warm_C"].shape[0], st)
+    env.C[env.keyC] = torch.from_numpy(g["warm_C"].copy()); env.T[env.keyT] = torch.from_numpy(g["warm_T"].copy())
+    assert float(np.abs(rdm_c4v.rdm1x1(st, env).numpy() - j[f"{base}_rdm1x1"]).max()) < 1e-12
+    model = j1j2.J1J2_C4V_BIPARTITE(j1=1.0, j2=0.3)
+    for canon in (False, True):
+        c = model.eval_corrf_SS(st, env, 4, canonical=canon)
+        for k, v in c.items():
+            assert float(np.abs(v.numpy() - j[f"{base}_corr{'_canon' if canon else ''}_{k}"]).max()) < 1e-10, (canon, k)

@@ -341,3 +341,22 @@ def test_c4v_rdm3x1_and_the_j3_term(eng, base):
     vals, labels = model.eval_obs(st, env)                                 # same labels, same order, same numbers as the reference
     assert ",".join(labels) == str(j[f"{base}_obs_labels"])
     assert float(np.abs(np.array([complex(v) for v in vals]) - j[f"{base}_obs"]).max()) < 1e-10
+
+
+@pytest.mark.parametrize("base", ["c4v_D2_chi8", "c4v_D3_chi18", "c4v_D2_chi8_c128"])
+def test_c4v_correlators_and_transfer_spectrum(eng, base):
+    """What the reference script prints after FINAL (examples/j1j2/ctmrg_j1j2_c4v.py:153-183): rho_1x1, <S(r).S(0)> plain and
+    canonical (corrf_c4v.corrf_1sO1sO), leading eigenvalues of the width-1 transfer operator (transferops_c4v.get_Top_spec_c4v)."""
+    from ctm.one_site_c4v import rdm_c4v, transferops_c4v
+    from models import j1j2
+    g, j = golden(base), golden("c4v_j3")
+    st, env = _state_env(g)
+    assert relerr(rdm_c4v.rdm1x1(st, env), j[f"{base}_rdm1x1"]) < 1e-11
+    model = j1j2.J1J2_C4V_BIPARTITE(j1=1.0, j2=0.3)
+    for canon in (False, True):
+        c = model.eval_corrf_SS(st, env, 4, canonical=canon)
+        for k, v in c.items():
+            assert float(np.abs(v.cpu().numpy() - j[f"{base}_corr{'_canon' if canon else ''}_{k}"]).max()) < 1e-10, (canon, k)
+    top = transferops_c4v.get_Top_spec_c4v(3, st, env).cpu().numpy()
+    ref = j[f"{base}_top"]
+    assert float(np.abs(np.hypot(top[:, 0], top[:, 1]) - np.hypot(ref[:, 0], ref[:, 1])).max()) < 1e-8     # moduli (conjugate pairs may swap)

@@ -204,3 +204,12 @@ def test_c4v_rdm3x1_oracle_vs_reference(base):
     g, j = golden(base), golden("c4v_j3")
     r = O4.rdm3x1_sl(g["site"], g["warm_C"], g["warm_T"], sym_pos_def=True)
     assert abs(r - j[f"{base}_rdm3x1"]).max() < 1e-10
+
+
+@pytest.mark.parametrize("base", ["c4v_D2_chi8", "c4v_D3_chi18", "c4v_D2_chi8_c128"])
+def test_c4v_rdm1x1_and_row_correlator_oracle_vs_reference(base):
+    g, j = golden(base), golden("c4v_j3")
+    A, C, T = g["site"], g["warm_C"], g["warm_T"]
+    assert abs(O4.rdm1x1(A, C, T) - j[f"{base}_rdm1x1"]).max() < 1e-12
+    sz = np.diag([0.5, -0.5]).astype(A.dtype)
+    assert abs(O4.corrf_1sO1sO(A, C, T, sz, lambda r: sz, 3) - j[f"{base}_corr_szsz_plain"]).max() < 1e-11
