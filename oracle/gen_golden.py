@@ -434,6 +434,7 @@ def c4v_j3_case():
         close(oc, rc, 1e-11, f"corrf_1sO1sO {base}")
         out[f"{base}_corr_szsz_plain"] = rc
         out[f"{base}_top"] = t2n(ref_top4.get_Top_spec_c4v(3, st, env))
+        out[f"{base}_corr_dd"] = t2n(model.eval_corrf_DD_H(st, env, 3)["dd"])
     np.savez_compressed(os.path.join(GOLD, "c4v_j3.npz"), **out)
     print("  c4v_j3 ok")
 

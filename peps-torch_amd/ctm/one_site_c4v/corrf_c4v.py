@@ -58,3 +58,45 @@ def corrf_1sO1sO(state, env, op1, get_op2, dist, rl_0=None, verbosity=0):
         m = E0.abs().max()
         E0, E1 = E0 / m, E1 / m
     return corrf
+
+
+def apply_TM_2sO(state, env, edge, op=None, verbosity=0):
+    """Two transfer steps with a two-site operator op[s1, s2, s1', s2'] inserted (:435-592): op is split by an SVD of its
+    (s1 s1') x (s2 s2') matrix into op_l[m, n, q] and op_r[m, n, q] (tiny, on the host), the bond q travels with the edge between
+    the two steps."""
+    a, C, T = _parts(state, env)
+    chi, D, p = T.shape[0], a.shape[1], a.shape[0]
+    if op is not None:
+        if op.dim() != 4:
+            raise ValueError("apply_TM_2sO: op must have four physical legs")
+        m = op.detach().cpu().permute(0, 2, 1, 3).contiguous().reshape(p * p, p * p)
+        U, S, Vh = torch.linalg.svd(m)
+        op_l = U.reshape(p, p, S.shape[0])
+        op_r = (S[:, None] * Vh).reshape(S.shape[0], p, p).permute(1, 2, 0).contiguous()
+    else:
+        op_l = op_r = torch.eye(p, dtype=a.dtype)[:, :, None]
+    op_l = op_l.to(dtype=a.dtype, device=a.device).contiguous()
+    op_r = op_r.to(dtype=a.dtype, device=a.device).contiguous()
+    e4 = edge.reshape(chi, D, D, chi)
+    Tv = T.reshape(chi, chi, D, D)
+    e5 = einsum('alLc,xauU,muldr,mnq,nULDR,cydD->xrRqy', e4, Tv, a, op_l, a, Tv, conj=(4,))
+    r = einsum('alLqc,xauU,muldr,mnq,nULDR,cydD->xrRy', e5, Tv, a, op_r, a, Tv, conj=(4,))
+    return r.reshape(chi, D * D, chi)
+
+
+def corrf_2sOH2sOH_E1(state, env, op1, get_op2, dist, verbosity=0):
+    """<op1(0,1) op2(r+2, r+3)> / <1> of two horizontal two-site operators along a row, r = 0 .. dist (:666-737)."""
+    E0 = get_edge(state, env)
+    E1 = apply_TM_2sO(state, env, E0, op=op1)
+    E0 = apply_TM_2sO(state, env, E0)
+    corrf = torch.empty(dist + 1, dtype=E0.dtype, device=E0.device)
+    for r in range(dist + 1):
+        E12 = apply_TM_2sO(state, env, E1, op=get_op2(r))
+        E0 = apply_TM_1sO(state, env, E0)
+        E1 = apply_TM_1sO(state, env, E1)
+        n12 = apply_edge(state, env, E12)
+        n00 = apply_edge(state, env, apply_TM_1sO(state, env, E0))
+        corrf[r] = n12 / n00
+        m = E0.abs().max()
+        E0, E1 = E0 / m, E1 / m
+    return corrf

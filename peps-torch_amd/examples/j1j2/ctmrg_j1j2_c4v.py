@@ -76,11 +76,15 @@ def main(args=None):
     print("FINAL " + ", ".join([f"{e}"] + [f"{v}" for v in obs_values]))
 
     # additional observables, as the reference script prints them after FINAL (examples/j1j2/ctmrg_j1j2_c4v.py:153-183); the
-    # dimer-dimer correlators (two-site operators in the transfer matrix) are not built
+    # vertical dimer-dimer correlator (--corrf_dd_v) and the width-2 transfer operator (--top2) are not built
     corrSS = model.eval_corrf_SS(state, env, args.corrf_r, canonical=args.corrf_canonical)
     print("\n\nSS r " + " ".join(corrSS.keys()) + f" canonical {args.corrf_canonical}")
     for i in range(args.corrf_r):
         print(f"{i} " + " ".join([f"{corrSS[label][i]}" for label in corrSS.keys()]))
+    corrDD = model.eval_corrf_DD_H(state, env, args.corrf_r)
+    print("\n\nDD r " + " ".join(corrDD.keys()))
+    for i in range(args.corrf_r):
+        print(f"{i} " + " ".join([f"{corrDD[label][i]}" for label in corrDD.keys()]))
     print("\n\nspectrum(C)")
     s = get_engine_svdvals(env.C[env.keyC])
     for i in range(args.chi):

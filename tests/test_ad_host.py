@@ -262,3 +262,5 @@ def test_c4v_correlators_host_layer(fake, base):
         c = model.eval_corrf_SS(st, env, 4, canonical=canon)
         for k, v in c.items():
             assert float(np.abs(v.numpy() - j[f"{base}_corr{'_canon' if canon else ''}_{k}"]).max()) < 1e-10, (canon, k)
+    dd = model.eval_corrf_DD_H(st, env, 3)["dd"]
+    assert float(np.abs(dd.numpy() - j[f"{base}_corr_dd"]).max()) < 1e-10

@@ -357,6 +357,7 @@ def test_c4v_correlators_and_transfer_spectrum(eng, base):
         c = model.eval_corrf_SS(st, env, 4, canonical=canon)
         for k, v in c.items():
             assert float(np.abs(v.cpu().numpy() - j[f"{base}_corr{'_canon' if canon else ''}_{k}"]).max()) < 1e-10, (canon, k)
+    assert float(np.abs(model.eval_corrf_DD_H(st, env, 3)["dd"].cpu().numpy() - j[f"{base}_corr_dd"]).max()) < 1e-10
     top = transferops_c4v.get_Top_spec_c4v(3, st, env).cpu().numpy()
     ref = j[f"{base}_top"]
     assert float(np.abs(np.hypot(top[:, 0], top[:, 1]) - np.hypot(ref[:, 0], ref[:, 1])).max()) < 1e-8     # moduli (conjugate pairs may swap)
