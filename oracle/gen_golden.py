@@ -439,6 +439,31 @@ def c4v_j3_case():
     print("  c4v_j3 ok")
 
 
+def generic_corr_case():
+    """J1J2.eval_corrf_SS / eval_corrf_SpSm (models/j1j2.py:477-527) on the warm generic goldens, both directions."""
+    from helpers_cpu import sites_from, env_from
+    out = {}
+    for base, cplx in (("generic_D2_chi8_f64", False), ("generic_D2_chi8_c128", True)):
+        set_dtype(cplx)
+        g = np.load(os.path.join(GOLD, base + ".npz"))
+        st = ref_state(sites_from(g))
+        C, T = env_from(g, "warm_")
+        env = ENV(next(iter(C.values())).shape[0], st)
+        env.C = {k: torch.from_numpy(v.copy()) for k, v in C.items()}
+        env.T = {k: torch.from_numpy(v.copy()) for k, v in T.items()}
+        model = j1j2.J1J2(j1=1.0, j2=0.5)
+        for d in ((1, 0), (0, 1)):
+            for conj_ in (False, True):
+                c = model.eval_corrf_SS((0, 0), d, st, env, 2, conjugate=conj_)
+                for k, v in c.items():
+                    out[f"{base}_ss_{d[0]}{d[1]}_{int(conj_)}_{k}"] = t2n(v)
+            c = model.eval_corrf_SpSm((1, 0), d, st, env, 2)
+            for k, v in c.items():
+                out[f"{base}_spsm_{d[0]}{d[1]}_{k}"] = t2n(v)
+    np.savez_compressed(os.path.join(GOLD, "generic_corr.npz"), **out)
+    print("  generic_corr ok")
+
+
 def envinit_case():
     """init_prod / init_from_ipeps_obc (ctm/generic/env.py:274-365, 538-716) on random 2x2 states, chi below and above D^2."""
     out = {}
@@ -730,7 +755,7 @@ def input_files_case():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["decomp", "generic", "c4v", "c4v_ad", "generic_ad", "c4v_j3", "envinit", "rvb", "files", "variants", "aklt", "inputs", "backward"]
+    which = sys.argv[1:] or ["decomp", "generic", "c4v", "c4v_ad", "generic_ad", "c4v_j3", "generic_corr", "envinit", "rvb", "files", "variants", "aklt", "inputs", "backward"]
     if "backward" in which:
         backward_case()
     if "inputs" in which:
@@ -761,6 +786,9 @@ if __name__ == "__main__":
         generic_ad_case("generic_ad_D2_chi8_f64_4x2", "generic_D2_chi8_f64", moves=((0, -1), (1, 0)), projector_method='4X2')
     if "c4v_j3" in which:
         c4v_j3_case()
+    if "generic_corr" in which:
+        sys.path.insert(0, os.path.join(REPO, "tests"))
+        generic_corr_case()
     if "envinit" in which:
         envinit_case()
     if "rvb" in which:

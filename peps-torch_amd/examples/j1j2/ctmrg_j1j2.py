@@ -22,6 +22,8 @@ parser.add_argument("--h_uni", nargs=3, type=float, default=[0, 0, 0], help="uni
 parser.add_argument("--delta_zz", type=float, default=1.)
 parser.add_argument("--tiling", default="BIPARTITE", help="BIPARTITE, 1SITE, 2SITE, 4SITE, 8SITE")
 parser.add_argument("--top_freq", type=int, default=-1)
+parser.add_argument("--corrf_r", type=int, default=1, help="maximal correlation function distance")
+parser.add_argument("--top_n", type=int, default=2, help="number of leading eigenvalues of the transfer operator to compute")
 
 TILINGS = {
     "BIPARTITE": lambda c: ((((c[0] + abs(c[0]) * 2) % 2) + abs(c[1])) % 2, 0),
@@ -86,6 +88,26 @@ def main(args=None):
     print(", ".join([f"{len(history)}", f"{e}"] + [f"{v}" for v in obs_values]))
     print(f"TIMINGS ctm: {t_ctm} conv_check: {t_obs}")
     print("FINAL " + ", ".join([f"{e}"] + [f"{v}" for v in obs_values]))
+
+    # additional observables, as the reference script prints them after FINAL (examples/j1j2/ctmrg_j1j2.py:176-201)
+    from ctm.generic import transferops
+    from backend import get_engine
+    for direction in ((1, 0), (0, 1)):
+        corrSS = model.eval_corrf_SS((0, 0), direction, state, env, args.corrf_r)
+        print(f"\n\nSS[(0,0),{direction}] r " + " ".join(corrSS.keys()))
+        for i in range(args.corrf_r):
+            print(f"{i} " + " ".join([f"{corrSS[label][i]}" for label in corrSS.keys()]))
+    print("\n")
+    for c_loc, c_ten in env.C.items():
+        s = get_engine().svdvals(c_ten)
+        print(f"spectrum C[{c_loc}]")
+        for i in range(args.chi):
+            print(f"{i} {s[i]}")
+    for sdp in (((0, 0), (1, 0)), ((0, 0), (0, 1))):
+        print(f"\n\nspectrum(T)[{sdp[0]},{sdp[1]}]")
+        l = transferops.get_Top_spec(args.top_n, *sdp, state, env)
+        for i in range(l.size()[0]):
+            print(f"{i} {l[i, 0]} {l[i, 1]}")
     return float(e), obs_values
 
 

@@ -184,6 +184,31 @@ class J1J2():
             + [f"SS2x1{c}" for c in state.sites.keys()] + [f"SS1x2{c}" for c in state.sites.keys()]
         return [obs[l] for l in labels], labels
 
+    def _bilat(self, op, conjugate):
+        """models/j1j2.py:18-25: the operator on every second site carries the sublattice rotation when `conjugate`."""
+        if not conjugate:
+            return lambda r: op
+        rot = su2.get_rot_op(self.phys_dim, dtype=op.dtype, device=op.device)
+        op_rot = torch.einsum('ki,kl,lj->ij', rot, op, rot)
+        return lambda r: op_rot if r % 2 == 0 else op
+
+    def eval_corrf_SS(self, coord, direction, state, env, dist, conjugate=False):
+        """<S(r).S(0)> and its zz / xx / yy parts for r = 1 .. dist + 1 from `coord` along `direction` (models/j1j2.py:477-497)."""
+        from ctm.generic import corrf
+        sx = 0.5 * (self.obs_ops["sp"] + self.obs_ops["sm"])
+        isy = -0.5 * (self.obs_ops["sp"] - self.obs_ops["sm"])
+        zz = corrf.corrf_1sO1sO(coord, direction, state, env, self.obs_ops["sz"], self._bilat(self.obs_ops["sz"], conjugate), dist)
+        xx = corrf.corrf_1sO1sO(coord, direction, state, env, sx, self._bilat(sx, conjugate), dist)
+        nyy = corrf.corrf_1sO1sO(coord, direction, state, env, isy, self._bilat(isy, conjugate), dist)
+        return dict({"ss": zz + xx - nyy, "szsz": zz, "sxsx": xx, "sysy": -nyy})
+
+    def eval_corrf_SpSm(self, coord, direction, state, env, dist, conjugate=False):
+        """<S^+(0) S^-(r)> and <S^-(0) S^+(r)> (models/j1j2.py:499-527)."""
+        from ctm.generic import corrf
+        sp, sm = self.obs_ops["sp"], self.obs_ops["sm"]
+        return dict({"spsm": corrf.corrf_1sO1sO(coord, direction, state, env, sp, self._bilat(sm, conjugate), dist),
+                     "smsp": corrf.corrf_1sO1sO(coord, direction, state, env, sm, self._bilat(sp, conjugate), dist)})
+
     def eval_obs(self, state, env): return self._eval_obs(state, env, self.SS)
     def eval_obs_1site_BP(self, state, env): return self._eval_obs(state, env, self.SS_rot)
 

@@ -307,3 +307,21 @@ def test_env_init_variants_on_the_engine(eng, tag, chi, kind):
     C, T = env_from(g, f"{tag}_{kind}_")
     for k in C: assert relerr(env.C[k], C[k]) < 1e-13 or float(np.abs(C[k]).max()) == 0
     for k in T: assert tuple(env.T[k].shape) == T[k].shape and relerr(env.T[k], T[k]) < 1e-13
+
+
+@pytest.mark.parametrize("base", ["generic_D2_chi8_f64", "generic_D2_chi8_c128"])
+def test_model_correlators_against_the_reference(eng, base):
+    """J1J2.eval_corrf_SS (with and without the sublattice rotation) and eval_corrf_SpSm in both directions (models/j1j2.py:477-527)."""
+    from models import j1j2
+    g, c = golden(base), golden("generic_corr")
+    C, T = env_from(g, "warm_")
+    st, env = device_state_env(sites_from(g), C, T, next(iter(C.values())).shape[0])
+    model = j1j2.J1J2(j1=1.0, j2=0.5)
+    for d in ((1, 0), (0, 1)):
+        for conj_ in (False, True):
+            r = model.eval_corrf_SS((0, 0), d, st, env, 2, conjugate=conj_)
+            for k, v in r.items():
+                assert float(np.abs(v.cpu().numpy() - c[f"{base}_ss_{d[0]}{d[1]}_{int(conj_)}_{k}"]).max()) < 1e-10, (d, conj_, k)
+        r = model.eval_corrf_SpSm((1, 0), d, st, env, 2)
+        for k, v in r.items():
+            assert float(np.abs(v.cpu().numpy() - c[f"{base}_spsm_{d[0]}{d[1]}_{k}"]).max()) < 1e-10, (d, k)
