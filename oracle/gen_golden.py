@@ -435,6 +435,10 @@ def c4v_j3_case():
         out[f"{base}_corr_szsz_plain"] = rc
         out[f"{base}_top"] = t2n(ref_top4.get_Top_spec_c4v(3, st, env))
         out[f"{base}_corr_dd"] = t2n(model.eval_corrf_DD_H(st, env, 3)["dd"])
+        out[f"{base}_corr_dd_v"] = t2n(model.eval_corrf_DD_V(st, env, 2)["dd"])
+        out[f"{base}_eh3"] = t2n(ref_top4.get_EH_spec_Ttensor(2, 3, st, env))
+        if base != "c4v_D3_chi18":
+            out[f"{base}_top2"] = t2n(ref_top4.get_Top2_spec_c4v(2, st, env))
     np.savez_compressed(os.path.join(GOLD, "c4v_j3.npz"), **out)
     print("  c4v_j3 ok")
 

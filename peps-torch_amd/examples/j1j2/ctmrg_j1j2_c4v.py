@@ -23,6 +23,8 @@ parser.add_argument("--top_freq", type=int, default=-1)
 parser.add_argument("--corrf_canonical", action='store_true', help="align spin operators with the vector of spontaneous magnetization")
 parser.add_argument("--corrf_r", type=int, default=1, help="maximal correlation function distance")
 parser.add_argument("--top_n", type=int, default=2, help="number of leading eigenvalues of the transfer operator to compute")
+parser.add_argument("--corrf_dd_v", action='store_true', help="compute vertical dimer-dimer correlation function")
+parser.add_argument("--top2", action='store_true', help="compute transfer matrix for width-2 channel")
 
 
 def main(args=None):
@@ -75,8 +77,7 @@ def main(args=None):
     print(f"TIMINGS ctm: {t_ctm} conv_check: {t_obs}")
     print("FINAL " + ", ".join([f"{e}"] + [f"{v}" for v in obs_values]))
 
-    # additional observables, as the reference script prints them after FINAL (examples/j1j2/ctmrg_j1j2_c4v.py:153-183); the
-    # vertical dimer-dimer correlator (--corrf_dd_v) and the width-2 transfer operator (--top2) are not built
+    # additional observables, as the reference script prints them after FINAL (examples/j1j2/ctmrg_j1j2_c4v.py:153-183)
     corrSS = model.eval_corrf_SS(state, env, args.corrf_r, canonical=args.corrf_canonical)
     print("\n\nSS r " + " ".join(corrSS.keys()) + f" canonical {args.corrf_canonical}")
     for i in range(args.corrf_r):
@@ -85,6 +86,11 @@ def main(args=None):
     print("\n\nDD r " + " ".join(corrDD.keys()))
     for i in range(args.corrf_r):
         print(f"{i} " + " ".join([f"{corrDD[label][i]}" for label in corrDD.keys()]))
+    if args.corrf_dd_v:
+        corrDD_V = model.eval_corrf_DD_V(state, env, args.corrf_r)
+        print("\n\nDD_v r " + " ".join(corrDD_V.keys()))
+        for i in range(args.corrf_r):
+            print(f"{i} " + " ".join([f"{corrDD_V[label][i]}" for label in corrDD_V.keys()]))
     print("\n\nspectrum(C)")
     s = get_engine_svdvals(env.C[env.keyC])
     for i in range(args.chi):
@@ -94,6 +100,11 @@ def main(args=None):
     l = transferops_c4v.get_Top_spec_c4v(args.top_n, state, env)
     for i in range(l.size()[0]):
         print(f"{i} {l[i, 0]} {l[i, 1]}")
+    if args.top2:
+        print("\n\nspectrum(T2)")
+        l = transferops_c4v.get_Top2_spec_c4v(args.top_n, state, env)
+        for i in range(l.size()[0]):
+            print(f"{i} {l[i, 0]} {l[i, 1]}")
     return float(e), obs_values
 
 

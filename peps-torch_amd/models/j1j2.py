@@ -277,6 +277,15 @@ class J1J2_C4V_BIPARTITE(J1J2):
         op_rot = SS_rot.permute(1, 0, 3, 2).contiguous()                           # ... on the second spin
         return dict({"dd": corrf_c4v.corrf_2sOH2sOH_E1(state, env_c4v, SS_rot, lambda r: SS_rot if r % 2 == 0 else op_rot, dist)})
 
+    def eval_corrf_DD_V(self, state, env_c4v, dist, verbosity=0):
+        """Vertical dimer-dimer correlator in the width-2 channel, r = 0 .. dist (models/j1j2.py:899-926)."""
+        from ctm.one_site_c4v import corrf_c4v
+        dt = state.site().dtype
+        rot = su2.get_rot_op(self.phys_dim, dtype=dt, device="cpu")
+        SS_rot = torch.einsum('ki,kjcb,ca->ijab', rot, self.SS.to(dt), rot)
+        op_rot = SS_rot.permute(1, 0, 3, 2).contiguous()
+        return dict({"dd": corrf_c4v.corrf_2sOV2sOV_E2(state, env_c4v, SS_rot, lambda r: SS_rot if r % 2 == 0 else op_rot, dist)})
+
     def eval_obs(self, state, env_c4v, force_cpu=False):
         """<m>, <S^z>, <S^+>, <S^->, nearest-neighbour S.S from rho_2x1 and -- as the couplings are switched on -- S.S of the
         diagonal pair (j2), of the 3x1 pair (j3) and the chiral term (lambda) (models/j1j2.py:710-770, same labels and order)."""

@@ -264,3 +264,8 @@ def test_c4v_correlators_host_layer(fake, base):
             assert float(np.abs(v.numpy() - j[f"{base}_corr{'_canon' if canon else ''}_{k}"]).max()) < 1e-10, (canon, k)
     dd = model.eval_corrf_DD_H(st, env, 3)["dd"]
     assert float(np.abs(dd.numpy() - j[f"{base}_corr_dd"]).max()) < 1e-10
+    ddv = model.eval_corrf_DD_V(st, env, 2)["dd"]                           # width-2 channel
+    assert float(np.abs(ddv.numpy() - j[f"{base}_corr_dd_v"]).max()) < 1e-10
+    from ctm.one_site_c4v import transferops_c4v
+    eh, ref = transferops_c4v.get_EH_spec_Ttensor(2, 3, st, env).numpy(), j[f"{base}_eh3"]
+    assert float(np.abs(np.hypot(eh[:, 0], eh[:, 1]) - np.hypot(ref[:, 0], ref[:, 1])).max()) < 1e-8

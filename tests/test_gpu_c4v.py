@@ -361,3 +361,11 @@ def test_c4v_correlators_and_transfer_spectrum(eng, base):
     top = transferops_c4v.get_Top_spec_c4v(3, st, env).cpu().numpy()
     ref = j[f"{base}_top"]
     assert float(np.abs(np.hypot(top[:, 0], top[:, 1]) - np.hypot(ref[:, 0], ref[:, 1])).max()) < 1e-8     # moduli (conjugate pairs may swap)
+    # width-2 channel: vertical dimer-dimer correlator (corrf_c4v.corrf_2sOV2sOV_E2) and transfer operator (get_Top2_spec_c4v)
+    assert float(np.abs(model.eval_corrf_DD_V(st, env, 2)["dd"].cpu().numpy() - j[f"{base}_corr_dd_v"]).max()) < 1e-10
+    eh, refe = transferops_c4v.get_EH_spec_Ttensor(2, 3, st, env).cpu().numpy(), j[f"{base}_eh3"]      # exp(EH) of a 3-leg cylinder
+    assert float(np.abs(np.hypot(eh[:, 0], eh[:, 1]) - np.hypot(refe[:, 0], refe[:, 1])).max()) < 1e-8
+    if f"{base}_top2" in j:
+        top2 = transferops_c4v.get_Top2_spec_c4v(2, st, env).cpu().numpy()
+        ref2 = j[f"{base}_top2"]
+        assert float(np.abs(np.hypot(top2[:, 0], top2[:, 1]) - np.hypot(ref2[:, 0], ref2[:, 1])).max()) < 1e-8

@@ -16,6 +16,7 @@ def _run(script, args):
     assert r.returncode == 0, r.stderr[-2000:]
     final = [l for l in r.stdout.splitlines() if l.startswith("FINAL")]
     assert len(final) == 1, r.stdout[-2000:]
+    _run.stdout = r.stdout
     return [float(v) for v in final[0][6:].split(",")]
 
 
@@ -40,8 +41,13 @@ def test_ctmrg_j1j2_c4v_script_rvb(tmp_path):
     f = str(tmp_path / "rvb.json")
     IPEPS_C4V(torch.from_numpy(g["site"])).write_to_file(f, symmetrize=False)
     vals = _run("ctmrg_j1j2_c4v.py", ["--instate", f, "--chi", "16", "--bond_dim", "3", "--j2", "0.5", "--CTMARGS_ctm_max_iter", "200",
-                                      "--GLOBALARGS_device", "cuda:0", "--out_prefix", str(tmp_path / "o")])
+                                      "--GLOBALARGS_device", "cuda:0", "--out_prefix", str(tmp_path / "o"),
+                                      "--corrf_r", "2", "--corrf_dd_v", "--top2"])
     assert abs(vals[0] - (-0.47684229)) < 1e-8
+    out = _run.stdout                                           # the optional width-2 sections of the reference script (:166-183)
+    assert "DD_v r dd" in out and "spectrum(T2)" in out
+    t2 = out[out.index("spectrum(T2)"):].splitlines()[1].split()
+    assert t2[0] == "0" and abs(float(t2[1]) - 1.0) < 1e-12
 
 
 def test_ctmrg_j1j2_script_bipartite_golden(tmp_path):
