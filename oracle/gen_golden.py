@@ -392,6 +392,53 @@ def generic_ad_case(name, base, complex_=False, moves=((0, -1), (-1, 0), (0, 1),
     print(f"  {name} ok  E={float(torch.real(e)):.12f} |grad|={gn:.6e}")
 
 
+def c4v_optim_case(name, base, complex_=False, epochs=4, chi=16, ctm_iter=8, j2=0.2, line_search="default"):
+    """Trajectory of the reference's optimiser (examples/j1j2/optim_j1j2_c4v.py: loss_fn = symmetrise + normalise -> init_env ->
+    `ctm_iter` CTM moves -> energy_1x1_lowmem; optim/ad_optim_lbfgs_mod.optimize_state, L-BFGS with the default fixed step) from
+    the on-site tensor of golden `base`: loss of every epoch and the parameters it ends with."""
+    import tempfile, copy
+    from ipeps.ipeps_c4v import to_ipeps_c4v
+    from optim.ad_optim_lbfgs_mod import optimize_state
+    set_dtype(complex_)
+    g = np.load(os.path.join(GOLD, base + ".npz"))
+    A0 = torch.from_numpy(g["site"].copy())
+    A0 = A0 / A0.norm()
+    st = IPEPS_C4V(A0.clone())
+    model = j1j2.J1J2_C4V_BIPARTITE(j1=1.0, j2=j2)
+    ctm_args = copy.deepcopy(cfg.ctm_args); ctm_args.ctm_max_iter = ctm_iter; ctm_args.ctm_conv_tol = -1.0
+    opt_args = copy.deepcopy(cfg.opt_args); opt_args.line_search = line_search; opt_args.opt_logging = False
+    main_args = copy.deepcopy(cfg.main_args); main_args.opt_max_iter = epochs
+    tmp = tempfile.mkdtemp(); main_args.out_prefix = os.path.join(tmp, "o"); main_args.opt_resume = None
+
+    @torch.no_grad()
+    def conv_f(state, env, history, ctm_args=ctm_args):
+        if not history: history = dict({"log": []})
+        r = rdm_c4v.rdm2x1_sl(state, env)
+        dist = float('inf')
+        if len(history["log"]) > 0: dist = torch.dist(r, history["rdm"], p=2).item()
+        history["rdm"] = r; history["log"].append(dist)
+        return (dist < ctm_args.ctm_conv_tol or len(history["log"]) >= ctm_args.ctm_max_iter), history
+
+    def loss_fn(state, env, ctx):
+        ss = to_ipeps_c4v(state, normalize=True)
+        if ctx["opt_args"].opt_ctm_reinit: env_c4v.init_env(ss, env)
+        env, *log_ = ctmrg_c4v.run(ss, env, conv_check=conv_f, ctm_args=ctx["ctm_args"])
+        return (model.energy_1x1_lowmem(ss, env), env, *log_)
+    sites_hist = []
+    def obs_fn(state, env, ctx):
+        if not ctx["line_search"]: sites_hist.append(t2n(state.site().detach().clone()))
+    env = ENV_C4V(chi, to_ipeps_c4v(st))
+    env_c4v.init_env(to_ipeps_c4v(st), env)
+    hist = {}
+    def post(state, env, ctx): hist["loss"] = list(ctx["loss_history"]["loss"])
+    optimize_state(st, env, loss_fn, obs_fn=obs_fn, post_proc=post, main_args=main_args, opt_args=opt_args, ctm_args=ctm_args)
+    best = read_ipeps_c4v(main_args.out_prefix + "_state.json")
+    out = dict(site0=t2n(A0), losses=np.array(hist["loss"]), site_final=t2n(st.site().detach()), sites=np.stack(sites_hist),
+               best=t2n(best.site()), chi=np.array(chi), ctm_iter=np.array(ctm_iter), j2=np.array(j2), epochs=np.array(epochs))
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **out)
+    print(f"  {name} ok  losses={hist['loss']}")
+
+
 def c4v_j3_case():
     """rdm3x1_sl and the j3 term of energy_1x1_lowmem (rdm_c4v.py:829-994, models/j1j2.py:672-676) on the warm C4v goldens."""
     out = {}
@@ -788,6 +835,9 @@ if __name__ == "__main__":
         generic_ad_case("generic_ad_D2_chi8_f64", "generic_D2_chi8_f64")
         generic_ad_case("generic_ad_D2_chi8_c128", "generic_D2_chi8_c128", complex_=True)
         generic_ad_case("generic_ad_D2_chi8_f64_4x2", "generic_D2_chi8_f64", moves=((0, -1), (1, 0)), projector_method='4X2')
+    if "c4v_optim" in which:
+        c4v_optim_case("c4v_optim_D2_chi16", "c4v_D2_chi8")
+        c4v_optim_case("c4v_optim_D2_chi16_c128", "c4v_D2_chi8_c128", complex_=True)
     if "c4v_j3" in which:
         c4v_j3_case()
     if "generic_corr" in which:

@@ -58,8 +58,10 @@ class CTMARGS(_Args):
 
 
 class OPTARGS(_Args):
-    _DEFAULTS = dict(lr=1.0, tolerance_grad=1e-5, tolerance_change=1e-9, opt_ctm_reinit=True, line_search="default",
-                     history_size=100, max_iter_per_epoch=1, verbosity_opt_epoch=1, opt_logging=True)
+    _DEFAULTS = dict(lr=1.0, momentum=0., dampening=0., tolerance_grad=1e-5, tolerance_change=1e-9, opt_ctm_reinit=True,
+                     env_sens_scale=10.0, env_sens_regauge=False, line_search="default", line_search_ctm_reinit=True,
+                     line_search_svd_method='DEFAULT', line_search_tol=1.0e-8, fd_eps=1.0e-4, fd_ctm_reinit=True,
+                     history_size=100, max_iter_per_epoch=1, verbosity_opt_epoch=1, opt_logging=True, opt_log_grad=False)
 
 
 main_args = MAINARGS()

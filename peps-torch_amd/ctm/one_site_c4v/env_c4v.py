@@ -134,6 +134,25 @@ def init_from_ipeps_pbc(state, env, verbosity=0):
     eng = get_engine()
     a = state.site()
     D2 = a.size(1) ** 2
+    from linalg.native_einsum import needs_grad, einsum
+    if needs_grad(a):
+        # the site is being optimised: the same construction as a graph of differentiable native nodes (the reference
+        # differentiates through the initial environment too, optim_j1j2_c4v.py:104-106); scales without gradient (:277-279,303-305)
+        c = einsum('mijef,mijab->eafb', a, a, conj=(1,)).reshape(D2, D2)
+        c = c / c.detach().abs().max()
+        assert torch.norm(c.detach().conj().t() - c.detach()) / c.detach().abs().max() < 1.0e-8, "a is not symmetric"
+        Dv, U = truncated_eig_sym(c, D2)
+        m = min(env.chi, D2)
+        C = torch.zeros(env.chi, env.chi, dtype=env.dtype, device=env.device)
+        C[:m, :m] = torch.diag(Dv.to(env.dtype))[:m, :m]
+        env.C[env.keyC] = C
+        t = einsum('meifg,maibc->eafbgc', a, a, conj=(1,)).reshape(D2, D2, D2)
+        t = t / t.detach().abs().max()
+        t2 = einsum('ai,abs,bj->ijs', U.contiguous(), t, U.contiguous(), conj=(2,))
+        T = torch.zeros((env.chi, env.chi, D2), dtype=env.dtype, device=env.device)
+        T[:m, :m, :] = t2[:m, :m, :]
+        env.T[env.keyT] = T
+        return
     c = eng.init_piece(0, a)                                   # 'mijef,mijab->eafb', /max-abs
     asym = torch.norm(c.conj().t() - c) / c.abs().max()
     assert asym < 1.0e-8, "a is not symmetric"

@@ -69,6 +69,15 @@ class IPEPS():
     def get_checkpoint(self):
         return self.sites
 
+    def load_checkpoint(self, checkpoint_file):
+        """ipeps.py:268-284: on-site tensors from an optimiser checkpoint (`optim.ad_optim_lbfgs_mod.store_checkpoint`)."""
+        checkpoint = torch.load(checkpoint_file, map_location=self.device, weights_only=False)
+        self.sites = checkpoint["parameters"]
+        for site_t in self.sites.values():
+            site_t.requires_grad_(False)
+        if True in [s.is_complex() for s in self.sites.values()]:
+            self.dtype = torch.complex128
+
     def get_aux_bond_dims(self):
         return [d for key in self.sites.keys() for d in self.sites[key].size()[1:]]
 

@@ -40,5 +40,5 @@ def serialize_bare_tensor_legacy(t, tol=1.0e-14):
     for idx in np.argwhere(np.abs(a) > tol):
         v = a[tuple(idx)]
         s = " ".join(str(int(i)) for i in idx)
-        entries.append(f"{s} {v.real!r} {v.imag!r}" if cplx else f"{s} {float(v)!r}")
+        entries.append(f"{s} {float(v.real)!r} {float(v.imag)!r}" if cplx else f"{s} {float(v)!r}")
     return {"dtype": "complex128" if cplx else "float64", "dims": list(a.shape), "numEntries": len(entries), "entries": entries}

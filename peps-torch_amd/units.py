@@ -9,6 +9,7 @@ an event recorded on the caller's stream before it starts, and the caller's stre
 event, so each phase is bracketed by full cross-stream barriers (which also makes cross-stream reuse of torch's
 cached blocks safe: tensors are only released at phase boundaries)."""
 import threading
+import queue
 from concurrent.futures import ThreadPoolExecutor
 import os
 import torch
@@ -23,36 +24,42 @@ class UnitPool:
         self.streams = [torch.cuda.Stream(self.device) for _ in range(nworkers)]
         self.engines = [None] * nworkers
         self.pool = ThreadPoolExecutor(max_workers=nworkers, thread_name_prefix="ctm-unit")
+        self.free = queue.Queue()
+        for slot in range(nworkers):
+            self.free.put(slot)
 
-    def _run(self, slot, fn, item, ev0):
-        s = self.streams[slot]
-        with torch.cuda.device(self.device), torch.cuda.stream(s):
-            s.wait_event(ev0)
-            if self.engines[slot] is None:
-                self.engines[slot] = self.main.spawn_worker()        # binds the current (= worker) stream
-            backend.set_thread_engine(self.engines[slot])
-            try:
-                out = fn(item)
-            finally:
-                backend.set_thread_engine(None)
-            ev = torch.cuda.Event()
-            ev.record(s)
-        return out, ev
+    def _run(self, fn, item, ev0):
+        slot = self.free.get()                                       # a worker context that is idle right now
+        try:
+            s = self.streams[slot]
+            with torch.cuda.device(self.device), torch.cuda.stream(s):
+                s.wait_event(ev0)
+                if self.engines[slot] is None:
+                    self.engines[slot] = self.main.spawn_worker()    # binds the current (= worker) stream
+                backend.set_thread_engine(self.engines[slot])
+                try:
+                    out = fn(item)
+                finally:
+                    backend.set_thread_engine(None)
+                ev = torch.cuda.Event()
+                ev.record(s)
+            return out, ev
+        finally:
+            self.free.put(slot)
 
     def map(self, fn, items):
-        """[fn(item) for item in items], at most `nworkers` at a time, each on its own stream/context."""
+        """[fn(item) for item in items], at most `nworkers` at a time, each on its own stream/context; a worker takes the next
+        item as soon as it has issued its previous one (no barrier between groups of `nworkers` items)."""
         items = list(items)
         main_stream = torch.cuda.current_stream(self.device)
+        ev0 = torch.cuda.Event()
+        ev0.record(main_stream)
+        futs = [self.pool.submit(self._run, fn, it, ev0) for it in items]
         outs = []
-        for c0 in range(0, len(items), self.n):
-            chunk = items[c0:c0 + self.n]
-            ev0 = torch.cuda.Event()
-            ev0.record(main_stream)
-            futs = [self.pool.submit(self._run, slot, fn, it, ev0) for slot, it in enumerate(chunk)]
-            res = [f.result() for f in futs]
-            for out, ev in res:
-                main_stream.wait_event(ev)
-                outs.append(out)
+        for f in futs:
+            out, ev = f.result()
+            main_stream.wait_event(ev)
+            outs.append(out)
         return outs
 
 

@@ -112,6 +112,18 @@ class FakeEngine:
         r = r.reshape([sh[2 * i] * sh[2 * i + 1] for i in range(len(sh) // 2)])
         return _t(r / np.abs(r).max())
 
+    def move_c4v(self, a, C, T, cfg=None, normalize=1, basis=None):
+        from oracle import c4v_oracle as O4
+        nC, nT, Dv, _P = O4.ctm_move_sl(_n(a), _n(C), _n(T), return_P=True, norm_type='inf' if normalize == 1 else '2')
+        return _t(np.ascontiguousarray(nC)), _t(np.ascontiguousarray(nT)), _t(np.ascontiguousarray(Dv))
+
+    def rdm_c4v(self, which, a, C, T):
+        """C4v RDMs (native ctm_rdm_c4v returns them raw; the host's hermitisation / trace normalisation leaves the oracle's
+        already normalised ones unchanged)."""
+        from oracle import c4v_oracle as O4
+        f = [O4.rdm2x1_sl, O4.rdm2x2_NN_lowmem_sl, O4.rdm2x2_NNN_lowmem_sl, O4.rdm2x2][which]
+        return _t(np.ascontiguousarray(f(_n(a), _n(C), _n(T))))
+
     def rdm2x2(self, tensors16):
         cs = []
         for i, cid in enumerate((O.LU, O.RU, O.RD, O.LD)):

@@ -269,3 +269,34 @@ def test_c4v_correlators_host_layer(fake, base):
     from ctm.one_site_c4v import transferops_c4v
     eh, ref = transferops_c4v.get_EH_spec_Ttensor(2, 3, st, env).numpy(), j[f"{base}_eh3"]
     assert float(np.abs(np.hypot(eh[:, 0], eh[:, 1]) - np.hypot(ref[:, 0], ref[:, 1])).max()) < 1e-8
+
+
+@pytest.mark.parametrize("name", ["c4v_optim_D2_chi16", "c4v_optim_D2_chi16_c128"])
+def test_c4v_optimizer_follows_the_reference_trajectory(fake, name, tmp_path):
+    """optim.ad_optim_lbfgs_mod.optimize_state driving the differentiable C4v path (init_env, moves, energy: all graphs of native
+    nodes): the loss of every L-BFGS epoch and the parameters after the last one equal the reference's own optimisation run
+    (oracle/gen_golden.py c4v_optim_case) from the same start tensor."""
+    from helpers_cpu import run_c4v_optimizer
+    g = golden(name)
+    losses, site, best = run_c4v_optimizer(g, tmp_path)
+    assert len(losses) == len(g["losses"])
+    assert float(np.abs(np.array(losses) - g["losses"]).max()) < 1e-8, (losses, g["losses"])
+    assert float(np.abs(site - g["site_final"]).max()) < 1e-6
+    assert float(np.abs(best - g["best"]).max()) < 1e-6
+
+
+@pytest.mark.parametrize("ls", ["strong_wolfe", "backtracking"])
+def test_c4v_optimizer_line_searches_lower_the_energy(fake, ls, tmp_path):
+    """OPTARGS.line_search = strong_wolfe / backtracking (reference lbfgs_modified.py:312-365): the loss never rises from one epoch
+    to the next, the best state on file is the lowest point visited, and a checkpoint resumes."""
+    import copy, os
+    from helpers_cpu import run_c4v_optimizer
+    g = golden("c4v_optim_D2_chi16")
+    losses, site, best = run_c4v_optimizer(g, tmp_path, line_search=ls, epochs=3)
+    assert len(losses) >= 2 and all(b <= a + 1e-12 for a, b in zip(losses, losses[1:])), losses
+    assert losses[-1] < losses[0] - 1e-3
+    assert os.path.exists(os.path.join(str(tmp_path), "o_checkpoint.p"))
+    from ipeps.ipeps_c4v import IPEPS_C4V
+    st = IPEPS_C4V()
+    st.load_checkpoint(os.path.join(str(tmp_path), "o_checkpoint.p"))
+    assert float((st.site().detach().cpu() - torch.from_numpy(site)).abs().max()) == 0.0 and not st.site().requires_grad

@@ -260,3 +260,23 @@ def test_generic_small_rdm_gradients_on_the_engine(eng):
         with torch.no_grad():
             fd = (float(val({k: s0[k] + h * ds[k] for k in s0})) - float(val({k: s0[k] - h * ds[k] for k in s0}))) / (2 * h)
         assert abs(lin - fd) < 1e-6 * max(1.0, abs(fd)), (fn.__name__, lin, fd)
+
+
+@pytest.mark.parametrize("name", ["c4v_optim_D2_chi16", "c4v_optim_D2_chi16_c128"])
+def test_c4v_optimizer_follows_the_reference_trajectory_on_the_engine(eng, name, tmp_path):
+    """The caller of the differentiable path: optim.ad_optim_lbfgs_mod.optimize_state (L-BFGS, fixed step) over init_env -> 8 CTM
+    moves -> energy_1x1_lowmem, all forward and adjoint contractions / eigendecompositions on the native kernels.  Loss of every
+    epoch and the final parameters against the reference's own optimisation run (oracle/gen_golden.py c4v_optim_case)."""
+    import config as cfg
+    from helpers_cpu import run_c4v_optimizer
+    g = golden(name)
+    old = cfg.global_args.torch_dtype
+    cfg.global_args.torch_dtype = torch.complex128 if name.endswith("c128") else torch.float64
+    try:
+        losses, site, best = run_c4v_optimizer(g, tmp_path, device="cuda")
+    finally:
+        cfg.global_args.torch_dtype = old
+    assert len(losses) == len(g["losses"])
+    assert float(np.abs(np.array(losses) - g["losses"]).max()) < 1e-8, (losses, g["losses"])
+    assert float(np.abs(site - g["site_final"]).max()) < 1e-6
+    assert float(np.abs(best - g["best"]).max()) < 1e-6

@@ -66,3 +66,20 @@ def test_ctmrg_j1j2_script_bipartite_golden(tmp_path):
     # FINAL observables of the published line (m, m_A, m_B, ...): first four values
     for v, ref in zip(vals[1:4], (0.4884474386344192, 0.48844697363007333, 0.4884479036387651)):
         assert abs(v - ref) < 1e-6
+
+
+def test_optim_j1j2_c4v_script(tmp_path):
+    """examples/j1j2/optim_j1j2_c4v.py:179-200 of the reference (TestOpt: D = 2, chi = 16, three epochs from a random tensor): the
+    script runs the optimisation through the differentiable native path, prints one line per epoch, writes the best state and a
+    checkpoint, and ends with the observables of the best state; the energy goes down."""
+    env = dict(os.environ, PYTHONPATH=PKG + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    pre = str(tmp_path / "opt")
+    r = subprocess.run([sys.executable, os.path.join(PKG, "examples", "j1j2", "optim_j1j2_c4v.py"), "--bond_dim", "2", "--chi", "16",
+                        "--opt_max_iter", "3", "--seed", "123", "--CTMARGS_ctm_max_iter", "20", "--GLOBALARGS_device", "cuda:0",
+                        "--out_prefix", pre], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    rows = [l.split(", ") for l in r.stdout.splitlines() if l[:1].isdigit() or l.startswith("-1, ")]
+    e = {int(x[0]): float(x[1]) for x in rows}
+    assert set(e) >= {-1, 1, 2, 3}, r.stdout[-2000:]
+    assert e[3] <= e[1] + 1e-12 and e[3] < -0.4
+    assert os.path.exists(pre + "_state.json") and os.path.exists(pre + "_checkpoint.p")

@@ -58,6 +58,11 @@ def test_json_roundtrip(tmp_path, cpu_cfg):
     write_ipeps(st, f, aux_seq=[1, 0, 3, 2])
     st3 = read_ipeps(f, aux_seq=[1, 0, 3, 2])
     assert torch.equal(st.sites[(0, 0)], st3.sites[(0, 0)].cpu())
+    # complex128 tensors: "s u l d r re im" with plain floats (a numpy scalar's repr is not one)
+    stc = IPEPS({(0, 0): torch.from_numpy(rng.random((2, 2, 2, 2, 2)) + 1j * rng.random((2, 2, 2, 2, 2)))})
+    write_ipeps(stc, f)
+    assert "np." not in open(f).read()
+    assert torch.equal(stc.sites[(0, 0)], read_ipeps(f).sites[(0, 0)].cpu())
     # legacy sparse entries "s u l d r re" with physDim/auxDim
     js = {"lX": 1, "lY": 1, "sites": [{"siteId": "A0", "physDim": 2, "auxDim": 2, "entries": ["0 0 0 0 0 1.5", "1 1 0 1 0 -2.0 0.0"]}],
           "map": [{"siteId": "A0", "x": 0, "y": 0}]}
