@@ -439,6 +439,54 @@ def c4v_optim_case(name, base, complex_=False, epochs=4, chi=16, ctm_iter=8, j2=
     print(f"  {name} ok  losses={hist['loss']}")
 
 
+def generic_optim_case(name, base, complex_=False, epochs=3, chi=8, ctm_iter=3, j2=0.3):
+    """Trajectory of the reference's optimiser on a generic 2x2 cell (examples/j1j2/optim_j1j2.py: loss_fn = init_env ->
+    `ctm_iter` CTM iterations of 8 directional moves -> energy_2x2_4site; L-BFGS, default fixed step) from the sites of golden
+    `base`: loss of every epoch and the parameters it ends with."""
+    import tempfile, copy
+    import optim.ad_optim_lbfgs_mod as _opt
+    from optim.ad_optim_lbfgs_mod import optimize_state
+    if not isinstance(_opt.NoFixedPointError, type):          # without yastn the module binds an exception INSTANCE: `except` needs a class
+        class _NoFixedPoint(Exception): pass
+        _opt.NoFixedPointError = _NoFixedPoint
+    set_dtype(complex_)
+    g = np.load(os.path.join(GOLD, base + ".npz"))
+    sites = {tuple(int(v) for v in k.split('_')[1:]): g[k].copy() for k in g.files if k.startswith('site_')}
+    st = ref_state(sites)
+    model = j1j2.J1J2(j1=1.0, j2=j2)
+    ctm_args = copy.deepcopy(cfg.ctm_args); ctm_args.ctm_max_iter = ctm_iter
+    opt_args = copy.deepcopy(cfg.opt_args); opt_args.opt_logging = False
+    main_args = copy.deepcopy(cfg.main_args); main_args.opt_max_iter = epochs
+    tmp = tempfile.mkdtemp(); main_args.out_prefix = os.path.join(tmp, "o"); main_args.opt_resume = None
+
+    @torch.no_grad()
+    def conv_f(state, env, history, ctm_args=ctm_args):
+        history = (history or []) + [0.]
+        return len(history) >= ctm_args.ctm_max_iter, history
+
+    def loss_fn(state, env, ctx):
+        if ctx["opt_args"].opt_ctm_reinit: init_env(state, env)
+        env_out, *log_ = ctmrg.run(state, env, conv_check=conv_f, ctm_args=ctx["ctm_args"])
+        # energy_per_site (models/j1j2.py:223-247) with rdm2x2_legacy standing in for rdm2x2 (opt_einsum is not installed here)
+        e = 0.
+        for c in state.sites.keys():
+            e = e + torch.einsum('ijklabcd,ijklabcd', rdm.rdm2x2_legacy(c, state, env), model.get_hp(c))
+        e = e / len(state.sites)
+        return (torch.real(e) if e.is_complex() else e, env, *log_)
+    hist = {}
+    def post(state, env, ctx): hist["loss"] = list(ctx["loss_history"]["loss"])
+    env = ENV(chi, st)
+    init_env(st, env)
+    optimize_state(st, env, loss_fn, post_proc=post, main_args=main_args, opt_args=opt_args, ctm_args=ctm_args)
+    out = dict(losses=np.array(hist["loss"]), chi=np.array(chi), ctm_iter=np.array(ctm_iter), j2=np.array(j2), epochs=np.array(epochs))
+    for c, t in sites.items():
+        out[f"site0_{c[0]}_{c[1]}"] = t
+    for c, t in st.sites.items():
+        out[f"final_{c[0]}_{c[1]}"] = t2n(t.detach())
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **out)
+    print(f"  {name} ok  losses={hist['loss']}")
+
+
 def c4v_j3_case():
     """rdm3x1_sl and the j3 term of energy_1x1_lowmem (rdm_c4v.py:829-994, models/j1j2.py:672-676) on the warm C4v goldens."""
     out = {}
@@ -838,6 +886,9 @@ if __name__ == "__main__":
     if "c4v_optim" in which:
         c4v_optim_case("c4v_optim_D2_chi16", "c4v_D2_chi8")
         c4v_optim_case("c4v_optim_D2_chi16_c128", "c4v_D2_chi8_c128", complex_=True)
+    if "generic_optim" in which:
+        generic_optim_case("generic_optim_D2_chi8_f64", "generic_D2_chi8_f64")
+        generic_optim_case("generic_optim_D2_chi8_c128", "generic_D2_chi8_c128", complex_=True)
     if "c4v_j3" in which:
         c4v_j3_case()
     if "generic_corr" in which:

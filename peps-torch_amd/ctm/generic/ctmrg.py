@@ -57,8 +57,9 @@ def run(state, env, conv_check=None, ctm_args=cfg.ctm_args, global_args=cfg.glob
         wargs = copy.deepcopy(ctm_args)
         wargs.projector_svd_method = ctm_args.warmup_projector_svd_method
         maxD = max(state.get_aux_bond_dims())
-        for i in range(max(ctm_args.ctm_warmup_iter, ceil(env.chi / maxD ** 2))):
-            t0 = time.perf_counter(); _ctmrg_iter(i, loc_ctm_args=wargs); eng.sync(); t_ctm += time.perf_counter() - t0
+        with torch.no_grad():                                   # the warm-up carries no gradient (ctmrg.py:80)
+            for i in range(max(ctm_args.ctm_warmup_iter, ceil(env.chi / maxD ** 2))):
+                t0 = time.perf_counter(); _ctmrg_iter(i, loc_ctm_args=wargs); eng.sync(); t_ctm += time.perf_counter() - t0
     for i in range(ctm_args.ctm_max_iter):
         t0 = time.perf_counter()
         _ctmrg_iter(i)

@@ -210,6 +210,22 @@ _C_KIND = {(-1, -1): (0, 3, 4), (1, -1): (1, 2, 3), (1, 1): (2, 1, 2), (-1, 1): 
 _T_KIND = {(0, -1): 4, (-1, 0): 5, (0, 1): 6, (1, 0): 7}
 
 
+_PIECE_EXPR = ['mijef,mijab->eafb', 'miefj,miabj->eafb', 'mefij,mabij->eafb', 'meijf,maijb->eafb',
+               'miefg,miabc->eafbgc', 'meifg,maibc->eafbgc', 'mefig,mabic->eafbgc', 'mefgi,mabci->eafbgc']
+
+
+def _init_piece(eng, kind, A):
+    """Double-layer partial trace number `kind` of the site A, fused leg pairs, divided by its max-abs.  A site that is being
+    optimised gets it as a differentiable native contraction node, the scale taken without gradient (env.py:369-372)."""
+    from linalg.native_einsum import needs_grad, einsum
+    if not needs_grad(A):
+        return eng.init_piece(kind, A)
+    r = einsum(_PIECE_EXPR[kind], A, A, conj=(1,))
+    sh = r.shape
+    r = r.reshape([sh[2 * i] * sh[2 * i + 1] for i in range(len(sh) // 2)])
+    return r / r.detach().abs().max()
+
+
 def init_from_ipeps_pbc(state, env, verbosity=0):
     """env.py:367-536: each env tensor of `coord` = normalised double-layer partial trace of the
     neighbouring site in direction vec (native kernel), zero padded to chi."""
@@ -219,7 +235,7 @@ def init_from_ipeps_pbc(state, env, verbosity=0):
     for coord in state.sites.keys():
         for vec, (kind, i0, i1) in _C_KIND.items():
             A = state.site((coord[0] + vec[0], coord[1] + vec[1]))
-            a = eng.init_piece(kind, A)
+            a = _init_piece(eng, kind, A)
             C = torch.zeros(chi, chi, **o)
             m0, m1 = min(chi, A.size(i0) ** 2), min(chi, A.size(i1) ** 2)
             C[:m0, :m1] = a[:m0, :m1]
@@ -227,7 +243,7 @@ def init_from_ipeps_pbc(state, env, verbosity=0):
         for vec, kind in _T_KIND.items():
             A = state.site((coord[0] + vec[0], coord[1] + vec[1]))
             d = A.size()
-            a = eng.init_piece(kind, A)
+            a = _init_piece(eng, kind, A)
             if vec == (0, -1):
                 T = torch.zeros((chi, d[3] ** 2, chi), **o); m0, m2 = min(chi, d[2] ** 2), min(chi, d[4] ** 2)
                 T[:m0, :, :m2] = a[:m0, :, :m2]

@@ -60,3 +60,43 @@ def run_c4v_optimizer(g, tmpdir, device="cpu", line_search="default", epochs=Non
     optimize_state(st, env, loss_fn, post_proc=post, main_args=main_args, opt_args=opt_args, ctm_args=ctm_args)
     best = read_ipeps_c4v(main_args.out_prefix + "_state.json")
     return hist["loss"], st.site().detach().cpu().numpy(), best.site().cpu().numpy()
+
+
+def run_generic_optimizer(g, tmpdir, device="cpu"):
+    """The loss function of examples/j1j2/optim_j1j2.py (init_env -> a fixed number of CTM iterations -> energy_2x2_4site) under
+    optim.ad_optim_lbfgs_mod.optimize_state, from the start tensors of the golden trajectory `g` (oracle/gen_golden.py
+    generic_optim_case).  Returns (losses per epoch, final parameters by site)."""
+    import copy, os
+    import torch
+    import config as cfg
+    from ipeps.ipeps import IPEPS
+    from ctm.generic.env import ENV, init_env
+    from ctm.generic import ctmrg
+    from models import j1j2
+    from optim.ad_optim_lbfgs_mod import optimize_state
+    sites = {tuple(int(v) for v in k.split('_')[1:]): torch.from_numpy(g[k].copy()).to(device) for k in g.files if k.startswith('site0_')}
+    st = IPEPS(sites, lX=max(k[0] for k in sites) + 1, lY=max(k[1] for k in sites) + 1)
+    model = j1j2.J1J2(j1=1.0, j2=float(g["j2"]))
+    ctm_args = copy.deepcopy(cfg.ctm_args); ctm_args.ctm_max_iter = int(g["ctm_iter"])
+    opt_args = copy.deepcopy(cfg.opt_args); opt_args.opt_logging = False
+    main_args = copy.deepcopy(cfg.main_args); main_args.opt_max_iter = int(g["epochs"])
+    main_args.out_prefix = os.path.join(str(tmpdir), "o"); main_args.opt_resume = None
+
+    @torch.no_grad()
+    def conv_f(state, env, history, ctm_args=ctm_args):
+        history = (history or []) + [0.]
+        return len(history) >= ctm_args.ctm_max_iter, history
+
+    def loss_fn(state, env, ctx):
+        if ctx["opt_args"].opt_ctm_reinit:
+            init_env(state, env)
+        env_out, *log_ = ctmrg.run(state, env, conv_check=conv_f, ctm_args=ctx["ctm_args"])
+        return (model.energy_2x2_4site(state, env), env, *log_)
+    hist = {}
+
+    def post(state, env, ctx):
+        hist["loss"] = list(ctx["loss_history"]["loss"])
+    env = ENV(int(g["chi"]), st)
+    init_env(st, env)
+    optimize_state(st, env, loss_fn, post_proc=post, main_args=main_args, opt_args=opt_args, ctm_args=ctm_args)
+    return hist["loss"], {c: t.detach().cpu().numpy() for c, t in st.sites.items()}

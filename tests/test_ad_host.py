@@ -300,3 +300,17 @@ def test_c4v_optimizer_line_searches_lower_the_energy(fake, ls, tmp_path):
     st = IPEPS_C4V()
     st.load_checkpoint(os.path.join(str(tmp_path), "o_checkpoint.p"))
     assert float((st.site().detach().cpu() - torch.from_numpy(site)).abs().max()) == 0.0 and not st.site().requires_grad
+
+
+@pytest.mark.parametrize("name", ["generic_optim_D2_chi8_f64", "generic_optim_D2_chi8_c128"])
+def test_generic_optimizer_follows_the_reference_trajectory(fake, name, tmp_path):
+    """The same on a 2x2 cell (examples/j1j2/optim_j1j2.py): init_env, 3 CTM iterations of 8 directional moves (32 full SVDs each
+    with the regularised backward) and the plaquette energy as one graph; L-BFGS losses and final tensors against the reference's
+    run (oracle/gen_golden.py generic_optim_case)."""
+    from helpers_cpu import run_generic_optimizer
+    g = golden(name)
+    losses, sites = run_generic_optimizer(g, tmp_path)
+    assert len(losses) == len(g["losses"])
+    assert float(np.abs(np.array(losses) - g["losses"]).max()) < 1e-8, (losses, g["losses"])
+    for c, t in sites.items():
+        assert float(np.abs(t - g[f"final_{c[0]}_{c[1]}"]).max()) < 1e-6, c

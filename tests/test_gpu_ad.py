@@ -280,3 +280,23 @@ def test_c4v_optimizer_follows_the_reference_trajectory_on_the_engine(eng, name,
     assert float(np.abs(np.array(losses) - g["losses"]).max()) < 1e-8, (losses, g["losses"])
     assert float(np.abs(site - g["site_final"]).max()) < 1e-6
     assert float(np.abs(best - g["best"]).max()) < 1e-6
+
+
+@pytest.mark.parametrize("name", ["generic_optim_D2_chi8_f64", "generic_optim_D2_chi8_c128"])
+def test_generic_optimizer_follows_the_reference_trajectory_on_the_engine(eng, name, tmp_path):
+    """examples/j1j2/optim_j1j2.py on a 2x2 cell: init_env -> 3 CTM iterations (8 directional moves each, 96 full SVDs with the
+    regularised backward in one graph) -> plaquette energy, under optim.ad_optim_lbfgs_mod.optimize_state; losses and final
+    tensors against the reference's own run (oracle/gen_golden.py generic_optim_case)."""
+    import config as cfg
+    from helpers_cpu import run_generic_optimizer
+    g = golden(name)
+    old = cfg.global_args.torch_dtype
+    cfg.global_args.torch_dtype = torch.complex128 if name.endswith("c128") else torch.float64
+    try:
+        losses, sites = run_generic_optimizer(g, tmp_path, device="cuda")
+    finally:
+        cfg.global_args.torch_dtype = old
+    assert len(losses) == len(g["losses"])
+    assert float(np.abs(np.array(losses) - g["losses"]).max()) < 1e-8, (losses, g["losses"])
+    for c, t in sites.items():
+        assert float(np.abs(t - g[f"final_{c[0]}_{c[1]}"]).max()) < 1e-6, c

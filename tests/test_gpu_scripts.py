@@ -83,3 +83,24 @@ def test_optim_j1j2_c4v_script(tmp_path):
     assert set(e) >= {-1, 1, 2, 3}, r.stdout[-2000:]
     assert e[3] <= e[1] + 1e-12 and e[3] < -0.4
     assert os.path.exists(pre + "_state.json") and os.path.exists(pre + "_checkpoint.p")
+
+
+def test_optim_j1j2_script(tmp_path):
+    """examples/j1j2/optim_j1j2.py of the reference (TestOptim_*: a few epochs from a random state on a small cell): BIPARTITE
+    tiling, D = 2, chi = 8, three epochs; one line per epoch, best state and checkpoint on disk, the energy goes down; then the
+    checkpoint resumes for one more epoch."""
+    env = dict(os.environ, PYTHONPATH=PKG + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    pre = str(tmp_path / "opt")
+    base = [sys.executable, os.path.join(PKG, "examples", "j1j2", "optim_j1j2.py"), "--tiling", "BIPARTITE", "--bond_dim", "2", "--chi", "8",
+            "--seed", "123", "--CTMARGS_ctm_max_iter", "10", "--GLOBALARGS_device", "cuda:0", "--j2", "0.2"]
+    r = subprocess.run(base + ["--opt_max_iter", "3", "--out_prefix", pre], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    rows = [l.split(", ") for l in r.stdout.splitlines() if l[:1].isdigit() or l.startswith("-1, ")]
+    e = {int(x[0]): float(x[1]) for x in rows}
+    assert set(e) >= {-1, 1, 2, 3}, r.stdout[-2000:]
+    assert e[3] < e[1]
+    assert os.path.exists(pre + "_state.json") and os.path.exists(pre + "_checkpoint.p")
+    r2 = subprocess.run(base + ["--opt_max_iter", "1", "--opt_resume", pre + "_checkpoint.p", "--out_prefix", pre + "b"], capture_output=True,
+                        text=True, env=env, timeout=900)
+    assert r2.returncode == 0, r2.stderr[-3000:]
+    assert "resuming from check point" in r2.stdout
