@@ -1115,6 +1115,22 @@ __global__ void fill_wq_c_kernel(const double* Mr, const double* Mi, int n, doub
     }
 }
 
+// X (2*np real rows x ld) <- panel layout of [ Y (n x n complex, planar) | W (n x n complex, planar) ], everything else zero
+__global__ void fill_wq_c2_kernel(const double* Yr, const double* Yi, const double* Wr, const double* Wi, int n, double* X, int np, long long ld) {
+    const long long W = n + np;
+    const size_t tot = (size_t)np * W;
+    for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < tot; q += (size_t)gridDim.x * blockDim.x) {
+        const long long r = q / W, c = q - r * W;
+        double vr = 0.0, vi = 0.0;
+        if (r < n) {
+            if (c < n) { vr = Yr[r * n + c]; vi = Yi[r * n + c]; }
+            else if (c - n < n) { vr = Wr[r * n + (c - n)]; vi = Wi[r * n + (c - n)]; }
+        }
+        const long long rr = (r / BC) * (2 * BC) + (r % BC);
+        X[rr * ld + c] = vr; X[(rr + BC) * ld + c] = vi;
+    }
+}
+
 // dst = i * src on panel rows: real-part rows <- -imag rows, imag rows <- real-part rows
 __global__ void panel_times_i_kernel(const double* src, long long lds, double* dst, long long ldd, int R, int cols) {
     const size_t tot = (size_t)R * cols;
@@ -2599,7 +2615,27 @@ int jacobi_eigh_top(ctm_ctx* ctx, const double* A, int n, int k, double* D, doub
     CTM_TRY(st);
     const double shift = fro * 1.0009765625 + 1e-300;
     CTM_TRY(symmetrize_lower(ctx, A, As, n, shift));
-    CTM_LAUNCH(ctx, fill_wq_kernel, dim3(2048), dim3(256), 0, As, n, n, (long long)n, X, np, ld, 1);
+    // Warm start of the FULL decomposition (k == n, the differentiable route of an optimisation: the same matrix comes back, slightly
+    // changed, epoch after epoch): with W = the previous eigenvector rows, the rows of W (A + shift I) are already almost
+    // orthogonal (off-diagonal Gram entries of the size of the change), so the sweeps start in the quadratically convergent regime.
+    // Any orthonormal W is a valid start -- the result does not depend on it beyond rounding.
+    bool warm_full = false;
+    if (warm && k == n && ctx->eigh_warm) {
+        int st2;
+        std::vector<double> hw;
+        const double fw = host_fro(ctx, warm, n, n, n, norms, hw, &st2);
+        CTM_TRY(st2);
+        warm_full = std::fabs(fw - std::sqrt((double)n)) <= 1e-6 * std::sqrt((double)n);
+        for (int i = 0; warm_full && i < n; ++i) warm_full = std::fabs(hw[i] - 1.0) <= 1e-6;
+    }
+    if (warm_full) {
+        CTM_TRY(fill_f64(ctx, X, (size_t)np * ld, 0.0));
+        GemmDesc gw; gw.M = n; gw.N = n; gw.K = n; gw.A = warm; gw.sam = n; gw.sak = 1; gw.B = As; gw.sbk = n; gw.sbn = 1; gw.C = X; gw.ldc = ld;
+        CTM_TRY(gemm_f64(ctx, gw));
+        CTM_TRY(copy2d(ctx, warm, n, X + n, ld, n, n));
+        ctx->eigh_warm_hits += 1;
+    } else
+        CTM_LAUNCH(ctx, fill_wq_kernel, dim3(2048), dim3(256), 0, As, n, n, (long long)n, X, np, ld, 1);
     CTM_TRY(jacobi_rows(ctx, X, np, ld, n, (int)ld, b, 0, shift * std::sqrt((double)n), ctx->jacobi_max_sweeps));
     CTM_TRY(row_norms(ctx, X, np, n, ld, norms));
     h.resize(np);
@@ -2623,6 +2659,7 @@ int jacobi_eigh_top(ctm_ctx* ctx, const double* A, int n, int k, double* D, doub
     GemmDesc g; g.M = k; g.N = n; g.K = n; g.A = Ut; g.sam = n; g.sak = 1; g.B = As; g.sbk = n; g.sbn = 1; g.C = Y; g.ldc = n;
     CTM_TRY(gemm_f64(ctx, g));
     CTM_TRY(row_dots(ctx, Y, Ut, k, n, n, D));
+    if (warm && k == n) CTM_HIP_CHECK(ctx, hipMemcpyAsync(warm, Ut, sizeof(double) * (size_t)n * n, hipMemcpyDeviceToDevice, ctx->stream));
     return CTM_OK;
 }
 
@@ -2698,7 +2735,27 @@ int jacobi_eigh_top_c(ctm_ctx* ctx, const double* Ar, const double* Ai, int n, i
     CTM_TRY(st);
     const double shift = fro * 1.0009765625 + 1e-300;
     CTM_TRY(hermitize_lower_c128(ctx, Ar, Ai, As, As + nn, n, shift));
-    CTM_LAUNCH(ctx, fill_wq_c_kernel, dim3(2048), dim3(256), 0, (const double*)As, (const double*)(As + nn), n, X, np, ld, 1);
+    bool warm_full = false;          // warm start of the full decomposition: see jacobi_eigh_top()
+    if (warm && k == n && ctx->eigh_warm) {
+        int st2;
+        std::vector<double> hw;
+        const double fw = host_fro(ctx, warm, 2 * n, n, n, norms, hw, &st2);
+        CTM_TRY(st2);
+        warm_full = std::fabs(fw - std::sqrt((double)n)) <= 1e-6 * std::sqrt((double)n);
+        for (int i = 0; warm_full && i < n; ++i) warm_full = std::fabs(std::sqrt(hw[i] * hw[i] + hw[n + i] * hw[n + i]) - 1.0) <= 1e-6;
+    }
+    if (warm_full) {
+        ArenaScope ws(ctx);
+        double* Yw;
+        CTM_TRY(arena_alloc(ctx, sizeof(double) * 2 * nn, (void**)&Yw));
+        XM w{warm, warm + nn, n, false, false}, a{As, As + nn, n, false, false};
+        CTM_TRY(xgemm(ctx, n, n, n, w, a, Yw, Yw + nn, n));                       // rows u^H (A + shift I)
+        CTM_LAUNCH(ctx, fill_wq_c2_kernel, dim3(2048), dim3(256), 0, (const double*)Yw, (const double*)(Yw + nn), (const double*)warm,
+                   (const double*)(warm + nn), n, X, np, ld);
+        CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));                     // Yw is released with the scope
+        ctx->eigh_warm_hits += 1;
+    } else
+        CTM_LAUNCH(ctx, fill_wq_c_kernel, dim3(2048), dim3(256), 0, (const double*)As, (const double*)(As + nn), n, X, np, ld, 1);
     CTM_TRY(jacobi_rows(ctx, X, 2 * np, ld, n, (int)ld, 2 * BC, 0, shift * std::sqrt((double)n), ctx->jacobi_max_sweeps, true));
     std::vector<double> hc;
     CTM_TRY(panel_row_norms(ctx, X, np, n, ld, norms, hc));
@@ -2721,6 +2778,7 @@ int jacobi_eigh_top_c(ctm_ctx* ctx, const double* Ar, const double* Ai, int n, i
     CTM_TRY(row_dots(ctx, Y, Ut, k, n, n, D));
     CTM_TRY(row_dots(ctx, Y + kn, Ut + kn, k, n, n, d2));
     CTM_LAUNCH(ctx, add_inplace_kernel, dim3((k + 255) / 256), dim3(256), 0, D, (const double*)d2, (size_t)k);
+    if (warm && k == n) CTM_HIP_CHECK(ctx, hipMemcpyAsync(warm, Ut, sizeof(double) * 2 * nn, hipMemcpyDeviceToDevice, ctx->stream));
     return CTM_OK;
 }
 

@@ -21,6 +21,7 @@ def run(state, env, conv_check=None, ctm_args=cfg.ctm_args, global_args=cfg.glob
     history = None
     for i in range(ctm_args.ctm_max_iter):
         t0 = time.perf_counter()
+        env.__dict__["_move_index"] = i          # the differentiable route keeps one eigenbasis per move of a run (see _ctm_MOVE_sl_ad)
         ctm_MOVE_sl(a, env, None, ctm_args=ctm_args, global_args=global_args)
         eng.sync()
         t1 = time.perf_counter()
@@ -64,9 +65,25 @@ def _ctm_MOVE_sl_ad(a, env, f_c2x2_decomp, norm_kind, ctm_args):
     from ctm.one_site_c4v.ctm_components_c4v import c2x2_sl
     from linalg.custom_eig import truncated_eig_sym
     if f_c2x2_decomp is None:
+        # An optimisation evaluates the same sequence of moves again and again on slowly changing tensors: move i of this run sees
+        # almost the matrix move i of the previous run saw.  The environment therefore keeps the eigenvectors of every move of a
+        # run (n x n each, handed on by ENV_C4V.detach()), and the full decomposition of the next evaluation starts from them.
+        basis = None
+        idx = env.__dict__.get("_move_index")
+        eng = get_engine()
+        if idx is not None and getattr(ctm_args, "projector_warm_start", True) and hasattr(eng, "warm_basis_c4v") and a.is_cuda:
+            n = env.chi * a.shape[1] ** 2
+            ws = env.__dict__.setdefault("_warm_ad", {})
+            basis = ws.get(idx)
+            if basis is None or tuple(basis.shape) != ((2 if a.is_complex() else 1) * n, n) or basis.device != a.device:
+                if len(ws) * n * n * 8 * (2 if a.is_complex() else 1) < 0.05 * torch.cuda.get_device_properties(a.device).total_memory:
+                    basis = ws[idx] = eng.warm_basis_c4v(n, n, a.dtype)
+                else:
+                    basis = None
+
         def f_c2x2_decomp(M, chi):
             return truncated_eig_sym(M, chi, keep_multiplets=True, eps_multiplet=1.0e-12, abs_tol=1.0e-14,
-                                     ad_decomp_reg=ctm_args.ad_decomp_reg)
+                                     ad_decomp_reg=ctm_args.ad_decomp_reg, basis=basis)
     chi = env.chi
 
     def core(a, C, T):

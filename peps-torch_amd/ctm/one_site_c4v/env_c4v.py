@@ -34,6 +34,8 @@ class ENV_C4V():
         e = ENV_C4V(self.chi, bond_dim=self.bond_dim, ctm_args=ctm_args, global_args=global_args)
         e.dtype, e.device = self.dtype, self.device
         e.C[e.keyC] = f(self.get_C()); e.T[e.keyT] = f(self.get_T())
+        if "_warm_ad" in self.__dict__:          # solver workspaces of the differentiable route travel with the environment
+            e.__dict__["_warm_ad"] = self.__dict__["_warm_ad"]
         return e
 
     def clone(self, ctm_args=cfg.ctm_args, global_args=cfg.global_args): return self._like(lambda t: t.clone(), ctm_args, global_args)

@@ -25,11 +25,12 @@ def _multiplet_chi(D, chi, eps_multiplet, abs_tol):
 
 
 def truncated_eig_sym(M, chi, abs_tol=1.0e-14, rel_tol=None, ad_decomp_reg=1.0e-12,
-                      keep_multiplets=False, eps_multiplet=1.0e-12, verbosity=0):
+                      keep_multiplets=False, eps_multiplet=1.0e-12, verbosity=0, basis=None):
+    """basis (differentiable route only): warm-start workspace of the full decomposition, see SYMEIG.forward."""
     eng = get_engine()
     if needs_grad(M):
         from linalg.eig_sym import SYMEIG
-        D, U = SYMEIG.apply(M, ad_decomp_reg)
+        D, U = SYMEIG.apply(M, ad_decomp_reg, basis)
         n = D.shape[0]
         if keep_multiplets and chi < n:
             chi_new = _multiplet_chi(D, chi, eps_multiplet, abs_tol)

@@ -7,9 +7,12 @@ from backend import get_engine
 
 class SYMEIG(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, A, ad_decomp_reg):
+    def forward(ctx, A, ad_decomp_reg, basis=None):
+        """basis: optional n x n workspace (engine.warm_basis_c4v(n, n, dtype)) holding the eigenvectors of the previous call on a
+        nearby matrix -- the Jacobi sweeps then start from rows that are already almost orthogonal; updated in place."""
         eng = get_engine()
-        D, U = eng.truncated_eigh(A.detach(), A.shape[0], eng.cfg(keep_multiplets=False))
+        kw = {"basis": basis} if basis is not None else {}
+        D, U = eng.truncated_eigh(A.detach(), A.shape[0], eng.cfg(keep_multiplets=False), **kw)
         ctx.save_for_backward(D, U)
         ctx.reg = float(ad_decomp_reg)
         return D, U
@@ -17,4 +20,4 @@ class SYMEIG(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dD, dU):
         D, U = ctx.saved_tensors
-        return get_engine().eigh_backward(D, U, dD, dU, reg=ctx.reg), None
+        return get_engine().eigh_backward(D, U, dD, dU, reg=ctx.reg), None, None

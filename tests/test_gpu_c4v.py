@@ -369,3 +369,45 @@ def test_c4v_correlators_and_transfer_spectrum(eng, base):
         top2 = transferops_c4v.get_Top2_spec_c4v(2, st, env).cpu().numpy()
         ref2 = j[f"{base}_top2"]
         assert float(np.abs(np.hypot(top2[:, 0], top2[:, 1]) - np.hypot(ref2[:, 0], ref2[:, 1])).max()) < 1e-8
+
+
+@pytest.mark.parametrize("cplx", [False, True])
+def test_full_decomposition_warm_start_changes_the_work_not_the_result(eng, cplx):
+    """k = n (the differentiable route's SYMEIG node) with a workspace of n rows: the second call on a slightly changed matrix starts
+    the Jacobi sweeps from the previous eigenvector rows -- fewer sweeps, same eigenpairs as a cold call (clusters and exact
+    degeneracies included: any orthonormal start is valid)."""
+    n = 384
+    g = torch.Generator().manual_seed(17)
+    lam = torch.cat([torch.linspace(1.0, 0.2, n - 8, dtype=torch.float64) * torch.where(torch.arange(n - 8) % 4 == 2, -1.0, 1.0),
+                     torch.tensor([0.15, 0.15, 0.15, -0.15, 1e-9, 1e-9, 0.0, 0.0], dtype=torch.float64)])
+    if cplx:
+        Q, _ = torch.linalg.qr(torch.randn(n, n, generator=g, dtype=torch.complex128))
+        P = torch.randn(n, n, generator=g, dtype=torch.complex128); P = 0.5 * (P + P.conj().T)
+    else:
+        Q, _ = torch.linalg.qr(torch.randn(n, n, generator=g, dtype=torch.float64))
+        P = torch.randn(n, n, generator=g, dtype=torch.float64); P = 0.5 * (P + P.T)
+    A0 = ((Q * lam) @ Q.conj().T).cuda()
+    A1 = (A0 + 1e-4 * P.cuda() / n ** 0.5)
+    A1 = 0.5 * (A1 + A1.conj().T)
+    cfgT = eng.cfg(keep_multiplets=False)
+    basis = eng.warm_basis_c4v(n, n, A0.dtype)
+    assert tuple(basis.shape) == ((2 if cplx else 1) * n, n)
+    eng.timers(reset=True)
+    eng.truncated_eigh(A0, n, cfgT, basis=basis)                      # cold: fills the workspace
+    cold_sweeps = eng.stat("total_sweeps")
+    assert eng.stat("eigh_warm_hits") == 0
+    eng.timers(reset=True)
+    D1, U1 = eng.truncated_eigh(A1, n, cfgT, basis=basis)
+    assert eng.stat("eigh_warm_hits") == 1 and eng.stat("total_sweeps") < cold_sweeps
+    Dc, Uc = eng.truncated_eigh(A1, n, cfgT)
+    assert float((D1 - Dc).abs().max()) < 1e-13
+    I = torch.eye(n, device=U1.device, dtype=U1.dtype)
+    assert float((U1.conj().T @ U1 - I).abs().max()) < 1e-12
+    assert float(((A1 @ U1) - U1 * D1.to(U1.dtype)).abs().max()) < 1e-12
+    w = torch.linalg.eigvalsh(A1.cpu())
+    w = w[torch.argsort(-w.abs())]
+    assert float((D1.cpu() - w).abs().max()) < 1e-13
+    # a stale workspace (zeros, or rows that are not orthonormal) is ignored
+    eng.timers(reset=True)
+    D2, _ = eng.truncated_eigh(A1, n, cfgT, basis=torch.zeros_like(basis))
+    assert eng.stat("eigh_warm_hits") == 0 and float((D2 - Dc).abs().max()) < 1e-13
