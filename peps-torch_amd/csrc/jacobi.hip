@@ -627,8 +627,12 @@ int get_tables(ctm_ctx* ctx, int nbk, long long ld, int b, int Cg, RRTables** ou
 // its pair and finishes reading it before it writes.
 // ktop > 0: only the ktop largest rows need full relative accuracy -- pairs of smaller rows are measured against
 // tau = (ktop-th largest row norm), which still bounds the spectral norm of the remaining rows by tau(1 + R tol).
+// null_rel > 0 (full decompositions whose numerically null rows are rebuilt afterwards, see svd_full): pairs of rows that are BOTH below
+// null_rel x the largest row norm are not rotated against each other -- such rows are rounding noise of the big ones, their mutual
+// overlaps never settle (every rotation with a big row re-injects noise of their own size) and the accumulated rotations stay
+// orthogonal whether or not they are touched.
 int jacobi_rows(ctm_ctx* ctx, double* X, int R, long long ld, int Cg, int Ctot, int b, int ktop, double fro, int max_sweeps, bool cplx = false,
-                bool tau_both = false) {
+                bool tau_both = false, double null_rel = 0.0) {
     const int nbk = R / b, rounds = nbk - 1, pairs = nbk / 2, m = 2 * b;
     if (cplx && b != 32) { ctx->set_error("jacobi_rows: complex panels are 16 + 16 real rows"); return CTM_ERR_BADARG; }
     RRTables* T;
@@ -659,6 +663,16 @@ int jacobi_rows(ctm_ctx* ctx, double* X, int R, long long ld, int Cg, int Ctot, 
             }
             std::nth_element(h.begin(), h.begin() + (ktop - 1), h.begin() + nr, std::greater<double>());
             tau2 = std::max(floor2, h[ktop - 1] * h[ktop - 1]);
+        }
+        if (null_rel > 0.0) {
+            CTM_TRY(row_norms(ctx, X, R, Cg, ld, norms));
+            CTM_HIP_CHECK(ctx, hipMemcpyAsync(h.data(), norms, sizeof(double) * R, hipMemcpyDeviceToHost, ctx->stream));
+            CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+            double mx2 = 0.0;
+            if (cplx) { for (int cr = 0; cr < R / 2; ++cr) { const int rr = (cr / 16) * 32 + (cr % 16); mx2 = std::max(mx2, h[rr] * h[rr] + h[rr + 16] * h[rr + 16]); } }
+            else for (int i = 0; i < R; ++i) mx2 = std::max(mx2, h[i] * h[i]);
+            tau2 = std::max(tau2, null_rel * null_rel * mx2);
+            tau_both = true;
         }
         CTM_HIP_CHECK(ctx, hipMemsetAsync(stat, 0, 2 * sizeof(double), ctx->stream));
         for (int r = 0; r < rounds; ++r) {
@@ -711,6 +725,11 @@ inline int padded(int n, int b) {
     if (nbk < 2) nbk = 2;
     if (nbk & 1) ++nbk;
     return nbk * b;
+}
+
+__global__ void sub_eye_kernel(double* G, int m) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < m) G[(size_t)i * m + i] -= 1.0;
 }
 
 // dst (R x ld) <- [ src (rows x cols, lds) zero padded to R rows | identity (R x R) if with_eye ] ; other columns untouched
@@ -797,7 +816,10 @@ double host_fro(ctm_ctx* ctx, const double* M, int rows, int cols, long long ld,
 // ---------------------------------------------------------------------------------------------
 // full decomposition: every row pair is orthogonalised (O(n^3) per sweep)
 // ---------------------------------------------------------------------------------------------
-int svd_full(ctm_ctx* ctx, const double* M, int n, int k, double* S, double* Ut, double* Vt) {
+// warm (optional, k == n only): n x n workspace with the left vectors u_i^T of the previous decomposition of a nearby matrix.  The rows
+// of W M are then almost orthogonal already and the sweeps start in the quadratically convergent regime (the differentiable route
+// of an optimisation decomposes the same sequence of matrices again and again); any orthonormal W is a valid start.  Updated.
+int svd_full(ctm_ctx* ctx, const double* M, int n, int k, double* S, double* Ut, double* Vt, double* warm = nullptr) {
     const int b = choose_block(ctx, n), np = padded(n, b);
     ArenaScope scope(ctx);
     const bool with_q = (Ut != nullptr);
@@ -807,13 +829,30 @@ int svd_full(ctm_ctx* ctx, const double* M, int n, int k, double* S, double* Ut,
     CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)np * ld, (void**)&X));
     CTM_TRY(arena_alloc(ctx, sizeof(double) * np, (void**)&norms));
     CTM_TRY(arena_alloc(ctx, sizeof(int) * np, (void**)&d_idx));
-    CTM_LAUNCH(ctx, fill_wq_kernel, dim3(2048), dim3(256), 0, M, n, n, (long long)n, X, np, ld, with_q ? 1 : 0);
     std::vector<double> h;
     int st;
+    bool warm_full = false;
+    if (warm && with_q && k == n && ctx->eigh_warm) {
+        const double fw = host_fro(ctx, warm, n, n, n, norms, h, &st);
+        CTM_TRY(st);
+        warm_full = std::fabs(fw - std::sqrt((double)n)) <= 1e-6 * std::sqrt((double)n);
+        for (int i = 0; warm_full && i < n; ++i) warm_full = std::fabs(h[i] - 1.0) <= 1e-6;
+    }
+    if (warm_full) {
+        CTM_TRY(fill_f64(ctx, X, (size_t)np * ld, 0.0));
+        GemmDesc gw; gw.M = n; gw.N = n; gw.K = n; gw.A = warm; gw.sam = n; gw.sak = 1; gw.B = M; gw.sbk = n; gw.sbn = 1; gw.C = X; gw.ldc = ld;
+        CTM_TRY(gemm_f64(ctx, gw));
+        CTM_TRY(copy2d(ctx, warm, n, X + n, ld, n, n));
+        ctx->eigh_warm_hits += 1;
+    } else
+        CTM_LAUNCH(ctx, fill_wq_kernel, dim3(2048), dim3(256), 0, M, n, n, (long long)n, X, np, ld, with_q ? 1 : 0);
     const double fro = host_fro(ctx, X, np, n, ld, norms, h, &st);
     CTM_TRY(st);
-    CTM_TRY(jacobi_rows(ctx, X, np, ld, n, (int)ld, b, (k < n) ? k : 0, fro, ctx->jacobi_max_sweeps));
+    // full decomposition with vectors: rows below 0.1 svd_null_tol s_0 are rebuilt as an orthonormal complement below anyway
+    const double null_rel = (Ut && Vt && k == n) ? 0.1 * ctx->svd_null_tol : 0.0;
+    CTM_TRY(jacobi_rows(ctx, X, np, ld, n, (int)ld, b, (k < n) ? k : 0, fro, ctx->jacobi_max_sweeps, false, false, null_rel));
     CTM_TRY(row_norms(ctx, X, np, n, ld, norms));
+    h.resize(np);
     CTM_HIP_CHECK(ctx, hipMemcpyAsync(h.data(), norms, sizeof(double) * np, hipMemcpyDeviceToHost, ctx->stream));
     CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     std::vector<int> idx(np);
@@ -829,6 +868,7 @@ int svd_full(ctm_ctx* ctx, const double* M, int n, int k, double* S, double* Ut,
     // k x n x n GEMM so that S and V carry no accumulated rounding of the sweeps (|error| = O(eps |M|)).
     CTM_TRY(gather_rows(ctx, X + n, ld, d_idx, k, n, Ut, n, nullptr));
     CTM_TRY(reorth_rows(ctx, Ut, k, n, n, 2));
+    if (warm && k == n) CTM_HIP_CHECK(ctx, hipMemcpyAsync(warm, Ut, sizeof(double) * (size_t)n * n, hipMemcpyDeviceToDevice, ctx->stream));
     if (Vt) {
         double* inv;
         CTM_TRY(arena_alloc(ctx, sizeof(double) * k, (void**)&inv));
@@ -853,9 +893,67 @@ int svd_full(ctm_ctx* ctx, const double* M, int n, int k, double* S, double* Ut,
             GemmDesc gp; gp.M = n; gp.N = n; gp.K = kg; gp.A = Vt; gp.sam = 1; gp.sak = n; gp.B = Vt; gp.sbk = n; gp.sbn = 1; gp.C = Pm; gp.ldc = n;
             gp.alpha = -1.0; gp.beta = 1.0;
             CTM_TRY(gemm_f64(ctx, gp));
-            CTM_TRY(jacobi_eigh_top(ctx, Pm, n, k - kg, Dn, Wn, nullptr));
-            CTM_HIP_CHECK(ctx, hipMemcpyAsync(Vt + (size_t)kg * n, Wn, sizeof(double) * (size_t)(k - kg) * n, hipMemcpyDeviceToDevice, ctx->stream));
-            CTM_TRY(reorth_rows(ctx, Vt, k, n, n, 1));
+            // Full complement (k == n): the n - kg rows of the projector with the largest norm (|P e_j|^2 = P_jj: pivoting) span it unless
+            // they happen to be dependent; a row Jacobi on those m rows (m^2 n work instead of the n^3 of the projector's
+            // eigendecomposition) orthogonalises them, and row norms that stay O(1) certify the span.  Otherwise: eigenvectors.
+            bool done = false;
+            const int m = k - kg;
+            if (k == n) {
+                std::vector<double> pd(n);
+                CTM_HIP_CHECK(ctx, hipMemcpy2DAsync(pd.data(), sizeof(double), Pm, sizeof(double) * ((size_t)n + 1), sizeof(double), n,
+                                                    hipMemcpyDeviceToHost, ctx->stream));
+                CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+                std::vector<int> jd(n);
+                std::iota(jd.begin(), jd.end(), 0);
+                std::stable_sort(jd.begin(), jd.end(), [&](int a, int c) { return pd[a] > pd[c]; });
+                const int b2 = choose_block(ctx, n), mp = padded(m, b2);
+                ArenaScope zs(ctx);
+                double *Z, *zn;
+                int* dj;
+                CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)mp * n, (void**)&Z));
+                CTM_TRY(arena_alloc(ctx, sizeof(double) * mp, (void**)&zn));
+                CTM_TRY(arena_alloc(ctx, sizeof(int) * mp, (void**)&dj));
+                CTM_HIP_CHECK(ctx, hipMemcpyAsync(dj, jd.data(), sizeof(int) * m, hipMemcpyHostToDevice, ctx->stream));
+                CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+                CTM_TRY(fill_f64(ctx, Z, (size_t)mp * n, 0.0));
+                CTM_TRY(gather_rows(ctx, Pm, n, dj, m, n, Z, n, nullptr));
+                // orthonormalise the m rows: Newton-Schulz iteration for the polar factor, Z <- Z - (Z Z^T - I) Z / 2 (two small GEMMs per
+                // step; singular values of the pivoted rows lie in (0, 1], each step moves them towards 1, quadratically at the end)
+                double *G2, *Z2;
+                CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)m * m, (void**)&G2));
+                CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)mp * n, (void**)&Z2));
+                std::vector<double> hz(m);
+                double dev = 1.0;
+                for (int it = 0; it < 48; ++it) {
+                    GemmDesc gg; gg.M = m; gg.N = m; gg.K = n; gg.A = Z; gg.sam = n; gg.sak = 1; gg.B = Z; gg.sbk = 1; gg.sbn = n; gg.C = G2; gg.ldc = m;
+                    CTM_TRY(gemm_f64(ctx, gg));
+                    CTM_LAUNCH(ctx, sub_eye_kernel, dim3((m + 255) / 256), dim3(256), 0, G2, m);
+                    CTM_TRY(row_norms(ctx, G2, m, m, m, zn));
+                    CTM_HIP_CHECK(ctx, hipMemcpyAsync(hz.data(), zn, sizeof(double) * m, hipMemcpyDeviceToHost, ctx->stream));
+                    CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+                    const double prev = dev;
+                    dev = *std::max_element(hz.begin(), hz.end());
+                    if (!(dev == dev) || dev <= 1e-13 || (it > 0 && dev < 1e-10 && dev > 0.5 * prev)) break;    // converged / at the rounding floor
+                    CTM_HIP_CHECK(ctx, hipMemcpyAsync(Z2, Z, sizeof(double) * (size_t)m * n, hipMemcpyDeviceToDevice, ctx->stream));
+                    GemmDesc gz; gz.M = m; gz.N = n; gz.K = m; gz.A = G2; gz.sam = m; gz.sak = 1; gz.B = Z; gz.sbk = n; gz.sbn = 1; gz.C = Z2; gz.ldc = n;
+                    gz.alpha = -0.5; gz.beta = 1.0;
+                    CTM_TRY(gemm_f64(ctx, gz));
+                    std::swap(Z, Z2);
+                }
+                if (dev == dev && dev <= 1e-10) {
+                    CTM_HIP_CHECK(ctx, hipMemcpyAsync(Vt + (size_t)kg * n, Z, sizeof(double) * (size_t)m * n, hipMemcpyDeviceToDevice, ctx->stream));
+                    CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+                    done = true;
+                }
+            }
+            if (!done) {
+                const bool save = ctx->si_enable; ctx->si_enable = false;      // a projector's spectrum is flat: the leading-k iteration cannot converge on it
+                const int st3 = jacobi_eigh_top(ctx, Pm, n, m, Dn, Wn, nullptr);
+                ctx->si_enable = save;
+                CTM_TRY(st3);
+                CTM_HIP_CHECK(ctx, hipMemcpyAsync(Vt + (size_t)kg * n, Wn, sizeof(double) * (size_t)m * n, hipMemcpyDeviceToDevice, ctx->stream));
+            }
+            CTM_TRY(reorth_rows(ctx, Vt, k, n, n, done ? 2 : 1));
         } else
             CTM_TRY(reorth_rows(ctx, Vt, k, n, n, 2));
     }
@@ -1223,22 +1321,42 @@ int reorth_rows_c(ctm_ctx* ctx, double* V, int k, int n, int iters) {
     return CTM_OK;
 }
 
-int svd_full_c(ctm_ctx* ctx, const double* Mr, const double* Mi, int n, int k, double* S, double* Ut, double* Vt) {
+int svd_full_c(ctm_ctx* ctx, const double* Mr, const double* Mi, int n, int k, double* S, double* Ut, double* Vt, double* warm = nullptr) {
     const int np = padded(n, BC);
     ArenaScope scope(ctx);
     const bool with_q = (Ut != nullptr);
     const long long ld = (long long)n + (with_q ? np : 0);
+    const size_t nn = (size_t)n * n;
     double *X, *norms;
     int* d_idx;
     CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)2 * np * ld, (void**)&X));
     CTM_TRY(arena_alloc(ctx, sizeof(double) * 2 * np, (void**)&norms));
     CTM_TRY(arena_alloc(ctx, sizeof(int) * 2 * np, (void**)&d_idx));
-    CTM_LAUNCH(ctx, fill_wq_c_kernel, dim3(2048), dim3(256), 0, Mr, Mi, n, X, np, ld, with_q ? 1 : 0);
     std::vector<double> h;
     int st;
+    bool warm_full = false;          // warm start of the full decomposition (planar rows u_i^H): see svd_full()
+    if (warm && with_q && k == n && ctx->eigh_warm) {
+        const double fw = host_fro(ctx, warm, 2 * n, n, n, norms, h, &st);
+        CTM_TRY(st);
+        warm_full = std::fabs(fw - std::sqrt((double)n)) <= 1e-6 * std::sqrt((double)n);
+        for (int i = 0; warm_full && i < n; ++i) warm_full = std::fabs(std::sqrt(h[i] * h[i] + h[n + i] * h[n + i]) - 1.0) <= 1e-6;
+    }
+    if (warm_full) {
+        ArenaScope ws(ctx);
+        double* Yw;
+        CTM_TRY(arena_alloc(ctx, sizeof(double) * 2 * nn, (void**)&Yw));
+        XM w{warm, warm + nn, n, false, false}, m{Mr, Mi, n, false, false};
+        CTM_TRY(xgemm(ctx, n, n, n, w, m, Yw, Yw + nn, n));
+        CTM_LAUNCH(ctx, fill_wq_c2_kernel, dim3(2048), dim3(256), 0, (const double*)Yw, (const double*)(Yw + nn), (const double*)warm,
+                   (const double*)(warm + nn), n, X, np, ld);
+        CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->eigh_warm_hits += 1;
+    } else
+        CTM_LAUNCH(ctx, fill_wq_c_kernel, dim3(2048), dim3(256), 0, Mr, Mi, n, X, np, ld, with_q ? 1 : 0);
     const double fro = host_fro(ctx, X, 2 * np, n, ld, norms, h, &st);
     CTM_TRY(st);
-    CTM_TRY(jacobi_rows(ctx, X, 2 * np, ld, n, (int)ld, 2 * BC, (k < n) ? k : 0, fro, ctx->jacobi_max_sweeps, true));
+    const double null_rel = (Ut && Vt && k == n) ? 0.1 * ctx->svd_null_tol : 0.0;       // see svd_full()
+    CTM_TRY(jacobi_rows(ctx, X, 2 * np, ld, n, (int)ld, 2 * BC, (k < n) ? k : 0, fro, ctx->jacobi_max_sweeps, true, false, null_rel));
     std::vector<double> hc;
     CTM_TRY(panel_row_norms(ctx, X, np, n, ld, norms, hc));
     std::vector<int> idx(np);
@@ -1252,6 +1370,7 @@ int svd_full_c(ctm_ctx* ctx, const double* Mr, const double* Mi, int n, int k, d
     // rows of the accumulated unitary Q are u_k^H; Sigma V^H = Q M is recomputed by one k x n x n product (drift-free)
     CTM_TRY(panel_gather(ctx, X + n, ld, idx, k, n, Ut, d_idx));
     CTM_TRY(reorth_rows_c(ctx, Ut, k, n, 2));
+    if (warm && k == n) CTM_HIP_CHECK(ctx, hipMemcpyAsync(warm, Ut, sizeof(double) * 2 * nn, hipMemcpyDeviceToDevice, ctx->stream));
     if (Vt) {
         const size_t kn = (size_t)k * n;
         double* inv;
@@ -1279,7 +1398,12 @@ int svd_full_c(ctm_ctx* ctx, const double* Mr, const double* Mi, int n, int k, d
             XM ah{Vg, Vg + (size_t)kg * n, n, true, true}, a{Vg, Vg + (size_t)kg * n, n, false, false};
             CTM_TRY(xgemm(ctx, n, n, kg, ah, a, Pr, Pi, n));
             CTM_LAUNCH(ctx, eye_minus_kernel, dim3(1024), dim3(256), 0, Pr, Pi, n);
-            CTM_TRY(jacobi_eigh_top_c(ctx, Pr, Pi, n, kb, Dn, Wn, nullptr));
+            {
+                const bool save = ctx->si_enable; ctx->si_enable = false;      // a projector's spectrum is flat: the leading-k iteration cannot converge on it
+                const int st3 = jacobi_eigh_top_c(ctx, Pr, Pi, n, kb, Dn, Wn, nullptr);
+                ctx->si_enable = save;
+                CTM_TRY(st3);
+            }
             CTM_HIP_CHECK(ctx, hipMemcpyAsync(Vt, Vg, sizeof(double) * (size_t)kg * n, hipMemcpyDeviceToDevice, ctx->stream));
             CTM_HIP_CHECK(ctx, hipMemcpyAsync(Vt + kn, Vg + (size_t)kg * n, sizeof(double) * (size_t)kg * n, hipMemcpyDeviceToDevice, ctx->stream));
             CTM_HIP_CHECK(ctx, hipMemcpyAsync(Vt + (size_t)kg * n, Wn, sizeof(double) * (size_t)kb * n, hipMemcpyDeviceToDevice, ctx->stream));
@@ -2239,7 +2363,10 @@ int jacobi_svd_top_op(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* U
             }
             ctx->si_fallbacks += 1;
         }
-        if (op.M) { CTM_TRY(svd_full_c(ctx, op.M, op.Mi, n, k, S, Ut, Vt)); return keep_warm(); }
+        if (op.M) {
+            if (k == n) return svd_full_c(ctx, op.M, op.Mi, n, k, S, Ut, Vt, op.warm);     // full decomposition: the workspace keeps the left vectors
+            CTM_TRY(svd_full_c(ctx, op.M, op.Mi, n, k, S, Ut, Vt)); return keep_warm();
+        }
         ArenaScope scope(ctx);
         const size_t nn = (size_t)n * n;
         double *R, *Rt, *M;
@@ -2294,7 +2421,10 @@ int jacobi_svd_top_op(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* U
         }
         ctx->si_fallbacks += 1;
     }
-    if (op.M) { CTM_TRY(svd_full(ctx, op.M, n, k, S, Ut, Vt)); return keep_warm(); }
+    if (op.M) {
+        if (k == n) return svd_full(ctx, op.M, n, k, S, Ut, Vt, op.warm);                   // full decomposition: the workspace keeps the left vectors
+        CTM_TRY(svd_full(ctx, op.M, n, k, S, Ut, Vt)); return keep_warm();
+    }
     // materialise M = R^T Rt for the full decomposition: M = I * M
     ArenaScope scope(ctx);
     double *M, *I;

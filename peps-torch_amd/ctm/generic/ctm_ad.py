@@ -12,6 +12,7 @@ The tables are the reference's geometry: which environment tensors surround an e
 halves of a cut, which tensors an absorb reads (Appendix A of SURVEY.md)."""
 import torch
 import config as cfg
+from backend import get_engine
 from linalg.native_einsum import einsum, needs_grad
 
 LU, RU, RD, LD = 0, 1, 2, 3
@@ -92,13 +93,13 @@ def halves(direction, coord, state, env, four_by_two=False):
     return out[0], out[1]
 
 
-def projectors_from_matrices(R, Rt, chi, ctm_args=cfg.ctm_args):
+def projectors_from_matrices(R, Rt, chi, ctm_args=cfg.ctm_args, basis=None):
     """ctm_get_projectors_from_matrices (ctm_projectors.py:142-293) with the GESDD route: M = R^T R~ = U S V^H (full, regularised
     backward), S^-1/2 on the values above projector_svd_reltol, P = R conj(U) S^-1/2, P~ = R~ V S^-1/2."""
     from linalg.custom_svd import truncated_svd_gesdd
     M = einsum('ba,bc->ac', R, Rt)
     U, S, V = truncated_svd_gesdd(M, chi, keep_multiplets=True, abs_tol=ctm_args.projector_multiplet_abstol,
-                                  eps_multiplet=ctm_args.projector_eps_multiplet, ad_decomp_reg=ctm_args.ad_decomp_reg)
+                                  eps_multiplet=ctm_args.projector_eps_multiplet, ad_decomp_reg=ctm_args.ad_decomp_reg, basis=basis)
     nz = int((S.detach() / S.detach()[0] > ctm_args.projector_svd_reltol).sum())
     S_sqrt = torch.cat([torch.rsqrt(S[:nz]), torch.zeros(S.shape[0] - nz, dtype=S.dtype, device=S.device)])
     P = einsum('ab,bk->ak', R, U, conj=(1,)) * S_sqrt.to(U.dtype)[None, :]
@@ -127,6 +128,26 @@ def absorb(direction, coord, state, env, P, Pt):
     return nC1, nC2, nT.reshape(sh[:f0] + [sh[f0] * sh[f1]] + sh[f1 + 1:])
 
 
+def _warm_ws(env, coord, R, ctm_args):
+    """An optimisation evaluates the same sequence of moves again and again on slowly changing tensors: the decomposition of
+    (move of the run, site) sees almost the matrix it saw in the previous evaluation.  The environment keeps the left singular
+    vectors of each (set by ctmrg.run as env._move_index; handed on by ENV.detach()), and the next full decomposition starts from
+    them.  None outside a run, off the GPU, or when the workspaces would take more than 5 % of the device memory."""
+    idx = env.__dict__.get("_move_index")
+    eng = get_engine()
+    if idx is None or not getattr(ctm_args, "projector_warm_start", True) or not hasattr(eng, "warm_basis") or not R.is_cuda:
+        return None
+    n = R.shape[1]
+    ws = env.__dict__.setdefault("_warm_ad", {})
+    key = (idx, coord)
+    b = ws.get(key)
+    if b is None or tuple(b.shape) != ((2 if R.is_complex() else 1) * n + 1, n) or b.device != R.device:
+        if (len(ws) + 1) * n * n * 8 * (2 if R.is_complex() else 1) > 0.05 * torch.cuda.get_device_properties(R.device).total_memory:
+            return None
+        b = ws[key] = eng.warm_basis(n, n, R.dtype)
+    return b
+
+
 def ctm_MOVE(direction, state, env, ctm_args=cfg.ctm_args):
     """ctm_MOVE (ctmrg.py:179-319): projectors of all sites from the old environment, absorb of all sites, each new tensor divided
     by its own norm taken without gradient (:210-230), scatter to coord - direction.  fwd_checkpoint_move recomputes in backward."""
@@ -144,7 +165,7 @@ def ctm_MOVE(direction, state, env, ctm_args=cfg.ctm_args):
         P, Pt = {}, {}
         for coord in keys_s:
             R, Rt = halves(direction, coord, st, ev, four_by_two)
-            P[coord], Pt[coord] = projectors_from_matrices(R, Rt, env.chi, ctm_args)
+            P[coord], Pt[coord] = projectors_from_matrices(R, Rt, env.chi, ctm_args, basis=_warm_ws(env, coord, R, ctm_args))
         out = []
         for coord in keys_s:
             new = absorb(direction, coord, st, ev, P, Pt)

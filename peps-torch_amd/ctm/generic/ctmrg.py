@@ -47,7 +47,8 @@ def run(state, env, conv_check=None, ctm_args=cfg.ctm_args, global_args=cfg.glob
         for direction in loc_ctm_args.ctm_move_sequence:
             diagnostics = {"ctm_i": i, "ctm_d": direction} if loc_ctm_args.verbosity_projectors > 0 else None
             n = state.lX if direction in [(-1, 0), (1, 0)] else state.lY
-            for _ in range(n):
+            for rep in range(n):
+                env.__dict__["_move_index"] = (i, direction, rep)       # the differentiable route keeps one basis per move of a run
                 ctm_MOVE(direction, state, env, ctm_args=loc_ctm_args, global_args=global_args,
                          verbosity=loc_ctm_args.verbosity_ctm_move, diagnostics=diagnostics)
 

@@ -44,7 +44,7 @@ class ENV():
         new = self.__class__.__new__(self.__class__)
         memo[id(self)] = new
         for k, v in self.__dict__.items():
-            if k not in ("_warm", "_corner_cache"):
+            if k not in ("_warm", "_corner_cache", "_warm_ad"):
                 new.__dict__[k] = copy.deepcopy(v, memo)
         return new
 
@@ -64,6 +64,8 @@ class ENV():
         e.dtype, e.device = self.dtype, self.device
         e.C = {k: f(c) for k, c in self.C.items()}
         e.T = {k: f(t) for k, t in self.T.items()}
+        if "_warm_ad" in self.__dict__:          # solver workspaces of the differentiable route travel with the environment
+            e.__dict__["_warm_ad"] = self.__dict__["_warm_ad"]
         return e
 
     def clone(self, ctm_args=cfg.ctm_args, global_args=cfg.global_args):

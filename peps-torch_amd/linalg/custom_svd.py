@@ -7,14 +7,15 @@ from linalg.native_einsum import needs_grad
 
 
 def truncated_svd_gesdd(M, chi, abs_tol=1.0e-14, rel_tol=None, ad_decomp_reg=1.0e-12,
-                        keep_multiplets=False, eps_multiplet=1.0e-12, verbosity=0, diagnostics=None):
+                        keep_multiplets=False, eps_multiplet=1.0e-12, verbosity=0, diagnostics=None, basis=None):
+    """basis (differentiable route only): warm-start workspace of the full decomposition, see SVDGESDD.forward."""
     eng = get_engine()
     if needs_grad(M):
         # the reference's own route (custom_svd.py:38-101): FULL decomposition through the differentiable SVDGESDD (native forward
         # with fix_svd_signs, regularised native backward), truncation by slicing / zeroing the cut multiplet
         from linalg.svd_gesdd import SVDGESDD
         from linalg.custom_eig import _multiplet_chi
-        U, S, V = SVDGESDD.apply(M, ad_decomp_reg)
+        U, S, V = SVDGESDD.apply(M, ad_decomp_reg, None, basis)
         if keep_multiplets and chi < S.shape[0]:
             chi_new = _multiplet_chi(S, chi, eps_multiplet, abs_tol)
             mask = torch.zeros(chi, dtype=S.dtype, device=S.device)

@@ -8,10 +8,13 @@ from backend import get_engine
 
 class SVDGESDD(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, A, cutoff, diagnostics=None):
+    def forward(ctx, A, cutoff, diagnostics=None, basis=None):
+        """basis: optional workspace (engine.warm_basis(n, n, dtype)) holding the left vectors of the previous call on a nearby
+        matrix -- the Jacobi sweeps then start from rows that are already almost orthogonal; updated in place."""
         eng = get_engine()
         n = min(A.shape)
-        U, S, V = eng.truncated_svd(A.detach(), n, eng.cfg(keep_multiplets=False))
+        kw = {"basis": basis} if basis is not None else {}
+        U, S, V = eng.truncated_svd(A.detach(), n, eng.cfg(keep_multiplets=False), **kw)
         ctx.save_for_backward(U, S, V)
         ctx.cutoff = float(cutoff)
         return U, S, V
@@ -19,4 +22,4 @@ class SVDGESDD(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gu, gsigma, gv):
         U, S, V = ctx.saved_tensors
-        return get_engine().svd_backward(U, S, V, gu, gsigma, gv, eps=ctx.cutoff), None, None
+        return get_engine().svd_backward(U, S, V, gu, gsigma, gv, eps=ctx.cutoff), None, None, None
