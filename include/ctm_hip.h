@@ -89,7 +89,9 @@ int ctm_truncated_svd(ctm_ctx* ctx, const double* M, int n, int chi, const ctm_t
 /* Same, warm started from the decomposition of a nearby matrix: `basis` as for ctm_projectors_4x4_ws ((min(chi+1,n) + 1) * n
  * doubles, CTM_C128 (2 min(chi+1,n) + 1) * n; zero-filled before the first call, passed again for the next matrix of the
  * sequence).  The result does not depend on the basis (residual-verified, and a full block started from it is not accepted
- * before its guard rows have seen the operator three times); only the work does. */
+ * before its guard rows have seen the operator three times); only the work does.
+ * chi >= n (FULL decomposition, the SVD node of the differentiable route): the workspace then keeps the n left vectors; the row
+ * Jacobi of the next call starts from W M (rows almost orthogonal when the matrix moved little) instead of M. */
 int ctm_truncated_svd_ws(ctm_ctx* ctx, const double* M, int n, int chi, const ctm_trunc_cfg* cfg, double* U, double* S,
                          double* V, double* basis);
 /* A symmetric (lower triangle referenced); D (chi, signed, ordered by |D| descending), U n x chi */
@@ -99,7 +101,9 @@ int ctm_truncated_eigh(ctm_ctx* ctx, const double* A, int n, int chi, const ctm_
  * first call.
  * A restart from the previous invariant subspace is accepted only if (a) every pair of a Rayleigh-Ritz inside it passes the
  * residual threshold of the cold solver and (b) a block of fresh pseudo-random rows iterated three times on the deflated matrix finds
- * nothing above the smallest accepted |lambda|; otherwise the regular iteration runs.  The result does not depend on the basis. */
+ * nothing above the smallest accepted |lambda|; otherwise the regular iteration runs.  The result does not depend on the basis.
+ * chi >= n (FULL decomposition, the SYMEIG node of the differentiable route): the workspace (n * n doubles) keeps all eigenvectors
+ * and the Jacobi sweeps of the next call start from W (A + shift I). */
 int ctm_truncated_eigh_ws(ctm_ctx* ctx, const double* A, int n, int chi, const ctm_trunc_cfg* cfg, double* D, double* U,
                           double* basis);
 /* SVD of a real SYMMETRIC matrix through its eigendecomposition (linalg/svd_symeig.py:12-34 SVDSYMEIG.forward and

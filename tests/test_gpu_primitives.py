@@ -187,3 +187,34 @@ def test_full_decomposition_of_a_rank_deficient_matrix_returns_orthonormal_facto
     Sref = torch.linalg.svdvals(M.cpu())
     assert float((S.cpu() - Sref).abs().max()) < 1e-12 * float(Sref[0])
     assert float((U * S.to(dt) @ V.conj().T - M).abs().max()) < 1e-12 * float(Sref[0])
+
+
+@pytest.mark.parametrize("cplx", [False, True])
+def test_full_svd_warm_start_and_rank_deficient_completion(eng, cplx):
+    """chi = n (the differentiable route's SVD node) with a workspace: the second call on a slightly changed matrix starts the sweeps
+    from the previous left vectors (fewer sweeps, same decomposition); the matrix has rank n - 40, so V's last 40 columns are an
+    orthonormal completion (float64: pivoted projector rows + Newton-Schulz) -- U, V unitary, U S V^H = M, S as LAPACK's."""
+    n, r = 320, 280
+    g = torch.Generator().manual_seed(23)
+    dt = torch.complex128 if cplx else torch.float64
+    A = torch.randn(n, r, generator=g, dtype=dt) @ torch.diag(torch.logspace(0, -6, r, dtype=torch.float64).to(dt)) @ torch.randn(r, n, generator=g, dtype=dt)
+    P = torch.randn(n, r, generator=g, dtype=dt)
+    M0 = A.cuda()
+    M1 = ((A + 1e-5 * P @ torch.linalg.pinv(torch.randn(n, r, generator=g, dtype=dt)) @ A)).cuda()      # same row space, slightly moved
+    cfgT = eng.cfg(keep_multiplets=False)
+    basis = eng.warm_basis(n, n, dt)
+    eng.timers(reset=True)
+    eng.truncated_svd(M0, n, cfgT, basis=basis)
+    cold = eng.stat("total_sweeps")
+    assert eng.stat("eigh_warm_hits") == 0
+    eng.timers(reset=True)
+    U, S, V = eng.truncated_svd(M1, n, cfgT, basis=basis)
+    assert eng.stat("eigh_warm_hits") == 1 and eng.stat("total_sweeps") <= cold
+    I = torch.eye(n, device=U.device, dtype=U.dtype)
+    assert float((U.conj().T @ U - I).abs().max()) < 1e-11
+    assert float((V.conj().T @ V - I).abs().max()) < 1e-11
+    s0 = float(S[0])
+    assert float(((U * S.to(U.dtype)) @ V.conj().T - M1).abs().max()) < 1e-11 * s0
+    ref = torch.linalg.svdvals(M1.cpu())
+    assert float((S.cpu() - ref).abs().max()) < 1e-12 * s0
+    assert int((S > 1e-11 * s0).sum()) == r
