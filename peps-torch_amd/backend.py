@@ -20,12 +20,27 @@ def set_engine(e):
     _override = e
 
 
+_by_stream = {}          # HIP stream handle -> worker engine bound to it (units.UnitPool registers its workers)
+
+
+def register_stream_engine(stream, e):
+    _by_stream[int(stream.cuda_stream)] = e
+
+
 def get_engine():
     e = getattr(_tls, "engine", None)
     if e is not None:
         return e
     if _override is not None:
         return _override
+    if _by_stream:
+        # autograd runs the backward of a node on the stream its forward ran on: a node built by a worker thread of the unit pool
+        # (differentiable moves) gets that worker's engine back, so that kernels, workspace and torch's allocator agree on the stream
+        import torch
+        if torch.cuda.is_available():
+            w = _by_stream.get(int(torch.cuda.current_stream().cuda_stream))
+            if w is not None:
+                return w
     import _native
     import config as cfg
     dev = str(getattr(cfg.global_args, "device", "") or "")

@@ -50,7 +50,11 @@ struct SmallEigParams {
 };
 
 // floor of the pair measure: with `both`, a pair that contains a row at or above the floor is measured relative to its own rows only
+// both == 2 (absolute accuracy, full decompositions of the differentiable route): tau2 holds s_0 (the largest row norm) and the pair
+// is measured against s_0 * max(|x_i|, |x_j|) instead of |x_i| |x_j| -- the orthogonality a pair needs for the reconstruction
+// U S V^H = M to hold to tol * s_0 (what LAPACK's bidiagonal SVD delivers), not for every small singular value to be relatively exact
 __device__ __forceinline__ double tau_floor(double a, double b, double tau2, int both) {
+    if (both == 2) return tau2 * sqrt(fmax(fabs(a), fabs(b)));
     return (both && (a >= tau2 || b >= tau2)) ? 0.0 : tau2;
 }
 
@@ -648,6 +652,7 @@ int jacobi_rows(ctm_ctx* ctx, double* X, int R, long long ld, int Cg, int Ctot, 
     std::vector<double> h(R);
     const double floor2 = (1e-14 * fro) * (1e-14 * fro);
     ctx->last_sweeps = 0;
+    bool abs_mode = false;
     for (int sweep = 0; sweep < max_sweeps; ++sweep) {
         double tau2 = floor2;
         if (ctx->jacobi_tau_relax && ktop > 0 && ktop < (cplx ? R / 2 : R)) {
@@ -673,6 +678,7 @@ int jacobi_rows(ctm_ctx* ctx, double* X, int R, long long ld, int Cg, int Ctot, 
             else for (int i = 0; i < R; ++i) mx2 = std::max(mx2, h[i] * h[i]);
             tau2 = std::max(tau2, null_rel * null_rel * mx2);
             tau_both = true;
+            if (ctx->svd_abs_accuracy) { tau2 = std::sqrt(mx2); abs_mode = true; }
         }
         CTM_HIP_CHECK(ctx, hipMemsetAsync(stat, 0, 2 * sizeof(double), ctx->stream));
         for (int r = 0; r < rounds; ++r) {
@@ -685,7 +691,7 @@ int jacobi_rows(ctm_ctx* ctx, double* X, int R, long long ld, int Cg, int Ctot, 
             CTM_TRY(gemm_f64(ctx, g));
             SmallEigParams sp;
             sp.G = G; sp.nsplit = T->nsplit; sp.split_stride = (long long)pairs * m * m; sp.J = J; sp.m = m; sp.tol = ctx->jacobi_tol * 0.1; sp.max_sweeps = (pairs == 1) ? 12 : (pairs >= 4 ? ctx->jacobi_inner_sweeps_many : ctx->jacobi_inner_sweeps);
-            sp.tau2 = tau2; sp.tau_both = tau_both ? 1 : 0; sp.stat_rel = stat; sp.stat_abs = stat + 1; sp.flags = flags;
+            sp.tau2 = tau2; sp.tau_both = abs_mode ? 2 : (tau_both ? 1 : 0); sp.stat_rel = stat; sp.stat_abs = stat + 1; sp.flags = flags;
             if (cplx) CTM_LAUNCH(ctx, small_eig_c_kernel, dim3(pairs), dim3(256), 0, sp);
             else if (m == 64 && ctx->eig64_pingpong) {
                 if (ctx->eig64_bpt == 4) CTM_LAUNCH(ctx, small_eig64_kernel<4>, dim3(pairs), dim3(256), 0, sp);

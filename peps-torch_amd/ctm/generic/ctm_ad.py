@@ -162,16 +162,34 @@ def ctm_MOVE(direction, state, env, ctm_args=cfg.ctm_args):
         ev = ENV(env.chi)
         ev.C = dict(zip(keys_C, tensors[len(keys_s):len(keys_s) + len(keys_C)]))
         ev.T = dict(zip(keys_T, tensors[len(keys_s) + len(keys_C):]))
+        # The sites of a move are independent (ctmrg.py:238-275) and a full decomposition at these sizes is latency bound (one
+        # workgroup per panel pair): like the forward-only path, they are issued from worker threads, each with its own native
+        # context and stream (units.UnitPool; autograd builds the per-site subgraphs from those threads, the phase barriers order
+        # the streams).  Grad mode is thread local: the workers inherit the caller's.
+        grad_on = torch.is_grad_enabled()
+
+        def proj(coord):
+            with torch.set_grad_enabled(grad_on):
+                R, Rt = halves(direction, coord, st, ev, four_by_two)
+                return projectors_from_matrices(R, Rt, env.chi, ctm_args, basis=_warm_ws(env, coord, R, ctm_args))
+
+        def absb(coord):
+            with torch.set_grad_enabled(grad_on):
+                new = absorb(direction, coord, st, ev, P, Pt)
+                with torch.no_grad():
+                    sc = [(t.abs().max() if norm_inf else torch.linalg.vector_norm(t)) for t in new]
+                return tuple(t / s for t, s in zip(new, sc))
+
+        pool = None
+        a0 = tensors[0]
+        if len(keys_s) > 1 and a0.is_cuda and getattr(ctm_args, "concurrent_units", True):
+            import units
+            n = env.chi * max(a0.shape[1:]) ** 2
+            pool = units.pool_for(get_engine(), len(keys_s), n, a0.is_complex(), est_bytes=40.0 * n * n * a0.element_size())
         P, Pt = {}, {}
-        for coord in keys_s:
-            R, Rt = halves(direction, coord, st, ev, four_by_two)
-            P[coord], Pt[coord] = projectors_from_matrices(R, Rt, env.chi, ctm_args, basis=_warm_ws(env, coord, R, ctm_args))
-        out = []
-        for coord in keys_s:
-            new = absorb(direction, coord, st, ev, P, Pt)
-            with torch.no_grad():
-                sc = [(t.abs().max() if norm_inf else torch.linalg.vector_norm(t)) for t in new]
-            out.append(tuple(t / s for t, s in zip(new, sc)))
+        for coord, (p_, pt_) in zip(keys_s, pool.map(proj, keys_s) if pool is not None else [proj(c) for c in keys_s]):
+            P[coord], Pt[coord] = p_, pt_
+        out = pool.map(absb, keys_s) if pool is not None else [absb(c) for c in keys_s]
         return tuple(x for trip in out for x in trip)
 
     tensors = tuple(state.sites[k] for k in keys_s) + tuple(env.C[k] for k in keys_C) + tuple(env.T[k] for k in keys_T)

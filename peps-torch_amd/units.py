@@ -36,6 +36,7 @@ class UnitPool:
                 s.wait_event(ev0)
                 if self.engines[slot] is None:
                     self.engines[slot] = self.main.spawn_worker()    # binds the current (= worker) stream
+                    backend.register_stream_engine(s, self.engines[slot])
                 backend.set_thread_engine(self.engines[slot])
                 try:
                     out = fn(item)
