@@ -352,7 +352,7 @@ def c4v_ad_case(name, base, nmoves=2, j2=0.5, complex_=False):
     print(f"  {name} ok  E={float(torch.real(e)):.12f} |grad|={np.linalg.norm(out['grad']):.6e} |grad_spec|={np.linalg.norm(out['grad_spec']):.6e}")
 
 
-def generic_ad_case(name, base, complex_=False, moves=((0, -1), (-1, 0), (0, 1), (1, 0)), j2=0.5, projector_method='4X4'):
+def generic_ad_case(name, base, complex_=False, moves=((0, -1), (-1, 0), (0, 1), (1, 0)), j2=0.5, projector_method='4X4', j3=0.0):
     """Gradient of energy_2x2_4site after one move per direction with respect to the four site tensors, by the reference's
     autograd through ctm_MOVE (halves, truncated_svd_gesdd / SVDGESDD.backward, projectors, absorb) and rdm2x2; the environment the
     moves start from (golden `base`: warm_*) is a constant."""
@@ -373,14 +373,16 @@ def generic_ad_case(name, base, complex_=False, moves=((0, -1), (-1, 0), (0, 1),
             ctmrg.ctm_MOVE(d, st, env)
     finally:
         cfg.ctm_args.projector_method = old
-    model = j1j2.J1J2(j1=1.0, j2=j2)
+    model = j1j2.J1J2(j1=1.0, j2=j2, j3=j3)
     # energy_per_site (models/j1j2.py:223-247) with rdm2x2_legacy standing in for rdm2x2 (opt_einsum is not installed here)
     e = 0.0
     for c in st.sites:
         e = e + torch.einsum('ijklabcd,ijklabcd', rdm.rdm2x2_legacy(c, st, env), model.get_hp(c))
+        if abs(j3) > 0:
+            e = e + j3 * j1j2.eval_nnnn_per_site((0, 0), st, env, model.obs_ops)          # :243-244
     e = torch.real(e) / len(st.sites)
     e.backward()
-    out = dict(energy=np.array(float(torch.real(e))), j2=np.array(j2), base=np.array(base), moves=np.array(moves),
+    out = dict(energy=np.array(float(torch.real(e))), j2=np.array(j2), j3=np.array(j3), base=np.array(base), moves=np.array(moves),
                projector_method=np.array(projector_method))
     for k, v in sites.items():
         out[f"grad_{k[0]}_{k[1]}"] = t2n(v.grad)
@@ -883,6 +885,8 @@ if __name__ == "__main__":
         generic_ad_case("generic_ad_D2_chi8_f64", "generic_D2_chi8_f64")
         generic_ad_case("generic_ad_D2_chi8_c128", "generic_D2_chi8_c128", complex_=True)
         generic_ad_case("generic_ad_D2_chi8_f64_4x2", "generic_D2_chi8_f64", moves=((0, -1), (1, 0)), projector_method='4X2')
+        generic_ad_case("generic_ad_D2_chi8_f64_j3", "generic_D2_chi8_f64", moves=((0, -1), (-1, 0)), j3=0.3)
+        generic_ad_case("generic_ad_D2_chi8_c128_j3", "generic_D2_chi8_c128", complex_=True, moves=((0, 1),), j3=0.3)
     if "c4v_optim" in which:
         c4v_optim_case("c4v_optim_D2_chi16", "c4v_D2_chi8")
         c4v_optim_case("c4v_optim_D2_chi16_c128", "c4v_D2_chi8_c128", complex_=True)

@@ -77,6 +77,8 @@ struct ctm_ctx {
     double si_tol = 2e-14;
     double rank_tol = 5e-13;             // numerical-rank threshold of the leading-k solvers (relative to s_0)
     long si_hits = 0, si_fallbacks = 0, si_total_iters = 0, si_warm_starts = 0;
+    int lz_abs_accuracy = 0;           // experiment: absolute criterion for the Ritz extraction of the block Krylov solver
+    bool force_abs = false;
     int svd_abs_accuracy = 1;          // full SVD with vectors (differentiable route): row pairs orthogonalised to tol * s_0 absolute (see tau_floor)
     int eigh_warm = 1;                 // symmetric problems with a warm basis: Rayleigh-Ritz in the warm subspace + deflated probe first
     long eigh_warm_hits = 0, eigh_warm_rejects = 0, eigh_probe_calls = 0;

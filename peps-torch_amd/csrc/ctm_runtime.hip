@@ -131,6 +131,7 @@ int ctm_set_option(ctm_ctx* ctx, const char* key, double value) {
     else if (k == "rows_target_wgs") ctx->rows_target_wgs = (int)value;
     else if (k == "eigh_warm") ctx->eigh_warm = (int)value;
     else if (k == "svd_abs_accuracy") ctx->svd_abs_accuracy = (int)value;
+    else if (k == "lz_abs_accuracy") ctx->lz_abs_accuracy = (int)value;
     else if (k == "splitk_max_tiles") ctx->splitk_max_tiles = (int)value;
     else if (k == "splitk_target_wgs") ctx->splitk_target_wgs = (int)value;
     else if (k == "rank_tol") ctx->rank_tol = value;

@@ -679,6 +679,12 @@ int jacobi_rows(ctm_ctx* ctx, double* X, int R, long long ld, int Cg, int Ctot, 
             tau2 = std::max(tau2, null_rel * null_rel * mx2);
             tau_both = true;
             if (ctx->svd_abs_accuracy) { tau2 = std::sqrt(mx2); abs_mode = true; }
+        } else if (ctx->force_abs && !cplx) {
+            // experiment knob (lz_abs_accuracy): the Ritz extraction of the block Krylov solver with the absolute criterion
+            CTM_TRY(row_norms(ctx, X, R, Cg, ld, norms));
+            CTM_HIP_CHECK(ctx, hipMemcpyAsync(h.data(), norms, sizeof(double) * R, hipMemcpyDeviceToHost, ctx->stream));
+            CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+            tau2 = *std::max_element(h.begin(), h.begin() + R); abs_mode = true;
         }
         CTM_HIP_CHECK(ctx, hipMemsetAsync(stat, 0, 2 * sizeof(double), ctx->stream));
         for (int r = 0; r < rounds; ++r) {
@@ -1893,7 +1899,9 @@ int svd_lanczos(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* Ut, dou
         GemmDesc ge; ge.M = m; ge.N = b; ge.K = n; ge.A = Zraw; ge.sam = n; ge.sak = 1; ge.B = Vn; ge.sbk = 1; ge.sbn = n; ge.C = E; ge.ldc = b;
         CTM_TRY(gemm_f64(ctx, ge));
         const bool save = ctx->si_enable; ctx->si_enable = false;
+        ctx->force_abs = ctx->lz_abs_accuracy != 0;
         const int st = svd_full(ctx, T, m, kq, Ss, Xt, Yt);                      // rows of Xt / Yt: x_i^T, y_i^T
+        ctx->force_abs = false;
         ctx->si_enable = save;
         CTM_TRY(st);
         ctx->lz_extractions += 1;

@@ -6,6 +6,7 @@ executor (`Engine.einsum`), layer by layer -- the double-layer site tensor of th
 import torch
 import config as cfg
 from backend import get_engine
+from linalg.native_einsum import einsum as _einsum, needs_grad as _needs_grad
 
 _UP, _LEFT, _DOWN, _RIGHT = (0, -1), (-1, 0), (0, 1), (1, 0)
 
@@ -33,19 +34,27 @@ def _split(t, axis, D):
     return t.reshape(s[:axis] + [D, D] + s[axis + 1:])
 
 
+def _dot3(v, E):
+    """sum_abc v_abc E_abc: one native contraction; with tensors that require grad the (chi D^2 chi-element) product in torch, whose
+    adjoint autograd knows (a contraction node with a scalar output has no adjoint network)."""
+    if _needs_grad(v, E):
+        return (v * E).sum()
+    return get_engine().einsum("abc,abc->", v.contiguous(), E.contiguous())
+
+
 def get_edge(coord, direction, state, env, verbosity=0):
     if direction not in _EDGE:
         raise ValueError("Invalid direction: " + str(direction))
     c = state.vertexToSite(coord)
     (c1, t, c2), expr = _EDGE[direction]
-    return get_engine().einsum(expr, env.C[(c, c1)], env.T[(c, t)], env.C[(c, c2)])
+    return _einsum(expr, env.C[(c, c1)], env.T[(c, t)], env.C[(c, c2)])
 
 
 def apply_edge(coord, direction, state, env, vec, verbosity=0):
     if vec.dim() != 3:
         raise ValueError("Unsupported edge: " + str(tuple(vec.shape)))
     E = get_edge(coord, direction, state, env)
-    return get_engine().einsum("abc,abc->", vec.contiguous(), E)
+    return _dot3(vec, E)
 
 
 def apply_TM_1sO(coord, direction, state, env, edge, op=None, verbosity=0):
@@ -65,7 +74,7 @@ def apply_TM_1sO(coord, direction, state, env, edge, op=None, verbosity=0):
     in_leg = {_UP: 3, _LEFT: 4, _DOWN: 1, _RIGHT: 2}[direction]          # site leg facing the incoming edge
     out_leg = {_UP: 1, _LEFT: 2, _DOWN: 3, _RIGHT: 4}[direction]
     E = _split(edge.contiguous(), 1, a.shape[in_leg])
-    out = get_engine().einsum(expr, T1, E, ket, a, T2, conj=(3,))
+    out = _einsum(expr, T1, E, ket, a, T2, conj=(3,))
     return out.reshape(out.shape[0], a.shape[out_leg] ** 2, out.shape[3])
 
 
@@ -78,7 +87,7 @@ def corrf_1sO1sO(coord, direction, state, env, op1, get_op2, dist, rl_0=None, ve
     rev = (-direction[0], -direction[1])
     E0 = get_edge(c0, rev, state, env) if rl_0 is None else rl_0[0](c0).contiguous()
     close = (lambda c, v: apply_edge(c, direction, state, env, v)) if rl_0 is None else \
-        (lambda c, v: eng.einsum("abc,abc->", v.contiguous(), rl_0[1](c).contiguous()))
+        (lambda c, v: _dot3(v, rl_0[1](c)))
     E1 = apply_TM_1sO(c0, direction, state, env, E0, op=op1)
     E0 = apply_TM_1sO(c0, direction, state, env, E0)
     corrf = torch.empty(dist + 1, dtype=state.dtype, device=state.device)

@@ -48,10 +48,26 @@ def _order(target, first, others, ext):
     return order
 
 
+def mark_stream(*tensors):
+    """Tell torch's caching allocator that these tensors are read on the CURRENT stream.  The site units of a differentiable move
+    run on worker streams (units.UnitPool) and autograd replays every node on the stream of its forward: a tensor allocated on one
+    stream is then an operand on another, and without the mark its block could be handed out again (on its own stream) as soon as
+    the last reference drops -- while the other stream's kernel that reads it is still queued."""
+    if not torch.cuda.is_available():
+        return
+    cur = None
+    for t in tensors:
+        if isinstance(t, torch.Tensor) and t.is_cuda:
+            if cur is None:
+                cur = torch.cuda.current_stream(t.device)
+            t.record_stream(cur)
+
+
 class EINSUM(torch.autograd.Function):
     @staticmethod
     def forward(ctx, expr, conj, *tensors):
         eng = get_engine()
+        mark_stream(*tensors)
         ctx.expr, ctx.conj = expr, tuple(conj)
         ctx.save_for_backward(*tensors)
         return eng.einsum(expr, *[t.detach() for t in tensors], conj=tuple(conj))
@@ -60,6 +76,7 @@ class EINSUM(torch.autograd.Function):
     def backward(ctx, gout):
         eng = get_engine()
         tensors = ctx.saved_tensors
+        mark_stream(gout, *tensors)
         lhs, out = ctx.expr.split("->")
         ins = lhs.split(",")
         ext = {}

@@ -4,6 +4,7 @@ backward = ctm_svd_backward (GEMMs + one elementwise kernel).  This is the decom
 (SURVEY 8 f4); the contractions of a move are differentiable nodes of their own (linalg/native_einsum.py, ctm/generic/ctm_ad.py)."""
 import torch
 from backend import get_engine
+from linalg.native_einsum import mark_stream
 
 
 class SVDGESDD(torch.autograd.Function):
@@ -12,6 +13,7 @@ class SVDGESDD(torch.autograd.Function):
         """basis: optional workspace (engine.warm_basis(n, n, dtype)) holding the left vectors of the previous call on a nearby
         matrix -- the Jacobi sweeps then start from rows that are already almost orthogonal; updated in place."""
         eng = get_engine()
+        mark_stream(A)
         n = min(A.shape)
         kw = {"basis": basis} if basis is not None else {}
         U, S, V = eng.truncated_svd(A.detach(), n, eng.cfg(keep_multiplets=False), **kw)
@@ -22,4 +24,5 @@ class SVDGESDD(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gu, gsigma, gv):
         U, S, V = ctx.saved_tensors
+        mark_stream(U, S, V, gu, gsigma, gv)
         return get_engine().svd_backward(U, S, V, gu, gsigma, gv, eps=ctx.cutoff), None, None, None

@@ -96,12 +96,12 @@ class J1J2():
         from ctm.generic import ctm_ad
         if ctm_ad.wants_grad(state, env):
             # differentiable route: the value stays a graph (no host floats), plaquettes one after the other
-            if abs(self.j3) > 0:
-                raise NotImplementedError("energy_per_site with tensors that require grad: the j3 correlator term is forward only")
             e = 0.
             for coord in coords:
                 r = rdm.rdm2x2(coord, state, env).cpu()
                 e = e + _cast_to_real(torch.einsum('ijklabcd,ijklabcd', r, self.get_hp(coord).to(r.dtype)))
+                if abs(self.j3) > 0:      # evaluated at (0,0) for every site of the cell (models/j1j2.py:243-244): transfer-matrix correlators as a graph
+                    e = e + _cast_to_real(self.j3 * eval_nnnn_per_site((0, 0), state, env, self.obs_ops)).cpu()
             return e / len(coords)
         groups = parallel.site_groups(len(coords))
         if any(len(g) > 1 for g in groups):

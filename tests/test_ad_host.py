@@ -134,12 +134,13 @@ def _generic_energy(name, fake_cfg, checkpoint=False):
     finally:
         fake_cfg.ctm_args.projector_method = old
         fake_cfg.ctm_args.fwd_checkpoint_move = False
-    e = j1j2.J1J2(j1=1.0, j2=float(g["j2"])).energy_2x2_4site(st, env)
+    e = j1j2.J1J2(j1=1.0, j2=float(g["j2"]), j3=float(g["j3"]) if "j3" in g else 0.0).energy_2x2_4site(st, env)
     e.backward()
     return g, float(e.detach()), {k: v.grad for k, v in sites.items()}
 
 
-@pytest.mark.parametrize("name", ["generic_ad_D2_chi8_f64", "generic_ad_D2_chi8_c128", "generic_ad_D2_chi8_f64_4x2"])
+@pytest.mark.parametrize("name", ["generic_ad_D2_chi8_f64", "generic_ad_D2_chi8_c128", "generic_ad_D2_chi8_f64_4x2",
+                                  "generic_ad_D2_chi8_f64_j3", "generic_ad_D2_chi8_c128_j3"])
 def test_generic_energy_gradient_equals_the_reference_autograd(fake, name):
     g, e, grads = _generic_energy(name, fake)
     assert abs(e - float(g["energy"])) < 1e-11

@@ -135,12 +135,13 @@ def _generic(name, checkpoint=False):
     finally:
         cfg.ctm_args.projector_method = old
         cfg.ctm_args.fwd_checkpoint_move = False
-    e = j1j2.J1J2(j1=1.0, j2=float(g["j2"])).energy_2x2_4site(st, env)
+    e = j1j2.J1J2(j1=1.0, j2=float(g["j2"]), j3=float(g["j3"]) if "j3" in g else 0.0).energy_2x2_4site(st, env)
     e.backward()
     return g, float(e.detach()), {k: v.grad.cpu().numpy() for k, v in sites.items()}, env
 
 
-@pytest.mark.parametrize("name", ["generic_ad_D2_chi8_f64", "generic_ad_D2_chi8_c128", "generic_ad_D2_chi8_f64_4x2"])
+@pytest.mark.parametrize("name", ["generic_ad_D2_chi8_f64", "generic_ad_D2_chi8_c128", "generic_ad_D2_chi8_f64_4x2",
+                                  "generic_ad_D2_chi8_f64_j3", "generic_ad_D2_chi8_c128_j3"])
 def test_generic_energy_gradient_equals_the_reference_autograd(eng, name):
     g, e, grads, env = _generic(name)
     assert abs(e - float(g["energy"])) < 1e-11
