@@ -1275,6 +1275,10 @@ __global__ void add_inplace_kernel(double* x, const double* y, size_t n) {
     for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (size_t)gridDim.x * blockDim.x) x[q] += y[q];
 }
 
+__global__ void axpy_kernel(double* x, const double* y, double a, size_t n) {
+    for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (size_t)gridDim.x * blockDim.x) x[q] += a * y[q];
+}
+
 __global__ void sub_inplace_kernel(double* x, const double* y, size_t n) {
     for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (size_t)gridDim.x * blockDim.x) x[q] -= y[q];
 }
@@ -1410,7 +1414,53 @@ int svd_full_c(ctm_ctx* ctx, const double* Mr, const double* Mi, int n, int k, d
             XM ah{Vg, Vg + (size_t)kg * n, n, true, true}, a{Vg, Vg + (size_t)kg * n, n, false, false};
             CTM_TRY(xgemm(ctx, n, n, kg, ah, a, Pr, Pi, n));
             CTM_LAUNCH(ctx, eye_minus_kernel, dim3(1024), dim3(256), 0, Pr, Pi, n);
-            {
+            // full complement (k == n): pivoted projector rows + Newton-Schulz polar iteration, as in svd_full(); rows here are v^H (planar)
+            bool done = false;
+            if (k == n) {
+                std::vector<double> pd(n);
+                CTM_HIP_CHECK(ctx, hipMemcpy2DAsync(pd.data(), sizeof(double), Pr, sizeof(double) * ((size_t)n + 1), sizeof(double), n,
+                                                    hipMemcpyDeviceToHost, ctx->stream));
+                CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+                std::vector<int> jd(n);
+                std::iota(jd.begin(), jd.end(), 0);
+                std::stable_sort(jd.begin(), jd.end(), [&](int a, int c) { return pd[a] > pd[c]; });
+                const int m = kb;
+                ArenaScope zs(ctx);
+                double *Z, *Z2, *G2, *zn;
+                int* dj;
+                const size_t mn = (size_t)m * n, mm = (size_t)m * m;
+                CTM_TRY(arena_alloc(ctx, sizeof(double) * 2 * mn, (void**)&Z));
+                CTM_TRY(arena_alloc(ctx, sizeof(double) * 2 * mn, (void**)&Z2));
+                CTM_TRY(arena_alloc(ctx, sizeof(double) * 2 * mm, (void**)&G2));
+                CTM_TRY(arena_alloc(ctx, sizeof(double) * m, (void**)&zn));
+                CTM_TRY(arena_alloc(ctx, sizeof(int) * m, (void**)&dj));
+                CTM_HIP_CHECK(ctx, hipMemcpyAsync(dj, jd.data(), sizeof(int) * m, hipMemcpyHostToDevice, ctx->stream));
+                CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+                CTM_TRY(gather_rows(ctx, Pr, n, dj, m, n, Z, n, nullptr));
+                CTM_TRY(gather_rows(ctx, Pi, n, dj, m, n, Z + mn, n, nullptr));
+                std::vector<double> hz(m);
+                double dev = 1.0;
+                for (int it = 0; it < 48; ++it) {
+                    XM z{Z, Z + mn, n, false, false}, zh{Z, Z + mn, n, true, true};
+                    CTM_TRY(xgemm(ctx, m, m, n, z, zh, G2, G2 + mm, m));
+                    CTM_LAUNCH(ctx, sub_eye_kernel, dim3((m + 255) / 256), dim3(256), 0, G2, m);
+                    CTM_TRY(row_norms_c128(ctx, G2, G2 + mm, m, m, m, zn));
+                    CTM_HIP_CHECK(ctx, hipMemcpyAsync(hz.data(), zn, sizeof(double) * m, hipMemcpyDeviceToHost, ctx->stream));
+                    CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+                    const double prev = dev;
+                    dev = *std::max_element(hz.begin(), hz.end());
+                    if (!(dev == dev) || dev <= 1e-13 || (it > 0 && dev < 1e-10 && dev > 0.5 * prev)) break;
+                    XM e{G2, G2 + mm, m, false, false};
+                    CTM_TRY(xgemm(ctx, m, n, m, e, z, Z2, Z2 + mn, n));                       // (Z Z^H - I) Z
+                    CTM_LAUNCH(ctx, axpy_kernel, dim3(1024), dim3(256), 0, Z, (const double*)Z2, -0.5, 2 * mn);
+                }
+                if (dev == dev && dev <= 1e-10) {
+                    CTM_HIP_CHECK(ctx, hipMemcpyAsync(Wn, Z, sizeof(double) * 2 * mn, hipMemcpyDeviceToDevice, ctx->stream));
+                    CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+                    done = true;
+                }
+            }
+            if (!done) {
                 const bool save = ctx->si_enable; ctx->si_enable = false;      // a projector's spectrum is flat: the leading-k iteration cannot converge on it
                 const int st3 = jacobi_eigh_top_c(ctx, Pr, Pi, n, kb, Dn, Wn, nullptr);
                 ctx->si_enable = save;
@@ -1420,7 +1470,7 @@ int svd_full_c(ctm_ctx* ctx, const double* Mr, const double* Mi, int n, int k, d
             CTM_HIP_CHECK(ctx, hipMemcpyAsync(Vt + kn, Vg + (size_t)kg * n, sizeof(double) * (size_t)kg * n, hipMemcpyDeviceToDevice, ctx->stream));
             CTM_HIP_CHECK(ctx, hipMemcpyAsync(Vt + (size_t)kg * n, Wn, sizeof(double) * (size_t)kb * n, hipMemcpyDeviceToDevice, ctx->stream));
             CTM_HIP_CHECK(ctx, hipMemcpyAsync(Vt + kn + (size_t)kg * n, Wn + (size_t)kb * n, sizeof(double) * (size_t)kb * n, hipMemcpyDeviceToDevice, ctx->stream));
-            CTM_TRY(reorth_rows_c(ctx, Vt, k, n, 1));
+            CTM_TRY(reorth_rows_c(ctx, Vt, k, n, done ? 2 : 1));
         } else
             CTM_TRY(reorth_rows_c(ctx, Vt, k, n, 2));
     }
