@@ -955,10 +955,11 @@ int svd_full(ctm_ctx* ctx, const double* M, int n, int k, double* S, double* Ut,
                 if (dev == dev && dev <= 1e-10) {
                     CTM_HIP_CHECK(ctx, hipMemcpyAsync(Vt + (size_t)kg * n, Z, sizeof(double) * (size_t)m * n, hipMemcpyDeviceToDevice, ctx->stream));
                     CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-                    done = true;
+                    done = true; ctx->svd_polar_completions += 1;
                 }
             }
             if (!done) {
+                ctx->svd_eig_completions += 1;
                 const bool save = ctx->si_enable; ctx->si_enable = false;      // a projector's spectrum is flat: the leading-k iteration cannot converge on it
                 const int st3 = jacobi_eigh_top(ctx, Pm, n, m, Dn, Wn, nullptr);
                 ctx->si_enable = save;
@@ -1457,10 +1458,11 @@ int svd_full_c(ctm_ctx* ctx, const double* Mr, const double* Mi, int n, int k, d
                 if (dev == dev && dev <= 1e-10) {
                     CTM_HIP_CHECK(ctx, hipMemcpyAsync(Wn, Z, sizeof(double) * 2 * mn, hipMemcpyDeviceToDevice, ctx->stream));
                     CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-                    done = true;
+                    done = true; ctx->svd_polar_completions += 1;
                 }
             }
             if (!done) {
+                ctx->svd_eig_completions += 1;
                 const bool save = ctx->si_enable; ctx->si_enable = false;      // a projector's spectrum is flat: the leading-k iteration cannot converge on it
                 const int st3 = jacobi_eigh_top_c(ctx, Pr, Pi, n, kb, Dn, Wn, nullptr);
                 ctx->si_enable = save;

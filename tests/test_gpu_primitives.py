@@ -210,6 +210,7 @@ def test_full_svd_warm_start_and_rank_deficient_completion(eng, cplx):
     eng.timers(reset=True)
     U, S, V = eng.truncated_svd(M1, n, cfgT, basis=basis)
     assert eng.stat("eigh_warm_hits") == 1 and eng.stat("total_sweeps") <= cold
+    assert eng.stat("svd_polar_completions") == 1 and eng.stat("svd_eig_completions") == 0      # pivoted projector rows + Newton-Schulz
     I = torch.eye(n, device=U.device, dtype=U.dtype)
     assert float((U.conj().T @ U - I).abs().max()) < 1e-11
     assert float((V.conj().T @ V - I).abs().max()) < 1e-11
