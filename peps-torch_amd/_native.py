@@ -114,6 +114,17 @@ def _chk_t(t, name="tensor", dtype=None):
     if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype in _DTYPES and (dtype is None or t.dtype == dtype)):
         raise NativeError(f"{name}: expected a {dtype or 'float64/complex128'} CUDA(HIP) tensor, got {type(t)} "
                           f"{getattr(t, 'dtype', None)} {getattr(t, 'device', None)}")
+    return _plain(t)
+
+
+def _plain(t):
+    """The tensor as the library reads it: contiguous memory holding the VALUES.  torch represents `x.conj()` (and `-x` in some
+    autograd paths) lazily as a flag on the same memory -- e.g. the gradient that flows back through `V.conj().transpose(-2, -1)` --
+    so the flags are materialised before a pointer is taken."""
+    if t.is_complex() and t.is_conj():
+        t = t.resolve_conj()
+    if t.is_neg():
+        t = t.resolve_neg()
     return t if t.is_contiguous() else t.contiguous()
 
 
@@ -368,8 +379,8 @@ class Engine:
         U, V = self._bind(U, V)
         m, k = U.shape
         n = V.shape[0]
-        S = S.contiguous()
-        g = [None if t is None else (t.to(U.dtype) if i != 1 else t.to(torch.float64)).contiguous() for i, t in enumerate((gU, gS, gV))]
+        S = _plain(S)
+        g = [None if t is None else _plain(t.to(U.dtype) if i != 1 else t.to(torch.float64)) for i, t in enumerate((gU, gS, gV))]
         dA = self.empty(m, n)
         opt = lambda t: _ptr(t) if t is not None else None
         self._ck(self.lib.ctm_svd_backward(self.h, _ptr(U), _ptr(S), _ptr(V), opt(g[0]), opt(g[1]), opt(g[2]), m, n, k, float(eps), _ptr(dA)),
@@ -380,9 +391,9 @@ class Engine:
         """dA of A = U diag(D) U^H given the gradients on D and U (reference SYMEIG.backward)."""
         U = self._bind(U)
         n, k = U.shape
-        D = D.contiguous()
-        gD = None if gD is None else gD.to(torch.float64).contiguous()
-        gU = None if gU is None else gU.to(U.dtype).contiguous()
+        D = _plain(D)
+        gD = None if gD is None else _plain(gD.to(torch.float64))
+        gU = None if gU is None else _plain(gU.to(U.dtype))
         dA = self.empty(n, n)
         opt = lambda t: _ptr(t) if t is not None else None
         self._ck(self.lib.ctm_eigh_backward(self.h, _ptr(D), _ptr(U), opt(gD), opt(gU), n, k, float(reg), _ptr(dA)), "eigh_backward")

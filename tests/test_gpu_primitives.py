@@ -219,3 +219,23 @@ def test_full_svd_warm_start_and_rank_deficient_completion(eng, cplx):
     ref = torch.linalg.svdvals(M1.cpu())
     assert float((S.cpu() - ref).abs().max()) < 1e-12 * s0
     assert int((S > 1e-11 * s0).sum()) == r
+
+
+def test_lazily_conjugated_tensors_are_read_by_value(eng):
+    """torch keeps `x.conj()` as a flag on x's memory (so does the gradient that flows back through `V.conj().transpose(-2, -1)`):
+    every entry point materialises it before taking the pointer."""
+    g = torch.Generator().manual_seed(31)
+    A = torch.randn(48, 48, generator=g, dtype=torch.complex128).cuda()
+    B = torch.randn(48, 48, generator=g, dtype=torch.complex128).cuda()
+    Ac = A.conj()
+    assert Ac.is_conj() and Ac.data_ptr() == A.data_ptr()
+    assert float((eng.gemm(Ac, B) - A.conj().resolve_conj() @ B).abs().max()) < 1e-12
+    assert float((eng.einsum('ab,bc->ac', Ac, B.conj()) - (A.conj() @ B.conj()).resolve_conj()).abs().max()) < 1e-12
+    s1 = eng.svdvals(Ac)
+    assert float((s1.cpu() - torch.linalg.svdvals(A.cpu())).abs().max()) < 1e-12
+    U, S, V = eng.truncated_svd(Ac, 48, eng.cfg(keep_multiplets=False))
+    assert float(((U * S.to(U.dtype)) @ V.conj().T - A.conj().resolve_conj()).abs().max()) < 1e-11
+    gU = torch.randn(48, 48, generator=g, dtype=torch.complex128).cuda()
+    d1 = eng.svd_backward(U, S, V, gU=gU.conj(), gS=None, gV=None)
+    d2 = eng.svd_backward(U, S, V, gU=gU.conj().resolve_conj(), gS=None, gV=None)
+    assert float((d1 - d2).abs().max()) == 0.0
