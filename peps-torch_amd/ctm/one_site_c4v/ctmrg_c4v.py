@@ -13,9 +13,14 @@ log = logging.getLogger(__name__)
 
 
 def run(state, env, conv_check=None, ctm_args=cfg.ctm_args, global_args=cfg.global_args):
-    if ctm_args.projector_svd_method not in ['DEFAULT', 'SYMEIG']:
+    # SYMARP / SYMLOBPCG (ctmrg_c4v.py:53-60: ARPACK / LOBPCG for the leading chi eigenpairs, forward only) name what the native
+    # truncation does anyway -- the leading-chi solver; they are accepted for runs that carry no gradient (e.g. the line search
+    # of the optimiser, OPTARGS.line_search_svd_method)
+    if ctm_args.projector_svd_method not in ['DEFAULT', 'SYMEIG', 'SYMARP', 'SYMLOBPCG']:
         raise Exception(f"Projector eig/svd method \"{ctm_args.projector_svd_method}\" not implemented")
     a = next(iter(state.sites.values()))
+    if ctm_args.projector_svd_method in ['SYMARP', 'SYMLOBPCG'] and needs_grad(a, env.C[env.keyC], env.T[env.keyT]):
+        raise NotImplementedError(f"projector_svd_method {ctm_args.projector_svd_method} is forward only; use SYMEIG for a differentiable run")
     eng = get_engine()
     t_obs = t_ctm = 0.
     history = None

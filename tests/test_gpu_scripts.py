@@ -104,3 +104,24 @@ def test_optim_j1j2_script(tmp_path):
                         text=True, env=env, timeout=900)
     assert r2.returncode == 0, r2.stderr[-3000:]
     assert "resuming from check point" in r2.stdout
+
+
+@pytest.mark.parametrize("extra", [["--GLOBALARGS_dtype", "complex128"], ["--CTMARGS_projector_svd_method", "SYMEIG", "--OPTARGS_line_search", "strong_wolfe"],
+                                   ["--CTMARGS_projector_svd_method", "SYMEIG", "--OPTARGS_line_search", "backtracking"],
+                                   ["--CTMARGS_projector_svd_method", "SYMEIG", "--OPTARGS_line_search", "backtracking",
+                                    "--OPTARGS_line_search_svd_method", "SYMARP"]],
+                         ids=["COMPLEX", "SYMEIG_LS_strong_wolfe", "SYMEIG_LS_backtracking", "SYMEIG_LS_backtracking_SYMARP"])
+def test_optim_j1j2_c4v_script_variants(tmp_path, extra):
+    """The other cases of the reference's TestOpt (examples/j1j2/optim_j1j2_c4v.py:193-217): complex128 tensors, the two line
+    searches, and the forward-only SYMARP method inside the line search."""
+    env = dict(os.environ, PYTHONPATH=PKG + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    pre = str(tmp_path / "opt")
+    r = subprocess.run([sys.executable, os.path.join(PKG, "examples", "j1j2", "optim_j1j2_c4v.py"), "--bond_dim", "2", "--chi", "16",
+                        "--opt_max_iter", "3", "--seed", "123", "--CTMARGS_ctm_max_iter", "20", "--GLOBALARGS_device", "cuda:0",
+                        "--out_prefix", pre] + extra, capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    rows = [l.split(", ") for l in r.stdout.splitlines() if l[:1].isdigit() or l.startswith("-1, ")]
+    e = {int(x[0]): float(x[1]) for x in rows}
+    assert 1 in e and max(e) == 3, r.stdout[-2000:]
+    assert e[3] <= e[1] + 1e-10
+    assert os.path.exists(pre + "_state.json")
