@@ -125,3 +125,24 @@ def test_optim_j1j2_c4v_script_variants(tmp_path, extra):
     assert 1 in e and max(e) == 3, r.stdout[-2000:]
     assert e[3] <= e[1] + 1e-10
     assert os.path.exists(pre + "_state.json")
+
+
+@pytest.mark.parametrize("extra", [["--tiling", "BIPARTITE"], ["--tiling", "BIPARTITE", "--OPTARGS_line_search", "strong_wolfe"],
+                                   ["--tiling", "BIPARTITE", "--OPTARGS_line_search", "backtracking", "--OPTARGS_line_search_svd_method", "ARP"],
+                                   ["--tiling", "4SITE"]],
+                         ids=["GESDD_BIPARTITE", "GESDD_BIPARTITE_LS_strong_wolfe", "GESDD_BIPARTITE_LS_backtracking", "GESDD_4SITE"])
+def test_optim_j1j2_script_variants(tmp_path, extra):
+    """The reference's TestOptBasic (examples/j1j2/optim_j1j2.py:238-300): j2 = j3 = hz_stag = 1, D = 2, chi = 8, GESDD projectors,
+    three epochs -- the j3 term differentiated through the transfer-matrix correlators, the staggered field in the plaquette term."""
+    env = dict(os.environ, PYTHONPATH=PKG + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    pre = str(tmp_path / "opt")
+    r = subprocess.run([sys.executable, os.path.join(PKG, "examples", "j1j2", "optim_j1j2.py"), "--bond_dim", "2", "--chi", "8", "--j2", "1.",
+                        "--j3", "1.", "--hz_stag", "1.", "--delta_zz", "1.", "--opt_max_iter", "3", "--seed", "123",
+                        "--CTMARGS_projector_svd_method", "GESDD", "--CTMARGS_ctm_max_iter", "10", "--GLOBALARGS_device", "cuda:0",
+                        "--out_prefix", pre] + extra, capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    rows = [l.split(", ") for l in r.stdout.splitlines() if l[:1].isdigit() or l.startswith("-1, ")]
+    e = {int(x[0]): float(x[1]) for x in rows}
+    assert 1 in e and max(e) == 3, r.stdout[-2000:]
+    assert e[3] <= e[1] + 1e-10
+    assert os.path.exists(pre + "_state.json") and os.path.exists(pre + "_checkpoint.p")
