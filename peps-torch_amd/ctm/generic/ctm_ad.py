@@ -186,10 +186,35 @@ def ctm_MOVE(direction, state, env, ctm_args=cfg.ctm_args):
             import units
             n = env.chi * max(a0.shape[1:]) ** 2
             pool = units.pool_for(get_engine(), len(keys_s), n, a0.is_complex(), est_bytes=40.0 * n * n * a0.element_size())
+        import parallel
+        mine = parallel.my_units(keys_s)                       # all sites in a single process; this rank's share under torch.distributed
         P, Pt = {}, {}
-        for coord, (p_, pt_) in zip(keys_s, pool.map(proj, keys_s) if pool is not None else [proj(c) for c in keys_s]):
+        for coord, (p_, pt_) in zip(mine, pool.map(proj, mine) if pool is not None and len(mine) > 1 else [proj(c) for c in mine]):
             P[coord], Pt[coord] = p_, pt_
-        out = pool.map(absb, keys_s) if pool is not None else [absb(c) for c in keys_s]
+        if parallel.is_distributed():
+            # the site-sharded move of ctmrg.ctm_MOVE with differentiable exchanges: every rank gets all projectors, absorbs for its
+            # sites, gets all new tensors; cotangents return to the owners through parallel._ExchangeAD
+            like = tensors[0]
+            shp = {c: tuple(P[mine[0]].shape) for c in keys_s} if mine else None
+            if shp is None or len({st.site(c).shape for c in keys_s}) != 1:
+                raise NotImplementedError("distributed differentiable move: uniform bond dimensions and at least one site per rank")
+            P = parallel.exchange_ad(P, keys_s, shp, like)
+            Pt = parallel.exchange_ad(Pt, keys_s, shp, like)
+        out_m = pool.map(absb, mine) if pool is not None and len(mine) > 1 else [absb(c) for c in mine]
+        if parallel.is_distributed():
+            shapes3 = [tuple(t.shape) for t in out_m[0]]
+            packs = {c: torch.cat([t.reshape(-1) for t in trip]) for c, trip in zip(mine, out_m)}
+            n3 = sum(int(torch.tensor(sh).prod()) for sh in shapes3)
+            packs = parallel.exchange_ad(packs, keys_s, {c: (n3,) for c in keys_s}, tensors[0])
+            out = []
+            for c in keys_s:
+                v, off, trip = packs[c], 0, []
+                for sh in shapes3:
+                    m_ = int(torch.tensor(sh).prod())
+                    trip.append(v[off:off + m_].reshape(sh)); off += m_
+                out.append(tuple(trip))
+        else:
+            out = out_m
         return tuple(x for trip in out for x in trip)
 
     tensors = tuple(state.sites[k] for k in keys_s) + tuple(env.C[k] for k in keys_C) + tuple(env.T[k] for k in keys_T)

@@ -140,10 +140,8 @@ def ctm_MOVE(direction, state, env, ctm_args=cfg.ctm_args, global_args=cfg.globa
     norm_kind = 1 if ctm_args.ctm_absorb_normalization == 'inf' else 2      # anything else is the 2-norm (ctmrg.py:212-214)
     from ctm.generic import ctm_ad
     if ctm_ad.wants_grad(state, env):
-        # a tensor requires grad: the explicit, differentiable route (graph of native contraction / SVD nodes);
-        # single process (the adjoint of the rank exchanges is not built)
-        if parallel.is_distributed():
-            raise NotImplementedError("ctm_MOVE with tensors that require grad is single-process")
+        # a tensor requires grad: the explicit, differentiable route (graph of native contraction / SVD nodes); under
+        # torch.distributed the sites are sharded as below and the exchanges are autograd nodes (parallel.exchange_ad)
         return ctm_ad.ctm_MOVE(direction, state, env, ctm_args)
     eng = get_engine()
     coords = list(state.sites.keys())

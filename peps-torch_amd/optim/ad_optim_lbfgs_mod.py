@@ -13,11 +13,14 @@ import logging
 import time
 import torch
 import config as cfg
+import parallel
 
 log = logging.getLogger(__name__)
 
 
 def store_checkpoint(checkpoint_file, state, optimizer, current_epoch, current_loss, verbosity=0):
+    if parallel.world()[0] != 0:            # replicated run: one writer
+        return
     torch.save({'epoch': current_epoch, 'loss': current_loss, 'parameters': state.get_checkpoint(),
                 'optimizer_state_dict': optimizer.state_dict()}, checkpoint_file)
     if verbosity > 0:
@@ -103,18 +106,22 @@ def optimize_state(state, ctm_env_init, loss_fn, obs_fn=None, post_proc=None, ma
         load_optimizer_state_(optimizer, state, main_args=main_args, opt_args=opt_args, ctm_args=ctm_args, global_args=global_args)
     calls = [0]
 
+    def _write_best():
+        if parallel.world()[0] == 0:        # replicated run: one writer
+            state.write_to_file(outputstatefile, normalize=True)
+
     def _record(loss, linesearching):
         if linesearching:
             t_data["loss_ls"].append(loss)
             if t_data["min_loss_ls"] > loss:
                 t_data["min_loss_ls"] = loss
                 if t_data["min_loss"] > loss:
-                    state.write_to_file(outputstatefile, normalize=True)
+                    _write_best()
         else:
             t_data["loss"].append(loss)
             if t_data["min_loss"] > loss:
                 t_data["min_loss"] = loss
-                state.write_to_file(outputstatefile, normalize=True)
+                _write_best()
 
     def closure():
         linesearching = calls[0] > 0            # torch's strong-Wolfe search re-enters the closure: the first call of a step is the epoch's
@@ -125,6 +132,7 @@ def optimize_state(state, ctm_env_init, loss_fn, obs_fn=None, post_proc=None, ma
         t_ctm, t_check = timings[0], timings[1]
         t0 = time.perf_counter()
         loss.backward()
+        parallel.average_grads(parameters)             # no-op in a single process; distributed runs: mean of the ranks' local gradients
         t1 = time.perf_counter()
         current_env[0] = ctm_env.detach()
         _record(loss.item(), linesearching)

@@ -134,3 +134,58 @@ def allreduce_max_int(x, device):
     t = torch.tensor([int(x)], dtype=torch.int64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return int(t.item())
+
+
+class _ExchangeAD(torch.autograd.Function):
+    """exchange() as an autograd node.  Every rank runs the same program on replicated tensors, so the "graph" of a distributed
+    differentiable run is the union of the ranks' local graphs joined at the exchanges: the output `key` on rank r is a copy of the
+    tensor its owner computed, hence the cotangent of that tensor is the SUM over ranks of the cotangents of their copies -- one
+    all-reduce of the stacked cotangents, of which a rank keeps the slices it owns.  (With every rank seeding its own replica of the
+    loss this differentiates sum_r L_r = R L: average_grads() divides by R.)"""
+
+    @staticmethod
+    def forward(ctx, keys, shapes, like, owners, *local_tensors):
+        rank, n = world()
+        own = owners if owners is not None else [owner_of(i, n) for i in range(len(keys))]
+        mine = [k for i, k in enumerate(keys) if own[i] == rank]
+        out = exchange({k: t.detach() for k, t in zip(mine, local_tensors)}, keys, shapes, like, owners=owners)
+        ctx.mine_idx = [i for i, k in enumerate(keys) if own[i] == rank]
+        return tuple(out[k].clone() if own[i] == rank else out[k] for i, k in enumerate(keys))
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        flat = torch.cat([(torch.view_as_real(g.contiguous()) if g.is_complex() else g.contiguous()).reshape(-1) for g in gouts])
+        dist.all_reduce(flat)
+        grads, off = [], 0
+        for i, g in enumerate(gouts):
+            m = g.numel() * (2 if g.is_complex() else 1)
+            if i in ctx.mine_idx:
+                piece = flat[off:off + m]
+                grads.append(torch.view_as_complex(piece.reshape(g.shape + (2,))) if g.is_complex() else piece.reshape(g.shape))
+            off += m
+        return (None, None, None, None) + tuple(grads)
+
+
+def exchange_ad(local, keys, shapes, like, owners=None):
+    """Differentiable exchange(): same result, and gradients flow back to the rank that computed each tensor."""
+    if not is_distributed():
+        return dict(local)
+    rank, n = world()
+    own = owners if owners is not None else [owner_of(i, n) for i in range(len(keys))]
+    mine = [k for i, k in enumerate(keys) if own[i] == rank]
+    outs = _ExchangeAD.apply(list(keys), shapes, like, owners, *[local[k] for k in mine])
+    return dict(zip(keys, outs))
+
+
+def average_grads(tensors):
+    """After loss.backward() of a distributed differentiable run: the gradient of the (replicated) loss with respect to the replicated
+    parameters is the mean over ranks of the local .grad fields (see _ExchangeAD)."""
+    if not is_distributed():
+        return
+    _, n = world()
+    for t in tensors:
+        if t.grad is None:
+            t.grad = torch.zeros_like(t)
+        buf = torch.view_as_real(t.grad) if t.grad.is_complex() else t.grad
+        dist.all_reduce(buf)
+        t.grad.div_(n)
