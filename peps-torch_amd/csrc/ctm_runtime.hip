@@ -132,6 +132,8 @@ int ctm_set_option(ctm_ctx* ctx, const char* key, double value) {
     else if (k == "eigh_warm") ctx->eigh_warm = (int)value;
     else if (k == "svd_abs_accuracy") ctx->svd_abs_accuracy = (int)value;
     else if (k == "lz_abs_accuracy") ctx->lz_abs_accuracy = (int)value;
+    else if (k == "svd_polar") ctx->svd_polar = (int)value;
+    else if (k == "svd_polar_min_n") ctx->svd_polar_min_n = (int)value;
     else if (k == "splitk_max_tiles") ctx->splitk_max_tiles = (int)value;
     else if (k == "splitk_target_wgs") ctx->splitk_target_wgs = (int)value;
     else if (k == "rank_tol") ctx->rank_tol = value;
@@ -174,6 +176,7 @@ int ctm_get_stat(ctm_ctx* ctx, const char* key, double* value) {
     else if (k == "eigh_warm_rejects") *value = (double)ctx->eigh_warm_rejects;
     else if (k == "svd_polar_completions") *value = (double)ctx->svd_polar_completions;
     else if (k == "svd_eig_completions") *value = (double)ctx->svd_eig_completions;
+    else if (k == "svd_polar_solves") *value = (double)ctx->svd_polar_solves;
     else if (k == "lz_hits") *value = (double)ctx->lz_hits;
     else if (k == "lz_total_steps") *value = (double)ctx->lz_total_steps;
     else if (k == "lz_extractions") *value = (double)ctx->lz_extractions;
@@ -210,7 +213,7 @@ int ctm_gemm_intervals(ctm_ctx* ctx, double* out, long long capacity, long long*
 int ctm_timers(ctm_ctx* ctx, double* out8, int reset) {
     gemm_timing_drain(ctx);       // event-timed phases are accumulated when their events are read
     for (int i = 0; i < CTM_T_COUNT; ++i) { if (out8) out8[i] = ctx->timers[i]; if (reset) ctx->timers[i] = 0.0; }
-    if (reset) { ctx->gemm_flops = 0; ctx->gemm_calls = 0; ctx->layer2_flops = 0; ctx->layer2_calls = 0; ctx->total_sweeps = 0; ctx->jacobi_calls = 0; ctx->si_hits = 0; ctx->si_fallbacks = 0; ctx->si_total_iters = 0; ctx->si_warm_starts = 0; ctx->eigh_warm_hits = 0; ctx->eigh_warm_rejects = 0; ctx->svd_polar_completions = 0; ctx->svd_eig_completions = 0; ctx->lz_hits = 0; ctx->lz_total_steps = 0; ctx->lz_extractions = 0; ctx->absorb_bytes = 0; ctx->absorb_calls = 0; }
+    if (reset) { ctx->gemm_flops = 0; ctx->gemm_calls = 0; ctx->layer2_flops = 0; ctx->layer2_calls = 0; ctx->total_sweeps = 0; ctx->jacobi_calls = 0; ctx->si_hits = 0; ctx->si_fallbacks = 0; ctx->si_total_iters = 0; ctx->si_warm_starts = 0; ctx->eigh_warm_hits = 0; ctx->eigh_warm_rejects = 0; ctx->svd_polar_completions = 0; ctx->svd_eig_completions = 0; ctx->svd_polar_solves = 0; ctx->lz_hits = 0; ctx->lz_total_steps = 0; ctx->lz_extractions = 0; ctx->absorb_bytes = 0; ctx->absorb_calls = 0; }
     return CTM_OK;
 }
 

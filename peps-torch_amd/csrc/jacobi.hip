@@ -739,6 +739,10 @@ inline int padded(int n, int b) {
     return nbk * b;
 }
 
+__global__ void axpy_kernel(double* x, const double* y, double a, size_t n) {
+    for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (size_t)gridDim.x * blockDim.x) x[q] += a * y[q];
+}
+
 __global__ void sub_eye_kernel(double* G, int m) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < m) G[(size_t)i * m + i] -= 1.0;
@@ -828,6 +832,84 @@ double host_fro(ctm_ctx* ctx, const double* M, int rows, int cols, long long ld,
 // ---------------------------------------------------------------------------------------------
 // full decomposition: every row pair is orthogonalised (O(n^3) per sweep)
 // ---------------------------------------------------------------------------------------------
+// Rows kg .. k-1 of the k x n row matrix Vt (orthonormal rows expected) <- an orthonormal basis of the orthogonal complement of rows
+// 0 .. kg-1 (or of part of it when k < n).  See svd_full().
+int complete_null_rows(ctm_ctx* ctx, double* Vt, int kg, int k, int n) {
+    ArenaScope cscope(ctx);
+        CTM_TRY(reorth_rows(ctx, Vt, kg, n, n, 2));
+        double *Pm, *Dn, *Wn;
+        CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)n * n, (void**)&Pm));
+        CTM_TRY(arena_alloc(ctx, sizeof(double) * (k - kg), (void**)&Dn));
+        CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)(k - kg) * n, (void**)&Wn));
+        CTM_TRY(set_identity(ctx, Pm, n, n));
+        GemmDesc gp; gp.M = n; gp.N = n; gp.K = kg; gp.A = Vt; gp.sam = 1; gp.sak = n; gp.B = Vt; gp.sbk = n; gp.sbn = 1; gp.C = Pm; gp.ldc = n;
+        gp.alpha = -1.0; gp.beta = 1.0;
+        CTM_TRY(gemm_f64(ctx, gp));
+        // Full complement (k == n): the n - kg rows of the projector with the largest norm (|P e_j|^2 = P_jj: pivoting) span it unless
+        // they happen to be dependent; a row Jacobi on those m rows (m^2 n work instead of the n^3 of the projector's
+        // eigendecomposition) orthogonalises them, and row norms that stay O(1) certify the span.  Otherwise: eigenvectors.
+        bool done = false;
+        const int m = k - kg;
+        if (k == n) {
+            std::vector<double> pd(n);
+            CTM_HIP_CHECK(ctx, hipMemcpy2DAsync(pd.data(), sizeof(double), Pm, sizeof(double) * ((size_t)n + 1), sizeof(double), n,
+                                                hipMemcpyDeviceToHost, ctx->stream));
+            CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+            std::vector<int> jd(n);
+            std::iota(jd.begin(), jd.end(), 0);
+            std::stable_sort(jd.begin(), jd.end(), [&](int a, int c) { return pd[a] > pd[c]; });
+            const int b2 = choose_block(ctx, n), mp = padded(m, b2);
+            ArenaScope zs(ctx);
+            double *Z, *zn;
+            int* dj;
+            CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)mp * n, (void**)&Z));
+            CTM_TRY(arena_alloc(ctx, sizeof(double) * mp, (void**)&zn));
+            CTM_TRY(arena_alloc(ctx, sizeof(int) * mp, (void**)&dj));
+            CTM_HIP_CHECK(ctx, hipMemcpyAsync(dj, jd.data(), sizeof(int) * m, hipMemcpyHostToDevice, ctx->stream));
+            CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+            CTM_TRY(fill_f64(ctx, Z, (size_t)mp * n, 0.0));
+            CTM_TRY(gather_rows(ctx, Pm, n, dj, m, n, Z, n, nullptr));
+            // orthonormalise the m rows: Newton-Schulz iteration for the polar factor, Z <- Z - (Z Z^T - I) Z / 2 (two small GEMMs per
+            // step; singular values of the pivoted rows lie in (0, 1], each step moves them towards 1, quadratically at the end)
+            double *G2, *Z2;
+            CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)m * m, (void**)&G2));
+            CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)mp * n, (void**)&Z2));
+            std::vector<double> hz(m);
+            double dev = 1.0;
+            for (int it = 0; it < 48; ++it) {
+                GemmDesc gg; gg.M = m; gg.N = m; gg.K = n; gg.A = Z; gg.sam = n; gg.sak = 1; gg.B = Z; gg.sbk = 1; gg.sbn = n; gg.C = G2; gg.ldc = m;
+                CTM_TRY(gemm_f64(ctx, gg));
+                CTM_LAUNCH(ctx, sub_eye_kernel, dim3((m + 255) / 256), dim3(256), 0, G2, m);
+                CTM_TRY(row_norms(ctx, G2, m, m, m, zn));
+                CTM_HIP_CHECK(ctx, hipMemcpyAsync(hz.data(), zn, sizeof(double) * m, hipMemcpyDeviceToHost, ctx->stream));
+                CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+                const double prev = dev;
+                dev = *std::max_element(hz.begin(), hz.end());
+                if (!(dev == dev) || dev <= 1e-13 || (it > 0 && dev < 1e-10 && dev > 0.5 * prev)) break;    // converged / at the rounding floor
+                CTM_HIP_CHECK(ctx, hipMemcpyAsync(Z2, Z, sizeof(double) * (size_t)m * n, hipMemcpyDeviceToDevice, ctx->stream));
+                GemmDesc gz; gz.M = m; gz.N = n; gz.K = m; gz.A = G2; gz.sam = m; gz.sak = 1; gz.B = Z; gz.sbk = n; gz.sbn = 1; gz.C = Z2; gz.ldc = n;
+                gz.alpha = -0.5; gz.beta = 1.0;
+                CTM_TRY(gemm_f64(ctx, gz));
+                std::swap(Z, Z2);
+            }
+            if (dev == dev && dev <= 1e-10) {
+                CTM_HIP_CHECK(ctx, hipMemcpyAsync(Vt + (size_t)kg * n, Z, sizeof(double) * (size_t)m * n, hipMemcpyDeviceToDevice, ctx->stream));
+                CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+                done = true; ctx->svd_polar_completions += 1;
+            }
+        }
+        if (!done) {
+            ctx->svd_eig_completions += 1;
+            const bool save = ctx->si_enable; ctx->si_enable = false;      // a projector's spectrum is flat: the leading-k iteration cannot converge on it
+            const int st3 = jacobi_eigh_top(ctx, Pm, n, m, Dn, Wn, nullptr);
+            ctx->si_enable = save;
+            CTM_TRY(st3);
+            CTM_HIP_CHECK(ctx, hipMemcpyAsync(Vt + (size_t)kg * n, Wn, sizeof(double) * (size_t)m * n, hipMemcpyDeviceToDevice, ctx->stream));
+        }
+        CTM_TRY(reorth_rows(ctx, Vt, k, n, n, done ? 2 : 1));
+    return CTM_OK;
+}
+
 // warm (optional, k == n only): n x n workspace with the left vectors u_i^T of the previous decomposition of a nearby matrix.  The rows
 // of W M are then almost orthogonal already and the sweeps start in the quadratically convergent regime (the differentiable route
 // of an optimisation decomposes the same sequence of matrices again and again); any orthonormal W is a valid start.  Updated.
@@ -896,80 +978,101 @@ int svd_full(ctm_ctx* ctx, const double* M, int n, int k, double* S, double* Ut,
         int kg = k;
         while (kg > 0 && !(hs[kg - 1] > ctx->svd_null_tol * hs[0])) --kg;
         if (kg > 0 && kg < k) {
-            CTM_TRY(reorth_rows(ctx, Vt, kg, n, n, 2));
-            double *Pm, *Dn, *Wn;
-            CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)n * n, (void**)&Pm));
-            CTM_TRY(arena_alloc(ctx, sizeof(double) * (k - kg), (void**)&Dn));
-            CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)(k - kg) * n, (void**)&Wn));
-            CTM_TRY(set_identity(ctx, Pm, n, n));
-            GemmDesc gp; gp.M = n; gp.N = n; gp.K = kg; gp.A = Vt; gp.sam = 1; gp.sak = n; gp.B = Vt; gp.sbk = n; gp.sbn = 1; gp.C = Pm; gp.ldc = n;
-            gp.alpha = -1.0; gp.beta = 1.0;
-            CTM_TRY(gemm_f64(ctx, gp));
-            // Full complement (k == n): the n - kg rows of the projector with the largest norm (|P e_j|^2 = P_jj: pivoting) span it unless
-            // they happen to be dependent; a row Jacobi on those m rows (m^2 n work instead of the n^3 of the projector's
-            // eigendecomposition) orthogonalises them, and row norms that stay O(1) certify the span.  Otherwise: eigenvectors.
-            bool done = false;
-            const int m = k - kg;
-            if (k == n) {
-                std::vector<double> pd(n);
-                CTM_HIP_CHECK(ctx, hipMemcpy2DAsync(pd.data(), sizeof(double), Pm, sizeof(double) * ((size_t)n + 1), sizeof(double), n,
-                                                    hipMemcpyDeviceToHost, ctx->stream));
-                CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-                std::vector<int> jd(n);
-                std::iota(jd.begin(), jd.end(), 0);
-                std::stable_sort(jd.begin(), jd.end(), [&](int a, int c) { return pd[a] > pd[c]; });
-                const int b2 = choose_block(ctx, n), mp = padded(m, b2);
-                ArenaScope zs(ctx);
-                double *Z, *zn;
-                int* dj;
-                CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)mp * n, (void**)&Z));
-                CTM_TRY(arena_alloc(ctx, sizeof(double) * mp, (void**)&zn));
-                CTM_TRY(arena_alloc(ctx, sizeof(int) * mp, (void**)&dj));
-                CTM_HIP_CHECK(ctx, hipMemcpyAsync(dj, jd.data(), sizeof(int) * m, hipMemcpyHostToDevice, ctx->stream));
-                CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-                CTM_TRY(fill_f64(ctx, Z, (size_t)mp * n, 0.0));
-                CTM_TRY(gather_rows(ctx, Pm, n, dj, m, n, Z, n, nullptr));
-                // orthonormalise the m rows: Newton-Schulz iteration for the polar factor, Z <- Z - (Z Z^T - I) Z / 2 (two small GEMMs per
-                // step; singular values of the pivoted rows lie in (0, 1], each step moves them towards 1, quadratically at the end)
-                double *G2, *Z2;
-                CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)m * m, (void**)&G2));
-                CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)mp * n, (void**)&Z2));
-                std::vector<double> hz(m);
-                double dev = 1.0;
-                for (int it = 0; it < 48; ++it) {
-                    GemmDesc gg; gg.M = m; gg.N = m; gg.K = n; gg.A = Z; gg.sam = n; gg.sak = 1; gg.B = Z; gg.sbk = 1; gg.sbn = n; gg.C = G2; gg.ldc = m;
-                    CTM_TRY(gemm_f64(ctx, gg));
-                    CTM_LAUNCH(ctx, sub_eye_kernel, dim3((m + 255) / 256), dim3(256), 0, G2, m);
-                    CTM_TRY(row_norms(ctx, G2, m, m, m, zn));
-                    CTM_HIP_CHECK(ctx, hipMemcpyAsync(hz.data(), zn, sizeof(double) * m, hipMemcpyDeviceToHost, ctx->stream));
-                    CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-                    const double prev = dev;
-                    dev = *std::max_element(hz.begin(), hz.end());
-                    if (!(dev == dev) || dev <= 1e-13 || (it > 0 && dev < 1e-10 && dev > 0.5 * prev)) break;    // converged / at the rounding floor
-                    CTM_HIP_CHECK(ctx, hipMemcpyAsync(Z2, Z, sizeof(double) * (size_t)m * n, hipMemcpyDeviceToDevice, ctx->stream));
-                    GemmDesc gz; gz.M = m; gz.N = n; gz.K = m; gz.A = G2; gz.sam = m; gz.sak = 1; gz.B = Z; gz.sbk = n; gz.sbn = 1; gz.C = Z2; gz.ldc = n;
-                    gz.alpha = -0.5; gz.beta = 1.0;
-                    CTM_TRY(gemm_f64(ctx, gz));
-                    std::swap(Z, Z2);
-                }
-                if (dev == dev && dev <= 1e-10) {
-                    CTM_HIP_CHECK(ctx, hipMemcpyAsync(Vt + (size_t)kg * n, Z, sizeof(double) * (size_t)m * n, hipMemcpyDeviceToDevice, ctx->stream));
-                    CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-                    done = true; ctx->svd_polar_completions += 1;
-                }
-            }
-            if (!done) {
-                ctx->svd_eig_completions += 1;
-                const bool save = ctx->si_enable; ctx->si_enable = false;      // a projector's spectrum is flat: the leading-k iteration cannot converge on it
-                const int st3 = jacobi_eigh_top(ctx, Pm, n, m, Dn, Wn, nullptr);
-                ctx->si_enable = save;
-                CTM_TRY(st3);
-                CTM_HIP_CHECK(ctx, hipMemcpyAsync(Vt + (size_t)kg * n, Wn, sizeof(double) * (size_t)m * n, hipMemcpyDeviceToDevice, ctx->stream));
-            }
-            CTM_TRY(reorth_rows(ctx, Vt, k, n, n, done ? 2 : 1));
+            CTM_TRY(complete_null_rows(ctx, Vt, kg, k, n));
         } else
             CTM_TRY(reorth_rows(ctx, Vt, k, n, n, 2));
     }
+    return CTM_OK;
+}
+
+__global__ void sym_avg_kernel(double* H, int n) {
+    const size_t tot = (size_t)n * n;
+    for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < tot; q += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = q / n, c = q - r * n;
+        if (r < c) { const double v = 0.5 * (H[r * n + c] + H[c * n + r]); H[r * n + c] = v; H[c * n + r] = v; }
+    }
+}
+
+// Full SVD with vectors of a real n x n matrix through its polar decomposition (differentiable route; `svd_polar`):
+//   X_0 = M / |M|_F,  X <- X - (X X^T - I) X / 2   (Newton-Schulz: X keeps M's singular vectors, its singular values go to 1 -- a value
+//                                                   s needs log_1.5(|M|_F / s) steps, so 80 steps resolve everything above 1e-14 |M|_F)
+//   H = X^T M = V S V^T  (symmetric positive semi-definite),  eigenvectors by the one-sided Jacobi on H + shift I -- a matrix WITHOUT small
+//   singular values, where the sweeps converge in a handful (and in 3-4 from the previous call's eigenvectors, `warm`), instead of
+//   the ~20 sweeps the row Jacobi needs on M itself when its spectrum is graded over many orders of magnitude;
+//   u_i = M v_i / |M v_i|, rows at the rounding level completed orthonormally (complete_null_rows).
+// Accuracy: absolute, eps |M| on values and on U S V^T = M (what a bidiagonalisation-based SVD delivers).
+int svd_full_polar(ctm_ctx* ctx, const double* M, int n, double* S, double* Ut, double* Vt, double* warm) {
+    ArenaScope scope(ctx);
+    const size_t nn = (size_t)n * n;
+    double *X, *X2, *E, *H, *Dv, *norms, *inv;
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * nn, (void**)&X));
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * nn, (void**)&X2));
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * nn, (void**)&E));
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * nn, (void**)&H));
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * n, (void**)&Dv));
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * n, (void**)&norms));
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * n, (void**)&inv));
+    std::vector<double> h;
+    int st;
+    const double fro = host_fro(ctx, M, n, n, n, norms, h, &st);
+    CTM_TRY(st);
+    if (!(fro > 0.0)) return svd_full(ctx, M, n, n, S, Ut, Vt, nullptr);
+    CTM_HIP_CHECK(ctx, hipMemcpyAsync(X, M, sizeof(double) * nn, hipMemcpyDeviceToDevice, ctx->stream));
+    CTM_LAUNCH(ctx, axpy_kernel, dim3(1024), dim3(256), 0, X, (const double*)M, 1.0 / fro - 1.0, nn);       // X = M / fro
+    for (int it = 0; it < 80; ++it) {
+        GemmDesc ge; ge.M = n; ge.N = n; ge.K = n; ge.A = X; ge.sam = n; ge.sak = 1; ge.B = X; ge.sbk = 1; ge.sbn = n; ge.C = E; ge.ldc = n;
+        CTM_TRY(gemm_f64(ctx, ge));                                                                       // X X^T
+        CTM_LAUNCH(ctx, sub_eye_kernel, dim3((n + 255) / 256), dim3(256), 0, E, n);
+        if (it % 8 == 7) {                                   // a full-rank, well conditioned matrix is done early
+            CTM_TRY(row_norms(ctx, E, n, n, n, norms));
+            CTM_HIP_CHECK(ctx, hipMemcpyAsync(h.data(), norms, sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream));
+            CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+            if (*std::max_element(h.begin(), h.begin() + n) <= 1e-13) break;
+        }
+        CTM_HIP_CHECK(ctx, hipMemcpyAsync(X2, X, sizeof(double) * nn, hipMemcpyDeviceToDevice, ctx->stream));
+        GemmDesc gx; gx.M = n; gx.N = n; gx.K = n; gx.A = E; gx.sam = n; gx.sak = 1; gx.B = X; gx.sbk = n; gx.sbn = 1; gx.C = X2; gx.ldc = n;
+        gx.alpha = -0.5; gx.beta = 1.0;
+        CTM_TRY(gemm_f64(ctx, gx));
+        std::swap(X, X2);
+    }
+    GemmDesc gh; gh.M = n; gh.N = n; gh.K = n; gh.A = X; gh.sam = 1; gh.sak = n; gh.B = M; gh.sbk = n; gh.sbn = 1; gh.C = H; gh.ldc = n;       // H = X^T M
+    CTM_TRY(gemm_f64(ctx, gh));
+    CTM_LAUNCH(ctx, sym_avg_kernel, dim3(1024), dim3(256), 0, H, n);
+    CTM_TRY(jacobi_eigh_top(ctx, H, n, n, Dv, Vt, warm));                  // rows of Vt: eigenvectors, ordered by |eigenvalue| descending
+    // U rows: (M v_i)^T, their norms are the singular values
+    GemmDesc gu; gu.M = n; gu.N = n; gu.K = n; gu.A = Vt; gu.sam = n; gu.sak = 1; gu.B = M; gu.sbk = 1; gu.sbn = n; gu.C = Ut; gu.ldc = n;       // Vt M^T
+    CTM_TRY(gemm_f64(ctx, gu));
+    CTM_TRY(row_norms(ctx, Ut, n, n, n, S));
+    h.resize(n);
+    CTM_HIP_CHECK(ctx, hipMemcpyAsync(h.data(), S, sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream));
+    CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    // order by the singular values (the eigenvalue order can differ among values that agree to rounding)
+    std::vector<int> idx(n);
+    std::iota(idx.begin(), idx.end(), 0);
+    std::stable_sort(idx.begin(), idx.end(), [&](int a, int c) { return h[a] > h[c]; });
+    bool sorted = true;
+    for (int i = 0; i < n; ++i) sorted = sorted && idx[i] == i;
+    std::vector<double> hs(n);
+    for (int i = 0; i < n; ++i) hs[i] = h[idx[i]];
+    if (!sorted) {
+        int* d_idx;
+        CTM_TRY(arena_alloc(ctx, sizeof(int) * n, (void**)&d_idx));
+        CTM_HIP_CHECK(ctx, hipMemcpyAsync(d_idx, idx.data(), sizeof(int) * n, hipMemcpyHostToDevice, ctx->stream));
+        CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        CTM_TRY(gather_rows(ctx, Ut, n, d_idx, n, n, X, n, nullptr));
+        CTM_HIP_CHECK(ctx, hipMemcpyAsync(Ut, X, sizeof(double) * nn, hipMemcpyDeviceToDevice, ctx->stream));
+        CTM_TRY(gather_rows(ctx, Vt, n, d_idx, n, n, X, n, nullptr));
+        CTM_HIP_CHECK(ctx, hipMemcpyAsync(Vt, X, sizeof(double) * nn, hipMemcpyDeviceToDevice, ctx->stream));
+        CTM_HIP_CHECK(ctx, hipMemcpyAsync(S, hs.data(), sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream));
+        CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    CTM_LAUNCH(ctx, inv_or_zero_kernel, dim3((n + 255) / 256), dim3(256), 0, S, inv, n);
+    CTM_LAUNCH(ctx, scale_rows_kernel, dim3(1024), dim3(256), 0, Ut, n, n, (long long)n, inv);
+    int kg = n;
+    while (kg > 0 && !(hs[kg - 1] > ctx->svd_null_tol * hs[0])) --kg;
+    if (kg > 0 && kg < n) CTM_TRY(complete_null_rows(ctx, Ut, kg, n, n));
+    else CTM_TRY(reorth_rows(ctx, Ut, n, n, n, 2));
+    ctx->svd_polar_solves += 1;
     return CTM_OK;
 }
 
@@ -1274,10 +1377,6 @@ __global__ void eye_minus_kernel(double* Pr, double* Pi, int n) {
 
 __global__ void add_inplace_kernel(double* x, const double* y, size_t n) {
     for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (size_t)gridDim.x * blockDim.x) x[q] += y[q];
-}
-
-__global__ void axpy_kernel(double* x, const double* y, double a, size_t n) {
-    for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (size_t)gridDim.x * blockDim.x) x[q] += a * y[q];
 }
 
 __global__ void sub_inplace_kernel(double* x, const double* y, size_t n) {
@@ -2488,6 +2587,7 @@ int jacobi_svd_top_op(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* U
         ctx->si_fallbacks += 1;
     }
     if (op.M) {
+        if (k == n && Ut && Vt && ctx->svd_polar && n >= ctx->svd_polar_min_n) return svd_full_polar(ctx, op.M, n, S, Ut, Vt, op.warm);   // workspace: right vectors
         if (k == n) return svd_full(ctx, op.M, n, k, S, Ut, Vt, op.warm);                   // full decomposition: the workspace keeps the left vectors
         CTM_TRY(svd_full(ctx, op.M, n, k, S, Ut, Vt)); return keep_warm();
     }
