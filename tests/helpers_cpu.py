@@ -80,6 +80,7 @@ def run_generic_optimizer(g, tmpdir, device="cpu"):
     ctm_args = copy.deepcopy(cfg.ctm_args); ctm_args.ctm_max_iter = int(g["ctm_iter"])
     opt_args = copy.deepcopy(cfg.opt_args); opt_args.opt_logging = False
     main_args = copy.deepcopy(cfg.main_args); main_args.opt_max_iter = int(g["epochs"])
+    os.makedirs(str(tmpdir), exist_ok=True)
     main_args.out_prefix = os.path.join(str(tmpdir), "o"); main_args.opt_resume = None
 
     @torch.no_grad()

@@ -301,3 +301,14 @@ def test_generic_optimizer_follows_the_reference_trajectory_on_the_engine(eng, n
     assert float(np.abs(np.array(losses) - g["losses"]).max()) < 1e-8, (losses, g["losses"])
     for c, t in sites.items():
         assert float(np.abs(t - g[f"final_{c[0]}_{c[1]}"]).max()) < 1e-6, c
+
+
+def test_concurrently_built_graphs_are_reproducible(eng, tmp_path):
+    """The site units of a differentiable move are built from worker threads on their own streams and replayed by autograd on those
+    streams: three identical optimisation runs in one process must give the same losses to rounding (a cross-stream ordering or
+    allocator hazard shows up as run-to-run scatter far above that)."""
+    from helpers_cpu import run_generic_optimizer
+    g = golden("generic_optim_D2_chi8_f64")
+    runs = [run_generic_optimizer(g, tmp_path / f"r{i}", device="cuda")[0] for i in range(3)]
+    for r in runs[1:]:
+        assert float(np.abs(np.array(r) - np.array(runs[0])).max()) < 1e-12, runs
