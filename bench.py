@@ -277,17 +277,20 @@ def run_workload(args, eng, dev, kind, D, chi, dtype, signed, steps, warmup, wor
     for _ in range(warmup):
         step()
     fence()
+    import parallel
+    parallel.comm_time_s(reset=True); parallel.comm_timing = world > 1
     eng.set_option("gemm_timing", 1)
     eng.timers(reset=True)
     if args.profile:
         eng.set_option("profile", 1)
-    step_ms = []
+    step_ms, step_hits = [], []
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
         if kind == "c4v":                 # ms-scale steps: per-step wall times (the sync costs ~10 us) for the steady-state figure
             torch.cuda.synchronize()
             step_ms.append(time.perf_counter())
+            step_hits.append(eng.stat("eigh_warm_hits"))
     fence()
     dt = time.perf_counter() - t0
     if step_ms:
@@ -298,6 +301,8 @@ def run_workload(args, eng, dev, kind, D, chi, dtype, signed, steps, warmup, wor
     k_fl = [eng.stat(f"k_flops{i}") for i in KK]
     k_n = [eng.stat(f"k_calls{i}") for i in KK]
     phase = eng.timers()
+    # time this rank spent in the two exchanges of every move (all-gather of P, Pt and of the new C, C, T): its own phase entry
+    phase["comm"] = parallel.comm_time_s(reset=True); parallel.comm_timing = False
     absorb_bytes, absorb_calls = eng.stat("absorb_bytes"), eng.stat("absorb_calls")
     svd = {"decompositions": int(eng.stat("jacobi_calls")),
            "avg_jacobi_sweeps": round(eng.stat("total_sweeps") / max(eng.stat("jacobi_calls"), 1), 2),
@@ -353,6 +358,15 @@ def run_workload(args, eng, dev, kind, D, chi, dtype, signed, steps, warmup, wor
     if step_ms:
         srt = sorted(step_ms)
         med = srt[len(srt) // 2]
+        # sweeps in which the environment still moved (the warm restart of the eigensolver was NOT accepted: the regular subspace
+        # iteration ran) against sweeps on a stationary corner (restart accepted)
+        hit = [b > a for a, b in zip([0] + step_hits[:-1], step_hits)]          # (the counter was reset with the timers above)
+        mov = [t for t, h in zip(step_ms, hit) if not h]
+        sta = [t for t, h in zip(step_ms, hit) if h]
+        out["moving_environment"] = {"sweeps": len(mov), "ms_per_step": round(sum(mov) / max(len(mov), 1), 4),
+                                     "sweeps_per_sec": round(1e3 * len(mov) / sum(mov), 1) if mov else None}
+        out["stationary_environment"] = {"sweeps": len(sta), "ms_per_step": round(sum(sta) / max(len(sta), 1), 4),
+                                         "sweeps_per_sec": round(1e3 * len(sta) / sum(sta), 1) if sta else None}
         out["steady_state"] = {"ms_per_step_median": round(med, 4), "sweeps_per_sec_at_median": round(1e3 / med, 1),
                                "ms_per_step_first": round(step_ms[0], 3), "ms_per_step_max": round(srt[-1], 3),
                                "warm_restarts_accepted": int(eng.stat("eigh_warm_hits")), "warm_restarts_rejected_by_probe": int(eng.stat("eigh_warm_rejects")),
@@ -374,6 +388,69 @@ def run_workload(args, eng, dev, kind, D, chi, dtype, signed, steps, warmup, wor
                                 ("positive random tensors A ~ U[0,1) (the state SURVEY 8d prescribes): numerically low-rank environment, "
                                  "see the full_rank block for the same shape on a full-rank state")}
     return out, dom, sites, state, env
+
+
+def energy_block(eng, state, env, world):
+    """The energy half of the metric at the size of the timed run: seconds for ONE evaluation of E/site = mean over the 4 sites of
+    tr(rho_2x2(coord) h_p) (reference models/j1j2.py:236-240, ctm/generic/rdm.py:1362-1592) on the environment the timed sweeps
+    ended with, plus the invariants of the four plaquette RDMs (trace, Hermiticity, smallest eigenvalue)."""
+    from models import j1j2
+    from ctm.generic import rdm
+    model = j1j2.J1J2(j1=1.0, j2=0.5)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    e = float(model.energy_per_site(state, env))
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    out = {"seconds_per_energy_4_sites": round(dt, 3), "energy_per_site_j2_0.5": e, "n_gpus": world,
+           "what": "rdm2x2 of the 4 sites (chunked open halves, split-K n^3 GEMMs) + tr(rho h_p), after the timed sweeps of this block"}
+    if world == 1:
+        r = rdm.rdm2x2((0, 0), state, env).reshape(16, 16).cpu()
+        out["rdm2x2_invariants"] = {"trace_minus_1": float(abs(torch.trace(r) - 1.0)), "hermiticity": float((r - r.conj().T).abs().max()),
+                                    "min_eigenvalue": float(torch.linalg.eigvalsh(0.5 * (r + r.conj().T)).min())}
+    return out
+
+
+def compact(res):
+    """One BASELINE configuration as a short block of the JSON line."""
+    roof = res["roofline"]
+    out = {"value": res["value"], "unit": "sweeps/s", "ms_per_step": res["ms_per_step"], "steps": res["steps"], "warmup": res["warmup"],
+           "dominant_kernel": {k: roof.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "frac_union")},
+           "svd": res["svd"]}
+    for k in ("state", "steady_state", "moving_environment", "stationary_environment"):
+        if k in res:
+            out[k] = res[k]
+    if "state" in out:
+        out["state"] = {k: v for k, v in out["state"].items() if k != "note"}
+    return out
+
+
+def other_configs(args, eng, dev, world, rank, dist):
+    """Every other single-GPU BASELINE configuration, a few sweeps each (the default line used to carry configs[3] only):
+    configs[1] C4v D4 chi64 (with the rate while the environment still moves), configs[2] generic D6 chi128 on both states,
+    configs[4] generic D8 chi384 complex128 (1 warm-up + 1 timed sweep per state: 10-20 s per sweep on one GPU)."""
+    import gc
+    out = {}
+    saved = (args.no_serial_pass,)
+    args.no_serial_pass = True
+    try:
+        for name, signed, steps, warmup in (("c4v_D4_chi64", False, 100, 0), ("generic_D6_chi128", False, 3, 4), ("generic_D6_chi128", True, 3, 4),
+                                            ("generic_D8_chi384_c128", False, 1, 1), ("generic_D8_chi384_c128", True, 1, 1)):
+            kind, D, chi, dtype = CONFIGS[name]
+            key = name + ("_signed" if signed else "")
+            try:
+                t0 = time.perf_counter()
+                res, dom, sites, state, env = run_workload(args, eng, dev, kind, D, chi, dtype, signed, steps, warmup, world, rank, dist)
+                out[key] = compact(res)
+                out[key]["dtype"] = dtype
+                out[key]["wall_s_incl_warmup"] = round(time.perf_counter() - t0, 1)
+                del state, env, sites
+            except Exception as e:
+                out[key] = {"error": repr(e)}
+            gc.collect(); torch.cuda.empty_cache()
+            if hasattr(eng, "trim"):
+                eng.trim()
+    finally:
+        args.no_serial_pass, = saved
+    return out
 
 
 def traffic_from_profile(args, world, dom, signed):
@@ -429,6 +506,8 @@ def main():
     ap.add_argument("--no-serial-pass", action="store_true", help="skip the extra serially issued sweep behind roofline.serial_pass")
     ap.add_argument("--serial-units", action="store_true", help="do not overlap the independent site-units of a move on streams")
     ap.add_argument("--cold-start", action="store_true", help="no warm start of the leading-chi iteration")
+    ap.add_argument("--no-energy", action="store_true", help="skip the energy block (E/site from rdm2x2 at the size of the timed run)")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the compact blocks of the other single-GPU BASELINE configurations")
     args = ap.parse_args()
     kind, D, chi, dtype = CONFIGS[args.config]
     steps = args.steps if args.steps is not None else (100 if kind == "c4v" else 2)
@@ -452,6 +531,7 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(os.environ.get("CTM_BENCH_BACKEND", "nccl"), rank=rank, world_size=world)
+        world, rank = dist.get_world_size(), dist.get_rank()        # n_gpus of the JSON line = size of the process group that ran
 
     import config as cfg
     cfg.global_args.device = f"cuda:{local}"
@@ -482,6 +562,11 @@ def main():
         ftr = traffic_from_profile(args, world, fdom, True)
         if ftr:
             full["roofline"]["traffic"] = ftr["dominant"]; full["roofline"]["traffic_source"] = ftr["source"]
+        if not args.no_energy and args.config == DEFAULT_CONFIG:
+            try:
+                full["energy"] = energy_block(eng, fstate, fenv, world)
+            except Exception as e:                        # reporting only
+                full["energy"] = {"error": repr(e)}
         del fstate, fenv
         gc.collect(); torch.cuda.empty_cache()
     else:
@@ -489,6 +574,11 @@ def main():
         if kind != "c4v" and rank == 0 and not args.no_cpu_baseline and world == 1:
             env_np = ({k: v.cpu().numpy() for k, v in env.C.items()}, {k: v.cpu().numpy() for k, v in env.T.items()})
 
+    others = None
+    if args.config == DEFAULT_CONFIG and not primary_signed and not args.no_other_configs and world == 1 and not args.no_full_rank:
+        del sites
+        others = other_configs(args, eng, dev, world, rank, dist)
+        sites = synth_sites(kind, D, dtype=dtype)                 # (the CPU baseline below takes the site tensors of the primary block)
     if rank == 0:
         out = {"metric": "ctm_sweeps_per_sec", "value": res["value"], "unit": "sweeps/s", "n_gpus": world, "steps": steps,
                "warmup": warmup, "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": "strong",
@@ -507,6 +597,10 @@ def main():
                                 "steps": full["steps"], "warmup": full["warmup"],
                                 "config": {"workload": args.config, "state": "A ~ U(-1,1), A /= max|A| (signed random tensors)", "n": chi * D * D},
                                 "state": full["state"], "roofline": full["roofline"], "svd": full["svd"], "phase_s": full["phase_s"]}
+        if full is not None and "energy" in full:
+            out["full_rank"]["energy"] = full["energy"]
+        if others is not None:
+            out["other_configs"] = others
         if not args.no_cpu_baseline and world == 1:
             try:
                 out["cpu_baseline"] = cpu_baseline(kind, D, chi, sites, env_np, svd_n=args.cpu_svd_n)

@@ -855,8 +855,29 @@ def input_files_case():
     print("  input files: copied", len(files), "reference data files and the arrays the reference parses from them")
 
 
+def chiral_case():
+    """energy_per_site with the chiral plaquette term (reference models/j1j2.py:236-247: the UN-rotated chiral_term added per plaquette)
+    on the stored complex128 state: the reference's own model tensors contracted with the reference's rdm2x2 of every site."""
+    set_dtype(True)
+    g = np.load(os.path.join(GOLD, "generic_D2_chi8_c128.npz"))
+    coords = [(0, 0), (1, 0), (0, 1), (1, 1)]
+    model = j1j2.J1J2(j1=1.0, j2=0.5, lmbd=0.3)
+    e = 0.
+    for c in coords:
+        r = torch.from_numpy(g[f"rdm2x2_{c[0]}_{c[1]}"])
+        e = e + torch.einsum('ijklabcd,ijklabcd', r, model.get_hp(c)) + model.lmbd * torch.einsum('ijklabcd,ijklabcd', r, model.chiral_term)
+    e = (e / len(coords))
+    assert abs(e.imag) < 1e-12
+    np.savez_compressed(os.path.join(GOLD, "chiral.npz"), energy_j2_05_lmbd_03=np.array(float(e.real)), lmbd=np.array(0.3),
+                        chiral_term=t2n(model.chiral_term))
+    print(f"  chiral: energy_per_site(j2=0.5, lmbd=0.3) on generic_D2_chi8_c128 = {float(e.real):.15f}")
+    set_dtype(False)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["decomp", "generic", "c4v", "c4v_ad", "generic_ad", "c4v_j3", "generic_corr", "envinit", "rvb", "files", "variants", "aklt", "inputs", "backward"]
+    if "chiral" in which:
+        chiral_case()
     if "backward" in which:
         backward_case()
     if "inputs" in which:

@@ -32,6 +32,8 @@
         }                                                                                             \
     } while (0)
 
+constexpr int CTM_TILE_COUNTERS = 8192;
+
 #define CTM_TRY(expr)                        \
     do {                                     \
         int _s = (expr);                     \
@@ -92,6 +94,11 @@ struct ctm_ctx {
     double lz_first_factor = 3.25;      // cold default: first extraction when the basis holds this many times k rows
     bool lz_verify_op = false;          // additionally check both relations of the Ritz triplets with operator applications (debug / tests)
     long lz_extractions = 0; double lz_last_est = 0.0; int lz_last_steps = 0;
+    int lz_jacobi_block = 0;            // > 0: panel height of the Jacobi SVD of the Ritz matrix (16: 32 x 32 pair Grams, 18 KB LDS eigensolver)
+    bool lz_async = true;               // block Krylov recurrence issued without host synchronisations (status words checked at the extraction)
+    bool lz_force_sync = false;         // (internal) the current solve is being repeated on the synchronous path
+    long lz_async_fallbacks = 0, lz_third_passes = 0;
+    bool lz_local_project = true;       // first Gram-Schmidt pass of a block step against the previous block only, second against all
     int last_sweeps = 0;
     long total_sweeps = 0, jacobi_calls = 0;
     double last_offnorm = 0;
@@ -119,6 +126,8 @@ struct ctm_ctx {
     int strip_target_wgs = 512;   // K slices x column tiles of the strip kernel: fewer slices = fewer partials (measured 512 <= 1024, 256)
     int rows_kernel_min_m = 1, rows_kernel_min_m_kc = 1;   // LDS-tiled row-block kernel from this many rows (n-contiguous / k-contiguous big operand)
     int rows_target_wgs = 768;    // its workgroup count (column tiles x K slices): three per CU
+    bool rows_fused_reduce = true;      // its K-slice partials are summed inside the launch by the last workgroup of a column tile
+    unsigned* tile_cnt = nullptr;       // per-column-tile arrival counters of that combine (zero between launches)
     bool gemm_split_rem = true;   // split a 128 q + r (r <= 64) dimension into a vectorised part and a strip
     int splitk_max_tiles = 256, splitk_target_wgs = 1024;   // split-K of skinny GEMMs: when few output tiles, how many workgroups to aim for
     bool eig64_pingpong = true;
@@ -195,6 +204,8 @@ struct GemmDesc {
     const double* colscale = nullptr;
     // optional per-batch skip flags (device): batch z is skipped when skip_flags[z] == 0
     const int* skip_flags = nullptr;
+    // optional device word: the whole product (and its split-K reduction) is skipped when *skip_all == 0 (generic kernel only)
+    const int* skip_all = nullptr;
 };
 int gemm_f64(ctm_ctx* ctx, const GemmDesc& d);
 void gemm_timing_drain(ctm_ctx* ctx);

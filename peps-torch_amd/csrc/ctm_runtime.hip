@@ -69,6 +69,7 @@ int ctm_destroy(ctm_ctx* ctx) {
     for (auto& s : ctx->arena.slabs) (void)hipFree(s.base);
     for (auto& e : ctx->ev_pool) (void)hipEventDestroy(e);
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
+    if (ctx->tile_cnt) (void)hipFree(ctx->tile_cnt);
     if (ctx->h_scratch) (void)hipHostFree(ctx->h_scratch);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -129,6 +130,7 @@ int ctm_set_option(ctm_ctx* ctx, const char* key, double value) {
     else if (k == "rows_kernel_min_m") ctx->rows_kernel_min_m = (int)value;
     else if (k == "rows_kernel_min_m_kc") ctx->rows_kernel_min_m_kc = (int)value;
     else if (k == "rows_target_wgs") ctx->rows_target_wgs = (int)value;
+    else if (k == "rows_fused_reduce") ctx->rows_fused_reduce = value != 0.0;
     else if (k == "eigh_warm") ctx->eigh_warm = (int)value;
     else if (k == "svd_abs_accuracy") ctx->svd_abs_accuracy = (int)value;
     else if (k == "lz_abs_accuracy") ctx->lz_abs_accuracy = (int)value;
@@ -144,6 +146,9 @@ int ctm_set_option(ctm_ctx* ctx, const char* key, double value) {
     else if (k == "lz_stride") ctx->lz_stride = (int)value;
     else if (k == "lz_first_factor") ctx->lz_first_factor = value;
     else if (k == "lz_verify_op") ctx->lz_verify_op = value != 0.0;
+    else if (k == "lz_async") ctx->lz_async = value != 0.0;
+    else if (k == "lz_jacobi_block") ctx->lz_jacobi_block = (int)value;
+    else if (k == "lz_local_project") ctx->lz_local_project = value != 0.0;
     else if (k == "layer2_cplx") ctx->layer2_cplx = value != 0.0;
     else if (k == "layer2_reg") ctx->layer2_reg = (int)value;
     else if (k == "eig64_bpt") ctx->eig64_bpt = (int)value;
@@ -181,6 +186,8 @@ int ctm_get_stat(ctm_ctx* ctx, const char* key, double* value) {
     else if (k == "lz_total_steps") *value = (double)ctx->lz_total_steps;
     else if (k == "lz_extractions") *value = (double)ctx->lz_extractions;
     else if (k == "lz_last_est") *value = ctx->lz_last_est;
+    else if (k == "lz_async_fallbacks") *value = (double)ctx->lz_async_fallbacks;
+    else if (k == "lz_third_passes") *value = (double)ctx->lz_third_passes;
     else if (k == "lz_last_steps") *value = (double)ctx->lz_last_steps;
     else if (k == "gemm_flops") *value = ctx->gemm_flops;
     else if (k == "gemm_calls") *value = (double)ctx->gemm_calls;

@@ -38,6 +38,7 @@ struct GemmParams {
     int splitA, splitB, splitC, splitB_dim;
     const double* colscale;
     const int* skip_flags;
+    const int* skip_all;                           // device word: the whole launch does nothing when *skip_all == 0
     int tilesM, tilesN;
     int ksplit, klen; long long split_stride;      // split-K: blockIdx.z = K slice, partial C written at z*split_stride
 };
@@ -52,6 +53,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmParams p) {
     double* Bs = smem + 2 * BK * LDA;
 
     if (p.skip_flags && p.skip_flags[blockIdx.z] == 0) return;   // uniform per workgroup
+    if (p.skip_all && *p.skip_all == 0) return;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wid = tid >> 6;
     const int wm = wid >> 1, wn = wid & 1;
@@ -322,6 +324,10 @@ struct StripParams {
     const double* B; long long ldb;          // BNF: row stride of K x N ; !BNF: row stride of N x K
     double* P;                               // partials [ks][M][N]
     int klen;
+    // row-block kernel only: the K-slice partials are summed inside the launch by the last workgroup to finish a column tile
+    // (fixed slice order: deterministic), which writes C = alpha * sum [* colscale] + beta * C.  ks == 1: written directly.
+    double* C = nullptr; long long ldc = 0; double alpha = 1.0, beta = 0.0; const double* colscale = nullptr;
+    unsigned* cnt = nullptr; int ks = 1;
 };
 
 typedef double d4v __attribute__((ext_vector_type(4)));
@@ -491,6 +497,25 @@ __global__ __launch_bounds__(256, 3) void gemm_rows_kernel(StripParams p) {
         if (kt + 1 < nk) store_tile(buf ^ 1);
         __syncthreads();
     }
+    if (p.ks == 1) {          // no K split: finished values
+#pragma unroll
+        for (int i = 0; i < TMW; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = i * 16 + lk + 4 * r;
+                if (m >= p.M) continue;
+                double* row = p.C + (long long)m * p.ldc + n0 + wn * 32;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int c = 16 * j + lr;
+                    double v = p.alpha * acc[i][j][r];
+                    if (p.colscale) v *= p.colscale[n0 + wn * 32 + c];
+                    if (p.beta != 0.0) v += p.beta * row[c];
+                    row[c] = v;
+                }
+            }
+        return;
+    }
     double* P = p.P + (long long)blockIdx.y * p.M * p.N;
 #pragma unroll
     for (int i = 0; i < TMW; ++i)
@@ -501,6 +526,55 @@ __global__ __launch_bounds__(256, 3) void gemm_rows_kernel(StripParams p) {
             double* row = P + (long long)m * p.N + n0 + wn * 32;
             row[lr] = acc[i][0][r]; row[16 + lr] = acc[i][1][r];
         }
+    if (p.ks <= 0) return;               // partials only: a separate reduce kernel follows
+    // In-launch combine of the K-slice partials (cdna_hip_programming.md, split-K counter recipe): plain slab stores, every wave
+    // drains its stores, one agent-scope release by lane 0, then the ticket; the workgroup that draws ks-1 acquires once and sums
+    // the slabs of its column tile in slice order.  Correct for any placement of the slices over XCDs; replaces a reduce launch
+    // that re-streamed ks * M * N partials through HBM behind a kernel boundary.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int* flag = reinterpret_cast<int*>(smem);              // the K loop is over: the tile buffers are free
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned t = __hip_atomic_fetch_add(&p.cnt[blockIdx.x], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = (t == (unsigned)(p.ks - 1));
+        if (last) {
+            __hip_atomic_store(&p.cnt[blockIdx.x], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        *flag = last;
+    }
+    __syncthreads();
+    if (!*flag) return;
+    // reducer: thread = (column pair, row group); rows rg, rg + 4, ...; 16-byte loads, four rows of all slices in flight
+    const int cp = tid & 63, rg = tid >> 6;
+    const long long slab = (long long)p.M * p.N;
+    const double* P0 = p.P + n0 + 2 * cp;
+    double cs0 = 1.0, cs1 = 1.0;
+    if (p.colscale) { cs0 = p.colscale[n0 + 2 * cp]; cs1 = p.colscale[n0 + 2 * cp + 1]; }
+    for (int m0 = rg; m0 < p.M; m0 += 16) {
+        d2 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = (d2){0.0, 0.0};
+        for (int s = 0; s < p.ks; ++s) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int m = m0 + 4 * u;
+                if (m < p.M) v[u] += *(const d2*)(P0 + s * slab + (long long)m * p.N);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int m = m0 + 4 * u;
+            if (m >= p.M) continue;
+            double* c = p.C + (long long)m * p.ldc + n0 + 2 * cp;
+            d2 w = v[u] * p.alpha;
+            w[0] *= cs0; w[1] *= cs1;
+            if (p.beta != 0.0) { w[0] += p.beta * c[0]; w[1] += p.beta * c[1]; }
+            c[0] = w[0]; c[1] = w[1];
+        }
+    }
 }
 
 template <bool BNF>
@@ -524,7 +598,9 @@ void launch_strip(int tm, dim3 grid, hipStream_t st, const StripParams& sp) {
 }
 
 __global__ void splitk_reduce_kernel(const double* __restrict__ part, int nsplit, long long stride, double* __restrict__ C, int M, int N,
-                                     long long ldc, double alpha, double beta, const double* __restrict__ colscale, int vec) {
+                                     long long ldc, double alpha, double beta, const double* __restrict__ colscale, int vec,
+                                     const int* __restrict__ skip_all = nullptr) {
+    if (skip_all && *skip_all == 0) return;
     // sum of the K-slice partials in a fixed order (deterministic).  Two adjacent elements per thread (16-byte loads when N is
     // even) and four slices in flight per step: the partials of a strip GEMM are tens of MB, this kernel is pure HBM streaming.
     const long long tot = (long long)M * N;
@@ -565,7 +641,7 @@ __global__ void splitk_reduce_kernel(const double* __restrict__ part, int nsplit
 // operands of a plain GEMM the vectorised 128x128 kernel can take (apart from M, N being multiples of 128)
 static bool fast_operands(const ctm_ctx* ctx, const GemmDesc& d) {
     const bool ak = d.sak == 1, amf = d.sam == 1, bnf = d.sbn == 1, bkf = d.sbk == 1;
-    return ctx->gemm_fast && !d.offs && d.splitB_dim == 0 && d.splitA >= d.M && d.splitC >= d.M && !d.skip_flags && d.K % 16 == 0 &&
+    return ctx->gemm_fast && !d.offs && d.splitB_dim == 0 && d.splitA >= d.M && d.splitC >= d.M && !d.skip_flags && !d.skip_all && d.K % 16 == 0 &&
            (ak || amf) && (bnf || bkf) && (((uintptr_t)d.A | (uintptr_t)d.B) & 15) == 0 && ((ak ? d.sam : d.sak) % 2 == 0) &&
            ((bnf ? d.sbk : d.sbn) % 2 == 0) && (d.strideA % 2 == 0) && (d.strideB % 2 == 0);
 }
@@ -598,7 +674,7 @@ int gemm_f64(ctm_ctx* ctx, const GemmDesc& d) {
     }
     ArenaScope split_scope(ctx);      // split-K partials live only until the (stream-ordered) reduce kernel
     // a block of <= 64 k-contiguous rows times a big operand that is read once: the streaming strip kernel
-    if (ctx->gemm_strip && d.M <= 64 && d.batch == 1 && !d.offs && d.splitB_dim == 0 && d.splitA >= d.M && d.splitC >= d.M && !d.skip_flags &&
+    if (ctx->gemm_strip && d.M <= 64 && d.batch == 1 && !d.offs && d.splitB_dim == 0 && d.splitA >= d.M && d.splitC >= d.M && !d.skip_flags && !d.skip_all &&
         d.sak == 1 && (d.sbn == 1 || d.sbk == 1) && d.K % 16 == 0 && d.N % 32 == 0 && d.K >= 1024 && (long long)d.N * d.K >= (1ll << 22) &&
         (((uintptr_t)d.A | (uintptr_t)d.B) & 15) == 0 && d.sam % 2 == 0 && (d.sbn == 1 ? d.sbk : d.sbn) % 2 == 0) {
         const bool bnf = d.sbn == 1;
@@ -611,10 +687,25 @@ int gemm_f64(ctm_ctx* ctx, const GemmDesc& d) {
         int ks = std::max(1, std::min(std::min((target + gx - 1) / gx, d.K / 256), 64));
         int klen = (((d.K + ks - 1) / ks) + 15) / 16 * 16;
         ks = (d.K + klen - 1) / klen;
-        double* part;
-        if (arena_alloc(ctx, sizeof(double) * (size_t)ks * d.M * d.N, (void**)&part) != CTM_OK) return CTM_ERR_NOMEM;
+        // the row-block kernel sums its K slices inside the launch (last workgroup of a column tile); the strip kernel keeps the
+        // separate fixed-order reduce kernel
+        auto overlaps = [](const double* a, size_t na, const double* b, size_t nb) { return a < b + nb && b < a + na; };
+        const size_t spanC = (size_t)(d.M - 1) * d.ldc + d.N, spanA = (size_t)(d.M - 1) * d.sam + d.K;
+        const size_t spanB = (size_t)((bnf ? d.K : d.N) - 1) * (bnf ? d.sbk : d.sbn) + (bnf ? d.N : d.K);
+        // (the combine writes C while other workgroups of the launch still read A and B: no aliasing)
+        const bool fused = rows_kernel && ctx->rows_fused_reduce && d.N / 128 <= CTM_TILE_COUNTERS && (d.ldc % 2 == 0) &&
+                           (((uintptr_t)d.C) & 15) == 0 && !overlaps(d.C, spanC, d.A, spanA) && !overlaps(d.C, spanC, d.B, spanB);
+        if (fused && !ctx->tile_cnt) {
+            if (hipMalloc((void**)&ctx->tile_cnt, sizeof(unsigned) * CTM_TILE_COUNTERS) != hipSuccess ||
+                hipMemset(ctx->tile_cnt, 0, sizeof(unsigned) * CTM_TILE_COUNTERS) != hipSuccess) { ctx->set_error("gemm: tile counters"); return CTM_ERR_NOMEM; }
+        }
+        double* part = nullptr;
+        if (!(fused && ks == 1))
+            if (arena_alloc(ctx, sizeof(double) * (size_t)ks * d.M * d.N, (void**)&part) != CTM_OK) return CTM_ERR_NOMEM;
         StripParams sp;
         sp.M = d.M; sp.N = d.N; sp.K = d.K; sp.A = d.A; sp.sam = d.sam; sp.B = d.B; sp.ldb = bnf ? d.sbk : d.sbn; sp.P = part; sp.klen = klen;
+        if (fused) { sp.C = d.C; sp.ldc = d.ldc; sp.alpha = d.alpha; sp.beta = d.beta; sp.colscale = d.colscale; sp.cnt = ctx->tile_cnt; sp.ks = ks; }
+        else sp.ks = 0;                  // partials only (ks == 1 included): the reduce kernel below finishes
         int e0 = timing_begin(ctx);
         if (rows_kernel) {
             if (bnf) launch_rows<true>((d.M + 15) / 16, dim3(d.N / 128, ks), ctx->stream, sp);
@@ -625,8 +716,9 @@ int gemm_f64(ctm_ctx* ctx, const GemmDesc& d) {
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) { ctx->set_error(std::string("strip gemm launch: ") + hipGetErrorString(e)); return CTM_ERR_HIP; }
         const long long tot = (long long)d.M * d.N;
-        CTM_LAUNCH(ctx, splitk_reduce_kernel, dim3((int)std::min<long long>((tot + 255) / 256, 2048)), dim3(256), 0,
-                           (const double*)part, ks, tot, d.C, d.M, d.N, d.ldc, d.alpha, d.beta, d.colscale, ctx->splitk_reduce_vec);
+        if (!fused)
+            CTM_LAUNCH(ctx, splitk_reduce_kernel, dim3((int)std::min<long long>((tot + 255) / 256, 2048)), dim3(256), 0,
+                               (const double*)part, ks, tot, d.C, d.M, d.N, d.ldc, d.alpha, d.beta, d.colscale, ctx->splitk_reduce_vec, (const int*)nullptr);
         const double fl = 2.0 * d.M * d.N * (double)d.K;
         // class 3 (<= 32 rows: HBM-bound) reports algorithmic BYTES, class 4 (33..64 rows: MFMA-bound) flops
         if (d.M <= 32) timing_end(ctx, e0, 3, 8.0 * ((double)d.K * d.N + (double)d.M * d.K + (double)d.M * d.N));
@@ -646,6 +738,7 @@ int gemm_f64(ctm_ctx* ctx, const GemmDesc& d) {
     p.splitA = d.splitA; p.splitB = d.splitB; p.splitC = d.splitC; p.splitB_dim = d.splitB_dim;
     p.colscale = d.colscale;
     p.skip_flags = d.skip_flags;
+    p.skip_all = d.skip_all;
     p.ksplit = 1; p.klen = 0; p.split_stride = 0;
     const long long tiles128 = (long long)((d.M + 127) / 128) * ((d.N + 127) / 128) * d.batch;
     // medium-skinny products (a few hundred rows or columns against a long K): the vectorised kernel with K split so that the
@@ -722,7 +815,7 @@ int gemm_f64(ctm_ctx* ctx, const GemmDesc& d) {
         const long long tot = (long long)d.M * d.N;
         int blocks = (int)std::min<long long>((tot + 255) / 256, 2048);
         CTM_LAUNCH(ctx, splitk_reduce_kernel, dim3(blocks), dim3(256), 0, (const double*)part, fast_ks > 1 ? fast_ks : p.ksplit, p.split_stride, d.C,
-                           d.M, d.N, d.ldc, d.alpha, d.beta, d.colscale, ctx->splitk_reduce_vec);
+                           d.M, d.N, d.ldc, d.alpha, d.beta, d.colscale, ctx->splitk_reduce_vec, d.skip_all);
     }
     const double fl = 2.0 * d.M * d.N * (double)d.K * d.batch;
     if (e1 >= 0) {

@@ -63,17 +63,21 @@ __device__ __forceinline__ double tau_floor(double a, double b, double tau2, int
 // Round-robin ordering: m/2 disjoint rotations per round; per round the rotation parameters are computed by
 // m/2 lanes, then every thread transforms whole 2x2 blocks W[{p1,q1}][{p2,q2}] <- R1^T B R2 (row and column
 // update fused: each block is owned by exactly one thread) and the eigenvector columns -- two barriers per round.
-__global__ __launch_bounds__(1024) void small_eig_kernel(SmallEigParams p) {
+// MX = 64 or 32: capacity of the LDS images (m <= MX).  The 32 variant holds 18 KB of LDS: a workgroup of it fits on a CU beside the
+// chip-filling kernels of another unit (row-block GEMM: 2 x 50 KB), which is what lets a Ritz extraction on 16-row panels proceed
+// while another unit's corner passes are resident.
+template <int MX>
+__global__ __launch_bounds__(MX == 64 ? 1024 : 256) void small_eig_kernel(SmallEigParams p) {
     const int NTH = blockDim.x;      // 1024 for m = 64 (one 2x2 block + two eigenvector rows per thread), 256 for m <= 32
-    __shared__ double W[MAXM][MAXM + 1];
-    __shared__ double Jm[MAXM][MAXM + 1];
-    __shared__ double cs_c[MAXM / 2], cs_s[MAXM / 2];
-    __shared__ int pr_p[MAXM / 2], pr_q[MAXM / 2];
+    __shared__ double W[MX][MX + 1];
+    __shared__ double Jm[MX][MX + 1];
+    __shared__ double cs_c[MX / 2], cs_s[MX / 2];
+    __shared__ int pr_p[MX / 2], pr_q[MX / 2];
     __shared__ double red[16];
     __shared__ int rot_flag;
     __shared__ int round_rot[2];
-    __shared__ unsigned char pair_tab[MAXM - 1][MAXM / 2][2];
-    __shared__ int rank_of[MAXM];
+    __shared__ unsigned char pair_tab[MX - 1][MX / 2][2];
+    __shared__ int rank_of[MX];
 
     const int m = p.m, tid = threadIdx.x;
     const double* G = p.G + (size_t)blockIdx.x * m * m;
@@ -704,7 +708,8 @@ int jacobi_rows(ctm_ctx* ctx, double* X, int R, long long ld, int Cg, int Ctot, 
                 else if (ctx->eig64_bpt == 2) CTM_LAUNCH(ctx, small_eig64_kernel<2>, dim3(pairs), dim3(512), 0, sp);
                 else CTM_LAUNCH(ctx, small_eig64_kernel<1>, dim3(pairs), dim3(1024), 0, sp);
             }
-            else CTM_LAUNCH(ctx, small_eig_kernel, dim3(pairs), dim3(m > 32 ? 1024 : 256), 0, sp);
+            else if (m > 32) CTM_LAUNCH(ctx, small_eig_kernel<64>, dim3(pairs), dim3(1024), 0, sp);
+            else CTM_LAUNCH(ctx, small_eig_kernel<32>, dim3(pairs), dim3(256), 0, sp);
             GemmDesc a;
             a.M = m; a.N = Ctot; a.K = m;
             a.A = J; a.sam = 1; a.sak = m;                       // J^T
@@ -1114,6 +1119,12 @@ int matop_apply(ctm_ctx* ctx, const MatOp& op, bool transpose, const double* B, 
 // Calls of a unit that start cold after its full-block warm probe (two half steps on k + k/2 rows) was handed to the Krylov solver
 // with relative residual r.  A probe is only kept below r = 1e-9; the environment of a converging run contracts by a factor
 // of a few per sweep and a unit is visited twice per sweep, so the next probe is scheduled for when it could succeed.
+// memory of a unit between sweeps (header row of its warm workspace, doubles): [0] calls left that skip the warm probe (svd_iter),
+// [1] block steps of the last accepted Krylov solve, [2] its residual estimate / s_0, [3] consecutive warm probes that were handed
+// to the Krylov solver (each one doubles the distance to the next probe: a full-rank environment at its rounding floor, where the
+// previous basis stays ~1e-10 away from the new operator for ever, otherwise pays two half steps on k + k/2 rows every few sweeps)
+enum { HDR_SKIP = 0, HDR_STEPS = 1, HDR_EST = 2, HDR_FAILS = 3, HDR_WORDS = 4 };
+
 inline int warm_skip_calls(const ctm_ctx* ctx, double r) {
     const int need = (int)std::ceil(2.0 * std::log(std::max(r, 1e-9) / 1e-9) / std::log(5.0)) - 1;
     return std::max(1, std::min(ctx->si_warm_skip_calls, need));
@@ -1155,11 +1166,25 @@ int svd_iter(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* Ut, double
     // have are zero) completed by pseudo-random rows projected onto its orthogonal complement -- or, cold, a
     // pseudo-random basis (need not be orthonormal)
     int kw = 0;
+    double hdr_fails = 0.0;
+    // a failed full-block warm probe: remember it, and place the next one further away each time
+    auto probe_failed = [&](double r) -> int {
+        if (!op.warm_hdr) return CTM_OK;
+        const double f = std::min(hdr_fails + 1.0, 8.0);
+        const int skip = std::max(warm_skip_calls(ctx, r), std::min(2048, ctx->si_warm_skip_calls << (int)(f - 1.0)));
+        CTM_TRY(fill_f64(ctx, op.warm_hdr + HDR_SKIP, 1, (double)skip));
+        return fill_f64(ctx, op.warm_hdr + HDR_FAILS, 1, f);
+    };
     if (op.warm) {
         double hdr = 0.0;
         CTM_TRY(row_norms(ctx, op.warm, k, n, n, norms));
         CTM_HIP_CHECK(ctx, hipMemcpyAsync(h.data(), norms, sizeof(double) * std::min(k, p_full), hipMemcpyDeviceToHost, ctx->stream));
-        if (op.warm_hdr) CTM_HIP_CHECK(ctx, hipMemcpyAsync(&hdr, op.warm_hdr, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        if (op.warm_hdr) {
+            double hw[HDR_WORDS];
+            CTM_HIP_CHECK(ctx, hipMemcpyAsync(hw, op.warm_hdr, sizeof(hw), hipMemcpyDeviceToHost, ctx->stream));
+            CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+            hdr = hw[HDR_SKIP]; hdr_fails = hw[HDR_FAILS];
+        }
         CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
         while (kw < std::min(k, p_full) && std::fabs(h[kw] - 1.0) < 1e-6) ++kw;
         std::fill(h.begin(), h.end(), 0.0);
@@ -1243,13 +1268,17 @@ int svd_iter(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* Ut, double
             if (want_krylov && ctx->lz_enable && k >= ctx->lz_min_k && !exhausted && warm && it == 1 && worst > 1e-9 * s0) {
                 // a warm basis that is not close (environment still changing) on a full-rank problem: block Krylov straight away,
                 // and the next calls of this unit do not pay for the full-block probe again (see warm_skip_calls())
-                if (op.warm_hdr) CTM_TRY(fill_f64(ctx, op.warm_hdr, 1, (double)warm_skip_calls(ctx, worst / s0)));
+                CTM_TRY(probe_failed(worst / s0));
                 *want_krylov = true; ctx->si_last_iters = it; ctx->si_total_iters += it; return CTM_OK;
             }
             if (want_krylov && ctx->lz_enable && k >= ctx->lz_min_k && !exhausted && worst_prev > 0.0 && worst < worst_prev) {
                 const double rate = worst / worst_prev, need = std::log(resid_tol(ctx, n) * s0 / worst) / std::log(rate);
-                if (need > ctx->lz_switch_steps) { *want_krylov = true; ctx->si_last_iters = it; ctx->si_total_iters += it; return CTM_OK; }
+                if (need > ctx->lz_switch_steps) {
+                    if (warm && p == p_full) CTM_TRY(probe_failed(worst / s0));
+                    *want_krylov = true; ctx->si_last_iters = it; ctx->si_total_iters += it; return CTM_OK;
+                }
             } else if (want_krylov && ctx->lz_enable && k >= ctx->lz_min_k && !exhausted && worst_prev > 0.0 && it >= 6) {
+                if (warm && p == p_full) CTM_TRY(probe_failed(worst / s0));
                 *want_krylov = true; ctx->si_last_iters = it; ctx->si_total_iters += it; return CTM_OK;      // not contracting at all
             }
             worst_prev = worst;
@@ -1304,6 +1333,7 @@ int svd_iter(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* Ut, double
     CTM_TRY(reorth_rows(ctx, Vt, kv, n, n, 1));
     ctx->si_last_rank = rank;
     ctx->si_warm_starts += warm ? 1 : 0;
+    if (warm && op.warm_hdr && hdr_fails > 0.0) CTM_TRY(fill_f64(ctx, op.warm_hdr + HDR_FAILS, 1, 0.0));
     return CTM_OK;
 }
 
@@ -1949,13 +1979,125 @@ int orthonormalise_block(ctm_ctx* ctx, double* W, int rows, int n, double* norms
     return CTM_OK;
 }
 
+// Sync-free variant of the block orthonormalisation (the Krylov recurrence issues its steps without waiting for the device):
+// Cholesky-QR of the 64 rows with the unit-norm scaling folded into the factorisation.  One workgroup of 256 threads:
+//   d_i = G_ii (squared row norms), A = D^-1/2 G D^-1/2 (unit diagonal), A = L L^T (right-looking; thread (ti, tk) keeps a 4 x 4
+//   block of the lower triangle in registers, one barrier per column), X = L^-1 (forward substitution, four lanes per column),
+//   out = X D^-1/2  so that  out * W  has orthonormal rows.  34 KB of LDS (L below the diagonal, X above it): the kernel fits on a
+//   CU beside two workgroups of the row-block GEMM, so another unit's corner passes do not delay it.
+// mode 0 (first pass): when a pivot of A falls below 1e-10 (rows nearly dependent: cond(W) > ~1e5, beyond two Cholesky-QR passes)
+//   the factorisation is repeated on A + 1e-10 I (shifted Cholesky-QR: the result is only roughly orthonormal, cond ~ 1e-5 cond(W))
+//   and *flag3 is set: a third pass then finishes.  mode 1: plain.  mode 2 (third pass): returns at once unless *flag3.
+// status[0] = smallest pivot of the accepted factorisation, [1] = smallest, [2] = largest row norm.  Nothing is decided on the
+// host here: the caller reads the status words of all its steps at its next host synchronisation.
+__global__ __launch_bounds__(256) void chol64_scaled_inv_kernel(const double* __restrict__ G, double* __restrict__ out, double* __restrict__ status,
+                                                                int* __restrict__ flag3, int mode) {
+    constexpr int M = 64;
+    __shared__ double LX[M][M + 1];            // L on and below the diagonal; X = L^-1 (strictly lower part) transposed above it
+    __shared__ double dinv[M], xd[M];
+    __shared__ double col[2][M];
+    const int tid = threadIdx.x;
+    if (mode == 2 && *flag3 == 0) { if (tid == 0) { status[0] = 1.0; status[1] = -1.0; status[2] = -1.0; } return; }   // skipped: marked by the -1
+    if (tid < M) { const double d = G[tid * M + tid]; dinv[tid] = d > 0.0 ? 1.0 / sqrt(d) : 0.0; }
+    __syncthreads();
+    const int ti = tid >> 4, tk = tid & 15, i0 = 4 * ti, k0 = 4 * tk;
+    double pmin = 1e300;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        const double shift = attempt == 0 ? 0.0 : 1e-10;
+        double a[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) a[u][v] = G[(i0 + u) * M + k0 + v] * dinv[i0 + u] * dinv[k0 + v] + ((i0 + u == k0 + v) ? shift : 0.0);
+        pmin = 1e300;
+        for (int j = 0; j < M; ++j) {
+            const int jb = j >> 2, jv = j & 3, buf = j & 1;
+            if (tk == jb && ti >= jb) {            // owners of column j publish it (unscaled, pivot included)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    double cv = a[u][0];
+                    if (jv == 1) cv = a[u][1]; else if (jv == 2) cv = a[u][2]; else if (jv == 3) cv = a[u][3];
+                    col[buf][i0 + u] = cv;
+                }
+            }
+            __syncthreads();
+            const double piv = col[buf][j];
+            pmin = fmin(pmin, piv);
+            const double ps = fmax(piv, 1e-300), rp = 1.0 / ps, rl = 1.0 / sqrt(ps);
+            if (tk == jb && ti >= jb) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) if (i0 + u >= j) LX[i0 + u][j] = col[buf][i0 + u] * rl;
+            }
+            if (tk >= jb && ti >= tk) {            // trailing update of my block: columns k > j, rows i >= k
+                double ci[4], ck[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { ci[u] = col[buf][i0 + u]; ck[u] = col[buf][k0 + u] * rp; }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v)
+                        if (k0 + v > j) a[u][v] -= ci[u] * ck[v];
+            }
+        }
+        __syncthreads();
+        if (mode != 0 || attempt == 1) break;
+        if (pmin > 1e-10) { if (tid == 0) *flag3 = 0; break; }      // (uniform: every thread tracked the same pivots)
+        if (tid == 0) *flag3 = 1;
+    }
+    // X = L^-1: column c by the four lanes (c, part 0..3) of one wave; row r of a column needs its rows < r
+    {
+        const int c = tid >> 2, part = tid & 3;
+        if (part == 0) xd[c] = 1.0 / LX[c][c];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        for (int r = c + 1; r < M; ++r) {
+            double acc = (part == 0) ? -LX[r][c] * xd[c] : 0.0;                  // t = c term
+            for (int t = c + 1 + part; t < r; t += 4) acc -= LX[r][t] * LX[c][t];   // X[t][c] lives at LX[c][t]
+            acc += __shfl_xor(acc, 1, 64);
+            acc += __shfl_xor(acc, 2, 64);
+            if (part == 0) LX[c][r] = acc / LX[r][r];
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");      // the four lanes sit in one wave: LDS program order suffices
+        }
+    }
+    __syncthreads();
+    for (int q = tid; q < M * M; q += 256) {
+        const int r = q >> 6, c = q & 63;
+        out[q] = (c < r) ? LX[c][r] * dinv[c] : (c == r ? xd[r] * dinv[r] : 0.0);
+    }
+    double mn = 1e300, mx = 0.0;
+    if (tid < M) { const double d = G[tid * M + tid]; const double nr = d > 0.0 ? sqrt(d) : 0.0; mn = nr; mx = nr; }
+    for (int off = 32; off > 0; off >>= 1) { mn = fmin(mn, __shfl_down(mn, off, 64)); mx = fmax(mx, __shfl_down(mx, off, 64)); }
+    if (tid == 0) { status[0] = pmin; status[1] = mn; status[2] = mx; }
+}
+
+// rows of W (64 x n) -> orthonormal rows spanning the same space: two Cholesky-QR passes, and a third one -- decided on the device --
+// when the first had to shift (nearly dependent rows); no host synchronisation.  Status words of the three passes go to
+// `status` (9 doubles: pivot, min norm, max norm per pass; a skipped third pass reports 1), `flag3` is a device word.
+int orthonormalise_block_async(ctm_ctx* ctx, double* W, int n, double* G, double* Li, double* status, int* flag3) {
+    for (int pass = 0; pass < 3; ++pass) {
+        GemmDesc g; g.M = 64; g.N = 64; g.K = n; g.A = W; g.sam = n; g.sak = 1; g.B = W; g.sbk = 1; g.sbn = n; g.C = G; g.ldc = 64;
+        if (pass == 2) g.skip_all = flag3;
+        CTM_TRY(gemm_f64(ctx, g));
+        CTM_LAUNCH(ctx, chol64_scaled_inv_kernel, dim3(1), dim3(256), 0, (const double*)G, Li, status + 3 * pass, flag3, pass);
+        GemmDesc a; a.M = 64; a.N = n; a.K = 64; a.A = Li; a.sam = 64; a.sak = 1; a.B = W; a.sbk = n; a.sbn = 1; a.C = W; a.ldc = n;
+        if (pass == 2) a.skip_all = flag3;
+        CTM_TRY(gemm_f64(ctx, a));                       // in place: a workgroup reads its whole column strip before it writes
+    }
+    return CTM_OK;
+}
+
 // W (b x n) -= (W B^T) B for the orthonormal row basis B (m x n); twice ("twice is enough")
-int project_out(ctm_ctx* ctx, double* W, int b, int n, const double* B, int m, double* G, int reps = 2) {
+// local > 0 (block recurrences): in exact arithmetic the new block only overlaps the LAST `local` rows of B (three-term recurrence),
+// and that overlap is O(|W|) while the overlaps with older rows are at rounding level.  The first pass then projects on those
+// rows only -- it removes the large component, and unlike a full first pass it does not inject its own rounding errors
+// (eps sqrt(n) |W| per coefficient) along every old direction -- and the second pass, on the now small remainder, runs over all of B.
+int project_out(ctm_ctx* ctx, double* W, int b, int n, const double* B, int m, double* G, int reps = 2, int local = 0) {
     if (m <= 0) return CTM_OK;
     for (int rep = 0; rep < reps; ++rep) {
-        GemmDesc g1; g1.M = b; g1.N = m; g1.K = n; g1.A = W; g1.sam = n; g1.sak = 1; g1.B = B; g1.sbk = 1; g1.sbn = n; g1.C = G; g1.ldc = m;
+        const int off = (rep == 0 && reps > 1 && local > 0 && m > local) ? m - local : 0, mm = m - off;
+        const double* Bo = B + (size_t)off * n;
+        GemmDesc g1; g1.M = b; g1.N = mm; g1.K = n; g1.A = W; g1.sam = n; g1.sak = 1; g1.B = Bo; g1.sbk = 1; g1.sbn = n; g1.C = G; g1.ldc = mm;
         CTM_TRY(gemm_f64(ctx, g1));
-        GemmDesc g2; g2.M = b; g2.N = n; g2.K = m; g2.A = G; g2.sam = m; g2.sak = 1; g2.B = B; g2.sbk = n; g2.sbn = 1; g2.C = W; g2.ldc = n;
+        GemmDesc g2; g2.M = b; g2.N = n; g2.K = mm; g2.A = G; g2.sam = mm; g2.sak = 1; g2.B = Bo; g2.sbk = n; g2.sbn = 1; g2.C = W; g2.ldc = n;
         g2.alpha = -1.0; g2.beta = 1.0;
         CTM_TRY(gemm_f64(ctx, g2));
     }
@@ -1964,7 +2106,7 @@ int project_out(ctm_ctx* ctx, double* W, int b, int n, const double* B, int m, d
 
 // memory of a unit between sweeps (header row of its warm workspace, doubles): [0] calls left that skip the warm probe (svd_iter),
 // [1] block steps of the last accepted Krylov solve, [2] its residual estimate / s_0
-enum { HDR_SKIP = 0, HDR_STEPS = 1, HDR_EST = 2, HDR_WORDS = 3 };
+// (HDR_* are declared ahead of svd_iter)
 
 int svd_lanczos(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* Ut, double* Vt, bool* converged) {
     *converged = false;
@@ -1989,6 +2131,27 @@ int svd_lanczos(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* Ut, dou
     CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)b * (rows_max + b), (void**)&G));
     CTM_TRY(arena_alloc(ctx, sizeof(double) * std::max<size_t>(rows_max, 1024), (void**)&norms));
     CTM_TRY(arena_alloc(ctx, sizeof(double) * std::max<size_t>(rows_max, 1024), (void**)&inv));
+    // Sync-free recurrence (`lz_async`): the block steps are issued without waiting for the device -- orthonormalisation by
+    // orthonormalise_block_async(), whose status words (pivots, row norms: 6 doubles per call) are collected in `ostat` and examined
+    // at the next scheduled host synchronisation (the Ritz extraction).  Anything unusual there (a pivot that signals near
+    // dependence, a breakdown of the recurrence) sends the whole solve through the synchronous path, which handles those cases.
+    const bool async = ctx->lz_async && !ctx->lz_force_sync;
+    double *ostat = nullptr, *Li = nullptr;
+    int* flag3 = nullptr;
+    const int nstat = 2 * jmax + 1, SW = 9;                    // status words per orthonormalisation
+    if (async) {
+        CTM_TRY(arena_alloc(ctx, sizeof(double) * SW * nstat, (void**)&ostat));
+        CTM_TRY(arena_alloc(ctx, sizeof(double) * 64 * 64, (void**)&Li));
+        CTM_TRY(arena_alloc(ctx, sizeof(int) * 64, (void**)&flag3));
+    }
+    auto resync = [&]() -> int {          // redo this solve on the synchronous path
+        if (ctx->jacobi_verbose) fprintf(stderr, "[lz] n=%d asynchronous recurrence flagged: repeating on the synchronous path\n", n);
+        ctx->lz_async_fallbacks += 1;
+        ctx->lz_force_sync = true;
+        const int st = svd_lanczos(ctx, op, k, S, Ut, Vt, converged);
+        ctx->lz_force_sync = false;
+        return st;
+    };
     const double tol = resid_tol(ctx, n);
     // When to look: a Ritz extraction (dense SVD of the m x m projected matrix) costs as much as 6-8 block steps, so it is
     // scheduled, not repeated.  The operator of a unit changes slowly from sweep to sweep: the step count that was
@@ -2011,7 +2174,8 @@ int svd_lanczos(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* Ut, dou
     double est_prev = 0.0; int steps_prev = 0;
     double mn, mx, s0 = 0.0;
     CTM_LAUNCH(ctx, hash_fill_kernel, dim3(1024), dim3(256), 0, Vall, b, n, (long long)n, 0x51f15eedULL);
-    CTM_TRY(orthonormalise_block(ctx, Vall, b, n, norms, inv, &mn, &mx));
+    if (async) CTM_TRY(orthonormalise_block_async(ctx, Vall, n, G, Li, ostat + SW * (nstat - 1), flag3));
+    else CTM_TRY(orthonormalise_block(ctx, Vall, b, n, norms, inv, &mn, &mx));
     int applications = 0;
     for (int j = 0; j < jmax; ++j) {
         double* Uj = Uall + (size_t)j * b * n;
@@ -2022,18 +2186,44 @@ int svd_lanczos(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* Ut, dou
         // U_j
         CTM_TRY(matop_apply(ctx, op, true, Vj, n, b, Wj, n, want_mid ? VRall + (size_t)j * b * n : nullptr)); applications += b;
         CTM_HIP_CHECK(ctx, hipMemcpyAsync(Uj, Wj, sizeof(double) * (size_t)b * n, hipMemcpyDeviceToDevice, ctx->stream));
-        CTM_TRY(project_out(ctx, Uj, b, n, Uall, j * b, G));
-        CTM_TRY(orthonormalise_block(ctx, Uj, b, n, norms, inv, &mn, &mx));
-        s0 = std::max(s0, mx);
-        if (mn <= 1e-13 * s0) { if (ctx->jacobi_verbose) fprintf(stderr, "[lz] n=%d breakdown at step %d (U)\n", n, j); return CTM_OK; }
+        CTM_TRY(project_out(ctx, Uj, b, n, Uall, j * b, G, 2, ctx->lz_local_project ? b : 0));
+        if (async) CTM_TRY(orthonormalise_block_async(ctx, Uj, n, G, Li, ostat + SW * (2 * j), flag3));
+        else {
+            CTM_TRY(orthonormalise_block(ctx, Uj, b, n, norms, inv, &mn, &mx));
+            s0 = std::max(s0, mx);
+            if (mn <= 1e-13 * s0) { if (ctx->jacobi_verbose) fprintf(stderr, "[lz] n=%d breakdown at step %d (U)\n", n, j); return CTM_OK; }
+        }
         // raw product and V_{j+1}
         CTM_TRY(matop_apply(ctx, op, false, Uj, n, b, Zj, n, want_mid ? URall + (size_t)j * b * n : nullptr)); applications += b;
         CTM_HIP_CHECK(ctx, hipMemcpyAsync(Vn, Zj, sizeof(double) * (size_t)b * n, hipMemcpyDeviceToDevice, ctx->stream));
-        CTM_TRY(project_out(ctx, Vn, b, n, Vall, (j + 1) * b, G));
-        CTM_TRY(orthonormalise_block(ctx, Vn, b, n, norms, inv, &mn, &mx));
-        if (mn <= 1e-13 * s0) { if (ctx->jacobi_verbose) fprintf(stderr, "[lz] n=%d breakdown at step %d (V)\n", n, j); return CTM_OK; }
+        CTM_TRY(project_out(ctx, Vn, b, n, Vall, (j + 1) * b, G, 2, ctx->lz_local_project ? b : 0));
+        if (async) CTM_TRY(orthonormalise_block_async(ctx, Vn, n, G, Li, ostat + SW * (2 * j + 1), flag3));
+        else {
+            CTM_TRY(orthonormalise_block(ctx, Vn, b, n, norms, inv, &mn, &mx));
+            if (mn <= 1e-13 * s0) { if (ctx->jacobi_verbose) fprintf(stderr, "[lz] n=%d breakdown at step %d (V)\n", n, j); return CTM_OK; }
+        }
         const int steps = j + 1, m = steps * b;
         if (steps < jnext && steps < jmax) continue;
+        if (async) {
+            // the status words of every orthonormalisation so far (the copy waits for the steps issued above)
+            std::vector<double> hst((size_t)SW * nstat, 0.0);
+            CTM_HIP_CHECK(ctx, hipMemcpyAsync(hst.data(), ostat, sizeof(double) * SW * nstat, hipMemcpyDeviceToHost, ctx->stream));
+            CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+            bool bad = false;
+            double s0a = 0.0;
+            auto check = [&](int slot, bool left) {
+                const double* q = hst.data() + SW * slot;
+                const bool third = q[7] >= 0.0;                                // the device ran the third pass (first one was shifted)
+                const double last = third ? q[6] : q[3];                       // pivot of the last pass: rows orthonormal to rounding iff ~1
+                if (!(q[0] > 0.0) || !(last > 0.5) || !(q[1] > 0.0)) bad = true;   // (NaN fails too), zero row
+                if (third) ctx->lz_third_passes += 1;
+                if (left) s0a = std::max(s0a, q[2]);
+                if (!(q[1] > 1e-13 * std::max(s0a, 1e-300)) && slot != nstat - 1) bad = true;    // breakdown of the recurrence
+            };
+            check(nstat - 1, false);
+            for (int jj = 0; jj <= j && !bad; ++jj) { check(2 * jj, true); check(2 * jj + 1, false); }
+            if (bad) return resync();
+        }
         // ---- small problem T = (U_all M) V_all^T  (m x m),  coupling E = (U_all M) V_{j+1}^T  (m x b)
         ArenaScope rs(ctx);
         double *T, *E, *Ss, *Xt, *Yt, *XE, *rn;
@@ -2051,7 +2241,10 @@ int svd_lanczos(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* Ut, dou
         CTM_TRY(gemm_f64(ctx, ge));
         const bool save = ctx->si_enable; ctx->si_enable = false;
         ctx->force_abs = ctx->lz_abs_accuracy != 0;
+        const int save_b = ctx->jacobi_block;
+        if (ctx->lz_jacobi_block > 0) ctx->jacobi_block = ctx->lz_jacobi_block;      // panel height of the dense SVD of the Ritz matrix
         const int st = svd_full(ctx, T, m, kq, Ss, Xt, Yt);                      // rows of Xt / Yt: x_i^T, y_i^T
+        ctx->jacobi_block = save_b;
         ctx->force_abs = false;
         ctx->si_enable = save;
         CTM_TRY(st);

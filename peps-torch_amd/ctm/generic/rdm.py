@@ -114,6 +114,9 @@ def _rdm2x2_raw(eng, t, env, group=None):
         budget = 0.85 * (free + arena)                          # the engine's own arena is reused
         while chunk > 1 and 1.15 * n * n * (2 * p * p + 1 + chunk) * el > budget:
             chunk //= 2
+    if len(members) > 1:
+        # the members of a group see different amounts of free HBM: the partition of the p^4 slices must not depend on the rank
+        chunk = parallel.allreduce_min_int_group(chunk, members, a.device)
     nparts = -(-P4 // chunk)
     if nparts == 1 and len(members) == 1:
         return eng.rdm2x2(t)
@@ -121,10 +124,11 @@ def _rdm2x2_raw(eng, t, env, group=None):
         while nparts < len(members) and chunk > 1:
             chunk //= 2; nparts = -(-P4 // chunk)
     R = torch.zeros(P4, P4, dtype=a.dtype, device=a.device)
-    for i in range(nparts):
+    ranges = [(i * chunk, min(P4, (i + 1) * chunk)) for i in range(nparts)]
+    assert ranges[0][0] == 0 and ranges[-1][1] == P4 and all(a_[1] == b_[0] for a_, b_ in zip(ranges, ranges[1:])), ranges
+    for i, (lo0, lo1) in enumerate(ranges):
         if i % len(members) != me:
             continue
-        lo0, lo1 = i * chunk, min(P4, (i + 1) * chunk)
         R[:, lo0:lo1] = eng.rdm2x2_part(t, lo0, lo1)
     if len(members) > 1:
         R = parallel.allreduce_sum_group(R, members)

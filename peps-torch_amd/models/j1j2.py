@@ -100,6 +100,8 @@ class J1J2():
             for coord in coords:
                 r = rdm.rdm2x2(coord, state, env).cpu()
                 e = e + _cast_to_real(torch.einsum('ijklabcd,ijklabcd', r, self.get_hp(coord).to(r.dtype)))
+                if abs(self.lmbd) > 0:    # chiral plaquette term, un-rotated as in the reference (models/j1j2.py:240-241)
+                    e = e + _cast_to_real(self.lmbd * torch.einsum('ijklabcd,ijklabcd', r, self.chiral_term.to(r.dtype)))
                 if abs(self.j3) > 0:      # evaluated at (0,0) for every site of the cell (models/j1j2.py:243-244): transfer-matrix correlators as a graph
                     e = e + _cast_to_real(self.j3 * eval_nnnn_per_site((0, 0), state, env, self.obs_ops)).cpu()
             return e / len(coords)
@@ -122,6 +124,8 @@ class J1J2():
         for coord, r in zip(mine, rdms):
             r = r.cpu()
             e += float(_cast_to_real(torch.einsum('ijklabcd,ijklabcd', r, self.get_hp(coord).to(r.dtype))))
+            if abs(self.lmbd) > 0:    # models/j1j2.py:240-241
+                e += float(_cast_to_real(self.lmbd * torch.einsum('ijklabcd,ijklabcd', r, self.chiral_term.to(r.dtype))))
             if abs(self.j3) > 0:      # the reference evaluates this term at (0,0) for every site of the cell (models/j1j2.py:243-244)
                 e += float(_cast_to_real(self.j3 * eval_nnnn_per_site((0, 0), state, env, self.obs_ops)))
         e = parallel.allreduce_sum_scalar(e, state.device)
@@ -147,6 +151,8 @@ class J1J2():
             if rank == members[0]:
                 r = rdm._sym_pos_def_rdm(raw, who="rdm2x2").cpu()
                 e += float(_cast_to_real(torch.einsum('ijklabcd,ijklabcd', r, self.get_hp(coord).to(r.dtype))))
+                if abs(self.lmbd) > 0:
+                    e += float(_cast_to_real(self.lmbd * torch.einsum('ijklabcd,ijklabcd', r, self.chiral_term.to(r.dtype))))
                 if abs(self.j3) > 0:
                     e += float(_cast_to_real(self.j3 * eval_nnnn_per_site((0, 0), state, env, self.obs_ops)))
         e = parallel.allreduce_sum_scalar(e, state.device)

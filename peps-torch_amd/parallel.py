@@ -85,14 +85,55 @@ def owners_shifted(coords, vertex_to_site, shift):
     return [owner_of(idx[vertex_to_site((c[0] + shift[0], c[1] + shift[1]))], n) for c in coords]
 
 
+# ---- time spent in the exchanges (bench.py: phase_s["comm"]) ----------------------------------------------------------------
+# Event pairs on the CURRENT stream around every collective of exchange(): torch makes the current stream wait for the collective,
+# so the second event fires when the data has arrived.  Read (and the events released) by comm_time_s(); no host synchronisation here.
+_comm_events = []
+_comm_host_s = 0.0
+comm_timing = False
+
+
+def _comm_begin(like):
+    if not comm_timing:
+        return None
+    if like.is_cuda:
+        e = torch.cuda.Event(enable_timing=True); e.record(torch.cuda.current_stream(like.device)); return e
+    import time
+    return time.perf_counter()
+
+
+def _comm_end(like, e0):
+    global _comm_host_s
+    if e0 is None:
+        return
+    if like.is_cuda:
+        e1 = torch.cuda.Event(enable_timing=True); e1.record(torch.cuda.current_stream(like.device)); _comm_events.append((e0, e1))
+    else:
+        import time
+        _comm_host_s += time.perf_counter() - e0
+
+
+def comm_time_s(reset=True):
+    """Seconds this rank spent in exchange() collectives since the last reset (device time between the bracketing events)."""
+    global _comm_host_s
+    if _comm_events:
+        _comm_events[-1][1].synchronize()
+    tot = _comm_host_s + 1e-3 * sum(a.elapsed_time(b) for a, b in _comm_events)
+    if reset:
+        _comm_events.clear(); _comm_host_s = 0.0
+    return tot
+
+
 def exchange(local, keys, shapes, like, owners=None):
     """All ranks end up with `{key: tensor}` for every key of `keys` (ordered list, identical on all
     ranks); `local` holds the entries this rank computed; `shapes[key]` is known to every rank (it
     follows from chi and the bond dimensions), `like` supplies dtype/device, `owners[i]` (default i mod ranks) is the rank that
     computed keys[i].  When all tensors of the
     exchange have one shape and every rank owns the same number of them (uniform-D cell, #sites a
-    multiple of #ranks) they travel as ONE all_gather of a stacked buffer (few, large messages: xGMI
-    is point-to-point, per-link bound); otherwise per-key broadcasts from the owner."""
+    multiple of #ranks) they travel as ONE all-gather into a preallocated (ranks x per-rank x shape) buffer (few, large messages:
+    xGMI is point-to-point, per-link bound) whose slices ARE the returned tensors -- no stacked send copy, no per-rank receive
+    list: with one tensor per rank the tensor itself is the send buffer, with several they are written once into this rank's
+    slice of the receive buffer and gathered in place.  Otherwise per-key broadcasts from the owner."""
     if not is_distributed():
         return dict(local)
     rank, n = world()
@@ -102,22 +143,41 @@ def exchange(local, keys, shapes, like, owners=None):
     uniform = len({len(o) for o in owned}) == 1 and len({tuple(shapes[k]) for k in keys}) == 1 and len(owned[0]) > 0
     cx = like.dtype.is_complex       # RCCL has no complex type: complex128 travels as its (re,im) float64 view
     if uniform:
-        send = torch.stack([local[k].contiguous() for k in owned[rank]]).contiguous()
-        if cx:
-            send = torch.view_as_real(send)
-        recv = [torch.empty_like(send) for _ in range(n)]
-        dist.all_gather(recv, send)
+        per, shp = len(owned[0]), tuple(shapes[keys[0]])
+        recv = torch.empty((n, per) + shp, dtype=like.dtype, device=like.device)
+        rbuf = torch.view_as_real(recv) if cx else recv
+        if per == 1:
+            t = local[owned[rank][0]].contiguous()
+            send = (torch.view_as_real(t) if cx else t).reshape(rbuf.shape[1:])
+        else:
+            for j, k in enumerate(owned[rank]):
+                recv[rank, j].copy_(local[k])
+            send = rbuf[rank]                                   # in-place all-gather: my slice of the receive buffer
+        e0 = _comm_begin(like)
+        # output = concatenation of the ranks' inputs along dim 0 (the form both RCCL and gloo accept)
+        dist.all_gather_into_tensor(rbuf.view((n * per,) + tuple(rbuf.shape[2:])), send)
+        _comm_end(like, e0)
         for r in range(n):
-            buf = torch.view_as_complex(recv[r]) if cx else recv[r]
             for j, k in enumerate(owned[r]):
-                out[k] = buf[j]
+                out[k] = recv[r, j]
         return out
+    e0 = _comm_begin(like)
     for i, k in enumerate(keys):
         src = own[i]
         t = local[k].contiguous() if src == rank else torch.empty(tuple(shapes[k]), dtype=like.dtype, device=like.device)
         dist.broadcast(torch.view_as_real(t) if cx else t, src)
         out[k] = t
+    _comm_end(like, e0)
     return out
+
+
+def allreduce_min_int_group(x, members, device):
+    """Minimum of an integer over the ranks in `members` (a process group created by prepare_groups)."""
+    if not is_distributed() or len(members) < 2:
+        return int(x)
+    t = torch.tensor([int(x)], dtype=torch.int64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=_process_group(members))
+    return int(t.item())
 
 
 def allreduce_sum_scalar(x, device):

@@ -106,7 +106,9 @@ def test_generic_unit_at_full_size(eng, D, chi, signed):
         assert eng.stat("lz_hits") > lz0, "signed state did not reach the block Krylov solver"
         assert int(min((s_ > 1e-8 * s_[0]).sum() for s_ in env.get_spectra().values())) >= chi // 2    # far from the rank-<= 30 of a positive state
     lz1 = eng.stat("lz_hits")
-    n = _check_unit(eng, st, env, chi, torch_svdvals=(D == 6))
+    # host LAPACK singular values of the explicit M (the reference's own route): always at n = 4608, and once at the full n = 16384 of
+    # BASELINE configs[3] on the full-rank state (minutes of host time: the one slow comparison of this file)
+    n = _check_unit(eng, st, env, chi, torch_svdvals=(D == 6 or signed))
     if signed:
         assert eng.stat("lz_hits") >= lz1 + 2
     assert n == chi * D * D
@@ -220,6 +222,35 @@ def test_rdm2x2_and_energy_at_D6_chi128(eng):
     eng.trim()
 
 
+def test_rdm2x2_and_energy_at_D8_chi256(eng):
+    """The energy half of the metric at BASELINE configs[3] size (generic 2x2, D = 8, chi = 256, n = 16384; reference models/j1j2.py:236-240,
+    ctm/generic/rdm.py:1362-1592): rdm2x2 of all four sites + energy_per_site after two sweeps of the signed (full-rank) state.
+    Invariants: Hermitian, unit trace, positive up to rounding, E/site unchanged under a -> 2a (new environment, new sweeps)."""
+    from ctm.generic.env import ENV, init_env
+    from ipeps.ipeps import IPEPS
+    D, chi = 8, 256
+    st = _state(D, 23, signed=True)
+    env = ENV(chi, st); init_env(st, env)
+    _sweep(st, env, 2)
+    e, rdms = _energy_and_rdms(st, env)
+    for c, r in rdms.items():
+        r = r.reshape(16, 16)
+        assert abs(float(torch.trace(r)) - 1.0) < 1e-13, c
+        assert float((r - r.T).abs().max()) < 1e-13, c
+        assert float(torch.linalg.eigvalsh(r.cpu()).min()) > -1e-11, c
+    assert -2.0 < e < 2.0
+    env.__dict__.pop("_corner_cache", None); env.__dict__.pop("_warm", None); eng.trim(); torch.cuda.empty_cache()
+    st2 = IPEPS({k: 2.0 * v for k, v in st.sites.items()})
+    env2 = ENV(chi, st2); init_env(st2, env2)
+    _sweep(st2, env2, 2)
+    e2, rdms2 = _energy_and_rdms(st2, env2)
+    assert abs(e - e2) < 1e-10 * max(abs(e), 1e-3)
+    for c in rdms:
+        assert float((rdms2[c] - rdms[c]).abs().max()) < 1e-10, c
+    env2.__dict__.pop("_corner_cache", None); env2.__dict__.pop("_warm", None)
+    eng.trim()
+
+
 def test_rdm2x2_and_energy_at_D4_chi64_against_the_oracle(eng):
     """n = 1024: the native rdm2x2 / energy of every site against the numpy oracle evaluated on the SAME (downloaded) environment
     after two native sweeps of a signed 4-site state."""
@@ -283,6 +314,30 @@ def test_whole_move_of_the_complex_config_at_full_size(eng):
     for k in a:
         assert float((a[k] - c[k]).abs().max()) < 1e-12, k
     eng.trim()
+
+
+def test_full_chunked_plaquette_of_the_complex_config_at_full_size(eng):
+    """BASELINE configs[4] (n = 24576, complex128): the WHOLE plaquette RDM of one site through rdm.rdm2x2 -- all 16 lower-half slices,
+    looped over in chunks on one GPU because the open halves (241 GB) do not fit at once (rdm._rdm2x2_raw; reference
+    ctm/generic/rdm.py:1362-1592).  Hermitian, unit trace, positive up to rounding; and its (cl = 0) block reproduces the single part
+    the next test evaluates directly."""
+    from ctm.generic.env import ENV, init_env
+    from ctm.generic import rdm
+    torch.cuda.empty_cache()
+    free, _ = torch.cuda.mem_get_info()
+    if free < 200e9:
+        pytest.skip("needs ~130 GB of free HBM")
+    chi, D = 384, 8
+    st = _state(D, 4, cplx=True)
+    env = ENV(chi, st); init_env(st, env)
+    r = rdm.rdm2x2((0, 0), st, env)
+    assert r.shape == (2,) * 8 and r.dtype == torch.complex128
+    m = r.reshape(16, 16)
+    tr = torch.trace(m)
+    assert abs(float(tr.real) - 1.0) < 1e-12 and abs(float(tr.imag)) < 1e-12
+    assert float((m - m.conj().T).abs().max()) < 1e-12
+    assert float(torch.linalg.eigvalsh(m.cpu()).min()) > -1e-11
+    eng.trim(); torch.cuda.empty_cache()
 
 
 def test_one_part_of_rdm2x2_of_the_complex_config_at_full_size(eng):

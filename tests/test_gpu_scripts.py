@@ -34,6 +34,35 @@ def test_ctmrg_j1j2_script_2site_golden(tmp_path):
     assert abs(vals[0] - float(g["energy"])) < 1e-9
 
 
+INPUTS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "test-input")
+
+
+def test_ctmrg_j1j2_c4v_script_config0_literal(tmp_path):
+    """BASELINE configs[0], literally: `ctmrg_j1j2_c4v.py --bond_dim 2 --chi 16 --instate test-input/RVB_1x1.in` (the reference's own
+    data file; j2 = 0, 50 sweeps) prints `FINAL -0.5901859430133278, ..., -0.29471077912392146` (reference
+    examples/j1j2/ctmrg_j1j2_c4v.py:38-193)."""
+    vals = _run("ctmrg_j1j2_c4v.py", ["--bond_dim", "2", "--chi", "16", "--instate", os.path.join(INPUTS, "RVB_1x1.in"),
+                                      "--GLOBALARGS_device", "cuda:0", "--out_prefix", str(tmp_path / "o")])
+    assert len(vals) == 6
+    assert abs(vals[0] - (-0.5901859430133278)) < 1e-10
+    assert abs(vals[5] - (-0.29471077912392146)) < 1e-10
+    assert all(abs(v) < 1e-12 for v in vals[1:5])                      # m, sz, sp, sm of the RVB state
+
+
+def test_ctmrg_j1j2_script_reads_the_reference_state_files(tmp_path):
+    """The committed copies of the reference's own JSON state files fed to ctmrg_j1j2.py directly (no re-writing through this build's
+    write_ipeps): the 2SITE and BIPARTITE golden energies of examples/j1j2/ctmrg_j1j2.py:248-266."""
+    vals = _run("ctmrg_j1j2.py", ["--instate", os.path.join(INPUTS, "gesdd-D2-chi50-j20.55-run0-iRND2x1_state.json"), "--tiling", "2SITE",
+                                  "--chi", "32", "--bond_dim", "2", "--j2", "0.55", "--CTMARGS_ctm_max_iter", "50",
+                                  "--GLOBALARGS_device", "cuda:0", "--out_prefix", str(tmp_path / "o2")])
+    assert abs(vals[0] - (-0.4434603770143078)) < 1e-6
+    assert abs(vals[0] - float(golden("twosite_D2_chi32")["energy"])) < 1e-9
+    vals = _run("ctmrg_j1j2.py", ["--instate", os.path.join(INPUTS, "BIPARTITE_j2_0_j3_1250_h_39000_D_3_chi_32_seed_100_state.json"),
+                                  "--tiling", "BIPARTITE", "--chi", "32", "--bond_dim", "3", "--j3", "0.125", "--h_uni", "3.9", "0", "0",
+                                  "--CTMARGS_ctm_max_iter", "100", "--GLOBALARGS_device", "cuda:0", "--out_prefix", str(tmp_path / "o3")])
+    assert abs(vals[0] - (-1.3896897615463615)) < 1e-6
+
+
 def test_ctmrg_j1j2_c4v_script_rvb(tmp_path):
     """examples/j1j2/ctmrg_j1j2_c4v.py:218-260 of the reference (TestRVB): E = -0.47684229 +- 1e-8."""
     from ipeps.ipeps_c4v import IPEPS_C4V

@@ -237,6 +237,50 @@ def test_energy_1site_BP_includes_j3_and_chiral_terms(cpu_cfg):
         j1j2.J1J2(j1=1.0, lmbd=0.5)
 
 
+def test_energy_per_site_includes_the_chiral_term(cpu_cfg):
+    """energy_per_site adds lmbd * tr(rho_2x2 chiral_term) per plaquette with the UN-rotated term (reference models/j1j2.py:236-247);
+    the expected number was produced with the reference's own model tensors (oracle/gen_golden.py chiral_case)."""
+    from ipeps.ipeps import IPEPS
+    from ctm.generic.env import ENV
+    from models import j1j2
+    g, gc = golden("generic_D2_chi8_c128"), golden("chiral")
+    old = cpu_cfg.global_args.torch_dtype
+    cpu_cfg.global_args.torch_dtype = torch.complex128
+    try:
+        st = IPEPS({k: torch.from_numpy(v.copy()) for k, v in sites_from(g).items()})
+        env = ENV(8, st)
+        C, T = env_from(g, "warm_")
+        env.C = {k: torch.from_numpy(v.copy()) for k, v in C.items()}; env.T = {k: torch.from_numpy(v.copy()) for k, v in T.items()}
+        model = j1j2.J1J2(j1=1.0, j2=0.5, lmbd=float(gc["lmbd"]))
+        assert np.abs(model.chiral_term.numpy() - gc["chiral_term"]).max() < 1e-15
+        e = float(model.energy_per_site(st, env))
+        e0 = float(j1j2.J1J2(j1=1.0, j2=0.5).energy_per_site(st, env))
+    finally:
+        cpu_cfg.global_args.torch_dtype = old
+    assert abs(e - float(gc["energy_j2_05_lmbd_03"])) < 1e-11
+    assert abs(e0 - float(g["energy_j2_0.5"])) < 1e-11 and abs(e - e0) > 1e-6       # the term is there and is not negligible
+
+
+def test_config0_script_prints_the_published_final_line(cpu_cfg, tmp_path, capsys, monkeypatch):
+    """BASELINE configs[0] through the host layer (script main() in process, engine double): `--bond_dim 2 --chi 16 --instate
+    test-input/RVB_1x1.in` -> `FINAL -0.5901859430133278, ..., -0.29471077912392146` (the reference's own output)."""
+    import importlib.util, conftest
+    monkeypatch.chdir(tmp_path)
+    f = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "test-input", "RVB_1x1.in")
+    spec = importlib.util.spec_from_file_location("ctmrg_j1j2_c4v_script", os.path.join(conftest.PKG, "examples", "j1j2", "ctmrg_j1j2_c4v.py"))
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    old = (cpu_cfg.ctm_args.ctm_max_iter,)
+    try:
+        mod.main(["--bond_dim", "2", "--chi", "16", "--instate", f, "--GLOBALARGS_device", "cpu", "--out_prefix", str(tmp_path / "o")])
+    finally:
+        cpu_cfg.ctm_args.ctm_max_iter, = old
+        cpu_cfg.global_args.device = 'cpu'
+    final = [l for l in capsys.readouterr().out.splitlines() if l.startswith("FINAL")]
+    assert len(final) == 1
+    vals = [float(v) for v in final[0][6:].split(",")]
+    assert abs(vals[0] - (-0.5901859430133278)) < 1e-11 and abs(vals[5] - (-0.29471077912392146)) < 1e-11
+
+
 def test_corrf_with_user_supplied_boundary_edges(cpu_cfg):
     """corrf_1sO1sO(..., rl_0=(right, left)) (reference corrf.py:980-1067): with the corner-T-corner edges passed explicitly the
     result equals the default; with rescaled edges it is unchanged (the ratio E12/E00 is scale invariant)."""
