@@ -18,6 +18,7 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(REPO, "peps-torch_amd"))
 sys.path.insert(0, REPO)
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")     # one hardware queue per stream of the concurrent units (see config.py)
 import numpy as np
 import torch
 

@@ -6,6 +6,7 @@ fallback: if the shared library is missing or a call fails, this module raises.
 """
 import ctypes as C
 import os
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # see config.py: one hardware queue per worker stream
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))

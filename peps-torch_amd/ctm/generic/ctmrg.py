@@ -162,8 +162,8 @@ def ctm_MOVE(direction, state, env, ctm_args=cfg.ctm_args, global_args=cfg.globa
         import units
         pool = units.pool_for(eng, len(mine), max(_proj_rows(direction, c, state, chi) for c in mine), like.dtype.is_complex)
 
-    def _each(fn, items):
-        return pool.map(fn, items) if pool is not None else [fn(it) for it in items]
+    def _each(fn, items, stagger=0.0):
+        return pool.map(fn, items, stagger=stagger) if pool is not None else [fn(it) for it in items]
 
     # phase A: projectors of my sites from the old env
     ownersA, mineA = None, mine
@@ -171,8 +171,9 @@ def ctm_MOVE(direction, state, env, ctm_args=cfg.ctm_args, global_args=cfg.globa
         ownersA = parallel.owners_shifted(coords, state.vertexToSite, _OWNER_SHIFT[direction])
         mineA = [c for c, o in zip(coords, ownersA) if o == parallel.world()[0]]
     P, Pt = {}, {}
+    stagger = float(getattr(ctm_args, "unit_stagger_ms", 0.0)) * 1e-3 if max(_proj_rows(direction, c, state, chi) for c in coords) >= 8192 else 0.0
     for coord, (p_, pt_) in zip(mineA, _each(lambda c: get_projectors(direction, c, state, env, ctm_args, global_args,
-                                                                              diagnostics=diagnostics), mineA)):
+                                                                              diagnostics=diagnostics), mineA, stagger)):
         P[coord], Pt[coord] = p_, pt_
     if parallel.is_distributed():
         shp = {}

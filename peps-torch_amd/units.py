@@ -9,6 +9,7 @@ an event recorded on the caller's stream before it starts, and the caller's stre
 event, so each phase is bracketed by full cross-stream barriers (which also makes cross-stream reuse of torch's
 cached blocks safe: tensors are only released at phase boundaries)."""
 import threading
+import time
 import queue
 from concurrent.futures import ThreadPoolExecutor
 import os
@@ -28,9 +29,11 @@ class UnitPool:
         for slot in range(nworkers):
             self.free.put(slot)
 
-    def _run(self, fn, item, ev0):
+    def _run(self, fn, item, ev0, delay=0.0):
         slot = self.free.get()                                       # a worker context that is idle right now
         try:
+            if delay > 0.0:
+                time.sleep(delay)
             s = self.streams[slot]
             with torch.cuda.device(self.device), torch.cuda.stream(s):
                 s.wait_event(ev0)
@@ -48,14 +51,16 @@ class UnitPool:
         finally:
             self.free.put(slot)
 
-    def map(self, fn, items):
+    def map(self, fn, items, stagger=0.0):
         """[fn(item) for item in items], at most `nworkers` at a time, each on its own stream/context; a worker takes the next
         item as soon as it has issued its previous one (no barrier between groups of `nworkers` items)."""
         items = list(items)
         main_stream = torch.cuda.current_stream(self.device)
         ev0 = torch.cuda.Event()
         ev0.record(main_stream)
-        futs = [self.pool.submit(self._run, fn, it, ev0) for it in items]
+        # `stagger` seconds between the starts of the first `nworkers` items: units whose latency-bound phases (orthogonalisations,
+        # Ritz extraction) would otherwise coincide run out of phase, so that one unit's small kernels overlap another's corner passes
+        futs = [self.pool.submit(self._run, fn, it, ev0, stagger * i if i < self.n else 0.0) for i, it in enumerate(items)]
         outs = []
         for f in futs:
             out, ev = f.result()
@@ -78,9 +83,13 @@ def pool_for(engine, nunits, n, is_complex, est_bytes=None):
     est = est_bytes if est_bytes is not None else 14.0 * n * n * 8 * (2 if is_complex else 1)   # corners, products, work
     nw = int(min(nunits, max(1, (0.5 * total) // max(est, 1.0))))
     if n >= 8192:
-        # kernels of this size fill the chip on their own: two units in flight hide the launch gaps and host synchronisations
-        # just as well as four (measured 1.228 vs 1.231 s/sweep at n = 16384) with half the workspace and less co-scheduling
-        nw = min(nw, int(os.environ.get("CTM_LARGE_N_UNITS", 2)))
+        # kernels of this size fill the chip on their own, but the latency-bound stages of a unit (block orthogonalisations, the
+        # dense SVD of the Ritz matrix: ~40 % of a full-rank unit's time, a few workgroups wide) only overlap with OTHER units'
+        # latency-bound stages -- the units of a move run in lockstep.  All four units of a move in flight: those stages are
+        # paid once per move instead of twice (full-rank D = 8 chi = 256: 3.71 -> 3.26 s/sweep).  Needs one hardware queue per
+        # stream (GPU_MAX_HW_QUEUES, see backend.py): with the default of four queues the four worker streams share two of them
+        # and run pairwise serialised (measured: no gain at all).
+        nw = min(nw, int(os.environ.get("CTM_LARGE_N_UNITS", 4)))
     nw = min(nw, int(os.environ.get("CTM_MAX_CONCURRENT_UNITS", nw)))       # experiment knob
     if nw < 2:
         return None

@@ -1,4 +1,5 @@
 import os, sys
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")     # as config.py does: before the HIP runtime initialises
 import pytest
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
