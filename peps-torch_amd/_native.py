@@ -235,6 +235,15 @@ class Engine:
             tot += v.value
         return tot
 
+    def own_stat(self, key):
+        """stat() of this engine's contexts only (no workers)."""
+        tot = 0.0
+        for h in self._handles.values():
+            v = C.c_double()
+            if self.lib.ctm_get_stat(h, key.encode(), C.byref(v)) == CTM_OK:
+                tot += v.value
+        return tot
+
     def timers(self, reset=False):
         names = ["corners", "halves", "svd", "proj", "absorb", "norm", "rdm", "eig"]
         tot = dict.fromkeys(names, 0.0)
@@ -639,4 +648,8 @@ def engine(device=None):
         idx = d.index if d.index is not None else torch.cuda.current_device()
     if idx not in _engines:
         _engines[idx] = Engine(torch.device("cuda", idx))
+        # development hook: engine options from the environment, "key=value,key=value" (same keys as Engine.set_option)
+        for kv in filter(None, os.environ.get("CTM_ENGINE_OPTS", "").split(",")):
+            k, v = kv.split("=")
+            _engines[idx].set_option(k.strip(), float(v))
     return _engines[idx]

@@ -126,6 +126,13 @@ struct ctm_ctx {
     int strip_target_wgs = 512;   // K slices x column tiles of the strip kernel: fewer slices = fewer partials (measured 512 <= 1024, 256)
     int rows_kernel_min_m = 1, rows_kernel_min_m_kc = 1;   // LDS-tiled row-block kernel from this many rows (n-contiguous / k-contiguous big operand)
     int rows_target_wgs = 768;    // its workgroup count (column tiles x K slices): three per CU
+    // Chip-filling launches (>= heavy_min_flops) of ALL contexts of a device run one at a time (device-side lock): the concurrent
+    // units of a move overlap their latency-bound stages with each other and with ONE corner pass at a time, instead of four
+    // corner passes splitting the chip (see HeavyScope, gemm_f64.hip)
+    bool heavy_serial = false; double heavy_min_flops = 1e10;      // (off: measured 2-5 % slower -- the tail of one chip-filling kernel is no longer filled by the next unit's)
+    double timing_min_flops = 1e8;
+    unsigned heavy_id = 0; bool in_heavy = false;          // owner id of this context in the device-side lock
+    long heavy_launches = 0;
     bool rows_fused_reduce = true;      // its K-slice partials are summed inside the launch by the last workgroup of a column tile
     unsigned* tile_cnt = nullptr;       // per-column-tile arrival counters of that combine (zero between launches)
     bool gemm_split_rem = true;   // split a 128 q + r (r <= 64) dimension into a vectorised part and a strip
@@ -179,6 +186,14 @@ struct PhaseTimer {
             c->timers[id] += std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - t0).count();
         } else if (e0 >= 0) timing_end(c, e0, CTM_KIND_PHASE0 + id, 0.0);
     }
+};
+
+// RAII around a chip-filling launch: an acquire kernel of the device-wide lock ahead of it and a release kernel behind it, both on
+// the context's own stream.
+struct HeavyScope {
+    ctm_ctx* c; bool on = false;
+    HeavyScope(ctm_ctx* ctx, double flops);
+    ~HeavyScope();
 };
 
 // ---- GEMM (gemm_f64.hip) -----------------------------------------------------------------

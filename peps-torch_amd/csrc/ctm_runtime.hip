@@ -131,6 +131,9 @@ int ctm_set_option(ctm_ctx* ctx, const char* key, double value) {
     else if (k == "rows_kernel_min_m_kc") ctx->rows_kernel_min_m_kc = (int)value;
     else if (k == "rows_target_wgs") ctx->rows_target_wgs = (int)value;
     else if (k == "rows_fused_reduce") ctx->rows_fused_reduce = value != 0.0;
+    else if (k == "heavy_serial") ctx->heavy_serial = value != 0.0;
+    else if (k == "heavy_min_flops") ctx->heavy_min_flops = value;
+    else if (k == "timing_min_flops") ctx->timing_min_flops = value;
     else if (k == "eigh_warm") ctx->eigh_warm = (int)value;
     else if (k == "svd_abs_accuracy") ctx->svd_abs_accuracy = (int)value;
     else if (k == "lz_abs_accuracy") ctx->lz_abs_accuracy = (int)value;
@@ -194,6 +197,7 @@ int ctm_get_stat(ctm_ctx* ctx, const char* key, double* value) {
     else if (k == "layer2_flops") *value = ctx->layer2_flops;
     else if (k == "layer2_calls") *value = (double)ctx->layer2_calls;
     else if (k == "arena_high") *value = (double)ctx->arena.high;
+    else if (k == "arena_total") *value = (double)ctx->arena.total;          // bytes this context holds right now
     else if (k == "absorb_bytes") *value = ctx->absorb_bytes;
     else if (k == "absorb_calls") *value = (double)ctx->absorb_calls;
     else if (k.rfind("k_", 0) == 0 && k.size() >= 5) {      // k_ms0, k_ms1, k_flops0, k_flops1, k_calls0, k_calls1

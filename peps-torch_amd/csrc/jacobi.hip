@@ -2044,14 +2044,25 @@ __global__ __launch_bounds__(256) void chol64_scaled_inv_kernel(const double* __
         if (pmin > 1e-10) { if (tid == 0) *flag3 = 0; break; }      // (uniform: every thread tracked the same pivots)
         if (tid == 0) *flag3 = 1;
     }
-    // X = L^-1: column c by the four lanes (c, part 0..3) of one wave; row r of a column needs its rows < r
+    // X = L^-1: column c by the four lanes (c, part 0..3) of one wave; row r of a column needs its rows < r.  The <= 16 terms of a
+    // lane's share of the dot product are issued as one batch of LDS loads (fixed trip count, clamped index, zero weight beyond
+    // the range) instead of a load-wait-multiply loop: the 63 dependent rows of a column cost ~150 cycles each, not ~2000.
     {
         const int c = tid >> 2, part = tid & 3;
         if (part == 0) xd[c] = 1.0 / LX[c][c];
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         for (int r = c + 1; r < M; ++r) {
-            double acc = (part == 0) ? -LX[r][c] * xd[c] : 0.0;                  // t = c term
-            for (int t = c + 1 + part; t < r; t += 4) acc -= LX[r][t] * LX[c][t];   // X[t][c] lives at LX[c][t]
+            double lv[16], xv[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int t = c + 1 + part + 4 * i, tc = t < r ? t : r - 1;      // (r - 1 >= c: a valid entry of both operands)
+                lv[i] = LX[r][tc]; xv[i] = (t < r) ? LX[c][tc] : 0.0;
+                if (tc == c) xv[i] = 0.0;                                           // column c itself is the t = c term below
+            }
+            double acc0 = (part == 0) ? -LX[r][c] * xd[c] : 0.0, acc1 = 0.0;
+#pragma unroll
+            for (int i = 0; i < 16; i += 2) { acc0 -= lv[i] * xv[i]; acc1 -= lv[i + 1] * xv[i + 1]; }
+            double acc = acc0 + acc1;
             acc += __shfl_xor(acc, 1, 64);
             acc += __shfl_xor(acc, 2, 64);
             if (part == 0) LX[c][r] = acc / LX[r][r];

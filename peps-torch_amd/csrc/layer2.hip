@@ -540,6 +540,7 @@ int dev_layer2(ctm_ctx* ctx, const std::string& iz, const DT& Z, const std::stri
     p.dbg = ctx->layer2_dbg;
     const long long npair = (long long)p.nx * p.ny;
     const double fl = 2.0 * npair * p.p * ((double)p.KA * p.KA * p.NE + (double)p.KA * p.NE * p.NE) * (cx ? 4.0 : 1.0);
+    HeavyScope heavy(ctx, fl);
     const int ev = timing_begin(ctx);
     int st = CTM_OK;
     if (cx) {

@@ -160,7 +160,13 @@ def ctm_MOVE(direction, state, env, ctm_args=cfg.ctm_args, global_args=cfg.globa
     pool = None
     if getattr(ctm_args, "concurrent_units", True) and len(mine) > 1:
         import units
-        pool = units.pool_for(eng, len(mine), max(_proj_rows(direction, c, state, chi) for c in mine), like.dtype.is_complex)
+        # large n: all units of the move in flight while their truncations run the block Krylov solver (long latency-bound stages
+        # that only overlap with other units'); two at a time otherwise (same sweep time, half the workspace, and the chip-filling
+        # kernels of a low-rank unit share the chip with one other launch instead of three)
+        krylov = env.__dict__.get("_krylov_units", False)
+        pool = units.pool_for(eng, len(mine), max(_proj_rows(direction, c, state, chi) for c in mine), like.dtype.is_complex,
+                              large_n_units=None if krylov else 2)
+    lz_before = eng.stat("lz_hits") if hasattr(eng, "stat") else 0
 
     def _each(fn, items, stagger=0.0):
         return pool.map(fn, items, stagger=stagger) if pool is not None else [fn(it) for it in items]
@@ -175,6 +181,8 @@ def ctm_MOVE(direction, state, env, ctm_args=cfg.ctm_args, global_args=cfg.globa
     for coord, (p_, pt_) in zip(mineA, _each(lambda c: get_projectors(direction, c, state, env, ctm_args, global_args,
                                                                               diagnostics=diagnostics), mineA, stagger)):
         P[coord], Pt[coord] = p_, pt_
+    if hasattr(eng, "stat"):
+        env.__dict__["_krylov_units"] = eng.stat("lz_hits") > lz_before
     if parallel.is_distributed():
         shp = {}
         for coord in coords:

@@ -110,8 +110,10 @@ def _rdm2x2_raw(eng, t, env, group=None):
     chunk = P4
     if a.is_cuda:
         free, _ = torch.cuda.mem_get_info(a.device)
-        arena = sum(getattr(e, "stat", lambda k: 0)("arena_high") for e in [eng]) if hasattr(eng, "stat") else 0
-        budget = 0.85 * (free + arena)                          # the engine's own arena is reused
+        # the bytes this engine's own arena holds right now are reused by the call (NOT the high-water marks of the worker contexts,
+        # whose arenas were given back before an evaluation of this size)
+        arena = eng.own_stat("arena_total") if hasattr(eng, "own_stat") else 0
+        budget = 0.85 * (free + arena)
         while chunk > 1 and 1.15 * n * n * (2 * p * p + 1 + chunk) * el > budget:
             chunk //= 2
     if len(members) > 1:

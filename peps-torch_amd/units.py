@@ -73,7 +73,7 @@ _pools = {}
 _lock = threading.Lock()
 
 
-def pool_for(engine, nunits, n, is_complex, est_bytes=None):
+def pool_for(engine, nunits, n, is_complex, est_bytes=None, large_n_units=None):
     """UnitPool sized for `nunits` concurrent units of fused dimension n, or None when concurrency is off / pointless
     (stand-in engines, a single unit, or not enough HBM for one workspace arena per unit).  est_bytes overrides the
     per-unit workspace estimate of a sweep unit."""
@@ -89,7 +89,7 @@ def pool_for(engine, nunits, n, is_complex, est_bytes=None):
         # paid once per move instead of twice (full-rank D = 8 chi = 256: 3.71 -> 3.26 s/sweep).  Needs one hardware queue per
         # stream (GPU_MAX_HW_QUEUES, see backend.py): with the default of four queues the four worker streams share two of them
         # and run pairwise serialised (measured: no gain at all).
-        nw = min(nw, int(os.environ.get("CTM_LARGE_N_UNITS", 4)))
+        nw = min(nw, int(os.environ.get("CTM_LARGE_N_UNITS", 4)) if large_n_units is None else large_n_units)
     nw = min(nw, int(os.environ.get("CTM_MAX_CONCURRENT_UNITS", nw)))       # experiment knob
     if nw < 2:
         return None
