@@ -26,7 +26,11 @@ int arena_alloc(ctm_ctx* ctx, size_t bytes, void** out) {
         if (!a.slabs.empty() && cap < a.slabs.back().cap) cap = a.slabs.back().cap;
         Slab s;
         hipError_t e = hipMalloc((void**)&s.base, cap);
-        if (e != hipSuccess && cap > bytes) { cap = bytes; e = hipMalloc((void**)&s.base, cap); }
+        if (e != hipSuccess && cap > bytes) {
+            (void)hipGetLastError();          // the failed attempt must not surface as the "launch error" of the next kernel
+            cap = bytes; e = hipMalloc((void**)&s.base, cap);
+        }
+        if (e != hipSuccess) (void)hipGetLastError();
         if (e != hipSuccess) {
             ctx->set_error("arena: hipMalloc of " + std::to_string(cap) + " bytes failed: " + hipGetErrorString(e));
             return CTM_ERR_NOMEM;
