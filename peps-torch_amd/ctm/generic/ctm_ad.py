@@ -187,6 +187,12 @@ def ctm_MOVE(direction, state, env, ctm_args=cfg.ctm_args):
             n = env.chi * max(a0.shape[1:]) ** 2
             pool = units.pool_for(get_engine(), len(keys_s), n, a0.is_complex(), est_bytes=40.0 * n * n * a0.element_size())
         import parallel
+        if parallel.is_distributed():
+            # decided on every rank alike, BEFORE any rank-dependent work: with more ranks than sites (or unequal bond dimensions) a rank
+            # that owns no unit must not bail out while the owners go on into the exchange and block there
+            if parallel.world()[1] > len(keys_s) or len({st.site(c).shape for c in keys_s}) != 1:
+                raise NotImplementedError("distributed differentiable move: uniform bond dimensions and at least one site per rank "
+                                          f"(world size {parallel.world()[1]}, {len(keys_s)} sites)")
         mine = parallel.my_units(keys_s)                       # all sites in a single process; this rank's share under torch.distributed
         P, Pt = {}, {}
         for coord, (p_, pt_) in zip(mine, pool.map(proj, mine) if pool is not None and len(mine) > 1 else [proj(c) for c in mine]):
