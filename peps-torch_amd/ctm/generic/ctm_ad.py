@@ -171,7 +171,9 @@ def ctm_MOVE(direction, state, env, ctm_args=cfg.ctm_args):
         def proj(coord):
             with torch.set_grad_enabled(grad_on):
                 R, Rt = halves(direction, coord, st, ev, four_by_two)
-                return projectors_from_matrices(R, Rt, env.chi, ctm_args, basis=_warm_ws(env, coord, R, ctm_args))
+                # (inside a checkpointed move the decomposition is run twice: no warm basis, which the first run would have advanced)
+                basis = None if getattr(ctm_args, "fwd_checkpoint_move", False) else _warm_ws(env, coord, R, ctm_args)
+                return projectors_from_matrices(R, Rt, env.chi, ctm_args, basis=basis)
 
         def absb(coord):
             with torch.set_grad_enabled(grad_on):
@@ -182,7 +184,9 @@ def ctm_MOVE(direction, state, env, ctm_args=cfg.ctm_args):
 
         pool = None
         a0 = tensors[0]
-        if len(keys_s) > 1 and a0.is_cuda and getattr(ctm_args, "concurrent_units", True):
+        # fwd_checkpoint_move: torch's non-reentrant checkpoint intercepts saved tensors through thread-local hooks, so nodes built
+        # in worker threads would not be checkpointed at all: the units of a checkpointed move run in the calling thread
+        if len(keys_s) > 1 and a0.is_cuda and getattr(ctm_args, "concurrent_units", True) and not getattr(ctm_args, "fwd_checkpoint_move", False):
             import units
             n = env.chi * max(a0.shape[1:]) ** 2
             pool = units.pool_for(get_engine(), len(keys_s), n, a0.is_complex(), est_bytes=40.0 * n * n * a0.element_size())

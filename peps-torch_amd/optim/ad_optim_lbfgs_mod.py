@@ -124,7 +124,9 @@ def optimize_state(state, ctm_env_init, loss_fn, obs_fn=None, post_proc=None, ma
                 _write_best()
 
     def closure():
-        linesearching = calls[0] > 0            # torch's strong-Wolfe search re-enters the closure: the first call of a step is the epoch's
+        # torch's strong-Wolfe search re-enters the closure: the first call of a step is the epoch's.  Without that search the extra
+        # closure calls of an epoch are plain inner iterations (max_iter_per_epoch > 1) and count as losses of their own
+        linesearching = calls[0] > 0 and opt_args.line_search == "strong_wolfe"
         calls[0] += 1
         context["line_search"] = linesearching
         optimizer.zero_grad()
@@ -172,9 +174,13 @@ def optimize_state(state, ctm_env_init, loss_fn, obs_fn=None, post_proc=None, ma
         x0 = [p.detach().clone() for p in parameters]
         group = optimizer.param_groups[0]
         lr0 = group["lr"]
+        st = optimizer.state[optimizer._params[0]]
+        n_iter0 = st.get("n_iter", 0)
         loss = optimizer.step(closure)
         st = optimizer.state[optimizer._params[0]]
-        if "d" not in st or loss is None:
+        # step() returns early (gradient below tolerance_grad, or no descent along d) WITHOUT a new direction: the state then still
+        # holds the previous epoch's d / t / prev_flat_grad, and searching along that stale direction would move the parameters
+        if "d" not in st or loss is None or st.get("n_iter", 0) == n_iter0:
             return
         d, t = st["d"], st["t"]
         loss0 = float(loss.detach())
