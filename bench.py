@@ -600,8 +600,9 @@ def main():
                "roofline": res["roofline"], "svd": res["svd"], "phase_s": res["phase_s"], "phase_s_note": res["phase_s_note"]}
         if "state" in res:
             out["state"] = res["state"]
-        if "steady_state" in res:
-            out["steady_state"] = res["steady_state"]
+        for k_ in ("steady_state", "moving_environment", "stationary_environment"):
+            if k_ in res:
+                out[k_] = res[k_]
         if full is not None:
             out["full_rank"] = {"metric": "ctm_sweeps_per_sec", "value": full["value"], "unit": "sweeps/s", "ms_per_step": full["ms_per_step"],
                                 "steps": full["steps"], "warmup": full["warmup"],

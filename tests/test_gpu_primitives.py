@@ -170,6 +170,29 @@ def test_row_block_times_big_operand_kernels(eng, rows_kernel):
         eng.set_option("rows_kernel_min_m", old[0]); eng.set_option("rows_kernel_min_m_kc", old[1])
 
 
+def test_in_launch_split_k_combine_equals_the_separate_reduce_kernel(eng):
+    """The row-block kernel sums its K-slice partials inside the launch (last workgroup of a column tile, fixed slice order); the
+    separate reduce kernel sums the same partials in the same order: bit-identical products, in both operand layouts, for several row
+    counts, and repeatedly (a stale or half-visible slab would show as a difference)."""
+    import torch
+    g = torch.Generator(device="cuda").manual_seed(7)
+    n, k = 4096, 8192
+    B = torch.randn(k, n, dtype=torch.float64, device="cuda", generator=g)
+    Bt = B.t().contiguous()
+    try:
+        for m in (16, 32, 48, 64):
+            A = torch.randn(m, k, dtype=torch.float64, device="cuda", generator=g)
+            eng.set_option("rows_fused_reduce", 0)
+            ref, reft = eng.gemm(A, B), eng.gemm(A, Bt, transB=True)
+            eng.set_option("rows_fused_reduce", 1)
+            for _ in range(5):
+                assert torch.equal(eng.gemm(A, B), ref), m
+                assert torch.equal(eng.gemm(A, Bt, transB=True), reft), m
+            assert (ref - A @ B).abs().max().item() < 1e-11 * ref.abs().max().item()
+    finally:
+        eng.set_option("rows_fused_reduce", 1)
+
+
 @pytest.mark.parametrize("cplx", [False, True])
 def test_full_decomposition_of_a_rank_deficient_matrix_returns_orthonormal_factors(eng, cplx):
     """chi = n on a matrix of rank n/3 (plus singular values at the rounding level): U and V are complete orthonormal bases, as
