@@ -725,6 +725,10 @@ int jacobi_rows(ctm_ctx* ctx, double* X, int R, long long ld, int Cg, int Ctot, 
         ctx->last_offnorm = srel;
         if (ctx->jacobi_verbose > 1) fprintf(stderr, "[jacobi] R=%d sweep %d  scaled=%.3e classical=%.3e tau=%.3e\n", R, sweep + 1, srel, ctx->h_scratch[1], std::sqrt(tau2));
         if (srel <= ctx->jacobi_tol) break;
+        // `srel` is the measure of the Gram matrices the sweep FOUND; in the quadratic regime the sweep leaves ~ srel^2 / gap.  A caller
+        // that verifies the result itself (the Ritz extraction of the block Krylov solver: residuals of both relations on the returned
+        // triplets) does not pay for a twelfth sweep that finds 1e-15 and rotates nothing
+        if (ctx->jacobi_quad_exit > 0.0 && srel <= ctx->jacobi_quad_exit) break;
     }
     ctx->total_sweeps += ctx->last_sweeps; ctx->jacobi_calls += 1;
     return CTM_OK;
@@ -1121,7 +1125,7 @@ int matop_apply(ctm_ctx* ctx, const MatOp& op, bool transpose, const double* B, 
 // of a few per sweep and a unit is visited twice per sweep, so the next probe is scheduled for when it could succeed.
 // memory of a unit between sweeps (header row of its warm workspace, doubles): [0] calls left that skip the warm probe (svd_iter),
 // [1] block steps of the last accepted Krylov solve, [2] its residual estimate / s_0, [3] consecutive warm probes that were handed
-// to the Krylov solver (each one doubles the distance to the next probe: a full-rank environment at its rounding floor, where the
+// to the Krylov solver (each one quadruples the distance to the next probe: a full-rank environment at its rounding floor, where the
 // previous basis stays ~1e-10 away from the new operator for ever, otherwise pays two half steps on k + k/2 rows every few sweeps)
 enum { HDR_SKIP = 0, HDR_STEPS = 1, HDR_EST = 2, HDR_FAILS = 3, HDR_WORDS = 4 };
 
@@ -1171,7 +1175,7 @@ int svd_iter(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* Ut, double
     auto probe_failed = [&](double r) -> int {
         if (!op.warm_hdr) return CTM_OK;
         const double f = std::min(hdr_fails + 1.0, 8.0);
-        const int skip = std::max(warm_skip_calls(ctx, r), std::min(2048, ctx->si_warm_skip_calls << (int)(f - 1.0)));
+        const int skip = std::max(warm_skip_calls(ctx, r), std::min(4096, ctx->si_warm_skip_calls << (2 * (int)(f - 1.0))));   // x4 per failure
         CTM_TRY(fill_f64(ctx, op.warm_hdr + HDR_SKIP, 1, (double)skip));
         return fill_f64(ctx, op.warm_hdr + HDR_FAILS, 1, f);
     };
@@ -2254,7 +2258,9 @@ int svd_lanczos(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* Ut, dou
         ctx->force_abs = ctx->lz_abs_accuracy != 0;
         const int save_b = ctx->jacobi_block;
         if (ctx->lz_jacobi_block > 0) ctx->jacobi_block = ctx->lz_jacobi_block;      // panel height of the dense SVD of the Ritz matrix
+        ctx->jacobi_quad_exit = ctx->lz_quad_exit;
         const int st = svd_full(ctx, T, m, kq, Ss, Xt, Yt);                      // rows of Xt / Yt: x_i^T, y_i^T
+        ctx->jacobi_quad_exit = 0.0;
         ctx->jacobi_block = save_b;
         ctx->force_abs = false;
         ctx->si_enable = save;
