@@ -467,12 +467,20 @@ def traffic_from_profile(args, world, dom, signed):
     """HBM traffic of the kernel families from the committed PMC pass of this same command (bench.py cannot attach counters to
     itself); None when no profile of this workload is committed."""
     try:
-        import csv
+        import csv, glob
         tag = "signed" if signed else "default"
-        prof = json.load(open(os.path.join(REPO, "profiles", f"r02_bench_{tag}.json")))
-        if prof["config"]["workload"] != args.config or world != 1:
+        # the newest committed round: profiles/rNN_bench_<tag>_pmc_hbm_traffic.csv next to the line the profiled command printed
+        cands = sorted(glob.glob(os.path.join(REPO, "profiles", f"r*_bench_{tag}_pmc_hbm_traffic.csv")))
+        if not cands or world != 1:
             return None
-        rows = list(csv.DictReader(open(os.path.join(REPO, "profiles", f"r02_bench_{tag}_pmc_hbm_traffic.csv"))))
+        fcsv = cands[-1]
+        rnd = os.path.basename(fcsv).split("_")[0]
+        line = [f for f in (os.path.join(REPO, "profiles", f"{rnd}_bench_{tag}_under_rocprof.json"), os.path.join(REPO, "profiles", f"{rnd}_bench_{tag}.json"))
+                if os.path.exists(f)]
+        prof = json.loads(open(line[0]).read().strip().splitlines()[-1])
+        if prof["config"]["workload"] != args.config:
+            return None
+        rows = list(csv.DictReader(open(fcsv)))
 
         def pmc(keys):
             tb = tn = 0.0
@@ -481,7 +489,7 @@ def traffic_from_profile(args, world, dom, signed):
                     tb += float(row["hbm_bytes_per_launch(2x_fetch_corrected)"]) * float(row["launches"]); tn += float(row["launches"])
             return round(tb / tn) if tn else None
         return {"dominant": pmc(CLS[dom][2]), "others": {str(i): pmc(CLS[i][2]) for i in CLS if i != dom},
-                "source": f"profiles/r02_bench_{tag}_pmc_hbm_traffic.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, average HBM bytes per launch)"}
+                "source": f"profiles/{os.path.basename(fcsv)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, average HBM bytes per launch)"}
     except Exception:
         return None
 
