@@ -95,6 +95,8 @@ struct ctm_ctx {
     bool lz_verify_op = false;          // additionally check both relations of the Ritz triplets with operator applications (debug / tests)
     long lz_extractions = 0; double lz_last_est = 0.0; int lz_last_steps = 0;
     double jacobi_quad_exit = 0.0;      // (internal) jacobi_rows stops after a sweep that FOUND <= this measure (quadratic regime)
+    double si_quad_exit = 0.0;          // ... optionally during the Rayleigh-Ritz of the subspace iteration (off: measured no gain -- the sweep it saves finds every
+                                        // pair below tolerance, and such a sweep costs ~10 us per round: the eigensolver exits early, the apply GEMMs are skipped)
     double lz_quad_exit = 1e-9;         // ... during the Ritz extraction of the block Krylov solver, whose triplets are verified afterwards
     int lz_jacobi_block = 0;            // > 0: panel height of the Jacobi SVD of the Ritz matrix (16: 32 x 32 pair Grams, 18 KB LDS eigensolver)
     bool lz_async = true;               // block Krylov recurrence issued without host synchronisations (status words checked at the extraction)

@@ -156,6 +156,7 @@ int ctm_set_option(ctm_ctx* ctx, const char* key, double value) {
     else if (k == "lz_async") ctx->lz_async = value != 0.0;
     else if (k == "lz_jacobi_block") ctx->lz_jacobi_block = (int)value;
     else if (k == "lz_quad_exit") ctx->lz_quad_exit = value;
+    else if (k == "si_quad_exit") ctx->si_quad_exit = value;
     else if (k == "lz_local_project") ctx->lz_local_project = value != 0.0;
     else if (k == "layer2_cplx") ctx->layer2_cplx = value != 0.0;
     else if (k == "layer2_reg") ctx->layer2_reg = (int)value;

@@ -1298,8 +1298,13 @@ int svd_iter(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* Ut, double
         int st;
         const double fro = host_fro(ctx, nxt, p, n, ld, norms, h, &st);
         CTM_TRY(st);
-        CTM_TRY(jacobi_rows(ctx, nxt, p, ld, n, (int)ld, p == 32 ? 16 : b, std::min(k, p - 1), fro, (have_prev || warm) ? ctx->si_rr_sweeps : std::min(3, ctx->si_rr_sweeps),
-                            false, ctx->si_tau_both != 0));
+        // (no verification sweep once a sweep found <= si_quad_exit: the residual test below certifies the triplets of the step that is
+        // accepted, and a sweep that found 1e-9 leaves ~1e-18 / gap -- see jacobi_rows)
+        ctx->jacobi_quad_exit = ctx->si_quad_exit;
+        const int st_rr = jacobi_rows(ctx, nxt, p, ld, n, (int)ld, p == 32 ? 16 : b, std::min(k, p - 1), fro, (have_prev || warm) ? ctx->si_rr_sweeps : std::min(3, ctx->si_rr_sweeps),
+                            false, ctx->si_tau_both != 0);
+        ctx->jacobi_quad_exit = 0.0;
+        CTM_TRY(st_rr);
         CTM_TRY(row_norms(ctx, nxt, p, n, ld, norms));
         h.assign(p_full, 0.0);
         CTM_HIP_CHECK(ctx, hipMemcpyAsync(h.data(), norms, sizeof(double) * p, hipMemcpyDeviceToHost, ctx->stream));
@@ -1763,8 +1768,11 @@ int svd_iter_c(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* Ut, doub
         std::vector<double> hh;
         const double fro = host_fro(ctx, nxt, R, n, ld, norms, hh, &st);
         CTM_TRY(st);
-        CTM_TRY(jacobi_rows(ctx, nxt, R, ld, n, (int)ld, 2 * BC, std::min(k, p - 1), fro, (have_prev || warm) ? ctx->si_rr_sweeps : std::min(3, ctx->si_rr_sweeps), true,
-                            ctx->si_tau_both != 0));
+        ctx->jacobi_quad_exit = ctx->si_quad_exit;
+        const int st_rr = jacobi_rows(ctx, nxt, R, ld, n, (int)ld, 2 * BC, std::min(k, p - 1), fro, (have_prev || warm) ? ctx->si_rr_sweeps : std::min(3, ctx->si_rr_sweeps), true,
+                            ctx->si_tau_both != 0);
+        ctx->jacobi_quad_exit = 0.0;
+        CTM_TRY(st_rr);
         CTM_TRY(row_norms(ctx, nxt, R, n, ld, norms));
         CTM_LAUNCH(ctx, panel_combine_kernel, dim3((R + 255) / 256), dim3(256), 0, norms, nc, R);
         CTM_HIP_CHECK(ctx, hipMemcpyAsync(tmp.data(), nc, sizeof(double) * R, hipMemcpyDeviceToHost, ctx->stream));
