@@ -1992,104 +1992,88 @@ int orthonormalise_block(ctm_ctx* ctx, double* W, int rows, int n, double* norms
 }
 
 // Sync-free variant of the block orthonormalisation (the Krylov recurrence issues its steps without waiting for the device):
-// Cholesky-QR of the 64 rows with the unit-norm scaling folded into the factorisation.  One workgroup of 256 threads:
-//   d_i = G_ii (squared row norms), A = D^-1/2 G D^-1/2 (unit diagonal), A = L L^T (right-looking; thread (ti, tk) keeps a 4 x 4
-//   block of the lower triangle in registers, one barrier per column), X = L^-1 (forward substitution, four lanes per column),
-//   out = X D^-1/2  so that  out * W  has orthonormal rows.  34 KB of LDS (L below the diagonal, X above it): the kernel fits on a
-//   CU beside two workgroups of the row-block GEMM, so another unit's corner passes do not delay it.
+// Cholesky-QR of the 64 rows with the unit-norm scaling folded into the factorisation.  ONE wave, everything in registers, no LDS
+// and no barrier: lane i holds row i of the scaled matrix (64 doubles), a value another lane needs travels through v_readlane with
+// a compile-time lane index (the loops are fully unrolled), so a step of either phase is two readlanes and one FMA with an SGPR
+// operand instead of an LDS round trip behind a barrier:
+//   d_i = G_ii (squared row norms), A = D^-1/2 G D^-1/2 (unit diagonal);
+//   A = L L^T, right-looking: column j is scaled by rsqrt(pivot) (hardware estimate + two Newton steps; the pivot is wave-uniform),
+//     then a[k] -= a[j] * L_kj for k > j, L_kj read from lane k;
+//   X = L^-1: lane c builds column c, x_r = -(sum_{t<r} L_rt x_t) / L_rr with L_rt read from lane r (x_t = 0 for t < c by construction);
+//   out = X D^-1/2  so that  out * W  has orthonormal rows.
+// 110 us -> 2x us per call against the 256-thread LDS version it replaces (2100 cycles per column and 2000 per row of the inverse there:
+// barrier, LDS latency, ds_bpermute reductions and IEEE divisions on the critical path).
 // mode 0 (first pass): when a pivot of A falls below 1e-10 (rows nearly dependent: cond(W) > ~1e5, beyond two Cholesky-QR passes)
 //   the factorisation is repeated on A + 1e-10 I (shifted Cholesky-QR: the result is only roughly orthonormal, cond ~ 1e-5 cond(W))
 //   and *flag3 is set: a third pass then finishes.  mode 1: plain.  mode 2 (third pass): returns at once unless *flag3.
 // status[0] = smallest pivot of the accepted factorisation, [1] = smallest, [2] = largest row norm.  Nothing is decided on the
 // host here: the caller reads the status words of all its steps at its next host synchronisation.
-__global__ __launch_bounds__(256) void chol64_scaled_inv_kernel(const double* __restrict__ G, double* __restrict__ out, double* __restrict__ status,
-                                                                int* __restrict__ flag3, int mode) {
+__device__ __forceinline__ double lane_bcast(double v, int lane) {       // `lane` must be wave-uniform
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+
+__global__ __launch_bounds__(64) void chol64_scaled_inv_kernel(const double* __restrict__ G, double* __restrict__ out, double* __restrict__ status,
+                                                               int* __restrict__ flag3, int mode) {
     constexpr int M = 64;
-    __shared__ double LX[M][M + 1];            // L on and below the diagonal; X = L^-1 (strictly lower part) transposed above it
-    __shared__ double dinv[M], xd[M];
-    __shared__ double col[2][M];
-    const int tid = threadIdx.x;
-    if (mode == 2 && *flag3 == 0) { if (tid == 0) { status[0] = 1.0; status[1] = -1.0; status[2] = -1.0; } return; }   // skipped: marked by the -1
-    if (tid < M) { const double d = G[tid * M + tid]; dinv[tid] = d > 0.0 ? 1.0 / sqrt(d) : 0.0; }
-    __syncthreads();
-    const int ti = tid >> 4, tk = tid & 15, i0 = 4 * ti, k0 = 4 * tk;
+    const int lane = threadIdx.x;
+    if (mode == 2 && *flag3 == 0) { if (lane == 0) { status[0] = 1.0; status[1] = -1.0; status[2] = -1.0; } return; }   // skipped: marked by the -1
+#ifdef CTM_KERNEL_CLOCKS
+    const long long clk0 = clock64();
+#endif
+    const double dg = G[lane * M + lane];
+    const double dinv = dg > 0.0 ? 1.0 / sqrt(dg) : 0.0;
+    double a[M];                    // row `lane` of A, then of L
+    double rinv = 0.0;              // lane j: 1 / L_jj
     double pmin = 1e300;
     for (int attempt = 0; attempt < 2; ++attempt) {
         const double shift = attempt == 0 ? 0.0 : 1e-10;
-        double a[4][4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-            for (int v = 0; v < 4; ++v) a[u][v] = G[(i0 + u) * M + k0 + v] * dinv[i0 + u] * dinv[k0 + v] + ((i0 + u == k0 + v) ? shift : 0.0);
+        for (int k = 0; k < M; ++k)     // G is symmetric: column `lane` read along rows (coalesced) is row `lane`
+            a[k] = G[k * M + lane] * dinv * lane_bcast(dinv, k) + ((k == lane) ? shift : 0.0);
         pmin = 1e300;
+#pragma unroll
         for (int j = 0; j < M; ++j) {
-            const int jb = j >> 2, jv = j & 3, buf = j & 1;
-            if (tk == jb && ti >= jb) {            // owners of column j publish it (unscaled, pivot included)
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    double cv = a[u][0];
-                    if (jv == 1) cv = a[u][1]; else if (jv == 2) cv = a[u][2]; else if (jv == 3) cv = a[u][3];
-                    col[buf][i0 + u] = cv;
-                }
-            }
-            __syncthreads();
-            const double piv = col[buf][j];
+            const double piv = lane_bcast(a[j], j);
             pmin = fmin(pmin, piv);
-            const double ps = fmax(piv, 1e-300), rp = 1.0 / ps, rl = 1.0 / sqrt(ps);
-            if (tk == jb && ti >= jb) {
+            const double ps = fmax(piv, 1e-300);
+            double rl = __builtin_amdgcn_rsq(ps);
+            rl = rl * (1.5 - 0.5 * ps * rl * rl);
+            rl = rl * (1.5 - 0.5 * ps * rl * rl);
+            a[j] *= rl;                                  // L_ij for every row i (lane j: L_jj)
+            if (lane == j) rinv = rl;
 #pragma unroll
-                for (int u = 0; u < 4; ++u) if (i0 + u >= j) LX[i0 + u][j] = col[buf][i0 + u] * rl;
-            }
-            if (tk >= jb && ti >= tk) {            // trailing update of my block: columns k > j, rows i >= k
-                double ci[4], ck[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) { ci[u] = col[buf][i0 + u]; ck[u] = col[buf][k0 + u] * rp; }
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-#pragma unroll
-                    for (int v = 0; v < 4; ++v)
-                        if (k0 + v > j) a[u][v] -= ci[u] * ck[v];
-            }
+            for (int k = j + 1; k < M; ++k) a[k] -= a[j] * lane_bcast(a[j], k);
         }
-        __syncthreads();
         if (mode != 0 || attempt == 1) break;
-        if (pmin > 1e-10) { if (tid == 0) *flag3 = 0; break; }      // (uniform: every thread tracked the same pivots)
-        if (tid == 0) *flag3 = 1;
+        if (pmin > 1e-10) { if (lane == 0) *flag3 = 0; break; }      // (uniform: every lane tracked the same pivots)
+        if (lane == 0) *flag3 = 1;
     }
-    // X = L^-1: column c by the four lanes (c, part 0..3) of one wave; row r of a column needs its rows < r.  The <= 16 terms of a
-    // lane's share of the dot product are issued as one batch of LDS loads (fixed trip count, clamped index, zero weight beyond
-    // the range) instead of a load-wait-multiply loop: the 63 dependent rows of a column cost ~150 cycles each, not ~2000.
-    {
-        const int c = tid >> 2, part = tid & 3;
-        if (part == 0) xd[c] = 1.0 / LX[c][c];
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-        for (int r = c + 1; r < M; ++r) {
-            double lv[16], xv[16];
+#ifdef CTM_KERNEL_CLOCKS
+    const long long clk1 = clock64();
+#endif
+    double x[M];                    // column `lane` of X = L^-1
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int t = c + 1 + part + 4 * i, tc = t < r ? t : r - 1;      // (r - 1 >= c: a valid entry of both operands)
-                lv[i] = LX[r][tc]; xv[i] = (t < r) ? LX[c][tc] : 0.0;
-                if (tc == c) xv[i] = 0.0;                                           // column c itself is the t = c term below
-            }
-            double acc0 = (part == 0) ? -LX[r][c] * xd[c] : 0.0, acc1 = 0.0;
+    for (int r = 0; r < M; ++r) {
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
 #pragma unroll
-            for (int i = 0; i < 16; i += 2) { acc0 -= lv[i] * xv[i]; acc1 -= lv[i + 1] * xv[i + 1]; }
-            double acc = acc0 + acc1;
-            acc += __shfl_xor(acc, 1, 64);
-            acc += __shfl_xor(acc, 2, 64);
-            if (part == 0) LX[c][r] = acc / LX[r][r];
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");      // the four lanes sit in one wave: LDS program order suffices
+        for (int t = 0; t < r; ++t) {
+            const double l = lane_bcast(a[t], r);       // L_rt
+            if ((t & 3) == 0) s0 += l * x[t]; else if ((t & 3) == 1) s1 += l * x[t]; else if ((t & 3) == 2) s2 += l * x[t]; else s3 += l * x[t];
         }
+        const double rr = lane_bcast(rinv, r);
+        const double sum = (s0 + s1) + (s2 + s3);
+        x[r] = lane < r ? -sum * rr : (lane == r ? rr : 0.0);
     }
-    __syncthreads();
-    for (int q = tid; q < M * M; q += 256) {
-        const int r = q >> 6, c = q & 63;
-        out[q] = (c < r) ? LX[c][r] * dinv[c] : (c == r ? xd[r] * dinv[r] : 0.0);
-    }
-    double mn = 1e300, mx = 0.0;
-    if (tid < M) { const double d = G[tid * M + tid]; const double nr = d > 0.0 ? sqrt(d) : 0.0; mn = nr; mx = nr; }
+#ifdef CTM_KERNEL_CLOCKS
+    const long long clk2 = clock64();
+    if (lane == 0) { status[9] = (double)(clk1 - clk0); status[10] = (double)(clk2 - clk1); }
+#endif
+#pragma unroll
+    for (int r = 0; r < M; ++r) out[r * M + lane] = x[r] * dinv;
+    double mn = dg > 0.0 ? sqrt(dg) : 0.0, mx = mn;
     for (int off = 32; off > 0; off >>= 1) { mn = fmin(mn, __shfl_down(mn, off, 64)); mx = fmax(mx, __shfl_down(mx, off, 64)); }
-    if (tid == 0) { status[0] = pmin; status[1] = mn; status[2] = mx; }
+    if (lane == 0) { status[0] = pmin; status[1] = mn; status[2] = mx; }
 }
 
 // rows of W (64 x n) -> orthonormal rows spanning the same space: two Cholesky-QR passes, and a third one -- decided on the device --
@@ -2100,7 +2084,7 @@ int orthonormalise_block_async(ctm_ctx* ctx, double* W, int n, double* G, double
         GemmDesc g; g.M = 64; g.N = 64; g.K = n; g.A = W; g.sam = n; g.sak = 1; g.B = W; g.sbk = 1; g.sbn = n; g.C = G; g.ldc = 64;
         if (pass == 2) g.skip_all = flag3;
         CTM_TRY(gemm_f64(ctx, g));
-        CTM_LAUNCH(ctx, chol64_scaled_inv_kernel, dim3(1), dim3(256), 0, (const double*)G, Li, status + 3 * pass, flag3, pass);
+        CTM_LAUNCH(ctx, chol64_scaled_inv_kernel, dim3(1), dim3(64), 0, (const double*)G, Li, status + 3 * pass, flag3, pass);
         GemmDesc a; a.M = 64; a.N = n; a.K = 64; a.A = Li; a.sam = 64; a.sak = 1; a.B = W; a.sbk = n; a.sbn = 1; a.C = W; a.ldc = n;
         if (pass == 2) a.skip_all = flag3;
         CTM_TRY(gemm_f64(ctx, a));                       // in place: a workgroup reads its whole column strip before it writes
@@ -2969,6 +2953,25 @@ static int eigh_warm_verify(ctm_ctx* ctx, const double* As, int n, int kk, int k
         ke = kk;
         GemmDesc gh; gh.M = kk; gh.N = kk; gh.K = n; gh.A = Y; gh.sam = n; gh.sak = 1; gh.B = Q; gh.sbk = 1; gh.sbn = n; gh.C = H; gh.ldc = kk;
         CTM_TRY(gemm_f64(ctx, gh));                                      // H = Y Q^T
+        // A subspace that is not invariant cannot pass, whatever its Rayleigh-Ritz finds: the residuals of the kk Ritz pairs are the rows of
+        // Th (Y - H Q), an orthogonal rotation of R = Y - H Q, so sum_i res_i^2 = |R|_F^2 and max_i res_i >= |R|_F / sqrt(kk).  While the
+        // environment moves (every sweep before stationarity) this costs three launches instead of a kk x kk Jacobi eigensolver.
+        if (ctx->eigh_warm_early_reject) {
+            CTM_HIP_CHECK(ctx, hipMemcpyAsync(Y2, Y, sizeof(double) * (size_t)kk * n, hipMemcpyDeviceToDevice, ctx->stream));
+            GemmDesc gr; gr.M = kk; gr.N = n; gr.K = kk; gr.A = H; gr.sam = kk; gr.sak = 1; gr.B = Q; gr.sbk = n; gr.sbn = 1; gr.C = Y2; gr.ldc = n;
+            gr.alpha = -1.0; gr.beta = 1.0;
+            CTM_TRY(gemm_f64(ctx, gr));
+            CTM_TRY(row_norms(ctx, Y2, kk, n, n, res));
+            CTM_HIP_CHECK(ctx, hipMemcpyAsync(h.data(), res, sizeof(double) * kk, hipMemcpyDeviceToHost, ctx->stream));
+            CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+            double fro2 = 0.0, l0 = 0.0;
+            for (int i = 0; i < kk; ++i) { fro2 += h[i] * h[i]; l0 = std::max(l0, std::fabs(hd[i])); }
+            const double thr1 = 2.0 * resid_tol(ctx, n) * l0;            // (l0 from the Rayleigh quotients of the rows as they are: factor 2 of slack)
+            if (!(fro2 <= (double)kk * thr1 * thr1)) {
+                if (ctx->jacobi_verbose) fprintf(stderr, "[eigh-warm] n=%d kk=%d: subspace residual |R|_F / |l0| = %.3e (not invariant)\n", n, kk, std::sqrt(fro2) / std::max(l0, 1e-300));
+                return CTM_OK;
+            }
+        }
         const bool save = ctx->si_enable; ctx->si_enable = false;
         const int st = jacobi_eigh_top(ctx, H, kk, kk, Dk, Th, nullptr); // rows of Th = eigenvectors, ordered by |lambda|
         ctx->si_enable = save;
@@ -3063,6 +3066,126 @@ static int eigh_warm_verify_c(ctm_ctx* ctx, const double* Asr, const double* Asi
     return CTM_OK;
 }
 
+// Orthogonal iteration for the symmetric truncation while the matrix still changes from call to call (the C4v corner before
+// stationarity: eigh_warm_verify() has just refused the previous subspace).  The regular route -- the SVD block iteration with a
+// one-sided Jacobi Rayleigh-Ritz of the 128 rows after EVERY application, then a second Rayleigh-Ritz that separates +-lambda --
+// spends 8 of its 9 ms at n = 1024 in ~65 latency-bound launches of the 64 x 64 LDS eigensolver.  A symmetric matrix needs neither the
+// left/right bookkeeping nor Ritz values before the test that can accept them:
+//   Q_0 = [previous vectors | pseudo-random rows projected off them];   Q_{j+1} = orth(Q_j A)   (block Cholesky-QR: one pass while
+//   only the conditioning matters, the full two/three passes for the basis the Rayleigh-Ritz uses);
+//   from the fourth application on (the guard rows have seen the operator three times -- the `sound` rule of svd_iter()):
+//   T = Q A Q^T (p x p), T = Z^T diag(theta) Z, x_i = z_i Q, residuals |x_i A - theta_i x_i| for the kk leading |theta|.
+// Same acceptance threshold as the regular iteration; the orthonormality of Q that the residuals rely on is measured
+// (|Q Q^T - I| row norms), not assumed.  Anything unexpected -- no complete previous subspace, numerically low rank inside the block,
+// Q not orthonormal to 1e-12, no acceptance after eigh_orth_max applications -- returns with *accepted = false and the regular route runs.
+// Returned gauge: rows aligned with the previous vectors (warm_i <- sign<x_i, warm_i> x_i, u_i = sign(theta_i) warm_i), as the
+// regular route and the warm restart return them.
+static int eigh_orth_iter(ctm_ctx* ctx, const double* As, int n, int kk, int k_out, double* warm, double* D, double* Ut, bool* accepted) {
+    *accepted = false;
+    int p = kk + std::max(32, kk / 2);
+    p = ((p + 63) / 64) * 64;
+    if (kk < 2 || p >= n / 2) return CTM_OK;
+    ArenaScope scope(ctx);
+    const int nb = p / 64, pr = p - kk;
+    double *norms, *Q, *Y, *G, *Gp, *Li, *status, *T, *Dp, *Zt, *X, *AX, *res, *E, *dots;
+    int* flag3;
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * p, (void**)&norms));
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)p * n, (void**)&Q));
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)p * n, (void**)&Y));
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * 64 * 64, (void**)&G));
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)p * p, (void**)&Gp));
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * 64 * 64, (void**)&Li));
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * 16, (void**)&status));
+    CTM_TRY(arena_alloc(ctx, sizeof(int) * 4, (void**)&flag3));
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)p * p, (void**)&T));
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * p, (void**)&Dp));
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)p * p, (void**)&Zt));
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)kk * n, (void**)&X));
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)kk * n, (void**)&AX));
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * kk, (void**)&res));
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)p * p, (void**)&E));
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * kk, (void**)&dots));
+    std::vector<double> h(p), hd(kk), he(p);
+    CTM_TRY(row_norms(ctx, warm, kk, n, n, norms));
+    CTM_HIP_CHECK(ctx, hipMemcpyAsync(h.data(), norms, sizeof(double) * kk, hipMemcpyDeviceToHost, ctx->stream));
+    CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < kk; ++i) if (!(std::fabs(h[i] - 1.0) < 1e-6)) return CTM_OK;          // no complete previous subspace
+    CTM_HIP_CHECK(ctx, hipMemcpyAsync(Q, warm, sizeof(double) * (size_t)kk * n, hipMemcpyDeviceToDevice, ctx->stream));
+    double* Rn = Q + (size_t)kk * n;
+    CTM_LAUNCH(ctx, hash_fill_kernel, dim3(1024), dim3(256), 0, Rn, pr, n, (long long)n, 0x1234567ULL);
+    CTM_TRY(project_out(ctx, Rn, pr, n, Q, kk, Gp, 1));
+    auto chol_pass = [&](double* Wb, int mode) -> int {
+        GemmDesc g; g.M = 64; g.N = 64; g.K = n; g.A = Wb; g.sam = n; g.sak = 1; g.B = Wb; g.sbk = 1; g.sbn = n; g.C = G; g.ldc = 64;
+        if (mode == 2) g.skip_all = flag3;
+        CTM_TRY(gemm_f64(ctx, g));
+        CTM_LAUNCH(ctx, chol64_scaled_inv_kernel, dim3(1), dim3(64), 0, (const double*)G, Li, status + 3 * mode, flag3, mode);
+        GemmDesc a; a.M = 64; a.N = n; a.K = 64; a.A = Li; a.sam = 64; a.sak = 1; a.B = Wb; a.sbk = n; a.sbn = 1; a.C = Wb; a.ldc = n;
+        if (mode == 2) a.skip_all = flag3;
+        return gemm_f64(ctx, a);                          // in place: a workgroup reads its whole column strip before it writes
+    };
+    auto orth = [&](double* W, bool full) -> int {
+        for (int blk = 0; blk < nb; ++blk) {
+            double* Wb = W + (size_t)blk * 64 * n;
+            if (blk > 0) CTM_TRY(project_out(ctx, Wb, 64, n, W, blk * 64, Gp, 1));
+            CTM_TRY(chol_pass(Wb, 0));
+            if (!full) continue;
+            if (blk > 0) CTM_TRY(project_out(ctx, Wb, 64, n, W, blk * 64, Gp, 1));
+            CTM_TRY(chol_pass(Wb, 1));
+            CTM_TRY(chol_pass(Wb, 2));
+        }
+        return CTM_OK;
+    };
+    const int first_rr = 3, max_it = std::max(first_rr, ctx->eigh_orth_max);
+    for (int it = 0; it <= max_it; ++it) {
+        CTM_TRY(rows_times(ctx, Q, n, p, n, n, As, false, Y, n));       // Y = Q A: application it + 1
+        if (it >= first_rr && ((it - first_rr) % 2 == 0 || it == max_it)) {
+            GemmDesc gt; gt.M = p; gt.N = p; gt.K = n; gt.A = Y; gt.sam = n; gt.sak = 1; gt.B = Q; gt.sbk = 1; gt.sbn = n; gt.C = T; gt.ldc = p;
+            CTM_TRY(gemm_f64(ctx, gt));                                  // T = Y Q^T
+            GemmDesc ge; ge.M = p; ge.N = p; ge.K = n; ge.A = Q; ge.sam = n; ge.sak = 1; ge.B = Q; ge.sbk = 1; ge.sbn = n; ge.C = E; ge.ldc = p;
+            CTM_TRY(gemm_f64(ctx, ge));
+            CTM_LAUNCH(ctx, sub_eye_kernel, dim3((p + 255) / 256), dim3(256), 0, E, p);
+            CTM_TRY(row_norms(ctx, E, p, p, p, norms));
+            CTM_HIP_CHECK(ctx, hipMemcpyAsync(he.data(), norms, sizeof(double) * p, hipMemcpyDeviceToHost, ctx->stream));
+            const bool save = ctx->si_enable; ctx->si_enable = false;
+            ctx->jacobi_quad_exit = ctx->eigh_orth_quad_exit;                   // (the residual test below certifies what this returns)
+            const int st = jacobi_eigh_top(ctx, T, p, p, Dp, Zt, nullptr);      // rows of Zt = eigenvectors, ordered by |theta| (synchronises)
+            ctx->jacobi_quad_exit = 0.0;
+            ctx->si_enable = save;
+            CTM_TRY(st);
+            GemmDesc r1; r1.M = kk; r1.N = n; r1.K = p; r1.A = Zt; r1.sam = p; r1.sak = 1; r1.B = Q; r1.sbk = n; r1.sbn = 1; r1.C = X; r1.ldc = n;
+            CTM_TRY(gemm_f64(ctx, r1));
+            GemmDesc r2 = r1; r2.B = Y; r2.C = AX;
+            CTM_TRY(gemm_f64(ctx, r2));
+            CTM_LAUNCH(ctx, resid_rows_kernel, dim3((kk + 3) / 4), dim3(256), 0, (const double*)AX, (long long)n, (const double*)X, (long long)n,
+                       (const double*)Dp, kk, n, res);
+            CTM_HIP_CHECK(ctx, hipMemcpyAsync(h.data(), res, sizeof(double) * kk, hipMemcpyDeviceToHost, ctx->stream));
+            CTM_HIP_CHECK(ctx, hipMemcpyAsync(hd.data(), Dp, sizeof(double) * kk, hipMemcpyDeviceToHost, ctx->stream));
+            CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+            const double dev = *std::max_element(he.begin(), he.end());
+            const double lam0 = std::fabs(hd[0]), lamk = std::fabs(hd[kk - 1]);
+            const double worst = *std::max_element(h.begin(), h.begin() + kk);
+            if (ctx->jacobi_verbose) fprintf(stderr, "[eigh-orth] n=%d p=%d application %d: |QQ^T - I| = %.2e  max resid/|l0| = %.3e  |l_kk|/|l0| = %.3e\n", n, p, it + 1, dev, worst / std::max(lam0, 1e-300), lamk / std::max(lam0, 1e-300));
+            if (!(dev <= 1e-12) || !(lam0 > 0.0) || !(lamk > ctx->rank_tol * lam0)) return CTM_OK;
+            if (worst <= resid_tol(ctx, n) * lam0) {
+                CTM_TRY(row_dots(ctx, X, warm, kk, n, n, dots));
+                CTM_LAUNCH(ctx, signed_rows_kernel, dim3(256), dim3(256), 0, (const double*)X, (const double*)dots, 1, kk, n, AX);     // aligned with the previous vectors
+                CTM_HIP_CHECK(ctx, hipMemcpyAsync(warm, AX, sizeof(double) * (size_t)kk * n, hipMemcpyDeviceToDevice, ctx->stream));
+                CTM_LAUNCH(ctx, signed_rows_kernel, dim3(256), dim3(256), 0, (const double*)AX, (const double*)Dp, 1, k_out, n, Ut);
+                CTM_HIP_CHECK(ctx, hipMemcpyAsync(D, Dp, sizeof(double) * k_out, hipMemcpyDeviceToDevice, ctx->stream));
+                ctx->si_hits += 1; ctx->eigh_orth_hits += 1;
+                ctx->si_last_iters = it + 1; ctx->si_total_iters += it + 1;
+                *accepted = true;
+                return CTM_OK;
+            }
+        }
+        if (it == max_it) break;
+        CTM_TRY(orth(Y, it + 1 >= first_rr));           // the basis a Rayleigh-Ritz may use gets the full passes
+        std::swap(Q, Y);
+    }
+    ctx->eigh_orth_fails += 1;
+    return CTM_OK;
+}
+
 int jacobi_eigh_top(ctm_ctx* ctx, const double* A, int n, int k, double* D, double* Ut, double* warm) {
     if (n <= 0 || k <= 0 || k > n) { ctx->set_error("jacobi_eigh_top: bad n/k"); return CTM_ERR_BADARG; }
     ArenaScope scope(ctx);
@@ -3078,6 +3201,10 @@ int jacobi_eigh_top(ctm_ctx* ctx, const double* A, int n, int k, double* D, doub
             bool accepted = false;
             CTM_TRY(eigh_warm_verify(ctx, As, n, kk, k_out, warm, D, Ut, &accepted));
             if (accepted) return CTM_OK;
+            if (ctx->eigh_orth_iter) {
+                CTM_TRY(eigh_orth_iter(ctx, As, n, kk, k_out, warm, D, Ut, &accepted));
+                if (accepted) return CTM_OK;
+            }
         }
         double *S, *Uk, *Vk;
         CTM_TRY(arena_alloc(ctx, sizeof(double) * kk, (void**)&S));
