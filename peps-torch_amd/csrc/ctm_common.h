@@ -87,10 +87,11 @@ struct ctm_ctx {
     int svd_abs_accuracy = 1;          // full SVD with vectors (differentiable route): row pairs orthogonalised to tol * s_0 absolute (see tau_floor)
     int eigh_warm = 1;                 // symmetric problems with a warm basis: Rayleigh-Ritz in the warm subspace + deflated probe first
     long eigh_warm_hits = 0, eigh_warm_rejects = 0, eigh_probe_calls = 0;
+    int eigh_probe_orth_once = 1;      // ... the probe block is orthonormalised once (before its last application) instead of after each of the first two
     int eigh_warm_early_reject = 1;    // ... a subspace whose residual |Y - (Y Q^T) Q|_F already exceeds the threshold is refused before its Rayleigh-Ritz
     int eigh_orth_iter = 1;            // refused warm restart (the matrix moved): symmetric orthogonal iteration with Cholesky-QR steps and ONE Rayleigh-Ritz
     int eigh_orth_max = 9;             // ... applications before it gives up (the regular block iteration runs then)
-    double eigh_orth_quad_exit = 0.0;  // ... optional early exit of its small Jacobi eigensolver (see lz_quad_exit)
+    double eigh_orth_quad_exit = 1e-9; // ... early exit of its small Jacobi eigensolver (see lz_quad_exit; the residual test certifies what it returns)
     long eigh_orth_hits = 0, eigh_orth_fails = 0;
     // block Golub-Kahan-Lanczos for spectra that do not collapse inside a small block (svd_lanczos)
     bool lz_enable = true; int lz_min_k = 48; double lz_switch_steps = 6.0; double lz_last_resid = 1.0; long lz_hits = 0, lz_total_steps = 0;

@@ -1881,72 +1881,99 @@ __global__ __launch_bounds__(64) void chol64_inv_kernel(const double* G, double*
     if (i == 0) status[0] = pmin;
 }
 
+// One wave, register resident (see chol64_scaled_inv_kernel below for the scheme): a value another lane needs travels through
+// v_readlane, wave-wide maxima through DPP moves inside the rows of 16 lanes and four readlanes across them.
+__device__ __forceinline__ double lane_bcast(double v, int lane) {       // `lane` must be wave-uniform
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_move(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_max(double v) {                   // every lane receives the maximum over the 64 lanes
+    v = fmax(v, dpp_move<0xB1>(v));        // quad_perm [1,0,3,2]
+    v = fmax(v, dpp_move<0x4E>(v));        // quad_perm [2,3,0,1]
+    v = fmax(v, dpp_move<0x141>(v));       // row_half_mirror
+    v = fmax(v, dpp_move<0x140>(v));       // row_mirror: every lane of a row of 16 holds the row maximum
+    return fmax(fmax(lane_bcast(v, 0), lane_bcast(v, 16)), fmax(lane_bcast(v, 32), lane_bcast(v, 48)));
+}
+__device__ __forceinline__ double wave_sum(double v) {                   // every lane receives the sum over the 64 lanes (same value on all)
+    v += dpp_move<0xB1>(v);
+    v += dpp_move<0x4E>(v);
+    v += dpp_move<0x141>(v);
+    v += dpp_move<0x140>(v);
+    return (lane_bcast(v, 0) + lane_bcast(v, 16)) + (lane_bcast(v, 32) + lane_bcast(v, 48));
+}
+
 // Rank-revealing companion of chol64_inv_kernel: pivoted Cholesky of a 64 x 64 Gram matrix G = Z Z^T (lazy, left-looking: only the
 // pivot columns are ever formed), stopped at the first pivot below rel * (largest diagonal entry).  Output Mo (64 x 64, row-major):
 // rows k < rank hold row k of L_pp^-1 scattered to the pivot positions, so that Mo Z has orthonormal rows 0..rank-1 (Gram-Schmidt
-// of the pivot rows in pivot order) and zero rows beyond; status[0] = rank.  One wave; thread j owns row j of L.
+// of the pivot rows in pivot order) and zero rows beyond; status[0] = rank.  One wave; lane j keeps row j of L in registers (entry
+// t = pivot step t: the loops are fully unrolled, so the index is static) and reads the pivot row's entries from lane p by
+// v_readlane; G stays in LDS for the one row per step that is read.  (91 us -> 3x us against the LDS version: six ds_bpermute
+// rounds of the argmax and an LDS round trip per term were on the critical path of every step.)
 __global__ __launch_bounds__(64) void pivchol64_inv_kernel(const double* __restrict__ G, double rel, double* __restrict__ Mo, double* __restrict__ status) {
     constexpr int M = 64;
-    __shared__ double Lt[M][M];             // Lt[k][j]: entry of ORIGINAL row j in pivot step k (a wave reads a row: conflict free)
-    __shared__ double GX[M][M];             // G during the factorisation, then X = L_pp^-1
+    __shared__ double GS[M][M];
     const int j = threadIdx.x;
-    for (int r = 0; r < M; ++r) GX[r][j] = G[r * M + j];
+#pragma unroll 8
+    for (int r = 0; r < M; ++r) GS[r][j] = G[r * M + j];
     __syncthreads();
-    double d = GX[j][j];
+    double d = GS[j][j];
     bool chosen = false;
-    double d0 = 0.0;
-    int rank = 0, myperm = 0;               // thread k remembers the pivot of step k
+    double d0 = 0.0, rinv = 0.0;            // lane k: 1 / L_pp[k][k]
+    int rank = 0, myperm = 0;               // lane k remembers the pivot of step k
+    double L[M];
+    bool stop = false;                      // (no `break`: the loops must unroll completely for L[] and x[] to stay in registers)
+#pragma unroll
     for (int k = 0; k < M; ++k) {
-        double best = chosen ? -1.0 : d;
-        int who = j;
-        for (int off = 32; off > 0; off >>= 1) {
-            const double ob = __shfl_xor(best, off, 64);
-            const int ow = __shfl_xor(who, off, 64);
-            if (ob > best || (ob == best && ow < who)) { best = ob; who = ow; }
-        }
+        if (stop) continue;
+        const double cand = chosen ? -1.0 : d;
+        const double best = wave_max(cand);
         if (k == 0) d0 = best;
-        if (!(best > rel * d0) || !(best > 0.0)) break;           // uniform: every lane holds the same maximum
-        const int p = who;
-        double acc0 = GX[p][j], acc1 = 0.0;                       // G[j][p] (symmetric)
-        int t = 0;
-        for (; t + 8 <= k; t += 8) {
-            double a[8], b[8];
+        if (!(best > rel * d0) || !(best > 0.0)) { stop = true; continue; }     // uniform: every lane holds the same maximum
+        const int p = __builtin_amdgcn_readfirstlane(__ffsll((unsigned long long)__ballot(cand == best)) - 1);     // ties: the lowest index
+        double acc0 = GS[p][j], acc1 = 0.0;                       // G[j][p] (symmetric)
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { a[u] = Lt[t + u][j]; b[u] = Lt[t + u][p]; }
-#pragma unroll
-            for (int u = 0; u < 8; u += 2) { acc0 -= a[u] * b[u]; acc1 -= a[u + 1] * b[u + 1]; }
+        for (int t = 0; t < k; ++t) {
+            const double lp = lane_bcast(L[t], p);
+            if (t & 1) acc1 -= L[t] * lp; else acc0 -= L[t] * lp;
         }
-        for (; t < k; ++t) acc0 -= Lt[t][j] * Lt[t][p];
-        const double lkk = sqrt(best);
-        const double v = (j == p) ? lkk : (chosen ? 0.0 : (acc0 + acc1) / lkk);
-        Lt[k][j] = v;                                             // step k only reads steps < k
+        double rl = __builtin_amdgcn_rsq(best);
+        rl = rl * (1.5 - 0.5 * best * rl * rl);
+        rl = rl * (1.5 - 0.5 * best * rl * rl);
+        const double v = (j == p) ? best * rl : (chosen ? 0.0 : (acc0 + acc1) * rl);
+        L[k] = v;
         if (j == p) chosen = true; else if (!chosen) d -= v * v;
-        if (j == k) myperm = p;
+        if (j == k) { myperm = p; rinv = rl; }
         rank = k + 1;
-        __syncthreads();
     }
-    // X = L_pp^-1 with L_pp[r][t] = Lt[t][perm[r]] (lower triangular, rank x rank); thread c owns column c of X (stored in GX)
-    const int c = j;
-    for (int r = 0; r < rank; ++r) {
-        const int pr = __shfl(myperm, r, 64);
-        // the LDS reads do not depend on the accumulators: eight iterations' loads are issued together (two accumulator chains)
-        double acc0 = (r == c) ? 1.0 : 0.0, acc1 = 0.0;
-        int t = 0;
-        for (; t + 8 <= r; t += 8) {
-            double a[8], b[8];
+    // X = L_pp^-1 with L_pp[r][t] = L[t] of lane perm[r] (lower triangular, rank x rank); lane c builds column c
+    double x[M];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { a[u] = Lt[t + u][pr]; b[u] = GX[t + u][c]; }
+    for (int r = 0; r < M; ++r) {
+        if (r >= rank) { x[r] = 0.0; continue; }
+        const int pr = __builtin_amdgcn_readlane(myperm, r);
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
 #pragma unroll
-            for (int u = 0; u < 8; u += 2) { acc0 -= a[u] * b[u]; acc1 -= a[u + 1] * b[u + 1]; }
+        for (int t = 0; t < r; ++t) {
+            const double l = lane_bcast(L[t], pr);
+            if ((t & 3) == 0) s0 += l * x[t]; else if ((t & 3) == 1) s1 += l * x[t]; else if ((t & 3) == 2) s2 += l * x[t]; else s3 += l * x[t];
         }
-        for (; t < r; ++t) acc0 -= Lt[t][pr] * GX[t][c];
-        GX[r][c] = (r >= c && c < rank) ? (acc0 + acc1) / Lt[r][pr] : 0.0;
+        const double rr = lane_bcast(rinv, r);
+        x[r] = j < r ? -((s0 + s1) + (s2 + s3)) * rr : (j == r ? rr : 0.0);
     }
-    __syncthreads();
-    // Mo[k][perm[t]] = X[k][t]: thread j zeroes column j, then (j < rank) fills column perm[j]
+    // Mo[k][perm[t]] = X[k][t]: lane j zeroes column j, then (j < rank) fills column perm[j]
+#pragma unroll 8
     for (int k = 0; k < M; ++k) Mo[k * M + j] = 0.0;
     __syncthreads();
-    if (j < rank) for (int k = 0; k < rank; ++k) Mo[k * M + myperm] = GX[k][j];
+    if (j < rank) {
+#pragma unroll
+        for (int k = 0; k < M; ++k) if (k < rank) Mo[k * M + myperm] = x[k];
+    }
     if (j == 0) status[0] = (double)rank;
 }
 
@@ -2008,11 +2035,6 @@ int orthonormalise_block(ctm_ctx* ctx, double* W, int rows, int n, double* norms
 //   and *flag3 is set: a third pass then finishes.  mode 1: plain.  mode 2 (third pass): returns at once unless *flag3.
 // status[0] = smallest pivot of the accepted factorisation, [1] = smallest, [2] = largest row norm.  Nothing is decided on the
 // host here: the caller reads the status words of all its steps at its next host synchronisation.
-__device__ __forceinline__ double lane_bcast(double v, int lane) {       // `lane` must be wave-uniform
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
-    return __hiloint2double(hi, lo);
-}
-
 __global__ __launch_bounds__(64) void chol64_scaled_inv_kernel(const double* __restrict__ G, double* __restrict__ out, double* __restrict__ status,
                                                                int* __restrict__ flag3, int mode) {
     constexpr int M = 64;
@@ -2847,23 +2869,22 @@ __global__ __launch_bounds__(64) void sym64_lmax_kernel(const double* __restrict
     double xi = 1.0 + 0.37 * (double)((i * 29) % 64) / 64.0;       // generic positive start
     double est = 0.0;
     for (int it = 0; it <= iters; ++it) {
-        double q = xi * xi;
-        for (int off = 32; off > 0; off >>= 1) q += __shfl_xor(q, off, 64);
-        const double nrm = sqrt(q);
-        if (!(nrm > 0.0)) break;
-        const double xn = xi / nrm;
+        const double q = wave_sum(xi * xi);                     // (DPP moves + four readlanes: no ds_bpermute round trips on the critical path)
+        if (!(q > 0.0)) break;
+        double rn = __builtin_amdgcn_rsq(q);
+        rn = rn * (1.5 - 0.5 * q * rn * rn);
+        rn = rn * (1.5 - 0.5 * q * rn * rn);
+        const double xn = xi * rn;
         double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
 #pragma unroll
         for (int j = 0; j < 64; j += 4) {                       // x_j of lane j by lane broadcast (compile-time lane: v_readlane), no LDS round trip
-            a0 += row[j] * __shfl(xn, j, 64); a1 += row[j + 1] * __shfl(xn, j + 1, 64);
-            a2 += row[j + 2] * __shfl(xn, j + 2, 64); a3 += row[j + 3] * __shfl(xn, j + 3, 64);
+            a0 += row[j] * lane_bcast(xn, j); a1 += row[j + 1] * lane_bcast(xn, j + 1);
+            a2 += row[j + 2] * lane_bcast(xn, j + 2); a3 += row[j + 3] * lane_bcast(xn, j + 3);
         }
         xi = (a0 + a1) + (a2 + a3);                             // (G x)_i
         if (it == iters) {
-            double rho = xn * xi;
-            for (int off = 32; off > 0; off >>= 1) rho += __shfl_xor(rho, off, 64);
-            double r2 = (xi - rho * xn) * (xi - rho * xn);
-            for (int off = 32; off > 0; off >>= 1) r2 += __shfl_xor(r2, off, 64);
+            const double rho = wave_sum(xn * xi);
+            const double r2 = wave_sum((xi - rho * xn) * (xi - rho * xn));
             est = rho + sqrt(r2);
         }
     }
@@ -2912,14 +2933,9 @@ static int eigh_warm_verify(ctm_ctx* ctx, const double* As, int n, int kk, int k
     double *norms, *inv, *Q, *Y, *H, *Dk, *Th, *Q2, *Y2, *res;
     CTM_TRY(arena_alloc(ctx, sizeof(double) * std::max(kk, pb), (void**)&norms));
     CTM_TRY(arena_alloc(ctx, sizeof(double) * std::max(kk, pb), (void**)&inv));
-    std::vector<double> h(std::max(kk, pb)), hd(kk);
-    CTM_TRY(row_norms(ctx, warm, kk, n, n, norms));
-    CTM_HIP_CHECK(ctx, hipMemcpyAsync(h.data(), norms, sizeof(double) * kk, hipMemcpyDeviceToHost, ctx->stream));
-    CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-    for (int i = 0; i < kk; ++i) if (!(std::fabs(h[i] - 1.0) < 1e-6)) {
-        if (ctx->jacobi_verbose) fprintf(stderr, "[eigh-warm] n=%d kk=%d: workspace row %d has norm %.3e (no complete previous subspace)\n", n, kk, i, h[i]);
-        return CTM_OK;
-    }
+    std::vector<double> h(std::max(kk, pb)), hd(kk), hn(kk);
+    CTM_TRY(row_norms(ctx, warm, kk, n, n, norms));       // read back with the residuals below (one host synchronisation for both)
+    CTM_HIP_CHECK(ctx, hipMemcpyAsync(hn.data(), norms, sizeof(double) * kk, hipMemcpyDeviceToHost, ctx->stream));
     CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)kk * n, (void**)&Q));
     CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)kk * n, (void**)&Y));
     CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)kk * kk, (void**)&H));
@@ -2939,6 +2955,10 @@ static int eigh_warm_verify(ctm_ctx* ctx, const double* As, int n, int kk, int k
     CTM_HIP_CHECK(ctx, hipMemcpyAsync(h.data(), res, sizeof(double) * kk, hipMemcpyDeviceToHost, ctx->stream));
     CTM_HIP_CHECK(ctx, hipMemcpyAsync(hd.data(), Dk, sizeof(double) * kk, hipMemcpyDeviceToHost, ctx->stream));
     CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < kk; ++i) if (!(std::fabs(hn[i] - 1.0) < 1e-6)) {
+        if (ctx->jacobi_verbose) fprintf(stderr, "[eigh-warm] n=%d kk=%d: workspace row %d has norm %.3e (no complete previous subspace)\n", n, kk, i, hn[i]);
+        return CTM_OK;
+    }
     // The last kept rows may not be eigenvectors: when the kk-th |lambda| is shared by a pair of opposite sign (or a multiplet) that
     // the workspace cuts, its last row is a mixture.  `ke` = the leading rows that are (at least the k_out the caller uses plus one);
     // only those are deflated by the probe and compared with it.
@@ -3004,6 +3024,10 @@ static int eigh_warm_verify(ctm_ctx* ctx, const double* As, int n, int kk, int k
         std::swap(Z, Zn);
         CTM_TRY(project_out(ctx, Z, pb, n, Q2, ke, G, 1));
         if (q == 2) break;
+        // (an orthonormalisation does not change the span: the rows only have to be orthonormal before the LAST application, whose
+        //  Gram matrix is read as Ritz values; after the first application the rows stay as they are -- the pivoted factorisation
+        //  below is rank revealing relative to the largest pivot, and the direction the test is after is the dominant one)
+        if (q == 0 && ctx->eigh_probe_orth_once) continue;
         // orthonormal basis of the significant part of the row space: Gram matrix, pivoted Cholesky stopped at 1e-10 of the largest
         // pivot (rank revealing: the rows of a probe of a fast decaying spectrum are numerically dependent), rows <- L_pp^-1 (pivot rows)
         GemmDesc go; go.M = pb; go.N = pb; go.K = n; go.A = Z; go.sam = n; go.sak = 1; go.B = Z; go.sbk = 1; go.sbn = n; go.C = G64; go.ldc = pb;

@@ -53,7 +53,24 @@ int main() {
     }
     {
         const double t = time_us([&] { hipLaunchKernelGGL(pivchol64_inv_kernel, dim3(1), dim3(64), 0, 0, (const double*)dG, 1e-10, dOut, dStatus); }, 100);
-        printf("pivchol64_inv_kernel: %.1f us\n", t);
+        std::vector<double> Mo(M * M); double st;
+        hipMemcpy(Mo.data(), dOut, sizeof(double) * M * M, hipMemcpyDeviceToHost); hipMemcpy(&st, dStatus, sizeof(st), hipMemcpyDeviceToHost);
+        const int rank = (int)st;
+        double dev = 0;
+        for (int i = 0; i < M; ++i) for (int j2 = 0; j2 < M; ++j2) {
+            double s2 = 0;
+            for (int a = 0; a < M; ++a) { double t2 = 0; for (int b = 0; b < M; ++b) t2 += G[a * M + b] * Mo[j2 * M + b]; s2 += Mo[i * M + a] * t2; }
+            dev = std::max(dev, std::fabs(s2 - ((i == j2 && i < rank) ? 1.0 : 0.0)));
+        }
+        printf("pivchol64_inv_kernel: %.1f us   rank %d   |Mo G Mo^T - I_rank| = %.2e\n", t, rank, dev);
+    }
+    {
+        const double t = time_us([&] { hipLaunchKernelGGL(sym64_lmax_kernel, dim3(1), dim3(64), 0, 0, (const double*)dG, 48, dStatus); }, 100);
+        double o[2]; hipMemcpy(o, dStatus, sizeof(o), hipMemcpyDeviceToHost);
+        // reference: power iteration on the host
+        std::vector<double> x(M, 1.0), y(M); double lam = 0;
+        for (int it = 0; it < 2000; ++it) { double nn = 0; for (int i = 0; i < M; ++i) { y[i] = 0; for (int k = 0; k < M; ++k) y[i] += G[i * M + k] * x[k]; nn += y[i] * y[i]; } lam = std::sqrt(nn); for (int i = 0; i < M; ++i) x[i] = y[i] / lam; }
+        printf("sym64_lmax_kernel: %.1f us   |G|_F = %.6e  estimate %.12e  (lambda_max %.12e)\n", t, o[0], o[1], lam);
     }
     for (int which = 0; which < 2; ++which)
         for (int sweeps = 1; sweeps <= 3; ++sweeps) {
