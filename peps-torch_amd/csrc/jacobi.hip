@@ -349,8 +349,14 @@ __global__ __launch_bounds__(1024 / BPT) void small_eig64_kernel(SmallEigParams 
     __syncthreads();
     const int k2 = tid & 31, kb = tid >> 5;          // column pair; first of the BPT row pairs kb, kb + KS, ...
     int par = 0;
+#ifdef CTM_KERNEL_CLOCKS
+    long long ck_load = 0, ck_cs = 0, ck_upd = 0, ck_bar = 0;
+#endif
     for (int sweep = 0; sweep < p.max_sweeps; ++sweep) {
         for (int r = 0; r < M - 1; ++r) {
+#ifdef CTM_KERNEL_CLOCKS
+            const long long c0 = clock64();
+#endif
             const double (*S)[M + 1] = Wb[par];
             double (*D)[M + 1] = Wb[par ^ 1];
             int p2, q2;
@@ -365,8 +371,14 @@ __global__ __launch_bounds__(1024 / BPT) void small_eig64_kernel(SmallEigParams 
                 b00[u] = S[p1[u]][p2]; b01[u] = S[p1[u]][q2]; b10[u] = S[q1[u]][p2]; b11[u] = S[q1[u]][q2];
                 jp0[u] = Jm[k1][p2]; jq0[u] = Jm[k1][q2]; jp1[u] = Jm[k1 + 32][p2]; jq1[u] = Jm[k1 + 32][q2];
             }
+#ifdef CTM_KERNEL_CLOCKS
+            __builtin_amdgcn_s_waitcnt(0); const long long c1 = clock64();
+#endif
             double c2, s2; bool r2;
             jacobi_cs(a2, d2, g2, p.tol, p.tau2, p.tau_both, c2, s2, r2);
+#ifdef CTM_KERNEL_CLOCKS
+            __builtin_amdgcn_sched_barrier(0); const long long c2k = clock64(); __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
             for (int u = 0; u < BPT; ++u) {
                 const int k1 = kb + u * KS;
@@ -384,7 +396,14 @@ __global__ __launch_bounds__(1024 / BPT) void small_eig64_kernel(SmallEigParams 
                 if (r2 && k1 == k2) rot_flag = 1;
             }
             par ^= 1;
+#ifdef CTM_KERNEL_CLOCKS
+            __builtin_amdgcn_s_waitcnt(0); const long long c3 = clock64();
+#endif
             __syncthreads();
+#ifdef CTM_KERNEL_CLOCKS
+            const long long c4 = clock64();
+            ck_load += c1 - c0; ck_cs += c2k - c1; ck_upd += c3 - c2k; ck_bar += c4 - c3;
+#endif
         }
         const int any = rot_flag;
         __syncthreads();
@@ -392,6 +411,9 @@ __global__ __launch_bounds__(1024 / BPT) void small_eig64_kernel(SmallEigParams 
         if (tid == 0) rot_flag = 0;
         __syncthreads();
     }
+#ifdef CTM_KERNEL_CLOCKS
+    if (tid == 0) { p.stat_rel[4] = ck_load; p.stat_rel[5] = ck_cs; p.stat_rel[6] = ck_upd; p.stat_rel[7] = ck_bar; }
+#endif
     const double (*W)[M + 1] = Wb[par];
     if (tid < M) {
         const double d = W[tid][tid];
@@ -2925,8 +2947,9 @@ __global__ void embed_rows_kernel(const double* __restrict__ re, const double* _
 // x + iy) of eigh_warm_verify_c: only the keep-the-vectors route is taken (a rotation inside the doubly degenerate real spectrum
 // would not come back as complex vectors), the workspace is not written and D receives all kk Rayleigh quotients.
 static int eigh_warm_verify(ctm_ctx* ctx, const double* As, int n, int kk, int k_out, double* warm, double* D, double* Ut, bool* accepted,
-                            bool embedded = false) {
+                            bool embedded = false, bool* norms_ok = nullptr) {
     *accepted = false;
+    if (norms_ok) *norms_ok = false;
     if (kk > n / 4 || kk < 2) return CTM_OK;
     ArenaScope scope(ctx);
     const int pb = 64;
@@ -2959,6 +2982,7 @@ static int eigh_warm_verify(ctm_ctx* ctx, const double* As, int n, int kk, int k
         if (ctx->jacobi_verbose) fprintf(stderr, "[eigh-warm] n=%d kk=%d: workspace row %d has norm %.3e (no complete previous subspace)\n", n, kk, i, hn[i]);
         return CTM_OK;
     }
+    if (norms_ok) *norms_ok = true;
     // The last kept rows may not be eigenvectors: when the kk-th |lambda| is shared by a pair of opposite sign (or a multiplet) that
     // the workspace cuts, its last row is a mixture.  `ke` = the leading rows that are (at least the k_out the caller uses plus one);
     // only those are deflated by the probe and compared with it.
@@ -3104,7 +3128,8 @@ static int eigh_warm_verify_c(ctm_ctx* ctx, const double* Asr, const double* Asi
 // Q not orthonormal to 1e-12, no acceptance after eigh_orth_max applications -- returns with *accepted = false and the regular route runs.
 // Returned gauge: rows aligned with the previous vectors (warm_i <- sign<x_i, warm_i> x_i, u_i = sign(theta_i) warm_i), as the
 // regular route and the warm restart return them.
-static int eigh_orth_iter(ctm_ctx* ctx, const double* As, int n, int kk, int k_out, double* warm, double* D, double* Ut, bool* accepted) {
+static int eigh_orth_iter(ctm_ctx* ctx, const double* As, int n, int kk, int k_out, double* warm, double* D, double* Ut, bool* accepted,
+                          bool warm_checked) {
     *accepted = false;
     int p = kk + std::max(32, kk / 2);
     p = ((p + 63) / 64) * 64;
@@ -3130,14 +3155,17 @@ static int eigh_orth_iter(ctm_ctx* ctx, const double* As, int n, int kk, int k_o
     CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)p * p, (void**)&E));
     CTM_TRY(arena_alloc(ctx, sizeof(double) * kk, (void**)&dots));
     std::vector<double> h(p), hd(kk), he(p);
-    CTM_TRY(row_norms(ctx, warm, kk, n, n, norms));
-    CTM_HIP_CHECK(ctx, hipMemcpyAsync(h.data(), norms, sizeof(double) * kk, hipMemcpyDeviceToHost, ctx->stream));
-    CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-    for (int i = 0; i < kk; ++i) if (!(std::fabs(h[i] - 1.0) < 1e-6)) return CTM_OK;          // no complete previous subspace
+    if (!warm_checked) {                     // (the warm restart that has just refused the subspace has looked at the row norms already)
+        CTM_TRY(row_norms(ctx, warm, kk, n, n, norms));
+        CTM_HIP_CHECK(ctx, hipMemcpyAsync(h.data(), norms, sizeof(double) * kk, hipMemcpyDeviceToHost, ctx->stream));
+        CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        for (int i = 0; i < kk; ++i) if (!(std::fabs(h[i] - 1.0) < 1e-6)) return CTM_OK;          // no complete previous subspace
+    }
+    // start: the previous vectors and pseudo-random guard rows as they are -- the first orthonormalisation (after the first
+    // application) is a Gram-Schmidt in this order, which takes the previous vectors out of the guard rows anyway
     CTM_HIP_CHECK(ctx, hipMemcpyAsync(Q, warm, sizeof(double) * (size_t)kk * n, hipMemcpyDeviceToDevice, ctx->stream));
     double* Rn = Q + (size_t)kk * n;
     CTM_LAUNCH(ctx, hash_fill_kernel, dim3(1024), dim3(256), 0, Rn, pr, n, (long long)n, 0x1234567ULL);
-    CTM_TRY(project_out(ctx, Rn, pr, n, Q, kk, Gp, 1));
     auto chol_pass = [&](double* Wb, int mode) -> int {
         GemmDesc g; g.M = 64; g.N = 64; g.K = n; g.A = Wb; g.sam = n; g.sak = 1; g.B = Wb; g.sbk = 1; g.sbn = n; g.C = G; g.ldc = 64;
         if (mode == 2) g.skip_all = flag3;
@@ -3223,10 +3251,11 @@ int jacobi_eigh_top(ctm_ctx* ctx, const double* A, int n, int k, double* D, doub
         const int kk = std::min(n, k + 8), k_out = k;
         if (warm && ctx->eigh_warm) {
             bool accepted = false;
-            CTM_TRY(eigh_warm_verify(ctx, As, n, kk, k_out, warm, D, Ut, &accepted));
+            bool norms_ok = false;
+            CTM_TRY(eigh_warm_verify(ctx, As, n, kk, k_out, warm, D, Ut, &accepted, false, &norms_ok));
             if (accepted) return CTM_OK;
             if (ctx->eigh_orth_iter) {
-                CTM_TRY(eigh_orth_iter(ctx, As, n, kk, k_out, warm, D, Ut, &accepted));
+                CTM_TRY(eigh_orth_iter(ctx, As, n, kk, k_out, warm, D, Ut, &accepted, norms_ok));
                 if (accepted) return CTM_OK;
             }
         }

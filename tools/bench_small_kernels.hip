@@ -33,10 +33,10 @@ int main() {
     double *dG, *dGd, *dOut, *dStatus, *dJ; int *dFlag, *dFlags; unsigned long long* dStat;
     hipMalloc(&dG, sizeof(double) * M * M); hipMalloc(&dGd, sizeof(double) * M * M); hipMalloc(&dOut, sizeof(double) * M * M);
     hipMalloc(&dStatus, sizeof(double) * 16); hipMalloc(&dFlag, sizeof(int) * 4); hipMalloc(&dJ, sizeof(double) * M * M);
-    hipMalloc(&dFlags, sizeof(int) * 4); hipMalloc(&dStat, sizeof(unsigned long long) * 4);
+    hipMalloc(&dFlags, sizeof(int) * 4); hipMalloc(&dStat, sizeof(unsigned long long) * 16);
     hipMemcpy(dG, G.data(), sizeof(double) * M * M, hipMemcpyHostToDevice);
     hipMemcpy(dGd, Gd.data(), sizeof(double) * M * M, hipMemcpyHostToDevice);
-    hipMemset(dFlag, 0, sizeof(int) * 4); hipMemset(dStat, 0, sizeof(unsigned long long) * 4);
+    hipMemset(dFlag, 0, sizeof(int) * 4); hipMemset(dStat, 0, sizeof(unsigned long long) * 16);
     for (int mode = 0; mode < 2; ++mode) {
         const double t = time_us([&] { hipLaunchKernelGGL(chol64_scaled_inv_kernel, dim3(1), dim3(64), 0, 0, (const double*)dG, dOut, dStatus, dFlag, mode); }, 200);
         std::vector<double> L(M * M); double st[3];
@@ -78,7 +78,9 @@ int main() {
             sp.G = which ? dGd : dG; sp.nsplit = 1; sp.split_stride = 0; sp.J = dJ; sp.m = 64; sp.tol = 1e-15; sp.max_sweeps = sweeps;
             sp.tau2 = 0.0; sp.tau_both = 0; sp.stat_rel = dStat; sp.stat_abs = dStat + 1; sp.flags = dFlags;
             const double t = time_us([&] { hipLaunchKernelGGL(small_eig64_kernel<2>, dim3(1), dim3(512), 0, 0, sp); }, 100);
-            printf("small_eig64_kernel<2> %s Gram, max_sweeps %d: %.1f us\n", which ? "nearly diagonal" : "generic", sweeps, t);
+            long long ck[4]; hipMemcpy(ck, dStat + 4, sizeof(ck), hipMemcpyDeviceToHost);
+            printf("small_eig64_kernel<2> %s Gram, max_sweeps %d: %.1f us   clocks per round (wave 0): loads %.0f, rotation %.0f, updates %.0f, barrier %.0f\n",
+                   which ? "nearly diagonal" : "generic", sweeps, t, ck[0] / (63.0 * sweeps), ck[1] / (63.0 * sweeps), ck[2] / (63.0 * sweeps), ck[3] / (63.0 * sweeps));
         }
     return 0;
 }
