@@ -166,6 +166,76 @@ def test_warm_restart_on_a_moved_matrix_falls_back_and_stays_exact(eng):
     assert float((((A + E).cuda() @ U) - U * D).abs().max()) < 1e-12
 
 
+def test_moved_matrix_takes_the_orthogonal_iteration_and_equals_the_regular_route(eng):
+    """A refused warm restart (the matrix moved) goes to the symmetric orthogonal iteration (Cholesky-QR steps, one Rayleigh-Ritz):
+    same eigenpairs as the regular block iteration (option off) and as LAPACK, columns in the gauge of the previous call."""
+    n, chi = 1024, 64
+    lam = (0.85 ** torch.arange(n, dtype=torch.float64)) * torch.where(torch.arange(n) % 4 == 2, -1.0, 1.0)
+    A, _ = _sym_with_spectrum(n, lam, 21)
+    g = torch.Generator().manual_seed(22)
+    E = torch.randn(n, n, generator=g, dtype=torch.float64); E = E + E.T
+    E = E / torch.linalg.matrix_norm(E, 2)              # |E|_2 = 1: eps below is the size of the move (gap at the 64th eigenvalue: 5e-6)
+    res = {}
+    for orth in (1, 0):
+        eng.set_option("eigh_orth_iter", orth)
+        basis = eng.warm_basis_c4v(chi, n)
+        D0, U0 = eng.truncated_eigh(A.cuda(), chi, basis=basis)
+        eng.timers(reset=True)
+        outs = [(D0, U0)]
+        for eps in (3e-7, 1e-8, 1e-10):
+            outs.append(eng.truncated_eigh((A + eps * E).cuda(), chi, basis=basis))
+        res[orth] = (outs, eng.stat("eigh_orth_hits"), eng.stat("eigh_warm_hits"))
+    eng.set_option("eigh_orth_iter", 1)
+    assert res[1][1] == 3 and res[0][1] == 0 and res[1][2] == 0
+    for k, eps in enumerate((3e-7, 1e-8, 1e-10)):
+        M = A + eps * E
+        w = torch.linalg.eigvalsh(M)
+        w = w[torch.argsort(w.abs(), descending=True)][:chi]
+        (D1, U1), (D2, U2) = res[1][0][k + 1], res[0][0][k + 1]
+        assert float((D1.cpu() - w).abs().max()) < 1e-12 and float((D1 - D2).abs().max()) < 1e-12
+        assert float(((M.cuda() @ U1) - U1 * D1).abs().max()) < 1e-12
+        assert float((U1.T @ U1 - torch.eye(chi, device=U1.device, dtype=U1.dtype)).abs().max()) < 1e-12
+        # same vectors as the regular route (well separated eigenvalues: 0.85 ratio) and no sign flips against the previous call
+        assert float((U1 - U2).abs().max()) < 1e-8
+        assert float((U1 * res[1][0][k][1]).sum(0).min()) > 0.99
+
+
+def test_orthogonal_iteration_then_stationary_restart(eng):
+    """The workspace the orthogonal iteration leaves is the one the warm restart accepts once the matrix stops moving."""
+    n, chi = 768, 48
+    lam = (0.8 ** torch.arange(n, dtype=torch.float64)) * torch.where(torch.arange(n) % 3 == 1, -1.0, 1.0)
+    A, _ = _sym_with_spectrum(n, lam, 31)
+    g = torch.Generator().manual_seed(32)
+    E = torch.randn(n, n, generator=g, dtype=torch.float64); E = E + E.T
+    E = 1e-8 * E / torch.linalg.matrix_norm(E, 2)          # (the 57 kept |lambda| go down to 3e-6)
+    basis = eng.warm_basis_c4v(chi, n)
+    eng.truncated_eigh(A.cuda(), chi, basis=basis)
+    eng.timers(reset=True)
+    D1, U1 = eng.truncated_eigh((A + E).cuda(), chi, basis=basis)
+    assert eng.stat("eigh_orth_hits") == 1 and eng.stat("eigh_warm_hits") == 0
+    outs = [eng.truncated_eigh((A + E).cuda(), chi, basis=basis) for _ in range(3)]
+    assert eng.stat("eigh_warm_hits") >= 2 and eng.stat("eigh_orth_hits") <= 2
+    for D, U in outs:
+        assert float((D - D1).abs().max()) < 1e-13 and float((U - U1).abs().max()) < 1e-7
+
+
+def test_orthogonal_iteration_declines_a_numerically_low_rank_block(eng):
+    """Fewer significant eigenvalues than the iteration's block: it steps aside (no acceptance) and the regular route returns the pairs."""
+    n, chi = 768, 48
+    lam = torch.zeros(n, dtype=torch.float64); lam[:40] = 0.7 ** torch.arange(40, dtype=torch.float64)
+    A, _ = _sym_with_spectrum(n, lam, 41)
+    g = torch.Generator().manual_seed(42)
+    v = torch.randn(n, 1, generator=g, dtype=torch.float64); E = 1e-4 * (v @ v.T) / float(v.T @ v)
+    basis = eng.warm_basis_c4v(chi, n)
+    eng.truncated_eigh(A.cuda(), chi, basis=basis)
+    eng.timers(reset=True)
+    D, U = eng.truncated_eigh((A + E).cuda(), chi, basis=basis)
+    assert eng.stat("eigh_orth_hits") == 0
+    w = torch.linalg.eigvalsh(A + E)
+    w = w[torch.argsort(w.abs(), descending=True)][:chi]
+    assert float((D.cpu()[:41] - w[:41]).abs().max()) < 1e-12
+
+
 def test_c4v_run_with_and_without_the_warm_restart_agree(eng):
     """20 moves of a random C4v state (converges after ~7): the restart path takes over once the enlarged corner is stationary; corner
     spectrum and energy equal those of the run with the restart switched off."""
