@@ -13,3 +13,6 @@ python bench.py > gpurun_out/bench_final.json 2> gpurun_out/bench_final.err
 python bench.py --steps 20 --warmup 5 --no-other-configs --no-energy --no-cpu-baseline > gpurun_out/bench_20steps.json 2>/dev/null
 python bench.py --config c4v_D4_chi64 > gpurun_out/bench_c4v_final.json 2>/dev/null
 tail -c 600 gpurun_out/bench_final.json
+# latency-bound C4v path: kernel timeline of one moving sweep, and the single-workgroup kernels alone (tools/build_bench_small.sh first)
+bash tools/trace_sweep.sh c4v --config c4v_D4_chi64 --no-energy --no-other-configs --no-cpu-baseline --steps 12 --warmup 3 > /dev/null 2>&1
+[ -x tools/bin/bench_small_kernels ] && timeout 120 tools/bin/bench_small_kernels > gpurun_out/bench_small_kernels.txt 2>&1
