@@ -369,7 +369,9 @@ __global__ __launch_bounds__(1024 / BPT) void small_eig64_kernel(SmallEigParams 
                 const int k1 = kb + u * KS;
                 rr_pair64(r, k1, p1[u], q1[u]);
                 b00[u] = S[p1[u]][p2]; b01[u] = S[p1[u]][q2]; b10[u] = S[q1[u]][p2]; b11[u] = S[q1[u]][q2];
+#ifndef CTM_EIG64_SKIP_J      // (timing experiment of tools/bench_small_kernels.hip: the eigenvector accumulation left out)
                 jp0[u] = Jm[k1][p2]; jq0[u] = Jm[k1][q2]; jp1[u] = Jm[k1 + 32][p2]; jq1[u] = Jm[k1 + 32][q2];
+#endif
             }
 #ifdef CTM_KERNEL_CLOCKS
             __builtin_amdgcn_s_waitcnt(0); const long long c1 = clock64();
@@ -389,10 +391,12 @@ __global__ __launch_bounds__(1024 / BPT) void small_eig64_kernel(SmallEigParams 
                 const double t10 = c2 * b10[u] - s2 * b11[u], t11 = s2 * b10[u] + c2 * b11[u];
                 D[p1[u]][p2] = c1 * t00 - s1 * t10; D[p1[u]][q2] = c1 * t01 - s1 * t11;
                 D[q1[u]][p2] = s1 * t00 + c1 * t10; D[q1[u]][q2] = s1 * t01 + c1 * t11;
+#ifndef CTM_EIG64_SKIP_J
                 if (r2) {
                     Jm[k1][p2] = c2 * jp0[u] - s2 * jq0[u]; Jm[k1][q2] = s2 * jp0[u] + c2 * jq0[u];
                     Jm[k1 + 32][p2] = c2 * jp1[u] - s2 * jq1[u]; Jm[k1 + 32][q2] = s2 * jp1[u] + c2 * jq1[u];
                 }
+#endif
                 if (r2 && k1 == k2) rot_flag = 1;
             }
             par ^= 1;
@@ -2947,9 +2951,10 @@ __global__ void embed_rows_kernel(const double* __restrict__ re, const double* _
 // x + iy) of eigh_warm_verify_c: only the keep-the-vectors route is taken (a rotation inside the doubly degenerate real spectrum
 // would not come back as complex vectors), the workspace is not written and D receives all kk Rayleigh quotients.
 static int eigh_warm_verify(ctm_ctx* ctx, const double* As, int n, int kk, int k_out, double* warm, double* D, double* Ut, bool* accepted,
-                            bool embedded = false, bool* norms_ok = nullptr) {
+                            bool embedded = false, bool* norms_ok = nullptr, double* moved = nullptr) {
     *accepted = false;
     if (norms_ok) *norms_ok = false;
+    if (moved) *moved = 0.0;
     if (kk > n / 4 || kk < 2) return CTM_OK;
     ArenaScope scope(ctx);
     const int pb = 64;
@@ -3011,6 +3016,7 @@ static int eigh_warm_verify(ctm_ctx* ctx, const double* As, int n, int kk, int k
             double fro2 = 0.0, l0 = 0.0;
             for (int i = 0; i < kk; ++i) { fro2 += h[i] * h[i]; l0 = std::max(l0, std::fabs(hd[i])); }
             const double thr1 = 2.0 * resid_tol(ctx, n) * l0;            // (l0 from the Rayleigh quotients of the rows as they are: factor 2 of slack)
+            if (moved && l0 > 0.0) *moved = std::sqrt(fro2) / l0;
             if (!(fro2 <= (double)kk * thr1 * thr1)) {
                 if (ctx->jacobi_verbose) fprintf(stderr, "[eigh-warm] n=%d kk=%d: subspace residual |R|_F / |l0| = %.3e (not invariant)\n", n, kk, std::sqrt(fro2) / std::max(l0, 1e-300));
                 return CTM_OK;
@@ -3129,7 +3135,7 @@ static int eigh_warm_verify_c(ctm_ctx* ctx, const double* Asr, const double* Asi
 // Returned gauge: rows aligned with the previous vectors (warm_i <- sign<x_i, warm_i> x_i, u_i = sign(theta_i) warm_i), as the
 // regular route and the warm restart return them.
 static int eigh_orth_iter(ctm_ctx* ctx, const double* As, int n, int kk, int k_out, double* warm, double* D, double* Ut, bool* accepted,
-                          bool warm_checked) {
+                          bool warm_checked, double moved) {
     *accepted = false;
     int p = kk + std::max(32, kk / 2);
     p = ((p + 63) / 64) * 64;
@@ -3187,10 +3193,20 @@ static int eigh_orth_iter(ctm_ctx* ctx, const double* As, int n, int kk, int k_o
         }
         return CTM_OK;
     };
-    const int first_rr = 3, max_it = std::max(first_rr, ctx->eigh_orth_max);
+    // Where to look first: `moved` = |R|_F / |l0| of the previous subspace on this matrix (eigh_warm_verify), the residual contracts by
+    // roughly |lambda_{p+1} / lambda_kk| per application -- 0.005 .. 0.01 measured on the C4v corner; 0.01 assumed until a look has
+    // measured it -- so a subspace that moved by 4e-3 is looked at after six applications instead of after four AND six (a
+    // Rayleigh-Ritz costs as much as three applications).  Never before the fourth application (the `sound` rule).
+    const int min_rr = 3, max_it = std::max(min_rr, ctx->eigh_orth_max);
+    const double tol = resid_tol(ctx, n);
+    int next_rr = min_rr;
+    if (moved > 0.0 && ctx->eigh_orth_predict) {
+        const int need = (int)std::ceil(std::log(0.5 * tol / std::min(moved, 1.0)) / std::log(1e-2));      // applications
+        next_rr = std::min(max_it, std::max(min_rr, need - 1));
+    }
     for (int it = 0; it <= max_it; ++it) {
         CTM_TRY(rows_times(ctx, Q, n, p, n, n, As, false, Y, n));       // Y = Q A: application it + 1
-        if (it >= first_rr && ((it - first_rr) % 2 == 0 || it == max_it)) {
+        if (it >= next_rr || it == max_it) {
             GemmDesc gt; gt.M = p; gt.N = p; gt.K = n; gt.A = Y; gt.sam = n; gt.sak = 1; gt.B = Q; gt.sbk = 1; gt.sbn = n; gt.C = T; gt.ldc = p;
             CTM_TRY(gemm_f64(ctx, gt));                                  // T = Y Q^T
             GemmDesc ge; ge.M = p; ge.N = p; ge.K = n; ge.A = Q; ge.sam = n; ge.sak = 1; ge.B = Q; ge.sbk = 1; ge.sbn = n; ge.C = E; ge.ldc = p;
@@ -3218,7 +3234,7 @@ static int eigh_orth_iter(ctm_ctx* ctx, const double* As, int n, int kk, int k_o
             const double worst = *std::max_element(h.begin(), h.begin() + kk);
             if (ctx->jacobi_verbose) fprintf(stderr, "[eigh-orth] n=%d p=%d application %d: |QQ^T - I| = %.2e  max resid/|l0| = %.3e  |l_kk|/|l0| = %.3e\n", n, p, it + 1, dev, worst / std::max(lam0, 1e-300), lamk / std::max(lam0, 1e-300));
             if (!(dev <= 1e-12) || !(lam0 > 0.0) || !(lamk > ctx->rank_tol * lam0)) return CTM_OK;
-            if (worst <= resid_tol(ctx, n) * lam0) {
+            if (worst <= tol * lam0) {
                 CTM_TRY(row_dots(ctx, X, warm, kk, n, n, dots));
                 CTM_LAUNCH(ctx, signed_rows_kernel, dim3(256), dim3(256), 0, (const double*)X, (const double*)dots, 1, kk, n, AX);     // aligned with the previous vectors
                 CTM_HIP_CHECK(ctx, hipMemcpyAsync(warm, AX, sizeof(double) * (size_t)kk * n, hipMemcpyDeviceToDevice, ctx->stream));
@@ -3229,9 +3245,17 @@ static int eigh_orth_iter(ctm_ctx* ctx, const double* As, int n, int kk, int k_o
                 *accepted = true;
                 return CTM_OK;
             }
+            // next look: from the contraction measured so far (two applications when there is nothing to measure it against)
+            int need = 2;
+            if (moved > 0.0 && worst < moved * lam0 && ctx->eigh_orth_predict) {
+                const double rate = std::min(0.5, std::max(1e-3, std::pow(worst / (moved * lam0), 1.0 / (it + 1))));
+                need = (int)std::ceil(std::log(0.5 * tol * lam0 / worst) / std::log(rate));
+                need = std::max(1, std::min(need, 3));
+            }
+            next_rr = it + need;
         }
         if (it == max_it) break;
-        CTM_TRY(orth(Y, it + 1 >= first_rr));           // the basis a Rayleigh-Ritz may use gets the full passes
+        CTM_TRY(orth(Y, it + 1 >= next_rr));            // the basis a Rayleigh-Ritz may use gets the full passes
         std::swap(Q, Y);
     }
     ctx->eigh_orth_fails += 1;
@@ -3252,10 +3276,11 @@ int jacobi_eigh_top(ctm_ctx* ctx, const double* A, int n, int k, double* D, doub
         if (warm && ctx->eigh_warm) {
             bool accepted = false;
             bool norms_ok = false;
-            CTM_TRY(eigh_warm_verify(ctx, As, n, kk, k_out, warm, D, Ut, &accepted, false, &norms_ok));
+            double moved = 0.0;
+            CTM_TRY(eigh_warm_verify(ctx, As, n, kk, k_out, warm, D, Ut, &accepted, false, &norms_ok, &moved));
             if (accepted) return CTM_OK;
             if (ctx->eigh_orth_iter) {
-                CTM_TRY(eigh_orth_iter(ctx, As, n, kk, k_out, warm, D, Ut, &accepted, norms_ok));
+                CTM_TRY(eigh_orth_iter(ctx, As, n, kk, k_out, warm, D, Ut, &accepted, norms_ok, moved));
                 if (accepted) return CTM_OK;
             }
         }
