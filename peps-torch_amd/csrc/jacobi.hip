@@ -3250,9 +3250,9 @@ static int eigh_orth_iter(ctm_ctx* ctx, const double* As, int n, int kk, int k_o
             if (moved > 0.0 && worst < moved * lam0 && ctx->eigh_orth_predict) {
                 const double rate = std::min(0.5, std::max(1e-3, std::pow(worst / (moved * lam0), 1.0 / (it + 1))));
                 need = (int)std::ceil(std::log(0.5 * tol * lam0 / worst) / std::log(rate));
-                need = std::max(1, std::min(need, 3));
+                need = std::max(1, std::min(need, 6));
             }
-            next_rr = it + need;
+            next_rr = std::min(it + need, max_it);
         }
         if (it == max_it) break;
         CTM_TRY(orth(Y, it + 1 >= next_rr));            // the basis a Rayleigh-Ritz may use gets the full passes

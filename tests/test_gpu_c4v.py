@@ -219,6 +219,28 @@ def test_orthogonal_iteration_then_stationary_restart(eng):
         assert float((D - D1).abs().max()) < 1e-13 and float((U - U1).abs().max()) < 1e-7
 
 
+def test_orthogonal_iteration_with_a_slowly_contracting_block(eng):
+    """|lambda_129 / lambda_57| = 0.05: eight applications for a move of 1e-4 -- the looks are placed from the measured move and
+    contraction, the iteration stays on its route (no fallback to the regular one) and returns the exact pairs."""
+    n, chi = 768, 48
+    lam = torch.cat([torch.linspace(1.0, 0.2, 60), 0.1 * 0.97 ** torch.arange(n - 60, dtype=torch.float64)]).double()
+    lam = lam * torch.where(torch.arange(n) % 5 == 3, -1.0, 1.0)
+    A, _ = _sym_with_spectrum(n, lam, 51)
+    g = torch.Generator().manual_seed(52)
+    E = torch.randn(n, n, generator=g, dtype=torch.float64); E = E + E.T
+    E = 1e-4 * E / torch.linalg.matrix_norm(E, 2)
+    basis = eng.warm_basis_c4v(chi, n)
+    eng.truncated_eigh(A.cuda(), chi, basis=basis)
+    eng.timers(reset=True)
+    D, U = eng.truncated_eigh((A + E).cuda(), chi, basis=basis)
+    assert eng.stat("eigh_orth_hits") == 1 and eng.stat("eigh_orth_fails") == 0
+    w = torch.linalg.eigvalsh(A + E)
+    w = w[torch.argsort(w.abs(), descending=True)][:chi]
+    assert float((D.cpu() - w).abs().max()) < 1e-12
+    assert float((((A + E).cuda() @ U) - U * D).abs().max()) < 1e-12
+    assert float((U.T @ U - torch.eye(chi, device=U.device, dtype=U.dtype)).abs().max()) < 1e-12
+
+
 def test_orthogonal_iteration_declines_a_numerically_low_rank_block(eng):
     """Fewer significant eigenvalues than the iteration's block: it steps aside (no acceptance) and the regular route returns the pairs."""
     n, chi = 768, 48
