@@ -3200,6 +3200,7 @@ static int eigh_orth_iter(ctm_ctx* ctx, const double* As, int n, int kk, int k_o
     const int min_rr = 3, max_it = std::max(min_rr, ctx->eigh_orth_max);
     const double tol = resid_tol(ctx, n);
     int next_rr = min_rr;
+    double ref_val = moved; int ref_it = moved > 0.0 ? -1 : -2;       // (-2: nothing to measure the contraction against yet)
     if (moved > 0.0 && ctx->eigh_orth_predict) {
         const int need = (int)std::ceil(std::log(0.5 * tol / std::min(moved, 1.0)) / std::log(1e-2));      // applications
         next_rr = std::min(max_it, std::max(min_rr, need - 1));
@@ -3241,17 +3242,29 @@ static int eigh_orth_iter(ctm_ctx* ctx, const double* As, int n, int kk, int k_o
                 CTM_LAUNCH(ctx, signed_rows_kernel, dim3(256), dim3(256), 0, (const double*)AX, (const double*)Dp, 1, k_out, n, Ut);
                 CTM_HIP_CHECK(ctx, hipMemcpyAsync(D, Dp, sizeof(double) * k_out, hipMemcpyDeviceToDevice, ctx->stream));
                 ctx->si_hits += 1; ctx->eigh_orth_hits += 1;
+                ctx->eigh_orth_backoff = 0;
                 ctx->si_last_iters = it + 1; ctx->si_total_iters += it + 1;
                 *accepted = true;
                 return CTM_OK;
             }
             // next look: from the contraction measured so far (two applications when there is nothing to measure it against)
             int need = 2;
-            if (moved > 0.0 && worst < moved * lam0 && ctx->eigh_orth_predict) {
-                const double rate = std::min(0.5, std::max(1e-3, std::pow(worst / (moved * lam0), 1.0 / (it + 1))));
-                need = (int)std::ceil(std::log(0.5 * tol * lam0 / worst) / std::log(rate));
-                need = std::max(1, std::min(need, 6));
+            const double ref = ref_it >= -1 ? ref_val : 0.0;          // residual level `it - ref_it` applications ago
+            if (ref > 0.0 && ctx->eigh_orth_predict) {
+                // (a flat spectrum behind the kept pairs -- |lambda_{p+1} / lambda_kk| close to 1 -- is not a case for this route: leave at
+                //  the first look that can tell, and keep away from it for a growing number of calls)
+                const double rate = std::min(0.999, std::max(1e-3, std::pow(worst / (ref * lam0), 1.0 / (it - ref_it))));
+                const double needd = std::log(0.5 * tol * lam0 / worst) / std::log(rate);
+                if (!(needd <= (double)(max_it - it))) {
+                    if (ctx->jacobi_verbose) fprintf(stderr, "[eigh-orth] contraction %.3f per application: %.0f more needed, leaving\n", rate, needd);
+                    ctx->eigh_orth_fails += 1;
+                    ctx->eigh_orth_backoff = std::min(64, std::max(2, 2 * ctx->eigh_orth_backoff));
+                    ctx->eigh_orth_skip = ctx->eigh_orth_backoff;
+                    return CTM_OK;
+                }
+                need = std::max(1, std::min((int)std::ceil(needd), 6));
             }
+            ref_val = worst / lam0; ref_it = it;
             next_rr = std::min(it + need, max_it);
         }
         if (it == max_it) break;
@@ -3279,7 +3292,8 @@ int jacobi_eigh_top(ctm_ctx* ctx, const double* A, int n, int k, double* D, doub
             double moved = 0.0;
             CTM_TRY(eigh_warm_verify(ctx, As, n, kk, k_out, warm, D, Ut, &accepted, false, &norms_ok, &moved));
             if (accepted) return CTM_OK;
-            if (ctx->eigh_orth_iter) {
+            if (ctx->eigh_orth_iter && ctx->eigh_orth_skip > 0) ctx->eigh_orth_skip -= 1;
+            else if (ctx->eigh_orth_iter) {
                 CTM_TRY(eigh_orth_iter(ctx, As, n, kk, k_out, warm, D, Ut, &accepted, norms_ok, moved));
                 if (accepted) return CTM_OK;
             }

@@ -241,6 +241,29 @@ def test_orthogonal_iteration_with_a_slowly_contracting_block(eng):
     assert float((U.T @ U - torch.eye(chi, device=U.device, dtype=U.dtype)).abs().max()) < 1e-12
 
 
+def test_orthogonal_iteration_leaves_a_flat_spectrum_to_the_regular_route(eng):
+    """|lambda_129 / lambda_57| = 0.6: 36 applications for a move of 1e-6, more than the iteration allows itself.  The first look measures
+    the contraction, the iteration leaves (and stays away for the next calls); the regular route (63 half steps) returns the pairs."""
+    n, chi = 768, 48
+    lam = torch.cat([torch.linspace(1.0, 0.5, 57), 0.48 * 0.9935 ** torch.arange(n - 57, dtype=torch.float64)]).double()
+    A, _ = _sym_with_spectrum(n, lam, 61)
+    g = torch.Generator().manual_seed(62)
+    E = torch.randn(n, n, generator=g, dtype=torch.float64); E = E + E.T
+    E = 1e-6 * E / torch.linalg.matrix_norm(E, 2)
+    basis = eng.warm_basis_c4v(chi, n)
+    eng.truncated_eigh(A.cuda(), chi, basis=basis)
+    eng.timers(reset=True)
+    for k in (1, 2, 3):
+        M = A + k * E
+        D, U = eng.truncated_eigh(M.cuda(), chi, basis=basis)
+        w = torch.linalg.eigvalsh(M)
+        w = w[torch.argsort(w.abs(), descending=True)][:chi]
+        assert float((D.cpu() - w).abs().max()) < 1e-12
+        assert float(((M.cuda() @ U) - U * D).abs().max()) < 1e-12
+    assert eng.stat("eigh_orth_hits") == 0 and eng.stat("eigh_orth_fails") == 1      # the second and third call skipped it
+    eng.set_option("eigh_orth_iter", 1)
+
+
 def test_orthogonal_iteration_declines_a_numerically_low_rank_block(eng):
     """Fewer significant eigenvalues than the iteration's block: it steps aside (no acceptance) and the regular route returns the pairs."""
     n, chi = 768, 48
