@@ -90,7 +90,7 @@ struct ctm_ctx {
     int eigh_probe_orth_once = 1;      // ... the probe block is orthonormalised once (before its last application) instead of after each of the first two
     int eigh_warm_early_reject = 1;    // ... a subspace whose residual |Y - (Y Q^T) Q|_F already exceeds the threshold is refused before its Rayleigh-Ritz
     int eigh_orth_iter = 1;            // refused warm restart (the matrix moved): symmetric orthogonal iteration with Cholesky-QR steps and ONE Rayleigh-Ritz
-    int eigh_orth_max = 24;            // ... applications before it gives up (the regular block iteration runs then; an application + Cholesky-QR
+    int eigh_orth_max = 32;            // ... applications before it gives up (the regular block iteration runs then; an application + Cholesky-QR
                                        //     step costs a quarter of a half step of that iteration, so a slowly contracting block stays here)
     int eigh_orth_predict = 1;         // ... its looks (Rayleigh-Ritz + residual test) are placed where the residual is predicted to pass
     double eigh_orth_quad_exit = 1e-9; // ... early exit of its small Jacobi eigensolver (see lz_quad_exit; the residual test certifies what it returns)

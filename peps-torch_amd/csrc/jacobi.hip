@@ -3201,6 +3201,7 @@ static int eigh_orth_iter(ctm_ctx* ctx, const double* As, int n, int kk, int k_o
     const double tol = resid_tol(ctx, n);
     int next_rr = min_rr;
     double ref_val = moved; int ref_it = moved > 0.0 ? -1 : -2;       // (-2: nothing to measure the contraction against yet)
+    int looks = 0;
     if (moved > 0.0 && ctx->eigh_orth_predict) {
         const int need = (int)std::ceil(std::log(0.5 * tol / std::min(moved, 1.0)) / std::log(1e-2));      // applications
         next_rr = std::min(max_it, std::max(min_rr, need - 1));
@@ -3215,6 +3216,13 @@ static int eigh_orth_iter(ctm_ctx* ctx, const double* As, int n, int kk, int k_o
             CTM_LAUNCH(ctx, sub_eye_kernel, dim3((p + 255) / 256), dim3(256), 0, E, p);
             CTM_TRY(row_norms(ctx, E, p, p, p, norms));
             CTM_HIP_CHECK(ctx, hipMemcpyAsync(he.data(), norms, sizeof(double) * p, hipMemcpyDeviceToHost, ctx->stream));
+            CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+            const double dev = *std::max_element(he.begin(), he.end());
+            if (!(dev <= 1e-12)) {          // (NaN included: a numerically rank-deficient block breaks the Cholesky steps) -- not a case for this route
+                if (ctx->jacobi_verbose) fprintf(stderr, "[eigh-orth] n=%d p=%d application %d: |QQ^T - I| = %.2e, leaving\n", n, p, it + 1, dev);
+                ctx->eigh_orth_fails += 1;
+                return CTM_OK;
+            }
             const bool save = ctx->si_enable; ctx->si_enable = false;
             ctx->jacobi_quad_exit = ctx->eigh_orth_quad_exit;                   // (the residual test below certifies what this returns)
             const int st = jacobi_eigh_top(ctx, T, p, p, Dp, Zt, nullptr);      // rows of Zt = eigenvectors, ordered by |theta| (synchronises)
@@ -3230,12 +3238,14 @@ static int eigh_orth_iter(ctm_ctx* ctx, const double* As, int n, int kk, int k_o
             CTM_HIP_CHECK(ctx, hipMemcpyAsync(h.data(), res, sizeof(double) * kk, hipMemcpyDeviceToHost, ctx->stream));
             CTM_HIP_CHECK(ctx, hipMemcpyAsync(hd.data(), Dp, sizeof(double) * kk, hipMemcpyDeviceToHost, ctx->stream));
             CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-            const double dev = *std::max_element(he.begin(), he.end());
             const double lam0 = std::fabs(hd[0]), lamk = std::fabs(hd[kk - 1]);
             const double worst = *std::max_element(h.begin(), h.begin() + kk);
             if (ctx->jacobi_verbose) fprintf(stderr, "[eigh-orth] n=%d p=%d application %d: |QQ^T - I| = %.2e  max resid/|l0| = %.3e  |l_kk|/|l0| = %.3e\n", n, p, it + 1, dev, worst / std::max(lam0, 1e-300), lamk / std::max(lam0, 1e-300));
-            if (!(dev <= 1e-12) || !(lam0 > 0.0) || !(lamk > ctx->rank_tol * lam0)) return CTM_OK;
+            if (!(lam0 > 0.0) || !(lamk > ctx->rank_tol * lam0)) return CTM_OK;
             if (worst <= tol * lam0) {
+                // gauge: the sign of <x_i, v_i> (previous vectors).  (Rotating whole multiplets onto the previous vectors -- orthogonal
+                // Procrustes per cluster of equal |theta|, +-lambda eigenspaces matched by weight -- was tried for the SU(2) multiplets of
+                // the RVB state: the movement measure of the next call drops 2-4x, the number of applications does not: not kept.)
                 CTM_TRY(row_dots(ctx, X, warm, kk, n, n, dots));
                 CTM_LAUNCH(ctx, signed_rows_kernel, dim3(256), dim3(256), 0, (const double*)X, (const double*)dots, 1, kk, n, AX);     // aligned with the previous vectors
                 CTM_HIP_CHECK(ctx, hipMemcpyAsync(warm, AX, sizeof(double) * (size_t)kk * n, hipMemcpyDeviceToDevice, ctx->stream));
@@ -3262,8 +3272,9 @@ static int eigh_orth_iter(ctm_ctx* ctx, const double* As, int n, int kk, int k_o
                     ctx->eigh_orth_skip = ctx->eigh_orth_backoff;
                     return CTM_OK;
                 }
-                need = std::max(1, std::min((int)std::ceil(needd), 6));
+                need = std::max(1, std::min((int)std::ceil(needd), looks >= 1 ? 12 : 6));      // (the first estimate includes the fast initial drop)
             }
+            looks += 1;
             ref_val = worst / lam0; ref_it = it;
             next_rr = std::min(it + need, max_it);
         }

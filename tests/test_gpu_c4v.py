@@ -71,6 +71,39 @@ def test_rvb_known_answer(eng):
     assert np.abs(np.sort(spec)[::-1] - np.sort(g["spec"])[::-1]).max() < 1e-10
 
 
+def test_rvb_chi32_with_and_without_the_orthogonal_iteration(eng):
+    """RVB (D = 3) at chi = 32, n = 288: SU(2) multiplets and +-lambda pairs everywhere, and the 128-row block of the orthogonal
+    iteration is numerically rank deficient in some moves (its Cholesky steps then return garbage: the iteration has to notice and
+    leave -- it used to hand NaNs to the small eigensolver, which failed the whole move).  Gauge-independent results of 14 moves agree
+    between the two routes."""
+    import config as cfg
+    from ipeps.ipeps_c4v import IPEPS_C4V
+    from ctm.one_site_c4v.env_c4v import ENV_C4V, init_env
+    from ctm.one_site_c4v import ctmrg_c4v
+    from models import j1j2
+    g = golden("rvb_c4v")
+    m = j1j2.J1J2_C4V_BIPARTITE(j1=1.0, j2=0.5)
+    out = {}
+    save = cfg.ctm_args.ctm_max_iter
+    try:
+        for orth in (1, 0):
+            eng.set_option("eigh_orth_iter", orth)
+            st = IPEPS_C4V(dev(g["site"]))
+            env = ENV_C4V(32, st)
+            init_env(st, env)
+            cfg.ctm_args.ctm_max_iter = 14
+            eng.timers(reset=True)
+            ctmrg_c4v.run(st, env)
+            spec = np.sort(torch.diagonal(env.get_C()).abs().cpu().numpy())[::-1]
+            out[orth] = (float(m.energy_1x1_lowmem(st, env)), spec, eng.stat("eigh_orth_hits"))
+    finally:
+        cfg.ctm_args.ctm_max_iter = save
+        eng.set_option("eigh_orth_iter", 1)
+    assert out[1][2] >= 5 and out[0][2] == 0
+    assert np.isfinite(out[1][0]) and abs(out[1][0] - out[0][0]) < 1e-10
+    assert np.abs(out[1][1] - out[0][1]).max() < 1e-10 * out[0][1][0]
+
+
 def test_c4v_move_with_2norm_normalisation(case, eng):
     """ctm_absorb_normalization = '2' (_move_normalize_c, ctmrg_c4v.py:182-197): T divided by its vector 2-norm, C by |C[0,0]|."""
     import config as cfg
