@@ -95,6 +95,7 @@ struct ctm_ctx {
     int eigh_orth_predict = 1;         // ... its looks (Rayleigh-Ritz + residual test) are placed where the residual is predicted to pass
     double eigh_orth_quad_exit = 1e-9; // ... early exit of its small Jacobi eigensolver (see lz_quad_exit; the residual test certifies what it returns)
     long eigh_orth_hits = 0, eigh_orth_fails = 0;
+    double eigh_orth_rate = 0.0;       // contraction per application of the last accepted solve (places the first look of the next one)
     int eigh_orth_skip = 0, eigh_orth_backoff = 0;   // calls left that go straight to the regular route after the iteration left a flat spectrum (doubling)
     // block Golub-Kahan-Lanczos for spectra that do not collapse inside a small block (svd_lanczos)
     bool lz_enable = true; int lz_min_k = 48; double lz_switch_steps = 6.0; double lz_last_resid = 1.0; long lz_hits = 0, lz_total_steps = 0;

@@ -141,7 +141,7 @@ int ctm_set_option(ctm_ctx* ctx, const char* key, double value) {
     else if (k == "eigh_warm") ctx->eigh_warm = (int)value;
     else if (k == "eigh_warm_early_reject") ctx->eigh_warm_early_reject = (int)value;
     else if (k == "eigh_probe_orth_once") ctx->eigh_probe_orth_once = (int)value;
-    else if (k == "eigh_orth_iter") { ctx->eigh_orth_iter = (int)value; ctx->eigh_orth_skip = 0; ctx->eigh_orth_backoff = 0; }
+    else if (k == "eigh_orth_iter") { ctx->eigh_orth_iter = (int)value; ctx->eigh_orth_skip = 0; ctx->eigh_orth_backoff = 0; ctx->eigh_orth_rate = 0.0; }
     else if (k == "eigh_orth_max") ctx->eigh_orth_max = (int)value;
     else if (k == "eigh_orth_predict") ctx->eigh_orth_predict = (int)value;
     else if (k == "eigh_orth_quad_exit") ctx->eigh_orth_quad_exit = value;

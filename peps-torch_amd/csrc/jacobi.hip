@@ -3203,7 +3203,11 @@ static int eigh_orth_iter(ctm_ctx* ctx, const double* As, int n, int kk, int k_o
     double ref_val = moved; int ref_it = moved > 0.0 ? -1 : -2;       // (-2: nothing to measure the contraction against yet)
     int looks = 0;
     if (moved > 0.0 && ctx->eigh_orth_predict) {
-        const int need = (int)std::ceil(std::log(0.5 * tol / std::min(moved, 1.0)) / std::log(1e-2));      // applications
+        // (the contraction the previous accepted solve of this context saw from its own `moved` to its accepted residual -- a property
+        //  of the spectrum, which changes slowly from sweep to sweep -- places the first look better than the fixed guess: a signed
+        //  random C4v state contracts by 0.25-0.33 per application, not 0.01, and paid three looks per solve)
+        const double rho = ctx->eigh_orth_rate > 0.0 ? ctx->eigh_orth_rate : 1e-2;
+        const int need = (int)std::ceil(std::log(0.5 * tol / std::min(moved, 1.0)) / std::log(rho) + (ctx->eigh_orth_rate > 0.0 ? 0.5 : 0.0));      // applications
         next_rr = std::min(max_it, std::max(min_rr, need - 1));
     }
     for (int it = 0; it <= max_it; ++it) {
@@ -3253,6 +3257,7 @@ static int eigh_orth_iter(ctm_ctx* ctx, const double* As, int n, int kk, int k_o
                 CTM_HIP_CHECK(ctx, hipMemcpyAsync(D, Dp, sizeof(double) * k_out, hipMemcpyDeviceToDevice, ctx->stream));
                 ctx->si_hits += 1; ctx->eigh_orth_hits += 1;
                 ctx->eigh_orth_backoff = 0;
+                if (moved > 0.0) ctx->eigh_orth_rate = std::min(0.9, std::max(1e-3, std::pow(std::max(worst / lam0, 1e-16) / std::min(moved, 1.0), 1.0 / (it + 1))));
                 ctx->si_last_iters = it + 1; ctx->si_total_iters += it + 1;
                 *accepted = true;
                 return CTM_OK;
