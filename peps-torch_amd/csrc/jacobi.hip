@@ -1939,7 +1939,7 @@ __device__ __forceinline__ double wave_sum(double v) {                   // ever
 // rows k < rank hold row k of L_pp^-1 scattered to the pivot positions, so that Mo Z has orthonormal rows 0..rank-1 (Gram-Schmidt
 // of the pivot rows in pivot order) and zero rows beyond; status[0] = rank.  One wave; lane j keeps row j of L in registers (entry
 // t = pivot step t: the loops are fully unrolled, so the index is static) and reads the pivot row's entries from lane p by
-// v_readlane; G stays in LDS for the one row per step that is read.  (91 us -> 3x us against the LDS version: six ds_bpermute
+// v_readlane; G stays in LDS for the one row per step that is read.  (91 us -> 44 us against the LDS version: six ds_bpermute
 // rounds of the argmax and an LDS round trip per term were on the critical path of every step.)
 __global__ __launch_bounds__(64) void pivchol64_inv_kernel(const double* __restrict__ G, double rel, double* __restrict__ Mo, double* __restrict__ status) {
     constexpr int M = 64;
@@ -2054,7 +2054,7 @@ int orthonormalise_block(ctm_ctx* ctx, double* W, int rows, int n, double* norms
 //     then a[k] -= a[j] * L_kj for k > j, L_kj read from lane k;
 //   X = L^-1: lane c builds column c, x_r = -(sum_{t<r} L_rt x_t) / L_rr with L_rt read from lane r (x_t = 0 for t < c by construction);
 //   out = X D^-1/2  so that  out * W  has orthonormal rows.
-// 110 us -> 2x us per call against the 256-thread LDS version it replaces (2100 cycles per column and 2000 per row of the inverse there:
+// 108 us -> 41 us per call against the 256-thread LDS version it replaces (2100 cycles per column and 2000 per row of the inverse there:
 // barrier, LDS latency, ds_bpermute reductions and IEEE divisions on the critical path).
 // mode 0 (first pass): when a pivot of A falls below 1e-10 (rows nearly dependent: cond(W) > ~1e5, beyond two Cholesky-QR passes)
 //   the factorisation is repeated on A + 1e-10 I (shifted Cholesky-QR: the result is only roughly orthonormal, cond ~ 1e-5 cond(W))
