@@ -134,6 +134,7 @@ int ctm_set_option(ctm_ctx* ctx, const char* key, double value) {
     else if (k == "rows_kernel_min_m") ctx->rows_kernel_min_m = (int)value;
     else if (k == "rows_kernel_min_m_kc") ctx->rows_kernel_min_m_kc = (int)value;
     else if (k == "rows_target_wgs") ctx->rows_target_wgs = (int)value;
+    else if (k == "rows_min_klen") ctx->rows_min_klen = (int)value;
     else if (k == "rows_fused_reduce") ctx->rows_fused_reduce = value != 0.0;
     else if (k == "heavy_serial") ctx->heavy_serial = value != 0.0;
     else if (k == "heavy_min_flops") ctx->heavy_min_flops = value;
