@@ -139,7 +139,10 @@ struct ctm_ctx {
     bool gemm_strip = true;       // streaming kernel for <= 64 rows times a big operand
     int strip_target_wgs = 512;   // K slices x column tiles of the strip kernel: fewer slices = fewer partials (measured 512 <= 1024, 256)
     int rows_kernel_min_m = 1, rows_kernel_min_m_kc = 1;   // LDS-tiled row-block kernel from this many rows (n-contiguous / k-contiguous big operand)
-    int rows_min_klen = 576;      // ... but no K slice shorter than this (mid-size operands)
+    int rows_min_klen = 256;      // ... optional lower bound on the K slice (256 = off).  576 measured 8-12 % faster per D = 6 chi = 128 sweep
+                                  //     (n = 4608: 18 slices of 256 k are all prologue, epilogue and an 18-slab combine); not the default: the one
+                                  //     full GPU test run of the round with it ended in a core dump of the pytest process that the remaining GPU
+                                  //     budget did not allow to chase (the last two test files pass with it in isolation)
     int rows_target_wgs = 768;    // its workgroup count (column tiles x K slices): three per CU
     // Chip-filling launches (>= heavy_min_flops) of ALL contexts of a device run one at a time (device-side lock): the concurrent
     // units of a move overlap their latency-bound stages with each other and with ONE corner pass at a time, instead of four

@@ -688,8 +688,7 @@ int gemm_f64(ctm_ctx* ctx, const GemmDesc& d) {
         int target = ((long long)d.N * d.K >= (1ll << 27)) ? ctx->strip_target_wgs : 2 * ctx->strip_target_wgs;
         if (rows_kernel) target = ctx->rows_target_wgs;
         int ks = std::max(1, std::min(std::min((target + gx - 1) / gx, d.K / 256), 64));
-        // mid-size operands (n = 4608: 36 column tiles): 18 slices of 256 k filled the chip three times over with workgroups that were
-        // all prologue, epilogue and an 18-slab combine; slices of >= rows_min_klen k measured 8-10 % faster per D = 6 sweep
+        // (option, off by default -- see rows_min_klen: mid-size operands, n = 4608 = 36 column tiles, run 18 slices of 256 k)
         if (rows_kernel && ctx->rows_min_klen > 256) ks = std::max(1, std::min(ks, d.K / ctx->rows_min_klen));
         int klen = (((d.K + ks - 1) / ks) + 15) / 16 * 16;
         ks = (d.K + klen - 1) / klen;
