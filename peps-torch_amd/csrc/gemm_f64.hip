@@ -689,7 +689,9 @@ int gemm_f64(ctm_ctx* ctx, const GemmDesc& d) {
         if (rows_kernel) target = ctx->rows_target_wgs;
         int ks = std::max(1, std::min(std::min((target + gx - 1) / gx, d.K / 256), 64));
         // (option, off by default -- see rows_min_klen: mid-size operands, n = 4608 = 36 column tiles, run 18 slices of 256 k)
-        if (rows_kernel && ctx->rows_min_klen > 256) ks = std::max(1, std::min(ks, d.K / ctx->rows_min_klen));
+        // (never down to a single slice: the direct-write epilogue of the row-block kernel, ks == 1, is not reached by any shape of the
+        //  default rule -- K >= 1024 here -- and has not been through the test suite)
+        if (rows_kernel && ctx->rows_min_klen > 256 && ks > 2) ks = std::max(2, std::min(ks, d.K / ctx->rows_min_klen));
         int klen = (((d.K + ks - 1) / ks) + 15) / 16 * 16;
         ks = (d.K + klen - 1) / klen;
         // the row-block kernel sums its K slices inside the launch (last workgroup of a column tile); the strip kernel keeps the
