@@ -10,7 +10,8 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # see config.py: one hardwa
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIBPATH = os.path.join(_HERE, "libctm_hip.so")
+# CTM_LIB: another build of the same library (csrc/build.py --asan: host side under AddressSanitizer); never anything but libctm_hip
+_LIBPATH = os.environ.get("CTM_LIB") or os.path.join(_HERE, "libctm_hip.so")
 
 CTM_OK = 0
 _ERRNAMES = {1: "bad argument", 2: "shape mismatch", 3: "no convergence", 4: "HIP error", 5: "unsupported", 6: "out of memory"}
@@ -291,15 +292,23 @@ class Engine:
         return TruncCfg(svd_reltol, eps_multiplet, multiplet_abstol, int(keep_multiplets), int(fix_signs))
 
     # ---- primitives ---------------------------------------------------------------------------
-    def gemm(self, A, B, transA=False, transB=False, alpha=1.0):
+    def gemm(self, A, B, transA=False, transB=False, alpha=1.0, beta=0.0, out=None):
+        """alpha op(A) op(B) (+ beta out).  `out` (float64 only): an M x ldc row-major tensor, ldc >= N, updated in its first N columns."""
         A, B = self._bind(A, B)          # complex128: trans = 0/False 'N', 1/True 'T', 2 'C' (conjugate transpose)
         M, K = (A.shape[1], A.shape[0]) if transA else A.shape
         K2, N = (B.shape[1], B.shape[0]) if transB else B.shape
         if K != K2:
             raise NativeError("gemm: inner dimensions differ")
-        out = self.empty(M, N)
+        if out is None:
+            if beta != 0.0:
+                raise NativeError("gemm: beta != 0 needs `out`")
+            out = self.empty(M, N)
+        else:
+            out = _chk_t(out, "out", A.dtype)
+            if out.dim() != 2 or out.shape[0] != M or out.shape[1] < N:
+                raise NativeError("gemm: `out` must be M x ldc with ldc >= N")
         self._ck(self.lib.ctm_gemm(self.h, int(transA), int(transB), M, N, K, alpha, _ptr(A), A.shape[1], _ptr(B),
-                                   B.shape[1], 0.0, _ptr(out), N), "gemm")
+                                   B.shape[1], beta, _ptr(out), out.shape[1]), "gemm")
         return out
 
     def permute(self, x, perm):

@@ -156,7 +156,7 @@ def test_row_block_times_big_operand_kernels(eng, rows_kernel):
     n = 2048
     g = torch.Generator(device="cuda").manual_seed(3)
     B = torch.randn(n, n, dtype=torch.float64, device="cuda", generator=g)
-    old = (33, 33)
+    old = (1, 1)              # the defaults of csrc/ctm_common.h
     eng.set_option("rows_kernel_min_m", 1 if rows_kernel else 1000)
     eng.set_option("rows_kernel_min_m_kc", 1 if rows_kernel else 1000)
     try:

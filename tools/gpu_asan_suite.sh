@@ -1,0 +1,11 @@
+#!/bin/bash
+# Full GPU suite with the HOST side of libctm_hip under AddressSanitizer (csrc/build.py --asan), engine options from $1
+# (e.g. rows_min_klen=576).  Logs under gpurun_out/.
+cd "$(dirname "$0")/.."
+mkdir -p gpurun_out
+export CTM_LIB=$PWD/peps-torch_amd/libctm_hip_asan.so
+export ASAN_OPTIONS=detect_leaks=0:protect_shadow_gap=0:abort_on_error=1:halt_on_error=1:log_path=$PWD/gpurun_out/asan
+export CTM_ENGINE_OPTS="$1"
+shift
+ulimit -c 0
+LD_PRELOAD=$(python peps-torch_amd/csrc/build.py --asan-runtime) python -X faulthandler -m pytest "$@" 2>&1 | tail -60
