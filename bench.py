@@ -305,6 +305,8 @@ def run_workload(args, eng, dev, kind, D, chi, dtype, signed, steps, warmup, wor
     # time this rank spent in the two exchanges of every move (all-gather of P, Pt and of the new C, C, T): its own phase entry
     phase["comm"] = parallel.comm_time_s(reset=True); parallel.comm_timing = False
     absorb_bytes, absorb_calls = eng.stat("absorb_bytes"), eng.stat("absorb_calls")
+    # flop the engine EXECUTED in the timed region: every GEMM launch (all kernels of csrc/gemm_f64.hip) + the fused two-layer kernel
+    executed_flop = eng.stat("gemm_flops") + eng.stat("layer2_flops")
     svd = {"decompositions": int(eng.stat("jacobi_calls")),
            "avg_jacobi_sweeps": round(eng.stat("total_sweeps") / max(eng.stat("jacobi_calls"), 1), 2),
            "power_iter_hits": int(eng.stat("si_hits")), "power_iter_fallbacks_to_full": int(eng.stat("si_fallbacks")),
@@ -324,10 +326,17 @@ def run_workload(args, eng, dev, kind, D, chi, dtype, signed, steps, warmup, wor
         serial = ([eng.stat(f"k_ms{i}") for i in KK], [eng.stat(f"k_flops{i}") for i in KK], [eng.stat(f"k_calls{i}") for i in KK])
         eng.set_option("gemm_timing", 0)
         cfg.ctm_args.concurrent_units = True
+    comm_ranks = None
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        # time inside the exchanges per rank (min / max over ranks: an idle rank waits in the collective for the busiest one)
+        c = torch.tensor([phase["comm"], -phase["comm"], executed_flop], dtype=torch.float64, device=dev)
+        cmax = c.clone(); dist.all_reduce(cmax, op=dist.ReduceOp.MAX)
+        csum = c.clone(); dist.all_reduce(csum)
+        comm_ranks = {"max_s": float(cmax[0]), "min_s": float(-cmax[1]), "mean_s": float(csum[0]) / world}
+        executed_flop = float(csum[2])
     u_ms = [_union_ms(ivals, i) for i in KK]
     # the dominant kernel = the class the chip spends most time on (sum of its launch durations)
     dom = max((0, 2, 3, 4), key=lambda i: k_ms[i])
@@ -362,6 +371,12 @@ def run_workload(args, eng, dev, kind, D, chi, dtype, signed, steps, warmup, wor
             roof["absorb_step"]["mfma"] = {"flops_per_call": fl, "achieved": round(tf, 2), "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                                            "frac": round(tf / FP64_MFMA_PEAK_TFLOPS, 4),
                                            "note": "device time per call is measured on the unit's stream while the other units of the move share the chip"}
+    # sweep-level figure north_star asks for ("fraction of the FP64 MFMA roofline"): executed flop / wall time / (peak x GPUs).  NOT
+    # SURVEY 8d's dense flop count (3 n^3 GEMMs + a full SVD per unit): the engine never forms R, Rt, M
+    roof["executed_flop_per_sweep"] = executed_flop / steps
+    roof["sweep_mfma_frac"] = round(executed_flop / dt / (FP64_MFMA_PEAK_TFLOPS * 1e12 * world), 4)
+    if comm_ranks is not None:
+        roof["comm_per_rank"] = comm_ranks
     out = {"value": steps / dt, "ms_per_step": 1e3 * dt / steps, "steps": steps, "warmup": warmup, "roofline": roof, "svd": svd,
            "phase_s": {k: round(v, 4) for k, v in phase.items()},
            "phase_s_note": "device time per phase from HIP events on the engines' streams, summed over concurrent streams (not wall time)"}
@@ -424,6 +439,7 @@ def compact(res):
     roof = res["roofline"]
     out = {"value": res["value"], "unit": "sweeps/s", "ms_per_step": res["ms_per_step"], "steps": res["steps"], "warmup": res["warmup"],
            "dominant_kernel": {k: roof.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "frac_union")},
+           "executed_flop_per_sweep": roof.get("executed_flop_per_sweep"), "sweep_mfma_frac": roof.get("sweep_mfma_frac"),
            "svd": res["svd"]}
     for k in ("state", "steady_state", "moving_environment", "stationary_environment"):
         if k in res:
@@ -442,8 +458,10 @@ def other_configs(args, eng, dev, world, rank, dist):
     saved = (args.no_serial_pass,)
     args.no_serial_pass = True
     try:
-        for name, signed, steps, warmup in (("c4v_D4_chi64", False, 100, 1), ("c4v_D4_chi64", True, 100, 1), ("generic_D6_chi128", False, 3, 4), ("generic_D6_chi128", True, 3, 4),
-                                            ("generic_D8_chi384_c128", False, 1, 1), ("generic_D8_chi384_c128", True, 1, 1)):
+        # warm-up = ceil(chi / D^2) sweeps for every block: C4v 4, D6 chi128 4, D8 chi384 6 -- the signed complex128
+        # block then times a sweep whose 32 truncations run the complex block Krylov solver at n = 24576 (configs[4]'s hard regime)
+        for name, signed, steps, warmup in (("c4v_D4_chi64", False, 100, 4), ("c4v_D4_chi64", True, 100, 4), ("generic_D6_chi128", False, 3, 4), ("generic_D6_chi128", True, 3, 4),
+                                            ("generic_D8_chi384_c128", False, 1, 6), ("generic_D8_chi384_c128", True, 1, 6)):
             kind, D, chi, dtype = CONFIGS[name]
             key = name + ("_signed" if signed else "")
             try:
@@ -452,6 +470,8 @@ def other_configs(args, eng, dev, world, rank, dist):
                 out[key] = compact(res)
                 out[key]["dtype"] = dtype
                 out[key]["wall_s_incl_warmup"] = round(time.perf_counter() - t0, 1)
+                out[key]["units_in_flight"] = max(1, len([w for w in getattr(eng, "workers", []) if w.own_stat("arena_total") > 0]))
+                out[key]["hbm_free_GiB_after"] = round(torch.cuda.mem_get_info()[0] / 2 ** 30, 1)
                 del state, env, sites
             except Exception as e:
                 out[key] = {"error": repr(e)}
@@ -492,6 +512,91 @@ def traffic_from_profile(args, world, dom, signed):
                 "source": f"profiles/{os.path.basename(fcsv)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, average HBM bytes per launch)"}
     except Exception:
         return None
+
+
+def _short_kernel(name):
+    return name.split(" ")[0].split("(")[0] if name else None
+
+
+def _compact_block(b):
+    """A block of the detail (res of run_workload / compact()) as a handful of scalars."""
+    if not isinstance(b, dict) or "error" in b:
+        return b
+    dk = b.get("dominant_kernel") or b.get("roofline") or {}
+    o = {"value": round(b["value"], 5), "ms_per_step": round(b["ms_per_step"], 3), "steps": b["steps"], "warmup": b["warmup"],
+         "kernel": _short_kernel(dk.get("kernel")), "bound": dk.get("bound"), "frac": dk.get("frac"), "frac_union": dk.get("frac_union"),
+         "sweep_mfma_frac": b.get("sweep_mfma_frac", dk.get("sweep_mfma_frac"))}
+    sv = b.get("svd") or {}
+    if sv.get("block_krylov_solves") is not None:
+        o["block_krylov_solves"] = sv["block_krylov_solves"]; o["power_iter_solves"] = sv.get("power_iter_hits")
+    stt = b.get("state") or {}
+    if stt:
+        o["corner_rank_1e-8"] = stt.get("corner_values_above_1e-8"); o["low_rank"] = stt.get("effective_rank_much_smaller_than_chi")
+    for k_ in ("moving_environment", "stationary_environment"):
+        if k_ in b:
+            o[k_.split("_")[0] + "_sweeps_per_sec"] = b[k_].get("sweeps_per_sec"); o[k_.split("_")[0] + "_sweeps"] = b[k_].get("sweeps")
+    for k_ in ("dtype", "units_in_flight", "wall_s_incl_warmup"):
+        if k_ in b:
+            o[k_] = b[k_]
+    return o
+
+
+def metric_line(d):
+    """The ONE stdout line: the driver's contract keys, `roofline` with the scalars a reader plans with (both states of the default
+    workload: per-launch / union / alone fractions of the dominant kernel, executed flop per sweep, sweep-level MFMA fraction), the CPU
+    baseline, and every other configuration as a few scalars.  Everything else is in the detail (see main)."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config")
+    line = {k: d[k] for k in keep if k in d}
+    r = d["roofline"]
+    roof = {k: r.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "launches", "avg_launch_ms", "frac_union", "concurrent_streams",
+                                  "time_share_of_sweep", "algorithmic_work_per_launch", "traffic_source", "executed_flop_per_sweep", "sweep_mfma_frac", "comm_per_rank")
+            if r.get(k) is not None or k == "traffic"}
+    sp = (r.get("serial_pass") or {}).get("dominant")
+    if sp:
+        roof["frac_alone"] = sp["frac"]; roof["avg_launch_ms_alone"] = sp["avg_launch_ms"]
+    if "absorb_step" in r:
+        a = r["absorb_step"]
+        roof["absorb_step"] = {"achieved_GBps": a["achieved"], "frac_hbm": a["frac"], "device_ms_per_call": a["device_ms_per_call"],
+                               "frac_mfma": (a.get("mfma") or {}).get("frac")}
+    roof["note"] = ("frac = algorithmic work of the dominant kernel / sum of its launch durations in the timed region (HIP events on the engines' streams; "
+                    "units share the chip); frac_union = / union of its launch intervals; frac_alone = the same kernel in a serially issued sweep; "
+                    "sweep_mfma_frac = flop the engine executed per sweep / wall time / FP64 MFMA peak; traffic = committed PMC pass of this command, not measured by this run")
+    fr = d.get("full_rank")
+    if fr:
+        fro = fr["roofline"]
+        roof.update({"full_rank_value": round(fr["value"], 5), "full_rank_ms_per_step": round(fr["ms_per_step"], 2), "full_rank_kernel": _short_kernel(fro.get("kernel")),
+                     "full_rank_bound": fro.get("bound"), "full_rank_frac": fro.get("frac"), "full_rank_frac_union": fro.get("frac_union"),
+                     "full_rank_frac_alone": ((fro.get("serial_pass") or {}).get("dominant") or {}).get("frac"),
+                     "full_rank_executed_flop_per_sweep": fro.get("executed_flop_per_sweep"), "full_rank_sweep_mfma_frac": fro.get("sweep_mfma_frac"),
+                     "full_rank_traffic": fro.get("traffic")})
+        blk = {"value": fr["value"], "ms_per_step": fr["ms_per_step"], "steps": fr["steps"], "warmup": fr["warmup"], "state": {k: v for k, v in fr["state"].items() if k != "note"},
+               "svd": fr["svd"], "phase_s": fr["phase_s"]}
+        if "energy" in fr:
+            e = fr["energy"]
+            blk["energy"] = e if "error" in e else {"seconds_per_energy_4_sites": e["seconds_per_energy_4_sites"], "energy_per_site_j2_0.5": e["energy_per_site_j2_0.5"],
+                                                    "rdm2x2_invariants": e.get("rdm2x2_invariants")}
+        if "energy_parity" in fr:
+            blk["energy_parity"] = {k: fr["energy_parity"].get(k) for k in ("rel_err", "max_abs_err_corner_spectra", "tolerance")}
+        line["full_rank"] = blk
+    line["roofline"] = roof
+    if "cpu_baseline" in d:
+        line["cpu_baseline"] = d["cpu_baseline"]
+    for k in ("svd", "phase_s"):
+        if k in d:
+            line[k] = d[k]
+    if "state" in d:
+        line["state"] = {k: v for k, v in d["state"].items() if k != "note"}
+    for k in ("steady_state", "moving_environment", "stationary_environment"):
+        if k in d:
+            line[k] = {kk: vv for kk, vv in d[k].items() if kk != "note"}
+    if "signed_state" in d:
+        line["signed_state"] = _compact_block(d["signed_state"])
+    if "energy_parity" in d:
+        ep = d["energy_parity"]
+        line["energy_parity"] = ep if "error" in ep else {k: ep.get(k) for k in ("workload", "rel_err", "max_abs_err_corner_spectra", "tolerance")}
+    if "other_configs" in d:
+        line["other_configs"] = {k: _compact_block(v) for k, v in d["other_configs"].items()}
+    return line
 
 
 def spawn_ranks(n):
@@ -641,7 +746,18 @@ def main():
                     out["full_rank"]["energy_parity"] = energy_parity(dev, dtype, signed=True)
             except Exception as e:
                 out["energy_parity"] = {"error": repr(e)}
-        print(json.dumps(out), flush=True)
+        line = metric_line(out)
+        # the verbose blocks (per-class rooflines, serial passes, every other configuration in full) go to stderr and to a file; stdout
+        # carries ONE line that fits the driver's record
+        try:
+            os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
+            with open(os.path.join(REPO, "gpurun_out", "bench_detail.json"), "w") as f:
+                f.write(json.dumps(out) + "\n")
+            line["detail"] = "gpurun_out/bench_detail.json (and stderr, prefix BENCH_DETAIL)"
+        except OSError:
+            line["detail"] = "stderr, prefix BENCH_DETAIL"
+        print("BENCH_DETAIL " + json.dumps(out), file=sys.stderr, flush=True)
+        print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

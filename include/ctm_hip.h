@@ -66,6 +66,26 @@ int ctm_timers(ctm_ctx* ctx, double* out8, int reset);             /* corners,ha
  * *count (launches).  The same classes index the stats "k_ms<c>", "k_flops<c>", "k_calls<c>". */
 int ctm_gemm_intervals(ctm_ctx* ctx, double* out, long long capacity_doubles, long long* count);
 
+/* ---- communicator of a rank group that shares ONE unit (multi-GPU: more ranks than sites; reference independence argument
+ * ctm/generic/ctmrg.py:238-275 -- the per-site units of a move are independent, so 8 GPUs on a 4-site cell can only be used by
+ * splitting a unit) -------------------------------------------------------------------------------------------------------------
+ * rccl_comm: an ncclComm_t (RCCL over xGMI) spanning the `nranks` ranks of the group, `rank` = this process's rank in it; NULL with
+ * nranks == 1 detaches.  The context issues its collectives on ITS OWN stream (ctm_create), so they are stream-ordered with the
+ * kernels that produce and consume the buffers; nothing is retained beyond the handle.
+ * Contract of the column split a group executes (ABI frozen here, nranks == 1 is what is implemented):
+ *   - every rank of the group keeps the column block [rank n/nranks, (rank+1) n/nranks) of each n x n enlarged corner of the unit
+ *     (corner construction, corner cache and absorb split by OUTPUT columns: no communication);
+ *   - a corner pass B(<=64 x n) * corner yields this rank's n/nranks output columns; before the next pass the group runs ONE
+ *     in-place ncclAllGather of (rows x n/nranks) doubles per rank (complex128: both planes in the same call) on the context's
+ *     stream -- 8 passes per block step of the Krylov recurrence, ~104 per full-rank unit at n = 16384;
+ *   - the 64-row orthonormalisations and the Ritz extraction are replicated on every rank of the group (bit-identical inputs,
+ *     deterministic kernels: no broadcast of their results);
+ *   - projectors P, Pt come out replicated; the host layer exchanges them between groups as it does between single ranks
+ *     (parallel.exchange).
+ * Returns CTM_ERR_UNSUPPORTED for nranks > 1 in this build (the split is specified, costed and not built: it cannot be executed on
+ * the single-GPU boxes this library is developed on), CTM_ERR_BADARG for rank outside [0, nranks). */
+int ctm_set_comm(ctm_ctx* ctx, void* rccl_comm /* ncclComm_t or NULL */, int rank, int nranks);
+
 /* ---- primitives (replace tn_interface.py:3-27 contract/mm/permute) ------------------------------ */
 /* C[M,N] = alpha op(A) op(B) + beta C ; row-major; trans = 0 ('N') or 1 ('T', plain transpose); CTM_C128 also 2 ('C', conjugate
  * transpose), dense operands and beta == 0 */

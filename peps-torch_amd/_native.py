@@ -39,6 +39,7 @@ _SIGS = {
     "ctm_sync": [C.c_void_p],
     "ctm_trim": [C.c_void_p],
     "ctm_set_option": [C.c_void_p, C.c_char_p, C.c_double],
+    "ctm_set_comm": [C.c_void_p, C.c_void_p, C.c_int, C.c_int],
     "ctm_get_stat": [C.c_void_p, C.c_char_p, C.POINTER(C.c_double)],
     "ctm_timers": [C.c_void_p, C.POINTER(C.c_double), C.c_int],
     "ctm_gemm_intervals": [C.c_void_p, C.POINTER(C.c_double), C.c_longlong, C.POINTER(C.c_longlong)],
@@ -224,6 +225,14 @@ class Engine:
             if st != CTM_OK:
                 self.h = h
                 self._ck(st, "set_option")
+
+    def set_comm(self, comm, rank, nranks):
+        """Rank group that shares this engine's units (include/ctm_hip.h: ctm_set_comm; a one-rank group in this build)."""
+        for h in self._handles.values():
+            st = self.lib.ctm_set_comm(h, C.c_void_p(comm or 0), int(rank), int(nranks))
+            if st != CTM_OK:
+                self.h = h
+                self._ck(st, "set_comm")
 
     def stat(self, key):
         tot = sum(w.stat(key) for w in self.workers)

@@ -3,7 +3,7 @@
 --asan: a second library, libctm_hip_asan.so, whose HOST side (dispatchers, arena, Krylov / Jacobi drivers, the C-ABI marshalling) is
 compiled with AddressSanitizer (-fsanitize=address -fno-gpu-sanitize: device code unchanged, -O1 -g -fno-omit-frame-pointer).  Run a
 test under it with
-    CTM_LIB=peps-torch_amd/libctm_hip_asan.so LD_PRELOAD=$(python peps-torch_amd/csrc/build.py --asan-runtime) \
+    CTM_LIB=peps-torch_amd/libctm_hip_asan.so LD_PRELOAD="$(python peps-torch_amd/csrc/build.py --asan-runtime) $(gcc -print-file-name=libstdc++.so.6)" \
     ASAN_OPTIONS=detect_leaks=0:protect_shadow_gap=0:abort_on_error=1 python -m pytest tests -m gpu -x -q
 (python itself is not instrumented, hence the preload; protect_shadow_gap=0 leaves the address ranges the HSA runtime maps alone)."""
 import os, subprocess, sys, shutil

@@ -68,6 +68,7 @@ struct ctm_ctx {
     double svd_null_tol = 1e-11;       // full decomposition: right vectors of s_i <= svd_null_tol s_0 are completed orthonormally (svd_full)
     int jacobi_inner_sweeps = 2;        // inner sweeps of the LDS eigensolver per visit of a pair (2 or 3 pairs per round)
     int jacobi_inner_sweeps_many = 1;   // ... when a round has >= 4 pairs (dense small SVDs, full-block Rayleigh-Ritz): measured faster
+    int jacobi_cross_only = 0;          // many-panel block Jacobi: only the first round of a sweep solves the full 64 x 64 pair problems, the others rotate cross pairs only
     int jacobi_verbose = 0;
     // leading-k block power iteration (svd_iter): enabled for n >= si_min_n, residual tolerance relative to s_0
     bool si_enable = true;
@@ -139,10 +140,10 @@ struct ctm_ctx {
     bool gemm_strip = true;       // streaming kernel for <= 64 rows times a big operand
     int strip_target_wgs = 512;   // K slices x column tiles of the strip kernel: fewer slices = fewer partials (measured 512 <= 1024, 256)
     int rows_kernel_min_m = 1, rows_kernel_min_m_kc = 1;   // LDS-tiled row-block kernel from this many rows (n-contiguous / k-contiguous big operand)
-    int rows_min_klen = 256;      // ... optional lower bound on the K slice (256 = off).  576 measured 8-12 % faster per D = 6 chi = 128 sweep
-                                  //     (n = 4608: 18 slices of 256 k are all prologue, epilogue and an 18-slab combine); not the default: the one
-                                  //     full GPU test run of the round with it ended in a core dump of the pytest process that the remaining GPU
-                                  //     budget did not allow to chase (the last two test files pass with it in isolation)
+    int rows_min_klen = 576;      // ... lower bound on the K slice: mid-size operands (n = 4608 = 36 column tiles) otherwise run 18 slices of 256 k that are all
+                                  //     prologue, epilogue and an 18-slab combine (D = 6 chi = 128 sweep +8-12 %; n >= 12288 keeps its slice count).  Round 3 saw one
+                                  //     full test run with 576 end in a core dump; round 4 could not reproduce it: the shape sweep through every epilogue
+                                  //     (tests/test_gpu_gemm_rows.py, ks = 1 included) and the whole suite under AddressSanitizer with 576 are clean
     int rows_target_wgs = 768;    // its workgroup count (column tiles x K slices): three per CU
     // Chip-filling launches (>= heavy_min_flops) of ALL contexts of a device run one at a time (device-side lock): the concurrent
     // units of a move overlap their latency-bound stages with each other and with ONE corner pass at a time, instead of four
@@ -173,6 +174,7 @@ struct ctm_ctx {
     // 4 = the same row-block products with 33..64 rows: MFMA-bound (16 flop per byte of the big operand), k_flops[4] holds flops
     double k_ms[5] = {0, 0, 0, 0, 0}, k_flops[5] = {0, 0, 0, 0, 0};
     long k_calls[5] = {0, 0, 0, 0, 0};
+    void* comm = nullptr; int comm_rank = 0, comm_nranks = 1;   // rank group sharing one unit (ctm_set_comm; column split: include/ctm_hip.h)
     bool cplx = false;                   // CTM_C128 context: every tensor pointer of the C-ABI is interleaved complex128
     void set_error(const std::string& s) { last_error = s; }
 };

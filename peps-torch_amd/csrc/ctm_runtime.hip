@@ -98,6 +98,17 @@ int ctm_sync(ctm_ctx* ctx) {
     return CTM_OK;
 }
 
+int ctm_set_comm(ctm_ctx* ctx, void* rccl_comm, int rank, int nranks) {
+    if (!ctx) return CTM_ERR_BADARG;
+    if (nranks < 1 || rank < 0 || rank >= nranks) { ctx->set_error("set_comm: rank outside [0, nranks)"); return CTM_ERR_BADARG; }
+    if (nranks > 1) {
+        ctx->set_error("set_comm: the column split of a unit over a rank group (include/ctm_hip.h) is not built: nranks must be 1");
+        return CTM_ERR_UNSUPPORTED;
+    }
+    ctx->comm = rccl_comm; ctx->comm_rank = rank; ctx->comm_nranks = nranks;      // a one-rank group: every collective is the identity
+    return CTM_OK;
+}
+
 int ctm_set_option(ctm_ctx* ctx, const char* key, double value) {
     const std::string k(key ? key : "");
     if (k == "jacobi_tol") ctx->jacobi_tol = value;
@@ -111,6 +122,7 @@ int ctm_set_option(ctm_ctx* ctx, const char* key, double value) {
     else if (k == "jacobi_inner_sweeps") ctx->jacobi_inner_sweeps = (int)value;
     else if (k == "jacobi_inner_sweeps_many") ctx->jacobi_inner_sweeps_many = (int)value;
     else if (k == "jacobi_verbose") ctx->jacobi_verbose = (int)value;
+    else if (k == "jacobi_cross_only") ctx->jacobi_cross_only = (int)value;
     else if (k == "si_enable") ctx->si_enable = value != 0.0;
     else if (k == "si_min_n") ctx->si_min_n = (int)value;
     else if (k == "si_max_iter") ctx->si_max_iter = (int)value;

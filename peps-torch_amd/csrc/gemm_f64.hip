@@ -688,9 +688,9 @@ int gemm_f64(ctm_ctx* ctx, const GemmDesc& d) {
         int target = ((long long)d.N * d.K >= (1ll << 27)) ? ctx->strip_target_wgs : 2 * ctx->strip_target_wgs;
         if (rows_kernel) target = ctx->rows_target_wgs;
         int ks = std::max(1, std::min(std::min((target + gx - 1) / gx, d.K / 256), 64));
-        // (option, off by default -- see rows_min_klen: mid-size operands, n = 4608 = 36 column tiles, run 18 slices of 256 k)
-        // (never down to a single slice: the direct-write epilogue of the row-block kernel, ks == 1, is not reached by any shape of the
-        //  default rule -- K >= 1024 here -- and has not been through the test suite)
+        // mid-size operands (n = 4608: 36 column tiles) would run 18 slices of 256 k: no slice shorter than rows_min_klen, but at least
+        // two slices (a single slice means N / 128 workgroups: 36 on 256 CUs).  The direct-write epilogue (ks == 1) is reached when the
+        // column tiles alone fill the target (N >= 128 * rows_target_wgs) or by option; tests/test_gpu_gemm_rows.py drives it.
         if (rows_kernel && ctx->rows_min_klen > 256 && ks > 2) ks = std::max(2, std::min(ks, d.K / ctx->rows_min_klen));
         int klen = (((d.K + ks - 1) / ks) + 15) / 16 * 16;
         ks = (d.K + klen - 1) / klen;

@@ -47,6 +47,7 @@ struct SmallEigParams {
     unsigned long long* stat_rel;   // max |g_ij| / max(sqrt(g_ii g_jj), tau2)  (bits of a non-negative double)
     unsigned long long* stat_abs;   // max |g_ij| / sqrt(g_ii g_jj) (classical measure, diagnostics only)
     int* flags;          // per pair: 1 if J != I (the apply GEMM skips the others)
+    int cross = 0;       // small_eig64_kernel: 1 = rotate only the 32 x 32 pairs (row of panel 0, row of panel 1), 32 rounds instead of 63
 };
 
 // floor of the pair measure: with `both`, a pair that contains a row at or above the floor is measured relative to its own rows only
@@ -262,6 +263,10 @@ __device__ __forceinline__ void rr_pair64(int r, int k, int& p, int& q) {
     if (k == 0) { a = 63; b = r; }
     p = min(a, b); q = max(a, b);
 }
+// cross pairs only: round r (0..31), slot k -> (row k of the first panel, row (k + r) mod 32 of the second).  The rows inside a panel
+// were made orthogonal by the one full round of the sweep (jacobi_rows: round 0) and are not rotated against each other again:
+// the block sweep then is the classical cyclic sweep -- every row pair once -- instead of 27 repetitions of the intra-panel pairs
+__device__ __forceinline__ void cross_pair64(int r, int k, int& p, int& q) { p = k; q = 32 + ((k + r) & 31); }
 
 __device__ __forceinline__ void jacobi_cs(double a, double b, double g, double tol, double tau2in, int both, double& c, double& s, bool& rot) {
     c = 1.0; s = 0.0; rot = false;
@@ -352,22 +357,23 @@ __global__ __launch_bounds__(1024 / BPT) void small_eig64_kernel(SmallEigParams 
 #ifdef CTM_KERNEL_CLOCKS
     long long ck_load = 0, ck_cs = 0, ck_upd = 0, ck_bar = 0;
 #endif
+    const int cross = p.cross, nrounds = cross ? H : M - 1;
     for (int sweep = 0; sweep < p.max_sweeps; ++sweep) {
-        for (int r = 0; r < M - 1; ++r) {
+        for (int r = 0; r < nrounds; ++r) {
 #ifdef CTM_KERNEL_CLOCKS
             const long long c0 = clock64();
 #endif
             const double (*S)[M + 1] = Wb[par];
             double (*D)[M + 1] = Wb[par ^ 1];
             int p2, q2;
-            rr_pair64(r, k2, p2, q2);
+            if (cross) cross_pair64(r, k2, p2, q2); else rr_pair64(r, k2, p2, q2);
             const double a2 = S[p2][p2], d2 = S[q2][q2], g2 = S[p2][q2];
             int p1[BPT], q1[BPT];
             double b00[BPT], b01[BPT], b10[BPT], b11[BPT], jp0[BPT], jq0[BPT], jp1[BPT], jq1[BPT];
 #pragma unroll
             for (int u = 0; u < BPT; ++u) {
                 const int k1 = kb + u * KS;
-                rr_pair64(r, k1, p1[u], q1[u]);
+                if (cross) cross_pair64(r, k1, p1[u], q1[u]); else rr_pair64(r, k1, p1[u], q1[u]);
                 b00[u] = S[p1[u]][p2]; b01[u] = S[p1[u]][q2]; b10[u] = S[q1[u]][p2]; b11[u] = S[q1[u]][q2];
 #ifndef CTM_EIG64_SKIP_J      // (timing experiment of tools/bench_small_kernels.hip: the eigenvector accumulation left out)
                 jp0[u] = Jm[k1][p2]; jq0[u] = Jm[k1][q2]; jp1[u] = Jm[k1 + 32][p2]; jq1[u] = Jm[k1 + 32][q2];
@@ -728,6 +734,9 @@ int jacobi_rows(ctm_ctx* ctx, double* X, int R, long long ld, int Cg, int Ctot, 
             SmallEigParams sp;
             sp.G = G; sp.nsplit = T->nsplit; sp.split_stride = (long long)pairs * m * m; sp.J = J; sp.m = m; sp.tol = ctx->jacobi_tol * 0.1; sp.max_sweeps = (pairs == 1) ? 12 : (pairs >= 4 ? ctx->jacobi_inner_sweeps_many : ctx->jacobi_inner_sweeps);
             sp.tau2 = tau2; sp.tau_both = abs_mode ? 2 : (tau_both ? 1 : 0); sp.stat_rel = stat; sp.stat_abs = stat + 1; sp.flags = flags;
+            // cross-only rotations in every round but the first of a sweep (which pairs every panel once and solves the full 64 x 64
+            // problems: the intra-panel pairs); many-panel problems only (the dense SVD of a Ritz matrix, full-block Rayleigh-Ritz)
+            sp.cross = (ctx->jacobi_cross_only && !cplx && m == 64 && ctx->eig64_pingpong && pairs >= 4 && r > 0) ? 1 : 0;
             if (cplx) CTM_LAUNCH(ctx, small_eig_c_kernel, dim3(pairs), dim3(256), 0, sp);
             else if (m == 64 && ctx->eig64_pingpong) {
                 if (ctx->eig64_bpt == 4) CTM_LAUNCH(ctx, small_eig64_kernel<4>, dim3(pairs), dim3(256), 0, sp);

@@ -17,8 +17,14 @@ except Exception:                                      # pragma: no cover
     dist = None
 
 
+# Test-only switch (tests/test_gpu_dist.py, tools/check_rccl_world1.py): treat an initialised process group of ONE rank as distributed,
+# so that every collective of this module (RCCL init, device buffers, the (re,im) view of complex128, the in-place all-gather,
+# sub-groups) executes on the single GPU the build loop has.  Never set by the product path.
+single_rank_is_distributed = False
+
+
 def is_distributed():
-    return dist is not None and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    return dist is not None and dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or single_rank_is_distributed)
 
 
 def world():
@@ -63,13 +69,13 @@ def prepare_groups(groups):
     """Collective creation of the process groups of `groups` (all ranks call this with the same list)."""
     if is_distributed():
         for g in groups:
-            if len(g) > 1:
+            if len(g) > 1 or single_rank_is_distributed:
                 _process_group(g)
 
 
 def allreduce_sum_group(t, members):
     """Sum of `t` over the ranks in `members` (complex128 travels as its (re,im) float64 view)."""
-    if not is_distributed() or len(members) < 2:
+    if not is_distributed() or (len(members) < 2 and not single_rank_is_distributed):
         return t
     buf = torch.view_as_real(t.contiguous()) if t.is_complex() else t.contiguous()
     dist.all_reduce(buf, group=_process_group(members))
@@ -173,7 +179,7 @@ def exchange(local, keys, shapes, like, owners=None):
 
 def allreduce_min_int_group(x, members, device):
     """Minimum of an integer over the ranks in `members` (a process group created by prepare_groups)."""
-    if not is_distributed() or len(members) < 2:
+    if not is_distributed() or (len(members) < 2 and not single_rank_is_distributed):
         return int(x)
     t = torch.tensor([int(x)], dtype=torch.int64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MIN, group=_process_group(members))

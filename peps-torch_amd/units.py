@@ -18,19 +18,39 @@ import backend
 
 
 class UnitPool:
-    def __init__(self, main_engine, nworkers):
+    """ONE pool per device.  Slots (stream + native worker context with its workspace arena) are created on demand and never
+    duplicated: a call that wants fewer units in flight than the pool has slots is limited to the LOWEST slots (`limit`), so the
+    number of arenas that ever grow is the maximum any call asked for -- not the sum over the different widths a run used (a full-rank
+    run at n >= 8192 alternates between 2 and 4 units in flight; two pools meant six contexts of ~30 GB high-water arena each)."""
+    MAX_SLOTS = 16
+
+    def __init__(self, main_engine):
         self.main = main_engine
         self.device = main_engine.device
-        self.n = nworkers
-        self.streams = [torch.cuda.Stream(self.device) for _ in range(nworkers)]
-        self.engines = [None] * nworkers
-        self.pool = ThreadPoolExecutor(max_workers=nworkers, thread_name_prefix="ctm-unit")
-        self.free = queue.Queue()
-        for slot in range(nworkers):
-            self.free.put(slot)
+        self.streams = []
+        self.engines = []
+        self.pool = ThreadPoolExecutor(max_workers=self.MAX_SLOTS, thread_name_prefix="ctm-unit")      # (threads start lazily)
+        self.busy = set()
+        self.cv = threading.Condition()
 
-    def _run(self, fn, item, ev0, delay=0.0):
-        slot = self.free.get()                                       # a worker context that is idle right now
+    def _take(self, limit):
+        with self.cv:
+            while True:
+                for slot in range(limit):
+                    if slot not in self.busy:
+                        self.busy.add(slot)
+                        while len(self.streams) <= slot:
+                            self.streams.append(torch.cuda.Stream(self.device)); self.engines.append(None)
+                        return slot
+                self.cv.wait()
+
+    def _give(self, slot):
+        with self.cv:
+            self.busy.discard(slot)
+            self.cv.notify_all()
+
+    def _run(self, fn, item, ev0, limit, delay=0.0):
+        slot = self._take(limit)                                     # an idle worker context among the first `limit`
         try:
             if delay > 0.0:
                 time.sleep(delay)
@@ -49,18 +69,19 @@ class UnitPool:
                 ev.record(s)
             return out, ev
         finally:
-            self.free.put(slot)
+            self._give(slot)
 
-    def map(self, fn, items, stagger=0.0):
-        """[fn(item) for item in items], at most `nworkers` at a time, each on its own stream/context; a worker takes the next
-        item as soon as it has issued its previous one (no barrier between groups of `nworkers` items)."""
+    def map(self, fn, items, limit, stagger=0.0):
+        """[fn(item) for item in items], at most `limit` at a time, each on its own stream/context; a worker takes the next
+        item as soon as it has issued its previous one (no barrier between groups of `limit` items)."""
         items = list(items)
+        limit = max(1, min(int(limit), self.MAX_SLOTS))
         main_stream = torch.cuda.current_stream(self.device)
         ev0 = torch.cuda.Event()
         ev0.record(main_stream)
-        # `stagger` seconds between the starts of the first `nworkers` items: units whose latency-bound phases (orthogonalisations,
+        # `stagger` seconds between the starts of the first `limit` items: units whose latency-bound phases (orthogonalisations,
         # Ritz extraction) would otherwise coincide run out of phase, so that one unit's small kernels overlap another's corner passes
-        futs = [self.pool.submit(self._run, fn, it, ev0, stagger * i if i < self.n else 0.0) for i, it in enumerate(items)]
+        futs = [self.pool.submit(self._run, fn, it, ev0, limit, stagger * i if i < limit else 0.0) for i, it in enumerate(items)]
         outs = []
         for f in futs:
             out, ev = f.result()
@@ -69,14 +90,35 @@ class UnitPool:
         return outs
 
 
+class PoolView:
+    """What pool_for hands out: the device's pool with the number of units this caller may have in flight."""
+
+    def __init__(self, pool, n):
+        self.pool, self.n = pool, n
+
+    def map(self, fn, items, stagger=0.0):
+        return self.pool.map(fn, items, self.n, stagger=stagger)
+
+
 _pools = {}
 _lock = threading.Lock()
 
 
+def _held_bytes(pool, nslots):
+    """Workspace the first `nslots` worker contexts of the device's pool hold right now (arenas are high-water: they do not shrink
+    between calls)."""
+    tot = 0.0
+    for e in (pool.engines[:nslots] if pool is not None else []):
+        if e is not None:
+            tot += e.own_stat("arena_total")
+    return tot
+
+
 def pool_for(engine, nunits, n, is_complex, est_bytes=None, large_n_units=None):
-    """UnitPool sized for `nunits` concurrent units of fused dimension n, or None when concurrency is off / pointless
-    (stand-in engines, a single unit, or not enough HBM for one workspace arena per unit).  est_bytes overrides the
-    per-unit workspace estimate of a sweep unit."""
+    """The device's UnitPool limited to the number of concurrent units of fused dimension n that fit, or None when concurrency is
+    off / pointless (stand-in engines, a single unit, or not enough HBM for one workspace arena per unit).  est_bytes overrides the
+    per-unit workspace estimate of a sweep unit.  The HBM budget (half the device) is counted across everything the pool's
+    contexts already hold, not per call."""
     if nunits < 2 or not hasattr(engine, "spawn_worker"):
         return None
     total = torch.cuda.get_device_properties(engine.device).total_memory
@@ -93,11 +135,21 @@ def pool_for(engine, nunits, n, is_complex, est_bytes=None, large_n_units=None):
     nw = min(nw, int(os.environ.get("CTM_MAX_CONCURRENT_UNITS", nw)))       # experiment knob
     if nw < 2:
         return None
-    key = (engine.device.index, nw)
+    key = engine.device.index
     with _lock:
-        if key not in _pools:
-            _pools[key] = UnitPool(engine, nw)
-        return _pools[key]
+        pool = _pools.get(key)
+        if pool is None:
+            pool = _pools[key] = UnitPool(engine)
+        # contexts beyond the slots this call uses keep their arenas: when they and this call's estimate do not fit the budget
+        # together, give the idle ones back (between calls every arena stack is empty)
+        idle = pool.engines[nw:]
+        if idle and _held_bytes(pool, len(pool.engines)) - _held_bytes(pool, nw) + nw * est > 0.5 * total:
+            with pool.cv:
+                if not pool.busy:
+                    for e in idle:
+                        if e is not None:
+                            e.trim()
+        return PoolView(pool, nw)
 
 
 def shutdown():

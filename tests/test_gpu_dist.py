@@ -55,3 +55,18 @@ def test_differentiable_moves_on_two_ranks_give_the_reference_gradient(tmp_path,
         for k in o.files:
             if k.startswith("grad_"):
                 assert float(np.abs(o[k] - g[k]).max()) < 1e-9 * max(1.0, float(np.abs(g[k]).max())), (rank, k)
+
+
+def test_rccl_backend_executes_every_collective_on_one_rank():
+    """backend "nccl" (RCCL) with a one-rank process group on this GPU: tools/check_rccl_world1.py drives every collective of parallel.py
+    on device buffers (both dtypes, both branches of exchange(), sub-groups, autograd exchange), then two sharded sweeps + energy
+    bit-identical to the run without a process group, and the communicator entry of the C-ABI."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "check_rccl_world1.py"), str(port)], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["backend"] == "nccl" and len(out["checks"]) == 2
+    assert "not built" in out["set_comm_two_ranks"]
+    assert out["comm_s_torch.float64"] > 0.0 and out["comm_s_torch.complex128"] > 0.0

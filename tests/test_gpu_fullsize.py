@@ -143,6 +143,40 @@ def test_unit_of_the_complex_config_at_full_size(eng):
     eng.trim()
 
 
+def test_complex_config_in_its_full_rank_regime(eng):
+    """BASELINE configs[4] (generic 2x2, D = 8, chi = 384, complex128, n = 24576) where it is hard: signed complex tensors, sweeps from
+    the CTMRG init until every corner has at least chi/2 values above 1e-8 (rank D^2, D^4, ... : a few sweeps), then two more sweeps --
+    whose 64 truncations must have run the COMPLEX block Krylov solver (reference semantics: ctm_projectors.py:263-283,
+    linalg/custom_svd.py:66-95 on the full n x n matrix) -- then the unit property set on that environment: fused implicit operator
+    against the explicit n x n matrix, residuals of both relations <= 1e-12 s0, orthonormal factors, deflated norm, biorthogonality,
+    host ARPACK on the leading 20 values."""
+    from ctm.generic.env import ENV, init_env
+    free, _ = torch.cuda.mem_get_info()
+    if free < 200e9:
+        pytest.skip("needs ~200 GB of free HBM")
+    chi, D = 384, 8
+    st = _state(D, 4, cplx=True, signed=True)
+    env = ENV(chi, st); init_env(st, env)
+    rank = lambda: int(min((s_ > 1e-8 * s_[0]).sum() for s_ in env.get_spectra().values()))
+    warm = 0
+    while rank() < chi // 2:
+        assert warm < 6, "ceil(chi / D^2) = 6 warm-up sweeps did not fill the environment"
+        _sweep(st, env, 1); warm += 1
+    lz0, si0 = eng.stat("lz_hits"), eng.stat("si_fallbacks")
+    _sweep(st, env, 2)
+    assert rank() >= chi // 2
+    assert eng.stat("lz_hits") >= lz0 + 48, "the truncations of a full-rank complex sweep did not run the block Krylov solver"
+    assert eng.stat("si_fallbacks") == si0                                # nothing fell back to the dense decomposition
+    for k, t in list(env.C.items()) + list(env.T.items()):
+        assert abs(float(t.abs().max()) - 1.0) < 1e-13, k
+    env.__dict__.pop("_corner_cache", None)                               # room for the explicit n x n matrices of the check (9.7 GB each)
+    eng.trim()
+    lz1 = eng.stat("lz_hits")
+    n = _check_unit(eng, st, env, chi, host_arpack=True)
+    assert n == chi * D * D and eng.stat("lz_hits") >= lz1 + 2            # implicit and explicit operator both went through it
+    eng.trim()
+
+
 def test_sweep_invariances_at_full_size(eng):
     from ctm.generic.env import ENV, init_env
     D, chi = 6, 128

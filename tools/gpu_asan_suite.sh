@@ -8,4 +8,7 @@ export ASAN_OPTIONS=detect_leaks=0:protect_shadow_gap=0:abort_on_error=1:halt_on
 export CTM_ENGINE_OPTS="$1"
 shift
 ulimit -c 0
-LD_PRELOAD=$(python peps-torch_amd/csrc/build.py --asan-runtime) python -X faulthandler -m pytest "$@" 2>&1 | tail -60
+# (the runtime intercepts dlopen, so the RUNPATH of libtorch no longer finds its siblings: libcaffe2_nvrtc.so)
+export LD_LIBRARY_PATH=$(python -c "import os, torch; print(os.path.join(os.path.dirname(torch.__file__), 'lib'))"):$LD_LIBRARY_PATH
+# (libstdc++ preloaded as well: the runtime resolves the real __cxa_throw when it initialises, before python has loaded any C++ library)
+LD_PRELOAD="$(python peps-torch_amd/csrc/build.py --asan-runtime) $(gcc -print-file-name=libstdc++.so.6)" python -X faulthandler -m pytest "$@" 2>&1 | tail -60
