@@ -38,8 +38,18 @@ DEFAULT_CONFIG = "generic_D8_chi256"       # the configuration BASELINE.json's n
 FP64_MFMA_PEAK_TFLOPS = 78.6               # MI355X FP64 matrix peak (v_mfma_f64_16x16x4_f64, 32 flop/clk/SIMD)
 
 
-def synth_sites(kind, D, seed=1, dtype="f64"):
+def synth_sites(kind, D, seed=1, dtype="f64", signed=False):
+    """Random site tensors as the reference scripts build them: entries U[0,1) (re and im parts for complex128), A /= max|A|.
+    signed: entries U(-1,1) -- drawn from the same stream, re and im parts centred SEPARATELY before the normalisation (round 3 centred
+    the normalised complex tensor with 2 A - (1 + i): |A| <= 0.71 after A /= max|A|, so the parts kept a mean of -0.3 and the
+    "signed" complex128 state was as low-rank as the positive one: 13 corner values above 1e-8)."""
     rng = np.random.default_rng(seed)
+    if signed:
+        base = rng.random
+        class _R:                                   # same stream, centred
+            @staticmethod
+            def random(shape): return 2.0 * base(shape) - 1.0
+        rng = _R
     if kind == "c4v" and dtype == "c128":
         from groups.pg import make_c4v_symm
         A = make_c4v_symm(torch.from_numpy(rng.random((2, D, D, D, D)))) \
@@ -147,10 +157,7 @@ def energy_parity(dev, dtype="f64", D=3, chi=36, nsweeps=3, signed=False):
     from ctm.generic.env import ENV, init_env
     from ctm.generic import ctmrg
     from models import j1j2
-    sites = synth_sites("generic", D, seed=3, dtype=dtype)
-    if signed:
-        sites = {k: (2.0 * v - (1.0 + 1.0j if np.iscomplexobj(v) else 1.0)) for k, v in sites.items()}
-        sites = {k: v / np.abs(v).max() for k, v in sites.items()}
+    sites = synth_sites("generic", D, seed=3, dtype=dtype, signed=signed)
     st = IPEPS({k: torch.from_numpy(v).to(dev) for k, v in sites.items()})
     env = ENV(chi, st); init_env(st, env)
     for _ in range(nsweeps):
@@ -251,10 +258,7 @@ def run_workload(args, eng, dev, kind, D, chi, dtype, signed, steps, warmup, wor
     from ctm.generic import ctmrg
     from ctm.one_site_c4v.env_c4v import ENV_C4V, init_env as init_env_c4v
     from ctm.one_site_c4v import ctmrg_c4v
-    sites = synth_sites(kind, D, dtype=dtype)
-    if signed:
-        sites = {k: (2.0 * v - (1.0 + 1.0j if np.iscomplexobj(v) else 1.0)) for k, v in sites.items()}
-        sites = {k: v / np.abs(v).max() for k, v in sites.items()}
+    sites = synth_sites(kind, D, dtype=dtype, signed=signed)
     if kind == "c4v":
         state = IPEPS_C4V(torch.from_numpy(sites[(0, 0)]).to(dev))
         env = ENV_C4V(chi, state); init_env_c4v(state, env)
@@ -757,10 +761,18 @@ def main():
         except OSError:
             line["detail"] = "stderr, prefix BENCH_DETAIL"
         print("BENCH_DETAIL " + json.dumps(out), file=sys.stderr, flush=True)
-        print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # the metric line is the LAST thing on stdout: RCCL announces itself through C stdio ("Librccl path : ..."), which sits in a
+        # buffer until it is flushed -- at exit, i.e. after a line printed here -- unless it is flushed first
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":

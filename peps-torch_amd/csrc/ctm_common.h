@@ -69,6 +69,7 @@ struct ctm_ctx {
     int jacobi_inner_sweeps = 2;        // inner sweeps of the LDS eigensolver per visit of a pair (2 or 3 pairs per round)
     int jacobi_inner_sweeps_many = 1;   // ... when a round has >= 4 pairs (dense small SVDs, full-block Rayleigh-Ritz): measured faster
     int jacobi_cross_only = 0;          // many-panel block Jacobi: only the first round of a sweep solves the full 64 x 64 pair problems, the others rotate cross pairs only
+    int jacobi_rot_apply = 0;           // many-panel block Jacobi: rotations recorded by the eigensolver and applied to the rows on the vector ALUs (no J, no apply GEMM)
     int jacobi_verbose = 0;
     // leading-k block power iteration (svd_iter): enabled for n >= si_min_n, residual tolerance relative to s_0
     bool si_enable = true;
@@ -103,6 +104,10 @@ struct ctm_ctx {
     int lz_first = 0;                   // > 0: first Ritz extraction after this many block steps (development); 0: policy of svd_lanczos
     int lz_stride = 0;                  // > 0: fixed distance between Ritz extractions (development); 0: predicted from the residual estimate
     double lz_first_factor = 3.25;      // cold default: first extraction when the basis holds this many times k rows
+    double lz_first_factor32 = 2.5;     // ... with 32-row blocks
+    int lz_block = 0;                   // rows per block of the real block Krylov recurrence: 64, 32, or 0 = 32 for k > lz_block32_min_k
+    int lz_block32_min_k = 1 << 30;     // (0 -> always 32; default: never, until measured)
+    long lz_total_rows = 0;             // basis rows over all accepted solves (steps x block)
     bool lz_verify_op = false;          // additionally check both relations of the Ritz triplets with operator applications (debug / tests)
     long lz_extractions = 0; double lz_last_est = 0.0; int lz_last_steps = 0;
     double jacobi_quad_exit = 0.0;      // (internal) jacobi_rows stops after a sweep that FOUND <= this measure (quadratic regime)
@@ -144,6 +149,7 @@ struct ctm_ctx {
                                   //     prologue, epilogue and an 18-slab combine (D = 6 chi = 128 sweep +8-12 %; n >= 12288 keeps its slice count).  Round 3 saw one
                                   //     full test run with 576 end in a core dump; round 4 could not reproduce it: the shape sweep through every epilogue
                                   //     (tests/test_gpu_gemm_rows.py, ks = 1 included) and the whole suite under AddressSanitizer with 576 are clean
+    bool rows_quantise = true;    // ... its slice count is rounded down so that the last round of workgroups over the 256 CUs is nearly full
     int rows_target_wgs = 768;    // its workgroup count (column tiles x K slices): three per CU
     // Chip-filling launches (>= heavy_min_flops) of ALL contexts of a device run one at a time (device-side lock): the concurrent
     // units of a move overlap their latency-bound stages with each other and with ONE corner pass at a time, instead of four

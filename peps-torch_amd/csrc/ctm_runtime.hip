@@ -123,6 +123,7 @@ int ctm_set_option(ctm_ctx* ctx, const char* key, double value) {
     else if (k == "jacobi_inner_sweeps_many") ctx->jacobi_inner_sweeps_many = (int)value;
     else if (k == "jacobi_verbose") ctx->jacobi_verbose = (int)value;
     else if (k == "jacobi_cross_only") ctx->jacobi_cross_only = (int)value;
+    else if (k == "jacobi_rot_apply") ctx->jacobi_rot_apply = (int)value;
     else if (k == "si_enable") ctx->si_enable = value != 0.0;
     else if (k == "si_min_n") ctx->si_min_n = (int)value;
     else if (k == "si_max_iter") ctx->si_max_iter = (int)value;
@@ -147,6 +148,7 @@ int ctm_set_option(ctm_ctx* ctx, const char* key, double value) {
     else if (k == "rows_kernel_min_m_kc") ctx->rows_kernel_min_m_kc = (int)value;
     else if (k == "rows_target_wgs") ctx->rows_target_wgs = (int)value;
     else if (k == "rows_min_klen") ctx->rows_min_klen = (int)value;
+    else if (k == "rows_quantise") ctx->rows_quantise = value != 0.0;
     else if (k == "rows_fused_reduce") ctx->rows_fused_reduce = value != 0.0;
     else if (k == "heavy_serial") ctx->heavy_serial = value != 0.0;
     else if (k == "heavy_min_flops") ctx->heavy_min_flops = value;
@@ -171,6 +173,9 @@ int ctm_set_option(ctm_ctx* ctx, const char* key, double value) {
     else if (k == "lz_first") ctx->lz_first = (int)value;
     else if (k == "lz_stride") ctx->lz_stride = (int)value;
     else if (k == "lz_first_factor") ctx->lz_first_factor = value;
+    else if (k == "lz_first_factor32") ctx->lz_first_factor32 = value;
+    else if (k == "lz_block") ctx->lz_block = (int)value;
+    else if (k == "lz_block32_min_k") ctx->lz_block32_min_k = (int)value;
     else if (k == "lz_verify_op") ctx->lz_verify_op = value != 0.0;
     else if (k == "lz_async") ctx->lz_async = value != 0.0;
     else if (k == "lz_jacobi_block") ctx->lz_jacobi_block = (int)value;
@@ -214,6 +219,7 @@ int ctm_get_stat(ctm_ctx* ctx, const char* key, double* value) {
     else if (k == "svd_polar_solves") *value = (double)ctx->svd_polar_solves;
     else if (k == "lz_hits") *value = (double)ctx->lz_hits;
     else if (k == "lz_total_steps") *value = (double)ctx->lz_total_steps;
+    else if (k == "lz_total_rows") *value = (double)ctx->lz_total_rows;
     else if (k == "lz_extractions") *value = (double)ctx->lz_extractions;
     else if (k == "lz_last_est") *value = ctx->lz_last_est;
     else if (k == "lz_async_fallbacks") *value = (double)ctx->lz_async_fallbacks;
@@ -251,7 +257,7 @@ int ctm_gemm_intervals(ctm_ctx* ctx, double* out, long long capacity, long long*
 int ctm_timers(ctm_ctx* ctx, double* out8, int reset) {
     gemm_timing_drain(ctx);       // event-timed phases are accumulated when their events are read
     for (int i = 0; i < CTM_T_COUNT; ++i) { if (out8) out8[i] = ctx->timers[i]; if (reset) ctx->timers[i] = 0.0; }
-    if (reset) { ctx->gemm_flops = 0; ctx->gemm_calls = 0; ctx->layer2_flops = 0; ctx->layer2_calls = 0; ctx->total_sweeps = 0; ctx->jacobi_calls = 0; ctx->si_hits = 0; ctx->si_fallbacks = 0; ctx->si_total_iters = 0; ctx->si_warm_starts = 0; ctx->eigh_warm_hits = 0; ctx->eigh_warm_rejects = 0; ctx->eigh_orth_hits = 0; ctx->eigh_orth_fails = 0; ctx->svd_polar_completions = 0; ctx->svd_eig_completions = 0; ctx->svd_polar_solves = 0; ctx->lz_hits = 0; ctx->lz_total_steps = 0; ctx->lz_extractions = 0; ctx->absorb_bytes = 0; ctx->absorb_calls = 0; }
+    if (reset) { ctx->gemm_flops = 0; ctx->gemm_calls = 0; ctx->layer2_flops = 0; ctx->layer2_calls = 0; ctx->total_sweeps = 0; ctx->jacobi_calls = 0; ctx->si_hits = 0; ctx->si_fallbacks = 0; ctx->si_total_iters = 0; ctx->si_warm_starts = 0; ctx->eigh_warm_hits = 0; ctx->eigh_warm_rejects = 0; ctx->eigh_orth_hits = 0; ctx->eigh_orth_fails = 0; ctx->svd_polar_completions = 0; ctx->svd_eig_completions = 0; ctx->svd_polar_solves = 0; ctx->lz_hits = 0; ctx->lz_total_steps = 0; ctx->lz_total_rows = 0; ctx->lz_extractions = 0; ctx->absorb_bytes = 0; ctx->absorb_calls = 0; }
     return CTM_OK;
 }
 

@@ -457,14 +457,18 @@ __global__ __launch_bounds__(256, 3) void gemm_rows_kernel(StripParams p) {
     d4 acc[TMW][2];
 #pragma unroll
     for (int i = 0; i < TMW; ++i) { acc[i][0] = (d4){0., 0., 0., 0.}; acc[i][1] = (d4){0., 0., 0., 0.}; }
-    d2 ra[NA], rb[4];
-    auto load_tile = [&]() {
+    // Two register sets: while tile kt is multiplied out of LDS, tile kt + 1 waits in one set (loaded during the previous iteration, stored
+    // to the other LDS buffer after the MFMAs) and tile kt + 2 is being loaded into the other -- a load has two compute phases to land.
+    // With three workgroups per CU (big operands) one phase was enough; a mid-size operand (n = 4608: 36 column tiles x 7 slices) runs ONE
+    // workgroup per CU and paid the HBM latency in every K tile (64 rows x n = 4608: 127 us alone for 2.7e9 flop).
+    d2 ra0[NA], rb0[4], ra1[NA], rb1[4];
+    auto load_tile = [&](d2* ra, d2* rb) {
 #pragma unroll
         for (int i = 0; i < NA; ++i) { if (a_on[i]) ra[i] = *(const d2*)ap[i]; ap[i] += BK; }
 #pragma unroll
         for (int i = 0; i < 4; ++i) { rb[i] = __builtin_nontemporal_load((const d2*)bp[i]); bp[i] += b_step; }
     };
-    auto store_tile = [&](int buf) {
+    auto store_tile = [&](int buf, const d2* ra, const d2* rb) {
         double* as = As + buf * BK * LDA;
         double* bs = Bs + buf * BK * LDB;
 #pragma unroll
@@ -475,13 +479,8 @@ __global__ __launch_bounds__(256, 3) void gemm_rows_kernel(StripParams p) {
             else { bs[b_lds[i]] = rb[i][0]; bs[b_lds[i] + LDB] = rb[i][1]; }
         }
     };
-    load_tile();
-    store_tile(0);
-    __syncthreads();
     const int lr = lane & 15, lk = lane >> 4;
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) load_tile();
+    auto compute = [&](int buf) {
         const double* as = As + buf * BK * LDA + lr;
         const double* bs = Bs + buf * BK * LDB + wn * 32 + lr;
 #pragma unroll
@@ -497,9 +496,25 @@ __global__ __launch_bounds__(256, 3) void gemm_rows_kernel(StripParams p) {
                 acc[i][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[1], acc[i][1], 0, 0, 0);
             }
         }
-        if (kt + 1 < nk) store_tile(buf ^ 1);
+    };
+    load_tile(ra0, rb0);
+    store_tile(0, ra0, rb0);
+    if (nk > 1) load_tile(ra1, rb1);                        // tile 1
+    __syncthreads();
+    int kt = 0;
+    for (; kt + 1 < nk; kt += 2) {
+        // even iteration: tile kt in LDS buffer 0, tile kt + 1 in set 1, set 0 free
+        if (kt + 2 < nk) load_tile(ra0, rb0);
+        compute(0);
+        store_tile(1, ra1, rb1);
+        __syncthreads();
+        // odd iteration: tile kt + 1 in LDS buffer 1, tile kt + 2 in set 0, set 1 free
+        if (kt + 3 < nk) load_tile(ra1, rb1);
+        compute(1);
+        if (kt + 2 < nk) store_tile(0, ra0, rb0);
         __syncthreads();
     }
+    if (kt < nk) { compute(0); __syncthreads(); }           // (nk odd: the last tile sits in buffer 0)
     if (p.ks == 1) {          // no K split: finished values
 #pragma unroll
         for (int i = 0; i < TMW; ++i)
@@ -691,7 +706,21 @@ int gemm_f64(ctm_ctx* ctx, const GemmDesc& d) {
         // mid-size operands (n = 4608: 36 column tiles) would run 18 slices of 256 k: no slice shorter than rows_min_klen, but at least
         // two slices (a single slice means N / 128 workgroups: 36 on 256 CUs).  The direct-write epilogue (ks == 1) is reached when the
         // column tiles alone fill the target (N >= 128 * rows_target_wgs) or by option; tests/test_gpu_gemm_rows.py drives it.
-        if (rows_kernel && ctx->rows_min_klen > 256 && ks > 2) ks = std::max(2, std::min(ks, d.K / ctx->rows_min_klen));
+        if (rows_kernel && ctx->rows_min_klen > 256 && ks > 2) {
+            ks = std::max(2, std::min(ks, d.K / ctx->rows_min_klen));
+            // ... and no partial round of workgroups: 36 column tiles x 8 slices = 288 workgroups on 256 CUs leave 32 CUs with two
+            // MFMA-bound workgroups and the others with one (the launch takes as long as 512); 7 slices = 252 fill one round.  Among the
+            // slice counts allowed above, take the largest whose workgroup count is at most a multiple of the CU count that it nearly
+            // fills (>= 85 % of the last round).
+            if (ctx->rows_quantise && gx * ks > 128) {
+                int best = ks;
+                for (int c = ks; c >= 2; --c) {
+                    const int w = gx * c, rounds = (w + 255) / 256;
+                    if (w >= rounds * 256 * 0.85) { best = c; break; }
+                }
+                ks = best;
+            }
+        }
         int klen = (((d.K + ks - 1) / ks) + 15) / 16 * 16;
         ks = (d.K + klen - 1) / klen;
         // the row-block kernel sums its K slices inside the launch (last workgroup of a column tile); the strip kernel keeps the

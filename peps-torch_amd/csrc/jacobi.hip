@@ -48,6 +48,8 @@ struct SmallEigParams {
     unsigned long long* stat_abs;   // max |g_ij| / sqrt(g_ii g_jj) (classical measure, diagnostics only)
     int* flags;          // per pair: 1 if J != I (the apply GEMM skips the others)
     int cross = 0;       // small_eig64_kernel: 1 = rotate only the 32 x 32 pairs (row of panel 0, row of panel 1), 32 rounds instead of 63
+    double* rot = nullptr;   // small_eig64_kernel<.., true>: per pair 63 x 32 rotations (c, s) of the ONE pass, instead of the accumulated J
+    int* perm = nullptr;     // ... and the final position of every row (eigenvalues descending)
 };
 
 // floor of the pair measure: with `both`, a pair that contains a row at or above the floor is measured relative to its own rows only
@@ -290,11 +292,14 @@ __device__ __forceinline__ void jacobi_cs(double a, double b, double g, double t
     }
 }
 
-template <int BPT>     // 2x2 blocks per thread: 1024 / BPT threads per workgroup
+// NOJ: the eigenvector matrix is not accumulated (half of the LDS traffic of a round: the kernel is LDS-bandwidth bound, 143 KB per round
+// against 128 B/clk); the (c, s) of every rotation of the ONE pass go to p.rot and the final row order to p.perm, and
+// rot_apply64_kernel applies the sequence to the panel rows -- the same arithmetic as X <- J^T X, done on the vector ALUs, one column per lane.
+template <int BPT, bool NOJ = false>     // 2x2 blocks per thread: 1024 / BPT threads per workgroup
 __global__ __launch_bounds__(1024 / BPT) void small_eig64_kernel(SmallEigParams p) {
     constexpr int M = 64, H = 32, NTH = 1024 / BPT, NW = NTH / 64, KS = H / BPT, EPT = (M * M) / NTH;
     __shared__ double Wb[2][M][M + 1];
-    __shared__ double Jm[M][M + 1];
+    __shared__ double Jm[NOJ ? 1 : M][M + 1];
     __shared__ double red[16];
     __shared__ int rot_flag;
     __shared__ int rank_of[M];
@@ -311,7 +316,7 @@ __global__ __launch_bounds__(1024 / BPT) void small_eig64_kernel(SmallEigParams 
             for (int u = 0; u < EPT; ++u) acc[u] += Gs[tid + u * NTH];
         }
 #pragma unroll
-        for (int u = 0; u < EPT; ++u) { const int q = tid + u * NTH, r = q >> 6, c = q & 63; Wb[0][r][c] = acc[u]; Jm[r][c] = (r == c) ? 1.0 : 0.0; }
+        for (int u = 0; u < EPT; ++u) { const int q = tid + u * NTH, r = q >> 6, c = q & 63; Wb[0][r][c] = acc[u]; if (!NOJ) Jm[r][c] = (r == c) ? 1.0 : 0.0; }
     }
     __syncthreads();
     {
@@ -375,15 +380,14 @@ __global__ __launch_bounds__(1024 / BPT) void small_eig64_kernel(SmallEigParams 
                 const int k1 = kb + u * KS;
                 if (cross) cross_pair64(r, k1, p1[u], q1[u]); else rr_pair64(r, k1, p1[u], q1[u]);
                 b00[u] = S[p1[u]][p2]; b01[u] = S[p1[u]][q2]; b10[u] = S[q1[u]][p2]; b11[u] = S[q1[u]][q2];
-#ifndef CTM_EIG64_SKIP_J      // (timing experiment of tools/bench_small_kernels.hip: the eigenvector accumulation left out)
-                jp0[u] = Jm[k1][p2]; jq0[u] = Jm[k1][q2]; jp1[u] = Jm[k1 + 32][p2]; jq1[u] = Jm[k1 + 32][q2];
-#endif
+                if (!NOJ) { jp0[u] = Jm[k1][p2]; jq0[u] = Jm[k1][q2]; jp1[u] = Jm[k1 + 32][p2]; jq1[u] = Jm[k1 + 32][q2]; }
             }
 #ifdef CTM_KERNEL_CLOCKS
             __builtin_amdgcn_s_waitcnt(0); const long long c1 = clock64();
 #endif
             double c2, s2; bool r2;
             jacobi_cs(a2, d2, g2, p.tol, p.tau2, p.tau_both, c2, s2, r2);
+            if (NOJ && tid < H) { double* ro = p.rot + ((size_t)blockIdx.x * (M - 1) + r) * (2 * H); ro[2 * k2] = c2; ro[2 * k2 + 1] = s2; }
 #ifdef CTM_KERNEL_CLOCKS
             __builtin_amdgcn_sched_barrier(0); const long long c2k = clock64(); __builtin_amdgcn_sched_barrier(0);
 #endif
@@ -397,12 +401,10 @@ __global__ __launch_bounds__(1024 / BPT) void small_eig64_kernel(SmallEigParams 
                 const double t10 = c2 * b10[u] - s2 * b11[u], t11 = s2 * b10[u] + c2 * b11[u];
                 D[p1[u]][p2] = c1 * t00 - s1 * t10; D[p1[u]][q2] = c1 * t01 - s1 * t11;
                 D[q1[u]][p2] = s1 * t00 + c1 * t10; D[q1[u]][q2] = s1 * t01 + c1 * t11;
-#ifndef CTM_EIG64_SKIP_J
-                if (r2) {
+                if (!NOJ && r2) {
                     Jm[k1][p2] = c2 * jp0[u] - s2 * jq0[u]; Jm[k1][q2] = s2 * jp0[u] + c2 * jq0[u];
                     Jm[k1 + 32][p2] = c2 * jp1[u] - s2 * jq1[u]; Jm[k1 + 32][q2] = s2 * jp1[u] + c2 * jq1[u];
                 }
-#endif
                 if (r2 && k1 == k2) rot_flag = 1;
             }
             par ^= 1;
@@ -432,8 +434,94 @@ __global__ __launch_bounds__(1024 / BPT) void small_eig64_kernel(SmallEigParams 
         rank_of[tid] = rk;
     }
     __syncthreads();
+    if (NOJ) { if (tid < M) p.perm[(size_t)blockIdx.x * M + tid] = rank_of[tid]; return; }
 #pragma unroll
     for (int u = 0; u < EPT; ++u) { const int q = tid + u * NTH, r = q >> 6, c = q & 63; Jout[r * M + rank_of[c]] = Jm[r][c]; }
+}
+
+// The rotations of one pass of small_eig64_kernel<.., true> applied to the 64 rows of a panel pair, in place: lane = one column, its 64
+// values in registers (the schedule is static, the loops unroll completely), (c, s) of a rotation are wave-uniform (scalar loads).
+// Row update of X <- J^T X for J = R_1 R_2 ...: x_p <- c x_p - s x_q, x_q <- s x_p + c x_q, in the order the kernel rotated; then row c
+// moves to position perm[c].  CROSS: the 32-round cross schedule (cross_pair64), else the 63-round round robin (rr_pair64).
+template <bool CROSS>
+__global__ __launch_bounds__(256) void rot_apply64_kernel(double* __restrict__ X, long long ld, int cols, const GemmOff* __restrict__ offs,
+                                                          const double* __restrict__ rot, const int* __restrict__ perm, const int* __restrict__ flags) {
+    constexpr int M = 64, H = 32;
+    const int pair = blockIdx.y;
+    if (flags[pair] == 0) return;
+    const int col = blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= cols) return;
+    const GemmOff o = offs[pair];
+    double* r0 = X + o.b0 + col;
+    double* r1 = X + o.b1 + col;
+    const double* ro = rot + (size_t)pair * (M - 1) * (2 * H);
+    const int* pm = perm + (size_t)pair * M;
+    // The schedule of a round is a FIXED pattern of register positions when the rows travel through the registers instead (the round
+    // loop then need not unroll: 63 x 32 rotations exceed the unroll budget, and a rolled loop with computed row indices would put the
+    // column into scratch memory):
+    //   round robin -- w[i] holds row (i + r) mod 63, row 63 stays in f: the pairs of round r are (f, w[0]) and (w[k], w[63 - k]);
+    //   cross       -- u[j] holds row 32 + (j + r) mod 32: the pairs are (v[k], u[k]);  one register rotation per round.
+    if (CROSS) {
+        double v[H], u[H];
+#pragma unroll
+        for (int i = 0; i < H; ++i) { v[i] = r0[(long long)i * ld]; u[i] = r1[(long long)i * ld]; }
+#pragma unroll 1
+        for (int r = 0; r < H; ++r) {
+            const double* cs = ro + (size_t)r * (2 * H);
+#pragma unroll
+            for (int k = 0; k < H; ++k) {
+                const double c = cs[2 * k], s = cs[2 * k + 1];
+                const double xp = v[k], xq = u[k];
+                v[k] = c * xp - s * xq; u[k] = s * xp + c * xq;
+            }
+            const double t = u[0];
+#pragma unroll
+            for (int i = 0; i + 1 < H; ++i) u[i] = u[i + 1];
+            u[H - 1] = t;
+        }
+        // after 32 rotations of the registers u[j] holds row 32 + j again
+#pragma unroll
+        for (int i = 0; i < H; ++i) {
+            const int d0 = pm[i], d1 = pm[H + i];                 // (uniform)
+            *(d0 < H ? r0 + (long long)d0 * ld : r1 + (long long)(d0 - H) * ld) = v[i];
+            *(d1 < H ? r0 + (long long)d1 * ld : r1 + (long long)(d1 - H) * ld) = u[i];
+        }
+        return;
+    }
+    double w[M - 1], f;
+#pragma unroll
+    for (int i = 0; i < M - 1; ++i) w[i] = i < H ? r0[(long long)i * ld] : r1[(long long)(i - H) * ld];
+    f = r1[(long long)(H - 1) * ld];
+#pragma unroll 1
+    for (int r = 0; r < M - 1; ++r) {
+        const double* cs = ro + (size_t)r * (2 * H);
+        {   // slot 0: rows (r, 63), r < 63: p = w[0], q = f
+            const double c = cs[0], s = cs[1];
+            const double xp = w[0], xq = f;
+            w[0] = c * xp - s * xq; f = s * xp + c * xq;
+        }
+#pragma unroll
+        for (int k = 1; k < H; ++k) {
+            // rows a = (r + k) mod 63 in w[k], b = (r - k) mod 63 in w[63 - k]; the recorded (c, s) belong to (p, q) = (min, max)
+            int a = r + k; a = (a >= 63) ? a - 63 : a;
+            int b = r - k + 63; b = (b >= 63) ? b - 63 : b;
+            const double c = cs[2 * k], s0 = cs[2 * k + 1];
+            const double s = a < b ? s0 : -s0;                   // (uniform)
+            const double xa = w[k], xb = w[M - 1 - k];
+            w[k] = c * xa - s * xb; w[M - 1 - k] = s * xa + c * xb;
+        }
+        const double t = w[0];
+#pragma unroll
+        for (int i = 0; i + 1 < M - 1; ++i) w[i] = w[i + 1];
+        w[M - 2] = t;
+    }
+    // after 63 rotations of the registers w[i] holds row i again
+#pragma unroll
+    for (int i = 0; i < M - 1; ++i) {
+        const int d = pm[i];                                      // (uniform)
+        *(d < H ? r0 + (long long)d * ld : r1 + (long long)(d - H) * ld) = w[i];
+    }
+    { const int d = pm[M - 1]; *(d < H ? r0 + (long long)d * ld : r1 + (long long)(d - H) * ld) = f; }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -684,6 +772,11 @@ int jacobi_rows(ctm_ctx* ctx, double* X, int R, long long ld, int Cg, int Ctot, 
     CTM_TRY(arena_alloc(ctx, sizeof(double) * pairs * m * m, (void**)&J));
     CTM_TRY(arena_alloc(ctx, sizeof(double) * R, (void**)&norms));
     CTM_TRY(arena_alloc(ctx, sizeof(int) * pairs, (void**)&flags));
+    double* rot = nullptr; int* perm = nullptr;
+    if (ctx->jacobi_rot_apply && !cplx && m == 64 && pairs >= 4) {
+        CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)pairs * 63 * 64, (void**)&rot));
+        CTM_TRY(arena_alloc(ctx, sizeof(int) * (size_t)pairs * 64, (void**)&perm));
+    }
     unsigned long long* stat = (unsigned long long*)ctx->d_scratch;   // [0]=scaled, [1]=classical
     std::vector<double> h(R);
     const double floor2 = (1e-14 * fro) * (1e-14 * fro);
@@ -737,6 +830,17 @@ int jacobi_rows(ctm_ctx* ctx, double* X, int R, long long ld, int Cg, int Ctot, 
             // cross-only rotations in every round but the first of a sweep (which pairs every panel once and solves the full 64 x 64
             // problems: the intra-panel pairs); many-panel problems only (the dense SVD of a Ritz matrix, full-block Rayleigh-Ritz)
             sp.cross = (ctx->jacobi_cross_only && !cplx && m == 64 && ctx->eig64_pingpong && pairs >= 4 && r > 0) ? 1 : 0;
+            // many-panel real problems with ONE inner pass per visit: the eigensolver records its rotations instead of accumulating J, and the
+            // panel rows are rotated on the vector ALUs (rot_apply64_kernel) -- no J in LDS (the eigensolver is LDS-bandwidth bound), no apply GEMM
+            const bool use_rot = ctx->jacobi_rot_apply && !cplx && m == 64 && ctx->eig64_pingpong && sp.max_sweeps == 1 && rot != nullptr;
+            if (use_rot) {
+                sp.rot = rot; sp.perm = perm;
+                CTM_LAUNCH(ctx, (small_eig64_kernel<2, true>), dim3(pairs), dim3(512), 0, sp);
+                const dim3 grid((Ctot + 255) / 256, pairs);
+                if (sp.cross) CTM_LAUNCH(ctx, rot_apply64_kernel<true>, grid, dim3(256), 0, X, ld, Ctot, (const GemmOff*)(T->d_apply + (size_t)r * pairs), (const double*)rot, (const int*)perm, (const int*)flags);
+                else CTM_LAUNCH(ctx, rot_apply64_kernel<false>, grid, dim3(256), 0, X, ld, Ctot, (const GemmOff*)(T->d_apply + (size_t)r * pairs), (const double*)rot, (const int*)perm, (const int*)flags);
+                continue;
+            }
             if (cplx) CTM_LAUNCH(ctx, small_eig_c_kernel, dim3(pairs), dim3(256), 0, sp);
             else if (m == 64 && ctx->eig64_pingpong) {
                 if (ctx->eig64_bpt == 4) CTM_LAUNCH(ctx, small_eig64_kernel<4>, dim3(pairs), dim3(256), 0, sp);
@@ -1162,7 +1266,7 @@ int matop_apply(ctm_ctx* ctx, const MatOp& op, bool transpose, const double* B, 
 // [1] block steps of the last accepted Krylov solve, [2] its residual estimate / s_0, [3] consecutive warm probes that were handed
 // to the Krylov solver (each one quadruples the distance to the next probe: a full-rank environment at its rounding floor, where the
 // previous basis stays ~1e-10 away from the new operator for ever, otherwise pays two half steps on k + k/2 rows every few sweeps)
-enum { HDR_SKIP = 0, HDR_STEPS = 1, HDR_EST = 2, HDR_FAILS = 3, HDR_WORDS = 4 };
+enum { HDR_SKIP = 0, HDR_STEPS = 1, HDR_EST = 2, HDR_FAILS = 3, HDR_BLOCK = 4, HDR_WORDS = 5 };      // (HDR_BLOCK: block size the remembered step count belongs to)
 
 inline int warm_skip_calls(const ctm_ctx* ctx, double r) {
     const int need = (int)std::ceil(2.0 * std::log(std::max(r, 1e-9) / 1e-9) / std::log(5.0)) - 1;
@@ -1866,18 +1970,19 @@ int svd_iter_c(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* Ut, doub
 // ---------------------------------------------------------------------------------------------
 // Cholesky factor of a 64 x 64 Gram matrix and the inverse of its lower factor, one workgroup, everything in LDS:
 // G = L L^T, out = L^-1 (lower triangular, row-major); status[0] = smallest pivot met (<= 0: not positive definite).
-__global__ __launch_bounds__(64) void chol64_inv_kernel(const double* G, double* Linv, double* status) {
+__global__ __launch_bounds__(64) void chol64_inv_kernel(const double* G, double* Linv, double* status, int m = 64) {
     // ONE wave, thread i owns row i of L (kept in LDS, row stride 65: a column access by the wave is conflict free, a pivot-row
     // access is a broadcast).  Left-looking factorisation: every thread recomputes the pivot itself, so a column costs one
-    // barrier; then L X = I by forward substitution, thread c owning column c of X.
+    // barrier; then L X = I by forward substitution, thread c owning column c of X.  m <= 64: order of the (dense, leading dimension m) matrix.
     constexpr int M = 64;
     __shared__ double L[M][M + 1];
     __shared__ double X[M][M + 1];
     const int i = threadIdx.x;
-    for (int c = 0; c < M; ++c) L[i][c] = G[c * M + i];          // G is symmetric: column i read as row i, coalesced
+    const bool act = i < m;
+    for (int c = 0; c < m; ++c) L[i][c] = act ? G[c * m + i] : 0.0;          // G is symmetric: column i read as row i, coalesced
     __syncthreads();
     double pmin = 1e300;
-    for (int j = 0; j < M; ++j) {
+    for (int j = 0; j < m; ++j) {
         // the LDS reads do not depend on the accumulators: eight iterations' loads are issued together (four accumulator chains)
         double dot0 = 0.0, dot1 = 0.0, pd0 = 0.0, pd1 = 0.0;
         int t = 0;
@@ -1895,11 +2000,11 @@ __global__ __launch_bounds__(64) void chol64_inv_kernel(const double* G, double*
         const double l = sqrt(fmax(p, 1e-300));
         const double v = (i == j) ? l : (L[i][j] - dot) / l;
         __syncthreads();                                          // everybody has read the old L[j][j]
-        if (i >= j) L[i][j] = v;
+        if (i >= j && act) L[i][j] = v;
         __syncthreads();
     }
     const int c = i;
-    for (int r = 0; r < M; ++r) {       // X[t][c] = 0 for t < c: the sum may start at 0 for every thread (uniform trip count)
+    for (int r = 0; r < m; ++r) {       // X[t][c] = 0 for t < c: the sum may start at 0 for every thread (uniform trip count)
         double acc0 = (r == c) ? 1.0 : 0.0, acc1 = 0.0;
         int t = 0;
         for (; t + 8 <= r; t += 8) {
@@ -1912,7 +2017,7 @@ __global__ __launch_bounds__(64) void chol64_inv_kernel(const double* G, double*
         for (; t < r; ++t) acc0 -= L[r][t] * X[t][c];
         X[r][c] = (r >= c) ? (acc0 + acc1) / L[r][r] : 0.0;
     }
-    for (int r = 0; r < M; ++r) Linv[r * M + c] = X[r][c];
+    if (act) for (int r = 0; r < m; ++r) Linv[r * m + c] = X[r][c];
     if (i == 0) status[0] = pmin;
 }
 
@@ -2023,7 +2128,7 @@ int orthonormalise_block(ctm_ctx* ctx, double* W, int rows, int n, double* norms
     *max_norm = *std::max_element(h.begin(), h.end());
     CTM_LAUNCH(ctx, inv_or_zero_kernel, dim3((rows + 255) / 256), dim3(256), 0, norms, inv, rows);
     CTM_LAUNCH(ctx, scale_rows_kernel, dim3(1024), dim3(256), 0, W, rows, n, (long long)n, inv);
-    bool ok = (rows == 64) && (*min_norm > 0.0);
+    bool ok = (rows == 64 || rows == 32) && (*min_norm > 0.0);
     if (ok) {
         ArenaScope scope(ctx);
         double *G, *Li;
@@ -2031,13 +2136,13 @@ int orthonormalise_block(ctm_ctx* ctx, double* W, int rows, int n, double* norms
         CTM_TRY(arena_alloc(ctx, sizeof(double) * 64 * 64, (void**)&Li));
         double* status = ctx->d_scratch + 16;
         for (int pass = 0; pass < 2 && ok; ++pass) {
-            GemmDesc g; g.M = 64; g.N = 64; g.K = n; g.A = W; g.sam = n; g.sak = 1; g.B = W; g.sbk = 1; g.sbn = n; g.C = G; g.ldc = 64;
+            GemmDesc g; g.M = rows; g.N = rows; g.K = n; g.A = W; g.sam = n; g.sak = 1; g.B = W; g.sbk = 1; g.sbn = n; g.C = G; g.ldc = rows;
             CTM_TRY(gemm_f64(ctx, g));
-            CTM_LAUNCH(ctx, chol64_inv_kernel, dim3(1), dim3(64), 0, (const double*)G, Li, status);
+            CTM_LAUNCH(ctx, chol64_inv_kernel, dim3(1), dim3(64), 0, (const double*)G, Li, status, rows);
             CTM_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_scratch + 16, status, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
             CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
             if (!(ctx->h_scratch[16] > (pass == 0 ? 1e-10 : 0.5))) { ok = false; break; }      // unit rows: pivots in (0, 1]
-            GemmDesc a; a.M = 64; a.N = n; a.K = 64; a.A = Li; a.sam = 64; a.sak = 1; a.B = W; a.sbk = n; a.sbn = 1; a.C = W; a.ldc = n;
+            GemmDesc a; a.M = rows; a.N = n; a.K = rows; a.A = Li; a.sam = rows; a.sak = 1; a.B = W; a.sbk = n; a.sbn = 1; a.C = W; a.ldc = n;
             CTM_TRY(gemm_f64(ctx, a));                       // in place: a workgroup reads its whole column strip before it writes
         }
     }
@@ -2046,7 +2151,7 @@ int orthonormalise_block(ctm_ctx* ctx, double* W, int rows, int n, double* norms
     int st;
     const double fro = host_fro(ctx, W, rows, n, n, norms, h, &st);
     CTM_TRY(st);
-    CTM_TRY(jacobi_rows(ctx, W, rows, n, n, n, 32, 0, fro, ctx->si_rr_sweeps));
+    CTM_TRY(jacobi_rows(ctx, W, rows, n, n, n, rows >= 64 ? 32 : 16, 0, fro, ctx->si_rr_sweeps));
     CTM_TRY(row_norms(ctx, W, rows, n, n, norms));
     CTM_LAUNCH(ctx, inv_or_zero_kernel, dim3((rows + 255) / 256), dim3(256), 0, norms, inv, rows);
     CTM_LAUNCH(ctx, scale_rows_kernel, dim3(1024), dim3(256), 0, W, rows, n, (long long)n, inv);
@@ -2070,15 +2175,19 @@ int orthonormalise_block(ctm_ctx* ctx, double* W, int rows, int n, double* norms
 //   and *flag3 is set: a third pass then finishes.  mode 1: plain.  mode 2 (third pass): returns at once unless *flag3.
 // status[0] = smallest pivot of the accepted factorisation, [1] = smallest, [2] = largest row norm.  Nothing is decided on the
 // host here: the caller reads the status words of all its steps at its next host synchronisation.
+#ifdef CTM_KERNEL_CLOCKS
+__device__ double ctm_dbg_clocks[4];    // phase clocks of the single-wave kernels (tools/bench_small_kernels.hip); NOT in the callers' status words
+#endif
+template <int M>      // M = 64, or 32 (block Krylov recurrence on 32-row blocks: lanes >= M carry empty rows; 128 instead of 256 VGPRs of rows)
 __global__ __launch_bounds__(64) void chol64_scaled_inv_kernel(const double* __restrict__ G, double* __restrict__ out, double* __restrict__ status,
                                                                int* __restrict__ flag3, int mode) {
-    constexpr int M = 64;
     const int lane = threadIdx.x;
+    const bool act = lane < M;
     if (mode == 2 && *flag3 == 0) { if (lane == 0) { status[0] = 1.0; status[1] = -1.0; status[2] = -1.0; } return; }   // skipped: marked by the -1
 #ifdef CTM_KERNEL_CLOCKS
     const long long clk0 = clock64();
 #endif
-    const double dg = G[lane * M + lane];
+    const double dg = act ? G[lane * M + lane] : 1.0;
     const double dinv = dg > 0.0 ? 1.0 / sqrt(dg) : 0.0;
     double a[M];                    // row `lane` of A, then of L
     double rinv = 0.0;              // lane j: 1 / L_jj
@@ -2087,7 +2196,7 @@ __global__ __launch_bounds__(64) void chol64_scaled_inv_kernel(const double* __r
         const double shift = attempt == 0 ? 0.0 : 1e-10;
 #pragma unroll
         for (int k = 0; k < M; ++k)     // G is symmetric: column `lane` read along rows (coalesced) is row `lane`
-            a[k] = G[k * M + lane] * dinv * lane_bcast(dinv, k) + ((k == lane) ? shift : 0.0);
+            a[k] = act ? G[k * M + lane] * dinv * lane_bcast(dinv, k) + ((k == lane) ? shift : 0.0) : 0.0;
         pmin = 1e300;
 #pragma unroll
         for (int j = 0; j < M; ++j) {
@@ -2124,11 +2233,13 @@ __global__ __launch_bounds__(64) void chol64_scaled_inv_kernel(const double* __r
     }
 #ifdef CTM_KERNEL_CLOCKS
     const long long clk2 = clock64();
-    if (lane == 0) { status[9] = (double)(clk1 - clk0); status[10] = (double)(clk2 - clk1); }
+    if (lane == 0) { ctm_dbg_clocks[0] = (double)(clk1 - clk0); ctm_dbg_clocks[1] = (double)(clk2 - clk1); }
 #endif
+    if (act) {
 #pragma unroll
-    for (int r = 0; r < M; ++r) out[r * M + lane] = x[r] * dinv;
-    double mn = dg > 0.0 ? sqrt(dg) : 0.0, mx = mn;
+        for (int r = 0; r < M; ++r) out[r * M + lane] = x[r] * dinv;
+    }
+    double mn = act ? (dg > 0.0 ? sqrt(dg) : 0.0) : 1e300, mx = act ? (dg > 0.0 ? sqrt(dg) : 0.0) : 0.0;
     for (int off = 32; off > 0; off >>= 1) { mn = fmin(mn, __shfl_down(mn, off, 64)); mx = fmax(mx, __shfl_down(mx, off, 64)); }
     if (lane == 0) { status[0] = pmin; status[1] = mn; status[2] = mx; }
 }
@@ -2136,13 +2247,15 @@ __global__ __launch_bounds__(64) void chol64_scaled_inv_kernel(const double* __r
 // rows of W (64 x n) -> orthonormal rows spanning the same space: two Cholesky-QR passes, and a third one -- decided on the device --
 // when the first had to shift (nearly dependent rows); no host synchronisation.  Status words of the three passes go to
 // `status` (9 doubles: pivot, min norm, max norm per pass; a skipped third pass reports 1), `flag3` is a device word.
-int orthonormalise_block_async(ctm_ctx* ctx, double* W, int n, double* G, double* Li, double* status, int* flag3) {
+int orthonormalise_block_async(ctm_ctx* ctx, double* W, int b, int n, double* G, double* Li, double* status, int* flag3) {
     for (int pass = 0; pass < 3; ++pass) {
-        GemmDesc g; g.M = 64; g.N = 64; g.K = n; g.A = W; g.sam = n; g.sak = 1; g.B = W; g.sbk = 1; g.sbn = n; g.C = G; g.ldc = 64;
+        GemmDesc g; g.M = b; g.N = b; g.K = n; g.A = W; g.sam = n; g.sak = 1; g.B = W; g.sbk = 1; g.sbn = n; g.C = G; g.ldc = b;
         if (pass == 2) g.skip_all = flag3;
         CTM_TRY(gemm_f64(ctx, g));
-        CTM_LAUNCH(ctx, chol64_scaled_inv_kernel, dim3(1), dim3(64), 0, (const double*)G, Li, status + 3 * pass, flag3, pass);
-        GemmDesc a; a.M = 64; a.N = n; a.K = 64; a.A = Li; a.sam = 64; a.sak = 1; a.B = W; a.sbk = n; a.sbn = 1; a.C = W; a.ldc = n;
+        if (b == 64) CTM_LAUNCH(ctx, chol64_scaled_inv_kernel<64>, dim3(1), dim3(64), 0, (const double*)G, Li, status + 3 * pass, flag3, pass);
+        else if (b == 32) CTM_LAUNCH(ctx, chol64_scaled_inv_kernel<32>, dim3(1), dim3(64), 0, (const double*)G, Li, status + 3 * pass, flag3, pass);
+        else { ctx->set_error("orthonormalise_block_async: 32 or 64 rows"); return CTM_ERR_BADARG; }
+        GemmDesc a; a.M = b; a.N = n; a.K = b; a.A = Li; a.sam = b; a.sak = 1; a.B = W; a.sbk = n; a.sbn = 1; a.C = W; a.ldc = n;
         if (pass == 2) a.skip_all = flag3;
         CTM_TRY(gemm_f64(ctx, a));                       // in place: a workgroup reads its whole column strip before it writes
     }
@@ -2174,7 +2287,12 @@ int project_out(ctm_ctx* ctx, double* W, int b, int n, const double* B, int m, d
 
 int svd_lanczos(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* Ut, double* Vt, bool* converged) {
     *converged = false;
-    const int n = op.n, b = 64;
+    // Block size of the recurrence.  The basis a solve needs shrinks with the block: for the leading k of a slowly decaying spectrum a
+    // block of b rows reaches polynomial degree m / b with m basis rows (measured on the D = 6 chi = 128 spectrum, tools emulation in
+    // 2.5 k rows with b = k/8, 3.2 k with k/4, 4-4.5 k with k/2, 6 k with b = k) -- fewer corner passes in total AND a
+    // smaller Ritz matrix for the dense Jacobi SVD, against twice the orthonormalisation steps and passes that are HBM-bound
+    // (<= 32 rows: 0.36 ms for 32 rows against 0.62 ms for 64 at n = 16384).
+    const int n = op.n, b = (ctx->lz_block == 32 || (ctx->lz_block == 0 && k > ctx->lz_block32_min_k)) ? 32 : 64;
     const int jmin = (k + b - 1) / b + 1;                        // first step with at least k + b basis rows... (k rows needed)
     int jmax = std::min((n / 2) / b, (6 * k) / b + 8);
     if (jmax < jmin + 1) return CTM_OK;
@@ -2222,23 +2340,23 @@ int svd_lanczos(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* Ut, dou
     // accepted last time is tried first (one less when it passed with orders of magnitude to spare); cold, the first look
     // comes when the basis holds lz_first_factor * k rows; after a failed look the next one is placed where the observed (or a
     // typical) contraction of the residual estimate predicts convergence.
-    double hdr[HDR_WORDS] = {0.0, 0.0, 0.0};
+    double hdr[HDR_WORDS] = {0.0, 0.0, 0.0, 0.0, 0.0};
     if (op.warm_hdr) {
         CTM_HIP_CHECK(ctx, hipMemcpyAsync(hdr, op.warm_hdr, sizeof(hdr), hipMemcpyDeviceToHost, ctx->stream));
         CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     }
     int jnext;
     if (ctx->lz_first > 0) jnext = ctx->lz_first;
-    else if (hdr[HDR_STEPS] >= jmin && hdr[HDR_STEPS] <= jmax && hdr[HDR_EST] > 0.0)
+    else if (hdr[HDR_STEPS] >= jmin && hdr[HDR_STEPS] <= jmax && hdr[HDR_EST] > 0.0 && (int)hdr[HDR_BLOCK] == b)
         // the estimate falls by a factor 7-17 per block step (measured, D = 6 and 8): one step less when it passed with more than
         // that to spare, one more when it passed narrowly (a failed look costs five steps)
         jnext = (int)hdr[HDR_STEPS] + (hdr[HDR_EST] <= tol / 30.0 ? -1 : (hdr[HDR_EST] > tol / 3.0 ? 1 : 0));
-    else jnext = (int)std::ceil(ctx->lz_first_factor * k / b);
+    else jnext = (int)std::ceil((b == 32 ? ctx->lz_first_factor32 : ctx->lz_first_factor) * k / b);
     jnext = std::max(jmin, std::min(jnext, jmax));
     double est_prev = 0.0; int steps_prev = 0;
     double mn, mx, s0 = 0.0;
     CTM_LAUNCH(ctx, hash_fill_kernel, dim3(1024), dim3(256), 0, Vall, b, n, (long long)n, 0x51f15eedULL);
-    if (async) CTM_TRY(orthonormalise_block_async(ctx, Vall, n, G, Li, ostat + SW * (nstat - 1), flag3));
+    if (async) CTM_TRY(orthonormalise_block_async(ctx, Vall, b, n, G, Li, ostat + SW * (nstat - 1), flag3));
     else CTM_TRY(orthonormalise_block(ctx, Vall, b, n, norms, inv, &mn, &mx));
     int applications = 0;
     for (int j = 0; j < jmax; ++j) {
@@ -2251,7 +2369,7 @@ int svd_lanczos(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* Ut, dou
         CTM_TRY(matop_apply(ctx, op, true, Vj, n, b, Wj, n, want_mid ? VRall + (size_t)j * b * n : nullptr)); applications += b;
         CTM_HIP_CHECK(ctx, hipMemcpyAsync(Uj, Wj, sizeof(double) * (size_t)b * n, hipMemcpyDeviceToDevice, ctx->stream));
         CTM_TRY(project_out(ctx, Uj, b, n, Uall, j * b, G, 2, ctx->lz_local_project ? b : 0));
-        if (async) CTM_TRY(orthonormalise_block_async(ctx, Uj, n, G, Li, ostat + SW * (2 * j), flag3));
+        if (async) CTM_TRY(orthonormalise_block_async(ctx, Uj, b, n, G, Li, ostat + SW * (2 * j), flag3));
         else {
             CTM_TRY(orthonormalise_block(ctx, Uj, b, n, norms, inv, &mn, &mx));
             s0 = std::max(s0, mx);
@@ -2261,7 +2379,7 @@ int svd_lanczos(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* Ut, dou
         CTM_TRY(matop_apply(ctx, op, false, Uj, n, b, Zj, n, want_mid ? URall + (size_t)j * b * n : nullptr)); applications += b;
         CTM_HIP_CHECK(ctx, hipMemcpyAsync(Vn, Zj, sizeof(double) * (size_t)b * n, hipMemcpyDeviceToDevice, ctx->stream));
         CTM_TRY(project_out(ctx, Vn, b, n, Vall, (j + 1) * b, G, 2, ctx->lz_local_project ? b : 0));
-        if (async) CTM_TRY(orthonormalise_block_async(ctx, Vn, n, G, Li, ostat + SW * (2 * j + 1), flag3));
+        if (async) CTM_TRY(orthonormalise_block_async(ctx, Vn, b, n, G, Li, ostat + SW * (2 * j + 1), flag3));
         else {
             CTM_TRY(orthonormalise_block(ctx, Vn, b, n, norms, inv, &mn, &mx));
             if (mn <= 1e-13 * s0) { if (ctx->jacobi_verbose) fprintf(stderr, "[lz] n=%d breakdown at step %d (V)\n", n, j); return CTM_OK; }
@@ -2405,10 +2523,11 @@ int svd_lanczos(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* Ut, dou
             if (op.warm_hdr) {
                 CTM_TRY(fill_f64(ctx, op.warm_hdr + HDR_STEPS, 1, (double)steps));
                 CTM_TRY(fill_f64(ctx, op.warm_hdr + HDR_EST, 1, std::max(est / hs[0], 1e-300)));
+                CTM_TRY(fill_f64(ctx, op.warm_hdr + HDR_BLOCK, 1, (double)b));
             }
             CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
             *converged = true;
-            ctx->lz_hits += 1; ctx->lz_total_steps += steps;
+            ctx->lz_hits += 1; ctx->lz_total_steps += steps; ctx->lz_total_rows += (long)steps * b;
             return CTM_OK;
         }
         // estimate passed, verification did not (rounding beyond the polishing range): more basis does not help
@@ -2597,16 +2716,16 @@ int svd_lanczos_c(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* Ut, d
     auto Wr = [&](int j) { CRows r{Wraw + (size_t)j * bn, Wraw + planeU + (size_t)j * bn}; return r; };
     const double tol = resid_tol(ctx, n);
     // scheduling of the Ritz extractions: see svd_lanczos()
-    double hdr[HDR_WORDS] = {0.0, 0.0, 0.0};
+    double hdr[HDR_WORDS] = {0.0, 0.0, 0.0, 0.0, 0.0};
     if (op.warm_hdr) {
         CTM_HIP_CHECK(ctx, hipMemcpyAsync(hdr, op.warm_hdr, sizeof(hdr), hipMemcpyDeviceToHost, ctx->stream));
         CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     }
     int jnext;
     if (ctx->lz_first > 0) jnext = ctx->lz_first;
-    else if (hdr[HDR_STEPS] >= jmin && hdr[HDR_STEPS] <= jmax && hdr[HDR_EST] > 0.0)
+    else if (hdr[HDR_STEPS] >= jmin && hdr[HDR_STEPS] <= jmax && hdr[HDR_EST] > 0.0 && (int)hdr[HDR_BLOCK] == b)
         jnext = (int)hdr[HDR_STEPS] + (hdr[HDR_EST] <= tol / 30.0 ? -1 : (hdr[HDR_EST] > tol / 3.0 ? 1 : 0));
-    else jnext = (int)std::ceil(ctx->lz_first_factor * k / b);
+    else jnext = (int)std::ceil((b == 32 ? ctx->lz_first_factor32 : ctx->lz_first_factor) * k / b);
     jnext = std::max(jmin, std::min(jnext, jmax));
     double est_prev = 0.0; int steps_prev = 0;
     double mn, mx, s0 = 0.0;
@@ -2729,6 +2848,7 @@ int svd_lanczos_c(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* Ut, d
             if (op.warm_hdr) {
                 CTM_TRY(fill_f64(ctx, op.warm_hdr + HDR_STEPS, 1, (double)steps));
                 CTM_TRY(fill_f64(ctx, op.warm_hdr + HDR_EST, 1, std::max(est / hs[0], 1e-300)));
+                CTM_TRY(fill_f64(ctx, op.warm_hdr + HDR_BLOCK, 1, (double)b));
             }
             CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
             *converged = true;
@@ -3185,7 +3305,7 @@ static int eigh_orth_iter(ctm_ctx* ctx, const double* As, int n, int kk, int k_o
         GemmDesc g; g.M = 64; g.N = 64; g.K = n; g.A = Wb; g.sam = n; g.sak = 1; g.B = Wb; g.sbk = 1; g.sbn = n; g.C = G; g.ldc = 64;
         if (mode == 2) g.skip_all = flag3;
         CTM_TRY(gemm_f64(ctx, g));
-        CTM_LAUNCH(ctx, chol64_scaled_inv_kernel, dim3(1), dim3(64), 0, (const double*)G, Li, status + 3 * mode, flag3, mode);
+        CTM_LAUNCH(ctx, chol64_scaled_inv_kernel<64>, dim3(1), dim3(64), 0, (const double*)G, Li, status + 3 * mode, flag3, mode);
         GemmDesc a; a.M = 64; a.N = n; a.K = 64; a.A = Li; a.sam = 64; a.sak = 1; a.B = Wb; a.sbk = n; a.sbn = 1; a.C = Wb; a.ldc = n;
         if (mode == 2) a.skip_all = flag3;
         return gemm_f64(ctx, a);                          // in place: a workgroup reads its whole column strip before it writes

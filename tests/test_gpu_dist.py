@@ -66,7 +66,7 @@ def test_rccl_backend_executes_every_collective_on_one_rank():
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "check_rccl_world1.py"), str(port)], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
-    out = json.loads(r.stdout.strip().splitlines()[-1])
+    out = json.loads([l for l in r.stdout.strip().splitlines() if l.startswith("{")][-1])
     assert out["backend"] == "nccl" and len(out["checks"]) == 2
     assert "not built" in out["set_comm_two_ranks"]
     assert out["comm_s_torch.float64"] > 0.0 and out["comm_s_torch.complex128"] > 0.0

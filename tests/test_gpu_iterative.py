@@ -105,6 +105,9 @@ def test_values_below_the_numerical_rank_are_returned_as_zeros(eng):
     assert np.abs(S - ex).max() < 5e-13
 
 
+LZ_BLOCK_DEFAULT, CROSS_ONLY_DEFAULT, ROT_APPLY_DEFAULT = 0, 0, 0          # csrc/ctm_common.h
+
+
 def test_krylov_solver_variants_agree(eng):
     """The block Krylov truncation of a full-rank unit (signed 2x2 state, D = 4, chi = 64: n = 1024, k = 65) through its variants:
     the sync-free recurrence against the synchronous one, 16-row panels in the Ritz extraction (the 18 KB LDS eigensolver), the
@@ -138,11 +141,46 @@ def test_krylov_solver_variants_agree(eng):
             return {k: (s_ / s_[0]).cpu().numpy() for k, s_ in env.get_spectra().items()}
         finally:
             cfg.ctm_args.concurrent_units = old
-            for k_ in opts: eng.set_option(k_, {"lz_async": 1, "lz_jacobi_block": 0, "heavy_serial": 0, "heavy_min_flops": 1e10, "lz_local_project": 1}[k_])
+            for k_ in opts: eng.set_option(k_, {"lz_async": 1, "lz_jacobi_block": 0, "heavy_serial": 0, "heavy_min_flops": 1e10, "lz_local_project": 1,
+                                                "lz_block": LZ_BLOCK_DEFAULT, "jacobi_cross_only": CROSS_ONLY_DEFAULT, "jacobi_rot_apply": ROT_APPLY_DEFAULT}[k_])
     ref = run({})
     for name, opts, conc in (("synchronous recurrence", {"lz_async": 0}, True), ("16-row panels", {"lz_jacobi_block": 16}, True),
                              ("device-side lock", {"heavy_serial": 1, "heavy_min_flops": 1e7}, True), ("serial units", {}, False),
-                             ("two full projection passes", {"lz_local_project": 0}, True)):
+                             ("two full projection passes", {"lz_local_project": 0}, True),
+                             ("32-row blocks", {"lz_block": 32}, True), ("64-row blocks", {"lz_block": 64}, True),
+                             ("32-row blocks, synchronous recurrence", {"lz_block": 32, "lz_async": 0}, True),
+                             ("cross-pair rounds in the Ritz extraction", {"jacobi_cross_only": 1}, True), ("full rounds", {"jacobi_cross_only": 0}, True),
+                             ("rotation lists applied on the vector ALUs", {"jacobi_rot_apply": 1, "jacobi_cross_only": 0}, True),
+                             ("rotation lists, cross-pair rounds", {"jacobi_rot_apply": 1, "jacobi_cross_only": 1}, True),
+                             ("accumulated J + apply GEMM", {"jacobi_rot_apply": 0, "jacobi_cross_only": 0}, True)):
         got = run(opts, conc)
         for k in ref:
             assert np.abs(got[k] - ref[k]).max() < 1e-10, (name, k)
+
+
+@pytest.mark.parametrize("opts", [{"jacobi_rot_apply": 0, "jacobi_cross_only": 0}, {"jacobi_rot_apply": 1, "jacobi_cross_only": 0},
+                                  {"jacobi_rot_apply": 1, "jacobi_cross_only": 1}, {"jacobi_rot_apply": 0, "jacobi_cross_only": 1}],
+                         ids=["J-gemm", "rotation-lists", "rotation-lists-cross", "J-gemm-cross"])
+def test_many_panel_block_jacobi_variants_against_lapack(eng, opts):
+    """The dense one-sided block Jacobi SVD on many 32-row panels (the Ritz extraction of the block Krylov solver; here called directly
+    through the full decomposition of an explicit matrix): accumulated J + apply GEMM, or the eigensolver's rotation lists applied on
+    the vector ALUs, with full or cross-pair rounds -- singular values against LAPACK to 1e-13 s0, orthonormal factors, reconstruction."""
+    n = 640
+    rng = np.random.default_rng(3)
+    U, _ = np.linalg.qr(rng.standard_normal((n, n))); V, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    s = np.exp(-16.0 * (np.arange(n) / n) ** 0.5)              # steep head, slowly decaying dense tail
+    M = (U * s) @ V.T
+    keep = {"si_enable": 1, "jacobi_rot_apply": ROT_APPLY_DEFAULT, "jacobi_cross_only": CROSS_ONLY_DEFAULT}
+    try:
+        eng.set_option("si_enable", 0)                         # the dense path, not the leading-k iteration
+        for k_, v_ in opts.items(): eng.set_option(k_, v_)
+        Ug, Sg, Vg = (t.cpu().numpy() for t in eng.truncated_svd(dev(M), n, eng.cfg(keep_multiplets=False)))
+    finally:
+        for k_, v_ in keep.items(): eng.set_option(k_, v_)
+    ref = np.linalg.svd(M, compute_uv=False)
+    big = ref > 1e-11 * ref[0]
+    assert np.abs(Sg - ref)[big].max() < 1e-13 * ref[0]
+    kk = int(big.sum())
+    assert np.abs(Ug[:, :kk].T @ Ug[:, :kk] - np.eye(kk)).max() < 1e-12
+    assert np.abs(Vg[:, :kk].T @ Vg[:, :kk] - np.eye(kk)).max() < 1e-12
+    assert np.abs((Ug * Sg) @ Vg.T - M).max() < 1e-13 * ref[0] * n

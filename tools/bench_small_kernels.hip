@@ -3,7 +3,7 @@
 // other objects of the library:
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Ipeps-torch_amd/csrc -Iinclude tools/bench_small_kernels.hip \
 //         peps-torch_amd/csrc/build/{ctm_runtime,gemm_f64,tensor_ops,contract,layer2,ctm_ops,backward}.o -o tools/bin/bench_small_kernels
-#define CTM_KERNEL_CLOCKS 1      // phase clocks of the kernels (status words 9..)
+#define CTM_KERNEL_CLOCKS 1      // phase clocks of the kernels (device buffer ctm_dbg_clocks / stat words of the eigensolver)
 #include "../peps-torch_amd/csrc/jacobi.hip"
 #include <cstdio>
 #include <random>
@@ -38,7 +38,7 @@ int main() {
     hipMemcpy(dGd, Gd.data(), sizeof(double) * M * M, hipMemcpyHostToDevice);
     hipMemset(dFlag, 0, sizeof(int) * 4); hipMemset(dStat, 0, sizeof(unsigned long long) * 16);
     for (int mode = 0; mode < 2; ++mode) {
-        const double t = time_us([&] { hipLaunchKernelGGL(chol64_scaled_inv_kernel, dim3(1), dim3(64), 0, 0, (const double*)dG, dOut, dStatus, dFlag, mode); }, 200);
+        const double t = time_us([&] { hipLaunchKernelGGL(chol64_scaled_inv_kernel<64>, dim3(1), dim3(64), 0, 0, (const double*)dG, dOut, dStatus, dFlag, mode); }, 200);
         std::vector<double> L(M * M); double st[3];
         hipMemcpy(L.data(), dOut, sizeof(double) * M * M, hipMemcpyDeviceToHost); hipMemcpy(st, dStatus + 3 * 0, sizeof(st), hipMemcpyDeviceToHost);
         // check: out G out^T = I
@@ -48,7 +48,7 @@ int main() {
             for (int a = 0; a < M; ++a) { double t2 = 0; for (int b = 0; b < M; ++b) t2 += G[a * M + b] * L[j * M + b]; s += L[i * M + a] * t2; }
             dev = std::max(dev, std::fabs(s - (i == j ? 1.0 : 0.0)));
         }
-        double ck[2]; hipMemcpy(ck, dStatus + 9, sizeof(ck), hipMemcpyDeviceToHost);
+        double ck[2]; hipMemcpyFromSymbol(ck, HIP_SYMBOL(ctm_dbg_clocks), sizeof(ck));
         printf("chol64_scaled_inv_kernel mode %d: %.1f us   |L^-1 G L^-T - I| = %.2e   clocks: factorisation %.0f, inversion %.0f\n", mode, t, dev, ck[0], ck[1]);
     }
     {

@@ -95,4 +95,6 @@ except _native.NativeError as ex:
     out["set_comm_two_ranks"] = str(ex)
 dist.barrier()
 dist.destroy_process_group()
-print(json.dumps(out))
+import ctypes
+ctypes.CDLL(None).fflush(None)          # RCCL's own "Librccl path" line sits in C stdio until flushed: keep the JSON line last
+print(json.dumps(out), flush=True)

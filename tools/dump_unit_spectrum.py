@@ -13,8 +13,7 @@ from ctm.generic import ctmrg
 from ctm.generic.ctm_components import _halves_t
 D, chi, ns, out = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
 eng = _native.engine()
-sites = {k: 2.0 * v - 1.0 for k, v in synth_sites("generic", D).items()}
-sites = {k: v / np.abs(v).max() for k, v in sites.items()}
+sites = synth_sites("generic", D, signed=True)
 st = IPEPS({k: torch.from_numpy(v).cuda() for k, v in sites.items()})
 env = ENV(chi, st); init_env(st, env)
 for sw in range(ns):

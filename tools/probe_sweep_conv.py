@@ -15,8 +15,7 @@ eng = _native.engine()
 cplx = "c128" in sys.argv[4:]
 for kv in [a for a in sys.argv[4:] if "=" in a]:
     k, v = kv.split("="); eng.set_option(k, float(v))
-sites = {k: 2.0 * v - ((1.0 + 1.0j) if cplx else 1.0) for k, v in synth_sites("generic", D, dtype="c128" if cplx else "f64").items()}
-sites = {k: v / np.abs(v).max() for k, v in sites.items()}
+sites = synth_sites("generic", D, dtype="c128" if cplx else "f64", signed=True)
 st = IPEPS({k: torch.from_numpy(v).cuda() for k, v in sites.items()})
 env = ENV(chi, st); init_env(st, env)
 prev = None
@@ -32,4 +31,4 @@ for sw in range(ns):
     lz = eng.stat("lz_hits"); steps = eng.stat("lz_total_steps") / max(lz, 1)
     rank = min(int((s_ > 1e-8).sum()) for s_ in spec.values())
     print(f"sweep {sw+1:2d}: {dt:6.3f} s  dspec {ds:9.2e}  min corner rank {rank:3d}  hbm {torch.cuda.mem_get_info()[0] / 2**30:5.1f} GiB free  krylov solves {int(lz):3d} avg steps {steps:5.2f}  extractions {int(eng.stat('lz_extractions')):3d}  "
-          f"power-iter hits {int(eng.stat('si_hits')):3d}  jacobi calls {int(eng.stat('jacobi_calls')):4d} avg sweeps {eng.stat('total_sweeps')/max(eng.stat('jacobi_calls'),1):5.2f}  async fallbacks {int(eng.stat('lz_async_fallbacks'))} third passes {int(eng.stat('lz_third_passes'))}", flush=True)
+          f"power-iter hits {int(eng.stat('si_hits')):3d}  jacobi calls {int(eng.stat('jacobi_calls')):4d} avg sweeps {eng.stat('total_sweeps')/max(eng.stat('jacobi_calls'),1):5.2f}  async fallbacks {int(eng.stat('lz_async_fallbacks'))} third passes {int(eng.stat('lz_third_passes'))}  arena high {eng.stat('arena_high') / 2**30:.1f} GiB (all contexts)", flush=True)
