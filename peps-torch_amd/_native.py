@@ -275,6 +275,11 @@ class Engine:
             for h in self._handles.values():
                 self.lib.ctm_trim(h)
 
+    def trim_own(self):
+        """Give back the workspace arenas of THIS engine's contexts only (the units of a move are running on the workers)."""
+        for h in self._handles.values():
+            self.lib.ctm_trim(h)
+
     def gemm_intervals(self):
         """(kind, start_ms, end_ms, flops) of every GEMM launch timed since "gemm_timing" was switched on, over all
         contexts of this engine and of its workers (one process-wide clock)."""

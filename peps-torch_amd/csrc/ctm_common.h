@@ -97,8 +97,7 @@ struct ctm_ctx {
     int eigh_orth_predict = 1;         // ... its looks (Rayleigh-Ritz + residual test) are placed where the residual is predicted to pass
     double eigh_orth_quad_exit = 1e-9; // ... early exit of its small Jacobi eigensolver (see lz_quad_exit; the residual test certifies what it returns)
     long eigh_orth_hits = 0, eigh_orth_fails = 0;
-    double eigh_orth_rate = 0.0;       // contraction per application of the last accepted solve (places the first look of the next one)
-    int eigh_orth_skip = 0, eigh_orth_backoff = 0;   // calls left that go straight to the regular route after the iteration left a flat spectrum (doubling)
+                                       // (its contraction rate / back-off state is kept per warm workspace, see OrthState in jacobi.hip)
     // block Golub-Kahan-Lanczos for spectra that do not collapse inside a small block (svd_lanczos)
     bool lz_enable = true; int lz_min_k = 48; double lz_switch_steps = 6.0; double lz_last_resid = 1.0; long lz_hits = 0, lz_total_steps = 0;
     int lz_first = 0;                   // > 0: first Ritz extraction after this many block steps (development); 0: policy of svd_lanczos
@@ -106,7 +105,7 @@ struct ctm_ctx {
     double lz_first_factor = 3.25;      // cold default: first extraction when the basis holds this many times k rows
     double lz_first_factor32 = 2.5;     // ... with 32-row blocks
     int lz_block = 0;                   // rows per block of the real block Krylov recurrence: 64, 32, or 0 = 32 for k > lz_block32_min_k
-    int lz_block32_min_k = 1 << 30;     // (0 -> always 32; default: never, until measured)
+    int lz_block32_min_k = 0;           // (32-row blocks for every k: D = 6 chi = 128 full rank 0.49-0.57 -> 0.39 s/sweep, D = 8 chi = 256 3.26 -> 3.12)
     long lz_total_rows = 0;             // basis rows over all accepted solves (steps x block)
     bool lz_verify_op = false;          // additionally check both relations of the Ritz triplets with operator applications (debug / tests)
     long lz_extractions = 0; double lz_last_est = 0.0; int lz_last_steps = 0;
@@ -149,6 +148,7 @@ struct ctm_ctx {
                                   //     prologue, epilogue and an 18-slab combine (D = 6 chi = 128 sweep +8-12 %; n >= 12288 keeps its slice count).  Round 3 saw one
                                   //     full test run with 576 end in a core dump; round 4 could not reproduce it: the shape sweep through every epilogue
                                   //     (tests/test_gpu_gemm_rows.py, ks = 1 included) and the whole suite under AddressSanitizer with 576 are clean
+    bool rows_deep_prefetch = true;   // ... two K tiles in flight per workgroup when at most two workgroups share a CU (mid-size operands)
     bool rows_quantise = true;    // ... its slice count is rounded down so that the last round of workgroups over the 256 CUs is nearly full
     int rows_target_wgs = 768;    // its workgroup count (column tiles x K slices): three per CU
     // Chip-filling launches (>= heavy_min_flops) of ALL contexts of a device run one at a time (device-side lock): the concurrent
@@ -320,3 +320,4 @@ int jacobi_eigh_top(ctm_ctx* ctx, const double* A, int n, int k, double* D, doub
 int jacobi_eigh_top_c(ctm_ctx* ctx, const double* Ar, const double* Ai, int n, int k, double* D, double* Ut, double* warm = nullptr);
 // singular values only, small matrices (corner spectra)
 int jacobi_svdvals(ctm_ctx* ctx, const double* M, const double* Mi /* nullptr: real */, int n, double* S);
+void eigh_orth_state_reset();   // forget the per-workspace state of the orthogonal iteration (option "eigh_orth_iter")

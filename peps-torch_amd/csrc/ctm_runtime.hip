@@ -149,6 +149,7 @@ int ctm_set_option(ctm_ctx* ctx, const char* key, double value) {
     else if (k == "rows_target_wgs") ctx->rows_target_wgs = (int)value;
     else if (k == "rows_min_klen") ctx->rows_min_klen = (int)value;
     else if (k == "rows_quantise") ctx->rows_quantise = value != 0.0;
+    else if (k == "rows_deep_prefetch") ctx->rows_deep_prefetch = value != 0.0;
     else if (k == "rows_fused_reduce") ctx->rows_fused_reduce = value != 0.0;
     else if (k == "heavy_serial") ctx->heavy_serial = value != 0.0;
     else if (k == "heavy_min_flops") ctx->heavy_min_flops = value;
@@ -156,7 +157,7 @@ int ctm_set_option(ctm_ctx* ctx, const char* key, double value) {
     else if (k == "eigh_warm") ctx->eigh_warm = (int)value;
     else if (k == "eigh_warm_early_reject") ctx->eigh_warm_early_reject = (int)value;
     else if (k == "eigh_probe_orth_once") ctx->eigh_probe_orth_once = (int)value;
-    else if (k == "eigh_orth_iter") { ctx->eigh_orth_iter = (int)value; ctx->eigh_orth_skip = 0; ctx->eigh_orth_backoff = 0; ctx->eigh_orth_rate = 0.0; }
+    else if (k == "eigh_orth_iter") { ctx->eigh_orth_iter = (int)value; eigh_orth_state_reset(); }
     else if (k == "eigh_orth_max") ctx->eigh_orth_max = (int)value;
     else if (k == "eigh_orth_predict") ctx->eigh_orth_predict = (int)value;
     else if (k == "eigh_orth_quad_exit") ctx->eigh_orth_quad_exit = value;

@@ -424,7 +424,7 @@ __global__ __launch_bounds__(256) void gemm_strip_kernel(StripParams p) {
 // one barrier per K tile; wave w owns the rows x 32 columns block w.  50 KB of LDS and ~120 VGPRs: three workgroups per CU
 // keep three K tiles of the stream in flight per CU.
 // ---------------------------------------------------------------------------------------------------------
-template <int TMW, bool BNF>
+template <int TMW, bool BNF, bool DEEP>
 __global__ __launch_bounds__(256, 3) void gemm_rows_kernel(StripParams p) {
     constexpr int BM = 16 * TMW, BN = 128, LDA = BM + PAD, LDB = BN + PAD;
     constexpr int NA = (BM * BK / 2 + 255) / 256;                 // d2 loads of A per thread per K tile (1 or 2)
@@ -499,22 +499,35 @@ __global__ __launch_bounds__(256, 3) void gemm_rows_kernel(StripParams p) {
     };
     load_tile(ra0, rb0);
     store_tile(0, ra0, rb0);
-    if (nk > 1) load_tile(ra1, rb1);                        // tile 1
-    __syncthreads();
-    int kt = 0;
-    for (; kt + 1 < nk; kt += 2) {
-        // even iteration: tile kt in LDS buffer 0, tile kt + 1 in set 1, set 0 free
-        if (kt + 2 < nk) load_tile(ra0, rb0);
-        compute(0);
-        store_tile(1, ra1, rb1);
+    if (DEEP) {
+        if (nk > 1) load_tile(ra1, rb1);                        // tile 1
         __syncthreads();
-        // odd iteration: tile kt + 1 in LDS buffer 1, tile kt + 2 in set 0, set 1 free
-        if (kt + 3 < nk) load_tile(ra1, rb1);
-        compute(1);
-        if (kt + 2 < nk) store_tile(0, ra0, rb0);
+        int kt = 0;
+        for (; kt + 1 < nk; kt += 2) {
+            // even iteration: tile kt in LDS buffer 0, tile kt + 1 in set 1, set 0 free
+            if (kt + 2 < nk) load_tile(ra0, rb0);
+            compute(0);
+            store_tile(1, ra1, rb1);
+            __syncthreads();
+            // odd iteration: tile kt + 1 in LDS buffer 1, tile kt + 2 in set 0, set 1 free
+            if (kt + 3 < nk) load_tile(ra1, rb1);
+            compute(1);
+            if (kt + 2 < nk) store_tile(0, ra0, rb0);
+            __syncthreads();
+        }
+        if (kt < nk) { compute(0); __syncthreads(); }           // (nk odd: the last tile sits in buffer 0)
+    } else {
+        // one tile ahead (one register set): with three or four workgroups per CU the other workgroups cover the latency, and the smaller
+        // register footprint keeps four workgroups of the <= 32-row instances resident (HBM-bound: 5.6 against 5.2 TB/s at n = 16384)
         __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            const int buf = kt & 1;
+            if (kt + 1 < nk) load_tile(ra0, rb0);
+            compute(buf);
+            if (kt + 1 < nk) store_tile(buf ^ 1, ra0, rb0);
+            __syncthreads();
+        }
     }
-    if (kt < nk) { compute(0); __syncthreads(); }           // (nk odd: the last tile sits in buffer 0)
     if (p.ks == 1) {          // no K split: finished values
 #pragma unroll
         for (int i = 0; i < TMW; ++i)
@@ -595,14 +608,19 @@ __global__ __launch_bounds__(256, 3) void gemm_rows_kernel(StripParams p) {
     }
 }
 
-template <bool BNF>
-void launch_rows(int tm, dim3 grid, hipStream_t st, const StripParams& sp) {
+template <bool BNF, bool DEEP>
+void launch_rows2(int tm, dim3 grid, hipStream_t st, const StripParams& sp) {
     switch (tm) {
-        case 1: hipLaunchKernelGGL((gemm_rows_kernel<1, BNF>), grid, dim3(256), 0, st, sp); break;
-        case 2: hipLaunchKernelGGL((gemm_rows_kernel<2, BNF>), grid, dim3(256), 0, st, sp); break;
-        case 3: hipLaunchKernelGGL((gemm_rows_kernel<3, BNF>), grid, dim3(256), 0, st, sp); break;
-        default: hipLaunchKernelGGL((gemm_rows_kernel<4, BNF>), grid, dim3(256), 0, st, sp); break;
+        case 1: hipLaunchKernelGGL((gemm_rows_kernel<1, BNF, DEEP>), grid, dim3(256), 0, st, sp); break;
+        case 2: hipLaunchKernelGGL((gemm_rows_kernel<2, BNF, DEEP>), grid, dim3(256), 0, st, sp); break;
+        case 3: hipLaunchKernelGGL((gemm_rows_kernel<3, BNF, DEEP>), grid, dim3(256), 0, st, sp); break;
+        default: hipLaunchKernelGGL((gemm_rows_kernel<4, BNF, DEEP>), grid, dim3(256), 0, st, sp); break;
     }
+}
+// two tiles ahead when a CU holds at most two workgroups of the launch (mid-size operands), one tile ahead otherwise
+template <bool BNF>
+void launch_rows(int tm, dim3 grid, hipStream_t st, const StripParams& sp, bool deep) {
+    if (deep) launch_rows2<BNF, true>(tm, grid, st, sp); else launch_rows2<BNF, false>(tm, grid, st, sp);
 }
 
 template <bool BNF>
@@ -748,8 +766,9 @@ int gemm_f64(ctm_ctx* ctx, const GemmDesc& d) {
         HeavyScope heavy(ctx, 2.0 * d.M * d.N * (double)d.K);
         int e0 = timing_begin(ctx);
         if (rows_kernel) {
-            if (bnf) launch_rows<true>((d.M + 15) / 16, dim3(d.N / 128, ks), ctx->stream, sp);
-            else launch_rows<false>((d.M + 15) / 16, dim3(d.N / 128, ks), ctx->stream, sp);
+            const bool deep = ctx->rows_deep_prefetch && (long long)(d.N / 128) * ks <= 512;
+            if (bnf) launch_rows<true>((d.M + 15) / 16, dim3(d.N / 128, ks), ctx->stream, sp, deep);
+            else launch_rows<false>((d.M + 15) / 16, dim3(d.N / 128, ks), ctx->stream, sp, deep);
         }
         else if (bnf) launch_strip<true>((d.M + 15) / 16, dim3(gx, ks), ctx->stream, sp);
         else launch_strip<false>((d.M + 15) / 16, dim3(gx, ks), ctx->stream, sp);

@@ -3263,6 +3263,20 @@ static int eigh_warm_verify_c(ctm_ctx* ctx, const double* Asr, const double* Asi
 // Q not orthonormal to 1e-12, no acceptance after eigh_orth_max applications -- returns with *accepted = false and the regular route runs.
 // Returned gauge: rows aligned with the previous vectors (warm_i <- sign<x_i, warm_i> x_i, u_i = sign(theta_i) warm_i), as the
 // regular route and the warm restart return them.
+// Adaptive state of the orthogonal iteration (contraction rate of the last accepted solve, back-off after a flat spectrum): a property
+// of the PROBLEM, i.e. of the caller's warm workspace -- contexts are shared by problems and handed to units dynamically, so the state is
+// keyed by the workspace pointer (process-wide), not kept on the context.
+struct OrthState { double rate = 0.0; int skip = 0, backoff = 0; };
+static std::mutex g_orth_mutex;
+static std::map<const double*, OrthState> g_orth_state;
+static OrthState orth_state_get(const double* ws) { std::lock_guard<std::mutex> l(g_orth_mutex); auto it = g_orth_state.find(ws); return it == g_orth_state.end() ? OrthState() : it->second; }
+static void orth_state_put(const double* ws, const OrthState& st) {
+    std::lock_guard<std::mutex> l(g_orth_mutex);
+    if (g_orth_state.size() > 4096) g_orth_state.clear();          // (workspaces come and go with the environments that own them)
+    g_orth_state[ws] = st;
+}
+void eigh_orth_state_reset() { std::lock_guard<std::mutex> l(g_orth_mutex); g_orth_state.clear(); }
+
 static int eigh_orth_iter(ctm_ctx* ctx, const double* As, int n, int kk, int k_out, double* warm, double* D, double* Ut, bool* accepted,
                           bool warm_checked, double moved) {
     *accepted = false;
@@ -3335,8 +3349,9 @@ static int eigh_orth_iter(ctm_ctx* ctx, const double* As, int n, int kk, int k_o
         // (the contraction the previous accepted solve of this context saw from its own `moved` to its accepted residual -- a property
         //  of the spectrum, which changes slowly from sweep to sweep -- places the first look better than the fixed guess: a signed
         //  random C4v state contracts by 0.25-0.33 per application, not 0.01, and paid three looks per solve)
-        const double rho = ctx->eigh_orth_rate > 0.0 ? ctx->eigh_orth_rate : 1e-2;
-        const int need = (int)std::ceil(std::log(0.5 * tol / std::min(moved, 1.0)) / std::log(rho) + (ctx->eigh_orth_rate > 0.0 ? 0.5 : 0.0));      // applications
+        const double prev_rate = orth_state_get(warm).rate;
+        const double rho = prev_rate > 0.0 ? prev_rate : 1e-2;
+        const int need = (int)std::ceil(std::log(0.5 * tol / std::min(moved, 1.0)) / std::log(rho) + (prev_rate > 0.0 ? 0.5 : 0.0));      // applications
         next_rr = std::min(max_it, std::max(min_rr, need - 1));
     }
     for (int it = 0; it <= max_it; ++it) {
@@ -3385,8 +3400,12 @@ static int eigh_orth_iter(ctm_ctx* ctx, const double* As, int n, int kk, int k_o
                 CTM_LAUNCH(ctx, signed_rows_kernel, dim3(256), dim3(256), 0, (const double*)AX, (const double*)Dp, 1, k_out, n, Ut);
                 CTM_HIP_CHECK(ctx, hipMemcpyAsync(D, Dp, sizeof(double) * k_out, hipMemcpyDeviceToDevice, ctx->stream));
                 ctx->si_hits += 1; ctx->eigh_orth_hits += 1;
-                ctx->eigh_orth_backoff = 0;
-                if (moved > 0.0) ctx->eigh_orth_rate = std::min(0.9, std::max(1e-3, std::pow(std::max(worst / lam0, 1e-16) / std::min(moved, 1.0), 1.0 / (it + 1))));
+                {
+                    OrthState os = orth_state_get(warm);
+                    os.backoff = 0;
+                    if (moved > 0.0) os.rate = std::min(0.9, std::max(1e-3, std::pow(std::max(worst / lam0, 1e-16) / std::min(moved, 1.0), 1.0 / (it + 1))));
+                    orth_state_put(warm, os);
+                }
                 ctx->si_last_iters = it + 1; ctx->si_total_iters += it + 1;
                 *accepted = true;
                 return CTM_OK;
@@ -3402,8 +3421,12 @@ static int eigh_orth_iter(ctm_ctx* ctx, const double* As, int n, int kk, int k_o
                 if (!(needd <= (double)(max_it - it))) {
                     if (ctx->jacobi_verbose) fprintf(stderr, "[eigh-orth] contraction %.3f per application: %.0f more needed, leaving\n", rate, needd);
                     ctx->eigh_orth_fails += 1;
-                    ctx->eigh_orth_backoff = std::min(64, std::max(2, 2 * ctx->eigh_orth_backoff));
-                    ctx->eigh_orth_skip = ctx->eigh_orth_backoff;
+                    {
+                        OrthState os = orth_state_get(warm);
+                        os.backoff = std::min(64, std::max(2, 2 * os.backoff));
+                        os.skip = os.backoff;
+                        orth_state_put(warm, os);
+                    }
                     return CTM_OK;
                 }
                 need = std::max(1, std::min((int)std::ceil(needd), looks >= 1 ? 12 : 6));      // (the first estimate includes the fast initial drop)
@@ -3437,7 +3460,8 @@ int jacobi_eigh_top(ctm_ctx* ctx, const double* A, int n, int k, double* D, doub
             double moved = 0.0;
             CTM_TRY(eigh_warm_verify(ctx, As, n, kk, k_out, warm, D, Ut, &accepted, false, &norms_ok, &moved));
             if (accepted) return CTM_OK;
-            if (ctx->eigh_orth_iter && ctx->eigh_orth_skip > 0) ctx->eigh_orth_skip -= 1;
+            OrthState os = ctx->eigh_orth_iter ? orth_state_get(warm) : OrthState();
+            if (ctx->eigh_orth_iter && os.skip > 0) { os.skip -= 1; orth_state_put(warm, os); }
             else if (ctx->eigh_orth_iter) {
                 CTM_TRY(eigh_orth_iter(ctx, As, n, kk, k_out, warm, D, Ut, &accepted, norms_ok, moved));
                 if (accepted) return CTM_OK;

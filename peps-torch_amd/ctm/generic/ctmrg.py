@@ -164,8 +164,17 @@ def ctm_MOVE(direction, state, env, ctm_args=cfg.ctm_args, global_args=cfg.globa
         # that only overlap with other units'); two at a time otherwise (same sweep time, half the workspace, and the chip-filling
         # kernels of a low-rank unit share the chip with one other launch instead of three)
         krylov = env.__dict__.get("_krylov_units", False)
-        pool = units.pool_for(eng, len(mine), max(_proj_rows(direction, c, state, chi) for c in mine), like.dtype.is_complex,
+        nmax = max(_proj_rows(direction, c, state, chi) for c in mine)
+        # workspace of one unit: 14 n^2 elements when its four enlarged corners live in the arena; with the corner cache they live in the
+        # cache buffers and the arena holds the corner intermediates and the Krylov bases (measured high-water marks: 3.3 n^2 elements at
+        # n = 16384 float64) -- what lets configs[4] (n = 24576 complex128, 155 GB of cached corners) keep more than one unit in flight
+        elem = 16 if like.dtype.is_complex else 8
+        cached = getattr(ctm_args, "corner_cache", True) and ctm_args.projector_method == '4X4' and hasattr(eng, "corner_numel") and \
+            4 * len(coords) * nmax * nmax * elem <= 0.6 * torch.cuda.get_device_properties(like.device).total_memory
+        pool = units.pool_for(eng, len(mine), nmax, like.dtype.is_complex, est_bytes=(4.5 * nmax * nmax * elem) if cached else None,
                               large_n_units=None if krylov else 2)
+    if pool is not None and nmax >= 8192 and hasattr(eng, "trim_own") and eng.own_stat("arena_total") > 2 ** 30:
+        eng.trim_own()       # the units run on the workers' contexts: an arena this engine grew in an earlier (serial) phase is tens of GB of idle HBM
     lz_before = eng.stat("lz_hits") if hasattr(eng, "stat") else 0
 
     def _each(fn, items, stagger=0.0):

@@ -123,7 +123,12 @@ def pool_for(engine, nunits, n, is_complex, est_bytes=None, large_n_units=None):
         return None
     total = torch.cuda.get_device_properties(engine.device).total_memory
     est = est_bytes if est_bytes is not None else 14.0 * n * n * 8 * (2 if is_complex else 1)   # corners, products, work
-    nw = int(min(nunits, max(1, (0.5 * total) // max(est, 1.0))))
+    # budget: half the device, and not more than what is free right now plus what the pool's contexts already hold (cached enlarged
+    # corners and the environment are not the pool's to use)
+    with _lock:
+        held = _held_bytes(_pools.get(engine.device.index), UnitPool.MAX_SLOTS)
+    budget = min(0.5 * total, 0.9 * (torch.cuda.mem_get_info(engine.device)[0] + held))
+    nw = int(min(nunits, max(1, budget // max(est, 1.0))))
     if n >= 8192:
         # kernels of this size fill the chip on their own, but the latency-bound stages of a unit (block orthogonalisations, the
         # dense SVD of the Ritz matrix: ~40 % of a full-rank unit's time, a few workgroups wide) only overlap with OTHER units'
@@ -143,7 +148,7 @@ def pool_for(engine, nunits, n, is_complex, est_bytes=None, large_n_units=None):
         # contexts beyond the slots this call uses keep their arenas: when they and this call's estimate do not fit the budget
         # together, give the idle ones back (between calls every arena stack is empty)
         idle = pool.engines[nw:]
-        if idle and _held_bytes(pool, len(pool.engines)) - _held_bytes(pool, nw) + nw * est > 0.5 * total:
+        if idle and _held_bytes(pool, len(pool.engines)) - _held_bytes(pool, nw) + nw * est > budget:
             with pool.cv:
                 if not pool.busy:
                     for e in idle:
