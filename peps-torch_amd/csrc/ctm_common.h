@@ -94,6 +94,7 @@ struct ctm_ctx {
     int eigh_orth_iter = 1;            // refused warm restart (the matrix moved): symmetric orthogonal iteration with Cholesky-QR steps and ONE Rayleigh-Ritz
     int eigh_orth_max = 32;            // ... applications before it gives up (the regular block iteration runs then; an application + Cholesky-QR
                                        //     step costs a quarter of a half step of that iteration, so a slowly contracting block stays here)
+    int eigh_orth_extra_blocks = 0;    // ... additional 64-row blocks of guard rows
     int eigh_orth_predict = 1;         // ... its looks (Rayleigh-Ritz + residual test) are placed where the residual is predicted to pass
     double eigh_orth_quad_exit = 1e-9; // ... early exit of its small Jacobi eigensolver (see lz_quad_exit; the residual test certifies what it returns)
     long eigh_orth_hits = 0, eigh_orth_fails = 0;

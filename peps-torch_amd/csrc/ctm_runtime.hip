@@ -159,6 +159,7 @@ int ctm_set_option(ctm_ctx* ctx, const char* key, double value) {
     else if (k == "eigh_probe_orth_once") ctx->eigh_probe_orth_once = (int)value;
     else if (k == "eigh_orth_iter") { ctx->eigh_orth_iter = (int)value; eigh_orth_state_reset(); }
     else if (k == "eigh_orth_max") ctx->eigh_orth_max = (int)value;
+    else if (k == "eigh_orth_extra_blocks") ctx->eigh_orth_extra_blocks = (int)value;
     else if (k == "eigh_orth_predict") ctx->eigh_orth_predict = (int)value;
     else if (k == "eigh_orth_quad_exit") ctx->eigh_orth_quad_exit = value;
     else if (k == "svd_abs_accuracy") ctx->svd_abs_accuracy = (int)value;

@@ -2247,8 +2247,19 @@ __global__ __launch_bounds__(64) void chol64_scaled_inv_kernel(const double* __r
 // rows of W (64 x n) -> orthonormal rows spanning the same space: two Cholesky-QR passes, and a third one -- decided on the device --
 // when the first had to shift (nearly dependent rows); no host synchronisation.  Status words of the three passes go to
 // `status` (9 doubles: pivot, min norm, max norm per pass; a skipped third pass reports 1), `flag3` is a device word.
+__global__ void mark_third_skipped_kernel(double* status, int nslots, int sw) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nslots) { status[(size_t)sw * i + 6] = 1.0; status[(size_t)sw * i + 7] = -1.0; status[(size_t)sw * i + 8] = -1.0; }
+}
+
 int orthonormalise_block_async(ctm_ctx* ctx, double* W, int b, int n, double* G, double* Li, double* status, int* flag3) {
-    for (int pass = 0; pass < 3; ++pass) {
+    // 32-row blocks: two passes.  The third one exists for a first pass that had to shift (64 nearly dependent rows: ~1.6 of the 28 blocks
+    // of a D = 8 solve); 32 rows are better conditioned -- not one shifted pass in any 32-row run so far -- and the always-enqueued,
+    // flag-skipped third pass was three idle launches per block (129 per unit).  Should a first pass shift all the same, the second
+    // pass reports a pivot below 0.5 and the caller repeats the solve on the synchronous path, as for any other status it does not like.
+    // (the caller has marked the third-pass words of every status slot as skipped: mark_third_skipped_kernel)
+    const int npass = b == 32 ? 2 : 3;
+    for (int pass = 0; pass < npass; ++pass) {
         GemmDesc g; g.M = b; g.N = b; g.K = n; g.A = W; g.sam = n; g.sak = 1; g.B = W; g.sbk = 1; g.sbn = n; g.C = G; g.ldc = b;
         if (pass == 2) g.skip_all = flag3;
         CTM_TRY(gemm_f64(ctx, g));
@@ -2325,6 +2336,7 @@ int svd_lanczos(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* Ut, dou
         CTM_TRY(arena_alloc(ctx, sizeof(double) * SW * nstat, (void**)&ostat));
         CTM_TRY(arena_alloc(ctx, sizeof(double) * 64 * 64, (void**)&Li));
         CTM_TRY(arena_alloc(ctx, sizeof(int) * 64, (void**)&flag3));
+        if (b == 32) CTM_LAUNCH(ctx, mark_third_skipped_kernel, dim3((nstat + 255) / 256), dim3(256), 0, ostat, nstat, SW);     // two-pass blocks
     }
     auto resync = [&]() -> int {          // redo this solve on the synchronous path
         if (ctx->jacobi_verbose) fprintf(stderr, "[lz] n=%d asynchronous recurrence flagged: repeating on the synchronous path\n", n);
@@ -3282,6 +3294,9 @@ static int eigh_orth_iter(ctm_ctx* ctx, const double* As, int n, int kk, int k_o
     *accepted = false;
     int p = kk + std::max(32, kk / 2);
     p = ((p + 63) / 64) * 64;
+    // more guard rows (whole 64-row blocks): the residual contracts by |lambda_{p+1} / lambda_kk| per application, so a spectrum that
+    // decays slowly behind the kept pairs (signed random C4v tensors: 0.25-0.33 with 55 guard rows) needs fewer applications with more
+    if (ctx->eigh_orth_extra_blocks > 0 && p + 64 * ctx->eigh_orth_extra_blocks < n / 2) p += 64 * ctx->eigh_orth_extra_blocks;
     if (kk < 2 || p >= n / 2) return CTM_OK;
     ArenaScope scope(ctx);
     const int nb = p / 64, pr = p - kk;
