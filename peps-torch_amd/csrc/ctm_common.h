@@ -149,6 +149,7 @@ struct ctm_ctx {
                                   //     prologue, epilogue and an 18-slab combine (D = 6 chi = 128 sweep +8-12 %; n >= 12288 keeps its slice count).  Round 3 saw one
                                   //     full test run with 576 end in a core dump; round 4 could not reproduce it: the shape sweep through every epilogue
                                   //     (tests/test_gpu_gemm_rows.py, ks = 1 included) and the whole suite under AddressSanitizer with 576 are clean
+    int rows_min_klen_hbm = 576;      // ... the same bound for <= 32-row blocks (HBM-bound)
     bool rows_deep_prefetch = true;   // ... two K tiles in flight per workgroup when at most two workgroups share a CU (mid-size operands)
     bool rows_quantise = true;    // ... its slice count is rounded down so that the last round of workgroups over the 256 CUs is nearly full
     int rows_target_wgs = 768;    // its workgroup count (column tiles x K slices): three per CU

@@ -148,6 +148,7 @@ int ctm_set_option(ctm_ctx* ctx, const char* key, double value) {
     else if (k == "rows_kernel_min_m_kc") ctx->rows_kernel_min_m_kc = (int)value;
     else if (k == "rows_target_wgs") ctx->rows_target_wgs = (int)value;
     else if (k == "rows_min_klen") ctx->rows_min_klen = (int)value;
+    else if (k == "rows_min_klen_hbm") ctx->rows_min_klen_hbm = (int)value;
     else if (k == "rows_quantise") ctx->rows_quantise = value != 0.0;
     else if (k == "rows_deep_prefetch") ctx->rows_deep_prefetch = value != 0.0;
     else if (k == "rows_fused_reduce") ctx->rows_fused_reduce = value != 0.0;

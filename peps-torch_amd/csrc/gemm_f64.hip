@@ -724,8 +724,10 @@ int gemm_f64(ctm_ctx* ctx, const GemmDesc& d) {
         // mid-size operands (n = 4608: 36 column tiles) would run 18 slices of 256 k: no slice shorter than rows_min_klen, but at least
         // two slices (a single slice means N / 128 workgroups: 36 on 256 CUs).  The direct-write epilogue (ks == 1) is reached when the
         // column tiles alone fill the target (N >= 128 * rows_target_wgs) or by option; tests/test_gpu_gemm_rows.py drives it.
-        if (rows_kernel && ctx->rows_min_klen > 256 && ks > 2) {
-            ks = std::max(2, std::min(ks, d.K / ctx->rows_min_klen));
+        // (<= 32 rows are HBM-bound: what a CU needs there is bytes in flight, i.e. more, shorter workgroups -- rows_min_klen_hbm)
+        const int min_klen = d.M <= 32 ? ctx->rows_min_klen_hbm : ctx->rows_min_klen;
+        if (rows_kernel && min_klen > 256 && ks > 2) {
+            ks = std::max(2, std::min(ks, d.K / min_klen));
             // ... and no partial round of workgroups: 36 column tiles x 8 slices = 288 workgroups on 256 CUs leave 32 CUs with two
             // MFMA-bound workgroups and the others with one (the launch takes as long as 512); 7 slices = 252 fill one round.  Among the
             // slice counts allowed above, take the largest whose workgroup count is at most a multiple of the CU count that it nearly

@@ -9,7 +9,9 @@ bash tools/profile_bench.sh default_serial -- --no-full-rank $X --serial-units >
 bash tools/profile_bench.sh signed --pmc -- --signed $X > gpurun_out/prof_signed.log 2>&1
 bash tools/profile_bench.sh signed_serial --mfma -- --signed $X --serial-units > gpurun_out/prof_signed_serial.log 2>&1
 bash tools/profile_bench.sh c4v -- --config c4v_D4_chi64 --no-cpu-baseline > gpurun_out/prof_c4v.log 2>&1
+bash tools/profile_bench.sh c128_signed -- --config generic_D8_chi384_c128 --signed --steps 1 --warmup 2 --no-cpu-baseline --no-serial-pass --no-energy > gpurun_out/prof_c128_signed.log 2>&1
 python bench.py > gpurun_out/bench_final.json 2> gpurun_out/bench_final.err
+cp gpurun_out/bench_detail.json gpurun_out/bench_final_detail.json
 python bench.py --steps 20 --warmup 5 --no-other-configs --no-energy --no-cpu-baseline > gpurun_out/bench_20steps.json 2>/dev/null
 python bench.py --config c4v_D4_chi64 > gpurun_out/bench_c4v_final.json 2>/dev/null
 tail -c 600 gpurun_out/bench_final.json
