@@ -522,8 +522,11 @@ def traffic_from_profile(args, world, dom, signed):
                 if any(k_ in row["kernel"] for k_ in keys):
                     tb += float(row["hbm_bytes_per_launch(2x_fetch_corrected)"]) * float(row["launches"]); tn += float(row["launches"])
             return round(tb / tn) if tn else None
+        cfile = os.path.join(REPO, "profiles", f"{rnd}_pmc_commit.txt")
+        commit = open(cfile).read().strip() if os.path.exists(cfile) else "unrecorded"
         return {"dominant": pmc(CLS[dom][2]), "others": {str(i): pmc(CLS[i][2]) for i in CLS if i != dom},
-                "source": f"profiles/{os.path.basename(fcsv)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, average HBM bytes per launch)"}
+                "source": f"profiles/{os.path.basename(fcsv)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on the build of commit {commit}, "
+                          "average HBM bytes per launch; read from the committed file, not measured by this run)"}
     except Exception:
         return None
 

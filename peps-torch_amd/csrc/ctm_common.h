@@ -107,6 +107,7 @@ struct ctm_ctx {
     double lz_first_factor32 = 2.5;     // ... with 32-row blocks
     int lz_block = 0;                   // rows per block of the real block Krylov recurrence: 64, 32, or 0 = 32 for k > lz_block32_min_k
     int lz_block32_min_k = 0;           // (32-row blocks for every k: D = 6 chi = 128 full rank 0.49-0.57 -> 0.39 s/sweep, D = 8 chi = 256 3.26 -> 3.12)
+    int lz_block_c = 32;                // complex rows per block of the complex recurrence (64 or 32; D = 8 chi = 384: 34.3 -> 31.6 s per full-rank sweep)
     long lz_total_rows = 0;             // basis rows over all accepted solves (steps x block)
     bool lz_verify_op = false;          // additionally check both relations of the Ritz triplets with operator applications (debug / tests)
     long lz_extractions = 0; double lz_last_est = 0.0; int lz_last_steps = 0;
@@ -162,6 +163,7 @@ struct ctm_ctx {
     long heavy_launches = 0;
     bool rows_fused_reduce = true;      // its K-slice partials are summed inside the launch by the last workgroup of a column tile
     unsigned* tile_cnt = nullptr;       // per-column-tile arrival counters of that combine (zero between launches)
+    bool xgemm_stack_rows = true; // complex row blocks (<= 64 rows, planes contiguous): two real products on the stacked 2M rows instead of four
     bool gemm_split_rem = true;   // split a 128 q + r (r <= 64) dimension into a vectorised part and a strip
     int splitk_max_tiles = 256, splitk_target_wgs = 1024;   // split-K of skinny GEMMs: when few output tiles, how many workgroups to aim for
     bool eig64_pingpong = true;

@@ -144,6 +144,7 @@ int ctm_set_option(ctm_ctx* ctx, const char* key, double value) {
     else if (k == "gemm_strip") ctx->gemm_strip = value != 0.0;
     else if (k == "strip_target_wgs") ctx->strip_target_wgs = (int)value;
     else if (k == "gemm_split_rem") ctx->gemm_split_rem = value != 0.0;
+    else if (k == "xgemm_stack_rows") ctx->xgemm_stack_rows = value != 0.0;
     else if (k == "rows_kernel_min_m") ctx->rows_kernel_min_m = (int)value;
     else if (k == "rows_kernel_min_m_kc") ctx->rows_kernel_min_m_kc = (int)value;
     else if (k == "rows_target_wgs") ctx->rows_target_wgs = (int)value;
@@ -179,6 +180,7 @@ int ctm_set_option(ctm_ctx* ctx, const char* key, double value) {
     else if (k == "lz_first_factor32") ctx->lz_first_factor32 = value;
     else if (k == "lz_block") ctx->lz_block = (int)value;
     else if (k == "lz_block32_min_k") ctx->lz_block32_min_k = (int)value;
+    else if (k == "lz_block_c") ctx->lz_block_c = (int)value;
     else if (k == "lz_verify_op") ctx->lz_verify_op = value != 0.0;
     else if (k == "lz_async") ctx->lz_async = value != 0.0;
     else if (k == "lz_jacobi_block") ctx->lz_jacobi_block = (int)value;

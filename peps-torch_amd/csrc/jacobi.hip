@@ -295,7 +295,8 @@ __device__ __forceinline__ void jacobi_cs(double a, double b, double g, double t
 // NOJ: the eigenvector matrix is not accumulated (half of the LDS traffic of a round: the kernel is LDS-bandwidth bound, 143 KB per round
 // against 128 B/clk); the (c, s) of every rotation of the ONE pass go to p.rot and the final row order to p.perm, and
 // rot_apply64_kernel applies the sequence to the panel rows -- the same arithmetic as X <- J^T X, done on the vector ALUs, one column per lane.
-template <int BPT, bool NOJ = false>     // 2x2 blocks per thread: 1024 / BPT threads per workgroup
+template <int BPT, bool NOJ = false, bool CROSS = false>     // 2x2 blocks per thread: 1024 / BPT threads per workgroup; CROSS: cross-pair rounds (compile time: a
+// run-time choice of the pairing inside the round loop cost 10 % of the kernel -- 600 -> 1130 clocks of address arithmetic + LDS loads per round)
 __global__ __launch_bounds__(1024 / BPT) void small_eig64_kernel(SmallEigParams p) {
     constexpr int M = 64, H = 32, NTH = 1024 / BPT, NW = NTH / 64, KS = H / BPT, EPT = (M * M) / NTH;
     __shared__ double Wb[2][M][M + 1];
@@ -362,7 +363,8 @@ __global__ __launch_bounds__(1024 / BPT) void small_eig64_kernel(SmallEigParams 
 #ifdef CTM_KERNEL_CLOCKS
     long long ck_load = 0, ck_cs = 0, ck_upd = 0, ck_bar = 0;
 #endif
-    const int cross = p.cross, nrounds = cross ? H : M - 1;
+    constexpr bool cross = CROSS;
+    constexpr int nrounds = CROSS ? H : M - 1;
     for (int sweep = 0; sweep < p.max_sweeps; ++sweep) {
         for (int r = 0; r < nrounds; ++r) {
 #ifdef CTM_KERNEL_CLOCKS
@@ -829,13 +831,14 @@ int jacobi_rows(ctm_ctx* ctx, double* X, int R, long long ld, int Cg, int Ctot, 
             sp.tau2 = tau2; sp.tau_both = abs_mode ? 2 : (tau_both ? 1 : 0); sp.stat_rel = stat; sp.stat_abs = stat + 1; sp.flags = flags;
             // cross-only rotations in every round but the first of a sweep (which pairs every panel once and solves the full 64 x 64
             // problems: the intra-panel pairs); many-panel problems only (the dense SVD of a Ritz matrix, full-block Rayleigh-Ritz)
-            sp.cross = (ctx->jacobi_cross_only && !cplx && m == 64 && ctx->eig64_pingpong && pairs >= 4 && r > 0) ? 1 : 0;
+            sp.cross = (ctx->jacobi_cross_only && !cplx && m == 64 && ctx->eig64_pingpong && ctx->eig64_bpt == 2 && pairs >= 4 && r > 0) ? 1 : 0;
             // many-panel real problems with ONE inner pass per visit: the eigensolver records its rotations instead of accumulating J, and the
             // panel rows are rotated on the vector ALUs (rot_apply64_kernel) -- no J in LDS (the eigensolver is LDS-bandwidth bound), no apply GEMM
             const bool use_rot = ctx->jacobi_rot_apply && !cplx && m == 64 && ctx->eig64_pingpong && sp.max_sweeps == 1 && rot != nullptr;
             if (use_rot) {
                 sp.rot = rot; sp.perm = perm;
-                CTM_LAUNCH(ctx, (small_eig64_kernel<2, true>), dim3(pairs), dim3(512), 0, sp);
+                if (sp.cross) CTM_LAUNCH(ctx, (small_eig64_kernel<2, true, true>), dim3(pairs), dim3(512), 0, sp);
+                else CTM_LAUNCH(ctx, (small_eig64_kernel<2, true, false>), dim3(pairs), dim3(512), 0, sp);
                 const dim3 grid((Ctot + 255) / 256, pairs);
                 if (sp.cross) CTM_LAUNCH(ctx, rot_apply64_kernel<true>, grid, dim3(256), 0, X, ld, Ctot, (const GemmOff*)(T->d_apply + (size_t)r * pairs), (const double*)rot, (const int*)perm, (const int*)flags);
                 else CTM_LAUNCH(ctx, rot_apply64_kernel<false>, grid, dim3(256), 0, X, ld, Ctot, (const GemmOff*)(T->d_apply + (size_t)r * pairs), (const double*)rot, (const int*)perm, (const int*)flags);
@@ -844,6 +847,7 @@ int jacobi_rows(ctm_ctx* ctx, double* X, int R, long long ld, int Cg, int Ctot, 
             if (cplx) CTM_LAUNCH(ctx, small_eig_c_kernel, dim3(pairs), dim3(256), 0, sp);
             else if (m == 64 && ctx->eig64_pingpong) {
                 if (ctx->eig64_bpt == 4) CTM_LAUNCH(ctx, small_eig64_kernel<4>, dim3(pairs), dim3(256), 0, sp);
+                else if (ctx->eig64_bpt == 2 && sp.cross) CTM_LAUNCH(ctx, (small_eig64_kernel<2, false, true>), dim3(pairs), dim3(512), 0, sp);
                 else if (ctx->eig64_bpt == 2) CTM_LAUNCH(ctx, small_eig64_kernel<2>, dim3(pairs), dim3(512), 0, sp);
                 else CTM_LAUNCH(ctx, small_eig64_kernel<1>, dim3(pairs), dim3(1024), 0, sp);
             }
@@ -2554,31 +2558,31 @@ int svd_lanczos(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* Ut, dou
 // complex128 block Golub-Kahan-Lanczos (planar data): the algorithm of svd_lanczos() with ^T -> ^H.  Row bases hold u^H, v^H.
 // ---------------------------------------------------------------------------------------------
 // Cholesky factor of a 64 x 64 Hermitian Gram matrix (planar) and the inverse of its lower factor
-__global__ __launch_bounds__(256) void chol64_inv_c_kernel(const double* Gr, const double* Gi, double* Lr, double* Li, double* status) {
-    constexpr int M = 64;
+__global__ __launch_bounds__(256) void chol64_inv_c_kernel(const double* Gr, const double* Gi, double* Lr, double* Li, double* status, int m = 64) {
+    constexpr int M = 64;                 // capacity; m <= 64 is the order of the (dense, leading dimension m) matrices
     __shared__ double Ar[M][M + 1], Ai[M][M + 1];
     __shared__ double Xr[M][M + 1], Xi[M][M + 1];
     __shared__ double piv_min;
     const int tid = threadIdx.x;
-    for (int q = tid; q < M * M; q += 256) {
-        const int i = q >> 6, c = q & 63;
+    for (int q = tid; q < m * m; q += 256) {
+        const int i = q / m, c = q - i * m;
         Ar[i][c] = Gr[q]; Ai[i][c] = (i == c) ? 0.0 : Gi[q];
         Xr[i][c] = (i == c) ? 1.0 : 0.0; Xi[i][c] = 0.0;
     }
     if (tid == 0) piv_min = 1e300;
     __syncthreads();
-    for (int j = 0; j < M; ++j) {
+    for (int j = 0; j < m; ++j) {
         const double d = Ar[j][j];
         if (tid == 0) piv_min = fmin(piv_min, d);
         const double l = sqrt(fmax(d, 1e-300));
         __syncthreads();
-        if (tid < M) {
+        if (tid < m) {
             if (tid == j) { Ar[j][j] = l; Ai[j][j] = 0.0; }
             else if (tid > j) { Ar[tid][j] /= l; Ai[tid][j] /= l; }
         }
         __syncthreads();
-        for (int q = tid; q < M * M; q += 256) {            // A[i][c] -= A[i][j] conj(A[c][j])   (lower triangle)
-            const int i = q >> 6, c = q & 63;
+        for (int q = tid; q < m * m; q += 256) {            // A[i][c] -= A[i][j] conj(A[c][j])   (lower triangle)
+            const int i = q / m, c = q - i * m;
             if (c > j && i >= c) {
                 const double xr = Ar[i][j], xi = Ai[i][j], yr = Ar[c][j], yi = Ai[c][j];
                 Ar[i][c] -= xr * yr + xi * yi;
@@ -2587,9 +2591,9 @@ __global__ __launch_bounds__(256) void chol64_inv_c_kernel(const double* Gr, con
         }
         __syncthreads();
     }
-    if (tid < M) {                                            // L X = I, one column per thread
+    if (tid < m) {                                            // L X = I, one column per thread
         const int c = tid;
-        for (int i = c; i < M; ++i) {
+        for (int i = c; i < m; ++i) {
             double ar = (i == c) ? 1.0 : 0.0, ai = 0.0;
             for (int t = c; t < i; ++t) {
                 ar -= Ar[i][t] * Xr[t][c] - Ai[i][t] * Xi[t][c];
@@ -2599,15 +2603,14 @@ __global__ __launch_bounds__(256) void chol64_inv_c_kernel(const double* Gr, con
         }
     }
     __syncthreads();
-    for (int q = tid; q < M * M; q += 256) { const int i = q >> 6, c = q & 63; Lr[q] = (c <= i) ? Xr[i][c] : 0.0; Li[q] = (c <= i) ? Xi[i][c] : 0.0; }
+    for (int q = tid; q < m * m; q += 256) { const int i = q / m, c = q - i * m; Lr[q] = (c <= i) ? Xr[i][c] : 0.0; Li[q] = (c <= i) ? Xi[i][c] : 0.0; }
     if (tid == 0) status[0] = piv_min;
 }
 
 struct CRows { double* re; double* im; };      // planar complex row block (rows x n, leading dimension n)
 
 // rows of W (64 x n complex) -> orthonormal rows: unit-norm scaling + two Cholesky-QR passes; *ok = false on near dependence
-int orthonormalise_block_c(ctm_ctx* ctx, CRows W, int n, double* norms, double* inv, double* min_norm, double* max_norm, bool* ok) {
-    const int rows = 64;
+int orthonormalise_block_c(ctm_ctx* ctx, CRows W, int rows, int n, double* norms, double* inv, double* min_norm, double* max_norm, bool* ok) {
     std::vector<double> h(rows);
     CTM_TRY(row_norms_c128(ctx, W.re, W.im, rows, n, n, norms));
     CTM_HIP_CHECK(ctx, hipMemcpyAsync(h.data(), norms, sizeof(double) * rows, hipMemcpyDeviceToHost, ctx->stream));
@@ -2630,7 +2633,7 @@ int orthonormalise_block_c(ctm_ctx* ctx, CRows W, int n, double* norms, double* 
         std::vector<double> hh; int st;
         const double fro = host_fro(ctx, P, 2 * rows, n, n, norms, hh, &st);
         CTM_TRY(st);
-        CTM_TRY(jacobi_rows(ctx, P, 2 * rows, n, n, n, 2 * BC, 0, fro, ctx->si_rr_sweeps, true));
+        CTM_TRY(jacobi_rows(ctx, P, 2 * rows, n, n, n, 2 * BC, 0, fro, ctx->si_rr_sweeps, true));     // (rows = 32: two panels of 16 complex rows)
         std::vector<int> idx(rows); std::iota(idx.begin(), idx.end(), 0);
         CTM_TRY(panel_gather(ctx, P, n, idx, rows, n, Tp, d_idx));
         CTM_HIP_CHECK(ctx, hipMemcpyAsync(W.re, Tp, sizeof(double) * (size_t)rows * n, hipMemcpyDeviceToDevice, ctx->stream));
@@ -2648,13 +2651,13 @@ int orthonormalise_block_c(ctm_ctx* ctx, CRows W, int n, double* norms, double* 
     double* status = ctx->d_scratch + 16;
     for (int pass = 0; pass < 2; ++pass) {
         XM w{W.re, W.im, n, false, false}, wh{W.re, W.im, n, true, true};
-        CTM_TRY(xgemm(ctx, 64, 64, n, w, wh, G, G + 4096, 64));                       // G = W W^H
-        CTM_LAUNCH(ctx, chol64_inv_c_kernel, dim3(1), dim3(256), 0, (const double*)G, (const double*)(G + 4096), Li, Li + 4096, status);
+        CTM_TRY(xgemm(ctx, rows, rows, n, w, wh, G, G + 4096, rows));                 // G = W W^H
+        CTM_LAUNCH(ctx, chol64_inv_c_kernel, dim3(1), dim3(256), 0, (const double*)G, (const double*)(G + 4096), Li, Li + 4096, status, rows);
         CTM_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_scratch + 16, status, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
         if (!(ctx->h_scratch[16] > (pass == 0 ? 1e-10 : 0.5))) return jacobi_fallback();
-        XM l{Li, Li + 4096, 64, false, false};
-        CTM_TRY(xgemm(ctx, 64, n, 64, l, w, T, T + (size_t)rows * n, n));             // W <- L^-1 W
+        XM l{Li, Li + 4096, rows, false, false};
+        CTM_TRY(xgemm(ctx, rows, n, rows, l, w, T, T + (size_t)rows * n, n));         // W <- L^-1 W
         CTM_HIP_CHECK(ctx, hipMemcpyAsync(W.re, T, sizeof(double) * (size_t)rows * n, hipMemcpyDeviceToDevice, ctx->stream));
         CTM_HIP_CHECK(ctx, hipMemcpyAsync(W.im, T + (size_t)rows * n, sizeof(double) * (size_t)rows * n, hipMemcpyDeviceToDevice, ctx->stream));
     }
@@ -2688,24 +2691,41 @@ int matop_apply_planar(ctm_ctx* ctx, const MatOp& op, bool adjoint, const double
     CTM_TRY(arena_alloc(ctx, sizeof(double) * 2 * rn, (void**)&t2));
     // factor i as the (kin x nout) right operand: stored kin x nout when !t (ld = nout), nout x kin when t (ld = kin)
     auto f = [&](int i, bool t, bool c, int kin, int nout) { XM x{op.c[i], op.ci[i], t ? kin : nout, t, c}; return x; };
-    auto x1 = [&](int ld) { XM x{t1, t1 + rn, ld, false, false}; return x; };
-    auto x2 = [&](int ld) { XM x{t2, t2 + rn, ld, false, false}; return x; };
-    if (!adjoint) {   // B opB(cB)^T opA(cA)^T opC(cC) opD(cD)
-        CTM_TRY(xgemm(ctx, rows, m0, n, b, f(1, !op.t[1], false, n, m0), t1, t1 + rn, m0));
-        CTM_TRY(xgemm(ctx, rows, n, m0, x1(m0), f(0, !op.t[0], false, m0, n), t2, t2 + rn, n));
-        CTM_TRY(xgemm(ctx, rows, m1, n, x2(n), f(2, op.t[2], false, n, m1), t1, t1 + rn, m1));
-        return xgemm(ctx, rows, n, m1, x1(m1), f(3, op.t[3], false, m1, n), Cre, Cim, n);
+    // a block whose planes lie one behind the other is what xgemm multiplies as ONE real block of twice the rows (two real products per
+    // corner pass instead of four): the intermediates are laid out that way (plane stride = rows x ld), and when all four inner
+    // dimensions are equal (uniform bond dimension) the caller's block is staged into that layout and the result copied out of it
+    const bool stack = ctx->xgemm_stack_rows && m0 == n && m1 == n && rows <= 64 && rows % 16 == 0;
+    const size_t rw = (size_t)rows * n;
+    auto x1 = [&](int ld) { XM x{t1, t1 + (stack ? (size_t)rows * ld : rn), ld, false, false}; return x; };
+    auto x2 = [&](int ld) { XM x{t2, t2 + (stack ? (size_t)rows * ld : rn), ld, false, false}; return x; };
+    if (stack) {
+        CTM_HIP_CHECK(ctx, hipMemcpyAsync(t2, Bre, sizeof(double) * rw, hipMemcpyDeviceToDevice, ctx->stream));
+        CTM_HIP_CHECK(ctx, hipMemcpyAsync(t2 + rw, Bim, sizeof(double) * rw, hipMemcpyDeviceToDevice, ctx->stream));
+        b = x2(n);
     }
-    // B opD(cD)^H opC(cC)^H conj(opA(cA)) conj(opB(cB))
-    CTM_TRY(xgemm(ctx, rows, m1, n, b, f(3, !op.t[3], true, n, m1), t1, t1 + rn, m1));
-    CTM_TRY(xgemm(ctx, rows, n, m1, x1(m1), f(2, !op.t[2], true, m1, n), t2, t2 + rn, n));
-    CTM_TRY(xgemm(ctx, rows, m0, n, x2(n), f(0, op.t[0], true, n, m0), t1, t1 + rn, m0));
-    return xgemm(ctx, rows, n, m0, x1(m0), f(1, op.t[1], true, m0, n), Cre, Cim, n);
+    double* Or = stack ? t2 : Cre;                       // (the last product writes a stacked block, copied out below)
+    double* Oi = stack ? t2 + rw : Cim;
+    if (!adjoint) {   // B opB(cB)^T opA(cA)^T opC(cC) opD(cD)
+        CTM_TRY(xgemm(ctx, rows, m0, n, b, f(1, !op.t[1], false, n, m0), t1, x1(m0).im ? const_cast<double*>(x1(m0).im) : nullptr, m0));
+        CTM_TRY(xgemm(ctx, rows, n, m0, x1(m0), f(0, !op.t[0], false, m0, n), t2, const_cast<double*>(x2(n).im), n));
+        CTM_TRY(xgemm(ctx, rows, m1, n, x2(n), f(2, op.t[2], false, n, m1), t1, const_cast<double*>(x1(m1).im), m1));
+        CTM_TRY(xgemm(ctx, rows, n, m1, x1(m1), f(3, op.t[3], false, m1, n), Or, Oi, n));
+    } else {          // B opD(cD)^H opC(cC)^H conj(opA(cA)) conj(opB(cB))
+        CTM_TRY(xgemm(ctx, rows, m1, n, b, f(3, !op.t[3], true, n, m1), t1, const_cast<double*>(x1(m1).im), m1));
+        CTM_TRY(xgemm(ctx, rows, n, m1, x1(m1), f(2, !op.t[2], true, m1, n), t2, const_cast<double*>(x2(n).im), n));
+        CTM_TRY(xgemm(ctx, rows, m0, n, x2(n), f(0, op.t[0], true, n, m0), t1, const_cast<double*>(x1(m0).im), m0));
+        CTM_TRY(xgemm(ctx, rows, n, m0, x1(m0), f(1, op.t[1], true, m0, n), Or, Oi, n));
+    }
+    if (stack) {
+        CTM_HIP_CHECK(ctx, hipMemcpyAsync(Cre, t2, sizeof(double) * rw, hipMemcpyDeviceToDevice, ctx->stream));
+        CTM_HIP_CHECK(ctx, hipMemcpyAsync(Cim, t2 + rw, sizeof(double) * rw, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    return CTM_OK;
 }
 
 int svd_lanczos_c(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* Ut, double* Vt, bool* converged) {
     *converged = false;
-    const int n = op.n, b = 64;
+    const int n = op.n, b = ctx->lz_block_c == 32 ? 32 : 64;          // complex rows per block (see svd_lanczos on the block size)
     const int jmin = (k + b - 1) / b + 1;
     const int jmax = std::min((n / 2) / b, (6 * k) / b + 8);
     if (jmax < jmin + 1) return CTM_OK;
@@ -2744,7 +2764,7 @@ int svd_lanczos_c(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* Ut, d
     bool ok;
     CTM_LAUNCH(ctx, hash_fill_kernel, dim3(1024), dim3(256), 0, Vall, b, n, (long long)n, 0x51f15eedULL);
     CTM_LAUNCH(ctx, hash_fill_kernel, dim3(1024), dim3(256), 0, Vall + planeV, b, n, (long long)n, 0x0dd5eedULL);
-    CTM_TRY(orthonormalise_block_c(ctx, Vr(0), n, norms, inv, &mn, &mx, &ok));
+    CTM_TRY(orthonormalise_block_c(ctx, Vr(0), b, n, norms, inv, &mn, &mx, &ok));
     if (!ok) return CTM_OK;
     int applications = 0;
     for (int j = 0; j < jmax; ++j) {
@@ -2753,14 +2773,14 @@ int svd_lanczos_c(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* Ut, d
         CTM_HIP_CHECK(ctx, hipMemcpyAsync(Uj.re, Wj.re, sizeof(double) * bn, hipMemcpyDeviceToDevice, ctx->stream));
         CTM_HIP_CHECK(ctx, hipMemcpyAsync(Uj.im, Wj.im, sizeof(double) * bn, hipMemcpyDeviceToDevice, ctx->stream));
         CTM_TRY(project_out_c(ctx, Uj, b, n, Uall, Uall + planeU, j * b, G, T2));
-        CTM_TRY(orthonormalise_block_c(ctx, Uj, n, norms, inv, &mn, &mx, &ok));
+        CTM_TRY(orthonormalise_block_c(ctx, Uj, b, n, norms, inv, &mn, &mx, &ok));
         s0 = std::max(s0, mx);
         if (!ok || mn <= 1e-13 * s0) { if (ctx->jacobi_verbose) fprintf(stderr, "[lz-c] n=%d breakdown at step %d (U)\n", n, j); return CTM_OK; }
         CTM_TRY(matop_apply_planar(ctx, op, false, Uj.re, Uj.im, b, Zj.re, Zj.im)); applications += b;
         CTM_HIP_CHECK(ctx, hipMemcpyAsync(Vn.re, Zj.re, sizeof(double) * bn, hipMemcpyDeviceToDevice, ctx->stream));
         CTM_HIP_CHECK(ctx, hipMemcpyAsync(Vn.im, Zj.im, sizeof(double) * bn, hipMemcpyDeviceToDevice, ctx->stream));
         CTM_TRY(project_out_c(ctx, Vn, b, n, Vall, Vall + planeV, (j + 1) * b, G, T2));
-        CTM_TRY(orthonormalise_block_c(ctx, Vn, n, norms, inv, &mn, &mx, &ok));
+        CTM_TRY(orthonormalise_block_c(ctx, Vn, b, n, norms, inv, &mn, &mx, &ok));
         if (!ok || mn <= 1e-13 * s0) { if (ctx->jacobi_verbose) fprintf(stderr, "[lz-c] n=%d breakdown at step %d (V)\n", n, j); return CTM_OK; }
         const int steps = j + 1, m = steps * b;
         if (steps < jnext && steps < jmax) continue;

@@ -184,3 +184,42 @@ def test_many_panel_block_jacobi_variants_against_lapack(eng, opts):
     assert np.abs(Ug[:, :kk].T @ Ug[:, :kk] - np.eye(kk)).max() < 1e-12
     assert np.abs(Vg[:, :kk].T @ Vg[:, :kk] - np.eye(kk)).max() < 1e-12
     assert np.abs((Ug * Sg) @ Vg.T - M).max() < 1e-13 * ref[0] * n
+
+
+def test_complex_krylov_solver_variants_agree(eng):
+    """complex128 twin of test_krylov_solver_variants_agree (signed complex 2x2 state, D = 4, chi = 64, n = 1024, k = 65): 32-row blocks of the
+    complex recurrence, and the corner passes as two real products on the stacked [re; im] rows (xgemm_stack_rows) or as four."""
+    import config as cfg
+    from ipeps.ipeps import IPEPS
+    from ctm.generic.env import ENV, init_env
+    from ctm.generic import ctmrg
+    rng = np.random.default_rng(12)
+    sites = {}
+    for y in range(2):
+        for x in range(2):
+            A = rng.random((2, 4, 4, 4, 4)) - 0.5 + 1j * (rng.random((2, 4, 4, 4, 4)) - 0.5)
+            sites[(x, y)] = torch.from_numpy(A / np.abs(A).max()).cuda()
+
+    def run(opts):
+        for k_, v_ in opts.items(): eng.set_option(k_, v_)
+        try:
+            st = IPEPS(dict(sites))
+            env = ENV(64, st); init_env(st, env)
+            lz0 = eng.stat("lz_hits")
+            for _ in range(2):
+                for d in cfg.ctm_args.ctm_move_sequence:
+                    for _r in range(2):
+                        ctmrg.ctm_MOVE(d, st, env)
+            assert eng.stat("lz_hits") > lz0, "the state did not reach the complex block Krylov solver"
+            return {k: (s_ / s_[0]).cpu().numpy() for k, s_ in env.get_spectra().items()}
+        finally:
+            for k_ in opts: eng.set_option(k_, {"lz_block_c": LZ_BLOCK_C_DEFAULT, "xgemm_stack_rows": 1}[k_])
+    ref = run({})
+    for name, opts in (("32 complex rows per block", {"lz_block_c": 32}), ("64 complex rows per block", {"lz_block_c": 64}),
+                       ("four real products per corner pass", {"xgemm_stack_rows": 0}), ("32 rows, four products", {"lz_block_c": 32, "xgemm_stack_rows": 0})):
+        got = run(opts)
+        for k in ref:
+            assert np.abs(got[k] - ref[k]).max() < 1e-10, (name, k)
+
+
+LZ_BLOCK_C_DEFAULT = 32          # csrc/ctm_common.h
