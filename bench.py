@@ -249,6 +249,7 @@ def _describe(i, kms, kfl, kn, ums=None):
     ach = _rate(kfl[i], kms[i], bound) if kn[i] else 0.0
     d = {"kernel": name, "bound": bound, "achieved": round(ach, 3), "peak": peak, "unit": "TFLOP/s" if bound == "mfma" else "GB/s",
          "frac": round(ach / peak, 4), "launches": int(kn[i]), "avg_launch_ms": round(kms[i] / max(kn[i], 1), 5),
+         "algorithmic_per_launch": round(kfl[i] / max(kn[i], 1)),          # flop (mfma classes) or bytes (hbm class) per launch: compare `traffic` with it on the hbm class
          "sum_launch_ms": round(kms[i], 3)}
     if ums is not None and kn[i]:
         d["busy_ms_union"] = round(ums[i], 3)
@@ -565,7 +566,7 @@ def metric_line(d):
     keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config")
     line = {k: d[k] for k in keep if k in d}
     r = d["roofline"]
-    roof = {k: r.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "launches", "avg_launch_ms", "frac_union", "concurrent_streams",
+    roof = {k: r.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "launches", "avg_launch_ms", "frac_union", "concurrent_streams", "algorithmic_per_launch",
                                   "time_share_of_sweep", "algorithmic_work_per_launch", "traffic_source", "executed_flop_per_sweep", "sweep_mfma_frac", "comm_per_rank")
             if r.get(k) is not None or k == "traffic"}
     sp = (r.get("serial_pass") or {}).get("dominant")
@@ -585,7 +586,8 @@ def metric_line(d):
                      "full_rank_bound": fro.get("bound"), "full_rank_frac": fro.get("frac"), "full_rank_frac_union": fro.get("frac_union"),
                      "full_rank_frac_alone": ((fro.get("serial_pass") or {}).get("dominant") or {}).get("frac"),
                      "full_rank_executed_flop_per_sweep": fro.get("executed_flop_per_sweep"), "full_rank_sweep_mfma_frac": fro.get("sweep_mfma_frac"),
-                     "full_rank_traffic": fro.get("traffic")})
+                     "full_rank_traffic": fro.get("traffic"), "full_rank_algorithmic_per_launch": fro.get("algorithmic_per_launch"),
+                     "full_rank_traffic_source": (fro.get("traffic_source") or "")[:60]})
         blk = {"value": fr["value"], "ms_per_step": fr["ms_per_step"], "steps": fr["steps"], "warmup": fr["warmup"], "state": {k: v for k, v in fr["state"].items() if k != "note"},
                "svd": fr["svd"], "phase_s": fr["phase_s"]}
         if "energy" in fr:
@@ -614,6 +616,53 @@ def metric_line(d):
     if "other_configs" in d:
         line["other_configs"] = {k: _compact_block(v) for k, v in d["other_configs"].items()}
     return line
+
+
+def traffic_live(args, dom, signed, warmup):
+    """HBM bytes per launch of the kernel families, MEASURED by this run: two child runs of this same script (one timed sweep of the same
+    workload and state) under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` -- separate passes, counters only, no tracing, as
+    MI355X_MICROARCH.md prescribes -- aggregated as tools/pmc_summary.py does: bytes = (2 FETCH_SIZE + WRITE_SIZE) x 1024 (rocprofv3 reports
+    KiB; FETCH_SIZE under-counts by 2x on gfx950).  None when rocprofv3 is not there or a pass fails (the committed pass is used then)."""
+    import csv, glob, shutil, subprocess, tempfile
+    from collections import defaultdict
+    prof = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if prof is None or os.environ.get("CTM_BENCH_CHILD") or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) \
+            or "rocprofiler" in os.environ.get("LD_PRELOAD", ""):
+        return None               # (no profiler, or this process is itself a child / running under one)
+    tot = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = tempfile.mkdtemp(prefix="ctm_pmc_", dir="/tmp")
+            cmd = [prof, "--pmc", counter, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__), "--config", args.config,
+                   "--steps", "1", "--warmup", str(warmup), "--no-cpu-baseline", "--no-serial-pass", "--no-other-configs", "--no-energy", "--no-live-traffic"] + \
+                  (["--signed"] if signed else ["--no-full-rank"]) + [x for kv in args.opt for x in ("--opt", kv)]
+            env = dict(os.environ, CTM_BENCH_CHILD="1", TMPDIR="/tmp")
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=900)
+            if r.returncode != 0:
+                return None
+            t, c = defaultdict(float), defaultdict(int)
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                with open(f, newline="") as fh:
+                    for row in csv.DictReader(fh):
+                        if row.get("Counter_Name") == counter:
+                            t[row["Kernel_Name"]] += float(row["Counter_Value"]); c[row["Kernel_Name"]] += 1
+            tot[counter] = (t, c)
+            shutil.rmtree(d, ignore_errors=True)
+
+        def per_launch(keys):
+            b = n = 0.0
+            for k, v in tot["FETCH_SIZE"][0].items():
+                if any(k_ in k for k_ in keys):
+                    b += 2.0 * v * 1024.0; n += tot["FETCH_SIZE"][1][k]
+            for k, v in tot["WRITE_SIZE"][0].items():
+                if any(k_ in k for k_ in keys):
+                    b += v * 1024.0
+            return round(b / n) if n else None
+        return {"dominant": per_launch(CLS[dom][2]), "others": {str(i): per_launch(CLS[i][2]) for i in CLS if i != dom},
+                "source": "measured by this run: child passes of this command under rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (one timed sweep each, "
+                          "counters only), bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 per launch of the kernel family"}
+    except Exception:
+        return None
 
 
 def spawn_ranks(n):
@@ -648,6 +697,7 @@ def main():
     ap.add_argument("--cold-start", action="store_true", help="no warm start of the leading-chi iteration")
     ap.add_argument("--no-energy", action="store_true", help="skip the energy block (E/site from rdm2x2 at the size of the timed run)")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the compact blocks of the other single-GPU BASELINE configurations")
+    ap.add_argument("--no-live-traffic", action="store_true", help="roofline.traffic from the committed PMC pass instead of two rocprofv3 --pmc child runs of this command")
     args = ap.parse_args()
     kind, D, chi, dtype = CONFIGS[args.config]
     steps = args.steps if args.steps is not None else (100 if kind == "c4v" else 2)
@@ -685,7 +735,9 @@ def main():
 
     primary_signed = bool(args.signed)
     res, dom, sites, state, env = run_workload(args, eng, dev, kind, D, chi, dtype, primary_signed, steps, warmup, world, rank, dist)
-    tr = traffic_from_profile(args, world, dom, primary_signed)
+    # (the child needs the workload's memory a second time: single-GPU float64 workloads up to n = 16384)
+    live = world == 1 and rank == 0 and not args.no_live_traffic and kind != "c4v" and dtype == "f64" and chi * D * D <= 16384
+    tr = (traffic_live(args, dom, primary_signed, min(warmup, 2)) if live else None) or traffic_from_profile(args, world, dom, primary_signed)
     if tr:
         res["roofline"]["traffic"] = tr["dominant"]; res["roofline"]["traffic_source"] = tr["source"]
         for i, dsc in res["roofline"]["other_kernels"].items():
@@ -699,7 +751,7 @@ def main():
         del state, env
         import gc; gc.collect(); torch.cuda.empty_cache()
         full, fdom, fsites, fstate, fenv = run_workload(args, eng, dev, kind, D, chi, dtype, True, steps, warmup, world, rank, dist)
-        ftr = traffic_from_profile(args, world, fdom, True)
+        ftr = (traffic_live(args, fdom, True, min(warmup, 2)) if live else None) or traffic_from_profile(args, world, fdom, True)
         if ftr:
             full["roofline"]["traffic"] = ftr["dominant"]; full["roofline"]["traffic_source"] = ftr["source"]
         if not args.no_energy and args.config == DEFAULT_CONFIG:
