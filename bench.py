@@ -566,8 +566,10 @@ def metric_line(d):
     keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config")
     line = {k: d[k] for k in keep if k in d}
     r = d["roofline"]
+    if r.get("traffic_source"):
+        r = dict(r, traffic_source=r["traffic_source"][:120])
     roof = {k: r.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "launches", "avg_launch_ms", "frac_union", "concurrent_streams", "algorithmic_per_launch",
-                                  "time_share_of_sweep", "algorithmic_work_per_launch", "traffic_source", "executed_flop_per_sweep", "sweep_mfma_frac", "comm_per_rank")
+                                  "time_share_of_sweep", "traffic_source", "executed_flop_per_sweep", "sweep_mfma_frac", "comm_per_rank")
             if r.get(k) is not None or k == "traffic"}
     sp = (r.get("serial_pass") or {}).get("dominant")
     if sp:
@@ -576,9 +578,8 @@ def metric_line(d):
         a = r["absorb_step"]
         roof["absorb_step"] = {"achieved_GBps": a["achieved"], "frac_hbm": a["frac"], "device_ms_per_call": a["device_ms_per_call"],
                                "frac_mfma": (a.get("mfma") or {}).get("frac")}
-    roof["note"] = ("frac = algorithmic work of the dominant kernel / sum of its launch durations in the timed region (HIP events on the engines' streams; "
-                    "units share the chip); frac_union = / union of its launch intervals; frac_alone = the same kernel in a serially issued sweep; "
-                    "sweep_mfma_frac = flop the engine executed per sweep / wall time / FP64 MFMA peak; traffic = committed PMC pass of this command, not measured by this run")
+    roof["note"] = ("frac: work / sum of launch durations in the timed region (HIP events, units share the chip); frac_union: / union of launch intervals; "
+                    "frac_alone: serially issued sweep; sweep_mfma_frac: executed flop / wall / FP64 MFMA peak; definitions in DESIGN.md section 5")
     fr = d.get("full_rank")
     if fr:
         fro = fr["roofline"]

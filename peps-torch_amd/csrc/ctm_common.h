@@ -68,7 +68,7 @@ struct ctm_ctx {
     double svd_null_tol = 1e-11;       // full decomposition: right vectors of s_i <= svd_null_tol s_0 are completed orthonormally (svd_full)
     int jacobi_inner_sweeps = 2;        // inner sweeps of the LDS eigensolver per visit of a pair (2 or 3 pairs per round)
     int jacobi_inner_sweeps_many = 1;   // ... when a round has >= 4 pairs (dense small SVDs, full-block Rayleigh-Ritz): measured faster
-    int jacobi_cross_only = 0;          // many-panel block Jacobi: only the first round of a sweep solves the full 64 x 64 pair problems, the others rotate cross pairs only
+    int jacobi_cross_only = 1;          // many-panel block Jacobi: only the first round of a sweep solves the full 64 x 64 pair problems, the others rotate cross pairs only
     int jacobi_rot_apply = 0;           // many-panel block Jacobi: rotations recorded by the eigensolver and applied to the rows on the vector ALUs (no J, no apply GEMM)
     int jacobi_verbose = 0;
     // leading-k block power iteration (svd_iter): enabled for n >= si_min_n, residual tolerance relative to s_0
@@ -153,7 +153,8 @@ struct ctm_ctx {
     int rows_min_klen_hbm = 576;      // ... the same bound for <= 32-row blocks (HBM-bound)
     bool rows_deep_prefetch = true;   // ... two K tiles in flight per workgroup when at most two workgroups share a CU (mid-size operands)
     bool rows_quantise = true;    // ... its slice count is rounded down so that the last round of workgroups over the 256 CUs is nearly full
-    int rows_target_wgs = 768;    // its workgroup count (column tiles x K slices): three per CU
+    int rows_target_wgs = 512;    // its workgroup count (column tiles x K slices): two per CU.  (768 until round 4: alone the same speed; with four units streaming
+                                  //     four corners 256 ... 640 all give 2.95-2.99 s per full-rank D = 8 sweep against 3.06 with 768: fewer, longer slices, fewer slabs to combine)
     // Chip-filling launches (>= heavy_min_flops) of ALL contexts of a device run one at a time (device-side lock): the concurrent
     // units of a move overlap their latency-bound stages with each other and with ONE corner pass at a time, instead of four
     // corner passes splitting the chip (see HeavyScope, gemm_f64.hip)

@@ -23,7 +23,7 @@ def _host(a, b):
     return torch.from_numpy(a.cpu().numpy() @ b.cpu().numpy())
 
 
-DEFAULTS = {"rows_target_wgs": 768, "rows_min_klen": 576, "rows_fused_reduce": 1, "rows_kernel_min_m": 1, "rows_kernel_min_m_kc": 1}   # csrc/ctm_common.h
+DEFAULTS = {"rows_target_wgs": 512, "rows_min_klen": 576, "rows_fused_reduce": 1, "rows_kernel_min_m": 1, "rows_kernel_min_m_kc": 1}   # csrc/ctm_common.h
 
 
 @pytest.fixture()

@@ -105,7 +105,7 @@ def test_values_below_the_numerical_rank_are_returned_as_zeros(eng):
     assert np.abs(S - ex).max() < 5e-13
 
 
-LZ_BLOCK_DEFAULT, CROSS_ONLY_DEFAULT, ROT_APPLY_DEFAULT = 0, 0, 0          # csrc/ctm_common.h
+LZ_BLOCK_DEFAULT, CROSS_ONLY_DEFAULT, ROT_APPLY_DEFAULT = 0, 1, 0          # csrc/ctm_common.h
 
 
 def test_krylov_solver_variants_agree(eng):

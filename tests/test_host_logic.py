@@ -342,3 +342,28 @@ def test_env_init_variants_host_layer(cpu_cfg, tag, chi, kind):
     C, T = env_from(g, f"{tag}_{kind}_")
     for k in C: assert float((env.C[k] - torch.from_numpy(C[k])).abs().max()) < 1e-13
     for k in T: assert tuple(env.T[k].shape) == T[k].shape and float((env.T[k] - torch.from_numpy(T[k])).abs().max()) < 1e-13
+
+
+def test_bench_metric_line_fits_the_driver_record():
+    """bench.py prints ONE stdout line; the driver keeps its last 8081 characters.  The line built from a committed detail of the default
+    command (profiles/r04_bench_final_detail.json) stays well below that and carries the contract keys plus both states' scalars in `roofline`."""
+    import importlib.util, json, os, sys
+    from conftest import REPO
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(REPO, "bench.py"))
+    argv, sys.argv = sys.argv, ["bench.py"]
+    try:
+        b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)
+    finally:
+        sys.argv = argv
+    d = json.loads(open(os.path.join(REPO, "profiles", "r04_bench_final_detail.json")).read())
+    line = b.metric_line(d)
+    assert len(json.dumps(line)) < 7400
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+              "roofline", "cpu_baseline"):
+        assert k in line, k
+    r = line["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "full_rank_value", "full_rank_ms_per_step", "full_rank_frac", "full_rank_frac_union",
+              "executed_flop_per_sweep", "sweep_mfma_frac", "full_rank_sweep_mfma_frac"):
+        assert k in r, k
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert set(line["other_configs"]) >= {"c4v_D4_chi64", "generic_D6_chi128_signed", "generic_D8_chi384_c128_signed"}
