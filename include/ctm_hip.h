@@ -75,9 +75,12 @@ int ctm_gemm_intervals(ctm_ctx* ctx, double* out, long long capacity_doubles, lo
  * Contract of the column split a group executes (ABI frozen here, nranks == 1 is what is implemented):
  *   - every rank of the group keeps the column block [rank n/nranks, (rank+1) n/nranks) of each n x n enlarged corner of the unit
  *     (corner construction, corner cache and absorb split by OUTPUT columns: no communication);
- *   - a corner pass B(<=64 x n) * corner yields this rank's n/nranks output columns; before the next pass the group runs ONE
- *     in-place ncclAllGather of (rows x n/nranks) doubles per rank (complex128: both planes in the same call) on the context's
- *     stream -- 8 passes per block step of the Krylov recurrence, ~104 per full-rank unit at n = 16384;
+ *   - every corner is applied in both orientations (M = cB^T cA^T cC cD and M^T), so a corner pass is one of two kinds:
+ *       B(<= 64 x n) * corner[:, J]      yields this rank's columns J of the product: ONE in-place ncclAllGather of (rows x n/nranks)
+ *                                        doubles per rank before the next pass;
+ *       B[:, J] * (corner[:, J])^T       yields a partial sum of the whole (rows x n) product: ONE ncclAllReduce (sum) of it;
+ *     complex128: both planes in the same call; all on the context's stream -- 8 passes per block step of the Krylov recurrence
+ *     (4 of each kind), ~170 per full-rank unit at n = 16384; every rank of the group ends each pass with the same bits;
  *   - the 64-row orthonormalisations and the Ritz extraction are replicated on every rank of the group (bit-identical inputs,
  *     deterministic kernels: no broadcast of their results);
  *   - projectors P, Pt come out replicated; the host layer exchanges them between groups as it does between single ranks

@@ -159,7 +159,7 @@ struct ctm_ctx {
     // units of a move overlap their latency-bound stages with each other and with ONE corner pass at a time, instead of four
     // corner passes splitting the chip (see HeavyScope, gemm_f64.hip)
     bool heavy_serial = false; double heavy_min_flops = 1e10;      // (off: measured 2-5 % slower -- the tail of one chip-filling kernel is no longer filled by the next unit's)
-    double timing_min_flops = 1e8;
+    double timing_min_flops = 5e9;      // event pairs only around the chip-filling launches (corner passes, corner builds, absorb GEMMs): pairs around the ~170 projection GEMMs of a unit (7e8 flop each) cost the full-rank sweep 1.6 %
     unsigned heavy_id = 0; bool in_heavy = false;          // owner id of this context in the device-side lock
     long heavy_launches = 0;
     bool rows_fused_reduce = true;      // its K-slice partials are summed inside the launch by the last workgroup of a column tile
