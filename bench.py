@@ -638,8 +638,15 @@ def traffic_live(args, dom, signed, warmup):
                    "--steps", "1", "--warmup", str(warmup), "--no-cpu-baseline", "--no-serial-pass", "--no-other-configs", "--no-energy", "--no-live-traffic"] + \
                   (["--signed"] if signed else ["--no-full-rank"]) + [x for kv in args.opt for x in ("--opt", kv)]
             env = dict(os.environ, CTM_BENCH_CHILD="1", TMPDIR="/tmp")
-            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=900)
-            if r.returncode != 0:
+            pr = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+            try:
+                rc = pr.wait(timeout=300)
+            except subprocess.TimeoutExpired:
+                import signal
+                os.killpg(pr.pid, signal.SIGKILL)        # (the profiler wrapper and the child it started: this process group only)
+                pr.wait()
+                return None
+            if rc != 0:
                 return None
             t, c = defaultdict(float), defaultdict(int)
             for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):

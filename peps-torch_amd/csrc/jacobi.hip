@@ -3111,6 +3111,20 @@ __global__ void embed_rows_kernel(const double* __restrict__ re, const double* _
 // `embedded`: As is the real 2n x 2n embedding of a Hermitian matrix and `warm` the embedded rows ([x y] and [-y x] per complex row
 // x + iy) of eigh_warm_verify_c: only the keep-the-vectors route is taken (a rotation inside the doubly degenerate real spectrum
 // would not come back as complex vectors), the workspace is not written and D receives all kk Rayleigh quotients.
+// Adaptive state of the orthogonal iteration (contraction rate of the last accepted solve, back-off after a flat spectrum): a property
+// of the PROBLEM, i.e. of the caller's warm workspace -- contexts are shared by problems and handed to units dynamically, so the state is
+// keyed by the workspace pointer (process-wide), not kept on the context.
+struct OrthState { double rate = 0.0; int skip = 0, backoff = 0; bool rows_seen_valid = false; };     // (rows_seen_valid: see eigh_warm_verify)
+static std::mutex g_orth_mutex;
+static std::map<const double*, OrthState> g_orth_state;
+static OrthState orth_state_get(const double* ws) { std::lock_guard<std::mutex> l(g_orth_mutex); auto it = g_orth_state.find(ws); return it == g_orth_state.end() ? OrthState() : it->second; }
+static void orth_state_put(const double* ws, const OrthState& st) {
+    std::lock_guard<std::mutex> l(g_orth_mutex);
+    if (g_orth_state.size() > 4096) g_orth_state.clear();          // (workspaces come and go with the environments that own them)
+    g_orth_state[ws] = st;
+}
+void eigh_orth_state_reset() { std::lock_guard<std::mutex> l(g_orth_mutex); g_orth_state.clear(); }
+
 static int eigh_warm_verify(ctm_ctx* ctx, const double* As, int n, int kk, int k_out, double* warm, double* D, double* Ut, bool* accepted,
                             bool embedded = false, bool* norms_ok = nullptr, double* moved = nullptr) {
     *accepted = false;
@@ -3125,6 +3139,18 @@ static int eigh_warm_verify(ctm_ctx* ctx, const double* As, int n, int kk, int k
     std::vector<double> h(std::max(kk, pb)), hd(kk), hn(kk);
     CTM_TRY(row_norms(ctx, warm, kk, n, n, norms));       // read back with the residuals below (one host synchronisation for both)
     CTM_HIP_CHECK(ctx, hipMemcpyAsync(hn.data(), norms, sizeof(double) * kk, hipMemcpyDeviceToHost, ctx->stream));
+    // ... once this workspace has been seen to hold a complete subspace.  Before that (a cold call, a workspace the caller has just
+    // zeroed or never filled) the row check comes first and alone: one launch and one synchronisation, instead of pushing zeros or
+    // garbage through the re-orthonormalisation, the product with A and the residual kernel before finding out.
+    OrthState ws_state = orth_state_get(warm);
+    if (!ws_state.rows_seen_valid) {
+        CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        for (int i = 0; i < kk; ++i) if (!(std::fabs(hn[i] - 1.0) < 1e-6)) {
+            if (ctx->jacobi_verbose) fprintf(stderr, "[eigh-warm] n=%d kk=%d: workspace row %d has norm %.3e (no complete previous subspace)\n", n, kk, i, hn[i]);
+            return CTM_OK;
+        }
+        ws_state.rows_seen_valid = true; orth_state_put(warm, ws_state);
+    }
     CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)kk * n, (void**)&Q));
     CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)kk * n, (void**)&Y));
     CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)kk * kk, (void**)&H));
@@ -3295,20 +3321,6 @@ static int eigh_warm_verify_c(ctm_ctx* ctx, const double* Asr, const double* Asi
 // Q not orthonormal to 1e-12, no acceptance after eigh_orth_max applications -- returns with *accepted = false and the regular route runs.
 // Returned gauge: rows aligned with the previous vectors (warm_i <- sign<x_i, warm_i> x_i, u_i = sign(theta_i) warm_i), as the
 // regular route and the warm restart return them.
-// Adaptive state of the orthogonal iteration (contraction rate of the last accepted solve, back-off after a flat spectrum): a property
-// of the PROBLEM, i.e. of the caller's warm workspace -- contexts are shared by problems and handed to units dynamically, so the state is
-// keyed by the workspace pointer (process-wide), not kept on the context.
-struct OrthState { double rate = 0.0; int skip = 0, backoff = 0; };
-static std::mutex g_orth_mutex;
-static std::map<const double*, OrthState> g_orth_state;
-static OrthState orth_state_get(const double* ws) { std::lock_guard<std::mutex> l(g_orth_mutex); auto it = g_orth_state.find(ws); return it == g_orth_state.end() ? OrthState() : it->second; }
-static void orth_state_put(const double* ws, const OrthState& st) {
-    std::lock_guard<std::mutex> l(g_orth_mutex);
-    if (g_orth_state.size() > 4096) g_orth_state.clear();          // (workspaces come and go with the environments that own them)
-    g_orth_state[ws] = st;
-}
-void eigh_orth_state_reset() { std::lock_guard<std::mutex> l(g_orth_mutex); g_orth_state.clear(); }
-
 static int eigh_orth_iter(ctm_ctx* ctx, const double* As, int n, int kk, int k_out, double* warm, double* D, double* Ut, bool* accepted,
                           bool warm_checked, double moved) {
     *accepted = false;
