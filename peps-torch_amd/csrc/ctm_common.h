@@ -69,6 +69,7 @@ struct ctm_ctx {
     int jacobi_inner_sweeps = 2;        // inner sweeps of the LDS eigensolver per visit of a pair (2 or 3 pairs per round)
     int jacobi_inner_sweeps_many = 1;   // ... when a round has >= 4 pairs (dense small SVDs, full-block Rayleigh-Ritz): measured faster
     int jacobi_cross_only = 1;          // many-panel block Jacobi: only the first round of a sweep solves the full 64 x 64 pair problems, the others rotate cross pairs only
+    int jacobi_persist = 0;             // many-panel block Jacobi: one launch per sweep (jacobi_sweep_kernel) instead of three per round
     int jacobi_rot_apply = 0;           // many-panel block Jacobi: rotations recorded by the eigensolver and applied to the rows on the vector ALUs (no J, no apply GEMM)
     int jacobi_verbose = 0;
     // leading-k block power iteration (svd_iter): enabled for n >= si_min_n, residual tolerance relative to s_0

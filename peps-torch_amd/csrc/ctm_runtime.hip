@@ -124,6 +124,7 @@ int ctm_set_option(ctm_ctx* ctx, const char* key, double value) {
     else if (k == "jacobi_verbose") ctx->jacobi_verbose = (int)value;
     else if (k == "jacobi_cross_only") ctx->jacobi_cross_only = (int)value;
     else if (k == "jacobi_rot_apply") ctx->jacobi_rot_apply = (int)value;
+    else if (k == "jacobi_persist") ctx->jacobi_persist = (int)value;
     else if (k == "si_enable") ctx->si_enable = value != 0.0;
     else if (k == "si_min_n") ctx->si_min_n = (int)value;
     else if (k == "si_max_iter") ctx->si_max_iter = (int)value;

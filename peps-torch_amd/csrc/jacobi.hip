@@ -23,9 +23,11 @@
 #include <cmath>
 #include <numeric>
 #include <mutex>
+#include <type_traits>
 
 namespace {
 
+typedef double d4 __attribute__((ext_vector_type(4)));
 constexpr int MAXM = 64;   // largest pair-Gram the LDS solver handles (2 * block)
 
 // acceptance threshold of the leading-k solvers on the residual / s_0: the configured tolerance, but never below the rounding
@@ -527,6 +529,225 @@ __global__ __launch_bounds__(256) void rot_apply64_kernel(double* __restrict__ X
 }
 
 // ---------------------------------------------------------------------------------------------
+// One whole SWEEP of the many-panel one-sided block Jacobi in ONE launch (real, 32-row panels, 64 x 64 pair problems).
+// The classic driver (jacobi_rows) issues three dependent launches per round -- batched pair Grams, the LDS eigensolver, the batched
+// apply -- i.e. ~60 per sweep of a Ritz matrix with their launch gaps: the extraction of the block Krylov solver is the one latency-bound
+// stage a move's barrier still waits for.  Here pairs x S workgroups stay resident for the sweep: workgroup (pair, slice) computes the
+// partial Gram of its slice of the Gram columns on the matrix cores, the S workgroups of a pair meet at a counter, each sums the S
+// partials and runs the (same) LDS eigensolver pass redundantly, applies J^T to its slice of ALL columns on the matrix cores, and all
+// workgroups meet at a second counter before the panels are re-paired.  Counters: agent-scope release / acquire around a relaxed
+// atomic (the split-K recipe of gemm_f64.hip); every spin is bounded (1 s) and raises an abort word the host turns into an error --
+// the grid must be co-resident (pairs x S <= 64 workgroups: four units in flight fit the 256 CUs together).
+// ---------------------------------------------------------------------------------------------
+struct SweepParams {
+    double* X; long long ld; int Cg, Ctot, pairs, S, rounds;
+    const int* tab;              // [rounds][pairs][2]: panels (i < j) of every pair of every round
+    double* Gp;                  // [pairs][S][64 x 64] partial Grams
+    unsigned* bar;               // [0] all workgroups, [1 + pair] the workgroups of a pair, [1 + pairs] abort; zeroed before the launch
+    double tol, tau2; int tau_both, cross;
+    unsigned long long* stat_rel; unsigned long long* stat_abs;
+};
+
+__device__ __forceinline__ bool sweep_barrier(unsigned* cnt, unsigned target, unsigned* abort_word, int tid, int* abort_s) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const long long t0 = wall_clock64();                   // 100 MHz
+        int ab = 0;
+        while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            if (__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { ab = 1; break; }
+            if (wall_clock64() - t0 > 100000000ll) { __hip_atomic_store(abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ab = 1; break; }
+            __builtin_amdgcn_s_sleep(8);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        *abort_s = ab;
+    }
+    __syncthreads();
+    return *abort_s == 0;
+}
+
+__global__ __launch_bounds__(512) void jacobi_sweep_kernel(SweepParams p) {
+    constexpr int M = 64, H = 32, NTH = 512, NW = 8, KS = 16, EPT = 8, BPT = 2;
+    __shared__ double Wb[2][M][M + 1];
+    __shared__ double Jm[M][M + 1];
+    __shared__ double red[16];
+    __shared__ int rot_flag, abort_s;
+    __shared__ int rank_of[M];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, lk = lane >> 4;
+    const int pair = blockIdx.x / p.S, sl = blockIdx.x % p.S, nwg = p.pairs * p.S;
+    const int cgs = (((p.Cg + p.S - 1) / p.S) + 15) / 16 * 16, cts = (((p.Ctot + p.S - 1) / p.S) + 15) / 16 * 16;
+    const int g0 = min(p.Cg, sl * cgs), g1 = min(p.Cg, g0 + cgs), a0 = min(p.Ctot, sl * cts), a1 = min(p.Ctot, a0 + cts);
+    double (*St)[M + 1] = Wb[0];                  // staging image of phases 1 and 3
+    double* Gmine = p.Gp + ((size_t)pair * p.S + sl) * M * M;
+    const int k2 = tid & 31, kb = tid >> 5;
+    for (int r = 0; r < p.rounds; ++r) {
+        const int pi = p.tab[((size_t)r * p.pairs + pair) * 2], pj = p.tab[((size_t)r * p.pairs + pair) * 2 + 1];
+        double* Pi = p.X + (size_t)pi * H * p.ld;
+        double* Pj = p.X + (size_t)pj * H * p.ld;
+        auto rowp = [&](int row) { return row < H ? Pi + (size_t)row * p.ld : Pj + (size_t)(row - H) * p.ld; };
+        // ---- phase 1: partial Gram of my slice of the Gram columns.  Wave w owns the 16 x 16 tiles 2w, 2w + 1 of the 4 x 4 tile grid
+        d4 acc[2];
+        acc[0] = (d4){0., 0., 0., 0.}; acc[1] = (d4){0., 0., 0., 0.};
+        {
+            double pre[EPT];                          // the next 64-column chunk travels in registers while this one is multiplied
+            auto fetch = [&](int c0, int lim) {
+#pragma unroll
+                for (int e = 0; e < EPT; ++e) { const int q = tid + e * NTH, row = q >> 6, col = q & 63; pre[e] = (c0 + col < lim) ? rowp(row)[c0 + col] : 0.0; }
+            };
+            if (g0 < g1) fetch(g0, g1);
+            for (int c0 = g0; c0 < g1; c0 += M) {
+#pragma unroll
+                for (int e = 0; e < EPT; ++e) { const int q = tid + e * NTH; St[q & 63][q >> 6] = pre[e]; }          // k-major image: St[k][row]
+                __syncthreads();
+                if (c0 + M < g1) fetch(c0 + M, g1);
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int t = wave * 2 + u, tr = t >> 2, tc = t & 3;
+#pragma unroll
+                    for (int k4 = 0; k4 < M / 4; ++k4) {
+                        const int kr = k4 * 4 + lk;
+                        acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(St[kr][tr * 16 + lr], St[kr][tc * 16 + lr], acc[u], 0, 0, 0);
+                    }
+                }
+                __syncthreads();
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int t = wave * 2 + u, tr = t >> 2, tc = t & 3;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) Gmine[(tr * 16 + lk + 4 * q) * M + tc * 16 + lr] = acc[u][q];
+        }
+        if (!sweep_barrier(p.bar + 1 + pair, (unsigned)(p.S * (r + 1)), p.bar + 1 + p.pairs, tid, &abort_s)) return;
+        // ---- phase 2: the pair's Gram (sum of the S partials, fixed order) and ONE eigensolver pass, redundantly in every workgroup of the pair
+        {
+            const double* G0 = p.Gp + (size_t)pair * p.S * M * M;
+#pragma unroll
+            for (int e = 0; e < EPT; ++e) {
+                const int q = tid + e * NTH;
+                double v = 0.0;
+                for (int s2 = 0; s2 < p.S; ++s2) v += G0[(size_t)s2 * M * M + q];
+                Wb[0][q >> 6][q & 63] = v; Jm[q >> 6][q & 63] = ((q >> 6) == (q & 63)) ? 1.0 : 0.0;
+            }
+        }
+        if (tid == 0) rot_flag = 0;
+        __syncthreads();
+        double srel = 0.0, sabs = 0.0;
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            const int q = tid + e * NTH, rr = q >> 6, c = q & 63;
+            if (rr < c) {
+                const double g = fabs(Wb[0][rr][c]), a = Wb[0][rr][rr], b = Wb[0][c][c];
+                if (g > 0.0) {
+                    const double sc = sqrt(fabs(a * b));
+                    srel = fmax(srel, g / fmax(sc, tau_floor(a, b, p.tau2, p.tau_both)));
+                    if (sc > 0.0) sabs = fmax(sabs, g / sc);
+                }
+            }
+        }
+        for (int off = 32; off > 0; off >>= 1) { srel = fmax(srel, __shfl_down(srel, off, 64)); sabs = fmax(sabs, __shfl_down(sabs, off, 64)); }
+        if (lane == 0) { red[wave] = srel; red[8 + wave] = sabs; }
+        __syncthreads();
+        if (tid == 0) {
+            double v = 0.0, w = 0.0;
+            for (int q = 0; q < NW; ++q) { v = fmax(v, red[q]); w = fmax(w, red[8 + q]); }
+            if (sl == 0) { atomicMax(p.stat_rel, (unsigned long long)__double_as_longlong(v)); atomicMax(p.stat_abs, (unsigned long long)__double_as_longlong(w)); }
+            red[0] = v;
+        }
+        __syncthreads();
+        const bool active = red[0] > p.tol;                   // (uniform over the workgroup AND over the S workgroups of the pair: same Gram, same arithmetic)
+        if (active) {
+            int par = 0;
+            // (the pairing as a compile-time choice: decided inside the round loop it costs the eigensolver 10 %)
+            auto rounds_of = [&](auto CR) {
+                constexpr bool cross = decltype(CR)::value;
+                constexpr int nr = cross ? H : M - 1;
+                for (int rd = 0; rd < nr; ++rd) {
+                    const double (*Sr)[M + 1] = Wb[par];
+                    double (*D)[M + 1] = Wb[par ^ 1];
+                    int p2, q2;
+                    if (cross) cross_pair64(rd, k2, p2, q2); else rr_pair64(rd, k2, p2, q2);
+                    const double a2 = Sr[p2][p2], d2 = Sr[q2][q2], g2 = Sr[p2][q2];
+                    int p1[BPT], q1[BPT];
+                    double b00[BPT], b01[BPT], b10[BPT], b11[BPT], jp0[BPT], jq0[BPT], jp1[BPT], jq1[BPT];
+    #pragma unroll
+                    for (int u = 0; u < BPT; ++u) {
+                        const int k1 = kb + u * KS;
+                        if (cross) cross_pair64(rd, k1, p1[u], q1[u]); else rr_pair64(rd, k1, p1[u], q1[u]);
+                        b00[u] = Sr[p1[u]][p2]; b01[u] = Sr[p1[u]][q2]; b10[u] = Sr[q1[u]][p2]; b11[u] = Sr[q1[u]][q2];
+                        jp0[u] = Jm[k1][p2]; jq0[u] = Jm[k1][q2]; jp1[u] = Jm[k1 + 32][p2]; jq1[u] = Jm[k1 + 32][q2];
+                    }
+                    double c2, s2; bool r2;
+                    jacobi_cs(a2, d2, g2, p.tol, p.tau2, p.tau_both, c2, s2, r2);
+    #pragma unroll
+                    for (int u = 0; u < BPT; ++u) {
+                        const int k1 = kb + u * KS;
+                        const int src = (tid & 32) | k1;
+                        const double c1 = __shfl(c2, src, 64), s1 = __shfl(s2, src, 64);
+                        const double t00 = c2 * b00[u] - s2 * b01[u], t01 = s2 * b00[u] + c2 * b01[u];
+                        const double t10 = c2 * b10[u] - s2 * b11[u], t11 = s2 * b10[u] + c2 * b11[u];
+                        D[p1[u]][p2] = c1 * t00 - s1 * t10; D[p1[u]][q2] = c1 * t01 - s1 * t11;
+                        D[q1[u]][p2] = s1 * t00 + c1 * t10; D[q1[u]][q2] = s1 * t01 + c1 * t11;
+                        if (r2) {
+                            Jm[k1][p2] = c2 * jp0[u] - s2 * jq0[u]; Jm[k1][q2] = s2 * jp0[u] + c2 * jq0[u];
+                            Jm[k1 + 32][p2] = c2 * jp1[u] - s2 * jq1[u]; Jm[k1 + 32][q2] = s2 * jp1[u] + c2 * jq1[u];
+                        }
+                    }
+                    par ^= 1;
+                    __syncthreads();
+                }
+            };
+            if (p.cross && r > 0) rounds_of(std::true_type{}); else rounds_of(std::false_type{});
+            if (tid < M) {
+                const double d = Wb[par][tid][tid];
+                int rk = 0;
+                for (int j = 0; j < M; ++j) { const double dj = Wb[par][j][j]; rk += (dj > d) || (dj == d && j < tid); }
+                rank_of[tid] = rk;
+            }
+            __syncthreads();
+            // Js[k][o] = J[k][c] with o = rank_of[c] (rows of the pair re-ordered by eigenvalue), kept in Wb[1]; Wb[0] is the staging image again
+#pragma unroll
+            for (int e = 0; e < EPT; ++e) { const int q = tid + e * NTH, k = q >> 6, c = q & 63; Wb[1][k][rank_of[c]] = Jm[k][c]; }
+            __syncthreads();
+            // ---- phase 3: X_pair[:, my slice] <- Js^T X_pair[:, my slice], 64 columns at a time (the chunk is in LDS before anything is written)
+            {
+                double pre[EPT];
+                auto fetch = [&](int c0) {
+#pragma unroll
+                    for (int e = 0; e < EPT; ++e) { const int q = tid + e * NTH, row = q >> 6, col = q & 63; pre[e] = (c0 + col < a1) ? rowp(row)[c0 + col] : 0.0; }
+                };
+                if (a0 < a1) fetch(a0);
+                for (int c0 = a0; c0 < a1; c0 += M) {
+#pragma unroll
+                    for (int e = 0; e < EPT; ++e) { const int q = tid + e * NTH; St[q >> 6][q & 63] = pre[e]; }      // St[k = old row][col]
+                    __syncthreads();
+                    if (c0 + M < a1) fetch(c0 + M);                  // (columns of the NEXT chunk: nobody writes them before they are in registers)
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const int t = wave * 2 + u, to = t >> 2, tc = t & 3;
+                        d4 o4 = (d4){0., 0., 0., 0.};
+#pragma unroll
+                        for (int k4 = 0; k4 < M / 4; ++k4) {
+                            const int kr = k4 * 4 + lk;
+                            o4 = __builtin_amdgcn_mfma_f64_16x16x4f64(Wb[1][kr][to * 16 + lr], St[kr][tc * 16 + lr], o4, 0, 0, 0);
+                        }
+                        const int col = c0 + tc * 16 + lr;
+                        if (col < a1) {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) rowp(to * 16 + lk + 4 * q)[col] = o4[q];
+                        }
+                    }
+                    __syncthreads();
+                }
+            }
+        }
+        if (!sweep_barrier(p.bar, (unsigned)(nwg * (r + 1)), p.bar + 1 + p.pairs, tid, &abort_s)) return;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // complex128 variant.  A panel of bc = 16 complex rows is stored as 16 real rows (real parts) followed by 16 real
 // rows (imaginary parts), so a pair of panels is 64 REAL rows and the Gram / apply GEMMs of jacobi_rows() run
 // unchanged on real data.  This kernel turns the 64 x 64 real Gram of such a pair into the 32 x 32 Hermitian Gram
@@ -701,6 +922,7 @@ struct RRTables {
     int nbk = 0, b = 0, nsplit = 1, klen = 0; long long ld = 0;
     GemmOff* d_gram = nullptr;    // [rounds][pairs]
     GemmOff* d_apply = nullptr;   // [rounds][pairs]
+    int* d_pairs = nullptr;       // [rounds][pairs][2]: the panels of every pair (jacobi_sweep_kernel)
 };
 
 std::map<std::string, RRTables>& tables() { static std::map<std::string, RRTables> t; return t; }
@@ -721,12 +943,14 @@ int get_tables(ctm_ctx* ctx, int nbk, long long ld, int b, int Cg, RRTables** ou
     int klen = (((Cg + nsplit - 1) / nsplit) + 15) / 16 * 16;
     nsplit = (Cg + klen - 1) / klen;
     std::vector<GemmOff> gram((size_t)rounds * pairs * nsplit), app((size_t)rounds * pairs);
+    std::vector<int> plist((size_t)rounds * pairs * 2);
     for (int r = 0; r < rounds; ++r) {
         for (int k = 0; k < pairs; ++k) {
             int i, j;
             if (k == 0) { i = nbk - 1; j = r % (nbk - 1); }
             else { i = (r + k) % (nbk - 1); j = (r - k + (nbk - 1)) % (nbk - 1); }
             if (i > j) std::swap(i, j);
+            plist[((size_t)r * pairs + k) * 2] = i; plist[((size_t)r * pairs + k) * 2 + 1] = j;
             const long long oi = (long long)i * b * ld, oj = (long long)j * b * ld;
             for (int s = 0; s < nsplit; ++s) {
                 const long long k0 = (long long)s * klen;
@@ -741,9 +965,11 @@ int get_tables(ctm_ctx* ctx, int nbk, long long ld, int b, int Cg, RRTables** ou
     }
     RRTables t; t.nbk = nbk; t.ld = ld; t.b = b; t.nsplit = nsplit; t.klen = klen;
     if (hipMalloc(&t.d_gram, gram.size() * sizeof(GemmOff)) != hipSuccess ||
-        hipMalloc(&t.d_apply, app.size() * sizeof(GemmOff)) != hipSuccess) {
+        hipMalloc(&t.d_apply, app.size() * sizeof(GemmOff)) != hipSuccess ||
+        hipMalloc(&t.d_pairs, plist.size() * sizeof(int)) != hipSuccess) {
         ctx->set_error("jacobi: table alloc"); return CTM_ERR_NOMEM;
     }
+    CTM_HIP_CHECK(ctx, hipMemcpy(t.d_pairs, plist.data(), plist.size() * sizeof(int), hipMemcpyHostToDevice));
     CTM_HIP_CHECK(ctx, hipMemcpy(t.d_gram, gram.data(), gram.size() * sizeof(GemmOff), hipMemcpyHostToDevice));
     CTM_HIP_CHECK(ctx, hipMemcpy(t.d_apply, app.data(), app.size() * sizeof(GemmOff), hipMemcpyHostToDevice));
     T[key] = t;
@@ -774,6 +1000,14 @@ int jacobi_rows(ctm_ctx* ctx, double* X, int R, long long ld, int Cg, int Ctot, 
     CTM_TRY(arena_alloc(ctx, sizeof(double) * pairs * m * m, (void**)&J));
     CTM_TRY(arena_alloc(ctx, sizeof(double) * R, (void**)&norms));
     CTM_TRY(arena_alloc(ctx, sizeof(int) * pairs, (void**)&flags));
+    // one launch per sweep (jacobi_sweep_kernel) for the many-panel real problems with one eigensolver pass per visit
+    const bool persist = ctx->jacobi_persist && !cplx && m == 64 && b == 32 && pairs >= 4 && ctx->jacobi_inner_sweeps_many == 1 && ctx->eig64_pingpong && !ctx->jacobi_rot_apply;
+    const int pS = persist ? std::max(2, std::min(8, 56 / pairs)) : 0;
+    double* Gp = nullptr; unsigned* bar = nullptr;
+    if (persist && pairs * pS <= 64) {
+        CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)pairs * pS * m * m, (void**)&Gp));
+        CTM_TRY(arena_alloc(ctx, sizeof(unsigned) * (pairs + 2), (void**)&bar));
+    }
     double* rot = nullptr; int* perm = nullptr;
     if (ctx->jacobi_rot_apply && !cplx && m == 64 && pairs >= 4) {
         CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)pairs * 63 * 64, (void**)&rot));
@@ -818,7 +1052,16 @@ int jacobi_rows(ctm_ctx* ctx, double* X, int R, long long ld, int Cg, int Ctot, 
             tau2 = *std::max_element(h.begin(), h.begin() + R); abs_mode = true;
         }
         CTM_HIP_CHECK(ctx, hipMemsetAsync(stat, 0, 2 * sizeof(double), ctx->stream));
-        for (int r = 0; r < rounds; ++r) {
+        if (Gp) {
+            SweepParams wp;
+            wp.X = X; wp.ld = ld; wp.Cg = Cg; wp.Ctot = Ctot; wp.pairs = pairs; wp.S = pS; wp.rounds = rounds; wp.tab = T->d_pairs; wp.Gp = Gp; wp.bar = bar;
+            wp.tol = ctx->jacobi_tol * 0.1; wp.tau2 = tau2; wp.tau_both = abs_mode ? 2 : (tau_both ? 1 : 0); wp.cross = ctx->jacobi_cross_only ? 1 : 0;
+            wp.stat_rel = stat; wp.stat_abs = stat + 1;
+            CTM_HIP_CHECK(ctx, hipMemsetAsync(bar, 0, sizeof(unsigned) * (pairs + 2), ctx->stream));
+            CTM_LAUNCH(ctx, jacobi_sweep_kernel, dim3(pairs * pS), dim3(512), 0, wp);
+            CTM_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_scratch + 4, bar + 1 + pairs, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
+        }
+        for (int r = 0; r < (Gp ? 0 : rounds); ++r) {
             GemmDesc g;
             g.M = m; g.N = m; g.K = Cg;
             g.A = X; g.sam = ld; g.sak = 1; g.splitA = b;
@@ -863,6 +1106,10 @@ int jacobi_rows(ctm_ctx* ctx, double* X, int R, long long ld, int Cg, int Ctot, 
         }
         CTM_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_scratch, stat, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        if (Gp && *reinterpret_cast<unsigned*>(ctx->h_scratch + 4) != 0u) {
+            ctx->set_error("jacobi: a barrier of the one-launch sweep timed out (workgroups not co-resident?)");
+            return CTM_ERR_HIP;
+        }
         const double srel = ctx->h_scratch[0];
         ctx->last_sweeps = sweep + 1;
         ctx->last_offnorm = srel;

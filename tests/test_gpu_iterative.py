@@ -105,7 +105,7 @@ def test_values_below_the_numerical_rank_are_returned_as_zeros(eng):
     assert np.abs(S - ex).max() < 5e-13
 
 
-LZ_BLOCK_DEFAULT, CROSS_ONLY_DEFAULT, ROT_APPLY_DEFAULT = 0, 1, 0          # csrc/ctm_common.h
+LZ_BLOCK_DEFAULT, CROSS_ONLY_DEFAULT, ROT_APPLY_DEFAULT, PERSIST_DEFAULT = 0, 1, 0, 0          # csrc/ctm_common.h
 
 
 def test_krylov_solver_variants_agree(eng):
@@ -142,7 +142,8 @@ def test_krylov_solver_variants_agree(eng):
         finally:
             cfg.ctm_args.concurrent_units = old
             for k_ in opts: eng.set_option(k_, {"lz_async": 1, "lz_jacobi_block": 0, "heavy_serial": 0, "heavy_min_flops": 1e10, "lz_local_project": 1,
-                                                "lz_block": LZ_BLOCK_DEFAULT, "jacobi_cross_only": CROSS_ONLY_DEFAULT, "jacobi_rot_apply": ROT_APPLY_DEFAULT}[k_])
+                                                "lz_block": LZ_BLOCK_DEFAULT, "jacobi_cross_only": CROSS_ONLY_DEFAULT, "jacobi_rot_apply": ROT_APPLY_DEFAULT,
+                                                "jacobi_persist": PERSIST_DEFAULT}[k_])
     ref = run({})
     for name, opts, conc in (("synchronous recurrence", {"lz_async": 0}, True), ("16-row panels", {"lz_jacobi_block": 16}, True),
                              ("device-side lock", {"heavy_serial": 1, "heavy_min_flops": 1e7}, True), ("serial units", {}, False),
@@ -152,15 +153,19 @@ def test_krylov_solver_variants_agree(eng):
                              ("cross-pair rounds in the Ritz extraction", {"jacobi_cross_only": 1}, True), ("full rounds", {"jacobi_cross_only": 0}, True),
                              ("rotation lists applied on the vector ALUs", {"jacobi_rot_apply": 1, "jacobi_cross_only": 0}, True),
                              ("rotation lists, cross-pair rounds", {"jacobi_rot_apply": 1, "jacobi_cross_only": 1}, True),
-                             ("accumulated J + apply GEMM", {"jacobi_rot_apply": 0, "jacobi_cross_only": 0}, True)):
+                             ("accumulated J + apply GEMM", {"jacobi_rot_apply": 0, "jacobi_cross_only": 0}, True),
+                             ("one launch per Jacobi sweep, cross-pair rounds", {"jacobi_persist": 1, "jacobi_cross_only": 1}, True),
+                             ("one launch per Jacobi sweep, full rounds", {"jacobi_persist": 1, "jacobi_cross_only": 0}, True),
+                             ("three launches per round", {"jacobi_persist": 0}, True)):
         got = run(opts, conc)
         for k in ref:
             assert np.abs(got[k] - ref[k]).max() < 1e-10, (name, k)
 
 
 @pytest.mark.parametrize("opts", [{"jacobi_rot_apply": 0, "jacobi_cross_only": 0}, {"jacobi_rot_apply": 1, "jacobi_cross_only": 0},
-                                  {"jacobi_rot_apply": 1, "jacobi_cross_only": 1}, {"jacobi_rot_apply": 0, "jacobi_cross_only": 1}],
-                         ids=["J-gemm", "rotation-lists", "rotation-lists-cross", "J-gemm-cross"])
+                                  {"jacobi_rot_apply": 1, "jacobi_cross_only": 1}, {"jacobi_rot_apply": 0, "jacobi_cross_only": 1},
+                                  {"jacobi_persist": 1, "jacobi_cross_only": 0, "jacobi_rot_apply": 0}, {"jacobi_persist": 1, "jacobi_cross_only": 1, "jacobi_rot_apply": 0}],
+                         ids=["J-gemm", "rotation-lists", "rotation-lists-cross", "J-gemm-cross", "one-launch-sweep", "one-launch-sweep-cross"])
 def test_many_panel_block_jacobi_variants_against_lapack(eng, opts):
     """The dense one-sided block Jacobi SVD on many 32-row panels (the Ritz extraction of the block Krylov solver; here called directly
     through the full decomposition of an explicit matrix): accumulated J + apply GEMM, or the eigensolver's rotation lists applied on
@@ -170,7 +175,7 @@ def test_many_panel_block_jacobi_variants_against_lapack(eng, opts):
     U, _ = np.linalg.qr(rng.standard_normal((n, n))); V, _ = np.linalg.qr(rng.standard_normal((n, n)))
     s = np.exp(-16.0 * (np.arange(n) / n) ** 0.5)              # steep head, slowly decaying dense tail
     M = (U * s) @ V.T
-    keep = {"si_enable": 1, "jacobi_rot_apply": ROT_APPLY_DEFAULT, "jacobi_cross_only": CROSS_ONLY_DEFAULT}
+    keep = {"si_enable": 1, "jacobi_rot_apply": ROT_APPLY_DEFAULT, "jacobi_cross_only": CROSS_ONLY_DEFAULT, "jacobi_persist": PERSIST_DEFAULT}
     try:
         eng.set_option("si_enable", 0)                         # the dense path, not the leading-k iteration
         for k_, v_ in opts.items(): eng.set_option(k_, v_)
