@@ -53,7 +53,10 @@ int ctm_set_option(ctm_ctx* ctx, const char* key, double value);
  *                "si_enable","si_min_n","si_max_iter","si_tol","si_rr_sweeps","si_warm_skip_calls","si_block32","rank_tol","lz_enable","lz_min_k","lz_switch_steps"
  *   kernels:     "use_layer2","layer2_reg","layer2_cplx","gemm_fast","gemm_strip","strip_target_wgs","gemm_split_rem",
  *                "splitk_max_tiles","splitk_target_wgs","einsum_in_relayout","z_spectators_first","chain_as_strips","gemm_log"
- *   measurement: "gemm_timing","profile"                                                                                      */
+ *   round 4:     "lz_block" (rows per block of the real block Krylov recurrence: 32 / 64), "lz_block_c" (complex), "xgemm_stack_rows",
+ *                "rows_min_klen","rows_min_klen_hbm","rows_target_wgs","rows_quantise","rows_deep_prefetch" (K-slice rule / pipeline of the row-block GEMM),
+ *                "jacobi_cross_only","jacobi_rot_apply","jacobi_persist" (variants of the many-panel block Jacobi), "eigh_orth_extra_blocks"
+ *   measurement: "gemm_timing","timing_min_flops","profile"                                                                   */
 int ctm_get_stat(ctm_ctx* ctx, const char* key, double* value);
 /*   "last_sweeps","last_offnorm","total_sweeps","jacobi_calls","si_hits","si_fallbacks","si_total_iters","si_last_iters",
  *   "si_last_rank","si_warm_starts","si_warm_skips","corner_cache_hits","lz_hits","lz_total_steps","gemm_flops","gemm_calls","layer2_flops","layer2_calls",
