@@ -3,6 +3,7 @@
 # (e.g. rows_min_klen=576).  Logs under gpurun_out/.
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
+python peps-torch_amd/csrc/build.py --asan > /dev/null || exit 1      # (rebuilt when a source is newer: hipcc is on the GPU box too)
 export CTM_LIB=$PWD/peps-torch_amd/libctm_hip_asan.so
 export ASAN_OPTIONS=detect_leaks=0:protect_shadow_gap=0:abort_on_error=1:halt_on_error=1:log_path=$PWD/gpurun_out/asan
 export CTM_ENGINE_OPTS="$1"
