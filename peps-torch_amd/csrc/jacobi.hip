@@ -2498,18 +2498,11 @@ __global__ __launch_bounds__(64) void chol64_scaled_inv_kernel(const double* __r
 // rows of W (64 x n) -> orthonormal rows spanning the same space: two Cholesky-QR passes, and a third one -- decided on the device --
 // when the first had to shift (nearly dependent rows); no host synchronisation.  Status words of the three passes go to
 // `status` (9 doubles: pivot, min norm, max norm per pass; a skipped third pass reports 1), `flag3` is a device word.
-__global__ void mark_third_skipped_kernel(double* status, int nslots, int sw) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < nslots) { status[(size_t)sw * i + 6] = 1.0; status[(size_t)sw * i + 7] = -1.0; status[(size_t)sw * i + 8] = -1.0; }
-}
-
 int orthonormalise_block_async(ctm_ctx* ctx, double* W, int b, int n, double* G, double* Li, double* status, int* flag3) {
-    // 32-row blocks: two passes.  The third one exists for a first pass that had to shift (64 nearly dependent rows: ~1.6 of the 28 blocks
-    // of a D = 8 solve); 32 rows are better conditioned -- not one shifted pass in any 32-row run so far -- and the always-enqueued,
-    // flag-skipped third pass was three idle launches per block (129 per unit).  Should a first pass shift all the same, the second
-    // pass reports a pivot below 0.5 and the caller repeats the solve on the synchronous path, as for any other status it does not like.
-    // (the caller has marked the third-pass words of every status slot as skipped: mark_third_skipped_kernel)
-    const int npass = b == 32 ? 2 : 3;
+    // (Two passes for 32-row blocks were tried: no shifted first pass in any run on random tensors, three idle launches per block saved, < 0.5 % of
+    // a sweep -- but on an SU(2)-symmetric state (RVB D = 3 tiled on the 2 x 2 cell, chi = 80: exactly dependent rows inside multiplets) a shifted
+    // pass then sends the whole solve to the synchronous path.  The third, flag-skipped pass stays for every block size.)
+    const int npass = 3;
     for (int pass = 0; pass < npass; ++pass) {
         GemmDesc g; g.M = b; g.N = b; g.K = n; g.A = W; g.sam = n; g.sak = 1; g.B = W; g.sbk = 1; g.sbn = n; g.C = G; g.ldc = b;
         if (pass == 2) g.skip_all = flag3;
@@ -2587,7 +2580,6 @@ int svd_lanczos(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* Ut, dou
         CTM_TRY(arena_alloc(ctx, sizeof(double) * SW * nstat, (void**)&ostat));
         CTM_TRY(arena_alloc(ctx, sizeof(double) * 64 * 64, (void**)&Li));
         CTM_TRY(arena_alloc(ctx, sizeof(int) * 64, (void**)&flag3));
-        if (b == 32) CTM_LAUNCH(ctx, mark_third_skipped_kernel, dim3((nstat + 255) / 256), dim3(256), 0, ostat, nstat, SW);     // two-pass blocks
     }
     auto resync = [&]() -> int {          // redo this solve on the synchronous path
         if (ctx->jacobi_verbose) fprintf(stderr, "[lz] n=%d asynchronous recurrence flagged: repeating on the synchronous path\n", n);
@@ -2654,19 +2646,26 @@ int svd_lanczos(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* Ut, dou
             std::vector<double> hst((size_t)SW * nstat, 0.0);
             CTM_HIP_CHECK(ctx, hipMemcpyAsync(hst.data(), ostat, sizeof(double) * SW * nstat, hipMemcpyDeviceToHost, ctx->stream));
             CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-            bool bad = false;
+            bool bad = false, broke = false;
             double s0a = 0.0;
             auto check = [&](int slot, bool left) {
                 const double* q = hst.data() + SW * slot;
                 const bool third = q[7] >= 0.0;                                // the device ran the third pass (first one was shifted)
                 const double last = third ? q[6] : q[3];                       // pivot of the last pass: rows orthonormal to rounding iff ~1
+                if (left) s0a = std::max(s0a, q[2]);
+                // breakdown of the recurrence: a new block with (numerically) nothing in it -- the Krylov space has exhausted the range of a
+                // rank-deficient operator (symmetric states at small chi: every solve).  Not a case for this solver on either path: leave
+                // at once, as the synchronous recurrence does, instead of repeating the whole solve there to find the same thing
+                if (q[1] == q[1] && !(q[1] > 1e-13 * std::max(s0a, 1e-300)) && slot != nstat - 1) { broke = true; return; }
                 if (!(q[0] > 0.0) || !(last > 0.5) || !(q[1] > 0.0)) bad = true;   // (NaN fails too), zero row
                 if (third) ctx->lz_third_passes += 1;
-                if (left) s0a = std::max(s0a, q[2]);
-                if (!(q[1] > 1e-13 * std::max(s0a, 1e-300)) && slot != nstat - 1) bad = true;    // breakdown of the recurrence
             };
             check(nstat - 1, false);
-            for (int jj = 0; jj <= j && !bad; ++jj) { check(2 * jj, true); check(2 * jj + 1, false); }
+            for (int jj = 0; jj <= j && !bad && !broke; ++jj) { check(2 * jj, true); check(2 * jj + 1, false); }
+            if (broke && !bad) {
+                if (ctx->jacobi_verbose) fprintf(stderr, "[lz] n=%d breakdown of the asynchronous recurrence by step %d (rank-deficient operator)\n", n, j + 1);
+                return CTM_OK;
+            }
             if (bad) return resync();
         }
         // ---- small problem T = (U_all M) V_all^T  (m x m),  coupling E = (U_all M) V_{j+1}^T  (m x b)
