@@ -120,10 +120,8 @@ int add_to(ctm_ctx* ctx, const DT& y, const DT& x, double a) {
 
 }  // namespace
 
-extern "C" {
-
-int ctm_svd_backward(ctm_ctx* ctx, const double* U, const double* S, const double* V, const double* gU, const double* gS,
-                     const double* gV, int m, int n, int k, double eps, double* dA) {
+static int svd_backward_impl(ctm_ctx* ctx, const double* U, const double* S, const double* V, const double* gU, const double* gS,
+                             const double* gV, int m, int n, int k, double eps, double* dA) {
     if (m < 1 || n < 1 || k < 1 || k > std::min(m, n) || !U || !S || !V || !dA) { ctx->set_error("svd_backward: bad arguments"); return CTM_ERR_BADARG; }
     ArenaScope scope(ctx);
     Marsh io(ctx);
@@ -171,8 +169,8 @@ int ctm_svd_backward(ctm_ctx* ctx, const double* U, const double* S, const doubl
     return CTM_OK;
 }
 
-int ctm_eigh_backward(ctm_ctx* ctx, const double* D, const double* U, const double* gD, const double* gU, int n, int k, double reg,
-                      double* dA) {
+static int eigh_backward_impl(ctm_ctx* ctx, const double* D, const double* U, const double* gD, const double* gU, int n, int k, double reg,
+                              double* dA) {
     if (n < 1 || k < 1 || k > n || !D || !U || !dA) { ctx->set_error("eigh_backward: bad arguments"); return CTM_ERR_BADARG; }
     ArenaScope scope(ctx);
     Marsh io(ctx);
@@ -190,6 +188,26 @@ int ctm_eigh_backward(ctm_ctx* ctx, const double* D, const double* U, const doub
     CTM_TRY(io.finish());
     CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     return CTM_OK;
+}
+
+// The C-ABI entries proper.  A C++ exception must not cross the boundary (it would end the caller's process in std::terminate): one full
+// run of the GPU suite in round 4 ended with SIGABRT inside ctm_svd_backward (the complex gradcheck of the reference's own SVDGESDD test,
+// once in nine runs, never in isolation, never under AddressSanitizer) -- whatever threw or aborted there, an exception now comes back as
+// a status with its message.
+extern "C" {
+
+int ctm_svd_backward(ctm_ctx* ctx, const double* U, const double* S, const double* V, const double* gU, const double* gS,
+                     const double* gV, int m, int n, int k, double eps, double* dA) {
+    try { return svd_backward_impl(ctx, U, S, V, gU, gS, gV, m, n, k, eps, dA); }
+    catch (const std::exception& e) { if (ctx) ctx->set_error(std::string("svd_backward: C++ exception: ") + e.what()); return CTM_ERR_HIP; }
+    catch (...) { if (ctx) ctx->set_error("svd_backward: unknown C++ exception"); return CTM_ERR_HIP; }
+}
+
+int ctm_eigh_backward(ctm_ctx* ctx, const double* D, const double* U, const double* gD, const double* gU, int n, int k, double reg,
+                      double* dA) {
+    try { return eigh_backward_impl(ctx, D, U, gD, gU, n, k, reg, dA); }
+    catch (const std::exception& e) { if (ctx) ctx->set_error(std::string("eigh_backward: C++ exception: ") + e.what()); return CTM_ERR_HIP; }
+    catch (...) { if (ctx) ctx->set_error("eigh_backward: unknown C++ exception"); return CTM_ERR_HIP; }
 }
 
 }  // extern "C"

@@ -149,8 +149,8 @@ struct ctm_ctx {
     int rows_kernel_min_m = 1, rows_kernel_min_m_kc = 1;   // LDS-tiled row-block kernel from this many rows (n-contiguous / k-contiguous big operand)
     int rows_min_klen = 576;      // ... lower bound on the K slice: mid-size operands (n = 4608 = 36 column tiles) otherwise run 18 slices of 256 k that are all
                                   //     prologue, epilogue and an 18-slab combine (D = 6 chi = 128 sweep +8-12 %; n >= 12288 keeps its slice count).  Round 3 saw one
-                                  //     full test run with 576 end in a core dump; round 4 could not reproduce it: the shape sweep through every epilogue
-                                  //     (tests/test_gpu_gemm_rows.py, ks = 1 included) and the whole suite under AddressSanitizer with 576 are clean
+                                  //     full test run with 576 end in a core dump and suspected this option; round 4 cleared it (shape sweep through every epilogue,
+                                  //     tests/test_gpu_gemm_rows.py, ks = 1 included; the whole suite under AddressSanitizer) -- the crash sits elsewhere
     int rows_min_klen_hbm = 576;      // ... the same bound for <= 32-row blocks (HBM-bound)
     bool rows_deep_prefetch = true;   // ... two K tiles in flight per workgroup when at most two workgroups share a CU (mid-size operands)
     bool rows_quantise = true;    // ... its slice count is rounded down so that the last round of workgroups over the 256 CUs is nearly full

@@ -5,7 +5,8 @@ The K-slice rule of the dispatcher (`rows_target_wgs`, `rows_min_klen`) is drive
 a single slice (direct write: alpha, beta, ldc > N), two slices, the default rule, odd slice lengths with a short last slice, the
 in-launch combine and the separate reduce kernel -- on both layouts of the big operand.  (Round 3 ended one full test run with
 `rows_min_klen=576` in a core dump; this is the sweep that run did not have.  It passes, and so does the whole suite under
-AddressSanitizer with that value -- the crash did not reproduce and 576 is the default since round 4.)"""
+AddressSanitizer with that value: the option is cleared and is the default since round 4.  The crash itself recurred once and
+sits elsewhere -- inside ctm_svd_backward of a 25 x 25 complex gradcheck)"""
 import numpy as np
 import pytest
 import torch
