@@ -42,6 +42,9 @@ typedef struct ctm_trunc_cfg {
 } ctm_trunc_cfg;
 
 /* ---- context ------------------------------------------------------------------------------ */
+/* Diagnostic: with CTM_ABORT_BACKTRACE=1 in the environment the first ctm_create installs a SIGABRT / SIGSEGV handler that writes the
+ * native stack of the failing thread to fd 2 and then hands the signal to its previous owner.  Off by default (a library should not
+ * take over a host application's signals); the test-suite turns it on. */
 int ctm_create(ctm_ctx** out, void* hip_stream /* hipStream_t or NULL */, int dtype);
 int ctm_destroy(ctm_ctx* ctx);
 const char* ctm_last_error(ctm_ctx* ctx);

@@ -1,5 +1,45 @@
 // Context, workspace arena and the primitive entry points of the C-ABI (include/ctm_hip.h).
 #include "ctm_common.h"
+#include <execinfo.h>
+#include <signal.h>
+#include <unistd.h>
+#include <mutex>
+
+namespace {
+
+// Diagnostic, off unless the environment holds CTM_ABORT_BACKTRACE=1 (tests/conftest.py sets it): on SIGABRT / SIGSEGV write the
+// NATIVE stack of the failing thread to fd 2, then hand the signal to whoever owned it before (Python's faulthandler under pytest,
+// else the default action).  A Python traceback ends at the ctypes call; this says which frame below it aborted.
+struct sigaction g_prev_abrt, g_prev_segv;
+
+void fatal_backtrace(int sig, siginfo_t*, void*) {
+    static const char head[] = "ctm_hip: fatal signal -- native stack of the failing thread:\n";
+    (void)!write(2, head, sizeof(head) - 1);
+    void* frames[96];
+    const int n = backtrace(frames, 96);
+    backtrace_symbols_fd(frames, n, 2);
+    sigaction(sig, sig == SIGABRT ? &g_prev_abrt : &g_prev_segv, nullptr);
+    raise(sig);
+}
+
+void install_fatal_backtrace() {
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char* e = getenv("CTM_ABORT_BACKTRACE");
+        if (!e || !*e || *e == '0') return;
+        void* warm[2];
+        (void)backtrace(warm, 2);                  // loads the unwinder now: its first call allocates
+        struct sigaction sa;
+        memset(&sa, 0, sizeof(sa));
+        sa.sa_sigaction = fatal_backtrace;
+        sa.sa_flags = SA_SIGINFO | SA_NODEFER;
+        sigemptyset(&sa.sa_mask);
+        sigaction(SIGABRT, &sa, &g_prev_abrt);
+        sigaction(SIGSEGV, &sa, &g_prev_segv);
+    });
+}
+
+}  // namespace
 
 int arena_alloc(ctm_ctx* ctx, size_t bytes, void** out) {
     Arena& a = ctx->arena;
@@ -54,6 +94,7 @@ int ctm_create(ctm_ctx** out, void* hip_stream, int dtype) {
     if (!out) return CTM_ERR_BADARG;
     *out = nullptr;
     if (dtype != CTM_F64 && dtype != CTM_C128) return CTM_ERR_UNSUPPORTED;
+    install_fatal_backtrace();
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return CTM_ERR_HIP;
     ctm_ctx* c = new ctm_ctx();

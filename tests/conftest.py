@@ -1,5 +1,6 @@
 import os, sys
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")     # as config.py does: before the HIP runtime initialises
+os.environ.setdefault("CTM_ABORT_BACKTRACE", "1")   # csrc/ctm_runtime.hip: native stack on SIGABRT / SIGSEGV (the rare adjoint abort)
 import pytest
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
