@@ -58,12 +58,13 @@ int ctm_set_option(ctm_ctx* ctx, const char* key, double value);
  *                "splitk_max_tiles","splitk_target_wgs","einsum_in_relayout","z_spectators_first","chain_as_strips","gemm_log"
  *   round 4:     "lz_block" (rows per block of the real block Krylov recurrence: 32 / 64), "lz_block_c" (complex), "xgemm_stack_rows",
  *                "rows_min_klen","rows_min_klen_hbm","rows_target_wgs","rows_quantise","rows_deep_prefetch" (K-slice rule / pipeline of the row-block GEMM),
- *                "jacobi_cross_only","jacobi_rot_apply","jacobi_persist" (variants of the many-panel block Jacobi), "eigh_orth_extra_blocks"
+ *                "jacobi_cross_only","jacobi_rot_apply","jacobi_persist" (variants of the many-panel block Jacobi), "eigh_orth_extra_blocks",
+ *                "eigh_orth_double","eigh_orth_double_min_ratio" (two shifted applications per Cholesky-QR step of the symmetric orthogonal iteration)
  *   measurement: "gemm_timing","timing_min_flops","profile"                                                                   */
 int ctm_get_stat(ctm_ctx* ctx, const char* key, double* value);
 /*   "last_sweeps","last_offnorm","total_sweeps","jacobi_calls","si_hits","si_fallbacks","si_total_iters","si_last_iters",
  *   "si_last_rank","si_warm_starts","si_warm_skips","corner_cache_hits","lz_hits","lz_total_steps","gemm_flops","gemm_calls","layer2_flops","layer2_calls",
- *   "arena_high","k_ms0..3","k_flops0..3","k_calls0..3"                                                                   */
+ *   "arena_high","k_ms0..3","k_flops0..3","k_calls0..3","eigh_warm_hits","eigh_orth_hits","eigh_orth_fails","eigh_orth_doubled"                                                                 */
 int ctm_timers(ctm_ctx* ctx, double* out8, int reset);             /* corners,halves,svd,proj,absorb,norm,rdm,eig (s) */
 /* GEMM launches timed with HIP events while the option "gemm_timing" is on: quadruples (kind, start_ms, end_ms, flops) on a
  * process-wide clock (kind 0 = 128x128-tile GEMM kernels, 1 = 64x64-tile GEMM kernel, 2 = fused two-layer kernel, 3 = streaming

@@ -204,6 +204,8 @@ int ctm_set_option(ctm_ctx* ctx, const char* key, double value) {
     else if (k == "eigh_orth_iter") { ctx->eigh_orth_iter = (int)value; eigh_orth_state_reset(); }
     else if (k == "eigh_orth_max") ctx->eigh_orth_max = (int)value;
     else if (k == "eigh_orth_extra_blocks") ctx->eigh_orth_extra_blocks = (int)value;
+    else if (k == "eigh_orth_double") ctx->eigh_orth_double = (int)value;
+    else if (k == "eigh_orth_double_min_ratio") ctx->eigh_orth_double_min_ratio = value;
     else if (k == "eigh_orth_predict") ctx->eigh_orth_predict = (int)value;
     else if (k == "eigh_orth_quad_exit") ctx->eigh_orth_quad_exit = value;
     else if (k == "svd_abs_accuracy") ctx->svd_abs_accuracy = (int)value;
@@ -261,6 +263,7 @@ int ctm_get_stat(ctm_ctx* ctx, const char* key, double* value) {
     else if (k == "eigh_warm_rejects") *value = (double)ctx->eigh_warm_rejects;
     else if (k == "eigh_orth_hits") *value = (double)ctx->eigh_orth_hits;
     else if (k == "eigh_orth_fails") *value = (double)ctx->eigh_orth_fails;
+    else if (k == "eigh_orth_doubled") *value = (double)ctx->eigh_orth_doubled;
     else if (k == "svd_polar_completions") *value = (double)ctx->svd_polar_completions;
     else if (k == "svd_eig_completions") *value = (double)ctx->svd_eig_completions;
     else if (k == "svd_polar_solves") *value = (double)ctx->svd_polar_solves;
@@ -304,7 +307,7 @@ int ctm_gemm_intervals(ctm_ctx* ctx, double* out, long long capacity, long long*
 int ctm_timers(ctm_ctx* ctx, double* out8, int reset) {
     gemm_timing_drain(ctx);       // event-timed phases are accumulated when their events are read
     for (int i = 0; i < CTM_T_COUNT; ++i) { if (out8) out8[i] = ctx->timers[i]; if (reset) ctx->timers[i] = 0.0; }
-    if (reset) { ctx->gemm_flops = 0; ctx->gemm_calls = 0; ctx->layer2_flops = 0; ctx->layer2_calls = 0; ctx->total_sweeps = 0; ctx->jacobi_calls = 0; ctx->si_hits = 0; ctx->si_fallbacks = 0; ctx->si_total_iters = 0; ctx->si_warm_starts = 0; ctx->eigh_warm_hits = 0; ctx->eigh_warm_rejects = 0; ctx->eigh_orth_hits = 0; ctx->eigh_orth_fails = 0; ctx->svd_polar_completions = 0; ctx->svd_eig_completions = 0; ctx->svd_polar_solves = 0; ctx->lz_hits = 0; ctx->lz_total_steps = 0; ctx->lz_total_rows = 0; ctx->lz_extractions = 0; ctx->absorb_bytes = 0; ctx->absorb_calls = 0; }
+    if (reset) { ctx->gemm_flops = 0; ctx->gemm_calls = 0; ctx->layer2_flops = 0; ctx->layer2_calls = 0; ctx->total_sweeps = 0; ctx->jacobi_calls = 0; ctx->si_hits = 0; ctx->si_fallbacks = 0; ctx->si_total_iters = 0; ctx->si_warm_starts = 0; ctx->eigh_warm_hits = 0; ctx->eigh_warm_rejects = 0; ctx->eigh_orth_hits = 0; ctx->eigh_orth_fails = 0; ctx->eigh_orth_doubled = 0; ctx->svd_polar_completions = 0; ctx->svd_eig_completions = 0; ctx->svd_polar_solves = 0; ctx->lz_hits = 0; ctx->lz_total_steps = 0; ctx->lz_total_rows = 0; ctx->lz_extractions = 0; ctx->absorb_bytes = 0; ctx->absorb_calls = 0; }
     return CTM_OK;
 }
 

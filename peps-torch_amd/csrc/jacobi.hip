@@ -3360,7 +3360,7 @@ __global__ void embed_rows_kernel(const double* __restrict__ re, const double* _
 // Adaptive state of the orthogonal iteration (contraction rate of the last accepted solve, back-off after a flat spectrum): a property
 // of the PROBLEM, i.e. of the caller's warm workspace -- contexts are shared by problems and handed to units dynamically, so the state is
 // keyed by the workspace pointer (process-wide), not kept on the context.
-struct OrthState { double rate = 0.0; int skip = 0, backoff = 0; bool rows_seen_valid = false; };     // (rows_seen_valid: see eigh_warm_verify)
+struct OrthState { double rate = 0.0; int skip = 0, backoff = 0; bool rows_seen_valid = false; double theta_k = 0.0, theta_0 = 0.0, c_ratio = 0.0; };     // (rows_seen_valid: see eigh_warm_verify; theta: last kept / largest |Ritz value| of the last accepted look; c_ratio: contraction per application of the last UNSHIFTED solve)
 static std::mutex g_orth_mutex;
 static std::map<const double*, OrthState> g_orth_state;
 static OrthState orth_state_get(const double* ws) { std::lock_guard<std::mutex> l(g_orth_mutex); auto it = g_orth_state.find(ws); return it == g_orth_state.end() ? OrthState() : it->second; }
@@ -3596,7 +3596,23 @@ static int eigh_orth_iter(ctm_ctx* ctx, const double* As, int n, int kk, int k_o
     CTM_TRY(arena_alloc(ctx, sizeof(double) * kk, (void**)&res));
     CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)p * p, (void**)&E));
     CTM_TRY(arena_alloc(ctx, sizeof(double) * kk, (void**)&dots));
-    std::vector<double> h(p), hd(kk), he(p);
+    std::vector<double> h(p), hd(p), he(p);
+    // Two applications per Cholesky-QR step (option eigh_orth_double): the step costs 8 dependent launches against one for the product.
+    // Each 64-row block is factorised on its own after the blocks before it have been projected out, so what matters is the spread
+    // INSIDE a block, squared: (|lambda_kk| / |lambda_0|)^2 for the kept rows -- taken only while the previous look of this workspace
+    // measured that ratio above eigh_orth_double_min_ratio (Gram matrix of condition <= 1e12: the scaled Cholesky passes cope; never on
+    // the quickly decaying spectrum of a positive state, which needs four to six applications anyway).  Value 2 adds the shift
+    // Q (A^2 - c^2/2), c = |lambda_kk| x the contraction per application an unshifted solve of this workspace measured (an estimate of
+    // the largest |eigenvalue| the block does not hold): |lambda^2 - c^2/2| <= c^2/2 for |lambda| <= c halves what is left of the rest.
+    double dbl_shift = 0.0; bool dbl = false; double* Z2 = nullptr;
+    if (ctx->eigh_orth_double) {
+        const OrthState os0 = orth_state_get(warm);
+        if (os0.theta_0 > 0.0 && os0.theta_k > ctx->eigh_orth_double_min_ratio * os0.theta_0) {
+            dbl = true;
+            if (ctx->eigh_orth_double >= 2 && os0.c_ratio > 0.0 && os0.c_ratio < 0.7) { const double c = os0.c_ratio * os0.theta_k; dbl_shift = 0.5 * c * c; }
+            CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)p * n, (void**)&Z2));
+        }
+    }
     if (!warm_checked) {                     // (the warm restart that has just refused the subspace has looked at the row norms already)
         CTM_TRY(row_norms(ctx, warm, kk, n, n, norms));
         CTM_HIP_CHECK(ctx, hipMemcpyAsync(h.data(), norms, sizeof(double) * kk, hipMemcpyDeviceToHost, ctx->stream));
@@ -3649,6 +3665,15 @@ static int eigh_orth_iter(ctm_ctx* ctx, const double* As, int n, int kk, int k_o
     }
     for (int it = 0; it <= max_it; ++it) {
         CTM_TRY(rows_times(ctx, Q, n, p, n, n, As, false, Y, n));       // Y = Q A: application it + 1
+        if (dbl && it + 2 <= next_rr) {                                  // (no look before application it + 3)
+            CTM_TRY(rows_times(ctx, Y, n, p, n, n, As, false, Z2, n));  // application it + 2
+            if (dbl_shift > 0.0) CTM_LAUNCH(ctx, axpy_kernel, dim3(1024), dim3(256), 0, Z2, (const double*)Q, -dbl_shift, (size_t)p * n);
+            CTM_TRY(orth(Z2, it + 2 >= next_rr));
+            std::swap(Q, Z2);
+            ctx->eigh_orth_doubled += 1;
+            it += 1;
+            continue;
+        }
         if (it >= next_rr || it == max_it) {
             GemmDesc gt; gt.M = p; gt.N = p; gt.K = n; gt.A = Y; gt.sam = n; gt.sak = 1; gt.B = Q; gt.sbk = 1; gt.sbn = n; gt.C = T; gt.ldc = p;
             CTM_TRY(gemm_f64(ctx, gt));                                  // T = Y Q^T
@@ -3677,11 +3702,11 @@ static int eigh_orth_iter(ctm_ctx* ctx, const double* As, int n, int kk, int k_o
             CTM_LAUNCH(ctx, resid_rows_kernel, dim3((kk + 3) / 4), dim3(256), 0, (const double*)AX, (long long)n, (const double*)X, (long long)n,
                        (const double*)Dp, kk, n, res);
             CTM_HIP_CHECK(ctx, hipMemcpyAsync(h.data(), res, sizeof(double) * kk, hipMemcpyDeviceToHost, ctx->stream));
-            CTM_HIP_CHECK(ctx, hipMemcpyAsync(hd.data(), Dp, sizeof(double) * kk, hipMemcpyDeviceToHost, ctx->stream));
+            CTM_HIP_CHECK(ctx, hipMemcpyAsync(hd.data(), Dp, sizeof(double) * p, hipMemcpyDeviceToHost, ctx->stream));
             CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
             const double lam0 = std::fabs(hd[0]), lamk = std::fabs(hd[kk - 1]);
             const double worst = *std::max_element(h.begin(), h.begin() + kk);
-            if (ctx->jacobi_verbose) fprintf(stderr, "[eigh-orth] n=%d p=%d application %d: |QQ^T - I| = %.2e  max resid/|l0| = %.3e  |l_kk|/|l0| = %.3e\n", n, p, it + 1, dev, worst / std::max(lam0, 1e-300), lamk / std::max(lam0, 1e-300));
+            if (ctx->jacobi_verbose) fprintf(stderr, "[eigh-orth] n=%d p=%d application %d: |QQ^T - I| = %.2e  max resid/|l0| = %.3e  |l_kk|/|l0| = %.3e  |l_p|/|l0| = %.3e  double=%d shift/l_kk^2=%.3f\n", n, p, it + 1, dev, worst / std::max(lam0, 1e-300), lamk / std::max(lam0, 1e-300), std::fabs(hd[p - 1]) / std::max(lam0, 1e-300), (int)dbl, dbl_shift / std::max(lamk * lamk, 1e-300));
             if (!(lam0 > 0.0) || !(lamk > ctx->rank_tol * lam0)) return CTM_OK;
             if (worst <= tol * lam0) {
                 // gauge: the sign of <x_i, v_i> (previous vectors).  (Rotating whole multiplets onto the previous vectors -- orthogonal
@@ -3696,7 +3721,9 @@ static int eigh_orth_iter(ctm_ctx* ctx, const double* As, int n, int kk, int k_o
                 {
                     OrthState os = orth_state_get(warm);
                     os.backoff = 0;
+                    os.theta_0 = lam0; os.theta_k = lamk;
                     if (moved > 0.0) os.rate = std::min(0.9, std::max(1e-3, std::pow(std::max(worst / lam0, 1e-16) / std::min(moved, 1.0), 1.0 / (it + 1))));
+                    if (moved > 0.0 && dbl_shift == 0.0) os.c_ratio = os.rate;
                     orth_state_put(warm, os);
                 }
                 ctx->si_last_iters = it + 1; ctx->si_total_iters += it + 1;
