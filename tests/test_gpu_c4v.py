@@ -306,39 +306,6 @@ def test_orthogonal_iteration_with_a_slowly_contracting_block(eng):
     assert float((U.T @ U - torch.eye(chi, device=U.device, dtype=U.dtype)).abs().max()) < 1e-12
 
 
-def test_orthogonal_iteration_with_two_applications_per_cholesky_step(eng):
-    """Option eigh_orth_double (off by default): once a look of this workspace has measured |lambda_kk / lambda_0| above the gate, the
-    iteration orthonormalises after every SECOND application (1), with the shift Q (A^2 - c^2/2) once an unshifted solve has
-    measured the contraction (2).  Same acceptance test, so the same exact pairs as LAPACK; the doubled steps are counted."""
-    n, chi = 768, 48
-    lam = torch.cat([torch.linspace(1.0, 0.2, 60), 0.1 * 0.97 ** torch.arange(n - 60, dtype=torch.float64)]).double()
-    lam = lam * torch.where(torch.arange(n) % 5 == 3, -1.0, 1.0)
-    A, _ = _sym_with_spectrum(n, lam, 61)
-    g = torch.Generator().manual_seed(62)
-    E = torch.randn(n, n, generator=g, dtype=torch.float64); E = E + E.T
-    E = E / torch.linalg.matrix_norm(E, 2)
-    try:
-        eng.set_option("eigh_orth_double", 2)
-        basis = eng.warm_basis_c4v(chi, n)
-        eng.truncated_eigh(A.cuda(), chi, basis=basis)
-        eng.timers(reset=True)
-        doubled = []
-        for k, eps in enumerate((1e-4, 2e-4, 3e-4, 4e-4)):          # (first move: measures the ratio; second: doubled; from the third: shifted)
-            M = A + eps * E
-            D, U = eng.truncated_eigh(M.cuda(), chi, basis=basis)
-            doubled.append(eng.stat("eigh_orth_doubled"))
-            w = torch.linalg.eigvalsh(M)
-            w = w[torch.argsort(w.abs(), descending=True)][:chi]
-            assert float((D.cpu() - w).abs().max()) < 1e-12, k
-            assert float(((M.cuda() @ U) - U * D).abs().max()) < 1e-12, k
-            assert float((U.T @ U - torch.eye(chi, device=U.device, dtype=U.dtype)).abs().max()) < 1e-12, k
-        assert eng.stat("eigh_orth_hits") == 4 and eng.stat("eigh_orth_fails") == 0
-        # (the first move doubles only if a previous owner of this workspace's address left a measured ratio: the state is keyed by pointer)
-        assert doubled[3] > doubled[2] > doubled[1] > doubled[0] >= 0, doubled
-    finally:
-        eng.set_option("eigh_orth_double", 0)
-
-
 def test_orthogonal_iteration_leaves_a_flat_spectrum_to_the_regular_route(eng):
     """|lambda_129 / lambda_57| = 0.6: 36 applications for a move of 1e-6, more than the iteration allows itself.  The first look measures
     the contraction, the iteration leaves (and stays away for the next calls); the regular route (63 half steps) returns the pairs."""
@@ -624,3 +591,37 @@ def test_full_decomposition_warm_start_changes_the_work_not_the_result(eng, cplx
     eng.timers(reset=True)
     D2, _ = eng.truncated_eigh(A1, n, cfgT, basis=torch.zeros_like(basis))
     assert eng.stat("eigh_warm_hits") == 0 and float((D2 - Dc).abs().max()) < 1e-13
+
+
+def test_orthogonal_iteration_with_two_applications_per_cholesky_step(eng):
+    """Option eigh_orth_double (off by default): once a look of this workspace has measured |lambda_kk / lambda_0| above the gate, the
+    iteration orthonormalises after every SECOND application (1), with the shift Q (A^2 - c^2/2) once an unshifted solve has
+    measured the contraction (2).  Same acceptance test, so the same exact pairs as LAPACK; the doubled steps are counted."""
+    n, chi = 768, 48
+    lam = torch.cat([torch.linspace(1.0, 0.2, 60), 0.1 * 0.97 ** torch.arange(n - 60, dtype=torch.float64)]).double()
+    lam = lam * torch.where(torch.arange(n) % 5 == 3, -1.0, 1.0)
+    A, _ = _sym_with_spectrum(n, lam, 61)
+    g = torch.Generator().manual_seed(62)
+    E = torch.randn(n, n, generator=g, dtype=torch.float64); E = E + E.T
+    E = E / torch.linalg.matrix_norm(E, 2)
+    try:
+        eng.set_option("eigh_orth_iter", 1)          # (forgets the adaptive state of every workspace: it is keyed by address, and this workspace's address has had owners)
+        eng.set_option("eigh_orth_double", 2)
+        basis = eng.warm_basis_c4v(chi, n)
+        eng.truncated_eigh(A.cuda(), chi, basis=basis)
+        eng.timers(reset=True)
+        doubled = []
+        for k, eps in enumerate((1e-4, 2e-4, 3e-4, 4e-4)):          # (first move: measures the ratio; second: doubled; from the third: shifted)
+            M = A + eps * E
+            D, U = eng.truncated_eigh(M.cuda(), chi, basis=basis)
+            doubled.append(eng.stat("eigh_orth_doubled"))
+            w = torch.linalg.eigvalsh(M)
+            w = w[torch.argsort(w.abs(), descending=True)][:chi]
+            assert float((D.cpu() - w).abs().max()) < 1e-12, k
+            assert float(((M.cuda() @ U) - U * D).abs().max()) < 1e-12, k
+            assert float((U.T @ U - torch.eye(chi, device=U.device, dtype=U.dtype)).abs().max()) < 1e-12, k
+        assert eng.stat("eigh_orth_hits") == 4 and eng.stat("eigh_orth_fails") == 0
+        assert doubled[0] == 0 and doubled[3] > doubled[2] > doubled[1] > 0, doubled
+    finally:
+        eng.set_option("eigh_orth_double", 0)
+        eng.set_option("eigh_orth_iter", 1)          # (and leaves none behind)
