@@ -39,3 +39,28 @@ def test_no_gpu_means_loud_failure():
     backend.set_engine(None)
     with pytest.raises(_native.NativeError):
         backend.get_engine()
+
+
+def test_fatal_signal_diagnostic_writes_the_native_stack_and_hands_the_signal_on():
+    """CTM_ABORT_BACKTRACE=1 (include/ctm_hip.h, ctm_create): on SIGABRT the library writes the native stack of the failing thread to
+    fd 2 and then lets the previous owner of the signal act (here Python's faulthandler, then the default action: the process still
+    dies of SIGABRT).  Without the variable the library leaves the signals alone.  Runs in child processes; no GPU needed (the handler
+    is installed before ctm_create looks for a device)."""
+    import signal, subprocess, sys
+    code = ("import ctypes, os, faulthandler\n"
+            "faulthandler.enable()\n"
+            "lib = ctypes.CDLL(%r)\n"
+            "h = ctypes.c_void_p()\n"
+            "lib.ctm_create(ctypes.byref(h), None, 0)\n"
+            "os.abort()\n") % os.path.join(PKG, "libctm_hip.so")
+    for armed in (True, False):
+        env = dict(os.environ)
+        env.pop("CTM_ABORT_BACKTRACE", None)
+        if armed:
+            env["CTM_ABORT_BACKTRACE"] = "1"
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+        assert r.returncode == -signal.SIGABRT, (armed, r.returncode)
+        assert ("ctm_hip: fatal signal" in r.stderr) == armed, r.stderr[-2000:]
+        assert "Fatal Python error: Aborted" in r.stderr, r.stderr[-2000:]         # faulthandler still got the signal
+        if armed:
+            assert "libctm_hip.so" in r.stderr and "abort" in r.stderr
