@@ -415,8 +415,11 @@ def run_workload(args, eng, dev, kind, D, chi, dtype, signed, steps, warmup, wor
         # what the engine could exploit on THIS state: numerical rank of the truncation and the number of projector columns above
         # projector_svd_reltol, out of chi
         nc = env.__dict__.get("_ncol") or {}
-        S = [float((s_ > 1e-8 * s_[0]).sum()) for s_ in (v for v in env.get_spectra().values())]
+        spec = list(env.get_spectra().values())
+        S = [float((s_ > 1e-8 * s_[0]).sum()) for s_ in spec]
         out["state"] = {"chi": chi, "signed": bool(signed),
+                        # sum of the normalised corner spectra after the last timed sweep: the same number from 1, 2, 4 ranks (tests/test_gpu_bench_ranks.py)
+                        "corner_spectra_checksum": float(sum(float((s_ / s_[0]).sum()) for s_ in spec)),
                         "corner_values_above_1e-8": int(min(S)) if S else None,
                         "nonzero_projector_columns": (max(nc.values()) if nc else chi),
                         "effective_rank_much_smaller_than_chi": bool(S and min(S) < 0.25 * chi),

@@ -27,7 +27,8 @@ extern "C" {
 typedef struct ctm_ctx ctm_ctx;
 
 enum { CTM_OK = 0, CTM_ERR_BADARG = 1, CTM_ERR_SHAPE = 2, CTM_ERR_NOCONV = 3, CTM_ERR_HIP = 4,
-       CTM_ERR_UNSUPPORTED = 5, CTM_ERR_NOMEM = 6 };
+       CTM_ERR_UNSUPPORTED = 5, CTM_ERR_NOMEM = 6,
+       CTM_ERR_BUSY = 7 /* the context is inside a call of another thread: one call at a time per context */ };
 enum { CTM_F64 = 0, CTM_C128 = 1 };
 enum { CTM_LU = 0, CTM_RU = 1, CTM_RD = 2, CTM_LD = 3 };          /* enlarged corners          */
 enum { CTM_UP = 0, CTM_LEFT = 1, CTM_DOWN = 2, CTM_RIGHT = 3 };   /* directional moves         */
@@ -127,12 +128,13 @@ int ctm_truncated_svd_ws(ctm_ctx* ctx, const double* M, int n, int chi, const ct
 /* A symmetric (lower triangle referenced); D (chi, signed, ordered by |D| descending), U n x chi */
 int ctm_truncated_eigh(ctm_ctx* ctx, const double* A, int n, int chi, const ctm_trunc_cfg* cfg, double* D, double* U);
 /* Same for a sequence of nearby matrices (the enlarged corner of consecutive C4v moves): `basis` is an opaque caller-owned device
- * workspace of min(n, min(chi+1,n) + 8) * n doubles (CTM_C128: twice that, real plane then imaginary plane), zero-filled before the
- * first call.
+ * workspace of (min(n, min(chi+1,n) + 8) + 1) * n doubles (CTM_C128: (2 min(...) + 1) * n, real plane then imaginary plane), zero-filled
+ * before the first call: the vectors, then ONE header row of n doubles in which the solver keeps the adaptive state of this sequence
+ * (contraction rate of its last accepted solve, back-off counters) -- the state is born and dies with the workspace.
  * A restart from the previous invariant subspace is accepted only if (a) every pair of a Rayleigh-Ritz inside it passes the
  * residual threshold of the cold solver and (b) a block of fresh pseudo-random rows iterated three times on the deflated matrix finds
  * nothing above the smallest accepted |lambda|; otherwise the regular iteration runs.  The result does not depend on the basis.
- * chi >= n (FULL decomposition, the SYMEIG node of the differentiable route): the workspace (n * n doubles) keeps all eigenvectors
+ * chi >= n (FULL decomposition, the SYMEIG node of the differentiable route): the workspace ((n + 1) * n doubles) keeps all eigenvectors
  * and the Jacobi sweeps of the next call start from W (A + shift I). */
 int ctm_truncated_eigh_ws(ctm_ctx* ctx, const double* A, int n, int chi, const ctm_trunc_cfg* cfg, double* D, double* U,
                           double* basis);
@@ -206,7 +208,7 @@ int ctm_c2x2_c4v(ctm_ctx* ctx, int open, const double* a, const double* C, const
                  double* out);
 int ctm_move_c4v(ctm_ctx* ctx, const double* a, const double* C, const double* T, int chi, int p, int D,
                  const ctm_trunc_cfg* cfg, double* C_out, double* T_out, double* D_out /* chi eigenvalues or NULL */);
-/* Same, warm started: `basis` is an opaque caller-owned device workspace of (min(chi+1,n)+8) * n doubles (CTM_C128: twice that), zero-filled before the
+/* Same, warm started: `basis` is an opaque caller-owned device workspace of (min(n, min(chi+1,n)+8) + 1) * n doubles (CTM_C128: (2 min(...) + 1) * n), zero-filled before the
  * first sweep and passed again on every later one (invariant subspace of the previous enlarged corner; see ctm_projectors_4x4_ws).
  * Once the enlarged corner is stationary a sweep restarts from that subspace (residual test on every kept pair + a deflated probe for
  * missed directions, see ctm_truncated_eigh_ws) instead of iterating; the returned tensors do not depend on the workspace. */

@@ -6,6 +6,7 @@ fallback: if the shared library is missing or a call fails, this module raises.
 """
 import ctypes as C
 import os
+import threading
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # see config.py: one hardware queue per worker stream
 import torch
 
@@ -14,7 +15,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIBPATH = os.environ.get("CTM_LIB") or os.path.join(_HERE, "libctm_hip.so")
 
 CTM_OK = 0
-_ERRNAMES = {1: "bad argument", 2: "shape mismatch", 3: "no convergence", 4: "HIP error", 5: "unsupported", 6: "out of memory"}
+_ERRNAMES = {1: "bad argument", 2: "shape mismatch", 3: "no convergence", 4: "HIP error", 5: "unsupported", 6: "out of memory",
+             7: "context busy (used by two threads at once)"}
 LU, RU, RD, LD = 0, 1, 2, 3
 UP, LEFT, DOWN, RIGHT = 0, 1, 2, 3
 DIR_INDEX = {(0, -1): UP, (-1, 0): LEFT, (0, 1): DOWN, (1, 0): RIGHT}
@@ -144,9 +146,31 @@ class Engine:
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self._handles = {}
         self._options = {}
+        self._tls = threading.local()          # the context selected by _bind is per CALLING THREAD (h, dtype below)
+        self._create_lock = threading.Lock()
         self.workers = []          # engines spawned for concurrent units (units.UnitPool): options/stats fan out to them
         self.default_cfg = TruncCfg(1e-8, 1e-8, 1e-14, 1, 1)
         self._bind_dtype(torch.float64)
+
+    # The handle / dtype a call works with.  Thread-local: autograd replays backward nodes on its own device thread while another
+    # thread may be inside a call of the same engine object with the other dtype; as plain instance attributes, a `_bind` of one
+    # thread changed the context the other was about to pass to the library (a complex128 context handed
+    # float64 buffers over-reads them).  Concurrent use of ONE native context is still refused by the library (CTM_ERR_BUSY).
+    @property
+    def h(self):
+        return self._tls.h
+
+    @h.setter
+    def h(self, v):
+        self._tls.h = v
+
+    @property
+    def dtype(self):
+        return self._tls.dtype
+
+    @dtype.setter
+    def dtype(self, v):
+        self._tls.dtype = v
 
     def spawn_worker(self):
         """A sibling engine on the CALLER's current stream (own native contexts and arenas), inheriting the options."""
@@ -160,15 +184,20 @@ class Engine:
         if dtype not in _DTYPES:
             raise NativeError(f"unsupported dtype {dtype}: the engine computes in float64 or complex128")
         if dtype not in self._handles:
-            with torch.cuda.device(self.device):
-                self.stream = torch.cuda.current_stream(self.device)
-                h = C.c_void_p()
-                st = self.lib.ctm_create(C.byref(h), C.c_void_p(self.stream.cuda_stream), _DTYPES[dtype])
-                if st != CTM_OK:
-                    raise NativeError(f"ctm_create failed: {_ERRNAMES.get(st, st)}")
-            self._handles[dtype] = h
-            for k, v in self._options.items():
-                self.lib.ctm_set_option(h, k.encode(), float(v))
+            with self._create_lock:
+                if dtype not in self._handles:
+                    with torch.cuda.device(self.device):
+                        # every context of an engine runs on the stream the engine was created on (the float64 context is made in
+                        # __init__): a complex128 context made lazily from inside some other stream scope must not bind that stream
+                        if getattr(self, "stream", None) is None:
+                            self.stream = torch.cuda.current_stream(self.device)
+                        h = C.c_void_p()
+                        st = self.lib.ctm_create(C.byref(h), C.c_void_p(self.stream.cuda_stream), _DTYPES[dtype])
+                        if st != CTM_OK:
+                            raise NativeError(f"ctm_create failed: {_ERRNAMES.get(st, st)}")
+                    for k, v in self._options.items():
+                        self.lib.ctm_set_option(h, k.encode(), float(v))
+                    self._handles[dtype] = h
         self.h = self._handles[dtype]
         self.dtype = dtype
 
@@ -389,7 +418,7 @@ class Engine:
         if basis is not None:
             k = chi + 1 if chi < n else n
             if not (basis.is_cuda and basis.dtype == torch.float64 and basis.is_contiguous()
-                    and tuple(basis.shape) == ((2 if A.dtype.is_complex else 1) * min(n, k + 8), n)):
+                    and tuple(basis.shape) == ((2 if A.dtype.is_complex else 1) * min(n, k + 8) + 1, n)):
                 raise NativeError("truncated_eigh: basis must come from warm_basis_c4v(chi, n, dtype)")
             self._ck(self.lib.ctm_truncated_eigh_ws(self.h, _ptr(A), n, chi, C.byref(cfg), _ptr(D), _ptr(U), _ptr(basis)), "truncated_eigh")
         else:
@@ -555,10 +584,10 @@ class Engine:
         return out
 
     def warm_basis_c4v(self, chi, n, dtype=torch.float64):
-        """Zero-filled warm-start workspace for move_c4v / truncated_eigh(..., basis=): (chi + 1 + 8) rows of length n, for complex128
-        matrices the real plane followed by the imaginary plane."""
+        """Zero-filled warm-start workspace for move_c4v / truncated_eigh(..., basis=): (chi + 1 + 8) rows of length n (for complex128
+        matrices the real plane followed by the imaginary plane) and one header row in which the solver keeps its adaptive state."""
         k = chi + 1 if chi < n else n
-        return torch.zeros((2 if dtype.is_complex else 1) * min(n, k + 8), n, dtype=torch.float64, device=self.device)
+        return torch.zeros((2 if dtype.is_complex else 1) * min(n, k + 8) + 1, n, dtype=torch.float64, device=self.device)   # + header row
 
     def move_c4v(self, a, C_, T, cfg=None, basis=None, normalize=1):
         a, C_, T = self._bind(a, C_, T)
@@ -569,7 +598,7 @@ class Engine:
             n = chi * D * D
             k = chi + 1 if chi < n else n
             if not (basis.is_cuda and basis.dtype == torch.float64 and basis.is_contiguous()
-                    and tuple(basis.shape) == ((2 if a.dtype.is_complex else 1) * min(n, k + 8), n)):
+                    and tuple(basis.shape) == ((2 if a.dtype.is_complex else 1) * min(n, k + 8) + 1, n)):
                 raise NativeError("move_c4v: basis must come from warm_basis_c4v(chi, n, dtype)")
         self._ck(self.lib.ctm_move_c4v_x(self.h, _ptr(a), _ptr(C_), _ptr(T), chi, p, D, C.byref(cfg), int(normalize), _ptr(nC), _ptr(nT), _ptr(Dv),
                                          _ptr(basis) if basis is not None else None), "move_c4v")

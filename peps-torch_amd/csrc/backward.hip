@@ -190,24 +190,17 @@ static int eigh_backward_impl(ctm_ctx* ctx, const double* D, const double* U, co
     return CTM_OK;
 }
 
-// The C-ABI entries proper.  A C++ exception must not cross the boundary (it would end the caller's process in std::terminate): one full
-// run of the GPU suite in round 4 ended with SIGABRT inside ctm_svd_backward (the complex gradcheck of the reference's own SVDGESDD test,
-// once in nine runs, never in isolation, never under AddressSanitizer) -- whatever threw or aborted there, an exception now comes back as
-// a status with its message.
+// The C-ABI entries proper (ctm_entry: one call at a time per context, no C++ exception crosses the boundary).
 extern "C" {
 
 int ctm_svd_backward(ctm_ctx* ctx, const double* U, const double* S, const double* V, const double* gU, const double* gS,
                      const double* gV, int m, int n, int k, double eps, double* dA) {
-    try { return svd_backward_impl(ctx, U, S, V, gU, gS, gV, m, n, k, eps, dA); }
-    catch (const std::exception& e) { if (ctx) ctx->set_error(std::string("svd_backward: C++ exception: ") + e.what()); return CTM_ERR_HIP; }
-    catch (...) { if (ctx) ctx->set_error("svd_backward: unknown C++ exception"); return CTM_ERR_HIP; }
+    return ctm_entry(ctx, "ctm_svd_backward", [&]() -> int { return svd_backward_impl(ctx, U, S, V, gU, gS, gV, m, n, k, eps, dA); });
 }
 
 int ctm_eigh_backward(ctm_ctx* ctx, const double* D, const double* U, const double* gD, const double* gU, int n, int k, double reg,
                       double* dA) {
-    try { return eigh_backward_impl(ctx, D, U, gD, gU, n, k, reg, dA); }
-    catch (const std::exception& e) { if (ctx) ctx->set_error(std::string("eigh_backward: C++ exception: ") + e.what()); return CTM_ERR_HIP; }
-    catch (...) { if (ctx) ctx->set_error("eigh_backward: unknown C++ exception"); return CTM_ERR_HIP; }
+    return ctm_entry(ctx, "ctm_eigh_backward", [&]() -> int { return eigh_backward_impl(ctx, D, U, gD, gU, n, k, reg, dA); });
 }
 
 }  // extern "C"

@@ -9,6 +9,9 @@
 #include <vector>
 #include <map>
 #include <chrono>
+#include <atomic>
+#include <thread>
+#include <new>
 
 #include "../../include/ctm_hip.h"
 
@@ -21,11 +24,19 @@
         }                                                                               \
     } while (0)
 
+// Diagnostics (environment, read once): CTM_SYNC_LAUNCH=1 waits for the stream after EVERY kernel launch and keeps the names of the last
+// launches in a process-wide ring that the fatal-signal handler of ctm_runtime.hip prints -- a GPU memory fault (raised
+// asynchronously by the HSA runtime, normally long after the offending launch) then names its kernel.
+extern int g_ctm_sync_launch;
+void ctm_note_launch(const char* kernel_name);
+
 // kernel launch on the context's stream with the launch error checked (a failed launch must not come back as CTM_OK)
 #define CTM_LAUNCH(ctx, kernel, grid, block, shmem, ...)                                              \
     do {                                                                                              \
+        if (g_ctm_sync_launch) ctm_note_launch(#kernel);                                              \
         hipLaunchKernelGGL(kernel, grid, block, shmem, (ctx)->stream, __VA_ARGS__);                   \
         hipError_t _le = hipGetLastError();                                                           \
+        if (_le == hipSuccess && g_ctm_sync_launch) _le = hipStreamSynchronize((ctx)->stream);        \
         if (_le != hipSuccess) {                                                                      \
             (ctx)->set_error(std::string("launch of " #kernel ": ") + hipGetErrorString(_le));        \
             return CTM_ERR_HIP;                                                                       \
@@ -47,7 +58,10 @@ struct Arena {
     int cur = -1;                  // current slab
     size_t top = 0;                // offset in the current slab
     size_t high = 0, total = 0;
+    std::vector<void*> guard_blocks;   // CTM_ARENA_GUARD=1 (diagnostic): every allocation its own hipMalloc, freed when its scope ends
 };
+extern int g_ctm_arena_guard;
+void arena_guard_release(struct ctm_ctx* ctx, size_t keep);
 
 // per-phase timers (seconds, host wall time with stream sync when profiling is enabled)
 enum { CTM_T_CORNERS = 0, CTM_T_HALVES, CTM_T_SVD, CTM_T_PROJ, CTM_T_ABSORB, CTM_T_NORM, CTM_T_RDM, CTM_T_EIG, CTM_T_COUNT };
@@ -69,8 +83,6 @@ struct ctm_ctx {
     int jacobi_inner_sweeps = 2;        // inner sweeps of the LDS eigensolver per visit of a pair (2 or 3 pairs per round)
     int jacobi_inner_sweeps_many = 1;   // ... when a round has >= 4 pairs (dense small SVDs, full-block Rayleigh-Ritz): measured faster
     int jacobi_cross_only = 1;          // many-panel block Jacobi: only the first round of a sweep solves the full 64 x 64 pair problems, the others rotate cross pairs only
-    int jacobi_persist = 0;             // many-panel block Jacobi: one launch per sweep (jacobi_sweep_kernel) instead of three per round
-    int jacobi_rot_apply = 0;           // many-panel block Jacobi: rotations recorded by the eigensolver and applied to the rows on the vector ALUs (no J, no apply GEMM)
     int jacobi_verbose = 0;
     // leading-k block power iteration (svd_iter): enabled for n >= si_min_n, residual tolerance relative to s_0
     bool si_enable = true;
@@ -118,7 +130,6 @@ struct ctm_ctx {
     double si_quad_exit = 0.0;          // ... optionally during the Rayleigh-Ritz of the subspace iteration (off: measured no gain -- the sweep it saves finds every
                                         // pair below tolerance, and such a sweep costs ~10 us per round: the eigensolver exits early, the apply GEMMs are skipped)
     double lz_quad_exit = 1e-9;         // ... during the Ritz extraction of the block Krylov solver, whose triplets are verified afterwards
-    int lz_jacobi_block = 0;            // > 0: panel height of the Jacobi SVD of the Ritz matrix (16: 32 x 32 pair Grams, 18 KB LDS eigensolver)
     bool lz_async = true;               // block Krylov recurrence issued without host synchronisations (status words checked at the extraction)
     bool lz_force_sync = false;         // (internal) the current solve is being repeated on the synchronous path
     long lz_async_fallbacks = 0, lz_third_passes = 0;
@@ -158,23 +169,14 @@ struct ctm_ctx {
     bool rows_quantise = true;    // ... its slice count is rounded down so that the last round of workgroups over the 256 CUs is nearly full
     int rows_target_wgs = 512;    // its workgroup count (column tiles x K slices): two per CU.  (768 until round 4: alone the same speed; with four units streaming
                                   //     four corners 256 ... 640 all give 2.95-2.99 s per full-rank D = 8 sweep against 3.06 with 768: fewer, longer slices, fewer slabs to combine)
-    // Chip-filling launches (>= heavy_min_flops) of ALL contexts of a device run one at a time (device-side lock): the concurrent
     // units of a move overlap their latency-bound stages with each other and with ONE corner pass at a time, instead of four
-    // corner passes splitting the chip (see HeavyScope, gemm_f64.hip)
-    bool heavy_serial = false; double heavy_min_flops = 1e10;      // (off: measured 2-5 % slower -- the tail of one chip-filling kernel is no longer filled by the next unit's)
     double timing_min_flops = 5e9;      // event pairs only around the chip-filling launches (corner passes, corner builds, absorb GEMMs): pairs around the ~170 projection GEMMs of a unit (7e8 flop each) cost the full-rank sweep 1.6 %
-    unsigned heavy_id = 0; bool in_heavy = false;          // owner id of this context in the device-side lock
-    long heavy_launches = 0;
     bool rows_fused_reduce = true;      // its K-slice partials are summed inside the launch by the last workgroup of a column tile
     unsigned* tile_cnt = nullptr;       // per-column-tile arrival counters of that combine (zero between launches)
     bool xgemm_stack_rows = true; // complex row blocks (<= 64 rows, planes contiguous): two real products on the stacked 2M rows instead of four
     bool gemm_split_rem = true;   // split a 128 q + r (r <= 64) dimension into a vectorised part and a strip
     int splitk_max_tiles = 256, splitk_target_wgs = 1024;   // split-K of skinny GEMMs: when few output tiles, how many workgroups to aim for
-    bool eig64_pingpong = true;
-    int eig64_bpt = 2;                  // 2x2 blocks per thread of the 64 x 64 LDS eigensolver (1, 2, 4 -> 1024, 512, 256 threads)         // one-barrier-per-round LDS eigensolver for 64 x 64 pair Grams
     bool layer2_cplx = true;            // fused kernel for complex128 operands too
-    int layer2_dbg = 0;
-    int layer2_reg = 1;                 // register-resident fused kernel for KT = KAp/16 >= this value (-1: never)
     // optional per-launch HIP-event timing of the GEMM kernels on ctx->stream (bench roofline):
     // kind 0 = 128x128 tile kernel, kind 1 = 64x64 tile kernel
     bool gemm_timing = false;
@@ -190,15 +192,61 @@ struct ctm_ctx {
     long k_calls[5] = {0, 0, 0, 0, 0};
     void* comm = nullptr; int comm_rank = 0, comm_nranks = 1;   // rank group sharing one unit (ctm_set_comm; column split: include/ctm_hip.h)
     bool cplx = false;                   // CTM_C128 context: every tensor pointer of the C-ABI is interleaved complex128
+    alignas(8) unsigned char orth_cur_storage[64] = {0};      // adaptive state of the symmetric orthogonal iteration for the workspace of the CURRENT call (jacobi.hip: OrthState)
+    // stationary fast path of the implicit-operator truncation (jacobi.hip: svd_stationary).  0 = off: every truncation is solved to resid_tol
+    double warm_accept_tol = 0.0;        // accept one Rayleigh-Ritz half step from the previous basis when its residual is <= this x s_0
+    double warm_try_factor = 3.0;        // ... tried when the previous basis lay within this x warm_accept_tol of the last solve's subspace
+    int warm_accept_max_run = 32;        // ... at most this many accepted calls of a unit between two full solves (0: no limit)
+    long warm_accepts = 0, warm_rejects = 0;
+    double warm_last_dist = 0.0;
+    // one call at a time: a context owns ONE arena stack and ONE stream, so two threads inside it at once corrupt both silently.
+    // EntryGuard (below) makes that a loud CTM_ERR_BUSY instead (same-thread nesting -- an entry implemented by another -- is fine)
+    std::atomic<int> busy{0};
+    std::thread::id owner;
+    int depth = 0;
     void set_error(const std::string& s) { last_error = s; }
 };
+
+struct EntryGuard {
+    ctm_ctx* c; bool ok;
+    explicit EntryGuard(ctm_ctx* ctx) : c(ctx), ok(true) {
+        const std::thread::id me = std::this_thread::get_id();
+        int expect = 0;
+        if (c->busy.compare_exchange_strong(expect, 1, std::memory_order_acquire)) { c->owner = me; c->depth = 1; }
+        else if (c->owner == me) ++c->depth;
+        else ok = false;
+    }
+    ~EntryGuard() { if (ok && --c->depth == 0) { c->owner = std::thread::id(); c->busy.store(0, std::memory_order_release); } }
+};
+
+// Body of every compute entry of the C-ABI: refuses concurrent use of one context, and no C++ exception crosses the boundary
+// (std::bad_alloc -> CTM_ERR_NOMEM, anything else -> CTM_ERR_HIP with its message in ctm_last_error).
+template <class F>
+int ctm_entry_nolock(ctm_ctx* ctx, const char* name, F&& body) {      // options, statistics, stream sync: callable from any thread
+    if (!ctx) return CTM_ERR_BADARG;
+    try { return body(); }
+    catch (const std::bad_alloc&) { ctx->set_error(std::string(name) + ": host allocation failed (std::bad_alloc)"); return CTM_ERR_NOMEM; }
+    catch (const std::exception& e) { ctx->set_error(std::string(name) + ": C++ exception: " + e.what()); return CTM_ERR_HIP; }
+    catch (...) { ctx->set_error(std::string(name) + ": unknown C++ exception"); return CTM_ERR_HIP; }
+}
+
+template <class F>
+int ctm_entry(ctm_ctx* ctx, const char* name, F&& body) {
+    if (!ctx) return CTM_ERR_BADARG;
+    EntryGuard g(ctx);
+    if (!g.ok) return CTM_ERR_BUSY;       // (last_error belongs to the thread that is inside: not touched)
+    try { return body(); }
+    catch (const std::bad_alloc&) { ctx->set_error(std::string(name) + ": host allocation failed (std::bad_alloc)"); return CTM_ERR_NOMEM; }
+    catch (const std::exception& e) { ctx->set_error(std::string(name) + ": C++ exception: " + e.what()); return CTM_ERR_HIP; }
+    catch (...) { ctx->set_error(std::string(name) + ": unknown C++ exception"); return CTM_ERR_HIP; }
+}
 
 // arena API (ctm_runtime.hip)
 int arena_alloc(ctm_ctx* ctx, size_t bytes, void** out);
 struct ArenaScope {
-    ctm_ctx* c; int cur; size_t top;
-    explicit ArenaScope(ctm_ctx* ctx) : c(ctx), cur(ctx->arena.cur), top(ctx->arena.top) {}
-    ~ArenaScope() { c->arena.cur = cur; c->arena.top = top; }
+    ctm_ctx* c; int cur; size_t top; size_t nguard;
+    explicit ArenaScope(ctm_ctx* ctx) : c(ctx), cur(ctx->arena.cur), top(ctx->arena.top), nguard(ctx->arena.guard_blocks.size()) {}
+    ~ArenaScope() { c->arena.cur = cur; c->arena.top = top; if (c->arena.guard_blocks.size() > nguard) arena_guard_release(c, nguard); }
 };
 
 // event pair around a launch on ctx->stream while "gemm_timing" is on: begin returns the slot (or -1), end files it under `kind`
@@ -222,13 +270,6 @@ struct PhaseTimer {
     }
 };
 
-// RAII around a chip-filling launch: an acquire kernel of the device-wide lock ahead of it and a release kernel behind it, both on
-// the context's own stream.
-struct HeavyScope {
-    ctm_ctx* c; bool on = false;
-    HeavyScope(ctm_ctx* ctx, double flops);
-    ~HeavyScope();
-};
 
 // ---- GEMM (gemm_f64.hip) -----------------------------------------------------------------
 // C(m,n) = alpha * sum_k A(m,k) B(k,n) + beta * C(m,n),  element addresses
@@ -328,4 +369,3 @@ int jacobi_eigh_top(ctm_ctx* ctx, const double* A, int n, int k, double* D, doub
 int jacobi_eigh_top_c(ctm_ctx* ctx, const double* Ar, const double* Ai, int n, int k, double* D, double* Ut, double* warm = nullptr);
 // singular values only, small matrices (corner spectra)
 int jacobi_svdvals(ctm_ctx* ctx, const double* M, const double* Mi /* nullptr: real */, int n, double* S);
-void eigh_orth_state_reset();   // forget the per-workspace state of the orthogonal iteration (option "eigh_orth_iter")

@@ -350,6 +350,7 @@ extern "C" {
 
 int ctm_einsum(ctm_ctx* ctx, const char* expr, int ntensors, const double* const* tensors, const int* ndims, const long long* dims,
                const int* conj, double* out) {
+    return ctm_entry(ctx, "ctm_einsum", [&]() -> int {
     if (!expr || ntensors < 2 || ntensors > 16) { ctx->set_error("einsum: 2..16 operands"); return CTM_ERR_BADARG; }
     const std::string e(expr);
     const size_t arrow = e.find("->");
@@ -386,10 +387,12 @@ int ctm_einsum(ctm_ctx* ctx, const char* expr, int ntensors, const double* const
     ArenaScope work(ctx);
     CTM_TRY(dev_network(ctx, e, ops, &res));
     return io.finish();
+    });
 }
 
 int ctm_c2x2(ctm_ctx* ctx, int corner, int open, const double* C, const double* T1, const double* T2, const double* a,
              int chi, const int* adims, double* out) {
+    return ctm_entry(ctx, "ctm_c2x2", [&]() -> int {
     if (corner < 0 || corner > 3) { ctx->set_error("c2x2: bad corner"); return CTM_ERR_BADARG; }
     PhaseTimer pt(ctx, CTM_T_CORNERS);
     ArenaScope scope(ctx);
@@ -403,9 +406,11 @@ int ctm_c2x2(ctm_ctx* ctx, int corner, int open, const double* C, const double* 
     CTM_TRY(io.out(out, (size_t)(n0 * n1 * pp), &res));
     CTM_TRY(corner_impl(ctx, corner, open, ci.C, ci.T1, ci.T2, ci.a, chi, adims, &res));
     return io.finish();
+    });
 }
 
 int ctm_halves(ctm_ctx* ctx, int dir, const double* const* t, int chi, const int* adims4x5, double* R, double* Rt) {
+    return ctm_entry(ctx, "ctm_halves", [&]() -> int {
     if (dir < 0 || dir > 3) { ctx->set_error("halves: bad direction"); return CTM_ERR_BADARG; }
     ArenaScope scope(ctx);
     IO io(ctx);
@@ -436,14 +441,18 @@ int ctm_halves(ctm_ctx* ctx, int dir, const double* const* t, int chi, const int
         CTM_TRY(xgemm(ctx, (int)M, (int)N, (int)Ka, xm(cA, a1, hs.tA != 0), xm(cB, b1, hs.tB != 0), res.p, res.q, N));
     }
     return io.finish();
+    });
 }
 
 int ctm_truncated_svd(ctm_ctx* ctx, const double* M, int n, int chi, const ctm_trunc_cfg* cfg_, double* U, double* S, double* V) {
+    return ctm_entry(ctx, "ctm_truncated_svd", [&]() -> int {
     return ctm_truncated_svd_ws(ctx, M, n, chi, cfg_, U, S, V, nullptr);
+    });
 }
 
 int ctm_truncated_svd_ws(ctm_ctx* ctx, const double* M, int n, int chi, const ctm_trunc_cfg* cfg_, double* U, double* S, double* V,
                          double* basis) {
+    return ctm_entry(ctx, "ctm_truncated_svd_ws", [&]() -> int {
     const ctm_trunc_cfg cfg = cfg_ ? *cfg_ : kDefaultCfg;
     if (chi < 1 || n < 1) { ctx->set_error("truncated_svd: bad dims"); return CTM_ERR_BADARG; }
     PhaseTimer pt(ctx, CTM_T_SVD);
@@ -468,6 +477,7 @@ int ctm_truncated_svd_ws(ctm_ctx* ctx, const double* M, int n, int chi, const ct
     CTM_TRY(io.finish());
     CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     return CTM_OK;
+    });
 }
 
 namespace {
@@ -476,11 +486,15 @@ int eigh_trunc_planar(ctm_ctx* ctx, const DT& A, int n, int chi, const ctm_trunc
 }
 
 int ctm_truncated_eigh(ctm_ctx* ctx, const double* A, int n, int chi, const ctm_trunc_cfg* cfg_, double* D, double* U) {
+    return ctm_entry(ctx, "ctm_truncated_eigh", [&]() -> int {
     return truncated_eigh_impl(ctx, A, n, chi, cfg_, D, U, nullptr);
+    });
 }
 
 int ctm_truncated_eigh_ws(ctm_ctx* ctx, const double* A, int n, int chi, const ctm_trunc_cfg* cfg_, double* D, double* U, double* basis) {
+    return ctm_entry(ctx, "ctm_truncated_eigh_ws", [&]() -> int {
     return truncated_eigh_impl(ctx, A, n, chi, cfg_, D, U, basis);
+    });
 }
 
 namespace {
@@ -573,6 +587,7 @@ __global__ void symeig_to_svd_kernel(const double* __restrict__ U, const double*
 }
 
 int ctm_svd_symeig(ctm_ctx* ctx, const double* A, int n, int chi, const ctm_trunc_cfg* cfg_, double* U, double* S, double* V) {
+    return ctm_entry(ctx, "ctm_svd_symeig", [&]() -> int {
     ctm_trunc_cfg cfg = cfg_ ? *cfg_ : kDefaultCfg;
     if (!cfg_) { cfg.eps_multiplet = 1.0e-12; cfg.keep_multiplets = 0; }
     if (chi < 1 || n < 1) { ctx->set_error("svd_symeig: bad dims"); return CTM_ERR_BADARG; }
@@ -588,14 +603,17 @@ int ctm_svd_symeig(ctm_ctx* ctx, const double* A, int n, int chi, const ctm_trun
     CTM_HIP_CHECK(ctx, hipGetLastError());
     CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     return CTM_OK;
+    });
 }
 
 int ctm_svdvals(ctm_ctx* ctx, const double* M, int n, double* S) {
+    return ctm_entry(ctx, "ctm_svdvals", [&]() -> int {
     ArenaScope scope(ctx);
     IO io(ctx);
     DT tM;
     CTM_TRY(io.in(M, {n, n}, &tM));
     return jacobi_svdvals(ctx, tM.p, tM.q, n, S);
+    });
 }
 
 namespace {
@@ -614,6 +632,7 @@ int upload_scale(ctm_ctx* ctx, const TruncOut& to, int kc, double reltol, double
 
 int ctm_projectors(ctm_ctx* ctx, const double* R, const double* Rt, int n, int chi, const ctm_trunc_cfg* cfg_, double* P,
                    double* Pt, double* S_out) {
+    return ctm_entry(ctx, "ctm_projectors", [&]() -> int {
     const ctm_trunc_cfg cfg = cfg_ ? *cfg_ : kDefaultCfg;
     if (chi < 1 || n < 1) { ctx->set_error("projectors: bad dims"); return CTM_ERR_BADARG; }
     ArenaScope scope(ctx);
@@ -652,20 +671,26 @@ int ctm_projectors(ctm_ctx* ctx, const double* R, const double* Rt, int n, int c
     CTM_TRY(io.finish());
     CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     return CTM_OK;
+    });
 }
 
 int ctm_projectors_4x4(ctm_ctx* ctx, int dir, const double* const* t, int chi, const int* adims4x5, const ctm_trunc_cfg* cfg_,
                        double* P, double* Pt, double* S_out) {
+    return ctm_entry(ctx, "ctm_projectors_4x4", [&]() -> int {
     return ctm_projectors_4x4_ws(ctx, dir, t, chi, adims4x5, cfg_, P, Pt, S_out, nullptr);
+    });
 }
 
 int ctm_projectors_4x4_ws(ctm_ctx* ctx, int dir, const double* const* t, int chi, const int* adims4x5, const ctm_trunc_cfg* cfg_,
                           double* P, double* Pt, double* S_out, double* basis) {
+    return ctm_entry(ctx, "ctm_projectors_4x4_ws", [&]() -> int {
     return ctm_projectors_4x4_cc(ctx, dir, t, chi, adims4x5, cfg_, P, Pt, S_out, basis, nullptr, nullptr);
+    });
 }
 
 int ctm_projectors_4x4_cc(ctm_ctx* ctx, int dir, const double* const* t, int chi, const int* adims4x5, const ctm_trunc_cfg* cfg_,
                           double* P, double* Pt, double* S_out, double* basis, double* const* corner_buf, const int* corner_valid) {
+    return ctm_entry(ctx, "ctm_projectors_4x4_cc", [&]() -> int {
     const ctm_trunc_cfg cfg = cfg_ ? *cfg_ : kDefaultCfg;
     if (dir < 0 || dir > 3) { ctx->set_error("projectors_4x4: bad direction"); return CTM_ERR_BADARG; }
     ArenaScope scope(ctx);
@@ -751,15 +776,19 @@ int ctm_projectors_4x4_cc(ctm_ctx* ctx, int dir, const double* const* t, int chi
     CTM_TRY(io.finish());
     CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     return CTM_OK;
+    });
 }
 
 int ctm_absorb(ctm_ctx* ctx, int dir, const double* const* t, int chi, const int* ad, int normalize, double* nC1,
                double* nC2, double* nT) {
+    return ctm_entry(ctx, "ctm_absorb", [&]() -> int {
     return ctm_absorb_x(ctx, dir, t, chi, chi, ad, normalize, nC1, nC2, nT);
+    });
 }
 
 int ctm_absorb_x(ctm_ctx* ctx, int dir, const double* const* t, int chi_in, int chi_out, const int* ad, int normalize, double* nC1,
                  double* nC2, double* nT) {
+    return ctm_entry(ctx, "ctm_absorb_x", [&]() -> int {
     if (dir < 0 || dir > 3) { ctx->set_error("absorb: bad direction"); return CTM_ERR_BADARG; }
     const AbsorbSpec& sp = kAbsorb[dir];
     // X: environment dimension of the incoming tensors; Y: dimension of the truncated (new) bond = columns of the projectors.
@@ -810,10 +839,12 @@ int ctm_absorb_x(ctm_ctx* ctx, int dir, const double* const* t, int chi_in, int 
         CTM_TRY(normalize_dt(ctx, r3.view({Y * Y * D2out}), kind));
     }
     return io.finish();
+    });
 }
 
 // ---- C4v -------------------------------------------------------------------------------------------
 int ctm_c2x2_c4v(ctm_ctx* ctx, int open, const double* a, const double* C, const double* T, int chi, int p, int D, double* out) {
+    return ctm_entry(ctx, "ctm_c2x2_c4v", [&]() -> int {
     PhaseTimer pt(ctx, CTM_T_CORNERS);
     ArenaScope scope(ctx);
     IO io(ctx);
@@ -826,20 +857,26 @@ int ctm_c2x2_c4v(ctm_ctx* ctx, int open, const double* a, const double* C, const
     CTM_TRY(dev_network(ctx, open ? "xy,cyuU,xelL,suldr,tULDR->edDcrRst" : "xy,cyuU,xelL,suldr,sULDR->edDcrR",
                         {tC, tT, tT, tA, tA.conj()}, &res));
     return io.finish();
+    });
 }
 
 int ctm_move_c4v(ctm_ctx* ctx, const double* a, const double* C, const double* T, int chi, int p, int D,
                  const ctm_trunc_cfg* cfg_, double* C_out, double* T_out, double* D_out) {
+    return ctm_entry(ctx, "ctm_move_c4v", [&]() -> int {
     return ctm_move_c4v_ws(ctx, a, C, T, chi, p, D, cfg_, C_out, T_out, D_out, nullptr);
+    });
 }
 
 int ctm_move_c4v_ws(ctm_ctx* ctx, const double* a, const double* C, const double* T, int chi, int p, int D,
                     const ctm_trunc_cfg* cfg_, double* C_out, double* T_out, double* D_out, double* basis) {
+    return ctm_entry(ctx, "ctm_move_c4v_ws", [&]() -> int {
     return ctm_move_c4v_x(ctx, a, C, T, chi, p, D, cfg_, 1, C_out, T_out, D_out, basis);
+    });
 }
 
 int ctm_move_c4v_x(ctm_ctx* ctx, const double* a, const double* C, const double* T, int chi, int p, int D,
                    const ctm_trunc_cfg* cfg_, int normalize, double* C_out, double* T_out, double* D_out, double* basis) {
+    return ctm_entry(ctx, "ctm_move_c4v_x", [&]() -> int {
     ctm_trunc_cfg cfg = cfg_ ? *cfg_ : kDefaultCfg;
     if (!cfg_) cfg.eps_multiplet = 1.0e-12;          // custom_eig.py default used by ctmrg_c4v.py:49-52
     const int n = chi * D * D;
@@ -875,14 +912,18 @@ int ctm_move_c4v_x(ctm_ctx* ctx, const double* a, const double* C, const double*
     CTM_TRY(div_by_device_scalar(ctx, rC.p, (size_t)chi * chi, Dv, 1));
     CTM_TRY(normalize_dt(ctx, rT.view({(long long)chi * chi * D * D}), normalize == 2 ? 2 : 1));
     return io.finish();
+    });
 }
 
 // ---- RDMs ------------------------------------------------------------------------------------------
 int ctm_rdm2x2(ctm_ctx* ctx, const double* const* t, int chi, const int* ad4, double* out) {
+    return ctm_entry(ctx, "ctm_rdm2x2", [&]() -> int {
     return ctm_rdm2x2_part(ctx, t, chi, ad4, 0, -1, out);
+    });
 }
 
 int ctm_rdm2x2_part(ctm_ctx* ctx, const double* const* t, int chi, const int* ad4, int lo0, int lo1, double* out) {
+    return ctm_entry(ctx, "ctm_rdm2x2_part", [&]() -> int {
     // rdm.py:1390-1588.  The reference holds the four open corners (n^2 p^2 each) and the two open halves (n^2 p^4 each) at
     // once; here the physical legs are unrolled: the lower half is kept as p^4 slices L[(s2 t2 s3 t3)] (n x n), the upper
     // half is produced one slice U[(s0 t0 s1 t1)] at a time and reduced against all of L immediately, so the peak is
@@ -957,9 +998,11 @@ int ctm_rdm2x2_part(ctm_ctx* ctx, const double* const* t, int chi, const int* ad
     CTM_TRY(permute_f64(ctx, R.p, r.p, 8, dims, perm));
     if (R.q) CTM_TRY(permute_f64(ctx, R.q, r.q, 8, dims, perm));
     return io.finish();
+    });
 }
 
 int ctm_rdm1x1(ctm_ctx* ctx, const double* const* t, int chi, const int* ad, double* out) {
+    return ctm_entry(ctx, "ctm_rdm1x1", [&]() -> int {
     PhaseTimer pt(ctx, CTM_T_RDM);
     ArenaScope scope(ctx);
     IO io(ctx);
@@ -973,9 +1016,11 @@ int ctm_rdm1x1(ctm_ctx* ctx, const double* const* t, int chi, const int* ad, dou
     // left column, then site ket/bra, then right column (every pairwise step is a plain GEMM)
     CTM_TRY(dev_seq_einsum(ctx, "ab,bUVc,aiLM,ih,XYhg,sULXR,tVMYQ,ce,eRQf,fg->st", {C1, T1, T4, C4, T3, A, A.conj(), C2, T2, C3}, &r));
     return io.finish();
+    });
 }
 
 int ctm_rdm2x1(ctm_ctx* ctx, const double* const* t, int chi, const int* ad2, double* out) {
+    return ctm_entry(ctx, "ctm_rdm2x1", [&]() -> int {
     // tensors12: C1,T1a,T4,C4,T3a,a0 (site 0), C2,T2,C3,T1b,T3b,a1 (site 1 = coord+(1,0))
     PhaseTimer pt(ctx, CTM_T_RDM);
     ArenaScope scope(ctx);
@@ -994,9 +1039,11 @@ int ctm_rdm2x1(ctm_ctx* ctx, const double* const* t, int chi, const int* ad2, do
     CTM_TRY(dev_seq_einsum(ctx, "ce,eRQf,fg,jUVc,XYhg,sULXR,tVMYQ->jLMhst", {C2, T2, C3, T1b, T3b, A1, A1.conj()}, &right));
     CTM_TRY(dev_einsum2(ctx, "cRQgst", left, "cRQguv", right, "sutv", &r));
     return io.finish();
+    });
 }
 
 int ctm_rdm1x2(ctm_ctx* ctx, const double* const* t, int chi, const int* ad2, double* out) {
+    return ctm_entry(ctx, "ctm_rdm1x2", [&]() -> int {
     // tensors12: C1,T1,C2,T4a,T2a,a0 (site 0), C4,T3,C3,T4b,T2b,a1 (site 1 = coord+(0,1))
     PhaseTimer pt(ctx, CTM_T_RDM);
     ArenaScope scope(ctx);
@@ -1015,9 +1062,11 @@ int ctm_rdm1x2(ctm_ctx* ctx, const double* const* t, int chi, const int* ad2, do
     CTM_TRY(dev_seq_einsum(ctx, "jh,XYhg,fg,ijLM,eRQf,sULXR,tVMYQ->iUVest", {C4, T3, C3, T4b, T2b, A1, A1.conj()}, &lo));
     CTM_TRY(dev_einsum2(ctx, "iXYfst", up, "iXYfuv", lo, "sutv", &r));
     return io.finish();
+    });
 }
 
 int ctm_rdm_c4v(ctm_ctx* ctx, int which, const double* a, const double* C, const double* T, int chi, int p, int D, double* out) {
+    return ctm_entry(ctx, "ctm_rdm_c4v", [&]() -> int {
     if (which < 0 || which > 3) { ctx->set_error("rdm_c4v: bad selector"); return CTM_ERR_BADARG; }
     PhaseTimer pt(ctx, CTM_T_RDM);
     ArenaScope scope(ctx);
@@ -1076,9 +1125,11 @@ int ctm_rdm_c4v(ctm_ctx* ctx, int which, const double* a, const double* C, const
     int pm[8] = {0, 2, 6, 4, 1, 3, 7, 5};
     CTM_TRY(perm(r8, r, 8, dims, pm));
     return io.finish();
+    });
 }
 
 int ctm_init_piece(ctm_ctx* ctx, int kind, const double* a, const int* ad, double* out) {
+    return ctm_entry(ctx, "ctm_init_piece", [&]() -> int {
     // env.py:367-536: 'mijef,mijab->eafb' etc.  A <- conj(A) pairs; implemented as one GEMM per piece:
     // permute the site so that the traced legs (+ physical) lead, then out[(kept ket),(kept bra)] = X^T X,
     // finally interleave ket/bra legs.
@@ -1109,6 +1160,7 @@ int ctm_init_piece(ctm_ctx* ctx, int kind, const double* a, const int* ad, doubl
     if (G.q) CTM_TRY(permute_f64(ctx, G.q, O.q, 2 * nk, gd, gp));
     CTM_TRY(normalize_dt(ctx, O.view({Mk * Mk})));
     return io.finish();
+    });
 }
 
 }  // extern "C"

@@ -4,6 +4,9 @@
 #include <signal.h>
 #include <unistd.h>
 #include <mutex>
+#include <atomic>
+
+int g_ctm_sync_launch = [] { const char* e = getenv("CTM_SYNC_LAUNCH"); return (e && *e && *e != '0') ? 1 : 0; }();
 
 namespace {
 
@@ -12,7 +15,24 @@ namespace {
 // else the default action).  A Python traceback ends at the ctypes call; this says which frame below it aborted.
 struct sigaction g_prev_abrt, g_prev_segv;
 
+constexpr int LAUNCH_RING = 32;
+const char* g_ring[LAUNCH_RING];
+std::atomic<unsigned> g_ring_pos{0};
+
+void print_launch_ring() {
+    if (!g_ctm_sync_launch) return;
+    static const char head[] = "ctm_hip: last kernel launches of the library (oldest first; CTM_SYNC_LAUNCH=1, so the last one is the one in flight):\n";
+    (void)!write(2, head, sizeof(head) - 1);
+    const unsigned pos = g_ring_pos.load();
+    for (unsigned i = pos >= LAUNCH_RING ? pos - LAUNCH_RING : 0; i < pos; ++i) {
+        const char* s = g_ring[i % LAUNCH_RING];
+        if (!s) continue;
+        (void)!write(2, "  ", 2); (void)!write(2, s, strlen(s)); (void)!write(2, "\n", 1);
+    }
+}
+
 void fatal_backtrace(int sig, siginfo_t*, void*) {
+    print_launch_ring();
     static const char head[] = "ctm_hip: fatal signal -- native stack of the failing thread:\n";
     (void)!write(2, head, sizeof(head) - 1);
     void* frames[96];
@@ -41,8 +61,33 @@ void install_fatal_backtrace() {
 
 }  // namespace
 
+void ctm_note_launch(const char* kernel_name) { g_ring[g_ring_pos.fetch_add(1) % LAUNCH_RING] = kernel_name; }
+
+// CTM_ARENA_GUARD=1 (diagnostic, with tools/guard/guard_malloc.cpp preloaded): every arena allocation is its own hipMalloc of exactly
+// the requested size (16-byte granular), so a kernel that runs past the end of a workspace buffer faults instead of landing in its
+// neighbour on the stack; the blocks of a scope are freed (after a stream sync) when the scope ends.
+int g_ctm_arena_guard = [] { const char* e = getenv("CTM_ARENA_GUARD"); return (e && *e && *e != '0') ? 1 : 0; }();
+
+void arena_guard_release(ctm_ctx* ctx, size_t keep) {
+    (void)hipStreamSynchronize(ctx->stream);
+    Arena& a = ctx->arena;
+    while (a.guard_blocks.size() > keep) { (void)hipFree(a.guard_blocks.back()); a.guard_blocks.pop_back(); }
+}
+
 int arena_alloc(ctm_ctx* ctx, size_t bytes, void** out) {
     Arena& a = ctx->arena;
+    if (g_ctm_arena_guard) {
+        void* p = nullptr;
+        const size_t b = bytes ? (bytes + 15) & ~(size_t)15 : 16;
+        if (hipMalloc(&p, b) != hipSuccess) {
+            (void)hipGetLastError();
+            ctx->set_error("arena (guard mode): hipMalloc of " + std::to_string(b) + " bytes failed");
+            return CTM_ERR_NOMEM;
+        }
+        a.guard_blocks.push_back(p);
+        *out = p;
+        return CTM_OK;
+    }
     bytes = (bytes + 255) & ~(size_t)255;
     if (bytes == 0) bytes = 256;
     if (a.cur >= 0 && a.top + bytes <= a.slabs[a.cur].cap) {
@@ -122,6 +167,7 @@ int ctm_destroy(ctm_ctx* ctx) {
 }
 
 int ctm_trim(ctm_ctx* ctx) {
+    return ctm_entry(ctx, "ctm_trim", [&]() -> int {
     // between calls the arena stack is empty: give every slab back to the device (it regrows on demand)
     if (!ctx) return CTM_OK;
     CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
@@ -130,16 +176,20 @@ int ctm_trim(ctm_ctx* ctx) {
     ctx->arena.slabs.clear();
     ctx->arena.total = 0;
     return CTM_OK;
+    });
 }
 
 const char* ctm_last_error(ctm_ctx* ctx) { return ctx ? ctx->last_error.c_str() : "null context"; }
 
 int ctm_sync(ctm_ctx* ctx) {
+    return ctm_entry_nolock(ctx, "ctm_sync", [&]() -> int {
     CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     return CTM_OK;
+    });
 }
 
 int ctm_set_comm(ctm_ctx* ctx, void* rccl_comm, int rank, int nranks) {
+    return ctm_entry_nolock(ctx, "ctm_set_comm", [&]() -> int {
     if (!ctx) return CTM_ERR_BADARG;
     if (nranks < 1 || rank < 0 || rank >= nranks) { ctx->set_error("set_comm: rank outside [0, nranks)"); return CTM_ERR_BADARG; }
     if (nranks > 1) {
@@ -148,93 +198,57 @@ int ctm_set_comm(ctm_ctx* ctx, void* rccl_comm, int rank, int nranks) {
     }
     ctx->comm = rccl_comm; ctx->comm_rank = rank; ctx->comm_nranks = nranks;      // a one-rank group: every collective is the identity
     return CTM_OK;
+    });
 }
 
 int ctm_set_option(ctm_ctx* ctx, const char* key, double value) {
+    return ctm_entry_nolock(ctx, "ctm_set_option", [&]() -> int {
+    // 37 keys (tests/test_gpu_options.py names every one).  Everything else that used to be settable is a constant of the build: the
+    // tuning parameters keep their measured values as member defaults of ctm_ctx (ctm_common.h), the variants that lost their
+    // measurement (one-launch Jacobi sweep, rotation lists, the device-side lock around chip-filling launches, the LDS-staged two-layer
+    // kernel, 1 / 4 blocks per thread in the 64 x 64 eigensolver) are gone.
     const std::string k(key ? key : "");
+    // -- accuracy / semantics
     if (k == "jacobi_tol") ctx->jacobi_tol = value;
-    else if (k == "svd_null_tol") ctx->svd_null_tol = value;
-    else if (k == "jacobi_tau_relax") ctx->jacobi_tau_relax = (int)value;
-    else if (k == "si_tau_both") ctx->si_tau_both = (int)value;
-    else if (k == "jacobi_gram_kmin") ctx->jacobi_gram_kmin = (int)value;
-    else if (k == "jacobi_gram_kmin_short") ctx->jacobi_gram_kmin_short = (int)value;
     else if (k == "jacobi_max_sweeps") ctx->jacobi_max_sweeps = (int)value;
-    else if (k == "jacobi_block") ctx->jacobi_block = (int)value;
-    else if (k == "jacobi_inner_sweeps") ctx->jacobi_inner_sweeps = (int)value;
-    else if (k == "jacobi_inner_sweeps_many") ctx->jacobi_inner_sweeps_many = (int)value;
-    else if (k == "jacobi_verbose") ctx->jacobi_verbose = (int)value;
-    else if (k == "jacobi_cross_only") ctx->jacobi_cross_only = (int)value;
-    else if (k == "jacobi_rot_apply") ctx->jacobi_rot_apply = (int)value;
-    else if (k == "jacobi_persist") ctx->jacobi_persist = (int)value;
+    else if (k == "svd_null_tol") ctx->svd_null_tol = value;
+    else if (k == "rank_tol") ctx->rank_tol = value;
+    else if (k == "si_tol") ctx->si_tol = value;
+    else if (k == "svd_abs_accuracy") ctx->svd_abs_accuracy = (int)value;
+    else if (k == "svd_polar") ctx->svd_polar = (int)value;
+    // -- which solver / kernel route
     else if (k == "si_enable") ctx->si_enable = value != 0.0;
     else if (k == "si_min_n") ctx->si_min_n = (int)value;
     else if (k == "si_max_iter") ctx->si_max_iter = (int)value;
-    else if (k == "si_tol") ctx->si_tol = value;
-    else if (k == "si_rr_sweeps") ctx->si_rr_sweeps = (int)value;
-    else if (k == "profile") ctx->profile = value != 0.0;
-    else if (k == "use_layer2") ctx->use_layer2 = value != 0.0;
-    else if (k == "layer2_dbg") ctx->layer2_dbg = (int)value;
-    else if (k == "gemm_fast") ctx->gemm_fast = value != 0.0;
-    else if (k == "einsum_in_relayout") ctx->einsum_in_relayout = value != 0.0;
-    else if (k == "z_spectators_first") ctx->z_spectators_first = value != 0.0;
-    else if (k == "chain_as_strips") ctx->chain_as_strips = value != 0.0;
-    else if (k == "proj_from_krylov") ctx->proj_from_krylov = value != 0.0;
-    else if (k == "si_block32") ctx->si_block32 = value != 0.0;
-    else if (k == "si_warm_skip_calls") ctx->si_warm_skip_calls = (int)value;
-    else if (k == "splitk_reduce_vec") ctx->splitk_reduce_vec = (int)value;
-    else if (k == "gemm_log") ctx->gemm_log = value != 0.0;
-    else if (k == "gemm_strip") ctx->gemm_strip = value != 0.0;
-    else if (k == "strip_target_wgs") ctx->strip_target_wgs = (int)value;
-    else if (k == "gemm_split_rem") ctx->gemm_split_rem = value != 0.0;
-    else if (k == "xgemm_stack_rows") ctx->xgemm_stack_rows = value != 0.0;
-    else if (k == "rows_kernel_min_m") ctx->rows_kernel_min_m = (int)value;
-    else if (k == "rows_kernel_min_m_kc") ctx->rows_kernel_min_m_kc = (int)value;
-    else if (k == "rows_target_wgs") ctx->rows_target_wgs = (int)value;
-    else if (k == "rows_min_klen") ctx->rows_min_klen = (int)value;
-    else if (k == "rows_min_klen_hbm") ctx->rows_min_klen_hbm = (int)value;
-    else if (k == "rows_quantise") ctx->rows_quantise = value != 0.0;
-    else if (k == "rows_deep_prefetch") ctx->rows_deep_prefetch = value != 0.0;
-    else if (k == "rows_fused_reduce") ctx->rows_fused_reduce = value != 0.0;
-    else if (k == "heavy_serial") ctx->heavy_serial = value != 0.0;
-    else if (k == "heavy_min_flops") ctx->heavy_min_flops = value;
-    else if (k == "timing_min_flops") ctx->timing_min_flops = value;
-    else if (k == "eigh_warm") ctx->eigh_warm = (int)value;
-    else if (k == "eigh_warm_early_reject") ctx->eigh_warm_early_reject = (int)value;
-    else if (k == "eigh_probe_orth_once") ctx->eigh_probe_orth_once = (int)value;
-    else if (k == "eigh_orth_iter") { ctx->eigh_orth_iter = (int)value; eigh_orth_state_reset(); }
-    else if (k == "eigh_orth_max") ctx->eigh_orth_max = (int)value;
-    else if (k == "eigh_orth_extra_blocks") ctx->eigh_orth_extra_blocks = (int)value;
-    else if (k == "eigh_orth_double") ctx->eigh_orth_double = (int)value;
-    else if (k == "eigh_orth_double_min_ratio") ctx->eigh_orth_double_min_ratio = value;
-    else if (k == "eigh_orth_predict") ctx->eigh_orth_predict = (int)value;
-    else if (k == "eigh_orth_quad_exit") ctx->eigh_orth_quad_exit = value;
-    else if (k == "svd_abs_accuracy") ctx->svd_abs_accuracy = (int)value;
-    else if (k == "lz_abs_accuracy") ctx->lz_abs_accuracy = (int)value;
-    else if (k == "svd_polar") ctx->svd_polar = (int)value;
-    else if (k == "svd_polar_min_n") ctx->svd_polar_min_n = (int)value;
-    else if (k == "splitk_max_tiles") ctx->splitk_max_tiles = (int)value;
-    else if (k == "splitk_target_wgs") ctx->splitk_target_wgs = (int)value;
-    else if (k == "rank_tol") ctx->rank_tol = value;
     else if (k == "lz_enable") ctx->lz_enable = value != 0.0;
     else if (k == "lz_min_k") ctx->lz_min_k = (int)value;
-    else if (k == "lz_switch_steps") ctx->lz_switch_steps = value;
-    else if (k == "lz_first") ctx->lz_first = (int)value;
-    else if (k == "lz_stride") ctx->lz_stride = (int)value;
-    else if (k == "lz_first_factor") ctx->lz_first_factor = value;
-    else if (k == "lz_first_factor32") ctx->lz_first_factor32 = value;
     else if (k == "lz_block") ctx->lz_block = (int)value;
-    else if (k == "lz_block32_min_k") ctx->lz_block32_min_k = (int)value;
     else if (k == "lz_block_c") ctx->lz_block_c = (int)value;
-    else if (k == "lz_verify_op") ctx->lz_verify_op = value != 0.0;
     else if (k == "lz_async") ctx->lz_async = value != 0.0;
-    else if (k == "lz_jacobi_block") ctx->lz_jacobi_block = (int)value;
-    else if (k == "lz_quad_exit") ctx->lz_quad_exit = value;
-    else if (k == "si_quad_exit") ctx->si_quad_exit = value;
     else if (k == "lz_local_project") ctx->lz_local_project = value != 0.0;
-    else if (k == "layer2_cplx") ctx->layer2_cplx = value != 0.0;
-    else if (k == "layer2_reg") ctx->layer2_reg = (int)value;
-    else if (k == "eig64_bpt") ctx->eig64_bpt = (int)value;
-    else if (k == "eig64_pingpong") ctx->eig64_pingpong = value != 0.0;
+    else if (k == "lz_verify_op") ctx->lz_verify_op = value != 0.0;
+    else if (k == "jacobi_cross_only") ctx->jacobi_cross_only = (int)value;
+    else if (k == "eigh_warm") ctx->eigh_warm = (int)value;
+    else if (k == "eigh_orth_iter") ctx->eigh_orth_iter = (int)value;
+    else if (k == "eigh_orth_double") ctx->eigh_orth_double = (int)value;
+    else if (k == "proj_from_krylov") ctx->proj_from_krylov = value != 0.0;
+    else if (k == "use_layer2") ctx->use_layer2 = value != 0.0;
+    else if (k == "gemm_fast") ctx->gemm_fast = value != 0.0;
+    else if (k == "xgemm_stack_rows") ctx->xgemm_stack_rows = value != 0.0;
+    // -- stationary fast path of the implicit-operator truncation (ctm_args.projector_warm_tol)
+    else if (k == "warm_accept_tol") ctx->warm_accept_tol = value;
+    else if (k == "warm_try_factor") ctx->warm_try_factor = value;
+    else if (k == "warm_accept_max_run") ctx->warm_accept_max_run = (int)value;
+    // -- row-block GEMM: the knobs tests/test_gpu_gemm_rows.py needs to reach every epilogue
+    else if (k == "rows_fused_reduce") ctx->rows_fused_reduce = value != 0.0;
+    else if (k == "rows_kernel_min_m") ctx->rows_kernel_min_m = (int)value;
+    else if (k == "rows_kernel_min_m_kc") ctx->rows_kernel_min_m_kc = (int)value;
+    else if (k == "rows_min_klen") ctx->rows_min_klen = (int)value;
+    else if (k == "rows_target_wgs") ctx->rows_target_wgs = (int)value;
+    // -- instrumentation
+    else if (k == "timing_min_flops") ctx->timing_min_flops = value;
+    else if (k == "profile") ctx->profile = value != 0.0;
+    else if (k == "jacobi_verbose") ctx->jacobi_verbose = (int)value;
     else if (k == "gemm_timing") {
         gemm_timing_drain(ctx);
         ctx->gemm_timing = value != 0.0;
@@ -243,9 +257,11 @@ int ctm_set_option(ctm_ctx* ctx, const char* key, double value) {
     }
     else { ctx->set_error("unknown option " + k); return CTM_ERR_BADARG; }
     return CTM_OK;
+    });
 }
 
 int ctm_get_stat(ctm_ctx* ctx, const char* key, double* value) {
+    return ctm_entry_nolock(ctx, "ctm_get_stat", [&]() -> int {
     const std::string k(key ? key : "");
     if (k == "last_sweeps") *value = ctx->last_sweeps;
     else if (k == "last_offnorm") *value = ctx->last_offnorm;
@@ -268,6 +284,9 @@ int ctm_get_stat(ctm_ctx* ctx, const char* key, double* value) {
     else if (k == "svd_eig_completions") *value = (double)ctx->svd_eig_completions;
     else if (k == "svd_polar_solves") *value = (double)ctx->svd_polar_solves;
     else if (k == "lz_hits") *value = (double)ctx->lz_hits;
+    else if (k == "warm_accepts") *value = (double)ctx->warm_accepts;
+    else if (k == "warm_rejects") *value = (double)ctx->warm_rejects;
+    else if (k == "warm_last_dist") *value = ctx->warm_last_dist;
     else if (k == "lz_total_steps") *value = (double)ctx->lz_total_steps;
     else if (k == "lz_total_rows") *value = (double)ctx->lz_total_rows;
     else if (k == "lz_extractions") *value = (double)ctx->lz_extractions;
@@ -294,25 +313,31 @@ int ctm_get_stat(ctm_ctx* ctx, const char* key, double* value) {
     }
     else { ctx->set_error("unknown stat " + k); return CTM_ERR_BADARG; }
     return CTM_OK;
+    });
 }
 
 int ctm_gemm_intervals(ctm_ctx* ctx, double* out, long long capacity, long long* count) {
+    return ctm_entry_nolock(ctx, "ctm_gemm_intervals", [&]() -> int {
     gemm_timing_drain(ctx);
     const long long n = (long long)ctx->intervals.size();
     if (count) *count = n / 4;
     if (out) for (long long i = 0; i < n && i < capacity; ++i) out[i] = ctx->intervals[i];
     return CTM_OK;
+    });
 }
 
 int ctm_timers(ctm_ctx* ctx, double* out8, int reset) {
+    return ctm_entry_nolock(ctx, "ctm_timers", [&]() -> int {
     gemm_timing_drain(ctx);       // event-timed phases are accumulated when their events are read
     for (int i = 0; i < CTM_T_COUNT; ++i) { if (out8) out8[i] = ctx->timers[i]; if (reset) ctx->timers[i] = 0.0; }
     if (reset) { ctx->gemm_flops = 0; ctx->gemm_calls = 0; ctx->layer2_flops = 0; ctx->layer2_calls = 0; ctx->total_sweeps = 0; ctx->jacobi_calls = 0; ctx->si_hits = 0; ctx->si_fallbacks = 0; ctx->si_total_iters = 0; ctx->si_warm_starts = 0; ctx->eigh_warm_hits = 0; ctx->eigh_warm_rejects = 0; ctx->eigh_orth_hits = 0; ctx->eigh_orth_fails = 0; ctx->eigh_orth_doubled = 0; ctx->svd_polar_completions = 0; ctx->svd_eig_completions = 0; ctx->svd_polar_solves = 0; ctx->lz_hits = 0; ctx->lz_total_steps = 0; ctx->lz_total_rows = 0; ctx->lz_extractions = 0; ctx->absorb_bytes = 0; ctx->absorb_calls = 0; }
     return CTM_OK;
+    });
 }
 
 int ctm_gemm(ctm_ctx* ctx, int transA, int transB, int M, int N, int K, double alpha, const double* A, long long lda,
              const double* B, long long ldb, double beta, double* C, long long ldc) {
+    return ctm_entry(ctx, "ctm_gemm", [&]() -> int {
     if (!ctx->cplx) {
         GemmDesc d;
         d.M = M; d.N = N; d.K = K; d.alpha = alpha; d.beta = beta;
@@ -342,18 +367,22 @@ int ctm_gemm(ctm_ctx* ctx, int transA, int transB, int M, int N, int K, double a
         CTM_TRY(div_by_device_scalar(ctx, c, 2 * nc, s, 0));
     }
     return interleave_c128(ctx, c, c + nc, C, nc);
+    });
 }
 
 int ctm_permute(ctm_ctx* ctx, const double* in, double* out, int nd, const long long* dims, const int* perm) {
+    return ctm_entry(ctx, "ctm_permute", [&]() -> int {
     if (!ctx->cplx) return permute_f64(ctx, in, out, nd, dims, perm);
     if (nd + 1 > CTM_MAXD) { ctx->set_error("permute(c128): rank"); return CTM_ERR_UNSUPPORTED; }
     long long d2[CTM_MAXD]; int p2[CTM_MAXD];
     for (int i = 0; i < nd; ++i) { d2[i] = dims[i]; p2[i] = perm[i]; }
     d2[nd] = 2; p2[nd] = nd;                       // the (re,im) pair travels as an innermost axis
     return permute_f64(ctx, in, out, nd + 1, d2, p2);
+    });
 }
 
 int ctm_normalize_inf(ctm_ctx* ctx, double* x, long long n) {
+    return ctm_entry(ctx, "ctm_normalize_inf", [&]() -> int {
     double* s = ctx->d_scratch + 8;
     if (!ctx->cplx) {
         CTM_TRY(absmax_f64(ctx, x, (size_t)n, s));
@@ -365,6 +394,7 @@ int ctm_normalize_inf(ctm_ctx* ctx, double* x, long long n) {
     CTM_TRY(deinterleave_c128(ctx, x, pl, pl + n, (size_t)n));
     CTM_TRY(absmax_c128(ctx, pl, pl + n, (size_t)n, s));
     return div_by_device_scalar(ctx, x, 2 * (size_t)n, s, 0);
+    });
 }
 
 }  // extern "C"

@@ -765,8 +765,8 @@ int gemm_f64(ctm_ctx* ctx, const GemmDesc& d) {
         sp.M = d.M; sp.N = d.N; sp.K = d.K; sp.A = d.A; sp.sam = d.sam; sp.B = d.B; sp.ldb = bnf ? d.sbk : d.sbn; sp.P = part; sp.klen = klen;
         if (fused) { sp.C = d.C; sp.ldc = d.ldc; sp.alpha = d.alpha; sp.beta = d.beta; sp.colscale = d.colscale; sp.cnt = ctx->tile_cnt; sp.ks = ks; }
         else sp.ks = 0;                  // partials only (ks == 1 included): the reduce kernel below finishes
-        HeavyScope heavy(ctx, 2.0 * d.M * d.N * (double)d.K);
         int e0 = timing_begin(ctx);
+        if (g_ctm_sync_launch) ctm_note_launch(rows_kernel ? "gemm_rows_kernel" : "gemm_strip_kernel");
         if (rows_kernel) {
             const bool deep = ctx->rows_deep_prefetch && (long long)(d.N / 128) * ks <= 512;
             if (bnf) launch_rows<true>((d.M + 15) / 16, dim3(d.N / 128, ks), ctx->stream, sp, deep);
@@ -775,6 +775,7 @@ int gemm_f64(ctm_ctx* ctx, const GemmDesc& d) {
         else if (bnf) launch_strip<true>((d.M + 15) / 16, dim3(gx, ks), ctx->stream, sp);
         else launch_strip<false>((d.M + 15) / 16, dim3(gx, ks), ctx->stream, sp);
         hipError_t e = hipGetLastError();
+        if (e == hipSuccess && g_ctm_sync_launch) e = hipStreamSynchronize(ctx->stream);
         if (e != hipSuccess) { ctx->set_error(std::string("strip gemm launch: ") + hipGetErrorString(e)); return CTM_ERR_HIP; }
         const long long tot = (long long)d.M * d.N;
         if (!fused)
@@ -849,7 +850,6 @@ int gemm_f64(ctm_ctx* ctx, const GemmDesc& d) {
             grid.z = (unsigned)ks;
         }
     }
-    HeavyScope heavy(ctx, 2.0 * d.M * d.N * (double)d.K * d.batch);
     int e0 = -1, e1 = -1;
     // event pair only around launches that matter for a roofline (>= timing_min_flops): the 64-tile products of the latency-bound
     // stages are ~90 % of all launches and ~0 % of the flops, and an event pair per launch costs the concurrent units ~10 % of a sweep
@@ -891,62 +891,6 @@ int gemm_f64(ctm_ctx* ctx, const GemmDesc& d) {
     return CTM_OK;
 }
 
-// ---- one chip-filling kernel at a time ------------------------------------------------------------------------------
-// The concurrent units of a move (one stream each) overlap their latency-bound stages; their chip-filling kernels gain nothing from
-// sharing the chip (four corner passes at once each take four times as long and thrash each other's L2 working set).  A device-side
-// lock serialises THOSE kernels only: an acquire kernel (one lane spinning on an agent-scope CAS) ahead of the launch and a release
-// kernel behind it, on the unit's own stream -- no cross-stream events, no host involvement, any free unit goes next.  The spin is
-// bounded (streams multiplexed onto one hardware queue could otherwise deadlock: the release kernel of the owner queued behind the
-// spinning acquire of a waiter): after ~2 ms the waiter proceeds without the lock -- exclusivity is a performance matter only.
-namespace {
-struct HeavyDev { unsigned* lock = nullptr; };
-HeavyDev& heavy_dev(int device, hipStream_t stream) {
-    static std::mutex gm;
-    static std::map<int, HeavyDev*> devs;
-    std::lock_guard<std::mutex> lk(gm);
-    auto it = devs.find(device);
-    if (it != devs.end()) return *it->second;
-    HeavyDev* d = new HeavyDev();
-    // (zeroed on the caller's stream and waited for, see the tile counters)
-    if (hipMalloc((void**)&d->lock, 256) != hipSuccess || hipMemsetAsync(d->lock, 0, 256, stream) != hipSuccess ||
-        hipStreamSynchronize(stream) != hipSuccess) d->lock = nullptr;
-    devs[device] = d;
-    return *d;
-}
-__global__ void heavy_acquire_kernel(unsigned* lock, unsigned id) {
-    if (threadIdx.x != 0) return;
-    const long long t0 = wall_clock64();                       // 100 MHz
-    for (;;) {
-        unsigned expect = 0u;
-        if (__hip_atomic_compare_exchange_strong(lock, &expect, id, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
-        if (wall_clock64() - t0 > 200000) return;              // 2 ms: go ahead without the lock
-        __builtin_amdgcn_s_sleep(64);
-    }
-}
-__global__ void heavy_release_kernel(unsigned* lock, unsigned id) {
-    if (threadIdx.x != 0) return;
-    unsigned expect = id;
-    (void)__hip_atomic_compare_exchange_strong(lock, &expect, 0u, __ATOMIC_RELEASE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // only the owner unlocks
-}
-std::atomic<unsigned> g_ctx_ids{0};
-}  // namespace
-
-HeavyScope::HeavyScope(ctm_ctx* ctx, double flops) : c(ctx) {
-    if (!ctx->heavy_serial || flops < ctx->heavy_min_flops || ctx->in_heavy) return;
-    HeavyDev& hd = heavy_dev(ctx->device, ctx->stream);
-    if (!hd.lock) return;
-    if (ctx->heavy_id == 0) ctx->heavy_id = ++g_ctx_ids;
-    hipLaunchKernelGGL(heavy_acquire_kernel, dim3(1), dim3(64), 0, ctx->stream, hd.lock, ctx->heavy_id);
-    ctx->in_heavy = true; on = true;
-}
-
-HeavyScope::~HeavyScope() {
-    if (!on) return;
-    HeavyDev& hd = heavy_dev(c->device, c->stream);
-    hipLaunchKernelGGL(heavy_release_kernel, dim3(1), dim3(64), 0, c->stream, hd.lock, c->heavy_id);
-    c->in_heavy = false;
-    c->heavy_launches += 1;
-}
 
 int timing_begin(ctm_ctx* ctx) {
     if (!ctx->gemm_timing) return -1;

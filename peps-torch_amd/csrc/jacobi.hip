@@ -50,8 +50,6 @@ struct SmallEigParams {
     unsigned long long* stat_abs;   // max |g_ij| / sqrt(g_ii g_jj) (classical measure, diagnostics only)
     int* flags;          // per pair: 1 if J != I (the apply GEMM skips the others)
     int cross = 0;       // small_eig64_kernel: 1 = rotate only the 32 x 32 pairs (row of panel 0, row of panel 1), 32 rounds instead of 63
-    double* rot = nullptr;   // small_eig64_kernel<.., true>: per pair 63 x 32 rotations (c, s) of the ONE pass, instead of the accumulated J
-    int* perm = nullptr;     // ... and the final position of every row (eigenvalues descending)
 };
 
 // floor of the pair measure: with `both`, a pair that contains a row at or above the floor is measured relative to its own rows only
@@ -294,15 +292,12 @@ __device__ __forceinline__ void jacobi_cs(double a, double b, double g, double t
     }
 }
 
-// NOJ: the eigenvector matrix is not accumulated (half of the LDS traffic of a round: the kernel is LDS-bandwidth bound, 143 KB per round
-// against 128 B/clk); the (c, s) of every rotation of the ONE pass go to p.rot and the final row order to p.perm, and
-// rot_apply64_kernel applies the sequence to the panel rows -- the same arithmetic as X <- J^T X, done on the vector ALUs, one column per lane.
-template <int BPT, bool NOJ = false, bool CROSS = false>     // 2x2 blocks per thread: 1024 / BPT threads per workgroup; CROSS: cross-pair rounds (compile time: a
+template <int BPT, bool CROSS = false>     // 2x2 blocks per thread: 1024 / BPT threads per workgroup; CROSS: cross-pair rounds (compile time: a
 // run-time choice of the pairing inside the round loop cost 10 % of the kernel -- 600 -> 1130 clocks of address arithmetic + LDS loads per round)
 __global__ __launch_bounds__(1024 / BPT) void small_eig64_kernel(SmallEigParams p) {
     constexpr int M = 64, H = 32, NTH = 1024 / BPT, NW = NTH / 64, KS = H / BPT, EPT = (M * M) / NTH;
     __shared__ double Wb[2][M][M + 1];
-    __shared__ double Jm[NOJ ? 1 : M][M + 1];
+    __shared__ double Jm[M][M + 1];
     __shared__ double red[16];
     __shared__ int rot_flag;
     __shared__ int rank_of[M];
@@ -319,7 +314,7 @@ __global__ __launch_bounds__(1024 / BPT) void small_eig64_kernel(SmallEigParams 
             for (int u = 0; u < EPT; ++u) acc[u] += Gs[tid + u * NTH];
         }
 #pragma unroll
-        for (int u = 0; u < EPT; ++u) { const int q = tid + u * NTH, r = q >> 6, c = q & 63; Wb[0][r][c] = acc[u]; if (!NOJ) Jm[r][c] = (r == c) ? 1.0 : 0.0; }
+        for (int u = 0; u < EPT; ++u) { const int q = tid + u * NTH, r = q >> 6, c = q & 63; Wb[0][r][c] = acc[u]; Jm[r][c] = (r == c) ? 1.0 : 0.0; }
     }
     __syncthreads();
     {
@@ -384,14 +379,13 @@ __global__ __launch_bounds__(1024 / BPT) void small_eig64_kernel(SmallEigParams 
                 const int k1 = kb + u * KS;
                 if (cross) cross_pair64(r, k1, p1[u], q1[u]); else rr_pair64(r, k1, p1[u], q1[u]);
                 b00[u] = S[p1[u]][p2]; b01[u] = S[p1[u]][q2]; b10[u] = S[q1[u]][p2]; b11[u] = S[q1[u]][q2];
-                if (!NOJ) { jp0[u] = Jm[k1][p2]; jq0[u] = Jm[k1][q2]; jp1[u] = Jm[k1 + 32][p2]; jq1[u] = Jm[k1 + 32][q2]; }
+                jp0[u] = Jm[k1][p2]; jq0[u] = Jm[k1][q2]; jp1[u] = Jm[k1 + 32][p2]; jq1[u] = Jm[k1 + 32][q2];
             }
 #ifdef CTM_KERNEL_CLOCKS
             __builtin_amdgcn_s_waitcnt(0); const long long c1 = clock64();
 #endif
             double c2, s2; bool r2;
             jacobi_cs(a2, d2, g2, p.tol, p.tau2, p.tau_both, c2, s2, r2);
-            if (NOJ && tid < H) { double* ro = p.rot + ((size_t)blockIdx.x * (M - 1) + r) * (2 * H); ro[2 * k2] = c2; ro[2 * k2 + 1] = s2; }
 #ifdef CTM_KERNEL_CLOCKS
             __builtin_amdgcn_sched_barrier(0); const long long c2k = clock64(); __builtin_amdgcn_sched_barrier(0);
 #endif
@@ -405,7 +399,7 @@ __global__ __launch_bounds__(1024 / BPT) void small_eig64_kernel(SmallEigParams 
                 const double t10 = c2 * b10[u] - s2 * b11[u], t11 = s2 * b10[u] + c2 * b11[u];
                 D[p1[u]][p2] = c1 * t00 - s1 * t10; D[p1[u]][q2] = c1 * t01 - s1 * t11;
                 D[q1[u]][p2] = s1 * t00 + c1 * t10; D[q1[u]][q2] = s1 * t01 + c1 * t11;
-                if (!NOJ && r2) {
+                if (r2) {
                     Jm[k1][p2] = c2 * jp0[u] - s2 * jq0[u]; Jm[k1][q2] = s2 * jp0[u] + c2 * jq0[u];
                     Jm[k1 + 32][p2] = c2 * jp1[u] - s2 * jq1[u]; Jm[k1 + 32][q2] = s2 * jp1[u] + c2 * jq1[u];
                 }
@@ -438,313 +432,8 @@ __global__ __launch_bounds__(1024 / BPT) void small_eig64_kernel(SmallEigParams 
         rank_of[tid] = rk;
     }
     __syncthreads();
-    if (NOJ) { if (tid < M) p.perm[(size_t)blockIdx.x * M + tid] = rank_of[tid]; return; }
 #pragma unroll
     for (int u = 0; u < EPT; ++u) { const int q = tid + u * NTH, r = q >> 6, c = q & 63; Jout[r * M + rank_of[c]] = Jm[r][c]; }
-}
-
-// The rotations of one pass of small_eig64_kernel<.., true> applied to the 64 rows of a panel pair, in place: lane = one column, its 64
-// values in registers (the schedule is static, the loops unroll completely), (c, s) of a rotation are wave-uniform (scalar loads).
-// Row update of X <- J^T X for J = R_1 R_2 ...: x_p <- c x_p - s x_q, x_q <- s x_p + c x_q, in the order the kernel rotated; then row c
-// moves to position perm[c].  CROSS: the 32-round cross schedule (cross_pair64), else the 63-round round robin (rr_pair64).
-template <bool CROSS>
-__global__ __launch_bounds__(256) void rot_apply64_kernel(double* __restrict__ X, long long ld, int cols, const GemmOff* __restrict__ offs,
-                                                          const double* __restrict__ rot, const int* __restrict__ perm, const int* __restrict__ flags) {
-    constexpr int M = 64, H = 32;
-    const int pair = blockIdx.y;
-    if (flags[pair] == 0) return;
-    const int col = blockIdx.x * blockDim.x + threadIdx.x;
-    if (col >= cols) return;
-    const GemmOff o = offs[pair];
-    double* r0 = X + o.b0 + col;
-    double* r1 = X + o.b1 + col;
-    const double* ro = rot + (size_t)pair * (M - 1) * (2 * H);
-    const int* pm = perm + (size_t)pair * M;
-    // The schedule of a round is a FIXED pattern of register positions when the rows travel through the registers instead (the round
-    // loop then need not unroll: 63 x 32 rotations exceed the unroll budget, and a rolled loop with computed row indices would put the
-    // column into scratch memory):
-    //   round robin -- w[i] holds row (i + r) mod 63, row 63 stays in f: the pairs of round r are (f, w[0]) and (w[k], w[63 - k]);
-    //   cross       -- u[j] holds row 32 + (j + r) mod 32: the pairs are (v[k], u[k]);  one register rotation per round.
-    if (CROSS) {
-        double v[H], u[H];
-#pragma unroll
-        for (int i = 0; i < H; ++i) { v[i] = r0[(long long)i * ld]; u[i] = r1[(long long)i * ld]; }
-#pragma unroll 1
-        for (int r = 0; r < H; ++r) {
-            const double* cs = ro + (size_t)r * (2 * H);
-#pragma unroll
-            for (int k = 0; k < H; ++k) {
-                const double c = cs[2 * k], s = cs[2 * k + 1];
-                const double xp = v[k], xq = u[k];
-                v[k] = c * xp - s * xq; u[k] = s * xp + c * xq;
-            }
-            const double t = u[0];
-#pragma unroll
-            for (int i = 0; i + 1 < H; ++i) u[i] = u[i + 1];
-            u[H - 1] = t;
-        }
-        // after 32 rotations of the registers u[j] holds row 32 + j again
-#pragma unroll
-        for (int i = 0; i < H; ++i) {
-            const int d0 = pm[i], d1 = pm[H + i];                 // (uniform)
-            *(d0 < H ? r0 + (long long)d0 * ld : r1 + (long long)(d0 - H) * ld) = v[i];
-            *(d1 < H ? r0 + (long long)d1 * ld : r1 + (long long)(d1 - H) * ld) = u[i];
-        }
-        return;
-    }
-    double w[M - 1], f;
-#pragma unroll
-    for (int i = 0; i < M - 1; ++i) w[i] = i < H ? r0[(long long)i * ld] : r1[(long long)(i - H) * ld];
-    f = r1[(long long)(H - 1) * ld];
-#pragma unroll 1
-    for (int r = 0; r < M - 1; ++r) {
-        const double* cs = ro + (size_t)r * (2 * H);
-        {   // slot 0: rows (r, 63), r < 63: p = w[0], q = f
-            const double c = cs[0], s = cs[1];
-            const double xp = w[0], xq = f;
-            w[0] = c * xp - s * xq; f = s * xp + c * xq;
-        }
-#pragma unroll
-        for (int k = 1; k < H; ++k) {
-            // rows a = (r + k) mod 63 in w[k], b = (r - k) mod 63 in w[63 - k]; the recorded (c, s) belong to (p, q) = (min, max)
-            int a = r + k; a = (a >= 63) ? a - 63 : a;
-            int b = r - k + 63; b = (b >= 63) ? b - 63 : b;
-            const double c = cs[2 * k], s0 = cs[2 * k + 1];
-            const double s = a < b ? s0 : -s0;                   // (uniform)
-            const double xa = w[k], xb = w[M - 1 - k];
-            w[k] = c * xa - s * xb; w[M - 1 - k] = s * xa + c * xb;
-        }
-        const double t = w[0];
-#pragma unroll
-        for (int i = 0; i + 1 < M - 1; ++i) w[i] = w[i + 1];
-        w[M - 2] = t;
-    }
-    // after 63 rotations of the registers w[i] holds row i again
-#pragma unroll
-    for (int i = 0; i < M - 1; ++i) {
-        const int d = pm[i];                                      // (uniform)
-        *(d < H ? r0 + (long long)d * ld : r1 + (long long)(d - H) * ld) = w[i];
-    }
-    { const int d = pm[M - 1]; *(d < H ? r0 + (long long)d * ld : r1 + (long long)(d - H) * ld) = f; }
-}
-
-// ---------------------------------------------------------------------------------------------
-// One whole SWEEP of the many-panel one-sided block Jacobi in ONE launch (real, 32-row panels, 64 x 64 pair problems).
-// The classic driver (jacobi_rows) issues three dependent launches per round -- batched pair Grams, the LDS eigensolver, the batched
-// apply -- i.e. ~60 per sweep of a Ritz matrix with their launch gaps: the extraction of the block Krylov solver is the one latency-bound
-// stage a move's barrier still waits for.  Here pairs x S workgroups stay resident for the sweep: workgroup (pair, slice) computes the
-// partial Gram of its slice of the Gram columns on the matrix cores, the S workgroups of a pair meet at a counter, each sums the S
-// partials and runs the (same) LDS eigensolver pass redundantly, applies J^T to its slice of ALL columns on the matrix cores, and all
-// workgroups meet at a second counter before the panels are re-paired.  Counters: agent-scope release / acquire around a relaxed
-// atomic (the split-K recipe of gemm_f64.hip); every spin is bounded (1 s) and raises an abort word the host turns into an error --
-// the grid must be co-resident (pairs x S <= 64 workgroups: four units in flight fit the 256 CUs together).
-// ---------------------------------------------------------------------------------------------
-struct SweepParams {
-    double* X; long long ld; int Cg, Ctot, pairs, S, rounds;
-    const int* tab;              // [rounds][pairs][2]: panels (i < j) of every pair of every round
-    double* Gp;                  // [pairs][S][64 x 64] partial Grams
-    unsigned* bar;               // [0] all workgroups, [1 + pair] the workgroups of a pair, [1 + pairs] abort; zeroed before the launch
-    double tol, tau2; int tau_both, cross;
-    unsigned long long* stat_rel; unsigned long long* stat_abs;
-};
-
-__device__ __forceinline__ bool sweep_barrier(unsigned* cnt, unsigned target, unsigned* abort_word, int tid, int* abort_s) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const long long t0 = wall_clock64();                   // 100 MHz
-        int ab = 0;
-        while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-            if (__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { ab = 1; break; }
-            if (wall_clock64() - t0 > 100000000ll) { __hip_atomic_store(abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ab = 1; break; }
-            __builtin_amdgcn_s_sleep(8);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        *abort_s = ab;
-    }
-    __syncthreads();
-    return *abort_s == 0;
-}
-
-__global__ __launch_bounds__(512) void jacobi_sweep_kernel(SweepParams p) {
-    constexpr int M = 64, H = 32, NTH = 512, NW = 8, KS = 16, EPT = 8, BPT = 2;
-    __shared__ double Wb[2][M][M + 1];
-    __shared__ double Jm[M][M + 1];
-    __shared__ double red[16];
-    __shared__ int rot_flag, abort_s;
-    __shared__ int rank_of[M];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, lk = lane >> 4;
-    const int pair = blockIdx.x / p.S, sl = blockIdx.x % p.S, nwg = p.pairs * p.S;
-    const int cgs = (((p.Cg + p.S - 1) / p.S) + 15) / 16 * 16, cts = (((p.Ctot + p.S - 1) / p.S) + 15) / 16 * 16;
-    const int g0 = min(p.Cg, sl * cgs), g1 = min(p.Cg, g0 + cgs), a0 = min(p.Ctot, sl * cts), a1 = min(p.Ctot, a0 + cts);
-    double (*St)[M + 1] = Wb[0];                  // staging image of phases 1 and 3
-    double* Gmine = p.Gp + ((size_t)pair * p.S + sl) * M * M;
-    const int k2 = tid & 31, kb = tid >> 5;
-    for (int r = 0; r < p.rounds; ++r) {
-        const int pi = p.tab[((size_t)r * p.pairs + pair) * 2], pj = p.tab[((size_t)r * p.pairs + pair) * 2 + 1];
-        double* Pi = p.X + (size_t)pi * H * p.ld;
-        double* Pj = p.X + (size_t)pj * H * p.ld;
-        auto rowp = [&](int row) { return row < H ? Pi + (size_t)row * p.ld : Pj + (size_t)(row - H) * p.ld; };
-        // ---- phase 1: partial Gram of my slice of the Gram columns.  Wave w owns the 16 x 16 tiles 2w, 2w + 1 of the 4 x 4 tile grid
-        d4 acc[2];
-        acc[0] = (d4){0., 0., 0., 0.}; acc[1] = (d4){0., 0., 0., 0.};
-        {
-            double pre[EPT];                          // the next 64-column chunk travels in registers while this one is multiplied
-            auto fetch = [&](int c0, int lim) {
-#pragma unroll
-                for (int e = 0; e < EPT; ++e) { const int q = tid + e * NTH, row = q >> 6, col = q & 63; pre[e] = (c0 + col < lim) ? rowp(row)[c0 + col] : 0.0; }
-            };
-            if (g0 < g1) fetch(g0, g1);
-            for (int c0 = g0; c0 < g1; c0 += M) {
-#pragma unroll
-                for (int e = 0; e < EPT; ++e) { const int q = tid + e * NTH; St[q & 63][q >> 6] = pre[e]; }          // k-major image: St[k][row]
-                __syncthreads();
-                if (c0 + M < g1) fetch(c0 + M, g1);
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const int t = wave * 2 + u, tr = t >> 2, tc = t & 3;
-#pragma unroll
-                    for (int k4 = 0; k4 < M / 4; ++k4) {
-                        const int kr = k4 * 4 + lk;
-                        acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(St[kr][tr * 16 + lr], St[kr][tc * 16 + lr], acc[u], 0, 0, 0);
-                    }
-                }
-                __syncthreads();
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int t = wave * 2 + u, tr = t >> 2, tc = t & 3;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) Gmine[(tr * 16 + lk + 4 * q) * M + tc * 16 + lr] = acc[u][q];
-        }
-        if (!sweep_barrier(p.bar + 1 + pair, (unsigned)(p.S * (r + 1)), p.bar + 1 + p.pairs, tid, &abort_s)) return;
-        // ---- phase 2: the pair's Gram (sum of the S partials, fixed order) and ONE eigensolver pass, redundantly in every workgroup of the pair
-        {
-            const double* G0 = p.Gp + (size_t)pair * p.S * M * M;
-#pragma unroll
-            for (int e = 0; e < EPT; ++e) {
-                const int q = tid + e * NTH;
-                double v = 0.0;
-                for (int s2 = 0; s2 < p.S; ++s2) v += G0[(size_t)s2 * M * M + q];
-                Wb[0][q >> 6][q & 63] = v; Jm[q >> 6][q & 63] = ((q >> 6) == (q & 63)) ? 1.0 : 0.0;
-            }
-        }
-        if (tid == 0) rot_flag = 0;
-        __syncthreads();
-        double srel = 0.0, sabs = 0.0;
-#pragma unroll
-        for (int e = 0; e < EPT; ++e) {
-            const int q = tid + e * NTH, rr = q >> 6, c = q & 63;
-            if (rr < c) {
-                const double g = fabs(Wb[0][rr][c]), a = Wb[0][rr][rr], b = Wb[0][c][c];
-                if (g > 0.0) {
-                    const double sc = sqrt(fabs(a * b));
-                    srel = fmax(srel, g / fmax(sc, tau_floor(a, b, p.tau2, p.tau_both)));
-                    if (sc > 0.0) sabs = fmax(sabs, g / sc);
-                }
-            }
-        }
-        for (int off = 32; off > 0; off >>= 1) { srel = fmax(srel, __shfl_down(srel, off, 64)); sabs = fmax(sabs, __shfl_down(sabs, off, 64)); }
-        if (lane == 0) { red[wave] = srel; red[8 + wave] = sabs; }
-        __syncthreads();
-        if (tid == 0) {
-            double v = 0.0, w = 0.0;
-            for (int q = 0; q < NW; ++q) { v = fmax(v, red[q]); w = fmax(w, red[8 + q]); }
-            if (sl == 0) { atomicMax(p.stat_rel, (unsigned long long)__double_as_longlong(v)); atomicMax(p.stat_abs, (unsigned long long)__double_as_longlong(w)); }
-            red[0] = v;
-        }
-        __syncthreads();
-        const bool active = red[0] > p.tol;                   // (uniform over the workgroup AND over the S workgroups of the pair: same Gram, same arithmetic)
-        if (active) {
-            int par = 0;
-            // (the pairing as a compile-time choice: decided inside the round loop it costs the eigensolver 10 %)
-            auto rounds_of = [&](auto CR) {
-                constexpr bool cross = decltype(CR)::value;
-                constexpr int nr = cross ? H : M - 1;
-                for (int rd = 0; rd < nr; ++rd) {
-                    const double (*Sr)[M + 1] = Wb[par];
-                    double (*D)[M + 1] = Wb[par ^ 1];
-                    int p2, q2;
-                    if (cross) cross_pair64(rd, k2, p2, q2); else rr_pair64(rd, k2, p2, q2);
-                    const double a2 = Sr[p2][p2], d2 = Sr[q2][q2], g2 = Sr[p2][q2];
-                    int p1[BPT], q1[BPT];
-                    double b00[BPT], b01[BPT], b10[BPT], b11[BPT], jp0[BPT], jq0[BPT], jp1[BPT], jq1[BPT];
-    #pragma unroll
-                    for (int u = 0; u < BPT; ++u) {
-                        const int k1 = kb + u * KS;
-                        if (cross) cross_pair64(rd, k1, p1[u], q1[u]); else rr_pair64(rd, k1, p1[u], q1[u]);
-                        b00[u] = Sr[p1[u]][p2]; b01[u] = Sr[p1[u]][q2]; b10[u] = Sr[q1[u]][p2]; b11[u] = Sr[q1[u]][q2];
-                        jp0[u] = Jm[k1][p2]; jq0[u] = Jm[k1][q2]; jp1[u] = Jm[k1 + 32][p2]; jq1[u] = Jm[k1 + 32][q2];
-                    }
-                    double c2, s2; bool r2;
-                    jacobi_cs(a2, d2, g2, p.tol, p.tau2, p.tau_both, c2, s2, r2);
-    #pragma unroll
-                    for (int u = 0; u < BPT; ++u) {
-                        const int k1 = kb + u * KS;
-                        const int src = (tid & 32) | k1;
-                        const double c1 = __shfl(c2, src, 64), s1 = __shfl(s2, src, 64);
-                        const double t00 = c2 * b00[u] - s2 * b01[u], t01 = s2 * b00[u] + c2 * b01[u];
-                        const double t10 = c2 * b10[u] - s2 * b11[u], t11 = s2 * b10[u] + c2 * b11[u];
-                        D[p1[u]][p2] = c1 * t00 - s1 * t10; D[p1[u]][q2] = c1 * t01 - s1 * t11;
-                        D[q1[u]][p2] = s1 * t00 + c1 * t10; D[q1[u]][q2] = s1 * t01 + c1 * t11;
-                        if (r2) {
-                            Jm[k1][p2] = c2 * jp0[u] - s2 * jq0[u]; Jm[k1][q2] = s2 * jp0[u] + c2 * jq0[u];
-                            Jm[k1 + 32][p2] = c2 * jp1[u] - s2 * jq1[u]; Jm[k1 + 32][q2] = s2 * jp1[u] + c2 * jq1[u];
-                        }
-                    }
-                    par ^= 1;
-                    __syncthreads();
-                }
-            };
-            if (p.cross && r > 0) rounds_of(std::true_type{}); else rounds_of(std::false_type{});
-            if (tid < M) {
-                const double d = Wb[par][tid][tid];
-                int rk = 0;
-                for (int j = 0; j < M; ++j) { const double dj = Wb[par][j][j]; rk += (dj > d) || (dj == d && j < tid); }
-                rank_of[tid] = rk;
-            }
-            __syncthreads();
-            // Js[k][o] = J[k][c] with o = rank_of[c] (rows of the pair re-ordered by eigenvalue), kept in Wb[1]; Wb[0] is the staging image again
-#pragma unroll
-            for (int e = 0; e < EPT; ++e) { const int q = tid + e * NTH, k = q >> 6, c = q & 63; Wb[1][k][rank_of[c]] = Jm[k][c]; }
-            __syncthreads();
-            // ---- phase 3: X_pair[:, my slice] <- Js^T X_pair[:, my slice], 64 columns at a time (the chunk is in LDS before anything is written)
-            {
-                double pre[EPT];
-                auto fetch = [&](int c0) {
-#pragma unroll
-                    for (int e = 0; e < EPT; ++e) { const int q = tid + e * NTH, row = q >> 6, col = q & 63; pre[e] = (c0 + col < a1) ? rowp(row)[c0 + col] : 0.0; }
-                };
-                if (a0 < a1) fetch(a0);
-                for (int c0 = a0; c0 < a1; c0 += M) {
-#pragma unroll
-                    for (int e = 0; e < EPT; ++e) { const int q = tid + e * NTH; St[q >> 6][q & 63] = pre[e]; }      // St[k = old row][col]
-                    __syncthreads();
-                    if (c0 + M < a1) fetch(c0 + M);                  // (columns of the NEXT chunk: nobody writes them before they are in registers)
-#pragma unroll
-                    for (int u = 0; u < 2; ++u) {
-                        const int t = wave * 2 + u, to = t >> 2, tc = t & 3;
-                        d4 o4 = (d4){0., 0., 0., 0.};
-#pragma unroll
-                        for (int k4 = 0; k4 < M / 4; ++k4) {
-                            const int kr = k4 * 4 + lk;
-                            o4 = __builtin_amdgcn_mfma_f64_16x16x4f64(Wb[1][kr][to * 16 + lr], St[kr][tc * 16 + lr], o4, 0, 0, 0);
-                        }
-                        const int col = c0 + tc * 16 + lr;
-                        if (col < a1) {
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) rowp(to * 16 + lk + 4 * q)[col] = o4[q];
-                        }
-                    }
-                    __syncthreads();
-                }
-            }
-        }
-        if (!sweep_barrier(p.bar, (unsigned)(nwg * (r + 1)), p.bar + 1 + p.pairs, tid, &abort_s)) return;
-    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1000,19 +689,6 @@ int jacobi_rows(ctm_ctx* ctx, double* X, int R, long long ld, int Cg, int Ctot, 
     CTM_TRY(arena_alloc(ctx, sizeof(double) * pairs * m * m, (void**)&J));
     CTM_TRY(arena_alloc(ctx, sizeof(double) * R, (void**)&norms));
     CTM_TRY(arena_alloc(ctx, sizeof(int) * pairs, (void**)&flags));
-    // one launch per sweep (jacobi_sweep_kernel) for the many-panel real problems with one eigensolver pass per visit
-    const bool persist = ctx->jacobi_persist && !cplx && m == 64 && b == 32 && pairs >= 4 && ctx->jacobi_inner_sweeps_many == 1 && ctx->eig64_pingpong && !ctx->jacobi_rot_apply;
-    const int pS = persist ? std::max(2, std::min(8, 56 / pairs)) : 0;
-    double* Gp = nullptr; unsigned* bar = nullptr;
-    if (persist && pairs * pS <= 64) {
-        CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)pairs * pS * m * m, (void**)&Gp));
-        CTM_TRY(arena_alloc(ctx, sizeof(unsigned) * (pairs + 2), (void**)&bar));
-    }
-    double* rot = nullptr; int* perm = nullptr;
-    if (ctx->jacobi_rot_apply && !cplx && m == 64 && pairs >= 4) {
-        CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)pairs * 63 * 64, (void**)&rot));
-        CTM_TRY(arena_alloc(ctx, sizeof(int) * (size_t)pairs * 64, (void**)&perm));
-    }
     unsigned long long* stat = (unsigned long long*)ctx->d_scratch;   // [0]=scaled, [1]=classical
     std::vector<double> h(R);
     const double floor2 = (1e-14 * fro) * (1e-14 * fro);
@@ -1052,16 +728,7 @@ int jacobi_rows(ctm_ctx* ctx, double* X, int R, long long ld, int Cg, int Ctot, 
             tau2 = *std::max_element(h.begin(), h.begin() + R); abs_mode = true;
         }
         CTM_HIP_CHECK(ctx, hipMemsetAsync(stat, 0, 2 * sizeof(double), ctx->stream));
-        if (Gp) {
-            SweepParams wp;
-            wp.X = X; wp.ld = ld; wp.Cg = Cg; wp.Ctot = Ctot; wp.pairs = pairs; wp.S = pS; wp.rounds = rounds; wp.tab = T->d_pairs; wp.Gp = Gp; wp.bar = bar;
-            wp.tol = ctx->jacobi_tol * 0.1; wp.tau2 = tau2; wp.tau_both = abs_mode ? 2 : (tau_both ? 1 : 0); wp.cross = ctx->jacobi_cross_only ? 1 : 0;
-            wp.stat_rel = stat; wp.stat_abs = stat + 1;
-            CTM_HIP_CHECK(ctx, hipMemsetAsync(bar, 0, sizeof(unsigned) * (pairs + 2), ctx->stream));
-            CTM_LAUNCH(ctx, jacobi_sweep_kernel, dim3(pairs * pS), dim3(512), 0, wp);
-            CTM_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_scratch + 4, bar + 1 + pairs, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
-        }
-        for (int r = 0; r < (Gp ? 0 : rounds); ++r) {
+        for (int r = 0; r < rounds; ++r) {
             GemmDesc g;
             g.M = m; g.N = m; g.K = Cg;
             g.A = X; g.sam = ld; g.sak = 1; g.splitA = b;
@@ -1074,25 +741,11 @@ int jacobi_rows(ctm_ctx* ctx, double* X, int R, long long ld, int Cg, int Ctot, 
             sp.tau2 = tau2; sp.tau_both = abs_mode ? 2 : (tau_both ? 1 : 0); sp.stat_rel = stat; sp.stat_abs = stat + 1; sp.flags = flags;
             // cross-only rotations in every round but the first of a sweep (which pairs every panel once and solves the full 64 x 64
             // problems: the intra-panel pairs); many-panel problems only (the dense SVD of a Ritz matrix, full-block Rayleigh-Ritz)
-            sp.cross = (ctx->jacobi_cross_only && !cplx && m == 64 && ctx->eig64_pingpong && ctx->eig64_bpt == 2 && pairs >= 4 && r > 0) ? 1 : 0;
-            // many-panel real problems with ONE inner pass per visit: the eigensolver records its rotations instead of accumulating J, and the
-            // panel rows are rotated on the vector ALUs (rot_apply64_kernel) -- no J in LDS (the eigensolver is LDS-bandwidth bound), no apply GEMM
-            const bool use_rot = ctx->jacobi_rot_apply && !cplx && m == 64 && ctx->eig64_pingpong && sp.max_sweeps == 1 && rot != nullptr;
-            if (use_rot) {
-                sp.rot = rot; sp.perm = perm;
-                if (sp.cross) CTM_LAUNCH(ctx, (small_eig64_kernel<2, true, true>), dim3(pairs), dim3(512), 0, sp);
-                else CTM_LAUNCH(ctx, (small_eig64_kernel<2, true, false>), dim3(pairs), dim3(512), 0, sp);
-                const dim3 grid((Ctot + 255) / 256, pairs);
-                if (sp.cross) CTM_LAUNCH(ctx, rot_apply64_kernel<true>, grid, dim3(256), 0, X, ld, Ctot, (const GemmOff*)(T->d_apply + (size_t)r * pairs), (const double*)rot, (const int*)perm, (const int*)flags);
-                else CTM_LAUNCH(ctx, rot_apply64_kernel<false>, grid, dim3(256), 0, X, ld, Ctot, (const GemmOff*)(T->d_apply + (size_t)r * pairs), (const double*)rot, (const int*)perm, (const int*)flags);
-                continue;
-            }
+            sp.cross = (ctx->jacobi_cross_only && !cplx && m == 64 && pairs >= 4 && r > 0) ? 1 : 0;
             if (cplx) CTM_LAUNCH(ctx, small_eig_c_kernel, dim3(pairs), dim3(256), 0, sp);
-            else if (m == 64 && ctx->eig64_pingpong) {
-                if (ctx->eig64_bpt == 4) CTM_LAUNCH(ctx, small_eig64_kernel<4>, dim3(pairs), dim3(256), 0, sp);
-                else if (ctx->eig64_bpt == 2 && sp.cross) CTM_LAUNCH(ctx, (small_eig64_kernel<2, false, true>), dim3(pairs), dim3(512), 0, sp);
-                else if (ctx->eig64_bpt == 2) CTM_LAUNCH(ctx, small_eig64_kernel<2>, dim3(pairs), dim3(512), 0, sp);
-                else CTM_LAUNCH(ctx, small_eig64_kernel<1>, dim3(pairs), dim3(1024), 0, sp);
+            else if (m == 64) {
+                if (sp.cross) CTM_LAUNCH(ctx, (small_eig64_kernel<2, true>), dim3(pairs), dim3(512), 0, sp);
+                else CTM_LAUNCH(ctx, small_eig64_kernel<2>, dim3(pairs), dim3(512), 0, sp);
             }
             else if (m > 32) CTM_LAUNCH(ctx, small_eig_kernel<64>, dim3(pairs), dim3(1024), 0, sp);
             else CTM_LAUNCH(ctx, small_eig_kernel<32>, dim3(pairs), dim3(256), 0, sp);
@@ -1106,10 +759,6 @@ int jacobi_rows(ctm_ctx* ctx, double* X, int R, long long ld, int Cg, int Ctot, 
         }
         CTM_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_scratch, stat, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-        if (Gp && *reinterpret_cast<unsigned*>(ctx->h_scratch + 4) != 0u) {
-            ctx->set_error("jacobi: a barrier of the one-launch sweep timed out (workgroups not co-resident?)");
-            return CTM_ERR_HIP;
-        }
         const double srel = ctx->h_scratch[0];
         ctx->last_sweeps = sweep + 1;
         ctx->last_offnorm = srel;
@@ -1517,7 +1166,12 @@ int matop_apply(ctm_ctx* ctx, const MatOp& op, bool transpose, const double* B, 
 // [1] block steps of the last accepted Krylov solve, [2] its residual estimate / s_0, [3] consecutive warm probes that were handed
 // to the Krylov solver (each one quadruples the distance to the next probe: a full-rank environment at its rounding floor, where the
 // previous basis stays ~1e-10 away from the new operator for ever, otherwise pays two half steps on k + k/2 rows every few sweeps)
-enum { HDR_SKIP = 0, HDR_STEPS = 1, HDR_EST = 2, HDR_FAILS = 3, HDR_BLOCK = 4, HDR_WORDS = 5 };      // (HDR_BLOCK: block size the remembered step count belongs to)
+enum { HDR_SKIP = 0, HDR_STEPS = 1, HDR_EST = 2, HDR_FAILS = 3, HDR_BLOCK = 4,      // (HDR_BLOCK: block size the remembered step count belongs to)
+       // stationary fast path (svd_stationary, option "warm_accept_tol"): [5] how far the previous basis lay outside the subspace of the last
+       // solve (or the residual / s_0 the last accepted Rayleigh-Ritz measured), 0 = unknown; [6] which side the workspace rows hold
+       // (0: right vectors, 1: left vectors); [7] accepted Rayleigh-Ritz calls since the last full solve; [8] calls left that do not try
+       // the fast path after a rejection; [9] consecutive rejections
+       HDR_DIST = 5, HDR_SIDE = 6, HDR_RUN = 7, HDR_SSKIP = 8, HDR_SFAILS = 9, HDR_WORDS = 10 };
 
 inline int warm_skip_calls(const ctm_ctx* ctx, double r) {
     const int need = (int)std::ceil(2.0 * std::log(std::max(r, 1e-9) / 1e-9) / std::log(5.0)) - 1;
@@ -2595,7 +2249,7 @@ int svd_lanczos(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* Ut, dou
     // accepted last time is tried first (one less when it passed with orders of magnitude to spare); cold, the first look
     // comes when the basis holds lz_first_factor * k rows; after a failed look the next one is placed where the observed (or a
     // typical) contraction of the residual estimate predicts convergence.
-    double hdr[HDR_WORDS] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    double hdr[HDR_WORDS] = {0.0};
     if (op.warm_hdr) {
         CTM_HIP_CHECK(ctx, hipMemcpyAsync(hdr, op.warm_hdr, sizeof(hdr), hipMemcpyDeviceToHost, ctx->stream));
         CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
@@ -2685,12 +2339,9 @@ int svd_lanczos(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* Ut, dou
         CTM_TRY(gemm_f64(ctx, ge));
         const bool save = ctx->si_enable; ctx->si_enable = false;
         ctx->force_abs = ctx->lz_abs_accuracy != 0;
-        const int save_b = ctx->jacobi_block;
-        if (ctx->lz_jacobi_block > 0) ctx->jacobi_block = ctx->lz_jacobi_block;      // panel height of the dense SVD of the Ritz matrix
         ctx->jacobi_quad_exit = ctx->lz_quad_exit;
         const int st = svd_full(ctx, T, m, kq, Ss, Xt, Yt);                      // rows of Xt / Yt: x_i^T, y_i^T
         ctx->jacobi_quad_exit = 0.0;
-        ctx->jacobi_block = save_b;
         ctx->force_abs = false;
         ctx->si_enable = save;
         CTM_TRY(st);
@@ -2994,7 +2645,7 @@ int svd_lanczos_c(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* Ut, d
     auto Wr = [&](int j) { CRows r{Wraw + (size_t)j * bn, Wraw + planeU + (size_t)j * bn}; return r; };
     const double tol = resid_tol(ctx, n);
     // scheduling of the Ritz extractions: see svd_lanczos()
-    double hdr[HDR_WORDS] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    double hdr[HDR_WORDS] = {0.0};
     if (op.warm_hdr) {
         CTM_HIP_CHECK(ctx, hipMemcpyAsync(hdr, op.warm_hdr, sizeof(hdr), hipMemcpyDeviceToHost, ctx->stream));
         CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
@@ -3142,6 +2793,139 @@ int svd_lanczos_c(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* Ut, d
 
 }  // namespace
 
+
+// ---------------------------------------------------------------------------------------------
+// Stationary environments (option "warm_accept_tol" > 0; ctm_args.projector_warm_tol on the host side).  Once a run has converged the
+// operator of a unit changes by ~1e-10 s_0 from sweep to sweep -- its own rounding floor: projectors carry S^-1/2 of values down to
+// 1e-8 s_0 -- and a cold block Krylov solve to 6e-14 s_0 resolves the operator far below the noise it carries.  This path takes the
+// previous row basis W (k rows of ONE side), completes it with pseudo-random guard rows, and does ONE Rayleigh-Ritz half step:
+//   C = W op(M)  ->  one-sided Jacobi on the rows of [C | W | W half-way]  ->  fresh side F = rows / |rows|, s = |rows|, W' = rotated W
+// (the relation W' op(M) = s F holds by construction), then verifies the other relation with one application on the k leading rows,
+// |F op(M)^T - s W'| <= warm_accept_tol s_0, and returns (F, s, W') or nothing.  The half-way products of the two applications are
+// u_i^T R^T and v_i^T Rt^T, so the projectors need no further corner passes.  The workspace keeps the FRESH side (HDR_SIDE says which):
+// successive calls alternate sides, i.e. they are the half steps of a subspace iteration that follows the slowly moving operator.
+// 8 corner passes on ~k + 64 / k rows and one Rayleigh-Ritz instead of ~170 passes of 32 rows and the dense SVD of the Ritz matrix.
+// The residual certifies singular triplets, not that they are the largest: the caller re-solves from scratch every
+// "warm_accept_max_run" accepted calls, and whenever the residual test fails.
+// ---------------------------------------------------------------------------------------------
+int svd_stationary(ctm_ctx* ctx, const MatOp& op, int k, int side0, double* S, double* Ut, double* Vt, bool* accepted, double* resid_rel) {
+    *accepted = false; *resid_rel = 0.0;
+    const int n = op.n, b = 32;
+    const int p = ((k + 8 + 63) / 64) * 64;
+    if (p >= n / 2 || op.M || !op.warm) return CTM_OK;
+    const bool want_mid = op.out_uR && op.out_vRt && op.have_mid;
+    ArenaScope scope(ctx);
+    const long long ld = (want_mid ? 3LL : 2LL) * n;
+    double *X, *B0, *M1 = nullptr, *norms, *inv, *res, *F, *G0, *M0 = nullptr, *C2, *M2 = nullptr, *dS;
+    int* d_idx;
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)p * ld, (void**)&X));
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)p * n, (void**)&B0));
+    if (want_mid) CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)p * n, (void**)&M1));
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * p, (void**)&norms));
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * p, (void**)&inv));
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * p, (void**)&res));
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * p, (void**)&dS));
+    CTM_TRY(arena_alloc(ctx, sizeof(int) * p, (void**)&d_idx));
+    // start block: the previous rows and guard rows in their orthogonal complement
+    CTM_TRY(copy2d(ctx, op.warm, n, B0, n, k, n));
+    {
+        double* Rn = B0 + (size_t)k * n;
+        const int pr = p - k;
+        CTM_LAUNCH(ctx, hash_fill_kernel, dim3(1024), dim3(256), 0, Rn, pr, n, (long long)n, 0x7e57ab1eULL + (unsigned long long)ctx->warm_accepts);
+        ArenaScope ws(ctx);
+        double* Gw;
+        CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)pr * k, (void**)&Gw));
+        GemmDesc g1; g1.M = pr; g1.N = k; g1.K = n; g1.A = Rn; g1.sam = n; g1.sak = 1; g1.B = B0; g1.sbk = 1; g1.sbn = n; g1.C = Gw; g1.ldc = k;
+        CTM_TRY(gemm_f64(ctx, g1));
+        GemmDesc g2; g2.M = pr; g2.N = n; g2.K = k; g2.A = Gw; g2.sam = k; g2.sak = 1; g2.B = B0; g2.sbk = n; g2.sbn = 1; g2.C = Rn; g2.ldc = n;
+        g2.alpha = -1.0; g2.beta = 1.0;
+        CTM_TRY(gemm_f64(ctx, g2));
+    }
+    // first application: side0 == 0: W = right vectors, C = W M^T (fresh side: left); side0 == 1: W = left vectors, C = W M
+    CTM_TRY(matop_apply(ctx, op, side0 == 0, B0, n, p, X, ld, M1));
+    CTM_TRY(copy2d(ctx, B0, n, X + n, ld, p, n));
+    if (want_mid) CTM_TRY(copy2d(ctx, M1, n, X + 2 * (size_t)n, ld, p, n));
+    std::vector<double> h(p, 0.0);
+    int st;
+    const double fro = host_fro(ctx, X, p, n, ld, norms, h, &st);
+    CTM_TRY(st);
+    if (!(fro > 0.0)) return CTM_OK;
+    ctx->jacobi_quad_exit = ctx->si_quad_exit;
+    const int st_rr = jacobi_rows(ctx, X, p, ld, n, (int)ld, b, std::min(k, p - 1), fro, ctx->si_rr_sweeps, false, ctx->si_tau_both != 0);
+    ctx->jacobi_quad_exit = 0.0;
+    CTM_TRY(st_rr);
+    CTM_TRY(row_norms(ctx, X, p, n, ld, norms));
+    CTM_HIP_CHECK(ctx, hipMemcpyAsync(h.data(), norms, sizeof(double) * p, hipMemcpyDeviceToHost, ctx->stream));
+    CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    std::vector<int> idx(p); std::iota(idx.begin(), idx.end(), 0);
+    std::stable_sort(idx.begin(), idx.end(), [&](int a, int c) { return h[a] > h[c]; });
+    const double s0 = h[idx[0]];
+    int kv = 0;
+    while (kv < k && h[idx[kv]] > ctx->rank_tol * s0) ++kv;
+    if (kv < k || !(s0 > 0.0)) return CTM_OK;                 // numerically low rank inside the block: the regular route is the cheap one there
+    std::vector<double> hs(k), hinv(k);
+    for (int i = 0; i < k; ++i) { hs[i] = h[idx[i]]; hinv[i] = 1.0 / hs[i]; }
+    CTM_HIP_CHECK(ctx, hipMemcpyAsync(d_idx, idx.data(), sizeof(int) * k, hipMemcpyHostToDevice, ctx->stream));
+    CTM_HIP_CHECK(ctx, hipMemcpyAsync(dS, hs.data(), sizeof(double) * k, hipMemcpyHostToDevice, ctx->stream));
+    CTM_HIP_CHECK(ctx, hipMemcpyAsync(inv, hinv.data(), sizeof(double) * k, hipMemcpyHostToDevice, ctx->stream));
+    CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    // sorted leading k: fresh rows (normalised), rotated start rows, rotated half-way products
+    double* fresh = side0 == 0 ? Ut : Vt;
+    double* kept = side0 == 0 ? Vt : Ut;
+    F = fresh; G0 = kept;
+    CTM_TRY(gather_rows(ctx, X, ld, d_idx, k, n, F, n, inv));
+    CTM_TRY(gather_rows(ctx, X + n, ld, d_idx, k, n, G0, n, nullptr));
+    if (want_mid) {
+        M0 = side0 == 0 ? op.out_vRt : op.out_uR;            // W Rt^T (W = V) resp. W R^T (W = U), rotated with W
+        M2 = side0 == 0 ? op.out_uR : op.out_vRt;
+        CTM_TRY(gather_rows(ctx, X + 2 * (size_t)n, ld, d_idx, k, n, M0, n, nullptr));
+    }
+    // second application, on the k fresh rows: the relation that does not hold by construction
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)k * n, (void**)&C2));
+    CTM_TRY(matop_apply(ctx, op, side0 != 0, F, n, k, C2, n, M2));
+    CTM_LAUNCH(ctx, resid_rows_kernel, dim3((k + 3) / 4), dim3(256), 0, C2, (long long)n, G0, (long long)n, dS, k, n, res);
+    std::vector<double> hr(k);
+    CTM_HIP_CHECK(ctx, hipMemcpyAsync(hr.data(), res, sizeof(double) * k, hipMemcpyDeviceToHost, ctx->stream));
+    CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    const double worst = *std::max_element(hr.begin(), hr.end());
+    *resid_rel = worst / s0;
+    if (ctx->jacobi_verbose) fprintf(stderr, "[stat] n=%d k=%d p=%d side %d  residual/s0 = %.3e (accept <= %.1e), %d Jacobi sweeps\n", n, k, p, side0, worst / s0, ctx->warm_accept_tol, ctx->last_sweeps);
+    if (!(worst <= ctx->warm_accept_tol * s0)) return CTM_OK;
+    CTM_HIP_CHECK(ctx, hipMemcpyAsync(S, dS, sizeof(double) * k, hipMemcpyDeviceToDevice, ctx->stream));
+    if (want_mid) *op.have_mid = true;
+    // the workspace keeps the fresh side
+    CTM_HIP_CHECK(ctx, hipMemcpyAsync(op.warm, F, sizeof(double) * (size_t)k * n, hipMemcpyDeviceToDevice, ctx->stream));
+    CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    *accepted = true;
+    return CTM_OK;
+}
+
+// How far the rows of `old_rows` (kd x n, orthonormal if valid) lie outside the span of the orthonormal rows `new_rows` (k x n):
+// |W - (W X^T) X|_F / sqrt(kd); 0 when the old rows are not a basis (a fresh workspace).
+int subspace_distance(ctm_ctx* ctx, const double* old_rows, int kd, const double* new_rows, int k, int n, double* dist) {
+    *dist = 0.0;
+    ArenaScope scope(ctx);
+    double *G, *R, *nr;
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)kd * k, (void**)&G));
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)kd * n, (void**)&R));
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * 2 * (size_t)kd, (void**)&nr));
+    CTM_TRY(row_norms(ctx, old_rows, kd, n, n, nr));
+    GemmDesc g1; g1.M = kd; g1.N = k; g1.K = n; g1.A = old_rows; g1.sam = n; g1.sak = 1; g1.B = new_rows; g1.sbk = 1; g1.sbn = n; g1.C = G; g1.ldc = k;
+    CTM_TRY(gemm_f64(ctx, g1));
+    CTM_TRY(copy2d(ctx, old_rows, n, R, n, kd, n));
+    GemmDesc g2; g2.M = kd; g2.N = n; g2.K = k; g2.A = G; g2.sam = k; g2.sak = 1; g2.B = new_rows; g2.sbk = n; g2.sbn = 1; g2.C = R; g2.ldc = n;
+    g2.alpha = -1.0; g2.beta = 1.0;
+    CTM_TRY(gemm_f64(ctx, g2));
+    CTM_TRY(row_norms(ctx, R, kd, n, n, nr + kd));
+    std::vector<double> h(2 * (size_t)kd);
+    CTM_HIP_CHECK(ctx, hipMemcpyAsync(h.data(), nr, sizeof(double) * 2 * kd, hipMemcpyDeviceToHost, ctx->stream));
+    CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    double r2 = 0.0;
+    for (int i = 0; i < kd; ++i) { if (std::fabs(h[i] - 1.0) > 1e-6) return CTM_OK; r2 += h[kd + i] * h[kd + i]; }
+    *dist = std::max(std::sqrt(r2 / kd), 1e-300);
+    return CTM_OK;
+}
+
 int jacobi_svd_top_op(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* Ut, double* Vt) {
     const int n = op.n;
     if (n <= 0 || k <= 0 || k > n) { ctx->set_error("jacobi_svd_top: bad n/k"); return CTM_ERR_BADARG; }
@@ -3149,6 +2933,21 @@ int jacobi_svd_top_op(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* U
     auto keep_warm = [&]() -> int {     // the right row factor is the next call's starting basis
         if (op.warm && Vt) CTM_HIP_CHECK(ctx, hipMemcpyAsync(op.warm, Vt, sizeof(double) * wz * (size_t)k * n, hipMemcpyDeviceToDevice, ctx->stream));
         return CTM_OK;
+    };
+    // after a full solve: with the stationary fast path enabled measure how far the previous basis was from this solve's (decides whether
+    // the next call tries the fast path); the workspace then holds RIGHT vectors again
+    double hdr[HDR_WORDS] = {0.0};
+    auto keep_warm_dist = [&](const double* hdr_old) -> int {
+        if (op.warm && op.warm_hdr && !op.M && !(op.Mi || op.ci[0]) && (ctx->warm_accept_tol > 0.0 || hdr_old[HDR_SIDE] >= 1.0)) {
+            double dist = 0.0;
+            const int kd = std::max(1, k - 8);           // (the last few rows sit at the truncation boundary: nearly degenerate neighbours swap freely)
+            if (ctx->warm_accept_tol > 0.0) CTM_TRY(subspace_distance(ctx, op.warm, kd, hdr_old[HDR_SIDE] >= 1.0 ? Ut : Vt, k, n, &dist));
+            const double w[5] = {dist, 0.0, 0.0, hdr_old[HDR_SSKIP], hdr_old[HDR_SFAILS]};     // HDR_DIST, HDR_SIDE, HDR_RUN, HDR_SSKIP, HDR_SFAILS
+            CTM_HIP_CHECK(ctx, hipMemcpyAsync(op.warm_hdr + HDR_DIST, w, sizeof(w), hipMemcpyHostToDevice, ctx->stream));
+            CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+            ctx->warm_last_dist = dist;
+        }
+        return keep_warm();
     };
     if (op.Mi || op.ci[0]) {        // complex128
         if (Ut && Vt && ctx->si_enable && k < n && n >= ctx->si_min_n) {
@@ -3211,23 +3010,48 @@ int jacobi_svd_top_op(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* U
         if (op.warm_hdr && ctx->lz_enable && k >= ctx->lz_min_k) {
             // a unit whose last solve needed the Krylov solver and whose warm probe is not due yet goes there directly (no
             // 64-row rank probe either); if that should fail the regular path below starts cold
-            double hdr[HDR_WORDS];
             CTM_HIP_CHECK(ctx, hipMemcpyAsync(hdr, op.warm_hdr, sizeof(hdr), hipMemcpyDeviceToHost, ctx->stream));
             CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+            if (ctx->warm_accept_tol > 0.0 && op.warm && !op.M && hdr[HDR_STEPS] >= 1.0) {
+                // stationary fast path: one Rayleigh-Ritz half step from the previous basis when the last solve found it close
+                if (hdr[HDR_SSKIP] >= 1.0) { hdr[HDR_SSKIP] -= 1.0; CTM_TRY(fill_f64(ctx, op.warm_hdr + HDR_SSKIP, 1, hdr[HDR_SSKIP])); }
+                else if (hdr[HDR_DIST] > 0.0 && hdr[HDR_DIST] <= ctx->warm_try_factor * ctx->warm_accept_tol &&
+                         (ctx->warm_accept_max_run <= 0 || hdr[HDR_RUN] < ctx->warm_accept_max_run)) {
+                    bool acc = false; double rr = 0.0;
+                    CTM_TRY(svd_stationary(ctx, op, k, hdr[HDR_SIDE] >= 1.0 ? 1 : 0, S, Ut, Vt, &acc, &rr));
+                    if (acc) {
+                        const double w[5] = {std::max(rr, 1e-300), hdr[HDR_SIDE] >= 1.0 ? 0.0 : 1.0, hdr[HDR_RUN] + 1.0, 0.0, 0.0};
+                        CTM_HIP_CHECK(ctx, hipMemcpyAsync(op.warm_hdr + HDR_DIST, w, sizeof(w), hipMemcpyHostToDevice, ctx->stream));
+                        CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+                        ctx->warm_accepts += 1; ctx->warm_last_dist = rr;
+                        return CTM_OK;
+                    }
+                    // refused: the full solve below; the next attempts back off (x2 per consecutive refusal)
+                    ctx->warm_rejects += 1;
+                    hdr[HDR_SFAILS] = std::min(hdr[HDR_SFAILS] + 1.0, 6.0);
+                    hdr[HDR_SSKIP] = std::ldexp(1.0, (int)hdr[HDR_SFAILS]) - 1.0;
+                    if (op.have_mid) *op.have_mid = false;
+                }
+            }
+            if (hdr[HDR_SIDE] >= 1.0) {
+                // the workspace holds LEFT vectors (kept by the fast path): the regular warm starts below expect right vectors
+                op1.warm = nullptr; op1.warm_hdr = nullptr;
+                if (hdr[HDR_SKIP] < 1.0) hdr[HDR_SKIP] = 1.0;
+            }
             if (hdr[HDR_SKIP] >= 1.0 && hdr[HDR_STEPS] >= 1.0) {
                 CTM_TRY(fill_f64(ctx, op.warm_hdr, 1, hdr[HDR_SKIP] - 1.0)); ctx->si_warm_skips += 1;
                 ctx->lz_last_resid = 1.0;
                 CTM_TRY(svd_lanczos(ctx, op, k, S, Ut, Vt, &ok));
-                if (ok) return keep_warm();
+                if (ok) return keep_warm_dist(hdr);
                 op1.warm = nullptr; op1.warm_hdr = nullptr;
             }
         }
         CTM_TRY(svd_iter(ctx, op1, k, S, Ut, Vt, &ok, &krylov));
-        if (ok) { ctx->si_hits += 1; return keep_warm(); }
+        if (ok) { ctx->si_hits += 1; return keep_warm_dist(hdr); }
         if (krylov) {
             ctx->lz_last_resid = 1.0;
             CTM_TRY(svd_lanczos(ctx, op, k, S, Ut, Vt, &ok));
-            if (ok) return keep_warm();
+            if (ok) return keep_warm_dist(hdr);
             // not accepted: finish with the subspace iteration (no further switching), started from the Ritz vectors when the
             // Krylov solve got close (their residual only missed the acceptance threshold by rounding)
             MatOp op2 = op;
@@ -3239,7 +3063,7 @@ int jacobi_svd_top_op(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* U
                 op2.warm = w2;
             }
             CTM_TRY(svd_iter(ctx, op2, k, S, Ut, Vt, &ok, nullptr));
-            if (ok) { ctx->si_hits += 1; return keep_warm(); }
+            if (ok) { ctx->si_hits += 1; return keep_warm_dist(hdr); }
         }
         ctx->si_fallbacks += 1;
     }
@@ -3256,7 +3080,7 @@ int jacobi_svd_top_op(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* U
     CTM_TRY(set_identity(ctx, I, n, n));
     CTM_TRY(matop_apply(ctx, op, false, I, n, n, M, n));
     CTM_TRY(svd_full(ctx, M, n, k, S, Ut, Vt));
-    return keep_warm();
+    return keep_warm_dist(hdr);
 }
 
 int jacobi_svd_top(ctm_ctx* ctx, const double* M, int n, int k, double* S, double* Ut, double* Vt) {
@@ -3358,24 +3182,37 @@ __global__ void embed_rows_kernel(const double* __restrict__ re, const double* _
 // x + iy) of eigh_warm_verify_c: only the keep-the-vectors route is taken (a rotation inside the doubly degenerate real spectrum
 // would not come back as complex vectors), the workspace is not written and D receives all kk Rayleigh quotients.
 // Adaptive state of the orthogonal iteration (contraction rate of the last accepted solve, back-off after a flat spectrum): a property
-// of the PROBLEM, i.e. of the caller's warm workspace -- contexts are shared by problems and handed to units dynamically, so the state is
-// keyed by the workspace pointer (process-wide), not kept on the context.
-struct OrthState { double rate = 0.0; int skip = 0, backoff = 0; bool rows_seen_valid = false; double theta_k = 0.0, theta_0 = 0.0, c_ratio = 0.0; };     // (rows_seen_valid: see eigh_warm_verify; theta: last kept / largest |Ritz value| of the last accepted look; c_ratio: contraction per application of the last UNSHIFTED solve)
-static std::mutex g_orth_mutex;
-static std::map<const double*, OrthState> g_orth_state;
-static OrthState orth_state_get(const double* ws) { std::lock_guard<std::mutex> l(g_orth_mutex); auto it = g_orth_state.find(ws); return it == g_orth_state.end() ? OrthState() : it->second; }
-static void orth_state_put(const double* ws, const OrthState& st) {
-    std::lock_guard<std::mutex> l(g_orth_mutex);
-    if (g_orth_state.size() > 4096) g_orth_state.clear();          // (workspaces come and go with the environments that own them)
-    g_orth_state[ws] = st;
+// of the PROBLEM, i.e. of the caller's warm workspace -- contexts are shared by problems and handed to units dynamically.  It lives in
+// the workspace's own header row (the n doubles behind its vectors, include/ctm_hip.h): it is born zero with the workspace and dies
+// with it (rounds 3-4 kept it in a process-wide map keyed by the workspace ADDRESS, which a new allocation at the same address
+// inherited).  eigh_warm_verify reads it with its first device->host copies (no extra synchronisation) into ctx->orth_cur; a change is
+// written back by one tiny launch.
+struct OrthState { double rate = 0.0; int skip = 0, backoff = 0; double theta_k = 0.0, theta_0 = 0.0, c_ratio = 0.0; };     // (theta: last kept / largest |Ritz value| of the last accepted look; c_ratio: contraction per application of the last UNSHIFTED solve)
+constexpr int ORTH_HDR_WORDS = 6;
+__global__ void set_words6_kernel(double* dst, double a0, double a1, double a2, double a3, double a4, double a5) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) { dst[0] = a0; dst[1] = a1; dst[2] = a2; dst[3] = a3; dst[4] = a4; dst[5] = a5; }
 }
-void eigh_orth_state_reset() { std::lock_guard<std::mutex> l(g_orth_mutex); g_orth_state.clear(); }
+static OrthState& orth_cur(ctm_ctx* ctx) { return *reinterpret_cast<OrthState*>(ctx->orth_cur_storage); }
+static_assert(sizeof(OrthState) <= sizeof(((ctm_ctx*)nullptr)->orth_cur_storage), "ctm_ctx::orth_cur_storage too small");
+static OrthState orth_state_get(ctm_ctx* ctx) { return orth_cur(ctx); }
+static void orth_state_load(ctm_ctx* ctx, const double* w) {          // w: the ORTH_HDR_WORDS doubles of a header row (host), or nullptr
+    OrthState os;
+    if (w) { os.rate = w[0]; os.skip = (int)w[1]; os.backoff = (int)w[2]; os.theta_k = w[3]; os.theta_0 = w[4]; os.c_ratio = w[5]; }
+    if (!(os.rate >= 0.0 && os.rate <= 1.0) || os.skip < 0 || os.skip > 4096 || os.backoff < 0 || os.backoff > 4096) os = OrthState();   // (not a state: a foreign header)
+    orth_cur(ctx) = os;
+}
+static int orth_state_put(ctm_ctx* ctx, double* hdr, const OrthState& os) {
+    orth_cur(ctx) = os;
+    if (hdr) CTM_LAUNCH(ctx, set_words6_kernel, dim3(1), dim3(64), 0, hdr, os.rate, (double)os.skip, (double)os.backoff, os.theta_k, os.theta_0, os.c_ratio);
+    return CTM_OK;
+}
 
 static int eigh_warm_verify(ctm_ctx* ctx, const double* As, int n, int kk, int k_out, double* warm, double* D, double* Ut, bool* accepted,
-                            bool embedded = false, bool* norms_ok = nullptr, double* moved = nullptr) {
+                            bool embedded = false, bool* norms_ok = nullptr, double* moved = nullptr, const double* state_hdr = nullptr) {
     *accepted = false;
     if (norms_ok) *norms_ok = false;
     if (moved) *moved = 0.0;
+    orth_state_load(ctx, nullptr);
     if (kk > n / 4 || kk < 2) return CTM_OK;
     ArenaScope scope(ctx);
     const int pb = 64;
@@ -3383,20 +3220,11 @@ static int eigh_warm_verify(ctm_ctx* ctx, const double* As, int n, int kk, int k
     CTM_TRY(arena_alloc(ctx, sizeof(double) * std::max(kk, pb), (void**)&norms));
     CTM_TRY(arena_alloc(ctx, sizeof(double) * std::max(kk, pb), (void**)&inv));
     std::vector<double> h(std::max(kk, pb)), hd(kk), hn(kk);
+    double hstate[ORTH_HDR_WORDS] = {0.0};
     CTM_TRY(row_norms(ctx, warm, kk, n, n, norms));       // read back with the residuals below (one host synchronisation for both)
     CTM_HIP_CHECK(ctx, hipMemcpyAsync(hn.data(), norms, sizeof(double) * kk, hipMemcpyDeviceToHost, ctx->stream));
-    // ... once this workspace has been seen to hold a complete subspace.  Before that (a cold call, a workspace the caller has just
-    // zeroed or never filled) the row check comes first and alone: one launch and one synchronisation, instead of pushing zeros or
-    // garbage through the re-orthonormalisation, the product with A and the residual kernel before finding out.
-    OrthState ws_state = orth_state_get(warm);
-    if (!ws_state.rows_seen_valid) {
-        CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-        for (int i = 0; i < kk; ++i) if (!(std::fabs(hn[i] - 1.0) < 1e-6)) {
-            if (ctx->jacobi_verbose) fprintf(stderr, "[eigh-warm] n=%d kk=%d: workspace row %d has norm %.3e (no complete previous subspace)\n", n, kk, i, hn[i]);
-            return CTM_OK;
-        }
-        ws_state.rows_seen_valid = true; orth_state_put(warm, ws_state);
-    }
+    // the adaptive state of this workspace travels with the same synchronisation (a fresh workspace: zeros = the default state)
+    if (state_hdr) CTM_HIP_CHECK(ctx, hipMemcpyAsync(hstate, state_hdr, sizeof(hstate), hipMemcpyDeviceToHost, ctx->stream));
     CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)kk * n, (void**)&Q));
     CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)kk * n, (void**)&Y));
     CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)kk * kk, (void**)&H));
@@ -3416,6 +3244,7 @@ static int eigh_warm_verify(ctm_ctx* ctx, const double* As, int n, int kk, int k
     CTM_HIP_CHECK(ctx, hipMemcpyAsync(h.data(), res, sizeof(double) * kk, hipMemcpyDeviceToHost, ctx->stream));
     CTM_HIP_CHECK(ctx, hipMemcpyAsync(hd.data(), Dk, sizeof(double) * kk, hipMemcpyDeviceToHost, ctx->stream));
     CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (state_hdr) orth_state_load(ctx, hstate);
     for (int i = 0; i < kk; ++i) if (!(std::fabs(hn[i] - 1.0) < 1e-6)) {
         if (ctx->jacobi_verbose) fprintf(stderr, "[eigh-warm] n=%d kk=%d: workspace row %d has norm %.3e (no complete previous subspace)\n", n, kk, i, hn[i]);
         return CTM_OK;
@@ -3568,7 +3397,7 @@ static int eigh_warm_verify_c(ctm_ctx* ctx, const double* Asr, const double* Asi
 // Returned gauge: rows aligned with the previous vectors (warm_i <- sign<x_i, warm_i> x_i, u_i = sign(theta_i) warm_i), as the
 // regular route and the warm restart return them.
 static int eigh_orth_iter(ctm_ctx* ctx, const double* As, int n, int kk, int k_out, double* warm, double* D, double* Ut, bool* accepted,
-                          bool warm_checked, double moved) {
+                          bool warm_checked, double moved, double* state_hdr) {
     *accepted = false;
     int p = kk + std::max(32, kk / 2);
     p = ((p + 63) / 64) * 64;
@@ -3606,7 +3435,7 @@ static int eigh_orth_iter(ctm_ctx* ctx, const double* As, int n, int kk, int k_o
     // the largest |eigenvalue| the block does not hold): |lambda^2 - c^2/2| <= c^2/2 for |lambda| <= c halves what is left of the rest.
     double dbl_shift = 0.0; bool dbl = false; double* Z2 = nullptr;
     if (ctx->eigh_orth_double) {
-        const OrthState os0 = orth_state_get(warm);
+        const OrthState os0 = orth_state_get(ctx);
         if (os0.theta_0 > 0.0 && os0.theta_k > ctx->eigh_orth_double_min_ratio * os0.theta_0) {
             dbl = true;
             if (ctx->eigh_orth_double >= 2 && os0.c_ratio > 0.0 && os0.c_ratio < 0.7) { const double c = os0.c_ratio * os0.theta_k; dbl_shift = 0.5 * c * c; }
@@ -3658,7 +3487,7 @@ static int eigh_orth_iter(ctm_ctx* ctx, const double* As, int n, int kk, int k_o
         // (the contraction the previous accepted solve of this context saw from its own `moved` to its accepted residual -- a property
         //  of the spectrum, which changes slowly from sweep to sweep -- places the first look better than the fixed guess: a signed
         //  random C4v state contracts by 0.25-0.33 per application, not 0.01, and paid three looks per solve)
-        const double prev_rate = orth_state_get(warm).rate;
+        const double prev_rate = orth_state_get(ctx).rate;
         const double rho = prev_rate > 0.0 ? prev_rate : 1e-2;
         const int need = (int)std::ceil(std::log(0.5 * tol / std::min(moved, 1.0)) / std::log(rho) + (prev_rate > 0.0 ? 0.5 : 0.0));      // applications
         next_rr = std::min(max_it, std::max(min_rr, need - 1));
@@ -3719,12 +3548,12 @@ static int eigh_orth_iter(ctm_ctx* ctx, const double* As, int n, int kk, int k_o
                 CTM_HIP_CHECK(ctx, hipMemcpyAsync(D, Dp, sizeof(double) * k_out, hipMemcpyDeviceToDevice, ctx->stream));
                 ctx->si_hits += 1; ctx->eigh_orth_hits += 1;
                 {
-                    OrthState os = orth_state_get(warm);
+                    OrthState os = orth_state_get(ctx);
                     os.backoff = 0;
                     os.theta_0 = lam0; os.theta_k = lamk;
                     if (moved > 0.0) os.rate = std::min(0.9, std::max(1e-3, std::pow(std::max(worst / lam0, 1e-16) / std::min(moved, 1.0), 1.0 / (it + 1))));
                     if (moved > 0.0 && dbl_shift == 0.0) os.c_ratio = os.rate;
-                    orth_state_put(warm, os);
+                    CTM_TRY(orth_state_put(ctx, state_hdr, os));
                 }
                 ctx->si_last_iters = it + 1; ctx->si_total_iters += it + 1;
                 *accepted = true;
@@ -3742,10 +3571,10 @@ static int eigh_orth_iter(ctm_ctx* ctx, const double* As, int n, int kk, int k_o
                     if (ctx->jacobi_verbose) fprintf(stderr, "[eigh-orth] contraction %.3f per application: %.0f more needed, leaving\n", rate, needd);
                     ctx->eigh_orth_fails += 1;
                     {
-                        OrthState os = orth_state_get(warm);
+                        OrthState os = orth_state_get(ctx);
                         os.backoff = std::min(64, std::max(2, 2 * os.backoff));
                         os.skip = os.backoff;
-                        orth_state_put(warm, os);
+                        CTM_TRY(orth_state_put(ctx, state_hdr, os));
                     }
                     return CTM_OK;
                 }
@@ -3778,12 +3607,13 @@ int jacobi_eigh_top(ctm_ctx* ctx, const double* A, int n, int k, double* D, doub
             bool accepted = false;
             bool norms_ok = false;
             double moved = 0.0;
-            CTM_TRY(eigh_warm_verify(ctx, As, n, kk, k_out, warm, D, Ut, &accepted, false, &norms_ok, &moved));
+            double* state_hdr = (n >= 8) ? warm + (size_t)kk * n : nullptr;      // header row behind the kk vectors (include/ctm_hip.h)
+            CTM_TRY(eigh_warm_verify(ctx, As, n, kk, k_out, warm, D, Ut, &accepted, false, &norms_ok, &moved, state_hdr));
             if (accepted) return CTM_OK;
-            OrthState os = ctx->eigh_orth_iter ? orth_state_get(warm) : OrthState();
-            if (ctx->eigh_orth_iter && os.skip > 0) { os.skip -= 1; orth_state_put(warm, os); }
+            OrthState os = ctx->eigh_orth_iter ? orth_state_get(ctx) : OrthState();
+            if (ctx->eigh_orth_iter && os.skip > 0) { os.skip -= 1; CTM_TRY(orth_state_put(ctx, state_hdr, os)); }
             else if (ctx->eigh_orth_iter) {
-                CTM_TRY(eigh_orth_iter(ctx, As, n, kk, k_out, warm, D, Ut, &accepted, norms_ok, moved));
+                CTM_TRY(eigh_orth_iter(ctx, As, n, kk, k_out, warm, D, Ut, &accepted, norms_ok, moved, state_hdr));
                 if (accepted) return CTM_OK;
             }
         }

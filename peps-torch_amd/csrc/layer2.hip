@@ -32,137 +32,7 @@ struct Layer2Params {
     int s_sel = 0, accumulate = 0;
 };
 
-// KT = KAp/16 = NEp/16 (square case: contracted and open leg pairs have the same padded size), 512 threads = 8 waves
-// (2 per SIMD).  Per pair (x,y): gather of the NEXT pair is issued into registers before the MFMA phases of the
-// current one; k loops are fully unrolled (compile-time KT) so LDS operand reads are batched ahead of the MFMAs.
-template <int KT>
-__global__ __launch_bounds__(512) void layer2_kernel(Layer2Params p) {
-    constexpr int KAp = 16 * KT, NEp = 16 * KT;
-    constexpr int NT = KT * KT;                       // tiles per step
-    constexpr int TPW = (NT + 7) / 8;                 // tiles per wave
-    constexpr int NZ = (KAp * KAp + 511) / 512;       // gathered elements per thread
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    double* Zs = smem;                               // KAp x ldz
-    double* As = Zs + (size_t)KAp * p.ldz;           // KAp x lda   (row kk: [s][e], e padded to NEp)
-    double* Ws = As + (size_t)KAp * p.lda;           // KAp x ldw
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int lr = lane & 15, lk = lane >> 4;
-
-    const int tot = KAp * (p.ldz + p.lda + p.ldw);
-    for (int q = tid; q < tot; q += 512) smem[q] = 0.0;
-    __syncthreads();
-    {
-        const int na = p.KA * p.p * p.NE;
-        for (int q = tid; q < na; q += 512) {
-            const int e = q % p.NE, s = (q / p.NE) % p.p, kk = q / (p.NE * p.p);
-            As[kk * p.lda + s * NEp + e] = p.A[q];
-        }
-    }
-    // per-thread gather map (identical for every pair): element j of this thread
-    long long zoff[NZ]; int zdst[NZ];
-    const int nz = p.KA * p.KA;
-#pragma unroll
-    for (int j = 0; j < NZ; ++j) {
-        const int e = tid + 512 * j;
-        if (e < nz) {
-            const int c2b = e % p.D2; int r = e / p.D2;
-            const int c2k = r % p.D2; r /= p.D2;
-            const int c1b = r % p.D1; const int c1k = r / p.D1;
-            zoff[j] = c1k * p.zs_c1k + c1b * p.zs_c1b + c2k * p.zs_c2k + c2b * p.zs_c2b;
-            zdst[j] = (c1b * p.D2 + c2b) * p.ldz + (c1k * p.D2 + c2k);
-        } else { zoff[j] = 0; zdst[j] = -1; }
-    }
-    // per-thread tiles and scatter map
-    int tm[TPW], tn[TPW]; bool tv[TPW];
-    long long ooff[TPW][4]; bool ook[TPW][4];
-#pragma unroll
-    for (int u = 0; u < TPW; ++u) {
-        const int t = wid + 8 * u;
-        tv[u] = t < NT;
-        const int tc = tv[u] ? t : 0;
-        tm[u] = tc / KT; tn[u] = tc % KT;
-        const int E = tn[u] * 16 + lr;
-        const long long ob = (long long)(E / p.E2) * p.os_e1b + (long long)(E % p.E2) * p.os_e2b;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int e = tm[u] * 16 + lk + 4 * r;
-            ook[u][r] = tv[u] && E < p.NE && e < p.NE && !(p.dbg & 4);
-            ooff[u][r] = (long long)(e / p.E2) * p.os_e1k + (long long)(e % p.E2) * p.os_e2k + ob;
-        }
-    }
-    const long long npair = (long long)p.nx * p.ny;
-    double zreg[NZ];
-    {   // first pair of this workgroup
-        const long long q = blockIdx.x;
-        if (q < npair) {
-            const double* z = p.Z + (q / p.ny) * p.zs_x + (q % p.ny) * p.zs_y;
-#pragma unroll
-            for (int j = 0; j < NZ; ++j) if (zdst[j] >= 0) zreg[j] = z[zoff[j]];
-        }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < NZ; ++j) if (zdst[j] >= 0) Zs[zdst[j]] = zreg[j];
-
-    for (long long q = blockIdx.x; q < npair; q += gridDim.x) {
-        __syncthreads();                               // Zs of this pair is complete
-        const long long qn = q + gridDim.x;
-        if (qn < npair && !(p.dbg & 1)) {              // prefetch the next pair into registers
-            const double* z = p.Z + (qn / p.ny) * p.zs_x + (qn % p.ny) * p.zs_y;
-#pragma unroll
-            for (int j = 0; j < NZ; ++j) if (zdst[j] >= 0) zreg[j] = z[zoff[j]];
-        }
-        d4 acc[TPW];
-#pragma unroll
-        for (int u = 0; u < TPW; ++u) acc[u] = (d4){0., 0., 0., 0.};
-        for (int s = 0; s < ((p.dbg & 2) ? 0 : p.p); ++s) {
-            // ---- step A: W[kb][e] = sum_kk Zs[kb][kk] As[kk][s][e]
-            d4 w[TPW];
-#pragma unroll
-            for (int u = 0; u < TPW; ++u) w[u] = (d4){0., 0., 0., 0.};
-#pragma unroll
-            for (int k0 = 0; k0 < KAp; k0 += 4) {
-#pragma unroll
-                for (int u = 0; u < TPW; ++u) {
-                    const double a = Zs[(tm[u] * 16 + lr) * p.ldz + lk + k0];
-                    const double b = As[(lk + k0) * p.lda + s * NEp + tn[u] * 16 + lr];
-                    w[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, w[u], 0, 0, 0);
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < TPW; ++u)
-                if (tv[u]) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) Ws[(tm[u] * 16 + lk + 4 * r) * p.ldw + tn[u] * 16 + lr] = w[u][r];
-                }
-            __syncthreads();
-            // ---- step B: O[e][E] += sum_kb W[kb][e] As[kb][s][E]
-#pragma unroll
-            for (int k0 = 0; k0 < KAp; k0 += 4) {
-#pragma unroll
-                for (int u = 0; u < TPW; ++u) {
-                    const double a = Ws[(lk + k0) * p.ldw + tm[u] * 16 + lr];
-                    const double b = As[(lk + k0) * p.lda + s * NEp + tn[u] * 16 + lr];
-                    acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[u], 0, 0, 0);
-                }
-            }
-            __syncthreads();
-        }
-        // ---- scatter O[(e1k,e2k)][(e1b,e2b)] in the caller's layout
-        double* o = p.out + (q / p.ny) * p.os_x + (q % p.ny) * p.os_y;
-#pragma unroll
-        for (int u = 0; u < TPW; ++u)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (ook[u][r]) o[ooff[u][r]] = acc[u][r];
-        // ---- stage the prefetched pair (all step-A reads of Zs finished before the last barrier)
-        if (qn < npair) {
-#pragma unroll
-            for (int j = 0; j < NZ; ++j) if (zdst[j] >= 0) Zs[zdst[j]] = zreg[j];
-        }
-    }
-}
-
+// KT = KAp/16 = NEp/16 (square case: contracted and open leg pairs have the same padded size).
 // Register-resident variant: KT waves per workgroup, wave w owns the open-ket block e in [16 w, 16 w + 16).  Step A produces the
 // W tiles (all KT contracted-bra blocks x this e block) in registers in the MFMA C/D layout, which IS the A-operand layout
 // of step B (lane l, register r of tile j holds W[kb = 16 j + 4 r + (l >> 4)][e = l & 15] = row e, k-slice r of block j), so W
@@ -429,19 +299,6 @@ int launch_layer2_reg(ctm_ctx* ctx, const Layer2Params& p) {
     return CTM_OK;
 }
 
-template <int KT>
-int launch_layer2(ctm_ctx* ctx, const Layer2Params& p, size_t lds_bytes) {
-    static std::once_flag attr_once;
-    std::call_once(attr_once, [] { (void)hipFuncSetAttribute((const void*)layer2_kernel<KT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
-    const long long npair = (long long)p.nx * p.ny;
-    const int per_cu = (lds_bytes <= 40 * 1024) ? 3 : (lds_bytes <= 76 * 1024 ? 2 : 1);
-    const int grid = (int)std::min<long long>(npair, 256LL * per_cu * 2);
-    CTM_LAUNCH(ctx, layer2_kernel<KT>, dim3(grid), dim3(512), lds_bytes, p);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) { ctx->set_error(std::string("layer2 launch: ") + hipGetErrorString(e)); return CTM_ERR_HIP; }
-    return CTM_OK;
-}
-
 long long stride_of(const std::string& idx, const DT& t, char ch) {
     long long s = 1;
     for (int a = (int)idx.size() - 1; a >= 0; --a) { if (idx[a] == ch) return s; s *= t.dims[a]; }
@@ -537,10 +394,9 @@ int dev_layer2(ctm_ctx* ctx, const std::string& iz, const DT& Z, const std::stri
     p.os_x = stride_of(io, O, sp[0]); p.os_y = stride_of(io, O, sp[1]);
     p.os_e1k = stride_of(io, O, ek[0]); p.os_e1b = stride_of(io, O, eb[0]);
     p.os_e2k = stride_of(io, O, ek[1]); p.os_e2b = stride_of(io, O, eb[1]);
-    p.dbg = ctx->layer2_dbg;
+    p.dbg = 0;
     const long long npair = (long long)p.nx * p.ny;
     const double fl = 2.0 * npair * p.p * ((double)p.KA * p.KA * p.NE + (double)p.KA * p.NE * p.NE) * (cx ? 4.0 : 1.0);
-    HeavyScope heavy(ctx, fl);
     const int ev = timing_begin(ctx);
     int st = CTM_OK;
     if (cx) {
@@ -554,19 +410,11 @@ int dev_layer2(ctm_ctx* ctx, const std::string& iz, const DT& Z, const std::stri
             }
         }
     } else
-    if (ctx->layer2_reg >= 0 && p.KAp / 16 >= ctx->layer2_reg) {
-        switch (p.KAp / 16) {
-            case 1: st = launch_layer2_reg<1>(ctx, p); break;
-            case 2: st = launch_layer2_reg<2>(ctx, p); break;
-            case 3: st = launch_layer2_reg<3>(ctx, p); break;
-            default: st = launch_layer2_reg<4>(ctx, p); break;
-        }
-    } else
     switch (p.KAp / 16) {
-        case 1: st = launch_layer2<1>(ctx, p, lds_bytes); break;
-        case 2: st = launch_layer2<2>(ctx, p, lds_bytes); break;
-        case 3: st = launch_layer2<3>(ctx, p, lds_bytes); break;
-        default: st = launch_layer2<4>(ctx, p, lds_bytes); break;
+        case 1: st = launch_layer2_reg<1>(ctx, p); break;
+        case 2: st = launch_layer2_reg<2>(ctx, p); break;
+        case 3: st = launch_layer2_reg<3>(ctx, p); break;
+        default: st = launch_layer2_reg<4>(ctx, p); break;
     }
     timing_end(ctx, ev, 2, fl);
     CTM_TRY(st);

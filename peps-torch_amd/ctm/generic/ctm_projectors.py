@@ -54,6 +54,10 @@ def ctm_get_projectors_4x4(direction, coord, state, env, ctm_args=cfg.ctm_args, 
                 b = ws[key] = eng.warm_basis(env.chi, n, a.dtype)
             basis = b
         corners, fresh = _cached_corners(eng, direction, coord, state, env, t16, ctm_args)
+        wtol = float(getattr(ctm_args, "projector_warm_tol", 0.0) or 0.0)
+        if getattr(eng, "_warm_tol", 0.0) != wtol and hasattr(eng, "set_option"):      # (per engine: the units of a move run on worker engines)
+            eng.set_option("warm_accept_tol", wtol)
+            eng._warm_tol = wtol
         P, Pt, S = eng.projectors_4x4(direction, t16, env.chi, _trunc_cfg(eng, ctm_args), return_S=True, basis=basis, corners=corners)
         for key, entry in fresh:                  # only after the call succeeded: the buffers now hold these corners
             env.__dict__["_corner_cache"][key] = entry

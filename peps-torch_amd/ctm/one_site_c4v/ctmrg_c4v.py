@@ -55,7 +55,7 @@ def ctm_MOVE_sl(a, env, f_c2x2_decomp=None, ctm_args=cfg.ctm_args, global_args=c
         n = env.chi * a.shape[1] ** 2
         basis = env.__dict__.get("_warm")
         k = env.chi + 1 if env.chi < n else n
-        if basis is None or tuple(basis.shape) != ((2 if a.is_complex() else 1) * min(n, k + 8), n) or basis.device != a.device:
+        if basis is None or tuple(basis.shape) != ((2 if a.is_complex() else 1) * min(n, k + 8) + 1, n) or basis.device != a.device:
             basis = env.__dict__["_warm"] = eng.warm_basis_c4v(env.chi, n, a.dtype)
     nC, nT, _D = eng.move_c4v(a, env.C[env.keyC], env.T[env.keyT], cfgT, normalize=norm_kind, **({"basis": basis} if basis is not None else {}))
     env.C[env.keyC] = nC
@@ -80,7 +80,7 @@ def _ctm_MOVE_sl_ad(a, env, f_c2x2_decomp, norm_kind, ctm_args):
             n = env.chi * a.shape[1] ** 2
             ws = env.__dict__.setdefault("_warm_ad", {})
             basis = ws.get(idx)
-            if basis is None or tuple(basis.shape) != ((2 if a.is_complex() else 1) * n, n) or basis.device != a.device:
+            if basis is None or tuple(basis.shape) != ((2 if a.is_complex() else 1) * n + 1, n) or basis.device != a.device:
                 if len(ws) * n * n * 8 * (2 if a.is_complex() else 1) < 0.05 * torch.cuda.get_device_properties(a.device).total_memory:
                     basis = ws[idx] = eng.warm_basis_c4v(n, n, a.dtype)
                 else:

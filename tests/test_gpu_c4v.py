@@ -205,8 +205,8 @@ def test_warm_restart_with_a_missing_leading_direction_is_rejected_by_the_probe(
     kk = chi + 1 + 8
     cols = [i for i in range(kk + 1) if i != 4]
     basis = eng.warm_basis_c4v(chi, n)
-    assert tuple(basis.shape) == (kk, n)
-    basis.copy_(Q[:, cols].T.contiguous().cuda())
+    assert tuple(basis.shape) == (kk + 1, n)                    # kk vectors + the header row (adaptive state of the sequence)
+    basis[:kk].copy_(Q[:, cols].T.contiguous().cuda())
     eng.timers(reset=True)
     D, U = eng.truncated_eigh(A.cuda(), chi, basis=basis)
     assert eng.stat("eigh_warm_rejects") == 1 and eng.stat("eigh_warm_hits") == 0
@@ -447,7 +447,7 @@ def test_complex_warm_restart_with_a_missing_leading_direction_is_rejected(eng):
     cols = [i for i in range(kk + 1) if i != 4]
     basis = eng.warm_basis_c4v(chi, n, A.dtype)
     Vh = Q[:, cols].conj().T.contiguous()                      # rows v_i^H
-    basis.copy_(torch.cat([Vh.real, Vh.imag]).cuda())
+    basis[:2 * kk].copy_(torch.cat([Vh.real, Vh.imag]).cuda())
     eng.timers(reset=True)
     D, U = eng.truncated_eigh(A.cuda(), chi, basis=basis)
     assert eng.stat("eigh_warm_rejects") == 1 and eng.stat("eigh_warm_hits") == 0
@@ -571,7 +571,7 @@ def test_full_decomposition_warm_start_changes_the_work_not_the_result(eng, cplx
     A1 = 0.5 * (A1 + A1.conj().T)
     cfgT = eng.cfg(keep_multiplets=False)
     basis = eng.warm_basis_c4v(n, n, A0.dtype)
-    assert tuple(basis.shape) == ((2 if cplx else 1) * n, n)
+    assert tuple(basis.shape) == ((2 if cplx else 1) * n + 1, n)
     eng.timers(reset=True)
     eng.truncated_eigh(A0, n, cfgT, basis=basis)                      # cold: fills the workspace
     cold_sweeps = eng.stat("total_sweeps")
@@ -605,8 +605,7 @@ def test_orthogonal_iteration_with_two_applications_per_cholesky_step(eng):
     E = torch.randn(n, n, generator=g, dtype=torch.float64); E = E + E.T
     E = E / torch.linalg.matrix_norm(E, 2)
     try:
-        eng.set_option("eigh_orth_iter", 1)          # (forgets the adaptive state of every workspace: it is keyed by address, and this workspace's address has had owners)
-        eng.set_option("eigh_orth_double", 2)
+        eng.set_option("eigh_orth_double", 2)          # (the adaptive state lives in the header row of the fresh workspace below: born zero)
         basis = eng.warm_basis_c4v(chi, n)
         eng.truncated_eigh(A.cuda(), chi, basis=basis)
         eng.timers(reset=True)
@@ -624,4 +623,3 @@ def test_orthogonal_iteration_with_two_applications_per_cholesky_step(eng):
         assert doubled[0] == 0 and doubled[3] > doubled[2] > doubled[1] > 0, doubled
     finally:
         eng.set_option("eigh_orth_double", 0)
-        eng.set_option("eigh_orth_iter", 1)          # (and leaves none behind)

@@ -105,13 +105,13 @@ def test_values_below_the_numerical_rank_are_returned_as_zeros(eng):
     assert np.abs(S - ex).max() < 5e-13
 
 
-LZ_BLOCK_DEFAULT, CROSS_ONLY_DEFAULT, ROT_APPLY_DEFAULT, PERSIST_DEFAULT = 0, 1, 0, 0          # csrc/ctm_common.h
+LZ_BLOCK_DEFAULT, CROSS_ONLY_DEFAULT = 0, 1          # csrc/ctm_common.h
 
 
 def test_krylov_solver_variants_agree(eng):
     """The block Krylov truncation of a full-rank unit (signed 2x2 state, D = 4, chi = 64: n = 1024, k = 65) through its variants:
-    the sync-free recurrence against the synchronous one, 16-row panels in the Ritz extraction (the 18 KB LDS eigensolver), the
-    device-side lock around chip-filling launches, all four units in flight against serial units.  Same singular values to 1e-12 s0
+    the sync-free recurrence against the synchronous one, 32- and 64-row blocks, full and cross-pair rounds in the Ritz extraction,
+    all four units in flight against serial units.  Same singular values to 1e-12 s0
     and the same environment after two sweeps to 1e-10 (every variant is residual-verified by the solver itself)."""
     import numpy as np, torch
     import config as cfg
@@ -141,41 +141,29 @@ def test_krylov_solver_variants_agree(eng):
             return {k: (s_ / s_[0]).cpu().numpy() for k, s_ in env.get_spectra().items()}
         finally:
             cfg.ctm_args.concurrent_units = old
-            for k_ in opts: eng.set_option(k_, {"lz_async": 1, "lz_jacobi_block": 0, "heavy_serial": 0, "heavy_min_flops": 1e10, "lz_local_project": 1,
-                                                "lz_block": LZ_BLOCK_DEFAULT, "jacobi_cross_only": CROSS_ONLY_DEFAULT, "jacobi_rot_apply": ROT_APPLY_DEFAULT,
-                                                "jacobi_persist": PERSIST_DEFAULT}[k_])
+            for k_ in opts: eng.set_option(k_, {"lz_async": 1, "lz_local_project": 1, "lz_block": LZ_BLOCK_DEFAULT, "jacobi_cross_only": CROSS_ONLY_DEFAULT}[k_])
     ref = run({})
-    for name, opts, conc in (("synchronous recurrence", {"lz_async": 0}, True), ("16-row panels", {"lz_jacobi_block": 16}, True),
-                             ("device-side lock", {"heavy_serial": 1, "heavy_min_flops": 1e7}, True), ("serial units", {}, False),
+    for name, opts, conc in (("synchronous recurrence", {"lz_async": 0}, True), ("serial units", {}, False),
                              ("two full projection passes", {"lz_local_project": 0}, True),
                              ("32-row blocks", {"lz_block": 32}, True), ("64-row blocks", {"lz_block": 64}, True),
                              ("32-row blocks, synchronous recurrence", {"lz_block": 32, "lz_async": 0}, True),
-                             ("cross-pair rounds in the Ritz extraction", {"jacobi_cross_only": 1}, True), ("full rounds", {"jacobi_cross_only": 0}, True),
-                             ("rotation lists applied on the vector ALUs", {"jacobi_rot_apply": 1, "jacobi_cross_only": 0}, True),
-                             ("rotation lists, cross-pair rounds", {"jacobi_rot_apply": 1, "jacobi_cross_only": 1}, True),
-                             ("accumulated J + apply GEMM", {"jacobi_rot_apply": 0, "jacobi_cross_only": 0}, True),
-                             ("one launch per Jacobi sweep, cross-pair rounds", {"jacobi_persist": 1, "jacobi_cross_only": 1}, True),
-                             ("one launch per Jacobi sweep, full rounds", {"jacobi_persist": 1, "jacobi_cross_only": 0}, True),
-                             ("three launches per round", {"jacobi_persist": 0}, True)):
+                             ("cross-pair rounds in the Ritz extraction", {"jacobi_cross_only": 1}, True), ("full rounds", {"jacobi_cross_only": 0}, True)):
         got = run(opts, conc)
         for k in ref:
             assert np.abs(got[k] - ref[k]).max() < 1e-10, (name, k)
 
 
-@pytest.mark.parametrize("opts", [{"jacobi_rot_apply": 0, "jacobi_cross_only": 0}, {"jacobi_rot_apply": 1, "jacobi_cross_only": 0},
-                                  {"jacobi_rot_apply": 1, "jacobi_cross_only": 1}, {"jacobi_rot_apply": 0, "jacobi_cross_only": 1},
-                                  {"jacobi_persist": 1, "jacobi_cross_only": 0, "jacobi_rot_apply": 0}, {"jacobi_persist": 1, "jacobi_cross_only": 1, "jacobi_rot_apply": 0}],
-                         ids=["J-gemm", "rotation-lists", "rotation-lists-cross", "J-gemm-cross", "one-launch-sweep", "one-launch-sweep-cross"])
+@pytest.mark.parametrize("opts", [{"jacobi_cross_only": 0}, {"jacobi_cross_only": 1}], ids=["full-rounds", "cross-pair-rounds"])
 def test_many_panel_block_jacobi_variants_against_lapack(eng, opts):
     """The dense one-sided block Jacobi SVD on many 32-row panels (the Ritz extraction of the block Krylov solver; here called directly
-    through the full decomposition of an explicit matrix): accumulated J + apply GEMM, or the eigensolver's rotation lists applied on
-    the vector ALUs, with full or cross-pair rounds -- singular values against LAPACK to 1e-13 s0, orthonormal factors, reconstruction."""
+    through the full decomposition of an explicit matrix) with full or cross-pair rounds -- singular values against LAPACK to 1e-13 s0,
+    orthonormal factors, reconstruction."""
     n = 640
     rng = np.random.default_rng(3)
     U, _ = np.linalg.qr(rng.standard_normal((n, n))); V, _ = np.linalg.qr(rng.standard_normal((n, n)))
     s = np.exp(-16.0 * (np.arange(n) / n) ** 0.5)              # steep head, slowly decaying dense tail
     M = (U * s) @ V.T
-    keep = {"si_enable": 1, "jacobi_rot_apply": ROT_APPLY_DEFAULT, "jacobi_cross_only": CROSS_ONLY_DEFAULT, "jacobi_persist": PERSIST_DEFAULT}
+    keep = {"si_enable": 1, "jacobi_cross_only": CROSS_ONLY_DEFAULT}
     try:
         eng.set_option("si_enable", 0)                         # the dense path, not the leading-k iteration
         for k_, v_ in opts.items(): eng.set_option(k_, v_)

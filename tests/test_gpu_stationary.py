@@ -1,0 +1,128 @@
+"""GPU: the stationary-environment fast path of the generic truncation (ctm_args.projector_warm_tol > 0; csrc/jacobi.hip: svd_stationary).
+
+Once a run has converged, the operator of a (direction, site) unit changes by ~1e-10 s_0 from sweep to sweep; with the option on a unit
+whose previous singular basis lies that close to its last full solve is truncated by ONE Rayleigh-Ritz half step from that basis,
+accepted on the residual of its triplets, instead of a cold block Krylov solve.  The option is off by default (every truncation
+solved to the rounding-level threshold, as the reference's full SVD `ctm/generic/ctm_projectors.py:214-229`); on, it plays the role of the
+reference's tolerance-driven partial solvers (`:229-257`).  Checked here: the converged corner spectra and the rdm2x2 energy of a run with
+the option agree with the run without it to 1e-10, the fast path really is taken, stationary sweeps are at least twice as fast as
+the sweeps that solve from scratch, and a basis that is NOT close (the environment still moves, or the state changed) is refused."""
+import time
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _sites(D, seed):
+    rng = np.random.default_rng(seed)
+    out = {}
+    for y in range(2):
+        for x in range(2):
+            A = rng.random((2, D, D, D, D)) - 0.5                      # signed random tensors: full-rank environment, block Krylov units
+            out[(x, y)] = torch.from_numpy(A / np.abs(A).max()).cuda()
+    return out
+
+
+def _converge(eng, sites, chi, warm_tol, conv_tol, max_sweeps, extra=0):
+    """Sweeps until ctmrg_conv_specC (reference ctm/generic/env.py:816-875) says so, plus `extra` sweeps; per-sweep wall times and the
+    number of truncations the fast path accepted in each sweep."""
+    import config as cfg
+    from ipeps.ipeps import IPEPS
+    from ctm.generic.env import ENV, init_env, ctmrg_conv_specC
+    from ctm.generic import ctmrg
+    import copy
+    args = copy.deepcopy(cfg.ctm_args)
+    args.projector_warm_tol = warm_tol
+    args.ctm_conv_tol = conv_tol
+    args.ctm_max_iter = max_sweeps
+    st = IPEPS(dict(sites))
+    env = ENV(chi, st); init_env(st, env)
+    times, accepts, krylov, hist, left = [], [], [], None, None
+    for i in range(max_sweeps + extra):
+        a0, l0 = eng.stat("warm_accepts"), eng.stat("lz_hits")
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for d in args.ctm_move_sequence:
+            for _ in range(2):
+                ctmrg.ctm_MOVE(d, st, env, ctm_args=args)
+        torch.cuda.synchronize()
+        times.append(time.perf_counter() - t0)
+        accepts.append(int(eng.stat("warm_accepts") - a0)); krylov.append(int(eng.stat("lz_hits") - l0))
+        if left is None:
+            conv, hist = ctmrg_conv_specC(st, env, hist, ctm_args=args)
+            if conv:
+                left = extra
+        if left is not None:
+            if left == 0:
+                break
+            left -= 1
+    return st, env, times, accepts, krylov, hist
+
+
+def _energy(st, env):
+    from models import j1j2
+    return float(j1j2.J1J2(j1=1.0, j2=0.5).energy_per_site(st, env))
+
+
+def _spectra(env):
+    return {k: (s / s[0]).cpu().numpy() for k, s in env.get_spectra().items()}
+
+
+@pytest.mark.parametrize("D,chi,conv_tol,max_sweeps", [(4, 64, 1e-9, 60), (6, 128, 1e-8, 40)], ids=["D4chi64", "D6chi128"])
+def test_converged_run_with_and_without_the_fast_path(eng, D, chi, conv_tol, max_sweeps):
+    sites = _sites(D, 11)
+    try:
+        st0, env0, t0, acc0, kr0, h0 = _converge(eng, sites, chi, 0.0, conv_tol, max_sweeps, extra=8)
+        assert sum(acc0) == 0 and sum(kr0) > 0, "option off: every truncation is a full solve (and the state must reach the block Krylov solver)"
+        st1, env1, t1, acc1, kr1, h1 = _converge(eng, sites, chi, 1e-9, conv_tol, max_sweeps, extra=8)
+    finally:
+        for e in [eng] + list(eng.workers):
+            e.set_option("warm_accept_tol", 0.0); e._warm_tol = 0.0
+    assert len(h0['diffs']) == len(h1['diffs']) or abs(len(h0['diffs']) - len(h1['diffs'])) <= 1      # same number of sweeps to convergence
+    s0, s1 = _spectra(env0), _spectra(env1)
+    for k in s0:
+        assert np.abs(s0[k] - s1[k]).max() < 1e-10, k                               # converged corner spectra
+    e0, e1 = _energy(st0, env0), _energy(st1, env1)
+    assert abs(e0 - e1) <= 1e-10 * abs(e0), (e0, e1)                                # rdm2x2 energy
+    # the fast path carried the stationary sweeps: 32 truncations per sweep, all accepted in the last sweeps
+    assert acc1[-1] == 32 and acc1[-2] == 32, acc1
+    assert kr1[-1] == 0, kr1
+    # ... and they are at least twice as fast as sweeps that solve every truncation from scratch
+    cold = min(t0[-4:])
+    stat = min(t1[-4:])
+    print(f"\nD={D} chi={chi}: {len(t0)} / {len(t1)} sweeps; solve-from-scratch sweep {1e3 * cold:.1f} ms, stationary sweep {1e3 * stat:.1f} ms "
+          f"({cold / stat:.2f}x); accepted per sweep {acc1}; E = {e0:.12f} / {e1:.12f}")
+    assert stat * 2.0 <= cold, (stat, cold)
+    env0.__dict__.pop("_corner_cache", None); env1.__dict__.pop("_corner_cache", None)
+    eng.trim()
+
+
+def test_a_basis_that_is_not_close_is_refused(eng):
+    """Converge with the fast path on, then swap in a DIFFERENT state under the same environment object (warm workspaces included): the
+    residual test must refuse the old bases (the units fall back to full solves), and the run must end where a fresh run on that state ends."""
+    import config as cfg
+    from ipeps.ipeps import IPEPS
+    from ctm.generic.env import ENV, init_env
+    from ctm.generic import ctmrg
+    import copy
+    D, chi = 4, 64
+    a, b = _sites(D, 11), _sites(D, 12)
+    args = copy.deepcopy(cfg.ctm_args)
+    args.projector_warm_tol = 1e-9
+    try:
+        st, env, *_ = _converge(eng, a, chi, 1e-9, 1e-9, 60, extra=2)
+        assert eng.stat("warm_accepts") > 0
+        st2 = IPEPS(dict(b))
+        r0, a0 = eng.stat("warm_rejects"), eng.stat("warm_accepts")
+        for _ in range(2):
+            for d in args.ctm_move_sequence:
+                for _r in range(2):
+                    ctmrg.ctm_MOVE(d, st2, env, ctm_args=args)
+        assert eng.stat("warm_rejects") > r0, "bases of another state were not refused"
+        assert eng.stat("warm_accepts") == a0, "a basis of another state passed the residual test"
+    finally:
+        for e in [eng] + list(eng.workers):
+            e.set_option("warm_accept_tol", 0.0); e._warm_tol = 0.0
+    env.__dict__.pop("_corner_cache", None)
+    eng.trim()
