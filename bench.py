@@ -258,6 +258,49 @@ def _describe(i, kms, kfl, kn, ums=None):
     return d
 
 
+def stationary_block(eng, step, env, warm_tol=1e-9, max_sweeps=14, timed=3):
+    """The stationary-environment fast path (ctm_args.projector_warm_tol, csrc/jacobi.hip: svd_stationary) on the environment the timed
+    sweeps ended with: sweeps with the option on until one sweep's truncations were ALL accepted from the previous basis (or max_sweeps),
+    then `timed` sweeps timed.  Reported next to the rate of the sweeps that solve every truncation from scratch; the option is off again
+    on return (it is opt-in: a residual tolerance instead of the rounding-level threshold)."""
+    import config as cfg
+    old = cfg.ctm_args.projector_warm_tol
+    cfg.ctm_args.projector_warm_tol = warm_tol
+    out = {"projector_warm_tol": warm_tol}
+    try:
+        per, n_before = [], None
+        spec0 = {k: (v / v[0]).cpu() for k, v in env.get_spectra().items()}
+        for i in range(max_sweeps):
+            a0, r0 = eng.stat("warm_accepts"), eng.stat("warm_rejects")
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            step()
+            torch.cuda.synchronize()
+            per.append((time.perf_counter() - t0, int(eng.stat("warm_accepts") - a0), int(eng.stat("warm_rejects") - r0)))
+            if per[-1][1] >= 32:
+                n_before = i
+                break
+        out["sweeps_until_every_truncation_is_accepted"] = n_before
+        out["accepted_per_sweep_on_the_way"] = [p_[1] for p_ in per]
+        if n_before is None:
+            out["note"] = "the environment did not become stationary to the tolerance within the sweeps tried"
+            return out
+        a0, l0 = eng.stat("warm_accepts"), eng.stat("lz_hits")
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(timed):
+            step()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        spec1 = {k: (v / v[0]).cpu() for k, v in env.get_spectra().items()}
+        out.update({"sweeps_per_sec": timed / dt, "ms_per_step": 1e3 * dt / timed, "steps": timed,
+                    "accepted_truncations": int(eng.stat("warm_accepts") - a0), "full_solves": int(eng.stat("lz_hits") - l0),
+                    "max_change_of_corner_spectra_since_the_timed_region": float(max(float((spec1[k] - spec0[k]).abs().max()) for k in spec0))})
+    finally:
+        cfg.ctm_args.projector_warm_tol = old
+        for e in [eng] + list(getattr(eng, "workers", [])):
+            e.set_option("warm_accept_tol", 0.0); e._warm_tol = 0.0
+    return out
+
+
 def run_workload(args, eng, dev, kind, D, chi, dtype, signed, steps, warmup, world, rank, dist):
     """Build the synthetic state, warm up, time `steps` sweeps; returns (dict for the JSON line, sites, state, env)."""
     import config as cfg
@@ -339,6 +382,12 @@ def run_workload(args, eng, dev, kind, D, chi, dtype, signed, steps, warmup, wor
         serial = ([eng.stat(f"k_ms{i}") for i in KK], [eng.stat(f"k_flops{i}") for i in KK], [eng.stat(f"k_calls{i}") for i in KK])
         eng.set_option("gemm_timing", 0)
         cfg.ctm_args.concurrent_units = True
+    stationary = None
+    if world == 1 and kind != "c4v" and signed and dtype == "f64" and not args.no_stationary:      # (the complex solver has no such path yet)
+        try:
+            stationary = stationary_block(eng, step, env)
+        except Exception as e:                         # reporting only
+            stationary = {"error": repr(e)}
     comm_ranks = None
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -393,6 +442,13 @@ def run_workload(args, eng, dev, kind, D, chi, dtype, signed, steps, warmup, wor
     out = {"value": steps / dt, "ms_per_step": 1e3 * dt / steps, "steps": steps, "warmup": warmup, "roofline": roof, "svd": svd,
            "phase_s": {k: round(v, 4) for k, v in phase.items()},
            "phase_s_note": "device time per phase from HIP events on the engines' streams, summed over concurrent streams (not wall time)"}
+    if stationary is not None:
+        # the generic twin of the C4v block's moving / stationary split: `value` is the rate of sweeps that solve every truncation from
+        # scratch (what every sweep of a default run pays, converged or not); with ctm_args.projector_warm_tol a converged run pays this
+        stationary["solve_from_scratch_sweeps_per_sec"] = steps / dt
+        if stationary.get("sweeps_per_sec"):
+            stationary["speedup"] = round(stationary["sweeps_per_sec"] * dt / steps, 3)
+        out["stationary_environment"] = stationary
     if step_ms:
         srt = sorted(step_ms)
         med = srt[len(srt) // 2]
@@ -555,7 +611,9 @@ def _compact_block(b):
         o["corner_rank_1e-8"] = stt.get("corner_values_above_1e-8"); o["low_rank"] = stt.get("effective_rank_much_smaller_than_chi")
     for k_ in ("moving_environment", "stationary_environment"):
         if k_ in b:
-            o[k_.split("_")[0] + "_sweeps_per_sec"] = b[k_].get("sweeps_per_sec"); o[k_.split("_")[0] + "_sweeps"] = b[k_].get("sweeps")
+            o[k_.split("_")[0] + "_sweeps_per_sec"] = b[k_].get("sweeps_per_sec"); o[k_.split("_")[0] + "_sweeps"] = b[k_].get("sweeps", b[k_].get("steps"))
+            if "solve_from_scratch_sweeps_per_sec" in b[k_]:        # generic full-rank block: the timed sweeps solve every truncation from scratch
+                o["moving_sweeps_per_sec"] = b[k_]["solve_from_scratch_sweeps_per_sec"]; o["stationary_warm_tol"] = b[k_].get("projector_warm_tol")
     for k_ in ("dtype", "units_in_flight", "wall_s_incl_warmup"):
         if k_ in b:
             o[k_] = b[k_]
@@ -594,6 +652,10 @@ def metric_line(d):
                      "full_rank_traffic_source": (fro.get("traffic_source") or "")[:60]})
         blk = {"value": fr["value"], "ms_per_step": fr["ms_per_step"], "steps": fr["steps"], "warmup": fr["warmup"], "state": {k: v for k, v in fr["state"].items() if k != "note"},
                "svd": fr["svd"], "phase_s": fr["phase_s"]}
+        if "stationary_environment" in fr:
+            se = fr["stationary_environment"]
+            blk["stationary_environment"] = {k: (round(v, 5) if isinstance(v, float) else v) for k, v in se.items() if k != "note"}
+            roof.update({"full_rank_stationary_value": se.get("sweeps_per_sec"), "full_rank_moving_value": se.get("solve_from_scratch_sweeps_per_sec")})
         if "energy" in fr:
             e = fr["energy"]
             blk["energy"] = e if "error" in e else {"seconds_per_energy_4_sites": e["seconds_per_energy_4_sites"], "energy_per_site_j2_0.5": e["energy_per_site_j2_0.5"],
@@ -706,6 +768,7 @@ def main():
     ap.add_argument("--no-serial-pass", action="store_true", help="skip the extra serially issued sweep behind roofline.serial_pass")
     ap.add_argument("--serial-units", action="store_true", help="do not overlap the independent site-units of a move on streams")
     ap.add_argument("--cold-start", action="store_true", help="no warm start of the leading-chi iteration")
+    ap.add_argument("--no-stationary", action="store_true", help="skip the stationary-environment block of the full-rank state (projector_warm_tol fast path)")
     ap.add_argument("--no-energy", action="store_true", help="skip the energy block (E/site from rdm2x2 at the size of the timed run)")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the compact blocks of the other single-GPU BASELINE configurations")
     ap.add_argument("--no-live-traffic", action="store_true", help="roofline.traffic from the committed PMC pass instead of two rocprofv3 --pmc child runs of this command")
@@ -809,6 +872,8 @@ def main():
                                 "steps": full["steps"], "warmup": full["warmup"],
                                 "config": {"workload": args.config, "state": "A ~ U(-1,1), A /= max|A| (signed random tensors)", "n": chi * D * D},
                                 "state": full["state"], "roofline": full["roofline"], "svd": full["svd"], "phase_s": full["phase_s"]}
+            if "stationary_environment" in full:
+                out["full_rank"]["stationary_environment"] = full["stationary_environment"]
         if full is not None and "energy" in full:
             out["full_rank"]["energy"] = full["energy"]
         if signed_c4v is not None:

@@ -203,6 +203,35 @@ int ctm_absorb(ctm_ctx* ctx, int dir, const double* const* tensors10, int chi, c
 int ctm_absorb_x(ctm_ctx* ctx, int dir, const double* const* tensors10, int chi_in, int chi_out, const int* adims, int normalize,
                  double* nC1, double* nC2, double* nT);
 
+/* ---- a whole directional move of the generic CTMRG in ONE call (ctm/generic/ctmrg.py:233-283 ctm_MOVE_c: raw tensors of the old
+ * environment in, nC1 / nC2 / nT of every site out) -------------------------------------------------------------------------------
+ * One unit per site of the unit cell.  Phase A runs ctm_projectors_4x4_cc for every unit, phase B ctm_absorb_x + normalisation for
+ * every unit with its own projectors (P, Pt) and those of unit `nb` (the neighbouring site along the move, ctmrg.py:351-425); no host
+ * code runs in between.  The units of a phase run concurrently, one thread of this library per worker context (`workers`: nworkers
+ * DISTINCT contexts of the same dtype as ctx, each with its own arena and stream; ctx itself is not among them); nworkers = 0: serially
+ * on ctx.  Worker streams wait for the work queued on ctx's stream when the call starts; the call returns after every stream has
+ * drained.  skip_zero_columns != 0: an absorb whose projectors (own and neighbour's) have at most chi/2 non-zero columns (S/S[0] >
+ * cfg->svd_reltol is a prefix of the descending spectrum) runs on that prefix, rounded up to a multiple of 16, and pads the result
+ * with the zeros the full product would have produced (same numbers).  All pointers: device memory, layouts as in the entries named. */
+typedef struct ctm_move_unit {
+    const double* proj[16];      /* in: tensors16 of ctm_projectors_4x4 for this site's 2x2 window */
+    int proj_adims[20];          /* in: adims4x5 */
+    double* basis;               /* in/out: warm-start workspace of this (direction, site) unit, or NULL */
+    double* corner_buf[4];       /* in/out: caller-kept enlarged corners (see ctm_projectors_4x4_cc); used when use_corner_cache != 0 */
+    int corner_valid[4];
+    int use_corner_cache;
+    const double* absorb[6];     /* in: C1, T1, T, T2, C2, A of ctm_absorb (tensors10 without the projectors) */
+    int absorb_adims[5];
+    int nb;                      /* in: index of the unit whose projectors are P1, Pt1 of this site's absorb */
+    long long n_rows;            /* in: rows of P / Pt = chi * D_cut^2 of this unit */
+    double* P; double* Pt;       /* out: n_rows x min(chi, n_rows) */
+    double* S;                   /* out: min(chi, n_rows) */
+    double* nC1; double* nC2; double* nT;   /* out: as ctm_absorb_x with chi_in = chi, chi_out = min(chi, n_rows) */
+    int ncol;                    /* out: number of non-zero projector columns of this unit */
+} ctm_move_unit;
+int ctm_move(ctm_ctx* ctx, ctm_ctx* const* workers, int nworkers, int dir, int nunits, ctm_move_unit* units, int chi,
+             const ctm_trunc_cfg* cfg, int normalize, int skip_zero_columns);
+
 /* ---- one-site C4v move (ctm/one_site_c4v/ctmrg_c4v.py:325-463; ctm_components_c4v.py:52-130) ---------- */
 int ctm_c2x2_c4v(ctm_ctx* ctx, int open, const double* a, const double* C, const double* T, int chi, int p, int D,
                  double* out);

@@ -33,6 +33,14 @@ class TruncCfg(C.Structure):
                 ("keep_multiplets", C.c_int), ("fix_signs", C.c_int)]
 
 
+class MoveUnit(C.Structure):
+    """include/ctm_hip.h: ctm_move_unit (one site of a whole-move call)."""
+    _fields_ = [("proj", C.c_void_p * 16), ("proj_adims", C.c_int * 20), ("basis", C.c_void_p), ("corner_buf", C.c_void_p * 4),
+                ("corner_valid", C.c_int * 4), ("use_corner_cache", C.c_int), ("absorb", C.c_void_p * 6), ("absorb_adims", C.c_int * 5),
+                ("nb", C.c_int), ("n_rows", C.c_longlong), ("P", C.c_void_p), ("Pt", C.c_void_p), ("S", C.c_void_p),
+                ("nC1", C.c_void_p), ("nC2", C.c_void_p), ("nT", C.c_void_p), ("ncol", C.c_int)]
+
+
 _lib = None
 
 _SIGS = {
@@ -82,6 +90,7 @@ _SIGS = {
     "ctm_rdm1x2": [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_int), C.c_void_p],
     "ctm_rdm_c4v": [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p],
     "ctm_init_piece": [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_int), C.c_void_p],
+    "ctm_move": [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.POINTER(MoveUnit), C.c_int, C.POINTER(TruncCfg), C.c_int, C.c_int],
 }
 EXPORTS = sorted(list(_SIGS) + ["ctm_last_error", "ctm_version"])
 
@@ -549,8 +558,14 @@ class Engine:
                     raise NativeError("projectors_4x4: corner buffers must be contiguous float64 device tensors")
             cb = (C.c_void_p * 4)(*[(_ptr(buf) if buf is not None else None) for buf, _ in corners])
             cv = (C.c_int * 4)(*[int(bool(v)) for _, v in corners])
-        self._ck(self.lib.ctm_projectors_4x4_cc(self.h, d, arr, chi, ad, C.byref(cfg), _ptr(P), _ptr(Pt), _ptr(S),
-                                                _ptr(basis) if basis is not None else None, cb, cv), "projectors_4x4")
+        st = self.lib.ctm_projectors_4x4_cc(self.h, d, arr, chi, ad, C.byref(cfg), _ptr(P), _ptr(Pt), _ptr(S),
+                                            _ptr(basis) if basis is not None else None, cb, cv)
+        if st == 5:
+            # the entry's shape check (before any kernel): the reference only asserts R.shape == Rt.shape (ctm_projectors.py:209); this
+            # engine truncates SQUARE halves -- the two bonds a cut crosses must have the same dimension
+            msg = self.lib.ctm_last_error(self.h)
+            raise ValueError("ctm_get_projectors_4x4: " + (msg.decode() if msg else "unsupported shapes"))
+        self._ck(st, "projectors_4x4")
         return (P, Pt, S) if return_S else (P, Pt)
 
     # axis of the NEW (truncated) bond in nC1 / nC2 per direction (output index order of the absorb contractions)
@@ -573,6 +588,63 @@ class Engine:
         nC1, nC2, nT = self.empty(*cs(n1)), self.empty(*cs(n2)), self.empty(*shapes[d])
         self._ck(self.lib.ctm_absorb_x(self.h, d, arr, chi_in, chi_out, self._adims(A), int(normalize), _ptr(nC1), _ptr(nC2), _ptr(nT)), "absorb")
         return nC1, nC2, nT
+
+    def move(self, direction, units, chi, cfg=None, normalize=1, skip_zero_columns=False, workers=()):
+        """One whole directional move in ONE native call (ctm_move): units = list of dicts, one per site, with
+        "t16" (projector window, as projectors_4x4), "basis" (or None), "corners" (list of four (buffer, valid) or None),
+        "absorb6" (C1, T1, T, T2, C2, A of the site's absorb) and "nb" (index of the neighbour unit along the move).
+        workers: engines (own contexts and streams) on which the units of a phase run concurrently; () = serially on this engine.
+        Returns per unit (P, Pt, S, nC1, nC2, nT, ncol)."""
+        d = DIR_INDEX[direction] if isinstance(direction, tuple) else direction
+        cfg = cfg or self.default_cfg
+        arr = (MoveUnit * len(units))()
+        keep, outs = [], []
+        dtype = None
+        for i, u in enumerate(units):
+            ts, parr, ad = self._pack16(u["t16"])
+            dtype = ts[0].dtype
+            m = arr[i]
+            for j in range(16): m.proj[j] = ts[j].data_ptr()
+            for j in range(20): m.proj_adims[j] = ad[j]
+            b = u.get("basis")
+            m.basis = b.data_ptr() if b is not None else None
+            cs = u.get("corners")
+            m.use_corner_cache = 1 if cs is not None else 0
+            for j in range(4):
+                buf, valid = cs[j] if cs is not None else (None, False)
+                m.corner_buf[j] = buf.data_ptr() if buf is not None else None
+                m.corner_valid[j] = int(bool(valid))
+            a6 = [_chk_t(t, "absorb tensor", dtype) for t in u["absorb6"]]
+            for j in range(6): m.absorb[j] = a6[j].data_ptr()
+            A = a6[5]
+            for j in range(5): m.absorb_adims[j] = A.shape[j]
+            m.nb = int(u["nb"])
+            chi_env = ts[0].shape[0]
+            n = chi_env * ts[3].shape[CUT_LEG[d]] ** 2
+            kc = min(chi, n)
+            m.n_rows = n
+            D2 = A.shape[(3, 4, 1, 2)[d]] ** 2
+            shapes = {UP: (kc, D2, kc), LEFT: (kc, kc, D2), DOWN: (D2, kc, kc), RIGHT: (kc, D2, kc)}
+            cs_ = lambda new_axis: (kc, chi_env) if new_axis == 0 else (chi_env, kc)
+            n1, n2 = self.NEW_AXIS[d]
+            P, Pt, S = torch.empty((n, kc), dtype=dtype, device=self.device), torch.empty((n, kc), dtype=dtype, device=self.device), self.empty_real(kc)
+            nC1, nC2 = torch.empty(cs_(n1), dtype=dtype, device=self.device), torch.empty(cs_(n2), dtype=dtype, device=self.device)
+            nT = torch.empty(shapes[d], dtype=dtype, device=self.device)
+            m.P, m.Pt, m.S, m.nC1, m.nC2, m.nT = P.data_ptr(), Pt.data_ptr(), S.data_ptr(), nC1.data_ptr(), nC2.data_ptr(), nT.data_ptr()
+            keep.append((ts, a6))
+            outs.append([P, Pt, S, nC1, nC2, nT])
+        self._bind_dtype(dtype)
+        wh = []
+        for w in workers:
+            w._bind_dtype(dtype)
+            wh.append(w._handles[dtype])
+        warr = (C.c_void_p * max(len(wh), 1))(*[h.value for h in wh])
+        st = self.lib.ctm_move(self.h, warr, len(wh), d, len(units), arr, chi, C.byref(cfg), int(normalize), int(bool(skip_zero_columns)))
+        if st == 5:
+            msg = self.lib.ctm_last_error(self.h)
+            raise ValueError("ctm_move: " + (msg.decode() if msg else "unsupported shapes"))
+        self._ck(st, "move")
+        return [tuple(o) + (int(arr[i].ncol),) for i, o in enumerate(outs)]
 
     # ---- C4v ------------------------------------------------------------------------------------------
     def c2x2_c4v(self, a, C_, T, open_=False):

@@ -1167,11 +1167,12 @@ int matop_apply(ctm_ctx* ctx, const MatOp& op, bool transpose, const double* B, 
 // to the Krylov solver (each one quadruples the distance to the next probe: a full-rank environment at its rounding floor, where the
 // previous basis stays ~1e-10 away from the new operator for ever, otherwise pays two half steps on k + k/2 rows every few sweeps)
 enum { HDR_SKIP = 0, HDR_STEPS = 1, HDR_EST = 2, HDR_FAILS = 3, HDR_BLOCK = 4,      // (HDR_BLOCK: block size the remembered step count belongs to)
-       // stationary fast path (svd_stationary, option "warm_accept_tol"): [5] how far the previous basis lay outside the subspace of the last
-       // solve (or the residual / s_0 the last accepted Rayleigh-Ritz measured), 0 = unknown; [6] which side the workspace rows hold
+       // stationary fast path (svd_stationary, option "warm_accept_tol"): [5] how far the normalised singular values moved between the last two
+       // solves (spectrum_movement; a lower bound on the movement of the operator), 0 = unknown; [6] which side the workspace rows hold
        // (0: right vectors, 1: left vectors); [7] accepted Rayleigh-Ritz calls since the last full solve; [8] calls left that do not try
        // the fast path after a rejection; [9] consecutive rejections
-       HDR_DIST = 5, HDR_SIDE = 6, HDR_RUN = 7, HDR_SSKIP = 8, HDR_SFAILS = 9, HDR_WORDS = 10 };
+       HDR_DIST = 5, HDR_SIDE = 6, HDR_RUN = 7, HDR_SSKIP = 8, HDR_SFAILS = 9, HDR_WORDS = 10,
+       HDR_SPREV = 16 /* from here: the k singular values of the previous solve (spectrum_movement) */ };
 
 inline int warm_skip_calls(const ctm_ctx* ctx, double r) {
     const int need = (int)std::ceil(2.0 * std::log(std::max(r, 1e-9) / 1e-9) / std::log(5.0)) - 1;
@@ -2900,29 +2901,26 @@ int svd_stationary(ctm_ctx* ctx, const MatOp& op, int k, int side0, double* S, d
     return CTM_OK;
 }
 
-// How far the rows of `old_rows` (kd x n, orthonormal if valid) lie outside the span of the orthonormal rows `new_rows` (k x n):
-// |W - (W X^T) X|_F / sqrt(kd); 0 when the old rows are not a basis (a fresh workspace).
-int subspace_distance(ctm_ctx* ctx, const double* old_rows, int kd, const double* new_rows, int k, int n, double* dist) {
-    *dist = 0.0;
-    ArenaScope scope(ctx);
-    double *G, *R, *nr;
-    CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)kd * k, (void**)&G));
-    CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)kd * n, (void**)&R));
-    CTM_TRY(arena_alloc(ctx, sizeof(double) * 2 * (size_t)kd, (void**)&nr));
-    CTM_TRY(row_norms(ctx, old_rows, kd, n, n, nr));
-    GemmDesc g1; g1.M = kd; g1.N = k; g1.K = n; g1.A = old_rows; g1.sam = n; g1.sak = 1; g1.B = new_rows; g1.sbk = 1; g1.sbn = n; g1.C = G; g1.ldc = k;
-    CTM_TRY(gemm_f64(ctx, g1));
-    CTM_TRY(copy2d(ctx, old_rows, n, R, n, kd, n));
-    GemmDesc g2; g2.M = kd; g2.N = n; g2.K = k; g2.A = G; g2.sam = k; g2.sak = 1; g2.B = new_rows; g2.sbk = n; g2.sbn = 1; g2.C = R; g2.ldc = n;
-    g2.alpha = -1.0; g2.beta = 1.0;
-    CTM_TRY(gemm_f64(ctx, g2));
-    CTM_TRY(row_norms(ctx, R, kd, n, n, nr + kd));
-    std::vector<double> h(2 * (size_t)kd);
-    CTM_HIP_CHECK(ctx, hipMemcpyAsync(h.data(), nr, sizeof(double) * 2 * kd, hipMemcpyDeviceToHost, ctx->stream));
+// How far a unit's operator moved since its previous solve, measured on what both solves share without further operator
+// applications: the singular values.  |s_i - s_i^prev| <= |M - M^prev|_2 (Weyl), so max_i |ds_i| / s_0 is a LOWER bound on the relative
+// movement of the operator -- and in a converging CTM run, where the operator changes by a smooth perturbation, also its order of
+// magnitude.  (A distance between the singular SUBSPACES is useless here: the vectors at the truncation boundary rotate by
+// movement / (s_k - s_{k+1}), 1e-4 and more for an operator that moved by 1e-10, while the residual of the previous triplets -- what the
+// fast path is accepted on -- is of the order of the movement itself.)  The previous values live in the header row, HDR_SPREV onwards.
+// S: device pointer to the k new values.  Writes HDR_DIST (0 = no previous values) and the new values; returns the measure.
+int spectrum_movement(ctm_ctx* ctx, double* hdr_row, int n, const double* S, int k, double* moved) {
+    *moved = 0.0;
+    if (n < HDR_SPREV + k) return CTM_OK;
+    std::vector<double> h(2 * (size_t)k);
+    CTM_HIP_CHECK(ctx, hipMemcpyAsync(h.data(), S, sizeof(double) * k, hipMemcpyDeviceToHost, ctx->stream));
+    CTM_HIP_CHECK(ctx, hipMemcpyAsync(h.data() + k, hdr_row + HDR_SPREV, sizeof(double) * k, hipMemcpyDeviceToHost, ctx->stream));
     CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-    double r2 = 0.0;
-    for (int i = 0; i < kd; ++i) { if (std::fabs(h[i] - 1.0) > 1e-6) return CTM_OK; r2 += h[kd + i] * h[kd + i]; }
-    *dist = std::max(std::sqrt(r2 / kd), 1e-300);
+    if (h[k] > 0.0 && h[0] > 0.0) {
+        double d = 0.0;
+        for (int i = 0; i < k; ++i) d = std::max(d, std::fabs(h[i] / h[0] - h[k + i] / h[k]));      // (normalised: the move's own normalisation rescales the operator)
+        *moved = std::max(d, 1e-300);
+    }
+    CTM_HIP_CHECK(ctx, hipMemcpyAsync(hdr_row + HDR_SPREV, S, sizeof(double) * k, hipMemcpyDeviceToDevice, ctx->stream));
     return CTM_OK;
 }
 
@@ -2940,8 +2938,7 @@ int jacobi_svd_top_op(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* U
     auto keep_warm_dist = [&](const double* hdr_old) -> int {
         if (op.warm && op.warm_hdr && !op.M && !(op.Mi || op.ci[0]) && (ctx->warm_accept_tol > 0.0 || hdr_old[HDR_SIDE] >= 1.0)) {
             double dist = 0.0;
-            const int kd = std::max(1, k - 8);           // (the last few rows sit at the truncation boundary: nearly degenerate neighbours swap freely)
-            if (ctx->warm_accept_tol > 0.0) CTM_TRY(subspace_distance(ctx, op.warm, kd, hdr_old[HDR_SIDE] >= 1.0 ? Ut : Vt, k, n, &dist));
+            if (ctx->warm_accept_tol > 0.0) CTM_TRY(spectrum_movement(ctx, op.warm_hdr, n, S, k, &dist));
             const double w[5] = {dist, 0.0, 0.0, hdr_old[HDR_SSKIP], hdr_old[HDR_SFAILS]};     // HDR_DIST, HDR_SIDE, HDR_RUN, HDR_SSKIP, HDR_SFAILS
             CTM_HIP_CHECK(ctx, hipMemcpyAsync(op.warm_hdr + HDR_DIST, w, sizeof(w), hipMemcpyHostToDevice, ctx->stream));
             CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
@@ -3020,7 +3017,9 @@ int jacobi_svd_top_op(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* U
                     bool acc = false; double rr = 0.0;
                     CTM_TRY(svd_stationary(ctx, op, k, hdr[HDR_SIDE] >= 1.0 ? 1 : 0, S, Ut, Vt, &acc, &rr));
                     if (acc) {
-                        const double w[5] = {std::max(rr, 1e-300), hdr[HDR_SIDE] >= 1.0 ? 0.0 : 1.0, hdr[HDR_RUN] + 1.0, 0.0, 0.0};
+                        double mv = 0.0;
+                        CTM_TRY(spectrum_movement(ctx, op.warm_hdr, n, S, k, &mv));
+                        const double w[5] = {std::max(mv, 1e-300), hdr[HDR_SIDE] >= 1.0 ? 0.0 : 1.0, hdr[HDR_RUN] + 1.0, 0.0, 0.0};
                         CTM_HIP_CHECK(ctx, hipMemcpyAsync(op.warm_hdr + HDR_DIST, w, sizeof(w), hipMemcpyHostToDevice, ctx->stream));
                         CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
                         ctx->warm_accepts += 1; ctx->warm_last_dist = rr;

@@ -29,6 +29,33 @@ def _trunc_cfg(eng, ctm_args):
                    multiplet_abstol=ctm_args.projector_multiplet_abstol, keep_multiplets=True)
 
 
+def _unit_inputs(eng, direction, coord, state, env, ctm_args):
+    """What one (direction, site) projector unit of the fused path takes: the 16 tensors of its 2x2 window, its warm-start workspace
+    (kept with the environment) and its cached enlarged corners ([(buffer, valid)] * 4 or None, plus the cache entries to store once
+    the unit has run)."""
+    t16 = _halves_t(direction, coord, state, env)
+    basis = None
+    if getattr(ctm_args, "projector_warm_start", True) and hasattr(eng, "warm_basis"):
+        a = t16[3]
+        n = env.chi * a.shape[{(0, -1): 2, (-1, 0): 3, (0, 1): 4, (1, 0): 1}[direction]] ** 2     # truncated bond chi * D_cut^2
+        ws = env.__dict__.setdefault("_warm", {})
+        key = (direction, coord)
+        k = env.chi + 1 if env.chi < n else n
+        b = ws.get(key)
+        if b is None or b.shape[1] != n or b.shape[0] != (2 if a.dtype.is_complex else 1) * k + 1 or b.device != a.device:
+            b = ws[key] = eng.warm_basis(env.chi, n, a.dtype)
+        basis = b
+    corners, fresh = _cached_corners(eng, direction, coord, state, env, t16, ctm_args)
+    return t16, basis, corners, fresh
+
+
+def _sync_warm_tol(eng, ctm_args):
+    wtol = float(getattr(ctm_args, "projector_warm_tol", 0.0) or 0.0)
+    if getattr(eng, "_warm_tol", 0.0) != wtol and hasattr(eng, "set_option"):      # (per engine: the units of a move run on worker engines)
+        eng.set_option("warm_accept_tol", wtol)
+        eng._warm_tol = wtol
+
+
 def ctm_get_projectors_4x4(direction, coord, state, env, ctm_args=cfg.ctm_args, global_args=cfg.global_args,
                            diagnostics=None):
     if direction not in [(0, -1), (-1, 0), (0, 1), (1, 0)]:
@@ -41,23 +68,8 @@ def ctm_get_projectors_4x4(direction, coord, state, env, ctm_args=cfg.ctm_args, 
         # fused native path: corners -> implicit M = R^T Rt -> P, Pt (halves never materialised).  The environment
         # remembers, per (direction, site), the right singular basis of the previous sweep: the leading-chi iteration of
         # the next sweep starts from it (residual-verified either way; `projector_warm_start=False` disables it).
-        t16 = _halves_t(direction, coord, state, env)
-        basis = None
-        if getattr(ctm_args, "projector_warm_start", True) and hasattr(eng, "warm_basis"):
-            a = t16[3]
-            n = env.chi * a.shape[{(0, -1): 2, (-1, 0): 3, (0, 1): 4, (1, 0): 1}[direction]] ** 2     # truncated bond chi * D_cut^2
-            ws = env.__dict__.setdefault("_warm", {})
-            key = (direction, coord)
-            k = env.chi + 1 if env.chi < n else n
-            b = ws.get(key)
-            if b is None or b.shape[1] != n or b.shape[0] != (2 if a.dtype.is_complex else 1) * k + 1 or b.device != a.device:
-                b = ws[key] = eng.warm_basis(env.chi, n, a.dtype)
-            basis = b
-        corners, fresh = _cached_corners(eng, direction, coord, state, env, t16, ctm_args)
-        wtol = float(getattr(ctm_args, "projector_warm_tol", 0.0) or 0.0)
-        if getattr(eng, "_warm_tol", 0.0) != wtol and hasattr(eng, "set_option"):      # (per engine: the units of a move run on worker engines)
-            eng.set_option("warm_accept_tol", wtol)
-            eng._warm_tol = wtol
+        t16, basis, corners, fresh = _unit_inputs(eng, direction, coord, state, env, ctm_args)
+        _sync_warm_tol(eng, ctm_args)
         P, Pt, S = eng.projectors_4x4(direction, t16, env.chi, _trunc_cfg(eng, ctm_args), return_S=True, basis=basis, corners=corners)
         for key, entry in fresh:                  # only after the call succeeded: the buffers now hold these corners
             env.__dict__["_corner_cache"][key] = entry

@@ -14,7 +14,7 @@ import torch
 import config as cfg
 from backend import get_engine
 import parallel
-from ctm.generic.ctm_projectors import ctm_get_projectors_4x4, ctm_get_projectors_4x2, _trunc_cfg
+from ctm.generic.ctm_projectors import ctm_get_projectors_4x4, ctm_get_projectors_4x2, _trunc_cfg, _unit_inputs, _sync_warm_tol
 from ctm.generic.ctm_components import _halves_t
 
 log = logging.getLogger(__name__)
@@ -179,6 +179,37 @@ def ctm_MOVE(direction, state, env, ctm_args=cfg.ctm_args, global_args=cfg.globa
 
     def _each(fn, items, stagger=0.0):
         return pool.map(fn, items, stagger=stagger) if pool is not None else [fn(it) for it in items]
+
+    if getattr(ctm_args, "native_move", True) and ctm_args.projector_method == '4X4' and hasattr(eng, "move") and not parallel.is_distributed() \
+            and float(getattr(ctm_args, "unit_stagger_ms", 0.0)) == 0.0:
+        # the whole move in ONE native call (ctm_move, include/ctm_hip.h; reference seam ctm_MOVE_c, ctmrg.py:233-283): both phases and
+        # the threads that overlap their units live in the library, on the worker contexts of the device's unit pool
+        workers = pool.engines() if pool is not None else ()
+        for e in (eng,) + tuple(workers):
+            _sync_warm_tol(e, ctm_args)
+        index = {c: i for i, c in enumerate(coords)}
+        ulist, fresh_all = [], []
+        for c in coords:
+            t16, basis, corners, fresh = _unit_inputs(eng, direction, c, state, env, ctm_args)
+            vecs, sh = _ABS[direction]
+            site = state.vertexToSite(c)
+            nb = state.vertexToSite((c[0] + sh[0], c[1] + sh[1]))
+            a6 = (env.C[(site, vecs[0])], env.T[(site, vecs[1])], env.T[(site, vecs[2])], env.T[(site, vecs[3])], env.C[(site, vecs[4])], state.site(c))
+            ulist.append({"t16": t16, "basis": basis, "corners": corners, "absorb6": a6, "nb": index[nb]})
+            fresh_all += fresh
+        res = eng.move(direction, ulist, chi, _trunc_cfg(eng, ctm_args), normalize=norm_kind,
+                       skip_zero_columns=env.__dict__.get("_ncol") is not None, workers=workers)
+        for key, entry in fresh_all:                  # only after the call succeeded: the buffers now hold these corners
+            env.__dict__["_corner_cache"][key] = entry
+        if env.__dict__.get("_ncol") is not None:
+            for c, r in zip(coords, res):
+                env.__dict__["_ncol"][(direction, state.vertexToSite(c))] = r[6]
+        env.__dict__["_krylov_units"] = eng.stat("lz_hits") > lz_before
+        r1, r2 = _REL[direction]
+        for coord, r in zip(coords, res):
+            nc = state.vertexToSite((coord[0] - direction[0], coord[1] - direction[1]))
+            env.C[(nc, r1)], env.C[(nc, r2)], env.T[(nc, direction)] = r[3], r[4], r[5]
+        return
 
     # phase A: projectors of my sites from the old env
     ownersA, mineA = None, mine

@@ -44,6 +44,18 @@ class UnitPool:
                         return slot
                 self.cv.wait()
 
+    def ensure(self, n):
+        """Streams and worker engines of the first n slots (for callers that hand the contexts to the library: Engine.move)."""
+        with self.cv:
+            while len(self.streams) < n:
+                self.streams.append(torch.cuda.Stream(self.device)); self.engines.append(None)
+            for slot in range(n):
+                if self.engines[slot] is None:
+                    with torch.cuda.device(self.device), torch.cuda.stream(self.streams[slot]):
+                        self.engines[slot] = self.main.spawn_worker()
+                        backend.register_stream_engine(self.streams[slot], self.engines[slot])
+            return self.engines[:n]
+
     def _give(self, slot):
         with self.cv:
             self.busy.discard(slot)
@@ -98,6 +110,9 @@ class PoolView:
 
     def map(self, fn, items, stagger=0.0):
         return self.pool.map(fn, items, self.n, stagger=stagger)
+
+    def engines(self):
+        return self.pool.ensure(self.n)
 
 
 _pools = {}

@@ -8,7 +8,8 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-FLAGS = ["--config", "generic_D6_chi128", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-other-configs", "--no-energy", "--no-live-traffic"]
+FLAGS = ["--config", "generic_D6_chi128", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-other-configs", "--no-energy", "--no-live-traffic",
+         "--no-serial-pass", "--no-stationary"]      # (both add sweeps to the single-process run only: the environments would differ by them)
 
 
 def _bench(n):

@@ -263,6 +263,37 @@ def test_absorb_of_nonzero_projector_prefix_is_identical(eng):
     for k in envs[0].T: assert torch.equal(envs[0].T[k], envs[1].T[k]), k
 
 
+@pytest.mark.parametrize("cplx", [False, True], ids=["f64", "c128"])
+@pytest.mark.parametrize("positive", [True, False], ids=["masked-columns", "full-rank"])
+def test_whole_move_in_one_native_call_equals_the_unit_by_unit_move(eng, cplx, positive):
+    """ctm_move (include/ctm_hip.h; reference seam ctm_MOVE_c, ctm/generic/ctmrg.py:233-283): both phases of a move and the threads
+    that overlap their units inside the library -- against the host-orchestrated move (one native call per unit), three sweeps,
+    bit for bit; with concurrent worker contexts and serially; with the masked-column absorb (positive tensors) and without."""
+    import copy
+    import config as cfg
+    from ipeps.ipeps import IPEPS
+    from ctm.generic.env import ENV, init_env
+    from ctm.generic import ctmrg
+    rng = np.random.default_rng(31)
+    mk = (lambda: rng.random((2, 3, 3, 3, 3)) - (0.0 if positive else 0.5))
+    sites = {(x, y): (mk() + (1j * mk() if cplx else 0)) for x in range(2) for y in range(2)}
+    envs = []
+    for native, conc in ((True, True), (True, False), (False, True)):
+        st = IPEPS({k: dev(v / np.abs(v).max()) for k, v in sites.items()})
+        env = ENV(40, st); init_env(st, env)
+        args = copy.deepcopy(cfg.ctm_args); args.native_move = native; args.concurrent_units = conc; args.absorb_skip_min_n = 0
+        for _ in range(3):
+            for d in args.ctm_move_sequence:
+                for _r in range(2):
+                    ctmrg.ctm_MOVE(d, st, env, ctm_args=args)
+        envs.append(env)
+    nc = envs[0].__dict__.get("_ncol")
+    assert (bool(nc) and max(nc.values()) <= 20) == positive                 # the compact absorb ran exactly in the low-rank case
+    for other in envs[1:]:
+        for k in envs[0].C: assert torch.equal(envs[0].C[k], other.C[k]), k
+        for k in envs[0].T: assert torch.equal(envs[0].T[k], other.T[k]), k
+
+
 def test_rdm2x2_from_parts_equals_the_whole(case, eng):
     """ctm_rdm2x2_part: the plaquette contraction split over ranges of lower-half slices (what a rank group shares, and what one
     GPU loops over when the open halves do not fit) reassembles to ctm_rdm2x2 exactly; and the host layer's chunked path gives

@@ -10,10 +10,11 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("cplx", [False, True], ids=["f64", "c128"])
-@pytest.mark.parametrize("D,chi", [(2, 5), (3, 7), (4, 6), (5, 9), (6, 8), (7, 5), (8, 6)])
+@pytest.mark.parametrize("D,chi", [(2, 5), (3, 7), (4, 6), (5, 9), (6, 8), (7, 5), (8, 6), (9, 4), (10, 3)])
 def test_corners_and_absorb_all_bond_dims(eng, D, chi, cplx):
     """c2x2 (4 corners, closed + open), the C4v corner and one absorb per direction for every D (fused kernel
-    variants KT=1..4 incl. zero padding 25->32, 36->48, 49->64) vs the oracle."""
+    variants KT=1..4 incl. zero padding 25->32, 36->48, 49->64) vs the oracle.  D = 9, 10: beyond the fused two-layer kernel
+    (csrc/layer2.hip: layer2_roles refuses legs > 8) -- the executor's pairwise permute + GEMM route (csrc/contract.hip)."""
     from oracle import ctm_oracle as O, c4v_oracle as O4
     rng = np.random.default_rng(100 * D + chi)
     rnd = (lambda *s_: rng.standard_normal(s_) + 1j * rng.standard_normal(s_)) if cplx else (lambda *s_: rng.standard_normal(s_))
@@ -300,3 +301,57 @@ def test_absorb_with_different_environment_and_projector_dimensions(eng, name, c
             for x, y in zip(got, want):
                 assert tuple(x.shape) == y.shape
                 assert relerr(x, y) < 1e-12
+
+
+def test_one_move_beyond_the_fused_kernel(eng):
+    """D = 9 (n = chi D^2 = 486): one whole directional move of a 1x1 cell -- corners by the pairwise route, fused and explicit
+    projector paths, absorb -- against the oracle."""
+    from ipeps.ipeps import IPEPS
+    from ctm.generic.env import ENV, init_env
+    from ctm.generic import ctmrg
+    from ctm.generic.ctm_components import _halves_t
+    from oracle import ctm_oracle as O
+    D, chi = 9, 6
+    rng = np.random.default_rng(99)
+    a = rng.random((2, D, D, D, D)) - 0.4
+    sites = {(0, 0): a / np.abs(a).max()}
+    st = IPEPS({k: dev(v) for k, v in sites.items()}, lX=1, lY=1)
+    env = ENV(chi, st); init_env(st, env)
+    ost = O.State(sites, lX=1, lY=1); oe = O.init_env_ctmrg(ost, chi)
+    for k in oe.C: assert relerr(env.C[k], oe.C[k]) < 1e-12
+    for k in oe.T: assert relerr(env.T[k], oe.T[k]) < 1e-12
+    d = (0, -1)
+    t16 = _halves_t(d, (0, 0), st, env)
+    R, Rt = eng.halves(d, t16)
+    Ro, Rto = O.halves(d, (0, 0), ost, oe)
+    assert relerr(R, Ro) < 1e-11 and relerr(Rt, Rto) < 1e-11
+    P2, Pt2, S2 = eng.projectors_4x4(d, t16, chi, return_S=True)
+    Po, Pto, So = O.projectors_from_matrices(Ro, Rto, chi, return_S=True)
+    assert relerr(S2, So) < 1e-11
+    assert relerr(P2 @ Pt2.t(), Po @ Pto.T) < 1e-6
+    ctmrg.ctm_MOVE(d, st, env)
+    O.ctm_move(d, ost, oe)
+    spec = env.get_spectra(); ospec = O.corner_spectra(oe)
+    for k in ospec: assert np.abs(spec[k].cpu().numpy() - ospec[k]).max() < 1e-9, k
+    for k in oe.T: assert relerr(env.T[k].abs(), np.abs(oe.T[k])) < 1e-7, k
+
+
+def test_bond_dimensions_that_differ_along_one_cut_are_refused_by_name(eng):
+    """The reference only asserts R.shape == Rt.shape (ctm/generic/ctm_projectors.py:209): horizontal bonds of dimension 2 in the upper row
+    and 3 in the lower row make the halves of an UP / DOWN move rectangular (n0 = chi 2^2, n1 = chi 3^2).  The engine truncates square
+    halves only; the host layer says so with a ValueError that names the limitation, raised by the entry's own shape check before any
+    kernel runs.  LEFT / RIGHT moves of the same state (vertical bonds all equal) go through."""
+    from ipeps.ipeps import IPEPS
+    from ctm.generic.env import ENV, init_env
+    from ctm.generic.ctm_projectors import ctm_get_projectors_4x4
+    rng = np.random.default_rng(3)
+    chi = 5
+    sites = {(x, y): dev(rng.random((2, 2, 2 + y, 2, 2 + y)) - 0.3) for y in range(2) for x in range(2)}     # a[p,u,l,d,r]: l = r = 2 (row 0), 3 (row 1)
+    st = IPEPS(sites)
+    env = ENV(chi, st); init_env(st, env)
+    for d in [(0, -1), (0, 1)]:
+        with pytest.raises(ValueError, match="differ along one cut"):
+            ctm_get_projectors_4x4(d, (0, 0), st, env)
+    for d in [(-1, 0), (1, 0)]:
+        P, Pt = ctm_get_projectors_4x4(d, (0, 0), st, env)
+        assert torch.isfinite(P).all() and torch.isfinite(Pt).all()
