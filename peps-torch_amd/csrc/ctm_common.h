@@ -195,7 +195,9 @@ struct ctm_ctx {
     alignas(8) unsigned char orth_cur_storage[64] = {0};      // adaptive state of the symmetric orthogonal iteration for the workspace of the CURRENT call (jacobi.hip: OrthState)
     // stationary fast path of the implicit-operator truncation (jacobi.hip: svd_stationary).  0 = off: every truncation is solved to resid_tol
     double warm_accept_tol = 0.0;        // accept one Rayleigh-Ritz half step from the previous basis when its residual is <= this x s_0
-    double warm_try_factor = 3.0;        // ... tried when the previous basis lay within this x warm_accept_tol of the last solve's subspace
+    double warm_try_factor = 1e-4;       // ... tried when the unit's normalised singular values moved by at most this x warm_accept_tol between its last two solves (a
+                                         // LOWER bound on the movement of the operator: measured on signed D = 6 chi = 128, the residual of the previous triplets passes
+                                         // 1e-9 s_0 once the values are stationary to ~1e-13; a refused attempt costs a fifth of a solve and backs off x2)
     int warm_accept_max_run = 32;        // ... at most this many accepted calls of a unit between two full solves (0: no limit)
     long warm_accepts = 0, warm_rejects = 0;
     double warm_last_dist = 0.0;

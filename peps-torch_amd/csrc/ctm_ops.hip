@@ -12,17 +12,38 @@ namespace {
 // ---------------------------------------------------------------------------------------------
 // fix_svd_signs (svd_gesdd.py:18-26) on row-stored factors: Ut, Vt are k x n; one workgroup per row:
 // argmax of the int64-quantised |U| (first occurrence), then both rows are multiplied by its sign.
-__global__ void fix_signs_rows_kernel(double* Ut, double* Vt, int k, int n, double* X1, double* X2) {
+// ref (optional, k x n): the rows this decomposition's predecessor returned for the same unit (left rows if ref_left, else right rows).
+// A row that still points along its predecessor (|cos| > 1/2) takes the predecessor's orientation instead of the argmax rule: the rule
+// flips a vector whenever two of its components of almost equal magnitude swap rank, i.e. it re-gauges legs of a CONVERGED environment
+// by signs from sweep to sweep (measured: singular values stationary to 1e-15, previous vectors with residual 3e-2 s_0) -- harmless for
+// every gauge-invariant quantity, fatal for restarting from the previous basis (stationary fast path, ctm_args.projector_warm_tol).
+__global__ void fix_signs_rows_kernel(double* Ut, double* Vt, int k, int n, double* X1, double* X2, const double* ref = nullptr, int ref_left = 0) {
     const int r = blockIdx.x;
     if (r >= k) return;
     double* u = Ut + (size_t)r * n;
     double* v = Vt + (size_t)r * n;
+    __shared__ long long sb[256]; __shared__ int si[256];
+    __shared__ double sd[3][256];
+    __shared__ double s_sg;
+    if (threadIdx.x == 0) s_sg = 0.0;
+    if (ref) {
+        const double* x = ref_left ? u : v; const double* y = ref + (size_t)r * n;
+        double d = 0.0, xx = 0.0, yy = 0.0;
+        for (int c = threadIdx.x; c < n; c += blockDim.x) { d += x[c] * y[c]; xx += x[c] * x[c]; yy += y[c] * y[c]; }
+        sd[0][threadIdx.x] = d; sd[1][threadIdx.x] = xx; sd[2][threadIdx.x] = yy;
+        __syncthreads();
+        for (int s = blockDim.x / 2; s > 0; s >>= 1) {
+            if (threadIdx.x < s) for (int q = 0; q < 3; ++q) sd[q][threadIdx.x] += sd[q][threadIdx.x + s];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0 && sd[0][0] * sd[0][0] > 0.25 * sd[1][0] * sd[2][0]) s_sg = sd[0][0] < 0.0 ? -1.0 : 1.0;
+    }
+    __syncthreads();
     long long best = -1; int bi = 0;
     for (int c = threadIdx.x; c < n; c += blockDim.x) {
         const long long a = (long long)(fabs(u[c]) * 1099511627776.0);   // 2^40
         if (a > best) { best = a; bi = c; }                                 // strided scan keeps the first max per thread
     }
-    __shared__ long long sb[256]; __shared__ int si[256];
     sb[threadIdx.x] = best; si[threadIdx.x] = bi;
     __syncthreads();
     for (int s = blockDim.x / 2; s > 0; s >>= 1) {
@@ -33,7 +54,7 @@ __global__ void fix_signs_rows_kernel(double* Ut, double* Vt, int k, int n, doub
         __syncthreads();
     }
     const double ph = u[si[0]];
-    const double sg = (ph < 0.0) ? -1.0 : 1.0;
+    const double sg = (s_sg != 0.0) ? s_sg : ((ph < 0.0) ? -1.0 : 1.0);
     __syncthreads();
     if (sg < 0.0) {
         for (int c = threadIdx.x; c < n; c += blockDim.x) { u[c] = -u[c]; v[c] = -v[c]; }
@@ -174,6 +195,19 @@ struct TruncOut { std::vector<double> S; int keep_last; int k; };
 int svd_rows_op(ctm_ctx* ctx, const MatOp& op, int chi, const ctm_trunc_cfg& cfg, double* Ut, double* Vt, double* dS, TruncOut* to) {
     const int n = op.n;
     const int k = (chi < n) ? chi + 1 : n;
+    // stationary fast path enabled: the orientation of the returned vectors follows the previous decomposition of this unit (see
+    // fix_signs_rows_kernel), whose sign-fixed rows the workspace holds -- kept aside, the solver overwrites them
+    ArenaScope ref_scope(ctx);
+    double* ref = nullptr; int ref_left = 0;
+    const bool follow = ctx->warm_accept_tol > 0.0 && !ctx->cplx && op.warm && op.warm_hdr && !op.M && cfg.fix_signs && k < n;
+    if (follow) {
+        double side = 0.0;
+        CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)k * n, (void**)&ref));
+        CTM_HIP_CHECK(ctx, hipMemcpyAsync(ref, op.warm, sizeof(double) * (size_t)k * n, hipMemcpyDeviceToDevice, ctx->stream));
+        CTM_HIP_CHECK(ctx, hipMemcpyAsync(&side, op.warm_hdr + 6 /* HDR_SIDE, jacobi.hip */, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        ref_left = side >= 1.0 ? 1 : 0;
+    }
     CTM_TRY(jacobi_svd_top_op(ctx, op, k, dS, Ut, Vt));
     to->S.resize(k); to->k = k;
     CTM_HIP_CHECK(ctx, hipMemcpyAsync(to->S.data(), dS, sizeof(double) * k, hipMemcpyDeviceToHost, ctx->stream));
@@ -184,7 +218,14 @@ int svd_rows_op(ctm_ctx* ctx, const MatOp& op, int chi, const ctm_trunc_cfg& cfg
         if (ctx->cplx) CTM_LAUNCH(ctx, fix_phase_rows_c_kernel, dim3(kf), dim3(256), 0, Ut, Ut + kn, Vt, Vt + kn, kf, n);
         else {
             const bool mids = op.have_mid && *op.have_mid;
-            CTM_LAUNCH(ctx, fix_signs_rows_kernel, dim3(kf), dim3(256), 0, Ut, Vt, kf, n, mids ? op.out_uR : (double*)nullptr, mids ? op.out_vRt : (double*)nullptr);
+            CTM_LAUNCH(ctx, fix_signs_rows_kernel, dim3(kf), dim3(256), 0, Ut, Vt, kf, n, mids ? op.out_uR : (double*)nullptr, mids ? op.out_vRt : (double*)nullptr,
+                       (const double*)ref, ref_left);
+            if (follow) {      // the workspace keeps the rows AS RETURNED (their orientation is the next call's reference)
+                double side = 0.0;
+                CTM_HIP_CHECK(ctx, hipMemcpyAsync(&side, op.warm_hdr + 6, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+                CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+                CTM_HIP_CHECK(ctx, hipMemcpyAsync(op.warm, side >= 1.0 ? Ut : Vt, sizeof(double) * (size_t)kf * n, hipMemcpyDeviceToDevice, ctx->stream));
+            }
         }
     }
     const int kc = std::min(chi, n);

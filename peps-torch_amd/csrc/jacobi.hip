@@ -2812,7 +2812,7 @@ int svd_lanczos_c(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* Ut, d
 int svd_stationary(ctm_ctx* ctx, const MatOp& op, int k, int side0, double* S, double* Ut, double* Vt, bool* accepted, double* resid_rel) {
     *accepted = false; *resid_rel = 0.0;
     const int n = op.n, b = 32;
-    const int p = ((k + 8 + 63) / 64) * 64;
+    const int p = ((k + 32 + 63) / 64) * 64, ng = 32;          // 32 orthonormal guard rows, zero rows up to the panel pairs of the Jacobi
     if (p >= n / 2 || op.M || !op.warm) return CTM_OK;
     const bool want_mid = op.out_uR && op.out_vRt && op.have_mid;
     ArenaScope scope(ctx);
@@ -2827,20 +2827,25 @@ int svd_stationary(ctm_ctx* ctx, const MatOp& op, int k, int side0, double* S, d
     CTM_TRY(arena_alloc(ctx, sizeof(double) * p, (void**)&res));
     CTM_TRY(arena_alloc(ctx, sizeof(double) * p, (void**)&dS));
     CTM_TRY(arena_alloc(ctx, sizeof(int) * p, (void**)&d_idx));
-    // start block: the previous rows and guard rows in their orthogonal complement
+    // start block: the previous rows, ng pseudo-random guard rows made ORTHONORMAL in their orthogonal complement (the trial basis of a
+    // single Rayleigh-Ritz step must be orthonormal: rows of norm 9 inflate the Ritz values of everything they are rotated with --
+    // measured: residual 1e-5 s_0 on the very operator the basis came from, 8e-16 with this), zero rows behind them
     CTM_TRY(copy2d(ctx, op.warm, n, B0, n, k, n));
     {
         double* Rn = B0 + (size_t)k * n;
-        const int pr = p - k;
-        CTM_LAUNCH(ctx, hash_fill_kernel, dim3(1024), dim3(256), 0, Rn, pr, n, (long long)n, 0x7e57ab1eULL + (unsigned long long)ctx->warm_accepts);
+        CTM_TRY(fill_f64(ctx, Rn, (size_t)(p - k) * n, 0.0));
+        CTM_LAUNCH(ctx, hash_fill_kernel, dim3(1024), dim3(256), 0, Rn, ng, n, (long long)n, 0x7e57ab1eULL + (unsigned long long)ctx->warm_accepts);
         ArenaScope ws(ctx);
         double* Gw;
-        CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)pr * k, (void**)&Gw));
-        GemmDesc g1; g1.M = pr; g1.N = k; g1.K = n; g1.A = Rn; g1.sam = n; g1.sak = 1; g1.B = B0; g1.sbk = 1; g1.sbn = n; g1.C = Gw; g1.ldc = k;
-        CTM_TRY(gemm_f64(ctx, g1));
-        GemmDesc g2; g2.M = pr; g2.N = n; g2.K = k; g2.A = Gw; g2.sam = k; g2.sak = 1; g2.B = B0; g2.sbk = n; g2.sbn = 1; g2.C = Rn; g2.ldc = n;
-        g2.alpha = -1.0; g2.beta = 1.0;
-        CTM_TRY(gemm_f64(ctx, g2));
+        CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)ng * k, (void**)&Gw));
+        for (int rep = 0; rep < 2; ++rep) {
+            GemmDesc g1; g1.M = ng; g1.N = k; g1.K = n; g1.A = Rn; g1.sam = n; g1.sak = 1; g1.B = B0; g1.sbk = 1; g1.sbn = n; g1.C = Gw; g1.ldc = k;
+            CTM_TRY(gemm_f64(ctx, g1));
+            GemmDesc g2; g2.M = ng; g2.N = n; g2.K = k; g2.A = Gw; g2.sam = k; g2.sak = 1; g2.B = B0; g2.sbk = n; g2.sbn = 1; g2.C = Rn; g2.ldc = n;
+            g2.alpha = -1.0; g2.beta = 1.0;
+            CTM_TRY(gemm_f64(ctx, g2));
+            if (rep == 0) { double mn, mx; CTM_TRY(orthonormalise_block(ctx, Rn, ng, n, norms, inv, &mn, &mx)); }
+        }
     }
     // first application: side0 == 0: W = right vectors, C = W M^T (fresh side: left); side0 == 1: W = left vectors, C = W M
     CTM_TRY(matop_apply(ctx, op, side0 == 0, B0, n, p, X, ld, M1));
@@ -2890,7 +2895,14 @@ int svd_stationary(ctm_ctx* ctx, const MatOp& op, int k, int side0, double* S, d
     CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     const double worst = *std::max_element(hr.begin(), hr.end());
     *resid_rel = worst / s0;
-    if (ctx->jacobi_verbose) fprintf(stderr, "[stat] n=%d k=%d p=%d side %d  residual/s0 = %.3e (accept <= %.1e), %d Jacobi sweeps\n", n, k, p, side0, worst / s0, ctx->warm_accept_tol, ctx->last_sweeps);
+    if (ctx->jacobi_verbose) {
+        fprintf(stderr, "[stat] n=%d k=%d p=%d side %d  residual/s0 = %.3e (accept <= %.1e), %d Jacobi sweeps\n", n, k, p, side0, worst / s0, ctx->warm_accept_tol, ctx->last_sweeps);
+        if (ctx->jacobi_verbose > 1) {
+            const int wi = (int)(std::max_element(hr.begin(), hr.end()) - hr.begin());
+            fprintf(stderr, "[stat]   worst row %d (source row %d, s/s0 = %.3e); res/s0 at 0,1,k/2,k-2,k-1: %.2e %.2e %.2e %.2e %.2e; s_k/s0 = %.3e; source rows of the last 4: %d %d %d %d; next Ritz value/s0 %.3e (row %d)\n",
+                    wi, idx[wi], hs[wi] / s0, hr[0] / s0, hr[1] / s0, hr[k / 2] / s0, hr[k - 2] / s0, hr[k - 1] / s0, hs[k - 1] / s0, idx[k - 4], idx[k - 3], idx[k - 2], idx[k - 1], h[idx[k]] / s0, idx[k]);
+        }
+    }
     if (!(worst <= ctx->warm_accept_tol * s0)) return CTM_OK;
     CTM_HIP_CHECK(ctx, hipMemcpyAsync(S, dS, sizeof(double) * k, hipMemcpyDeviceToDevice, ctx->stream));
     if (want_mid) *op.have_mid = true;

@@ -39,7 +39,11 @@ def _unit_inputs(eng, direction, coord, state, env, ctm_args):
         a = t16[3]
         n = env.chi * a.shape[{(0, -1): 2, (-1, 0): 3, (0, 1): 4, (1, 0): 1}[direction]] ** 2     # truncated bond chi * D_cut^2
         ws = env.__dict__.setdefault("_warm", {})
-        key = (direction, coord)
+        # one workspace per (direction, site, repetition): a sweep repeats the move of a direction lX / lY times (ctmrg.py:62-66), and the
+        # operators a site's unit sees in the repetitions of one sweep are different members of the fixed-point cycle -- same singular
+        # values to 1e-10, singular vectors O(1) apart (measured: a basis handed from one repetition to the next has residual 3e-2 s_0) --
+        # while the same repetition of the next sweep sees the operator again, moved by what the sweep moved the environment
+        key = (direction, coord, env.__dict__.get("_rep", {}).get(direction, 0))
         k = env.chi + 1 if env.chi < n else n
         b = ws.get(key)
         if b is None or b.shape[1] != n or b.shape[0] != (2 if a.dtype.is_complex else 1) * k + 1 or b.device != a.device:

@@ -145,6 +145,12 @@ def ctm_MOVE(direction, state, env, ctm_args=cfg.ctm_args, global_args=cfg.globa
         return ctm_ad.ctm_MOVE(direction, state, env, ctm_args)
     eng = get_engine()
     coords = list(state.sites.keys())
+    # which repetition of this direction's move inside a sweep this call is (consecutive calls with one direction cycle through them):
+    # the warm-start workspaces of the projector units are kept per repetition (ctm_projectors._unit_inputs)
+    nrep = max(1, state.lX if direction in [(-1, 0), (1, 0)] else state.lY)
+    cnt = env.__dict__.setdefault("_rep_count", {})
+    env.__dict__.setdefault("_rep", {})[direction] = cnt.get(direction, 0) % nrep
+    cnt[direction] = cnt.get(direction, 0) + 1
     mine = parallel.my_units(coords)
     chi = env.chi
     # number of non-zero projector columns per site of THIS move (filled by the fused projector path)
