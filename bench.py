@@ -383,7 +383,7 @@ def run_workload(args, eng, dev, kind, D, chi, dtype, signed, steps, warmup, wor
         eng.set_option("gemm_timing", 0)
         cfg.ctm_args.concurrent_units = True
     stationary = None
-    if world == 1 and kind != "c4v" and signed and dtype == "f64" and not args.no_stationary:      # (the complex solver has no such path yet)
+    if world == 1 and kind != "c4v" and signed and dtype == "f64" and not args.no_stationary and not args.warm_tol:      # (the complex solver has no such path yet)
         try:
             stationary = stationary_block(eng, step, env)
         except Exception as e:                         # reporting only
@@ -768,6 +768,7 @@ def main():
     ap.add_argument("--no-serial-pass", action="store_true", help="skip the extra serially issued sweep behind roofline.serial_pass")
     ap.add_argument("--serial-units", action="store_true", help="do not overlap the independent site-units of a move on streams")
     ap.add_argument("--cold-start", action="store_true", help="no warm start of the leading-chi iteration")
+    ap.add_argument("--warm-tol", type=float, default=0.0, help="ctm_args.projector_warm_tol for the WHOLE run (timed sweeps included): with enough warm-up sweeps the timed region is the stationary regime")
     ap.add_argument("--no-stationary", action="store_true", help="skip the stationary-environment block of the full-rank state (projector_warm_tol fast path)")
     ap.add_argument("--no-energy", action="store_true", help="skip the energy block (E/site from rdm2x2 at the size of the timed run)")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the compact blocks of the other single-GPU BASELINE configurations")
@@ -801,6 +802,7 @@ def main():
     cfg.global_args.device = f"cuda:{local}"
     cfg.ctm_args.concurrent_units = not args.serial_units
     cfg.ctm_args.projector_warm_start = not args.cold_start
+    cfg.ctm_args.projector_warm_tol = float(args.warm_tol)
     import _native
     eng = _native.engine()
     for kv in args.opt:

@@ -356,9 +356,12 @@ class Engine:
                 raise NativeError("gemm: beta != 0 needs `out`")
             out = self.empty(M, N)
         else:
-            out = _chk_t(out, "out", A.dtype)
+            if not (isinstance(out, torch.Tensor) and out.is_cuda and out.dtype == A.dtype and out.is_contiguous()) or (out.is_complex() and out.is_conj()) or out.is_neg():
+                raise NativeError("gemm: `out` must be a contiguous device tensor of the operands' dtype (a column slice would be written into a temporary copy)")
             if out.dim() != 2 or out.shape[0] != M or out.shape[1] < N:
                 raise NativeError("gemm: `out` must be M x ldc with ldc >= N")
+            if out.is_complex() and (out.shape[1] != N or beta != 0.0):
+                raise NativeError("gemm: complex128 `out` must be exactly M x N with beta = 0")
         self._ck(self.lib.ctm_gemm(self.h, int(transA), int(transB), M, N, K, alpha, _ptr(A), A.shape[1], _ptr(B),
                                    B.shape[1], beta, _ptr(out), out.shape[1]), "gemm")
         return out

@@ -931,13 +931,14 @@ int xgemm(ctm_ctx* ctx, int M, int N, int K, const XM& A, const XM& B, double* C
     // -- two real products with twice the rows instead of four: every plane of the big operand is streamed once, not twice, and 64
     // complex rows run on the 128-row tile (0.75-0.79 of the MFMA peak) instead of the 64-row row-block kernel (0.70).  This is every
     // corner pass of the complex block iterations (matop_apply_planar: 8 per Krylov step, 9.7 GB of corner planes each at n = 24576).
-    if (ctx->xgemm_stack_rows && !A.t && !A.c && M <= 64 && M % 16 == 0 && A.im == A.re + (size_t)M * A.ld && Cim == Cre + (size_t)M * ldc &&
+    if (ctx->xgemm_stack_rows && !A.t && !A.c && M <= 64 && M % 16 == 0 && A.ld == K /* whole rows are copied: no padding behind the last one */ &&
+        A.im == A.re + (size_t)M * A.ld && Cim == Cre + (size_t)M * ldc &&
         (long long)N * K >= (1ll << 22)) {
         ArenaScope scope(ctx);
         double* S2;
         CTM_TRY(arena_alloc(ctx, sizeof(double) * 2 * (size_t)M * A.ld, (void**)&S2));
         const size_t tot = (size_t)M * A.ld;
-        hipLaunchKernelGGL(planar_times_i_kernel, dim3((int)std::min<size_t>((tot + 255) / 256, 2048)), dim3(256), 0, ctx->stream, A.re, A.im, S2, tot);
+        CTM_LAUNCH(ctx, planar_times_i_kernel, dim3((int)std::min<size_t>((tot + 255) / 256, 2048)), dim3(256), 0, A.re, A.im, S2, tot);
         g.M = 2 * M;
         g.A = A.re; g.B = B.re; g.C = Cre; g.alpha = 1.0; g.beta = 0.0;   CTM_TRY(gemm_f64(ctx, g));
         g.A = S2;   g.B = B.im; g.C = Cre; g.alpha = sB;  g.beta = 1.0;   return gemm_f64(ctx, g);

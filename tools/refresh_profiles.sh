@@ -3,11 +3,12 @@
 # Copy what should be judged from gpurun_out/prof_* into profiles/ (see profiles/README.md).
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-X="--no-cpu-baseline --no-serial-pass --no-other-configs --no-energy --no-live-traffic"
+X="--no-cpu-baseline --no-serial-pass --no-other-configs --no-energy --no-live-traffic --no-stationary"
 bash tools/profile_bench.sh default --pmc -- --no-full-rank $X > gpurun_out/prof_default.log 2>&1
 bash tools/profile_bench.sh default_serial -- --no-full-rank $X --serial-units > gpurun_out/prof_default_serial.log 2>&1
 bash tools/profile_bench.sh signed --pmc -- --signed $X > gpurun_out/prof_signed.log 2>&1
 bash tools/profile_bench.sh signed_serial --mfma -- --signed $X --serial-units > gpurun_out/prof_signed_serial.log 2>&1
+bash tools/profile_bench.sh stationary -- --signed $X --warm-tol 1e-9 --warmup 16 --steps 3 > gpurun_out/prof_stationary.log 2>&1
 bash tools/profile_bench.sh c4v -- --config c4v_D4_chi64 --no-cpu-baseline --no-live-traffic > gpurun_out/prof_c4v.log 2>&1
 bash tools/profile_bench.sh c128_signed -- --config generic_D8_chi384_c128 --signed --steps 1 --warmup 2 --no-cpu-baseline --no-serial-pass --no-energy --no-live-traffic > gpurun_out/prof_c128_signed.log 2>&1
 python bench.py > gpurun_out/bench_final.json 2> gpurun_out/bench_final.err
