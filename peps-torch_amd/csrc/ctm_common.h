@@ -108,7 +108,7 @@ struct ctm_ctx {
     int eigh_orth_max = 32;            // ... applications before it gives up (the regular block iteration runs then; an application + Cholesky-QR
                                        //     step costs a quarter of a half step of that iteration, so a slowly contracting block stays here)
     int eigh_orth_extra_blocks = 0;    // ... additional 64-row blocks of guard rows
-    int eigh_orth_double = 0;          // ... two applications per Cholesky-QR step (1), shifted: Q (A^2 - c^2/2) (2)
+    int eigh_orth_double = 2;          // ... two applications per Cholesky-QR step (1), shifted: Q (A^2 - c^2/2) (2; default since round 5: the whole GPU suite, 386 tests, ran with it)
     double eigh_orth_double_min_ratio = 1e-3;   // ... only while |theta_kk| / |theta_0| of the previous look is above this (the kept block's condition number is its inverse square)
     int eigh_orth_predict = 1;         // ... its looks (Rayleigh-Ritz + residual test) are placed where the residual is predicted to pass
     double eigh_orth_quad_exit = 1e-9; // ... early exit of its small Jacobi eigensolver (see lz_quad_exit; the residual test certifies what it returns)

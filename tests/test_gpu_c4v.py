@@ -594,7 +594,7 @@ def test_full_decomposition_warm_start_changes_the_work_not_the_result(eng, cplx
 
 
 def test_orthogonal_iteration_with_two_applications_per_cholesky_step(eng):
-    """Option eigh_orth_double (off by default): once a look of this workspace has measured |lambda_kk / lambda_0| above the gate, the
+    """Option eigh_orth_double (2 by default since round 5; 0 = a Cholesky-QR step after every application): once a look of this workspace has measured |lambda_kk / lambda_0| above the gate, the
     iteration orthonormalises after every SECOND application (1), with the shift Q (A^2 - c^2/2) once an unshifted solve has
     measured the contraction (2).  Same acceptance test, so the same exact pairs as LAPACK; the doubled steps are counted."""
     n, chi = 768, 48
@@ -622,4 +622,4 @@ def test_orthogonal_iteration_with_two_applications_per_cholesky_step(eng):
         assert eng.stat("eigh_orth_hits") == 4 and eng.stat("eigh_orth_fails") == 0
         assert doubled[0] == 0 and doubled[3] > doubled[2] > doubled[1] > 0, doubled
     finally:
-        eng.set_option("eigh_orth_double", 0)
+        eng.set_option("eigh_orth_double", 2)

@@ -18,7 +18,7 @@ OPTIONS = {
     # routes
     "si_enable": (1, 0), "si_min_n": (256, 128), "si_max_iter": (40, 30), "lz_enable": (1, 0), "lz_min_k": (48, 64), "lz_block": (0, 64), "lz_block_c": (32, 64),
     "lz_async": (1, 0), "lz_local_project": (1, 0), "lz_verify_op": (0, 1), "jacobi_cross_only": (1, 0), "eigh_warm": (1, 0), "eigh_orth_iter": (1, 0),
-    "eigh_orth_double": (0, 2), "proj_from_krylov": (1, 0), "use_layer2": (1, 0), "gemm_fast": (1, 0), "xgemm_stack_rows": (1, 0),
+    "eigh_orth_double": (2, 0), "proj_from_krylov": (1, 0), "use_layer2": (1, 0), "gemm_fast": (1, 0), "xgemm_stack_rows": (1, 0),
     # stationary fast path (tests/test_gpu_stationary.py drives it)
     "warm_accept_tol": (0.0, None), "warm_try_factor": (1e-4, None), "warm_accept_max_run": (32, None),
     # row-block GEMM epilogues (tests/test_gpu_gemm_rows.py drives them)
