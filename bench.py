@@ -259,7 +259,7 @@ def _describe(i, kms, kfl, kn, ums=None):
 
 
 def stationary_block(eng, step, env, warm_tol=1e-9, max_sweeps=14, timed=3):
-    """The stationary-environment fast path (ctm_args.projector_warm_tol, csrc/jacobi.hip: svd_stationary) on the environment the timed
+    """The stationary-environment fast path (ctm_args.projector_warm_tol, csrc/svd_leading.hip: svd_stationary) on the environment the timed
     sweeps ended with: sweeps with the option on until one sweep's truncations were ALL accepted from the previous basis (or max_sweeps),
     then `timed` sweeps timed.  Reported next to the rate of the sweeps that solve every truncation from scratch; the option is off again
     on return (it is opt-in: a residual tolerance instead of the rounding-level threshold)."""

@@ -62,7 +62,7 @@ class CTMARGS(_Args):
         # engine options (not in the reference)
         # projector_warm_tol > 0 (opt-in, like the reference's tolerance-driven partial solvers ctm_projectors.py:229-257, ARP / PROPACK /
         # RSVD): once the previous sweep's singular basis of a unit lies within this distance of the new solve, the truncation is ONE
-        # Rayleigh-Ritz half step from that basis, accepted when the residual of its triplets is <= projector_warm_tol * s_0 (csrc/jacobi.hip:
+        # Rayleigh-Ritz half step from that basis, accepted when the residual of its triplets is <= projector_warm_tol * s_0 (csrc/svd_leading.hip:
         # svd_stationary); 0 = every truncation solved to the engine's rounding-level threshold
         jacobi_tol=1.0e-14, jacobi_max_sweeps=40)
 

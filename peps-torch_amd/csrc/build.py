@@ -10,8 +10,8 @@ import os, subprocess, sys, shutil
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
-SOURCES = ["ctm_runtime.hip", "gemm_f64.hip", "tensor_ops.hip", "jacobi.hip", "contract.hip", "layer2.hip", "ctm_ops.hip", "backward.hip", "ctm_move.hip"]
-HEADERS = ["ctm_common.h", "contract.h", os.path.join("..", "..", "include", "ctm_hip.h")]
+SOURCES = ["ctm_runtime.hip", "gemm_f64.hip", "tensor_ops.hip", "jacobi_core.hip", "svd_leading.hip", "eigh.hip", "contract.hip", "layer2.hip", "ctm_ops.hip", "backward.hip", "ctm_move.hip"]
+HEADERS = ["ctm_common.h", "contract.h", "jacobi_internal.h", os.path.join("..", "..", "include", "ctm_hip.h")]
 LIB = os.path.join(PKG, "libctm_hip.so")
 LIB_ASAN = os.path.join(PKG, "libctm_hip_asan.so")
 

@@ -113,7 +113,7 @@ struct ctm_ctx {
     int eigh_orth_predict = 1;         // ... its looks (Rayleigh-Ritz + residual test) are placed where the residual is predicted to pass
     double eigh_orth_quad_exit = 1e-9; // ... early exit of its small Jacobi eigensolver (see lz_quad_exit; the residual test certifies what it returns)
     long eigh_orth_hits = 0, eigh_orth_fails = 0, eigh_orth_doubled = 0;      // (doubled: Cholesky-QR steps that followed two applications)
-                                       // (its contraction rate / back-off state is kept per warm workspace, see OrthState in jacobi.hip)
+                                       // (its contraction rate / back-off state is kept per warm workspace, see OrthState in eigh.hip)
     // block Golub-Kahan-Lanczos for spectra that do not collapse inside a small block (svd_lanczos)
     bool lz_enable = true; int lz_min_k = 48; double lz_switch_steps = 6.0; double lz_last_resid = 1.0; long lz_hits = 0, lz_total_steps = 0;
     int lz_first = 0;                   // > 0: first Ritz extraction after this many block steps (development); 0: policy of svd_lanczos
@@ -193,7 +193,7 @@ struct ctm_ctx {
     void* comm = nullptr; int comm_rank = 0, comm_nranks = 1;   // rank group sharing one unit (ctm_set_comm; column split: include/ctm_hip.h)
     bool cplx = false;                   // CTM_C128 context: every tensor pointer of the C-ABI is interleaved complex128
     alignas(8) unsigned char orth_cur_storage[64] = {0};      // adaptive state of the symmetric orthogonal iteration for the workspace of the CURRENT call (jacobi.hip: OrthState)
-    // stationary fast path of the implicit-operator truncation (jacobi.hip: svd_stationary).  0 = off: every truncation is solved to resid_tol
+    // stationary fast path of the implicit-operator truncation (svd_leading.hip: svd_stationary).  0 = off: every truncation is solved to resid_tol
     double warm_accept_tol = 0.0;        // accept one Rayleigh-Ritz half step from the previous basis when its residual is <= this x s_0
     double warm_try_factor = 1e-4;       // ... tried when the unit's normalised singular values moved by at most this x warm_accept_tol between its last two solves (a
                                          // LOWER bound on the movement of the operator: measured on signed D = 6 chi = 128, the residual of the previous triplets passes
@@ -359,7 +359,7 @@ struct MatOp {
 // complex128 operators: Ut, Vt are planar (re plane k x n, then im plane), rows = u_k^H, v_k^H
 int jacobi_svd_top_op(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* Ut, double* Vt);
 
-// ---- Jacobi SVD / eig (jacobi.hip) -----------------------------------------------------------
+// ---- Jacobi SVD / eig (jacobi_core.hip, svd_leading.hip, eigh.hip) -----------------------------------------------------------
 // Full one-sided block Jacobi on the rows of M (n x n).  Outputs the k leading triplets:
 //   S[k] (descending), Ut (k x n, rows = u_i^T), Vt (k x n, rows = v_i^T).
 int jacobi_svd_top(ctm_ctx* ctx, const double* M, int n, int k, double* S, double* Ut, double* Vt);

@@ -204,7 +204,7 @@ int svd_rows_op(ctm_ctx* ctx, const MatOp& op, int chi, const ctm_trunc_cfg& cfg
         double side = 0.0;
         CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)k * n, (void**)&ref));
         CTM_HIP_CHECK(ctx, hipMemcpyAsync(ref, op.warm, sizeof(double) * (size_t)k * n, hipMemcpyDeviceToDevice, ctx->stream));
-        CTM_HIP_CHECK(ctx, hipMemcpyAsync(&side, op.warm_hdr + 6 /* HDR_SIDE, jacobi.hip */, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        CTM_HIP_CHECK(ctx, hipMemcpyAsync(&side, op.warm_hdr + 6 /* HDR_SIDE, svd_leading.hip */, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
         ref_left = side >= 1.0 ? 1 : 0;
     }

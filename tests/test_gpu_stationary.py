@@ -1,4 +1,4 @@
-"""GPU: the stationary-environment fast path of the generic truncation (ctm_args.projector_warm_tol > 0; csrc/jacobi.hip: svd_stationary).
+"""GPU: the stationary-environment fast path of the generic truncation (ctm_args.projector_warm_tol > 0; csrc/svd_leading.hip: svd_stationary).
 
 Once a run has converged, the operator of a (direction, site) unit changes by ~1e-10 s_0 from sweep to sweep; with the option on a unit
 whose previous singular basis lies that close to its last full solve is truncated by ONE Rayleigh-Ritz half step from that basis,

@@ -1,10 +1,11 @@
 // Micro-benchmark of the single-workgroup kernels of the latency-bound chains (Cholesky-QR step, 64 x 64 LDS eigensolver).
-// The kernels live in an anonymous namespace of jacobi.hip, so this translation unit includes that file and links against the
+// The kernels live in an anonymous namespace of jacobi_internal.h / jacobi_core.hip / eigh.hip, so this translation unit includes those files and links against the
 // other objects of the library:
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Ipeps-torch_amd/csrc -Iinclude tools/bench_small_kernels.hip \
 //         peps-torch_amd/csrc/build/{ctm_runtime,gemm_f64,tensor_ops,contract,layer2,ctm_ops,backward}.o -o tools/bin/bench_small_kernels
 #define CTM_KERNEL_CLOCKS 1      // phase clocks of the kernels (device buffer ctm_dbg_clocks / stat words of the eigensolver)
-#include "../peps-torch_amd/csrc/jacobi.hip"
+#include "../peps-torch_amd/csrc/jacobi_core.hip"
+#include "../peps-torch_amd/csrc/eigh.hip"
 #include <cstdio>
 #include <random>
 

@@ -6,7 +6,7 @@ Nothing here runs in the product or in a test.  The CTM sweep is restated in num
 corner, eigendecomposition truncated by |lambda|, half-row tensor absorbed and symmetrised, inf-norm normalisation), on the signed
 random state of the bench (bench.synth_sites("c4v", 4, signed=True), chi = 64).
 
-  orth     what csrc/jacobi.hip:eigh_orth_iter does: Q <- orth(Q A), p = 128 rows (kk previous vectors + pseudo-random guard rows),
+  orth     what csrc/eigh.hip:eigh_orth_iter does: Q <- orth(Q A), p = 128 rows (kk previous vectors + pseudo-random guard rows),
            one Rayleigh-Ritz when the residual passes.  (The product measured 24 ... 4 applications over the 22 moving sweeps.)
   krylov   block Krylov from the same start: Rayleigh-Ritz on span[Q, Q A, ..., Q A^m], fully re-orthogonalised, block = the kk previous
            vectors only (no guard rows) or the 128 rows.
