@@ -654,7 +654,7 @@ def metric_line(d):
                "svd": fr["svd"], "phase_s": fr["phase_s"]}
         if "stationary_environment" in fr:
             se = fr["stationary_environment"]
-            blk["stationary_environment"] = {k: (round(v, 5) if isinstance(v, float) else v) for k, v in se.items() if k != "note"}
+            blk["stationary_environment"] = {k: (float(f"{v:.5g}") if isinstance(v, float) else v) for k, v in se.items() if k != "note"}
             roof.update({"full_rank_stationary_value": se.get("sweeps_per_sec"), "full_rank_moving_value": se.get("solve_from_scratch_sweeps_per_sec")})
         if "energy" in fr:
             e = fr["energy"]

@@ -192,7 +192,7 @@ struct ctm_ctx {
     long k_calls[5] = {0, 0, 0, 0, 0};
     void* comm = nullptr; int comm_rank = 0, comm_nranks = 1;   // rank group sharing one unit (ctm_set_comm; column split: include/ctm_hip.h)
     bool cplx = false;                   // CTM_C128 context: every tensor pointer of the C-ABI is interleaved complex128
-    alignas(8) unsigned char orth_cur_storage[64] = {0};      // adaptive state of the symmetric orthogonal iteration for the workspace of the CURRENT call (jacobi.hip: OrthState)
+    alignas(8) unsigned char orth_cur_storage[64] = {0};      // adaptive state of the symmetric orthogonal iteration for the workspace of the CURRENT call (eigh.hip: OrthState)
     // stationary fast path of the implicit-operator truncation (svd_leading.hip: svd_stationary).  0 = off: every truncation is solved to resid_tol
     double warm_accept_tol = 0.0;        // accept one Rayleigh-Ritz half step from the previous basis when its residual is <= this x s_0
     double warm_try_factor = 1e-4;       // ... tried when the unit's normalised singular values moved by at most this x warm_accept_tol between its last two solves (a

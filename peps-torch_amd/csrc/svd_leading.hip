@@ -1155,9 +1155,12 @@ int svd_stationary(ctm_ctx* ctx, const MatOp& op, int k, int side0, double* S, d
         }
     }
     // first application: side0 == 0: W = right vectors, C = W M^T (fresh side: left); side0 == 1: W = left vectors, C = W M
-    CTM_TRY(matop_apply(ctx, op, side0 == 0, B0, n, p, X, ld, M1));
-    CTM_TRY(copy2d(ctx, B0, n, X + n, ld, p, n));
-    if (want_mid) CTM_TRY(copy2d(ctx, M1, n, X + 2 * (size_t)n, ld, p, n));
+    // (the rows behind the guard rows are zero and stay zero: only the k + ng real rows go through the corner passes)
+    const int pa = k + ng;
+    CTM_TRY(fill_f64(ctx, X + (size_t)pa * ld, (size_t)(p - pa) * ld, 0.0));
+    CTM_TRY(matop_apply(ctx, op, side0 == 0, B0, n, pa, X, ld, M1));
+    CTM_TRY(copy2d(ctx, B0, n, X + n, ld, pa, n));
+    if (want_mid) CTM_TRY(copy2d(ctx, M1, n, X + 2 * (size_t)n, ld, pa, n));
     std::vector<double> h(p, 0.0);
     int st;
     const double fro = host_fro(ctx, X, p, n, ld, norms, h, &st);
