@@ -75,17 +75,43 @@ __global__ void rows_to_cols_kernel(const double* rows, int n, int chi, int keep
 
 // complex fix_svd_signs on planar row factors (rows = u^H, v^H): the phase of the max-|U| entry is divided out, i.e.
 // both rows are multiplied by conj(ut)/|ut| with ut the (conjugated) pivot entry of the row.
-__global__ void fix_phase_rows_c_kernel(double* Ur, double* Ui, double* Vr, double* Vi, int k, int n) {
+__global__ void fix_phase_rows_c_kernel(double* Ur, double* Ui, double* Vr, double* Vi, int k, int n, const double* refr = nullptr,
+                                        const double* refi = nullptr, int ref_left = 0) {
     const int r = blockIdx.x;
     if (r >= k) return;
     double* ur = Ur + (size_t)r * n; double* ui = Ui + (size_t)r * n;
     double* vr = Vr + (size_t)r * n; double* vi = Vi + (size_t)r * n;
+    __shared__ long long sb[256]; __shared__ int si[256];
+    __shared__ double sd[4][256];
+    __shared__ double s_ph[2];
+    if (threadIdx.x == 0) { s_ph[0] = 0.0; s_ph[1] = 0.0; }
+    if (refr) {
+        // the row its predecessor returned for this unit: a row that still points along it (|cos| > 1/2) keeps ITS phase (see
+        // fix_signs_rows_kernel): <x e^{i phi}, ref> real positive
+        const double* xr = ref_left ? ur : vr; const double* xi = ref_left ? ui : vi;
+        const double* yr = refr + (size_t)r * n; const double* yi = refi + (size_t)r * n;
+        double zr = 0.0, zi = 0.0, xx = 0.0, yy = 0.0;
+        for (int c = threadIdx.x; c < n; c += blockDim.x) {
+            zr += xr[c] * yr[c] + xi[c] * yi[c]; zi += xi[c] * yr[c] - xr[c] * yi[c];
+            xx += xr[c] * xr[c] + xi[c] * xi[c]; yy += yr[c] * yr[c] + yi[c] * yi[c];
+        }
+        sd[0][threadIdx.x] = zr; sd[1][threadIdx.x] = zi; sd[2][threadIdx.x] = xx; sd[3][threadIdx.x] = yy;
+        __syncthreads();
+        for (int s = blockDim.x / 2; s > 0; s >>= 1) {
+            if (threadIdx.x < s) for (int q = 0; q < 4; ++q) sd[q][threadIdx.x] += sd[q][threadIdx.x + s];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            const double z2 = sd[0][0] * sd[0][0] + sd[1][0] * sd[1][0];
+            if (z2 > 0.25 * sd[2][0] * sd[3][0]) { const double m = sqrt(z2); s_ph[0] = sd[0][0] / m; s_ph[1] = -sd[1][0] / m; }
+        }
+    }
+    __syncthreads();
     long long best = -1; int bi = 0;
     for (int c = threadIdx.x; c < n; c += blockDim.x) {
         const long long a = (long long)(sqrt(ur[c] * ur[c] + ui[c] * ui[c]) * 1099511627776.0);
         if (a > best) { best = a; bi = c; }
     }
-    __shared__ long long sb[256]; __shared__ int si[256];
     sb[threadIdx.x] = best; si[threadIdx.x] = bi;
     __syncthreads();
     for (int s = blockDim.x / 2; s > 0; s >>= 1) {
@@ -97,9 +123,10 @@ __global__ void fix_phase_rows_c_kernel(double* Ur, double* Ui, double* Vr, doub
     }
     const double a = ur[si[0]], b = ui[si[0]];
     const double m = sqrt(a * a + b * b);
+    const bool follow = s_ph[0] != 0.0 || s_ph[1] != 0.0;
     __syncthreads();
-    if (m > 0.0) {
-        const double pr = a / m, pi = -b / m;
+    if (follow || m > 0.0) {
+        const double pr = follow ? s_ph[0] : a / m, pi = follow ? s_ph[1] : -b / m;
         for (int c = threadIdx.x; c < n; c += blockDim.x) {
             double x = ur[c], y = ui[c]; ur[c] = x * pr - y * pi; ui[c] = x * pi + y * pr;
             x = vr[c]; y = vi[c]; vr[c] = x * pr - y * pi; vi[c] = x * pi + y * pr;
@@ -199,11 +226,12 @@ int svd_rows_op(ctm_ctx* ctx, const MatOp& op, int chi, const ctm_trunc_cfg& cfg
     // fix_signs_rows_kernel), whose sign-fixed rows the workspace holds -- kept aside, the solver overwrites them
     ArenaScope ref_scope(ctx);
     double* ref = nullptr; int ref_left = 0;
-    const bool follow = ctx->warm_accept_tol > 0.0 && !ctx->cplx && op.warm && op.warm_hdr && !op.M && cfg.fix_signs && k < n;
+    const bool follow = ctx->warm_accept_tol > 0.0 && op.warm && op.warm_hdr && !op.M && cfg.fix_signs && k < n;
+    const size_t cz = ctx->cplx ? 2 : 1;
     if (follow) {
         double side = 0.0;
-        CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)k * n, (void**)&ref));
-        CTM_HIP_CHECK(ctx, hipMemcpyAsync(ref, op.warm, sizeof(double) * (size_t)k * n, hipMemcpyDeviceToDevice, ctx->stream));
+        CTM_TRY(arena_alloc(ctx, sizeof(double) * cz * (size_t)k * n, (void**)&ref));
+        CTM_HIP_CHECK(ctx, hipMemcpyAsync(ref, op.warm, sizeof(double) * cz * (size_t)k * n, hipMemcpyDeviceToDevice, ctx->stream));
         CTM_HIP_CHECK(ctx, hipMemcpyAsync(&side, op.warm_hdr + 6 /* HDR_SIDE, svd_leading.hip */, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
         ref_left = side >= 1.0 ? 1 : 0;
@@ -215,8 +243,17 @@ int svd_rows_op(ctm_ctx* ctx, const MatOp& op, int chi, const ctm_trunc_cfg& cfg
     if (cfg.fix_signs) {
         const int kf = std::min(k, chi);
         const size_t kn = (size_t)k * n;
-        if (ctx->cplx) CTM_LAUNCH(ctx, fix_phase_rows_c_kernel, dim3(kf), dim3(256), 0, Ut, Ut + kn, Vt, Vt + kn, kf, n);
-        else {
+        if (ctx->cplx) {
+            CTM_LAUNCH(ctx, fix_phase_rows_c_kernel, dim3(kf), dim3(256), 0, Ut, Ut + kn, Vt, Vt + kn, kf, n, (const double*)ref, (const double*)(ref ? ref + kn : nullptr), ref_left);
+            if (follow) {      // the workspace keeps the rows AS RETURNED (planar: real plane, imaginary plane)
+                double side = 0.0;
+                CTM_HIP_CHECK(ctx, hipMemcpyAsync(&side, op.warm_hdr + 6, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+                CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+                const double* src = side >= 1.0 ? Ut : Vt;
+                CTM_HIP_CHECK(ctx, hipMemcpyAsync(op.warm, src, sizeof(double) * (size_t)kf * n, hipMemcpyDeviceToDevice, ctx->stream));
+                CTM_HIP_CHECK(ctx, hipMemcpyAsync(op.warm + kn, src + kn, sizeof(double) * (size_t)kf * n, hipMemcpyDeviceToDevice, ctx->stream));
+            }
+        } else {
             const bool mids = op.have_mid && *op.have_mid;
             CTM_LAUNCH(ctx, fix_signs_rows_kernel, dim3(kf), dim3(256), 0, Ut, Vt, kf, n, mids ? op.out_uR : (double*)nullptr, mids ? op.out_vRt : (double*)nullptr,
                        (const double*)ref, ref_left);

@@ -507,4 +507,5 @@ int project_out_c(ctm_ctx* ctx, CRows W, int b, int n, const double* Bre, const 
 int matop_apply_planar(ctm_ctx* ctx, const MatOp& op, bool adjoint, const double* Bre, const double* Bim, int rows, double* Cre, double* Cim);
 int svd_lanczos_c(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* Ut, double* Vt, bool* converged);
 int svd_stationary(ctm_ctx* ctx, const MatOp& op, int k, int side0, double* S, double* Ut, double* Vt, bool* accepted, double* resid_rel);
+int svd_stationary_c(ctm_ctx* ctx, const MatOp& op, int k, int side0, double* S, double* Ut, double* Vt, bool* accepted, double* resid_rel);
 int spectrum_movement(ctm_ctx* ctx, double* hdr_row, int n, const double* S, int k, double* moved);

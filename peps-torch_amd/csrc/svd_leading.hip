@@ -1223,6 +1223,113 @@ int svd_stationary(ctm_ctx* ctx, const MatOp& op, int k, int side0, double* S, d
     return CTM_OK;
 }
 
+// complex128 twin of svd_stationary(): planar warm rows (u^H or v^H), panel layout for the Rayleigh-Ritz, no half-way products (the
+// complex projectors are built from the returned vectors by the caller's corner passes, as after a full complex solve).
+int svd_stationary_c(ctm_ctx* ctx, const MatOp& op, int k, int side0, double* S, double* Ut, double* Vt, bool* accepted, double* resid_rel) {
+    *accepted = false; *resid_rel = 0.0;
+    const int n = op.n, ng = 32;
+    const int p = ((k + ng + 63) / 64) * 64;               // complex rows; 2p real panel rows
+    if (p >= n / 2 || op.M || !op.warm) return CTM_OK;
+    ArenaScope scope(ctx);
+    const long long ld = 2LL * n;
+    const int R = 2 * p;
+    const size_t wkn = (size_t)k * n;
+    double *XA, *XB, *norms, *nc, *inv, *res;
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)R * ld, (void**)&XA));
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)R * ld, (void**)&XB));
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * 2 * R, (void**)&norms));
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * 2 * R, (void**)&nc));
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * 2 * R, (void**)&inv));
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * 2 * R, (void**)&res));
+    CTM_TRY(fill_f64(ctx, XB, (size_t)R * ld, 0.0));
+    {   // guard rows: pseudo-random, projected out of the previous rows, orthonormalised, projected again
+        ArenaScope ws(ctx);
+        double *Rn, *Gw, *Tw;
+        const size_t rn = (size_t)ng * n;
+        CTM_TRY(arena_alloc(ctx, sizeof(double) * 2 * rn, (void**)&Rn));
+        CTM_TRY(arena_alloc(ctx, sizeof(double) * 2 * (size_t)ng * k, (void**)&Gw));
+        CTM_TRY(arena_alloc(ctx, sizeof(double) * 2 * rn, (void**)&Tw));
+        CTM_LAUNCH(ctx, hash_fill_kernel, dim3(1024), dim3(256), 0, Rn, 2 * ng, n, (long long)n, 0x7e57ab1eULL + (unsigned long long)ctx->warm_accepts);
+        XM r{Rn, Rn + rn, n, false, false}, vh{op.warm, op.warm + wkn, n, true, true}, v{op.warm, op.warm + wkn, n, false, false};
+        for (int rep = 0; rep < 2; ++rep) {
+            CTM_TRY(xgemm(ctx, ng, k, n, r, vh, Gw, Gw + (size_t)ng * k, k));              // G = R W^H
+            XM g{Gw, Gw + (size_t)ng * k, k, false, false};
+            CTM_TRY(xgemm(ctx, ng, n, k, g, v, Tw, Tw + rn, n));                           // T = G W
+            CTM_LAUNCH(ctx, sub_inplace_kernel, dim3(2048), dim3(256), 0, Rn, Tw, 2 * rn);
+            if (rep == 0) {
+                double mn, mx; bool ok = false;
+                CTM_TRY(orthonormalise_block_c(ctx, CRows{Rn, Rn + rn}, ng, n, norms, inv, &mn, &mx, &ok));
+                if (!ok) return CTM_OK;
+            }
+        }
+        CTM_LAUNCH(ctx, planar_to_panel_kernel, dim3(2048), dim3(256), 0, op.warm, op.warm + wkn, (long long)n, k, n, XB, ld, 0);
+        CTM_LAUNCH(ctx, planar_to_panel_kernel, dim3(2048), dim3(256), 0, Rn, Rn + rn, (long long)n, ng, n, XB, ld, k);
+    }
+    // first application (all panel rows: the zero rows of the padding cost little next to 4 complex corner passes' fixed part)
+    CTM_TRY(matop_apply_c(ctx, op, side0 == 0, XB, ld, R, XA, ld));
+    CTM_TRY(copy2d(ctx, XB, ld, XA + n, ld, R, n));
+    int st;
+    std::vector<double> hh;
+    const double fro = host_fro(ctx, XA, R, n, ld, norms, hh, &st);
+    CTM_TRY(st);
+    if (!(fro > 0.0)) return CTM_OK;
+    ctx->jacobi_quad_exit = ctx->si_quad_exit;
+    const int st_rr = jacobi_rows(ctx, XA, R, ld, n, (int)ld, 2 * BC, std::min(k, p - 1), fro, ctx->si_rr_sweeps, true, ctx->si_tau_both != 0);
+    ctx->jacobi_quad_exit = 0.0;
+    CTM_TRY(st_rr);
+    std::vector<double> tmp(R), h(p, 0.0);
+    CTM_TRY(row_norms(ctx, XA, R, n, ld, norms));
+    CTM_LAUNCH(ctx, panel_combine_kernel, dim3((R + 255) / 256), dim3(256), 0, norms, nc, R);
+    CTM_HIP_CHECK(ctx, hipMemcpyAsync(tmp.data(), nc, sizeof(double) * R, hipMemcpyDeviceToHost, ctx->stream));
+    CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    for (int cr = 0; cr < p; ++cr) h[cr] = tmp[crow_re(cr)];
+    std::vector<int> idx(p); std::iota(idx.begin(), idx.end(), 0);
+    std::stable_sort(idx.begin(), idx.end(), [&](int a, int c) { return h[a] > h[c]; });
+    const double s0 = h[idx[0]];
+    int kv = 0;
+    while (kv < k && h[idx[kv]] > ctx->rank_tol * s0) ++kv;
+    if (kv < k || !(s0 > 0.0)) return CTM_OK;
+    CTM_LAUNCH(ctx, inv_or_zero_kernel, dim3((R + 255) / 256), dim3(256), 0, nc, inv, R);
+    CTM_LAUNCH(ctx, scale_rows_kernel, dim3(1024), dim3(256), 0, XA, R, n, ld, inv);
+    // sorted leading k complex rows, planar: the fresh side (normalised) and the rotated start rows
+    double* fresh = side0 == 0 ? Ut : Vt;
+    double* kept = side0 == 0 ? Vt : Ut;
+    int* d_idx;
+    CTM_TRY(arena_alloc(ctx, sizeof(int) * 2 * k, (void**)&d_idx));
+    CTM_TRY(panel_gather(ctx, XA, ld, idx, k, n, fresh, d_idx));
+    CTM_TRY(panel_gather(ctx, XA + n, ld, idx, k, n, kept, d_idx));
+    // second application on the k fresh rows (padded to whole 16-row panels): the relation that does not hold by construction
+    const int kp = ((k + BC - 1) / BC) * BC, R2 = 2 * kp;
+    double *P2, *C2, *G2, *srep;
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)R2 * n, (void**)&P2));
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)R2 * n, (void**)&C2));
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)R2 * n, (void**)&G2));
+    CTM_TRY(arena_alloc(ctx, sizeof(double) * R2, (void**)&srep));
+    CTM_TRY(fill_f64(ctx, P2, (size_t)R2 * n, 0.0));
+    CTM_TRY(fill_f64(ctx, G2, (size_t)R2 * n, 0.0));
+    CTM_LAUNCH(ctx, planar_to_panel_kernel, dim3(2048), dim3(256), 0, (const double*)fresh, (const double*)(fresh + wkn), (long long)n, k, n, P2, (long long)n, 0);
+    CTM_LAUNCH(ctx, planar_to_panel_kernel, dim3(2048), dim3(256), 0, (const double*)kept, (const double*)(kept + wkn), (long long)n, k, n, G2, (long long)n, 0);
+    std::vector<double> hs(k), hrep(R2, 0.0);
+    for (int i = 0; i < k; ++i) { hs[i] = h[idx[i]]; hrep[crow_re(i)] = hs[i]; hrep[crow_re(i) + BC] = hs[i]; }
+    CTM_HIP_CHECK(ctx, hipMemcpyAsync(srep, hrep.data(), sizeof(double) * R2, hipMemcpyHostToDevice, ctx->stream));
+    CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    CTM_TRY(matop_apply_c(ctx, op, side0 != 0, P2, n, R2, C2, n));
+    CTM_LAUNCH(ctx, resid_rows_kernel, dim3((R2 + 3) / 4), dim3(256), 0, (const double*)C2, (long long)n, (const double*)G2, (long long)n, (const double*)srep, R2, n, res);
+    std::vector<double> tr(R2);
+    CTM_HIP_CHECK(ctx, hipMemcpyAsync(tr.data(), res, sizeof(double) * R2, hipMemcpyDeviceToHost, ctx->stream));
+    CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    double worst = 0.0;
+    for (int i = 0; i < k; ++i) { const int rr = crow_re(i); worst = std::max(worst, std::sqrt(tr[rr] * tr[rr] + tr[rr + BC] * tr[rr + BC])); }
+    *resid_rel = worst / s0;
+    if (ctx->jacobi_verbose) fprintf(stderr, "[stat-c] n=%d k=%d p=%d side %d  residual/s0 = %.3e (accept <= %.1e), %d Jacobi sweeps\n", n, k, p, side0, worst / s0, ctx->warm_accept_tol, ctx->last_sweeps);
+    if (!(worst <= ctx->warm_accept_tol * s0)) return CTM_OK;
+    CTM_HIP_CHECK(ctx, hipMemcpyAsync(S, hs.data(), sizeof(double) * k, hipMemcpyHostToDevice, ctx->stream));
+    CTM_HIP_CHECK(ctx, hipMemcpyAsync(op.warm, fresh, sizeof(double) * 2 * wkn, hipMemcpyDeviceToDevice, ctx->stream));
+    CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    *accepted = true;
+    return CTM_OK;
+}
+
 // How far a unit's operator moved since its previous solve, measured on what both solves share without further operator
 // applications: the singular values.  |s_i - s_i^prev| <= |M - M^prev|_2 (Weyl), so max_i |ds_i| / s_0 is a LOWER bound on the relative
 // movement of the operator -- and in a converging CTM run, where the operator changes by a smooth perturbation, also its order of
@@ -1258,7 +1365,7 @@ int jacobi_svd_top_op(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* U
     // the next call tries the fast path); the workspace then holds RIGHT vectors again
     double hdr[HDR_WORDS] = {0.0};
     auto keep_warm_dist = [&](const double* hdr_old) -> int {
-        if (op.warm && op.warm_hdr && !op.M && !(op.Mi || op.ci[0]) && (ctx->warm_accept_tol > 0.0 || hdr_old[HDR_SIDE] >= 1.0)) {
+        if (op.warm && op.warm_hdr && !op.M && (ctx->warm_accept_tol > 0.0 || hdr_old[HDR_SIDE] >= 1.0)) {
             double dist = 0.0;
             if (ctx->warm_accept_tol > 0.0) CTM_TRY(spectrum_movement(ctx, op.warm_hdr, n, S, k, &dist));
             const double w[5] = {dist, 0.0, 0.0, hdr_old[HDR_SSKIP], hdr_old[HDR_SFAILS]};     // HDR_DIST, HDR_SIDE, HDR_RUN, HDR_SSKIP, HDR_SFAILS
@@ -1268,28 +1375,62 @@ int jacobi_svd_top_op(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* U
         }
         return keep_warm();
     };
+    // stationary fast path (option "warm_accept_tol"): one Rayleigh-Ritz half step from the previous basis when the unit's singular values
+    // hardly moved between its last two solves; *done: the triplets are in S, Ut, Vt and the workspace / header are up to date
+    const bool cplx_op = op.Mi || op.ci[0];
+    auto stationary_attempt = [&](bool* done) -> int {
+        *done = false;
+        if (!(ctx->warm_accept_tol > 0.0 && op.warm && !op.M && hdr[HDR_STEPS] >= 1.0)) return CTM_OK;
+        if (hdr[HDR_SSKIP] >= 1.0) { hdr[HDR_SSKIP] -= 1.0; return fill_f64(ctx, op.warm_hdr + HDR_SSKIP, 1, hdr[HDR_SSKIP]); }
+        if (!(hdr[HDR_DIST] > 0.0 && hdr[HDR_DIST] <= ctx->warm_try_factor * ctx->warm_accept_tol &&
+              (ctx->warm_accept_max_run <= 0 || hdr[HDR_RUN] < ctx->warm_accept_max_run))) return CTM_OK;
+        bool acc = false; double rr = 0.0;
+        const int side0 = hdr[HDR_SIDE] >= 1.0 ? 1 : 0;
+        if (cplx_op) CTM_TRY(svd_stationary_c(ctx, op, k, side0, S, Ut, Vt, &acc, &rr));
+        else CTM_TRY(svd_stationary(ctx, op, k, side0, S, Ut, Vt, &acc, &rr));
+        if (acc) {
+            double mv = 0.0;
+            CTM_TRY(spectrum_movement(ctx, op.warm_hdr, n, S, k, &mv));
+            const double w[5] = {std::max(mv, 1e-300), side0 ? 0.0 : 1.0, hdr[HDR_RUN] + 1.0, 0.0, 0.0};
+            CTM_HIP_CHECK(ctx, hipMemcpyAsync(op.warm_hdr + HDR_DIST, w, sizeof(w), hipMemcpyHostToDevice, ctx->stream));
+            CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+            ctx->warm_accepts += 1; ctx->warm_last_dist = rr;
+            *done = true;
+            return CTM_OK;
+        }
+        // refused: the full solve follows; the next attempts back off (x2 per consecutive refusal)
+        ctx->warm_rejects += 1;
+        hdr[HDR_SFAILS] = std::min(hdr[HDR_SFAILS] + 1.0, 6.0);
+        hdr[HDR_SSKIP] = std::ldexp(1.0, (int)hdr[HDR_SFAILS]) - 1.0;
+        if (op.have_mid) *op.have_mid = false;
+        return CTM_OK;
+    };
     if (op.Mi || op.ci[0]) {        // complex128
         if (Ut && Vt && ctx->si_enable && k < n && n >= ctx->si_min_n) {
             bool ok = false, krylov = false;
             MatOp op1 = op;
             if (op.warm_hdr && ctx->lz_enable && k >= ctx->lz_min_k) {      // direct Krylov entry of a full-rank unit, see the real branch below
-                double hdr[HDR_WORDS];
                 CTM_HIP_CHECK(ctx, hipMemcpyAsync(hdr, op.warm_hdr, sizeof(hdr), hipMemcpyDeviceToHost, ctx->stream));
                 CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+                { bool done = false; CTM_TRY(stationary_attempt(&done)); if (done) return CTM_OK; }
+                if (hdr[HDR_SIDE] >= 1.0) {      // the workspace holds LEFT vectors (kept by the fast path): the warm starts below expect right vectors
+                    op1.warm = nullptr; op1.warm_hdr = nullptr;
+                    if (hdr[HDR_SKIP] < 1.0) hdr[HDR_SKIP] = 1.0;
+                }
                 if (hdr[HDR_SKIP] >= 1.0 && hdr[HDR_STEPS] >= 1.0) {
                     CTM_TRY(fill_f64(ctx, op.warm_hdr, 1, hdr[HDR_SKIP] - 1.0)); ctx->si_warm_skips += 1;
                     ctx->lz_last_resid = 1.0;
                     CTM_TRY(svd_lanczos_c(ctx, op, k, S, Ut, Vt, &ok));
-                    if (ok) return keep_warm();
+                    if (ok) return keep_warm_dist(hdr);
                     op1.warm = nullptr; op1.warm_hdr = nullptr;
                 }
             }
             CTM_TRY(svd_iter_c(ctx, op1, k, S, Ut, Vt, &ok, &krylov));
-            if (ok) { ctx->si_hits += 1; return keep_warm(); }
+            if (ok) { ctx->si_hits += 1; return keep_warm_dist(hdr); }
             if (krylov) {
                 ctx->lz_last_resid = 1.0;
                 CTM_TRY(svd_lanczos_c(ctx, op, k, S, Ut, Vt, &ok));
-                if (ok) return keep_warm();
+                if (ok) return keep_warm_dist(hdr);
                 MatOp op2 = op;
                 ArenaScope ws(ctx);
                 if (ctx->lz_last_resid <= 1e-11) {
@@ -1299,7 +1440,7 @@ int jacobi_svd_top_op(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* U
                     op2.warm = w2;
                 }
                 CTM_TRY(svd_iter_c(ctx, op2, k, S, Ut, Vt, &ok, nullptr));
-                if (ok) { ctx->si_hits += 1; return keep_warm(); }
+                if (ok) { ctx->si_hits += 1; return keep_warm_dist(hdr); }
             }
             ctx->si_fallbacks += 1;
         }
@@ -1321,7 +1462,7 @@ int jacobi_svd_top_op(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* U
         XM rT{R, R + nn, n, true, false}, rt{Rt, Rt + nn, n, false, false};
         CTM_TRY(xgemm(ctx, n, n, n, rT, rt, M, M + nn, n));
         CTM_TRY(svd_full_c(ctx, M, M + nn, n, k, S, Ut, Vt));
-        return keep_warm();
+        return keep_warm_dist(hdr);
     }
     if (Ut && Vt && ctx->si_enable && k < n && n >= ctx->si_min_n) {
         bool ok = false, krylov = false;
@@ -1331,29 +1472,7 @@ int jacobi_svd_top_op(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* U
             // 64-row rank probe either); if that should fail the regular path below starts cold
             CTM_HIP_CHECK(ctx, hipMemcpyAsync(hdr, op.warm_hdr, sizeof(hdr), hipMemcpyDeviceToHost, ctx->stream));
             CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-            if (ctx->warm_accept_tol > 0.0 && op.warm && !op.M && hdr[HDR_STEPS] >= 1.0) {
-                // stationary fast path: one Rayleigh-Ritz half step from the previous basis when the last solve found it close
-                if (hdr[HDR_SSKIP] >= 1.0) { hdr[HDR_SSKIP] -= 1.0; CTM_TRY(fill_f64(ctx, op.warm_hdr + HDR_SSKIP, 1, hdr[HDR_SSKIP])); }
-                else if (hdr[HDR_DIST] > 0.0 && hdr[HDR_DIST] <= ctx->warm_try_factor * ctx->warm_accept_tol &&
-                         (ctx->warm_accept_max_run <= 0 || hdr[HDR_RUN] < ctx->warm_accept_max_run)) {
-                    bool acc = false; double rr = 0.0;
-                    CTM_TRY(svd_stationary(ctx, op, k, hdr[HDR_SIDE] >= 1.0 ? 1 : 0, S, Ut, Vt, &acc, &rr));
-                    if (acc) {
-                        double mv = 0.0;
-                        CTM_TRY(spectrum_movement(ctx, op.warm_hdr, n, S, k, &mv));
-                        const double w[5] = {std::max(mv, 1e-300), hdr[HDR_SIDE] >= 1.0 ? 0.0 : 1.0, hdr[HDR_RUN] + 1.0, 0.0, 0.0};
-                        CTM_HIP_CHECK(ctx, hipMemcpyAsync(op.warm_hdr + HDR_DIST, w, sizeof(w), hipMemcpyHostToDevice, ctx->stream));
-                        CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-                        ctx->warm_accepts += 1; ctx->warm_last_dist = rr;
-                        return CTM_OK;
-                    }
-                    // refused: the full solve below; the next attempts back off (x2 per consecutive refusal)
-                    ctx->warm_rejects += 1;
-                    hdr[HDR_SFAILS] = std::min(hdr[HDR_SFAILS] + 1.0, 6.0);
-                    hdr[HDR_SSKIP] = std::ldexp(1.0, (int)hdr[HDR_SFAILS]) - 1.0;
-                    if (op.have_mid) *op.have_mid = false;
-                }
-            }
+            { bool done = false; CTM_TRY(stationary_attempt(&done)); if (done) return CTM_OK; }
             if (hdr[HDR_SIDE] >= 1.0) {
                 // the workspace holds LEFT vectors (kept by the fast path): the regular warm starts below expect right vectors
                 op1.warm = nullptr; op1.warm_hdr = nullptr;

@@ -15,12 +15,14 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _sites(D, seed):
+def _sites(D, seed, cplx=False):
     rng = np.random.default_rng(seed)
     out = {}
     for y in range(2):
         for x in range(2):
             A = rng.random((2, D, D, D, D)) - 0.5                      # signed random tensors: full-rank environment, block Krylov units
+            if cplx:
+                A = A + 1j * (rng.random((2, D, D, D, D)) - 0.5)
             out[(x, y)] = torch.from_numpy(A / np.abs(A).max()).cuda()
     return out
 
@@ -69,9 +71,10 @@ def _spectra(env):
     return {k: (s / s[0]).cpu().numpy() for k, s in env.get_spectra().items()}
 
 
-@pytest.mark.parametrize("D,chi,conv_tol,max_sweeps", [(4, 64, 1e-9, 60), (6, 128, 1e-8, 40)], ids=["D4chi64", "D6chi128"])
-def test_converged_run_with_and_without_the_fast_path(eng, D, chi, conv_tol, max_sweeps):
-    sites = _sites(D, 11)
+@pytest.mark.parametrize("D,chi,conv_tol,max_sweeps,cplx", [(4, 64, 1e-9, 60, False), (6, 128, 1e-8, 40, False), (4, 64, 1e-9, 60, True)],
+                         ids=["D4chi64", "D6chi128", "D4chi64-c128"])
+def test_converged_run_with_and_without_the_fast_path(eng, D, chi, conv_tol, max_sweeps, cplx):
+    sites = _sites(D, 11, cplx)
     try:
         st0, env0, t0, acc0, kr0, h0 = _converge(eng, sites, chi, 0.0, conv_tol, max_sweeps, extra=8)
         assert sum(acc0) == 0 and sum(kr0) > 0, "option off: every truncation is a full solve (and the state must reach the block Krylov solver)"

@@ -17,6 +17,8 @@ sites = {}
 for y in range(2):
     for x in range(2):
         A = rng.random((2, D, D, D, D)) - 0.5
+        if os.environ.get("CPLX"):
+            A = A + 1j * (rng.random((2, D, D, D, D)) - 0.5)
         sites[(x, y)] = torch.from_numpy(A / np.abs(A).max()).cuda()
 args = copy.deepcopy(cfg.ctm_args); args.projector_warm_tol = tol; args.ctm_conv_tol = 0.0; args.ctm_max_iter = 10 ** 6
 st = IPEPS(sites); env = ENV(chi, st); init_env(st, env)
