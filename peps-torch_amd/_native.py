@@ -15,6 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIBPATH = os.environ.get("CTM_LIB") or os.path.join(_HERE, "libctm_hip.so")
 
 CTM_OK = 0
+CTM_ERR_NOMEM = 6
 _ERRNAMES = {1: "bad argument", 2: "shape mismatch", 3: "no convergence", 4: "HIP error", 5: "unsupported", 6: "out of memory",
              7: "context busy (used by two threads at once)"}
 LU, RU, RD, LD = 0, 1, 2, 3
@@ -25,7 +26,7 @@ CUT_LEG = {UP: 2, LEFT: 3, DOWN: 4, RIGHT: 1}
 
 
 class NativeError(RuntimeError):
-    pass
+    status = None          # the library's status code when the error came from a C entry (include/ctm_hip.h: CTM_ERR_*)
 
 
 class TruncCfg(C.Structure):
@@ -245,7 +246,9 @@ class Engine:
     def _ck(self, st, what):
         if st != CTM_OK:
             msg = self.lib.ctm_last_error(self.h)
-            raise NativeError(f"{what}: {_ERRNAMES.get(st, st)}: {msg.decode() if msg else ''}")
+            err = NativeError(f"{what}: {_ERRNAMES.get(st, st)}: {msg.decode() if msg else ''}")
+            err.status = st                  # include/ctm_hip.h status code (CTM_ERR_NOMEM = 6: callers may retry with less in flight)
+            raise err
 
     def empty(self, *shape):
         return torch.empty(shape, dtype=self.dtype, device=self.device)

@@ -219,6 +219,7 @@ __global__ __launch_bounds__(MX == 64 ? 1024 : 256) void small_eig_kernel(SmallE
             }
             __syncthreads();
         }
+        if (tid == 0) atomicAdd(p.stat_rel + 2, 1ULL);         // diagnostics: inner sweeps of this launch ([jacobi] line of jacobi_verbose = 2)
         if (rot_flag == 0) break;
         __syncthreads();
     }
@@ -403,6 +404,7 @@ __global__ __launch_bounds__(1024 / BPT) void small_eig64_kernel(SmallEigParams 
         }
         const int any = rot_flag;
         __syncthreads();
+        if (tid == 0) atomicAdd(p.stat_rel + 2, 1ULL);
         if (!any) break;
         if (tid == 0) rot_flag = 0;
         __syncthreads();
@@ -713,7 +715,7 @@ int jacobi_rows(ctm_ctx* ctx, double* X, int R, long long ld, int Cg, int Ctot, 
             CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
             tau2 = *std::max_element(h.begin(), h.begin() + R); abs_mode = true;
         }
-        CTM_HIP_CHECK(ctx, hipMemsetAsync(stat, 0, 2 * sizeof(double), ctx->stream));
+        CTM_HIP_CHECK(ctx, hipMemsetAsync(stat, 0, 3 * sizeof(double), ctx->stream));
         for (int r = 0; r < rounds; ++r) {
             GemmDesc g;
             g.M = m; g.N = m; g.K = Cg;
@@ -743,12 +745,16 @@ int jacobi_rows(ctm_ctx* ctx, double* X, int R, long long ld, int Cg, int Ctot, 
             a.batch = pairs; a.offs = T->d_apply + (size_t)r * pairs; a.skip_flags = flags;
             CTM_TRY(gemm_f64(ctx, a));
         }
-        CTM_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_scratch, stat, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        CTM_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_scratch, stat, 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
         const double srel = ctx->h_scratch[0];
         ctx->last_sweeps = sweep + 1;
         ctx->last_offnorm = srel;
-        if (ctx->jacobi_verbose > 1) fprintf(stderr, "[jacobi] R=%d sweep %d  scaled=%.3e classical=%.3e tau=%.3e\n", R, sweep + 1, srel, ctx->h_scratch[1], std::sqrt(tau2));
+        if (ctx->jacobi_verbose > 1) {
+            unsigned long long inner; memcpy(&inner, &ctx->h_scratch[2], sizeof(inner));
+            fprintf(stderr, "[jacobi] R=%d sweep %d  scaled=%.3e classical=%.3e tau=%.3e  inner sweeps of the LDS eigensolver: %llu in %d launches\n", R, sweep + 1, srel,
+                    ctx->h_scratch[1], std::sqrt(tau2), inner, rounds);
+        }
         if (srel <= ctx->jacobi_tol) break;
         // `srel` is the measure of the Gram matrices the sweep FOUND; in the quadratic regime the sweep leaves ~ srel^2 / gap.  A caller
         // that verifies the result itself (the Ritz extraction of the block Krylov solver: residuals of both relations on the returned

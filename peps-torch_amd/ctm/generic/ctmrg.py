@@ -13,6 +13,7 @@ from math import ceil
 import torch
 import config as cfg
 from backend import get_engine
+from _native import NativeError, CTM_ERR_NOMEM
 import parallel
 from ctm.generic.ctm_projectors import ctm_get_projectors_4x4, ctm_get_projectors_4x2, _trunc_cfg, _unit_inputs, _sync_warm_tol
 from ctm.generic.ctm_components import _halves_t
@@ -179,6 +180,11 @@ def ctm_MOVE(direction, state, env, ctm_args=cfg.ctm_args, global_args=cfg.globa
             4 * len(coords) * nmax * nmax * elem <= 0.6 * torch.cuda.get_device_properties(like.device).total_memory
         pool = units.pool_for(eng, len(mine), nmax, like.dtype.is_complex, est_bytes=(4.5 * nmax * nmax * elem) if cached else None,
                               large_n_units=None if krylov else 2)
+        # a move of this environment ran out of workspace with more units in flight (the estimate above is one measured high-water
+        # mark scaled by n^2): stay at the width that worked
+        cap = env.__dict__.get("_units_cap")
+        if pool is not None and cap is not None:
+            pool = units.PoolView(pool.pool, min(pool.n, cap)) if cap >= 2 else None
     if pool is not None and nmax >= 8192 and hasattr(eng, "trim_own") and eng.own_stat("arena_total") > 2 ** 30:
         eng.trim_own()       # the units run on the workers' contexts: an arena this engine grew in an earlier (serial) phase is tens of GB of idle HBM
     lz_before = eng.stat("lz_hits") if hasattr(eng, "stat") else 0
@@ -203,8 +209,28 @@ def ctm_MOVE(direction, state, env, ctm_args=cfg.ctm_args, global_args=cfg.globa
             a6 = (env.C[(site, vecs[0])], env.T[(site, vecs[1])], env.T[(site, vecs[2])], env.T[(site, vecs[3])], env.C[(site, vecs[4])], state.site(c))
             ulist.append({"t16": t16, "basis": basis, "corners": corners, "absorb6": a6, "nb": index[nb]})
             fresh_all += fresh
-        res = eng.move(direction, ulist, chi, _trunc_cfg(eng, ctm_args), normalize=norm_kind,
-                       skip_zero_columns=env.__dict__.get("_ncol") is not None, workers=workers)
+        try:
+            res = eng.move(direction, ulist, chi, _trunc_cfg(eng, ctm_args), normalize=norm_kind,
+                           skip_zero_columns=env.__dict__.get("_ncol") is not None, workers=workers)
+        except NativeError as e:
+            if e.status != CTM_ERR_NOMEM or not workers:
+                raise
+            # out of HBM with len(workers) units in flight: a move writes nothing before it has succeeded (new tensors, and the corner
+            # cache entries are committed below), so give every workspace arena back and repeat it with half the units in flight --
+            # serially on this engine's own context at the end -- and keep later moves of this environment at that width
+            width = len(workers)
+            while True:
+                eng.trim()                   # (this engine's arenas and every worker's)
+                width //= 2
+                env.__dict__["_units_cap"] = max(1, width)
+                workers = tuple(workers[:width]) if width >= 2 else ()
+                try:
+                    res = eng.move(direction, ulist, chi, _trunc_cfg(eng, ctm_args), normalize=norm_kind,
+                                   skip_zero_columns=env.__dict__.get("_ncol") is not None, workers=workers)
+                    break
+                except NativeError as e2:
+                    if e2.status != CTM_ERR_NOMEM or not workers:
+                        raise
         for key, entry in fresh_all:                  # only after the call succeeded: the buffers now hold these corners
             env.__dict__["_corner_cache"][key] = entry
         if env.__dict__.get("_ncol") is not None:

@@ -294,6 +294,55 @@ def test_whole_move_in_one_native_call_equals_the_unit_by_unit_move(eng, cplx, p
         for k in envs[0].T: assert torch.equal(envs[0].T[k], other.T[k]), k
 
 
+def test_a_move_that_runs_out_of_workspace_is_repeated_with_fewer_units_in_flight(eng, monkeypatch):
+    """The number of units a move keeps in flight comes from an ESTIMATE of a unit's workspace (ctmrg.ctm_MOVE: one measured high-water
+    mark scaled by n^2).  When the library reports CTM_ERR_NOMEM with worker contexts in use, the move -- which has written nothing
+    yet -- is repeated with half the width after the arenas were given back, and the environment remembers the width that worked.
+    The out-of-memory condition is injected at the C-ABI wrapper (the real one needs > 144 GB of workspace)."""
+    import copy
+    import config as cfg
+    import _native
+    from ipeps.ipeps import IPEPS
+    from ctm.generic.env import ENV, init_env
+    from ctm.generic import ctmrg
+    rng = np.random.default_rng(32)
+    sites = {(x, y): rng.random((2, 3, 3, 3, 3)) - 0.5 for x in range(2) for y in range(2)}
+    args = copy.deepcopy(cfg.ctm_args)
+
+    def sweeps(env, st, n=2):
+        for _ in range(n):
+            for d in args.ctm_move_sequence:
+                for _r in range(2):
+                    ctmrg.ctm_MOVE(d, st, env, ctm_args=args)
+
+    st = IPEPS({k: dev(v / np.abs(v).max()) for k, v in sites.items()})
+    ref = ENV(40, st); init_env(st, ref)
+    sweeps(ref, st)
+    real_move, widths = type(eng).move, []
+
+    def starved(self, direction, units, chi, cfgt, normalize=1, skip_zero_columns=False, workers=()):
+        widths.append(len(workers))
+        if len(workers) > 1 and len(widths) >= 3:                  # from the third move on: no room for more than one unit
+            err = _native.NativeError("ctm_move: out of memory: (injected)"); err.status = _native.CTM_ERR_NOMEM
+            raise err
+        return real_move(self, direction, units, chi, cfgt, normalize=normalize, skip_zero_columns=skip_zero_columns, workers=workers)
+
+    monkeypatch.setattr(type(eng), "move", starved)
+    env = ENV(40, st); init_env(st, env)
+    sweeps(env, st)
+    assert widths[:2] == [4, 4] and widths[2:5] == [4, 2, 0], widths        # 4 in flight, refused, 2 refused, then serially: accepted
+    assert set(widths[5:]) == {0} and env.__dict__["_units_cap"] == 1, widths   # ... and later moves do not try again
+    for k in ref.C: assert torch.equal(ref.C[k], env.C[k]), k
+    for k in ref.T: assert torch.equal(ref.T[k], env.T[k]), k
+    # an error that is not a shortage of memory, or one without worker contexts to give up, is the caller's
+    def broken(self, *a, **kw):
+        err = _native.NativeError("ctm_move: HIP error: (injected)"); err.status = 4
+        raise err
+    monkeypatch.setattr(type(eng), "move", broken)
+    with pytest.raises(_native.NativeError, match="injected"):
+        ctmrg.ctm_MOVE((0, -1), st, env, ctm_args=args)
+
+
 def test_rdm2x2_from_parts_equals_the_whole(case, eng):
     """ctm_rdm2x2_part: the plaquette contraction split over ranges of lower-half slices (what a rank group shares, and what one
     GPU loops over when the open halves do not fit) reassembles to ctm_rdm2x2 exactly; and the host layer's chunked path gives
