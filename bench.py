@@ -659,7 +659,7 @@ def metric_line(d):
         if "energy" in fr:
             e = fr["energy"]
             blk["energy"] = e if "error" in e else {"seconds_per_energy_4_sites": e["seconds_per_energy_4_sites"], "energy_per_site_j2_0.5": e["energy_per_site_j2_0.5"],
-                                                    "rdm2x2_invariants": e.get("rdm2x2_invariants")}
+                                                    "n_gpus": e.get("n_gpus"), "rdm2x2_invariants": e.get("rdm2x2_invariants")}
         if "energy_parity" in fr:
             blk["energy_parity"] = {k: fr["energy_parity"].get(k) for k in ("rel_err", "max_abs_err_corner_spectra", "tolerance")}
         line["full_rank"] = blk
@@ -771,6 +771,7 @@ def main():
     ap.add_argument("--warm-tol", type=float, default=0.0, help="ctm_args.projector_warm_tol for the WHOLE run (timed sweeps included): with enough warm-up sweeps the timed region is the stationary regime")
     ap.add_argument("--no-stationary", action="store_true", help="skip the stationary-environment block of the full-rank state (projector_warm_tol fast path)")
     ap.add_argument("--no-energy", action="store_true", help="skip the energy block (E/site from rdm2x2 at the size of the timed run)")
+    ap.add_argument("--energy", action="store_true", help="the energy block also for a --config other than the default one")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the compact blocks of the other single-GPU BASELINE configurations")
     ap.add_argument("--no-live-traffic", action="store_true", help="roofline.traffic from the committed PMC pass instead of two rocprofv3 --pmc child runs of this command")
     args = ap.parse_args()
@@ -830,7 +831,7 @@ def main():
         ftr = (traffic_live(args, fdom, True, min(warmup, 2)) if live else None) or traffic_from_profile(args, world, fdom, True)
         if ftr:
             full["roofline"]["traffic"] = ftr["dominant"]; full["roofline"]["traffic_source"] = ftr["source"]
-        if not args.no_energy and args.config == DEFAULT_CONFIG:
+        if not args.no_energy and (args.config == DEFAULT_CONFIG or args.energy):
             try:
                 full["energy"] = energy_block(eng, fstate, fenv, world)
             except Exception as e:                        # reporting only

@@ -12,12 +12,12 @@ FLAGS = ["--config", "generic_D6_chi128", "--steps", "1", "--warmup", "1", "--no
          "--no-serial-pass", "--no-stationary"]      # (both add sweeps to the single-process run only: the environments would differ by them)
 
 
-def _bench(n):
+def _bench(n, flags=None):
     env = dict(os.environ)
     env.update({"CTM_BENCH_ONE_DEVICE": "1", "CTM_BENCH_BACKEND": "gloo", "MASTER_ADDR": "127.0.0.1"})
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
         env.pop(k, None)
-    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", str(n)] + FLAGS, cwd=REPO, env=env, capture_output=True, text=True, timeout=900)
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", str(n)] + (FLAGS if flags is None else flags), cwd=REPO, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
     line = json.loads(lines[-1])                       # the LAST stdout line is the metric line (the driver's parser takes that one)
@@ -30,7 +30,7 @@ def single():
     return _bench(1)
 
 
-@pytest.mark.parametrize("n", [2, 4])
+@pytest.mark.parametrize("n", [2, 4, 8])
 def test_bench_with_n_ranks_on_one_device(single, n):
     line = _bench(n)
     assert line["n_gpus"] == n and single["n_gpus"] == 1
@@ -42,4 +42,31 @@ def test_bench_with_n_ranks_on_one_device(single, n):
     a, b = single["state"]["corner_spectra_checksum"], line["state"]["corner_spectra_checksum"]
     assert abs(a - b) <= 1e-9 * abs(a), (a, b)
     a, b = single["full_rank"]["state"]["corner_spectra_checksum"], line["full_rank"]["state"]["corner_spectra_checksum"]
+    assert abs(a - b) <= 1e-9 * abs(a), (a, b)
+
+
+EFLAGS = ["--config", "generic_D6_chi128", "--energy", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-other-configs", "--no-live-traffic",
+          "--no-serial-pass", "--no-stationary"]
+
+
+@pytest.fixture(scope="module")
+def single_with_energy():
+    return _bench(1, EFLAGS)
+
+
+@pytest.mark.parametrize("n", [2, 8])
+def test_energy_block_of_the_line_with_n_ranks(single_with_energy, n):
+    """After the full-rank sweeps the driver's command evaluates the energy once: with more than one rank the plaquette RDMs of the four
+    sites are shared out -- by site with 2 ranks, and with 8 ranks (more ranks than sites) the p^4 slices of a site's plaquette among the
+    ranks of its group, one all-reduce inside the group (parallel.site_groups, rdm._rdm2x2_raw) -- and reduced.  N ranks on the one
+    device against the single process (configs[2] shape, so that eight ranks fit one GPU): same environment, same energy."""
+    one, many = single_with_energy, _bench(n, EFLAGS)
+    assert many["n_gpus"] == n
+    for blk in (one, many):
+        assert "error" not in blk["full_rank"]["energy"], blk["full_rank"]["energy"]
+    e1, e2 = one["full_rank"]["energy"], many["full_rank"]["energy"]
+    assert e1["n_gpus"] == 1 and e2["n_gpus"] == n
+    a, b = e1["energy_per_site_j2_0.5"], e2["energy_per_site_j2_0.5"]
+    assert abs(a - b) <= 1e-10 * abs(a), (a, b)
+    a, b = one["full_rank"]["state"]["corner_spectra_checksum"], many["full_rank"]["state"]["corner_spectra_checksum"]
     assert abs(a - b) <= 1e-9 * abs(a), (a, b)
