@@ -6,6 +6,7 @@ and written to the site at `coord - direction`.  With torch.distributed initiali
 of both phases are sharded over the ranks (one MI355X each) with one all-gather after each phase
 (parallel.py); without it everything runs on the current device.
 """
+import os
 import time
 import copy
 import logging
@@ -167,9 +168,10 @@ def ctm_MOVE(direction, state, env, ctm_args=cfg.ctm_args, global_args=cfg.globa
     pool = None
     if getattr(ctm_args, "concurrent_units", True) and len(mine) > 1:
         import units
-        # large n: all units of the move in flight while their truncations run the block Krylov solver (long latency-bound stages
-        # that only overlap with other units'); two at a time otherwise (same sweep time, half the workspace, and the chip-filling
-        # kernels of a low-rank unit share the chip with one other launch instead of three)
+        # large n: all units of the move in flight -- while their truncations run the block Krylov solver (long latency-bound stages
+        # that only overlap with other units') and, since the move is one native call (ctm_move: no host-language thread hop per unit),
+        # also on low-rank environments: D = 8 chi = 256, prescribed state, 542 -> 530 ms per sweep with four instead of two
+        # (rounds 2-4, units issued from Python threads: no difference, so two were kept for their smaller workspace)
         krylov = env.__dict__.get("_krylov_units", False)
         nmax = max(_proj_rows(direction, c, state, chi) for c in mine)
         # workspace of one unit: 14 n^2 elements when its four enlarged corners live in the arena; with the corner cache they live in the
@@ -179,7 +181,7 @@ def ctm_MOVE(direction, state, env, ctm_args=cfg.ctm_args, global_args=cfg.globa
         cached = getattr(ctm_args, "corner_cache", True) and ctm_args.projector_method == '4X4' and hasattr(eng, "corner_numel") and \
             4 * len(coords) * nmax * nmax * elem <= 0.6 * torch.cuda.get_device_properties(like.device).total_memory
         pool = units.pool_for(eng, len(mine), nmax, like.dtype.is_complex, est_bytes=(4.5 * nmax * nmax * elem) if cached else None,
-                              large_n_units=None if krylov else 2)
+                              large_n_units=None if krylov else int(os.environ.get("CTM_LOWRANK_UNITS", 4)))
         # a move of this environment ran out of workspace with more units in flight (the estimate above is one measured high-water
         # mark scaled by n^2): stay at the width that worked
         cap = env.__dict__.get("_units_cap")
