@@ -37,7 +37,13 @@ struct Layer2Params {
 // W tiles (all KT contracted-bra blocks x this e block) in registers in the MFMA C/D layout, which IS the A-operand layout
 // of step B (lane l, register r of tile j holds W[kb = 16 j + 4 r + (l >> 4)][e = l & 15] = row e, k-slice r of block j), so W
 // never travels through LDS and the only workgroup barriers are the two around the staging of Z.
-template <int KT>
+// FULL: no padding anywhere (D1 D2 = 16 KT = E1 E2, e.g. D = 4, 8): every output element exists, the stores carry no predicate.
+// What one (x,y) pair costs besides its 2 p KT^3 * 4 matrix instructions runs on the same four waves, one per SIMD, with the matrix pipe
+// idle: at D = 8 the gather, the scatter and the loop bookkeeping were a third of the kernel (ablation with CTM_LAYER2_DBG, DESIGN.md
+// section 5 "Round 5") -- hence no 64-bit divisions in the loop (the pair index advances as (x, y) with carry), no per-element
+// branches in the gather (entries a padded shape does not have go to a padding slot of the LDS image) and, in the FULL
+// instantiation, none in the scatter.
+template <int KT, bool FULL>
 __global__ __launch_bounds__(64 * KT) void layer2_reg_kernel(Layer2Params p) {
     constexpr int KAp = 16 * KT, NEp = 16 * KT, NTH = 64 * KT;
     constexpr int NZ = (KAp * KAp + NTH - 1) / NTH;
@@ -67,7 +73,7 @@ __global__ __launch_bounds__(64 * KT) void layer2_reg_kernel(Layer2Params p) {
             const int c1b = r % p.D1; const int c1k = r / p.D1;
             zoff[j] = c1k * p.zs_c1k + c1b * p.zs_c1b + c2k * p.zs_c2k + c2b * p.zs_c2b;
             zdst[j] = (c1b * p.D2 + c2b) * p.ldz + (c1k * p.D2 + c2k);
-        } else { zoff[j] = 0; zdst[j] = -1; }
+        } else { zoff[j] = 0; zdst[j] = KAp; }          // (row 0, column KAp: the padding column of the image, never an operand)
     }
     long long ooff[KT][4]; bool ook[KT][4];
 #pragma unroll
@@ -83,38 +89,49 @@ __global__ __launch_bounds__(64 * KT) void layer2_reg_kernel(Layer2Params p) {
     }
     const long long npair = (long long)p.nx * p.ny;
     double zreg[NZ];
-    {
-        const long long q = blockIdx.x;
-        if (q < npair) {
-            const double* z = p.Z + (q / p.ny) * p.zs_x + (q % p.ny) * p.zs_y;
+    // pair q = x ny + y; q advances by the grid size: (x, y) += (gx, gy) with carry
+    const int gx = (int)(gridDim.x / (unsigned)p.ny), gy = (int)(gridDim.x % (unsigned)p.ny);
+    int x = (int)(blockIdx.x / (unsigned)p.ny), y = (int)(blockIdx.x % (unsigned)p.ny);
+    if ((long long)blockIdx.x < npair) {
+        const double* z = p.Z + x * p.zs_x + y * p.zs_y;
 #pragma unroll
-            for (int j = 0; j < NZ; ++j) if (zdst[j] >= 0) zreg[j] = z[zoff[j]];
-        }
+        for (int j = 0; j < NZ; ++j) zreg[j] = z[zoff[j]];
     }
     __syncthreads();
 #pragma unroll
-    for (int j = 0; j < NZ; ++j) if (zdst[j] >= 0) Zs[zdst[j]] = zreg[j];
+    for (int j = 0; j < NZ; ++j) Zs[zdst[j]] = zreg[j];
 
     for (long long q = blockIdx.x; q < npair; q += gridDim.x) {
         __syncthreads();                               // Zs of this pair is complete
         const long long qn = q + gridDim.x;
+        int xn = x + gx, yn = y + gy;
+        if (yn >= p.ny) { yn -= p.ny; xn += 1; }
         if (qn < npair && !(p.dbg & 1)) {
-            const double* z = p.Z + (qn / p.ny) * p.zs_x + (qn % p.ny) * p.zs_y;
+            const double* z = p.Z + xn * p.zs_x + yn * p.zs_y;
 #pragma unroll
-            for (int j = 0; j < NZ; ++j) if (zdst[j] >= 0) zreg[j] = z[zoff[j]];
+            for (int j = 0; j < NZ; ++j) zreg[j] = z[zoff[j]];
         }
         d4 acc[KT];
 #pragma unroll
         for (int n = 0; n < KT; ++n) acc[n] = (d4){0., 0., 0., 0.};
         for (int s = 0; s < ((p.dbg & 2) ? 0 : p.p); ++s) {
             const double* Asl = As + s * NEp;
+            // The B operands are fetched AHEAD of the matrix instructions that consume them, into registers of their own (left to itself
+            // the compiler reuses one register pair for all of them: ds_read, s_waitcnt lgkmcnt(0), two or four MFMAs, ds_read ...).
             // ---- step A: W[kb][e] = sum_kk Zs[kb][kk] As[kk][s][e]   (e block of this wave, every kb block)
+            double bA[KAp / 4];
+#pragma unroll
+            for (int kq = 0; kq < KAp / 4; ++kq) bA[kq] = Asl[(lk + 4 * kq) * p.lda + wid * 16 + lr];
+            double bB[2][KT];                                  // step B operands of two consecutive (j, r): double buffer
+#pragma unroll
+            for (int n = 0; n < KT; ++n) bB[0][n] = Asl[lk * p.lda + lr + n * 16];
+            __builtin_amdgcn_sched_barrier(0);
             d4 w[KT];
 #pragma unroll
             for (int j = 0; j < KT; ++j) w[j] = (d4){0., 0., 0., 0.};
 #pragma unroll
             for (int k0 = 0; k0 < KAp; k0 += 4) {
-                const double b = Asl[(lk + k0) * p.lda + wid * 16 + lr];
+                const double b = bA[k0 / 4];
 #pragma unroll
                 for (int j = 0; j < KT; ++j) {
                     const double a = Zs[(j * 16 + lr) * p.ldz + lk + k0];
@@ -123,27 +140,32 @@ __global__ __launch_bounds__(64 * KT) void layer2_reg_kernel(Layer2Params p) {
             }
             // ---- step B: O[e][E] += sum_kb W[kb][e] As[kb][s][E]   (W straight from the accumulator registers)
 #pragma unroll
-            for (int j = 0; j < KT; ++j) {
+            for (int jr = 0; jr < 4 * KT; ++jr) {
+                const int j = jr >> 2, r = jr & 3;
+                if (jr + 1 < 4 * KT) {
+                    const double* brow = Asl + (((jr + 1) >> 2) * 16 + 4 * ((jr + 1) & 3) + lk) * p.lda + lr;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const double a = w[j][r];
-                    const double* brow = Asl + (j * 16 + 4 * r + lk) * p.lda + lr;
-#pragma unroll
-                    for (int n = 0; n < KT; ++n) acc[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, brow[n * 16], acc[n], 0, 0, 0);
+                    for (int n = 0; n < KT; ++n) bB[(jr + 1) & 1][n] = brow[n * 16];
                 }
+                __builtin_amdgcn_sched_barrier(0);
+                const double a = w[j][r];
+#pragma unroll
+                for (int n = 0; n < KT; ++n) acc[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bB[jr & 1][n], acc[n], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
-        double* o = p.out + (q / p.ny) * p.os_x + (q % p.ny) * p.os_y;
+        double* o = p.out + x * p.os_x + y * p.os_y;
 #pragma unroll
         for (int n = 0; n < KT; ++n)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                if (ook[n][r]) o[ooff[n][r]] = acc[n][r];
+                if (FULL || ook[n][r]) o[ooff[n][r]] = acc[n][r];
         __syncthreads();                               // every wave finished reading Zs
         if (qn < npair) {
 #pragma unroll
-            for (int j = 0; j < NZ; ++j) if (zdst[j] >= 0) Zs[zdst[j]] = zreg[j];
+            for (int j = 0; j < NZ; ++j) Zs[zdst[j]] = zreg[j];
         }
+        x = xn; y = yn;
     }
 }
 
@@ -285,18 +307,24 @@ int launch_layer2_c(ctm_ctx* ctx, const Layer2Params& p) {
     return CTM_OK;
 }
 
-template <int KT>
-int launch_layer2_reg(ctm_ctx* ctx, const Layer2Params& p) {
+template <int KT, bool FULL>
+int launch_layer2_reg_t(ctm_ctx* ctx, const Layer2Params& p) {
     const size_t lds_bytes = sizeof(double) * (size_t)p.KAp * (p.ldz + p.lda);
     static std::once_flag attr_once;
-    std::call_once(attr_once, [] { (void)hipFuncSetAttribute((const void*)layer2_reg_kernel<KT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
+    std::call_once(attr_once, [] { (void)hipFuncSetAttribute((const void*)layer2_reg_kernel<KT, FULL>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
     const long long npair = (long long)p.nx * p.ny;
     const int per_cu = std::max(1, std::min(8, (int)((150 * 1024) / lds_bytes)));
     const int grid = (int)std::min<long long>(npair, 256LL * per_cu * 2);
-    CTM_LAUNCH(ctx, layer2_reg_kernel<KT>, dim3(grid), dim3(64 * KT), lds_bytes, p);
+    CTM_LAUNCH(ctx, (layer2_reg_kernel<KT, FULL>), dim3(grid), dim3(64 * KT), lds_bytes, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { ctx->set_error(std::string("layer2 launch: ") + hipGetErrorString(e)); return CTM_ERR_HIP; }
     return CTM_OK;
+}
+
+template <int KT>
+int launch_layer2_reg(ctm_ctx* ctx, const Layer2Params& p) {
+    const bool full = p.KA == p.KAp && p.NE == p.NEp && p.dbg == 0;
+    return full ? launch_layer2_reg_t<KT, true>(ctx, p) : launch_layer2_reg_t<KT, false>(ctx, p);
 }
 
 long long stride_of(const std::string& idx, const DT& t, char ch) {
@@ -394,7 +422,7 @@ int dev_layer2(ctm_ctx* ctx, const std::string& iz, const DT& Z, const std::stri
     p.os_x = stride_of(io, O, sp[0]); p.os_y = stride_of(io, O, sp[1]);
     p.os_e1k = stride_of(io, O, ek[0]); p.os_e1b = stride_of(io, O, eb[0]);
     p.os_e2k = stride_of(io, O, ek[1]); p.os_e2b = stride_of(io, O, eb[1]);
-    p.dbg = 0;
+    { static const int dbg_env = getenv("CTM_LAYER2_DBG") ? atoi(getenv("CTM_LAYER2_DBG")) : 0; p.dbg = dbg_env; }     // development (timing ablations; results are wrong): 1 skip gather, 2 skip MFMA, 4 skip scatter
     const long long npair = (long long)p.nx * p.ny;
     const double fl = 2.0 * npair * p.p * ((double)p.KA * p.KA * p.NE + (double)p.KA * p.NE * p.NE) * (cx ? 4.0 : 1.0);
     const int ev = timing_begin(ctx);
