@@ -208,7 +208,7 @@ __global__ __launch_bounds__(64 * KT) void layer2_c_kernel(Layer2Params p) {
             const int c1b = r % p.D1; const int c1k = r / p.D1;
             zoff[j] = c1k * p.zs_c1k + c1b * p.zs_c1b + c2k * p.zs_c2k + c2b * p.zs_c2b;
             zdst[j] = (c1b * p.D2 + c2b) * ldz + (c1k * p.D2 + c2k);
-        } else { zoff[j] = 0; zdst[j] = -1; }
+        } else { zoff[j] = 0; zdst[j] = KAp; }          // (padding column of row 0: never an operand)
     }
     long long ooff[KT][4]; bool ook[KT][4];
 #pragma unroll
@@ -224,25 +224,27 @@ __global__ __launch_bounds__(64 * KT) void layer2_c_kernel(Layer2Params p) {
     }
     const long long npair = (long long)p.nx * p.ny;
     double zr[NZ], zi[NZ];
-    {
-        const long long q = blockIdx.x;
-        if (q < npair) {
-            const long long zo = (q / p.ny) * p.zs_x + (q % p.ny) * p.zs_y;
+    // pair q = x ny + y advances by the grid size as (x, y) += (gx, gy) with carry (no 64-bit divisions in the loop, see layer2_reg_kernel)
+    const int gx = (int)(gridDim.x / (unsigned)p.ny), gy = (int)(gridDim.x % (unsigned)p.ny);
+    int x = (int)(blockIdx.x / (unsigned)p.ny), y = (int)(blockIdx.x % (unsigned)p.ny);
+    if ((long long)blockIdx.x < npair) {
+        const long long zo = x * p.zs_x + y * p.zs_y;
 #pragma unroll
-            for (int j = 0; j < NZ; ++j) if (zdst[j] >= 0) { zr[j] = p.Z[zo + zoff[j]]; zi[j] = p.Zi[zo + zoff[j]]; }
-        }
+        for (int j = 0; j < NZ; ++j) { zr[j] = p.Z[zo + zoff[j]]; zi[j] = p.Zi[zo + zoff[j]]; }
     }
     __syncthreads();
 #pragma unroll
-    for (int j = 0; j < NZ; ++j) if (zdst[j] >= 0) { Zr[zdst[j]] = zr[j]; Zi[zdst[j]] = zi[j]; }
+    for (int j = 0; j < NZ; ++j) { Zr[zdst[j]] = zr[j]; Zi[zdst[j]] = zi[j]; }
 
     for (long long q = blockIdx.x; q < npair; q += gridDim.x) {
         __syncthreads();
         const long long qn = q + gridDim.x;
+        int xn = x + gx, yn = y + gy;
+        if (yn >= p.ny) { yn -= p.ny; xn += 1; }
         if (qn < npair) {
-            const long long zo = (qn / p.ny) * p.zs_x + (qn % p.ny) * p.zs_y;
+            const long long zo = xn * p.zs_x + yn * p.zs_y;
 #pragma unroll
-            for (int j = 0; j < NZ; ++j) if (zdst[j] >= 0) { zr[j] = p.Z[zo + zoff[j]]; zi[j] = p.Zi[zo + zoff[j]]; }
+            for (int j = 0; j < NZ; ++j) { zr[j] = p.Z[zo + zoff[j]]; zi[j] = p.Zi[zo + zoff[j]]; }
         }
         d4 wr[KT], wi[KT], accr[KT], acci[KT];
 #pragma unroll
@@ -275,7 +277,7 @@ __global__ __launch_bounds__(64 * KT) void layer2_c_kernel(Layer2Params p) {
                 }
             }
         }
-        const long long oo = (q / p.ny) * p.os_x + (q % p.ny) * p.os_y;
+        const long long oo = x * p.os_x + y * p.os_y;
 #pragma unroll
         for (int n = 0; n < KT; ++n)
 #pragma unroll
@@ -288,8 +290,9 @@ __global__ __launch_bounds__(64 * KT) void layer2_c_kernel(Layer2Params p) {
         __syncthreads();
         if (qn < npair) {
 #pragma unroll
-            for (int j = 0; j < NZ; ++j) if (zdst[j] >= 0) { Zr[zdst[j]] = zr[j]; Zi[zdst[j]] = zi[j]; }
+            for (int j = 0; j < NZ; ++j) { Zr[zdst[j]] = zr[j]; Zi[zdst[j]] = zi[j]; }
         }
+        x = xn; y = yn;
     }
 }
 
