@@ -11,7 +11,7 @@ bash tools/profile_bench.sh signed_serial --mfma -- --signed $X --serial-units >
 bash tools/profile_bench.sh stationary -- --signed $X --warm-tol 1e-9 --warmup 16 --steps 3 > gpurun_out/prof_stationary.log 2>&1
 bash tools/profile_bench.sh c4v -- --config c4v_D4_chi64 --no-cpu-baseline --no-live-traffic > gpurun_out/prof_c4v.log 2>&1
 bash tools/profile_bench.sh c128_signed -- --config generic_D8_chi384_c128 --signed --steps 1 --warmup 2 --no-cpu-baseline --no-serial-pass --no-energy --no-live-traffic > gpurun_out/prof_c128_signed.log 2>&1
-/usr/bin/time -f "default bench.py wall %e s" -o gpurun_out/bench_final_wall.txt python bench.py > gpurun_out/bench_final.json 2> gpurun_out/bench_final.err
+SECONDS=0; python bench.py > gpurun_out/bench_final.json 2> gpurun_out/bench_final.err; echo "default bench.py: ${SECONDS} s of wall time" > gpurun_out/bench_final_wall.txt
 cp gpurun_out/bench_detail.json gpurun_out/bench_final_detail.json
 python bench.py --steps 20 --warmup 5 --no-other-configs --no-energy --no-cpu-baseline > gpurun_out/bench_20steps.json 2>/dev/null
 python bench.py --config c4v_D4_chi64 > gpurun_out/bench_c4v_final.json 2>/dev/null
