@@ -535,7 +535,7 @@ def other_configs(args, eng, dev, world, rank, dist):
         # on one GPU -- warms up with 2 sweeps: its corners carry 192 / 225 of 384 values above 1e-8 after the first / second sweep
         # (gpurun probe r4c), i.e. the timed sweep IS the full-rank regime, and 6 warm-up sweeps would add 2.5 minutes to the default run
         for name, signed, steps, warmup in (("c4v_D4_chi64", False, 100, 4), ("c4v_D4_chi64", True, 100, 4), ("generic_D6_chi128", False, 3, 4), ("generic_D6_chi128", True, 3, 4),
-                                            ("generic_D8_chi384_c128", False, 1, 6), ("generic_D8_chi384_c128", True, 1, 2)):
+                                            ("generic_D8_chi384_c128", False, 1, 3), ("generic_D8_chi384_c128", True, 1, 2)):
             kind, D, chi, dtype = CONFIGS[name]
             key = name + ("_signed" if signed else "")
             try:
@@ -700,7 +700,7 @@ def traffic_live(args, dom, signed, warmup):
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             d = tempfile.mkdtemp(prefix="ctm_pmc_", dir="/tmp")
             cmd = [prof, "--pmc", counter, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__), "--config", args.config,
-                   "--steps", "1", "--warmup", str(warmup), "--no-cpu-baseline", "--no-serial-pass", "--no-other-configs", "--no-energy", "--no-live-traffic"] + \
+                   "--steps", "1", "--warmup", str(warmup), "--no-cpu-baseline", "--no-serial-pass", "--no-other-configs", "--no-energy", "--no-live-traffic", "--no-stationary"] + \
                   (["--signed"] if signed else ["--no-full-rank"]) + [x for kv in args.opt for x in ("--opt", kv)]
             env = dict(os.environ, CTM_BENCH_CHILD="1", TMPDIR="/tmp")
             pr = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
@@ -771,6 +771,7 @@ def main():
     ap.add_argument("--warm-tol", type=float, default=0.0, help="ctm_args.projector_warm_tol for the WHOLE run (timed sweeps included): with enough warm-up sweeps the timed region is the stationary regime")
     ap.add_argument("--no-stationary", action="store_true", help="skip the stationary-environment block of the full-rank state (projector_warm_tol fast path)")
     ap.add_argument("--no-energy", action="store_true", help="skip the energy block (E/site from rdm2x2 at the size of the timed run)")
+    ap.add_argument("--live-traffic-full-rank", action="store_true", help="measure the HBM traffic of the full-rank block by child runs under rocprofv3 too (default: the primary block only)")
     ap.add_argument("--energy", action="store_true", help="the energy block also for a --config other than the default one")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the compact blocks of the other single-GPU BASELINE configurations")
     ap.add_argument("--no-live-traffic", action="store_true", help="roofline.traffic from the committed PMC pass instead of two rocprofv3 --pmc child runs of this command")
@@ -828,7 +829,9 @@ def main():
         del state, env
         import gc; gc.collect(); torch.cuda.empty_cache()
         full, fdom, fsites, fstate, fenv = run_workload(args, eng, dev, kind, D, chi, dtype, True, steps, warmup, world, rank, dist)
-        ftr = (traffic_live(args, fdom, True, min(warmup, 2)) if live else None) or traffic_from_profile(args, world, fdom, True)
+        # (the full-rank block takes its traffic from the committed PMC pass unless asked: two more child runs of the 50 000-launch sweep
+        # under counter collection were 2.5 of the 11 minutes of the default command)
+        ftr = (traffic_live(args, fdom, True, min(warmup, 2)) if live and args.live_traffic_full_rank else None) or traffic_from_profile(args, world, fdom, True)
         if ftr:
             full["roofline"]["traffic"] = ftr["dominant"]; full["roofline"]["traffic_source"] = ftr["source"]
         if not args.no_energy and (args.config == DEFAULT_CONFIG or args.energy):
