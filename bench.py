@@ -168,20 +168,27 @@ def energy_parity(dev, dtype="f64", D=3, chi=36, nsweeps=3, signed=False):
     sites = synth_sites("generic", D, seed=3, dtype=dtype, signed=signed)
     st = IPEPS({k: torch.from_numpy(v).to(dev) for k, v in sites.items()})
     env = ENV(chi, st); init_env(st, env)
+    import _native
+    eng = _native.engine()
+    l0 = eng.stat("lz_hits")
     for _ in range(nsweeps):
         for d in cfg.ctm_args.ctm_move_sequence:
             for _r in range(2):
                 ctmrg.ctm_MOVE(d, st, env)
     e = float(j1j2.J1J2(j1=1.0, j2=0.5).energy_per_site(st, env))
     spec = {k: v.cpu().numpy() for k, v in env.get_spectra().items()}
+    nkry = int(eng.stat("lz_hits") - l0)
+    t0 = time.perf_counter()
     ost = O.State(sites); oe = O.init_env_ctmrg(ost, chi)
     for _ in range(nsweeps):
         O.ctm_sweep(ost, oe)
     eo = OJ.energy_per_site([O.rdm2x2(c, ost, oe) for c in ost.sites], 1.0, 0.5)
     ospec = O.corner_spectra(oe)
     return {"workload": f"generic 2x2 D={D} chi={chi} {dtype}{' signed' if signed else ''}, {nsweeps} sweeps from the CTMRG init, J1-J2 j2=0.5", "energy_native": e,
-            "energy_oracle": float(eo), "rel_err": abs(e - eo) / max(abs(eo), 1e-300),
-            "max_abs_err_corner_spectra": float(max(np.abs(spec[k] - ospec[k]).max() for k in ospec)), "tolerance": 1e-10}
+            "energy_oracle": float(eo), "rel_err": abs(e - eo) / max(abs(eo), 1e-300), "abs_err": abs(e - eo),
+            "max_abs_err_corner_spectra": float(max(np.abs(spec[k] - ospec[k]).max() for k in ospec)), "tolerance": 1e-10,
+            # how many of the truncations of these sweeps were block Krylov solves (the full-rank route) rather than block power iterations
+            "block_krylov_solves": nkry, "truncations": 32 * nsweeps, "oracle_seconds": round(time.perf_counter() - t0, 1)}
 
 
 def cpu_baseline_large(O, ost, env, D, chi, threads, env_what="dense random environment"):
@@ -205,9 +212,11 @@ def cpu_baseline_large(O, ost, env, D, chi, threads, env_what="dense random envi
     t0 = time.perf_counter(); O.absorb_truncate(O.UP, (0, 0), ost, env, Pd, Pd); t_abs = time.perf_counter() - t0
     dt = t_corners + 3 * t_gemm + t_svd + t_proj + t_abs
     return {"value": 1.0 / (32 * dt), "unit": "sweeps/s", "cores": threads, "kind": "port",
-            "sample": f"one (site,direction) unit of the numpy oracle on the {env_what}, assembled from bounded pieces: 4 corners {t_corners:.1f} s + 3 x (n^3 GEMM "
-                      f"{t_gemm:.1f} s) + gesdd at n_s=4096 {t_svd_s:.1f} s scaled by (n/n_s)^3 = {t_svd:.0f} s + projector GEMMs {t_proj:.1f} s + "
-                      f"absorb {t_abs:.1f} s = {dt:.0f} s/unit, x32 units/sweep (extrapolated); {os.cpu_count()} host cpus"}
+            # (the driver keeps the first 120 characters: what is extrapolated comes first)
+            "sample": f"EXTRAPOLATED: dgesdd timed at n_s=4096, scaled x(n/n_s)^3 to n={n} = {100 * t_svd / dt:.0f}% of 1 unit; x32 units/sweep. "
+                      f"One (site,direction) unit of the numpy oracle on the {env_what}, assembled from bounded pieces: 4 corners {t_corners:.1f} s + 3 x (n^3 GEMM "
+                      f"{t_gemm:.1f} s) + gesdd at n_s=4096 {t_svd_s:.1f} s scaled = {t_svd:.0f} s + projector GEMMs {t_proj:.1f} s + "
+                      f"absorb {t_abs:.1f} s = {dt:.0f} s/unit; {os.cpu_count()} host cpus"}
 
 
 def _union_ms(ivals, kind):
@@ -383,11 +392,20 @@ def run_workload(args, eng, dev, kind, D, chi, dtype, signed, steps, warmup, wor
         eng.set_option("gemm_timing", 0)
         cfg.ctm_args.concurrent_units = True
     stationary = None
-    if world == 1 and kind != "c4v" and signed and dtype == "f64" and not args.no_stationary and not args.warm_tol:      # (the complex solver has no such path yet)
+    # both dtypes (svd_stationary / svd_stationary_c); bounded: up to 14 + 3 more sweeps -- skipped where that is more than ~2 minutes
+    # (configs[4] at 18-35 s per sweep: run `bench.py --config generic_D8_chi384_c128 --signed --stationary-budget-s 900` for that block)
+    if world == 1 and kind != "c4v" and signed and not args.no_stationary and not args.warm_tol and 17 * dt / steps > args.stationary_budget_s:
+        stationary = {"skipped": f"17 sweeps of {dt / steps:.1f} s exceed --stationary-budget-s {args.stationary_budget_s:.0f}"}
+    elif world == 1 and kind != "c4v" and signed and not args.no_stationary and not args.warm_tol:
+        # the block advances the environment by up to 14 + 3 approximately truncated sweeps: the `state` block below and the energy
+        # blocks of main() describe the environment the TIMED sweeps ended with (what `--gpus N` lines report too), so the block works
+        # on the environment and the old tensors are put back afterwards (a move rebinds env.C / env.T entries, it writes into none)
+        C_timed, T_timed = dict(env.C), dict(env.T)
         try:
             stationary = stationary_block(eng, step, env)
         except Exception as e:                         # reporting only
             stationary = {"error": repr(e)}
+        env.C, env.T = C_timed, T_timed
     comm_ranks = None
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -510,7 +528,8 @@ def compact(res):
     """One BASELINE configuration as a short block of the JSON line."""
     roof = res["roofline"]
     out = {"value": res["value"], "unit": "sweeps/s", "ms_per_step": res["ms_per_step"], "steps": res["steps"], "warmup": res["warmup"],
-           "dominant_kernel": {k: roof.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "frac_union")},
+           "dominant_kernel": {**{k: roof.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "frac_union")},
+                               "frac_alone": ((roof.get("serial_pass") or {}).get("dominant") or {}).get("frac")},
            "executed_flop_per_sweep": roof.get("executed_flop_per_sweep"), "sweep_mfma_frac": roof.get("sweep_mfma_frac"),
            "svd": res["svd"]}
     for k in ("state", "steady_state", "moving_environment", "stationary_environment"):
@@ -540,6 +559,9 @@ def other_configs(args, eng, dev, world, rank, dist):
             key = name + ("_signed" if signed else "")
             try:
                 t0 = time.perf_counter()
+                # the serially issued extra sweep (`frac_alone`) where a sweep is a fraction of a second (configs[2]); configs[4] at 10-35 s per
+                # sweep stays without it (bench.py --config generic_D8_chi384_c128 [--signed] prints it)
+                args.no_serial_pass = not (kind == "generic" and dtype == "f64")
                 res, dom, sites, state, env = run_workload(args, eng, dev, kind, D, chi, dtype, signed, steps, warmup, world, rank, dist)
                 out[key] = compact(res)
                 out[key]["dtype"] = dtype
@@ -602,6 +624,7 @@ def _compact_block(b):
     dk = b.get("dominant_kernel") or b.get("roofline") or {}
     o = {"value": round(b["value"], 5), "ms_per_step": round(b["ms_per_step"], 3), "steps": b["steps"], "warmup": b["warmup"],
          "kernel": _short_kernel(dk.get("kernel")), "bound": dk.get("bound"), "frac": dk.get("frac"), "frac_union": dk.get("frac_union"),
+         "frac_alone": dk.get("frac_alone", ((dk.get("serial_pass") or {}).get("dominant") or {}).get("frac")),
          "sweep_mfma_frac": b.get("sweep_mfma_frac", dk.get("sweep_mfma_frac"))}
     sv = b.get("svd") or {}
     if sv.get("block_krylov_solves") is not None:
@@ -661,7 +684,9 @@ def metric_line(d):
             blk["energy"] = e if "error" in e else {"seconds_per_energy_4_sites": e["seconds_per_energy_4_sites"], "energy_per_site_j2_0.5": e["energy_per_site_j2_0.5"],
                                                     "n_gpus": e.get("n_gpus"), "rdm2x2_invariants": e.get("rdm2x2_invariants")}
         if "energy_parity" in fr:
-            blk["energy_parity"] = {k: fr["energy_parity"].get(k) for k in ("rel_err", "max_abs_err_corner_spectra", "tolerance")}
+            ep_ = fr["energy_parity"]
+            blk["energy_parity"] = ep_ if "error" in ep_ else {k: ep_.get(k) for k in ("workload", "rel_err", "abs_err", "max_abs_err_corner_spectra", "tolerance",
+                                                                                       "block_krylov_solves", "oracle_seconds")}
         line["full_rank"] = blk
     line["roofline"] = roof
     if "cpu_baseline" in d:
@@ -678,7 +703,8 @@ def metric_line(d):
         line["signed_state"] = _compact_block(d["signed_state"])
     if "energy_parity" in d:
         ep = d["energy_parity"]
-        line["energy_parity"] = ep if "error" in ep else {k: ep.get(k) for k in ("workload", "rel_err", "max_abs_err_corner_spectra", "tolerance")}
+        line["energy_parity"] = ep if "error" in ep else {k: ep.get(k) for k in ("workload", "rel_err", "abs_err", "max_abs_err_corner_spectra", "tolerance",
+                                                                                  "block_krylov_solves", "oracle_seconds")}
     if "other_configs" in d:
         line["other_configs"] = {k: _compact_block(v) for k, v in d["other_configs"].items()}
     return line
@@ -769,6 +795,7 @@ def main():
     ap.add_argument("--serial-units", action="store_true", help="do not overlap the independent site-units of a move on streams")
     ap.add_argument("--cold-start", action="store_true", help="no warm start of the leading-chi iteration")
     ap.add_argument("--warm-tol", type=float, default=0.0, help="ctm_args.projector_warm_tol for the WHOLE run (timed sweeps included): with enough warm-up sweeps the timed region is the stationary regime")
+    ap.add_argument("--stationary-budget-s", type=float, default=120.0, help="skip the stationary-environment block where its 14 + 3 sweeps would take longer than this")
     ap.add_argument("--no-stationary", action="store_true", help="skip the stationary-environment block of the full-rank state (projector_warm_tol fast path)")
     ap.add_argument("--no-energy", action="store_true", help="skip the energy block (E/site from rdm2x2 at the size of the timed run)")
     ap.add_argument("--live-traffic-full-rank", action="store_true", help="measure the HBM traffic of the full-rank block by child runs under rocprofv3 too (default: the primary block only)")
@@ -893,10 +920,15 @@ def main():
                 out["cpu_baseline"] = {"error": repr(e)}
             try:
                 out["energy_parity"] = energy_parity(dev, dtype)
-                if full is not None:
-                    out["full_rank"]["energy_parity"] = energy_parity(dev, dtype, signed=True)
             except Exception as e:
                 out["energy_parity"] = {"error": repr(e)}
+            if full is not None:
+                # the metric's second half where the block Krylov solver actually runs: the largest full-rank size the oracle finishes
+                # in about a minute (D = 4 chi = 64 signed, n = 1024, 3 sweeps + four plaquette RDMs on the host)
+                try:
+                    out["full_rank"]["energy_parity"] = energy_parity(dev, dtype, D=4, chi=64, nsweeps=3, signed=True)
+                except Exception as e:
+                    out["full_rank"]["energy_parity"] = {"error": repr(e)}
         line = metric_line(out)
         # the verbose blocks (per-class rooflines, serial passes, every other configuration in full) go to stderr and to a file; stdout
         # carries ONE line that fits the driver's record

@@ -55,6 +55,24 @@ class Env:
         return e
 
 
+def env_extend(env, new_chi):
+    """ENV.extend (env.py:164-202): zero-padded copy with environment dimension new_chi (leading min(chi, new_chi) block kept)."""
+    e = Env(new_chi)
+    x = min(env.chi, new_chi)
+    for k, c in env.C.items():
+        e.C[k] = np.zeros((new_chi, new_chi), dtype=c.dtype); e.C[k][:x, :x] = c[:x, :x]
+    for k, t in env.T.items():
+        if k[1] in ((0, -1), (1, 0)):
+            e.T[k] = np.zeros((new_chi, t.shape[1], new_chi), dtype=t.dtype); e.T[k][:x, :, :x] = t[:x, :, :x]
+        elif k[1] == (-1, 0):
+            e.T[k] = np.zeros((new_chi, new_chi, t.shape[2]), dtype=t.dtype); e.T[k][:x, :x, :] = t[:x, :x, :]
+        elif k[1] == (0, 1):
+            e.T[k] = np.zeros((t.shape[0], new_chi, new_chi), dtype=t.dtype); e.T[k][:, :x, :x] = t[:, :x, :x]
+        else:
+            raise ValueError(f"Unexpected direction {k[1]}")
+    return e
+
+
 def _nrm(a):
     return a / np.abs(a).max()
 

@@ -220,6 +220,104 @@ def generic_case(name, D, chi, complex_, seed, warm_sweeps=2):
     np.savez_compressed(os.path.join(GOLD, name + ".npz"), **out)
 
 
+def signed_state(D, complex_, seed):
+    """A ~ U(-1/2, 1/2) (+ i U(-1/2, 1/2)), A /= max|A|: full-rank environments (every truncation keeps chi significant triplets)."""
+    rng = np.random.default_rng(seed)
+    sites = {}
+    for y in range(2):
+        for x in range(2):
+            A = rng.random((2, D, D, D, D)) - 0.5
+            if complex_:
+                A = A + 1j * (rng.random((2, D, D, D, D)) - 0.5)
+            sites[(x, y)] = A / np.abs(A).max()
+    return sites
+
+
+def _run_fixed(st, env, nsweeps):
+    """The reference's ctmrg.run for exactly nsweeps sweeps (a conv_check that only counts)."""
+    def count(state, env, history, ctm_args=cfg.ctm_args):
+        history = history or []
+        history.append(len(history))
+        return len(history) >= nsweeps, history
+    old = cfg.ctm_args.ctm_max_iter
+    cfg.ctm_args.ctm_max_iter = nsweeps
+    try:
+        env, hist, *_ = ctmrg.run(st, env, conv_check=count)
+    finally:
+        cfg.ctm_args.ctm_max_iter = old
+    assert len(hist) == nsweeps
+    return env
+
+
+def fixed_point_case(name, D, chi, complex_, seed, nsweeps):
+    """Signed random 2x2 state, the REFERENCE's ctmrg.run for a fixed number of sweeps that ends well inside the stationary regime (the
+    corner spectra stop moving at the 1e-11 level after ~16 sweeps): corner spectra, rdm2x2 energy and the per-sweep movement of the spectra.
+    n = chi D^2 >= 256 and chi >= 47, so the engine's truncations are block Krylov solves and -- with ctm_args.projector_warm_tol -- its
+    stationary fast path; what tests/test_gpu_stationary.py and tests/test_gpu_generic.py pin those routes against."""
+    set_dtype(complex_)
+    sites = signed_state(D, complex_, seed)
+    st = ref_state(sites); ost = O.State(sites)
+    env = ENV(chi, st); init_env(st, env)
+    env = _run_fixed(st, env, nsweeps)
+    spec = {k: t2n(v) for k, v in env.get_spectra().items()}
+    rd = [t2n(rdm.rdm2x2_legacy(c, st, env)) for c in sites]
+    e = OJ.energy_per_site(rd, 1.0, 0.5)
+    oe = O.init_env_ctmrg(ost, chi)
+    moved = []
+    prev = None
+    for _ in range(nsweeps):
+        O.ctm_sweep(ost, oe)
+        so = O.corner_spectra(oe)
+        if prev is not None:
+            moved.append(max(np.abs(so[k] - prev[k]).max() for k in so))
+        prev = so
+    worst = max(np.abs(so[k] - spec[k]).max() for k in spec)
+    eo = OJ.energy_per_site([O.rdm2x2(c, ost, oe) for c in sites], 1.0, 0.5)
+    print(f"  {name}: {nsweeps} sweeps, oracle-vs-ref spectra {worst:.2e}, energy {eo:.15f} vs {e:.15f}; movement of the spectra in the last sweeps {moved[-3:]}")
+    assert worst < 1e-10 and abs(eo - e) < 1e-10 * abs(e) + 1e-13
+    out = {f"site_{k[0]}_{k[1]}": v for k, v in sites.items()}
+    out.update(chi=np.array(chi), nsweeps=np.array(nsweeps), energy=np.array(e), spectra_movement=np.array(moved))
+    for (c, v), s_ in spec.items():
+        out[f"spec_{c[0]}_{c[1]}_{v[0]}_{v[1]}"] = s_
+    out["rdm2x2_0_0"] = rd[list(sites).index((0, 0))]
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **out)
+
+
+def chi_ramp_case(name, D, chi0, chi1, complex_, seed, n0, n1):
+    """ENV.extend (env.py:164-202) inside a run, as the reference's scripts ramp the environment dimension: n0 sweeps at chi0 from the
+    CTMRG init, extend to chi1 (zero padding), n1 more sweeps.  Stored: the extended environment right after extend() (exact), corner
+    spectra, |C|, |T| and the rdm2x2 energy at the end; the oracle's env_extend + sweeps are checked against the same run."""
+    set_dtype(complex_)
+    sites = signed_state(D, complex_, seed)
+    st = ref_state(sites); ost = O.State(sites)
+    env = ENV(chi0, st); init_env(st, env)
+    env = _run_fixed(st, env, n0)
+    env = env.extend(chi1)
+    Cx, Tx = env_to_np(env)
+    env = _run_fixed(st, env, n1)
+    spec = {k: t2n(v) for k, v in env.get_spectra().items()}
+    rd = [t2n(rdm.rdm2x2_legacy(c, st, env)) for c in sites]
+    e = OJ.energy_per_site(rd, 1.0, 0.5)
+    oe = O.init_env_ctmrg(ost, chi0)
+    for _ in range(n0): O.ctm_sweep(ost, oe)
+    oe = O.env_extend(oe, chi1)
+    for k in Cx: assert oe.C[k].shape == Cx[k].shape and np.abs(np.abs(oe.C[k]) - np.abs(Cx[k])).max() < 1e-7 * np.abs(Cx[k]).max(), k
+    for k in Tx: assert oe.T[k].shape == Tx[k].shape and np.abs(np.abs(oe.T[k]) - np.abs(Tx[k])).max() < 1e-7 * np.abs(Tx[k]).max(), k
+    for _ in range(n1): O.ctm_sweep(ost, oe)
+    so = O.corner_spectra(oe)
+    worst = max(np.abs(so[k] - spec[k]).max() for k in spec)
+    eo = OJ.energy_per_site([O.rdm2x2(c, ost, oe) for c in sites], 1.0, 0.5)
+    print(f"  {name}: chi {chi0} x {n0} sweeps -> extend({chi1}) -> {n1} sweeps, oracle-vs-ref spectra {worst:.2e}, energy {eo:.15f} vs {e:.15f}")
+    assert worst < 1e-10 and abs(eo - e) < 1e-10 * abs(e) + 1e-13
+    out = {f"site_{k[0]}_{k[1]}": v for k, v in sites.items()}
+    out.update(chi0=np.array(chi0), chi1=np.array(chi1), n0=np.array(n0), n1=np.array(n1), energy=np.array(e))
+    for (c, v), s_ in spec.items():
+        out[f"spec_{c[0]}_{c[1]}_{v[0]}_{v[1]}"] = s_
+    C1, T1 = env_to_np(env)
+    pack_env("end_", C1, T1, out)
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **out)
+
+
 def svd_cases():
     """truncated_svd_gesdd incl. multiplet back-off + fix_svd_signs; truncated_eig_sym."""
     set_dtype(False)
@@ -875,7 +973,7 @@ def chiral_case():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["decomp", "generic", "c4v", "c4v_ad", "generic_ad", "c4v_j3", "generic_corr", "envinit", "rvb", "files", "variants", "aklt", "inputs", "backward"]
+    which = sys.argv[1:] or ["decomp", "generic", "c4v", "c4v_ad", "generic_ad", "c4v_j3", "generic_corr", "envinit", "rvb", "files", "variants", "aklt", "inputs", "backward", "fixed_point", "chi_ramp"]
     if "chiral" in which:
         chiral_case()
     if "backward" in which:
@@ -888,6 +986,12 @@ if __name__ == "__main__":
         variants_check()
     if "decomp" in which:
         svd_cases()
+    if "fixed_point" in which:
+        fixed_point_case("fixed_point_D3_chi48_f64", 3, 48, False, 11, 26)
+        fixed_point_case("fixed_point_D3_chi48_c128", 3, 48, True, 12, 26)
+    if "chi_ramp" in which:
+        chi_ramp_case("chi_ramp_D3_chi16_36_f64", 3, 16, 36, False, 14, 3, 4)
+        chi_ramp_case("chi_ramp_D2_chi6_12_c128", 2, 6, 12, True, 15, 3, 4)
     if "generic" in which:
         generic_case("generic_D2_chi8_f64", 2, 8, False, 11)
         generic_case("generic_D3_chi18_f64", 3, 18, False, 12)

@@ -612,9 +612,25 @@ class Engine:
             m = arr[i]
             for j in range(16): m.proj[j] = ts[j].data_ptr()
             for j in range(20): m.proj_adims[j] = ad[j]
+            # the same argument checks as projectors_4x4 / absorb (a malformed workspace must be a NativeError, not a device write
+            # out of bounds): ctm_move reads the environment with dimension chi on every leg and writes chi x chi corners
+            chi_env = ts[0].shape[0]
+            n = chi_env * ts[3].shape[CUT_LEG[d]] ** 2
+            if chi_env != chi or u["absorb6"][0].shape[0] != chi or u["absorb6"][4].shape[0] != chi:
+                raise NativeError(f"move: unit {i}: environment tensors of dimension {chi_env} / {u['absorb6'][0].shape[0]} in a move to chi = {chi} "
+                                  "(ctm_move takes environments of dimension chi; use projectors_4x4 + absorb for chi-ramping)")
             b = u.get("basis")
+            if b is not None:
+                k = chi + 1 if chi < n else n
+                if not (b.is_cuda and b.device == ts[0].device and b.dtype == torch.float64 and b.is_contiguous()
+                        and tuple(b.shape) == ((2 if dtype.is_complex else 1) * k + 1, n)):
+                    raise NativeError(f"move: unit {i}: basis must come from warm_basis(chi, n, dtype)")
             m.basis = b.data_ptr() if b is not None else None
             cs = u.get("corners")
+            if cs is not None:
+                for buf, _ in cs:
+                    if buf is not None and not (buf.is_cuda and buf.device == ts[0].device and buf.dtype == torch.float64 and buf.is_contiguous()):
+                        raise NativeError(f"move: unit {i}: corner buffers must be contiguous float64 tensors on the engine's device")
             m.use_corner_cache = 1 if cs is not None else 0
             for j in range(4):
                 buf, valid = cs[j] if cs is not None else (None, False)
@@ -625,8 +641,6 @@ class Engine:
             A = a6[5]
             for j in range(5): m.absorb_adims[j] = A.shape[j]
             m.nb = int(u["nb"])
-            chi_env = ts[0].shape[0]
-            n = chi_env * ts[3].shape[CUT_LEG[d]] ** 2
             kc = min(chi, n)
             m.n_rows = n
             D2 = A.shape[(3, 4, 1, 2)[d]] ** 2

@@ -204,8 +204,8 @@ struct ctm_ctx {
     // one call at a time: a context owns ONE arena stack and ONE stream, so two threads inside it at once corrupt both silently.
     // EntryGuard (below) makes that a loud CTM_ERR_BUSY instead (same-thread nesting -- an entry implemented by another -- is fine)
     std::atomic<int> busy{0};
-    std::thread::id owner;
-    int depth = 0;
+    std::atomic<std::thread::id> owner{std::thread::id()};      // read by a contending thread while the owning one writes it: atomic, not a plain member
+    int depth = 0;                                              // touched by the owning thread only (after ownership is established)
     void set_error(const std::string& s) { last_error = s; }
 };
 
@@ -214,11 +214,11 @@ struct EntryGuard {
     explicit EntryGuard(ctm_ctx* ctx) : c(ctx), ok(true) {
         const std::thread::id me = std::this_thread::get_id();
         int expect = 0;
-        if (c->busy.compare_exchange_strong(expect, 1, std::memory_order_acquire)) { c->owner = me; c->depth = 1; }
-        else if (c->owner == me) ++c->depth;
+        if (c->busy.compare_exchange_strong(expect, 1, std::memory_order_acquire)) { c->owner.store(me, std::memory_order_relaxed); c->depth = 1; }
+        else if (c->owner.load(std::memory_order_relaxed) == me) ++c->depth;      // only the owner itself can read its own id here
         else ok = false;
     }
-    ~EntryGuard() { if (ok && --c->depth == 0) { c->owner = std::thread::id(); c->busy.store(0, std::memory_order_release); } }
+    ~EntryGuard() { if (ok && --c->depth == 0) { c->owner.store(std::thread::id(), std::memory_order_relaxed); c->busy.store(0, std::memory_order_release); } }
 };
 
 // Body of every compute entry of the C-ABI: refuses concurrent use of one context, and no C++ exception crosses the boundary

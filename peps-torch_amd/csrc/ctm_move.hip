@@ -94,6 +94,7 @@ int for_units(ctm_ctx* ctx, ctm_ctx* const* workers, int nw, int n, F&& fn, std:
                 try { st = fn(w, i); }
                 catch (const std::bad_alloc&) { st = CTM_ERR_NOMEM; w->set_error("ctm_move: host allocation failed in a unit"); }
                 catch (const std::exception& e) { st = CTM_ERR_HIP; w->set_error(std::string("ctm_move: C++ exception in a unit: ") + e.what()); }
+                catch (...) { st = CTM_ERR_HIP; w->set_error("ctm_move: unknown exception in a unit"); }      // nothing may reach std::terminate from a thread
                 if (st != CTM_OK) {
                     int expect = CTM_OK;
                     if (status.compare_exchange_strong(expect, st)) { std::lock_guard<std::mutex> l(emu); *err = w->last_error; }
@@ -128,9 +129,15 @@ extern "C" int ctm_move(ctm_ctx* ctx, ctm_ctx* const* workers, int nworkers, int
             CTM_HIP_CHECK(ctx, e);
         }
         std::string err;
+        // a unit that fails returns mid-pipeline: kernels writing its outputs or its arena may still be queued on its worker stream, and
+        // the caller gives the output tensors back to its allocator as soon as it sees the status -- every stream is drained first
+        auto drain = [&]() {
+            for (int t = 0; t < nworkers; ++t) (void)hipStreamSynchronize(workers[t]->stream);
+            (void)hipStreamSynchronize(ctx->stream);
+        };
         // phase A: projectors of every site from the old environment
         int st = for_units(ctx, workers, nworkers, nunits, [&](ctm_ctx* w, int i) { return run_projectors(w, dir, &units[i], chi, cfg); }, &err);
-        if (st != CTM_OK) { if (!err.empty()) ctx->set_error("ctm_move, projector unit: " + err); return st; }
+        if (st != CTM_OK) { drain(); if (!err.empty()) ctx->set_error("ctm_move, projector unit: " + err); return st; }
         // non-zero projector columns per site (S descending: a prefix); ctm_projectors_4x4 has drained its stream
         std::vector<double> hs(chi);
         for (int i = 0; i < nunits; ++i) {
@@ -155,7 +162,7 @@ extern "C" int ctm_move(ctm_ctx* ctx, ctm_ctx* const* workers, int nworkers, int
             if (hipStreamSynchronize(w->stream) != hipSuccess) { w->set_error("ctm_move: stream"); return (int)CTM_ERR_HIP; }
             return (int)CTM_OK;
         }, &err);
-        if (st != CTM_OK) { if (!err.empty()) ctx->set_error("ctm_move, absorb unit: " + err); return st; }
+        if (st != CTM_OK) { drain(); if (!err.empty()) ctx->set_error("ctm_move, absorb unit: " + err); return st; }
         return CTM_OK;
     });
 }

@@ -16,7 +16,7 @@ import config as cfg
 from backend import get_engine
 from _native import NativeError, CTM_ERR_NOMEM
 import parallel
-from ctm.generic.ctm_projectors import ctm_get_projectors_4x4, ctm_get_projectors_4x2, _trunc_cfg, _unit_inputs, _sync_warm_tol
+from ctm.generic.ctm_projectors import ctm_get_projectors_4x4, ctm_get_projectors_4x2, _trunc_cfg, _unit_inputs, _sync_warm_tol, SVD_METHODS, _note_method
 from ctm.generic.ctm_components import _halves_t
 
 log = logging.getLogger(__name__)
@@ -139,6 +139,11 @@ def ctm_MOVE(direction, state, env, ctm_args=cfg.ctm_args, global_args=cfg.globa
         raise ValueError("Invalid Projector method: " + str(ctm_args.projector_method))
     if direction not in _ABS:
         raise ValueError("Invalid direction: " + str(direction))
+    # every route of the move (the whole-move native call below never enters ctm_get_projectors_*): an unknown truncation method is
+    # refused and an aliased one announced once, as the reference's branch on the method does (ctm_projectors.py:213-257)
+    if ctm_args.projector_svd_method not in SVD_METHODS:
+        raise ValueError(f"Projector svd method \"{ctm_args.projector_svd_method}\" not implemented")
+    _note_method(ctm_args.projector_svd_method)
     norm_kind = 1 if ctm_args.ctm_absorb_normalization == 'inf' else 2      # anything else is the 2-norm (ctmrg.py:212-214)
     from ctm.generic import ctm_ad
     if ctm_ad.wants_grad(state, env):
@@ -152,7 +157,12 @@ def ctm_MOVE(direction, state, env, ctm_args=cfg.ctm_args, global_args=cfg.globa
     nrep = max(1, state.lX if direction in [(-1, 0), (1, 0)] else state.lY)
     cnt = env.__dict__.setdefault("_rep_count", {})
     env.__dict__.setdefault("_rep", {})[direction] = cnt.get(direction, 0) % nrep
+    _ctm_MOVE_units(direction, state, env, ctm_args, global_args, diagnostics, get_projectors, norm_kind, eng, coords)
+    # only now: a move that raised has not happened, and the repetition counter (which warm-start workspace the next call uses) stays
     cnt[direction] = cnt.get(direction, 0) + 1
+
+
+def _ctm_MOVE_units(direction, state, env, ctm_args, global_args, diagnostics, get_projectors, norm_kind, eng, coords):
     mine = parallel.my_units(coords)
     chi = env.chi
     # number of non-zero projector columns per site of THIS move (filled by the fused projector path)

@@ -103,10 +103,15 @@ def test_rdms_and_energy(case, eng):
     assert abs(e - float(g["energy_j2_0.5"])) < 1e-12 * abs(e)
 
 
-def test_converged_run(case, eng):
+@pytest.mark.parametrize("native_move", [True, False], ids=["ctm_move", "unit-by-unit"])
+@pytest.mark.parametrize("warm_tol", [0.0, 1e-9], ids=["warm_tol0", "warm_tol1e-9"])
+def test_converged_run(case, eng, warm_tol, native_move):
     """ctmrg.run with ctmrg_conv_specC from the CTMRG init: same number of sweeps as the reference,
-    corner spectra and rdm2x2 energy within 1e-10."""
+    corner spectra and rdm2x2 energy within 1e-10 -- on every route of the move: the whole move as one native call (ctm_move, the
+    default) or unit by unit, with and without ctm_args.projector_warm_tol (at these sizes, n < 256, every truncation is a dense solve
+    and the option must change nothing; tests/test_gpu_stationary.py pins it where the fast path is taken)."""
     import config as cfg
+    import copy
     from ipeps.ipeps import IPEPS
     from ctm.generic.env import ENV, init_env, ctmrg_conv_specC
     from ctm.generic import ctmrg
@@ -115,14 +120,67 @@ def test_converged_run(case, eng):
     st = IPEPS({k: dev(v) for k, v in case["sites"].items()})
     env = ENV(chi, st)
     init_env(st, env)
-    cfg.ctm_args.ctm_max_iter = 60
-    env, hist, t_ctm, t_obs = ctmrg.run(st, env, conv_check=ctmrg_conv_specC)
+    args = copy.deepcopy(cfg.ctm_args)
+    args.ctm_max_iter = 60
+    args.projector_warm_tol = warm_tol
+    args.native_move = native_move
+    try:
+        env, hist, t_ctm, t_obs = ctmrg.run(st, env, conv_check=ctmrg_conv_specC, ctm_args=args)
+    finally:
+        for e_ in [eng] + list(eng.workers):
+            e_.set_option("warm_accept_tol", 0.0); e_._warm_tol = 0.0
     assert len(hist['conv_crit']) == int(g["conv_nsweeps"])
     for k, s in env.get_spectra().items():
         ref = g[f"conv_spec_{k[0][0]}_{k[0][1]}_{k[1][0]}_{k[1][1]}"]
         assert np.abs(s.cpu().numpy() - ref).max() < 1e-10, k
     e = float(j1j2.J1J2(j1=1.0, j2=0.5).energy_per_site(st, env))
     assert abs(e - float(g["conv_energy"])) < 1e-10 * abs(e)
+
+
+@pytest.mark.parametrize("name", ["chi_ramp_D3_chi16_36_f64", "chi_ramp_D2_chi6_12_c128"])
+def test_chi_ramped_run_against_the_reference(eng, name):
+    """ENV.extend inside a run (reference ctm/generic/env.py:164-202; how its scripts ramp the environment dimension): n0 sweeps at
+    chi0 from the CTMRG init, extend(chi1), n1 more sweeps -- corner spectra and rdm2x2 energy of the end against the REFERENCE's run
+    (1e-10), |C|, |T| entrywise (gauge: 1e-7), and the extended environment itself against the oracle's env_extend (exact padding)."""
+    import config as cfg
+    import copy
+    from ipeps.ipeps import IPEPS
+    from ctm.generic.env import ENV, init_env
+    from ctm.generic import ctmrg
+    from models import j1j2
+    from oracle import ctm_oracle as O
+    g = golden(name)
+    chi0, chi1, n0, n1 = (int(g[k]) for k in ("chi0", "chi1", "n0", "n1"))
+    sites = sites_from(g)
+    st = IPEPS({k: dev(v) for k, v in sites.items()})
+    env = ENV(chi0, st); init_env(st, env)
+
+    def fixed(n):
+        def count(state, env, history, ctm_args=None):
+            history = (history or []) + [1]
+            return len(history) >= n, history
+        return count
+    args = copy.deepcopy(cfg.ctm_args)
+    args.ctm_max_iter = n0
+    env, *_ = ctmrg.run(st, env, conv_check=fixed(n0), ctm_args=args)
+    before = {k: v.cpu().numpy() for k, v in {**{("C",) + k: v for k, v in env.C.items()}, **{("T",) + k: v for k, v in env.T.items()}}.items()}
+    env = env.extend(chi1)
+    assert env.chi == chi1
+    # the extension is the oracle's (zero padding around the leading block), checked on this run's own tensors
+    oe = O.Env(chi0)
+    oe.C = {k[1:]: v for k, v in before.items() if k[0] == "C"}; oe.T = {k[1:]: v for k, v in before.items() if k[0] == "T"}
+    ox = O.env_extend(oe, chi1)
+    for k in ox.C: assert np.array_equal(env.C[k].cpu().numpy(), ox.C[k]), k
+    for k in ox.T: assert np.array_equal(env.T[k].cpu().numpy(), ox.T[k]), k
+    args.ctm_max_iter = n1
+    env, *_ = ctmrg.run(st, env, conv_check=fixed(n1), ctm_args=args)
+    for k, s_ in env.get_spectra().items():
+        assert np.abs(s_.cpu().numpy() - g[f"spec_{k[0][0]}_{k[0][1]}_{k[1][0]}_{k[1][1]}"]).max() < 1e-10, k
+    C1, T1 = env_from(g, "end_")
+    for k in C1: assert relerr(env.C[k].abs(), np.abs(C1[k])) < 1e-7, k
+    for k in T1: assert relerr(env.T[k].abs(), np.abs(T1[k])) < 1e-7, k
+    e = float(j1j2.J1J2(j1=1.0, j2=0.5).energy_per_site(st, env))
+    assert abs(e - float(g["energy"])) <= 1e-10 * abs(float(g["energy"])), (e, float(g["energy"]))
 
 
 def test_rdm2x2_partially_open(case, eng):

@@ -213,3 +213,23 @@ def test_c4v_rdm1x1_and_row_correlator_oracle_vs_reference(base):
     assert abs(O4.rdm1x1(A, C, T) - j[f"{base}_rdm1x1"]).max() < 1e-12
     sz = np.diag([0.5, -0.5]).astype(A.dtype)
     assert abs(O4.corrf_1sO1sO(A, C, T, sz, lambda r: sz, 3) - j[f"{base}_corr_szsz_plain"]).max() < 1e-11
+
+
+@pytest.mark.parametrize("name", ["chi_ramp_D2_chi6_12_c128", "chi_ramp_D3_chi16_36_f64"])
+def test_oracle_chi_ramped_run_vs_reference(name):
+    """oracle.env_extend (reference ENV.extend, ctm/generic/env.py:164-202) inside a run: n0 sweeps at chi0, extend(chi1), n1 sweeps --
+    corner spectra and rdm2x2 energy of the REFERENCE's run (tests/golden/chi_ramp_*.npz, oracle/gen_golden.py chi_ramp)."""
+    g = golden(name)
+    chi0, chi1, n0, n1 = (int(g[k]) for k in ("chi0", "chi1", "n0", "n1"))
+    sites = sites_from(g)
+    ost = O.State(sites)
+    oe = O.init_env_ctmrg(ost, chi0)
+    for _ in range(n0): O.ctm_sweep(ost, oe)
+    oe = O.env_extend(oe, chi1)
+    assert oe.chi == chi1 and all(c.shape == (chi1, chi1) for c in oe.C.values())
+    for _ in range(n1): O.ctm_sweep(ost, oe)
+    so = O.corner_spectra(oe)
+    for k, s in so.items():
+        assert np.abs(s - g[f"spec_{k[0][0]}_{k[0][1]}_{k[1][0]}_{k[1][1]}"]).max() < 1e-10, k
+    e = OJ.energy_per_site([O.rdm2x2(c, ost, oe) for c in sites], 1.0, 0.5)
+    assert abs(e - float(g["energy"])) < 1e-10 * abs(float(g["energy"]))
