@@ -377,7 +377,10 @@ def run_workload(args, eng, dev, kind, D, chi, dtype, signed, steps, warmup, wor
            "power_iter_hits": int(eng.stat("si_hits")), "power_iter_fallbacks_to_full": int(eng.stat("si_fallbacks")),
            "block_krylov_solves": int(eng.stat("lz_hits")),
            "avg_block_krylov_steps": round(eng.stat("lz_total_steps") / max(eng.stat("lz_hits"), 1), 2),
-           "ritz_extractions": int(eng.stat("lz_extractions"))}
+           "ritz_extractions": int(eng.stat("lz_extractions")),
+           # ... of which started from the rotations of the unit's previous extraction, and the Jacobi sweeps an extraction took on average
+           "ritz_warm_starts": int(eng.stat("ritz_warm_starts")),
+           "avg_sweeps_per_ritz_extraction": round(eng.stat("ritz_sweeps") / max(eng.stat("lz_extractions"), 1), 2)}
     eng.set_option("gemm_timing", 0)
     if args.profile:
         eng.set_option("profile", 0)

@@ -175,7 +175,10 @@ int ctm_projectors(ctm_ctx* ctx, const double* R, const double* Rt, int n, int c
 int ctm_projectors_4x4(ctm_ctx* ctx, int dir, const double* const* tensors16, int chi, const int* adims4x5,
                        const ctm_trunc_cfg* cfg, double* P, double* Pt, double* S);
 /* Same, warm started: `basis` is an opaque caller-owned device workspace of (min(chi+1,n) + 1) * n doubles (CTM_C128:
- * (2 min(chi+1,n) + 1) * n; the last row is a header the engine keeps its start-up policy in), zero-filled before the first call and passed again for the same (direction, site) on later sweeps.  It carries
+ * (2 min(chi+1,n) + 1) * n; the last row is a header the engine keeps its start-up policy in), zero-filled before the first call and passed again for the same (direction, site) on later sweeps.
+ * Optional Ritz region: a caller that allocates R more doubles BEHIND the header row writes R into header word 10 (after the zero fill); the block
+ * Krylov solver then keeps the accumulated rotations of the unit's last Ritz extraction there (16 words + m x m doubles, m ~ 2.7 chi rows of
+ * Krylov basis; R >= 16 + (4.5 (chi+1) + 64)^2 covers it) and starts the next extraction from them.  Word 10 == 0: no region, every extraction starts cold.  It carries
  * the right singular row basis of the previous call: the leading-chi iteration starts from it instead of a random block
  * (the result is residual-verified either way, so a stale or zero basis only costs iterations).  basis == NULL: cold. */
 int ctm_projectors_4x4_ws(ctm_ctx* ctx, int dir, const double* const* tensors16, int chi, const int* adims4x5,

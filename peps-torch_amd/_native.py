@@ -415,9 +415,8 @@ class Engine:
         U, S, V = self.empty(n, kc), self.empty_real(kc), self.empty(n, kc)
         cfg = cfg or self.default_cfg
         if basis is not None:
-            k = chi + 1 if chi < n else n
             if not (basis.is_cuda and basis.dtype == torch.float64 and basis.is_contiguous()
-                    and tuple(basis.shape) == ((2 if M.dtype.is_complex else 1) * k + 1, n)):
+                    and tuple(basis.shape) == (self.warm_rows(chi, n, M.dtype)[0], n)):
                 raise NativeError("truncated_svd: basis must come from warm_basis(chi, n, dtype)")
         self._ck(self.lib.ctm_truncated_svd_ws(self.h, _ptr(M), n, chi, C.byref(cfg), _ptr(U), _ptr(S), _ptr(V),
                                                _ptr(basis) if basis is not None else None), "truncated_svd")
@@ -529,10 +528,29 @@ class Engine:
         self._ck(self.lib.ctm_projectors(self.h, _ptr(R), _ptr(Rt), n, chi, C.byref(cfg), _ptr(P), _ptr(Pt), _ptr(S)), "projectors")
         return (P, Pt, S) if return_S else (P, Pt)
 
-    def warm_basis(self, chi, n, dtype):
-        """Zero-filled warm-start workspace for projectors_4x4(..., basis=) of one (direction, site) unit."""
+    @staticmethod
+    def warm_rows(chi, n, dtype):
+        """Rows (of n doubles) of a warm-start workspace: the k = min(chi + 1, n) basis rows (two planes for complex128), the header row, and
+        -- for the sizes the block Krylov solvers take (n >= 256, k >= 48, k < n) -- the Ritz region behind it: 16 words + the accumulated
+        rotations of the unit's last Ritz extraction (m x m, m up to ~4.5 k rows of Krylov basis; twice that for complex128), from which
+        the next extraction starts (csrc/svd_leading.hip: HDR_RITZ_CAP).  Returns (rows, ritz_doubles)."""
         k = chi + 1 if chi < n else n
-        return torch.zeros((2 if dtype.is_complex else 1) * k + 1, n, dtype=torch.float64, device=self.device)   # + header row
+        cz = 2 if dtype.is_complex else 1
+        ritz_rows = 0
+        if k < n and n >= 256 and k >= 48:
+            mcap = min((n // 2) // 64 * 64 + 64, (int(4.5 * k) + 127) // 64 * 64)     # (+ the dense solver's padding to an even panel count)
+            ritz_rows = -(-(16 + cz * mcap * mcap) // n)
+        return cz * k + 1 + ritz_rows, ritz_rows * n
+
+    def warm_basis(self, chi, n, dtype):
+        """Zero-filled warm-start workspace for projectors_4x4(..., basis=) / truncated_svd(..., basis=) of one (direction, site) unit
+        (layout: warm_rows)."""
+        rows, ritz = self.warm_rows(chi, n, dtype)
+        b = torch.zeros(rows, n, dtype=torch.float64, device=self.device)
+        if ritz:
+            k = chi + 1 if chi < n else n
+            b[(2 if dtype.is_complex else 1) * k, 10] = float(ritz)      # header word HDR_RITZ_CAP: doubles behind the header row
+        return b
 
     def corner_numel(self, corner, C_, a):
         """Doubles of an opaque corner buffer for projectors_4x4(corners=...): n0 * n1 (twice that for complex128)."""
@@ -553,9 +571,8 @@ class Engine:
         P, Pt, S = self.empty(n, kc), self.empty(n, kc), self.empty_real(kc)
         cfg = cfg or self.default_cfg
         if basis is not None:
-            k = chi + 1 if chi < n else n
             if not (basis.is_cuda and basis.dtype == torch.float64 and basis.is_contiguous()
-                    and tuple(basis.shape) == ((2 if ts[0].dtype.is_complex else 1) * k + 1, n)):
+                    and tuple(basis.shape) == (self.warm_rows(chi, n, ts[0].dtype)[0], n)):
                 raise NativeError("projectors_4x4: basis must come from warm_basis(chi, n, dtype)")
         cb = cv = None
         if corners is not None:
@@ -621,9 +638,8 @@ class Engine:
                                   "(ctm_move takes environments of dimension chi; use projectors_4x4 + absorb for chi-ramping)")
             b = u.get("basis")
             if b is not None:
-                k = chi + 1 if chi < n else n
                 if not (b.is_cuda and b.device == ts[0].device and b.dtype == torch.float64 and b.is_contiguous()
-                        and tuple(b.shape) == ((2 if dtype.is_complex else 1) * k + 1, n)):
+                        and tuple(b.shape) == (self.warm_rows(chi, n, dtype)[0], n)):
                     raise NativeError(f"move: unit {i}: basis must come from warm_basis(chi, n, dtype)")
             m.basis = b.data_ptr() if b is not None else None
             cs = u.get("corners")

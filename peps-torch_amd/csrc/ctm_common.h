@@ -126,6 +126,13 @@ struct ctm_ctx {
     long lz_total_rows = 0;             // basis rows over all accepted solves (steps x block)
     bool lz_verify_op = false;          // additionally check both relations of the Ritz triplets with operator applications (debug / tests)
     long lz_extractions = 0; double lz_last_est = 0.0; int lz_last_steps = 0;
+    // Ritz extraction of the block Krylov solvers started from the accumulated rotations of the unit's previous extraction ("ritz_warm", svd_full: rot)
+    int ritz_warm = 1; long ritz_warm_starts = 0, ritz_sweeps = 0;
+    // orientation of the returned singular vectors of a warm-started unit follows its previous decomposition (fix_signs_rows_kernel: ref) also
+    // without the stationary fast path: the largest-element rule re-gauges legs of the environment by signs from sweep to sweep, which makes
+    // the operator of the next sweep a DIFFERENT matrix (measured D = 4 chi = 64: |dM| / |M| = 5e-3 ... 7e-2 with | |M| - |M'| | = 5e-5) and
+    // its Krylov basis / Ritz matrix unrelated to the previous one
+    int sign_follow = 1;
     double jacobi_quad_exit = 0.0;      // (internal) jacobi_rows stops after a sweep that FOUND <= this measure (quadratic regime)
     double si_quad_exit = 0.0;          // ... optionally during the Rayleigh-Ritz of the subspace iteration (off: measured no gain -- the sweep it saves finds every
                                         // pair below tolerance, and such a sweep costs ~10 us per round: the eigensolver exits early, the apply GEMMs are skipped)

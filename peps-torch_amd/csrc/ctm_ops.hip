@@ -226,7 +226,7 @@ int svd_rows_op(ctm_ctx* ctx, const MatOp& op, int chi, const ctm_trunc_cfg& cfg
     // fix_signs_rows_kernel), whose sign-fixed rows the workspace holds -- kept aside, the solver overwrites them
     ArenaScope ref_scope(ctx);
     double* ref = nullptr; int ref_left = 0;
-    const bool follow = ctx->warm_accept_tol > 0.0 && op.warm && op.warm_hdr && !op.M && cfg.fix_signs && k < n;
+    const bool follow = (ctx->warm_accept_tol > 0.0 || ctx->sign_follow) && op.warm && op.warm_hdr && !op.M && cfg.fix_signs && k < n;
     const size_t cz = ctx->cplx ? 2 : 1;
     if (follow) {
         double side = 0.0;

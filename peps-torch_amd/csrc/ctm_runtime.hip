@@ -237,6 +237,8 @@ int ctm_set_option(ctm_ctx* ctx, const char* key, double value) {
     else if (k == "xgemm_stack_rows") ctx->xgemm_stack_rows = value != 0.0;
     // -- stationary fast path of the implicit-operator truncation (ctm_args.projector_warm_tol)
     else if (k == "warm_accept_tol") ctx->warm_accept_tol = value;
+    else if (k == "ritz_warm") ctx->ritz_warm = (int)value;
+    else if (k == "sign_follow") ctx->sign_follow = (int)value;
     else if (k == "warm_try_factor") ctx->warm_try_factor = value;
     else if (k == "warm_accept_max_run") ctx->warm_accept_max_run = (int)value;
     // -- row-block GEMM: the knobs tests/test_gpu_gemm_rows.py needs to reach every epilogue
@@ -290,6 +292,8 @@ int ctm_get_stat(ctm_ctx* ctx, const char* key, double* value) {
     else if (k == "lz_total_steps") *value = (double)ctx->lz_total_steps;
     else if (k == "lz_total_rows") *value = (double)ctx->lz_total_rows;
     else if (k == "lz_extractions") *value = (double)ctx->lz_extractions;
+    else if (k == "ritz_warm_starts") *value = (double)ctx->ritz_warm_starts;
+    else if (k == "ritz_sweeps") *value = (double)ctx->ritz_sweeps;
     else if (k == "lz_last_est") *value = ctx->lz_last_est;
     else if (k == "lz_async_fallbacks") *value = (double)ctx->lz_async_fallbacks;
     else if (k == "lz_third_passes") *value = (double)ctx->lz_third_passes;
@@ -330,7 +334,7 @@ int ctm_timers(ctm_ctx* ctx, double* out8, int reset) {
     return ctm_entry_nolock(ctx, "ctm_timers", [&]() -> int {
     gemm_timing_drain(ctx);       // event-timed phases are accumulated when their events are read
     for (int i = 0; i < CTM_T_COUNT; ++i) { if (out8) out8[i] = ctx->timers[i]; if (reset) ctx->timers[i] = 0.0; }
-    if (reset) { ctx->gemm_flops = 0; ctx->gemm_calls = 0; ctx->layer2_flops = 0; ctx->layer2_calls = 0; ctx->total_sweeps = 0; ctx->jacobi_calls = 0; ctx->si_hits = 0; ctx->si_fallbacks = 0; ctx->si_total_iters = 0; ctx->si_warm_starts = 0; ctx->eigh_warm_hits = 0; ctx->eigh_warm_rejects = 0; ctx->eigh_orth_hits = 0; ctx->eigh_orth_fails = 0; ctx->eigh_orth_doubled = 0; ctx->svd_polar_completions = 0; ctx->svd_eig_completions = 0; ctx->svd_polar_solves = 0; ctx->lz_hits = 0; ctx->lz_total_steps = 0; ctx->lz_total_rows = 0; ctx->lz_extractions = 0; ctx->absorb_bytes = 0; ctx->absorb_calls = 0; }
+    if (reset) { ctx->gemm_flops = 0; ctx->gemm_calls = 0; ctx->layer2_flops = 0; ctx->layer2_calls = 0; ctx->total_sweeps = 0; ctx->jacobi_calls = 0; ctx->si_hits = 0; ctx->si_fallbacks = 0; ctx->si_total_iters = 0; ctx->si_warm_starts = 0; ctx->eigh_warm_hits = 0; ctx->eigh_warm_rejects = 0; ctx->eigh_orth_hits = 0; ctx->eigh_orth_fails = 0; ctx->eigh_orth_doubled = 0; ctx->svd_polar_completions = 0; ctx->svd_eig_completions = 0; ctx->svd_polar_solves = 0; ctx->lz_hits = 0; ctx->lz_total_steps = 0; ctx->lz_total_rows = 0; ctx->lz_extractions = 0; ctx->ritz_warm_starts = 0; ctx->ritz_sweeps = 0; ctx->absorb_bytes = 0; ctx->absorb_calls = 0; }
     return CTM_OK;
     });
 }

@@ -887,7 +887,15 @@ int complete_null_rows(ctm_ctx* ctx, double* Vt, int kg, int k, int n) {
 // warm (optional, k == n only): n x n workspace with the left vectors u_i^T of the previous decomposition of a nearby matrix.  The rows
 // of W M are then almost orthogonal already and the sweeps start in the quadratically convergent regime (the differentiable route
 // of an optimisation decomposes the same sequence of matrices again and again); any orthonormal W is a valid start.  Updated.
-int svd_full(ctm_ctx* ctx, const double* M, int n, int k, double* S, double* Ut, double* Vt, double* warm) {
+// rot (optional, any k; needs Ut): np x np workspace, np = svd_full_rot_rows(ctx, n) (n padded to an even number of panels), for the ACCUMULATED
+// ROTATIONS of the sweeps on the padded problem [M; 0] (all np rows, in the order the sweeps leave them).  rot_valid: it holds the rotations of
+// an earlier decomposition of a nearby matrix (the Ritz matrix of the same unit in the previous CTM sweep, or of the same solve a few block
+// steps earlier, extended by the identity): the sweeps then start from rot[:, :n] . M, whose rows are orthogonal up to the change of the
+// matrix -- the quadratically convergent regime -- instead of from M.  Any orthogonal rot is a valid start (checked: unit row norms); on
+// return it holds this decomposition's rotations.
+int svd_full_rot_rows(ctm_ctx* ctx, int n) { return padded(n, choose_block(ctx, n)); }
+
+int svd_full(ctm_ctx* ctx, const double* M, int n, int k, double* S, double* Ut, double* Vt, double* warm, double* rot, bool rot_valid) {
     const int b = choose_block(ctx, n), np = padded(n, b);
     ArenaScope scope(ctx);
     const bool with_q = (Ut != nullptr);
@@ -900,13 +908,29 @@ int svd_full(ctm_ctx* ctx, const double* M, int n, int k, double* S, double* Ut,
     std::vector<double> h;
     int st;
     bool warm_full = false;
-    if (warm && with_q && k == n && ctx->eigh_warm) {
+    if (rot && (!with_q || warm)) { ctx->set_error("svd_full: rot needs Ut and excludes warm"); return CTM_ERR_BADARG; }
+    bool rot_start = false;
+    if (rot && rot_valid) {
+        const double fw = host_fro(ctx, rot, np, np, np, norms, h, &st);
+        CTM_TRY(st);
+        rot_start = std::fabs(fw - std::sqrt((double)np)) <= 1e-6 * std::sqrt((double)np);
+        for (int i = 0; rot_start && i < np; ++i) rot_start = std::fabs(h[i] - 1.0) <= 1e-6;
+        if (rot_start) ctx->ritz_warm_starts += 1;
+    }
+    if (rot_start) {
+        CTM_TRY(fill_f64(ctx, X, (size_t)np * ld, 0.0));
+        GemmDesc gw; gw.M = np; gw.N = n; gw.K = n; gw.A = rot; gw.sam = np; gw.sak = 1; gw.B = M; gw.sbk = n; gw.sbn = 1; gw.C = X; gw.ldc = ld;
+        CTM_TRY(gemm_f64(ctx, gw));
+        CTM_TRY(copy2d(ctx, rot, np, X + n, ld, np, np));
+    }
+    if (!warm_full && warm && with_q && k == n && ctx->eigh_warm) {
         const double fw = host_fro(ctx, warm, n, n, n, norms, h, &st);
         CTM_TRY(st);
         warm_full = std::fabs(fw - std::sqrt((double)n)) <= 1e-6 * std::sqrt((double)n);
         for (int i = 0; warm_full && i < n; ++i) warm_full = std::fabs(h[i] - 1.0) <= 1e-6;
     }
-    if (warm_full) {
+    if (rot_start) {
+    } else if (warm_full) {
         CTM_TRY(fill_f64(ctx, X, (size_t)np * ld, 0.0));
         GemmDesc gw; gw.M = n; gw.N = n; gw.K = n; gw.A = warm; gw.sam = n; gw.sak = 1; gw.B = M; gw.sbk = n; gw.sbn = 1; gw.C = X; gw.ldc = ld;
         CTM_TRY(gemm_f64(ctx, gw));
@@ -931,6 +955,7 @@ int svd_full(ctm_ctx* ctx, const double* M, int n, int k, double* S, double* Ut,
     CTM_HIP_CHECK(ctx, hipMemcpyAsync(d_idx, idx.data(), sizeof(int) * k, hipMemcpyHostToDevice, ctx->stream));
     CTM_HIP_CHECK(ctx, hipMemcpyAsync(S, hs.data(), sizeof(double) * k, hipMemcpyHostToDevice, ctx->stream));
     CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));   // host vectors go out of scope
+    if (rot) CTM_TRY(copy2d(ctx, X + n, ld, rot, np, np, np));    // every row of the accumulated rotations, unsorted: the next call's start
     if (!Ut) return CTM_OK;   // singular values only: row norms of the converged W
     // U = accumulated rotations (orthonormalised against drift); then Sigma V^T = U^T M is recomputed by one
     // k x n x n GEMM so that S and V carry no accumulated rounding of the sweeps (|error| = O(eps |M|)).
@@ -1095,7 +1120,8 @@ int reorth_rows_c(ctm_ctx* ctx, double* V, int k, int n, int iters) {
     return CTM_OK;
 }
 
-int svd_full_c(ctm_ctx* ctx, const double* Mr, const double* Mi, int n, int k, double* S, double* Ut, double* Vt, double* warm) {
+// rot / rot_valid: as svd_full() -- planar n x n (re plane, im plane) accumulated rotations, rows u_i^H in the order the sweeps leave them
+int svd_full_c(ctm_ctx* ctx, const double* Mr, const double* Mi, int n, int k, double* S, double* Ut, double* Vt, double* warm, double* rot, bool rot_valid) {
     const int np = padded(n, BC);
     ArenaScope scope(ctx);
     const bool with_q = (Ut != nullptr);
@@ -1109,7 +1135,15 @@ int svd_full_c(ctm_ctx* ctx, const double* Mr, const double* Mi, int n, int k, d
     std::vector<double> h;
     int st;
     bool warm_full = false;          // warm start of the full decomposition (planar rows u_i^H): see svd_full()
-    if (warm && with_q && k == n && ctx->eigh_warm) {
+    if (rot && (!with_q || np != n || warm)) { ctx->set_error("svd_full_c: rot needs Ut, excludes warm, and n must be an even number of 16-row panels"); return CTM_ERR_BADARG; }
+    if (rot && rot_valid) {
+        const double fw = host_fro(ctx, rot, 2 * n, n, n, norms, h, &st);
+        CTM_TRY(st);
+        bool okw = std::fabs(fw - std::sqrt((double)n)) <= 1e-6 * std::sqrt((double)n);
+        for (int i = 0; okw && i < n; ++i) okw = std::fabs(std::sqrt(h[i] * h[i] + h[n + i] * h[n + i]) - 1.0) <= 1e-6;
+        if (okw) { warm = rot; warm_full = true; ctx->ritz_warm_starts += 1; }
+    }
+    if (!warm_full && warm && with_q && k == n && ctx->eigh_warm) {
         const double fw = host_fro(ctx, warm, 2 * n, n, n, norms, h, &st);
         CTM_TRY(st);
         warm_full = std::fabs(fw - std::sqrt((double)n)) <= 1e-6 * std::sqrt((double)n);
@@ -1124,7 +1158,7 @@ int svd_full_c(ctm_ctx* ctx, const double* Mr, const double* Mi, int n, int k, d
         CTM_LAUNCH(ctx, fill_wq_c2_kernel, dim3(2048), dim3(256), 0, (const double*)Yw, (const double*)(Yw + nn), (const double*)warm,
                    (const double*)(warm + nn), n, X, np, ld);
         CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-        ctx->eigh_warm_hits += 1;
+        if (warm != rot) ctx->eigh_warm_hits += 1;
     } else
         CTM_LAUNCH(ctx, fill_wq_c_kernel, dim3(2048), dim3(256), 0, Mr, Mi, n, X, np, ld, with_q ? 1 : 0);
     const double fro = host_fro(ctx, X, 2 * np, n, ld, norms, h, &st);
@@ -1141,10 +1175,15 @@ int svd_full_c(ctm_ctx* ctx, const double* Mr, const double* Mi, int n, int k, d
     CTM_HIP_CHECK(ctx, hipMemcpyAsync(S, hs.data(), sizeof(double) * k, hipMemcpyHostToDevice, ctx->stream));
     CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     if (!Ut) return CTM_OK;
+    if (rot) {                       // every row of the accumulated rotations, unsorted, planar: the next call's start
+        std::vector<int> all(n);
+        std::iota(all.begin(), all.end(), 0);
+        CTM_TRY(panel_gather(ctx, X + n, ld, all, n, n, rot, d_idx));
+    }
     // rows of the accumulated unitary Q are u_k^H; Sigma V^H = Q M is recomputed by one k x n x n product (drift-free)
     CTM_TRY(panel_gather(ctx, X + n, ld, idx, k, n, Ut, d_idx));
     CTM_TRY(reorth_rows_c(ctx, Ut, k, n, 2));
-    if (warm && k == n) CTM_HIP_CHECK(ctx, hipMemcpyAsync(warm, Ut, sizeof(double) * 2 * nn, hipMemcpyDeviceToDevice, ctx->stream));
+    if (warm && warm != rot && k == n) CTM_HIP_CHECK(ctx, hipMemcpyAsync(warm, Ut, sizeof(double) * 2 * nn, hipMemcpyDeviceToDevice, ctx->stream));
     if (Vt) {
         const size_t kn = (size_t)k * n;
         double* inv;

@@ -483,13 +483,14 @@ int choose_block(ctm_ctx* ctx, int n);
 int reorth_rows(ctm_ctx* ctx, double* V, int k, int n, long long ld, int iters);
 double host_fro(ctm_ctx* ctx, const double* M, int rows, int cols, long long ld, double* d_tmp, std::vector<double>& h, int* status);
 int complete_null_rows(ctm_ctx* ctx, double* Vt, int kg, int k, int n);
-int svd_full(ctm_ctx* ctx, const double* M, int n, int k, double* S, double* Ut, double* Vt, double* warm = nullptr);
+int svd_full_rot_rows(ctm_ctx* ctx, int n);
+int svd_full(ctm_ctx* ctx, const double* M, int n, int k, double* S, double* Ut, double* Vt, double* warm = nullptr, double* rot = nullptr, bool rot_valid = false);
 int svd_full_polar(ctm_ctx* ctx, const double* M, int n, double* S, double* Ut, double* Vt, double* warm);
 int panel_row_norms(ctm_ctx* ctx, const double* X, int np, int cols, long long ld, double* norms, std::vector<double>& hc);
 int panel_gather(ctm_ctx* ctx, const double* X, long long ld, const std::vector<int>& idx, int k, int cols, double* out, int* d_idx2);
 int scale_planar_rows(ctm_ctx* ctx, double* V, int k, int n, const double* inv);
 int reorth_rows_c(ctm_ctx* ctx, double* V, int k, int n, int iters);
-int svd_full_c(ctm_ctx* ctx, const double* Mr, const double* Mi, int n, int k, double* S, double* Ut, double* Vt, double* warm = nullptr);
+int svd_full_c(ctm_ctx* ctx, const double* Mr, const double* Mi, int n, int k, double* S, double* Ut, double* Vt, double* warm = nullptr, double* rot = nullptr, bool rot_valid = false);
 int rows_times(ctm_ctx* ctx, const double* X, long long ldx, int p, int kin, int nout, const double* Z, bool transZ, double* Y, long long ldy);
 int matop_apply(ctm_ctx* ctx, const MatOp& op, bool transpose, const double* B, long long ldb, int p, double* C, long long ldc,
                    double* mid = nullptr);

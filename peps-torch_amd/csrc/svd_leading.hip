@@ -51,7 +51,11 @@ enum { HDR_SKIP = 0, HDR_STEPS = 1, HDR_EST = 2, HDR_FAILS = 3, HDR_BLOCK = 4,  
        // solves (spectrum_movement; a lower bound on the movement of the operator), 0 = unknown; [6] which side the workspace rows hold
        // (0: right vectors, 1: left vectors); [7] accepted Rayleigh-Ritz calls since the last full solve; [8] calls left that do not try
        // the fast path after a rejection; [9] consecutive rejections
-       HDR_DIST = 5, HDR_SIDE = 6, HDR_RUN = 7, HDR_SSKIP = 8, HDR_SFAILS = 9, HDR_WORDS = 10,
+       HDR_DIST = 5, HDR_SIDE = 6, HDR_RUN = 7, HDR_SSKIP = 8, HDR_SFAILS = 9,
+       // [10] doubles the workspace holds BEHIND the header row (written by whoever allocated it; 0 = none): the Ritz region of the block Krylov
+       // solvers -- [0] rows m of the stored rotation matrix, [1] block size of the recurrence it belongs to, [16 ...] the m x m accumulated
+       // rotations of the unit's last Ritz extraction (svd_full: rot), the start of the next one (include/ctm_hip.h: warm-start workspace)
+       HDR_RITZ_CAP = 10, HDR_WORDS = 11,
        HDR_SPREV = 16 /* from here: the k singular values of the previous solve (spectrum_movement) */ };
 
 inline int warm_skip_calls(const ctm_ctx* ctx, double r) {
@@ -702,15 +706,53 @@ int svd_lanczos(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* Ut, dou
         CTM_TRY(gemm_f64(ctx, gt));
         GemmDesc ge; ge.M = m; ge.N = b; ge.K = n; ge.A = Zraw; ge.sam = n; ge.sak = 1; ge.B = Vn; ge.sbk = 1; ge.sbn = n; ge.C = E; ge.ldc = b;
         CTM_TRY(gemm_f64(ctx, ge));
+        // The sweeps start from the rotations of the unit's previous extraction when the workspace carries them (a look of this solve a few
+        // block steps earlier, or the previous CTM sweep's solve: the recurrence starts from the same block and is continuous in the
+        // operator -- measured on D = 4 chi = 64, numpy oracle: |dT| / |T| = 2e-3 ... 9e-3 between consecutive sweeps of a moving
+        // environment, off-diagonal part of the rotated matrix 2e-4 ... 3e-3 s_0).  A basis that grew by whole blocks keeps its leading
+        // principal part of T, so the old rotations are padded with the identity.
+        // (The dense solver pads the problem to an even number of 32-row panels: the rotations are mr x mr, mr >= m.  The old rotations
+        // act on the old rows and -- when the old problem was padded -- on one block of coordinates that are new basis rows now: an orthogonal
+        // mixing of rows that are new anyway.)
+        double* rot = nullptr; bool rot_valid = false;
+        const int mr = svd_full_rot_rows(ctx, m);
+        double* ritz = (ctx->ritz_warm && op.warm_hdr && hdr[HDR_RITZ_CAP] >= 16.0 + (double)mr * mr) ? op.warm_hdr + n : nullptr;
+        if (ritz) {
+            double rh[3];
+            CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)mr * mr, (void**)&rot));
+            CTM_HIP_CHECK(ctx, hipMemcpyAsync(rh, ritz, sizeof(rh), hipMemcpyDeviceToHost, ctx->stream));
+            CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+            const int mp = (int)rh[0], mrp = (int)rh[2];
+            if (mp >= b && mp % b == 0 && (int)rh[1] == b && mrp >= mp && ((mp == m && mrp == mr) || (mp < m && mrp <= m))) {
+                if (mrp < mr) CTM_TRY(set_identity(ctx, rot, mr, mr));
+                CTM_TRY(copy2d(ctx, ritz + 16, mrp, rot, mr, mrp, mrp));
+                rot_valid = true;
+            }
+            if (ctx->jacobi_verbose) fprintf(stderr, "[lz] n=%d Ritz region: %d rows of block %d stored, %d wanted: %s\n", n, mp, (int)rh[1], m, rot_valid ? "warm" : "cold");
+        } else if (ctx->jacobi_verbose) fprintf(stderr, "[lz] n=%d no Ritz region (capacity word %.0f, need %.0f)\n", n, hdr[HDR_RITZ_CAP], 16.0 + (double)mr * mr);
         const bool save = ctx->si_enable; ctx->si_enable = false;
         ctx->force_abs = ctx->lz_abs_accuracy != 0;
         ctx->jacobi_quad_exit = ctx->lz_quad_exit;
-        const int st = svd_full(ctx, T, m, kq, Ss, Xt, Yt);                      // rows of Xt / Yt: x_i^T, y_i^T
+        const long sw0 = ctx->total_sweeps;
+        const int st = svd_full(ctx, T, m, kq, Ss, Xt, Yt, nullptr, rot, rot_valid);      // rows of Xt / Yt: x_i^T, y_i^T
         ctx->jacobi_quad_exit = 0.0;
         ctx->force_abs = false;
         ctx->si_enable = save;
         CTM_TRY(st);
-        ctx->lz_extractions += 1;
+        ctx->lz_extractions += 1; ctx->ritz_sweeps += ctx->total_sweeps - sw0;
+        if (rot && getenv("CTM_RITZ_DBG")) {      // development: the same matrix again from the rotations just stored -- its first sweep must find nothing
+            fprintf(stderr, "[lz-dbg] repeat of the extraction from its own rotations:\n");
+            ctx->si_enable = false;
+            const int st2 = svd_full(ctx, T, m, kq, Ss, Xt, Yt, nullptr, rot, true);
+            ctx->si_enable = save;
+            CTM_TRY(st2);
+        }
+        if (ritz) {
+            const double rh[3] = {(double)m, (double)b, (double)mr};
+            CTM_HIP_CHECK(ctx, hipMemcpyAsync(ritz, rh, sizeof(rh), hipMemcpyHostToDevice, ctx->stream));
+            CTM_HIP_CHECK(ctx, hipMemcpyAsync(ritz + 16, rot, sizeof(double) * (size_t)mr * mr, hipMemcpyDeviceToDevice, ctx->stream));
+            CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));       // (rh is a stack array)
+        }
         GemmDesc gx; gx.M = kq; gx.N = b; gx.K = m; gx.A = Xt; gx.sam = m; gx.sak = 1; gx.B = E; gx.sbk = b; gx.sbn = 1; gx.C = XE; gx.ldc = b;
         CTM_TRY(gemm_f64(ctx, gx));
         CTM_TRY(row_norms(ctx, XE, kq, b, b, rn));
@@ -1005,8 +1047,32 @@ int svd_lanczos_c(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* Ut, d
         XM z{Zraw, Zraw + planeU, n, false, false}, vh{Vall, Vall + planeV, n, true, true}, vnh{Vn.re, Vn.im, n, true, true};
         CTM_TRY(xgemm(ctx, m, m, n, z, vh, T, T + mm, m));                           // T = (U_all M) V_all^H
         CTM_TRY(xgemm(ctx, m, b, n, z, vnh, E, E + mb, b));                          // E = (U_all M) V_{j+1}^H
-        CTM_TRY(svd_full_c(ctx, T, T + mm, m, kq, Ss, Xt, Yt));                      // T = Xt^H diag(Ss) Yt
-        ctx->lz_extractions += 1;
+        // warm start from the rotations of the unit's previous extraction (planar m x m, see svd_lanczos): padded with the identity when
+        // the basis grew by whole blocks
+        double* rot = nullptr; bool rot_valid = false;
+        double* ritz = (ctx->ritz_warm && op.warm_hdr && hdr[HDR_RITZ_CAP] >= 16.0 + 2.0 * (double)m * m) ? op.warm_hdr + n : nullptr;
+        if (ritz) {
+            double rh[2];
+            CTM_TRY(arena_alloc(ctx, sizeof(double) * 2 * mm, (void**)&rot));
+            CTM_HIP_CHECK(ctx, hipMemcpyAsync(rh, ritz, sizeof(rh), hipMemcpyDeviceToHost, ctx->stream));
+            CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+            const int mp = (int)rh[0];
+            if (mp >= b && mp <= m && mp % b == 0 && (int)rh[1] == b) {
+                if (mp < m) { CTM_TRY(set_identity(ctx, rot, m, m)); CTM_TRY(fill_f64(ctx, rot + mm, mm, 0.0)); }
+                CTM_TRY(copy2d(ctx, ritz + 16, mp, rot, m, mp, mp));
+                CTM_TRY(copy2d(ctx, ritz + 16 + (size_t)mp * mp, mp, rot + mm, m, mp, mp));
+                rot_valid = true;
+            }
+        }
+        const long sw0 = ctx->total_sweeps;
+        CTM_TRY(svd_full_c(ctx, T, T + mm, m, kq, Ss, Xt, Yt, nullptr, rot, rot_valid));      // T = Xt^H diag(Ss) Yt
+        ctx->lz_extractions += 1; ctx->ritz_sweeps += ctx->total_sweeps - sw0;
+        if (ritz) {
+            const double rh[2] = {(double)m, (double)b};
+            CTM_HIP_CHECK(ctx, hipMemcpyAsync(ritz, rh, sizeof(rh), hipMemcpyHostToDevice, ctx->stream));
+            CTM_HIP_CHECK(ctx, hipMemcpyAsync(ritz + 16, rot, sizeof(double) * 2 * mm, hipMemcpyDeviceToDevice, ctx->stream));
+            CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        }
         XM x{Xt, Xt + km, m, false, false}, e{E, E + mb, b, false, false};
         CTM_TRY(xgemm(ctx, kq, b, m, x, e, XE, XE + kb, b));
         CTM_TRY(row_norms_c128(ctx, XE, XE + kb, kq, b, b, rn));

@@ -46,7 +46,7 @@ def _unit_inputs(eng, direction, coord, state, env, ctm_args):
         key = (direction, coord, env.__dict__.get("_rep", {}).get(direction, 0))
         k = env.chi + 1 if env.chi < n else n
         b = ws.get(key)
-        if b is None or b.shape[1] != n or b.shape[0] != (2 if a.dtype.is_complex else 1) * k + 1 or b.device != a.device:
+        if b is None or b.shape[1] != n or b.shape[0] != eng.warm_rows(env.chi, n, a.dtype)[0] or b.device != a.device:
             b = ws[key] = eng.warm_basis(env.chi, n, a.dtype)
         basis = b
     corners, fresh = _cached_corners(eng, direction, coord, state, env, t16, ctm_args)

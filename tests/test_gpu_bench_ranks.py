@@ -54,7 +54,7 @@ def single_with_energy():
     return _bench(1, EFLAGS)
 
 
-@pytest.mark.parametrize("n", [2, 8])
+@pytest.mark.parametrize("n", [2, pytest.param(8, marks=pytest.mark.soak)])
 def test_energy_block_of_the_line_with_n_ranks(single_with_energy, n):
     """After the full-rank sweeps the driver's command evaluates the energy once: with more than one rank the plaquette RDMs of the four
     sites are shared out -- by site with 2 ranks, and with 8 ranks (more ranks than sites) the p^4 slices of a site's plaquette among the

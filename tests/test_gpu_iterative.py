@@ -9,7 +9,9 @@ from helpers import dev, relerr
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("cplx,chi,nsweeps", [(False, 32, 3), (True, 32, 2), (False, 64, 1), (True, 64, 1)],
+# (most of a case is the numpy oracle on the host: the sweep counts are the smallest that still warm-start, and the complex128 Krylov
+# case -- 64 s, also pinned against the reference by tests/test_gpu_stationary.py::test_fixed_number_of_sweeps_against_the_reference -- is `soak`)
+@pytest.mark.parametrize("cplx,chi,nsweeps", [(False, 32, 2), (True, 32, 2), (False, 64, 1), pytest.param(True, 64, 1, marks=pytest.mark.soak)],
                          ids=["f64", "c128", "f64-krylov", "c128-krylov"])
 def test_sweeps_match_oracle_on_iterative_path(eng, cplx, chi, nsweeps):
     import config as cfg

@@ -140,6 +140,7 @@ def test_optim_j1j2_script(tmp_path):
                                    ["--CTMARGS_projector_svd_method", "SYMEIG", "--OPTARGS_line_search", "backtracking",
                                     "--OPTARGS_line_search_svd_method", "SYMARP"]],
                          ids=["COMPLEX", "SYMEIG_LS_strong_wolfe", "SYMEIG_LS_backtracking", "SYMEIG_LS_backtracking_SYMARP"])
+@pytest.mark.soak          # optim/ is outside SURVEY section 8's scope; the two plain optimiser scripts above stay in the selected set
 def test_optim_j1j2_c4v_script_variants(tmp_path, extra):
     """The other cases of the reference's TestOpt (examples/j1j2/optim_j1j2_c4v.py:193-217): complex128 tensors, the two line
     searches, and the forward-only SYMARP method inside the line search."""
@@ -160,6 +161,7 @@ def test_optim_j1j2_c4v_script_variants(tmp_path, extra):
                                    ["--tiling", "BIPARTITE", "--OPTARGS_line_search", "backtracking", "--OPTARGS_line_search_svd_method", "ARP"],
                                    ["--tiling", "4SITE"]],
                          ids=["GESDD_BIPARTITE", "GESDD_BIPARTITE_LS_strong_wolfe", "GESDD_BIPARTITE_LS_backtracking", "GESDD_4SITE"])
+@pytest.mark.soak
 def test_optim_j1j2_script_variants(tmp_path, extra):
     """The reference's TestOptBasic (examples/j1j2/optim_j1j2.py:238-300): j2 = j3 = hz_stag = 1, D = 2, chi = 8, GESDD projectors,
     three epochs -- the j3 term differentiated through the transfer-matrix correlators, the staggered field in the plaquette term."""

@@ -11,4 +11,5 @@ for f in $(ls tests/test_*.py | sort); do
     *) files="$files $f" ;;
   esac
 done
-exec python -X faulthandler -m pytest $files -m gpu -q -p no:cacheprovider "$@"
+# (--soak: with the long repeats, wall-clock reports and optimiser script variants the driver's selection leaves out, tests/conftest.py)
+exec python -X faulthandler -m pytest $files -m gpu --soak -q -p no:cacheprovider "$@"
