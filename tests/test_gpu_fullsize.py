@@ -69,12 +69,25 @@ def _check_unit(eng, st, env, chi, coord=(0, 0), direction=UP, torch_svdvals=Fal
     s0 = float(S[0])
     assert float((S - S2).abs().max()) < 1e-11 * s0
     if torch_svdvals:
-        ref = torch.linalg.svdvals(M.cpu())[:chi].to(S.device)       # LAPACK on the host, the reference's own route
+        # an independent dense decomposition of the explicit M: torch's own (LAPACK-style bidiagonalisation through its solver library on
+        # the device; on the host -- 20-50 s at n = 4608, the reference's own route -- if that is not available)
+        try:
+            ref = torch.linalg.svdvals(M)[:chi]
+        except RuntimeError:
+            ref = torch.linalg.svdvals(M.cpu())[:chi].to(S.device)
         kept = (S > 0)
         assert float((S - ref)[kept].abs().max()) < 1e-11 * s0
     if host_arpack:
-        from scipy.sparse.linalg import svds
-        ref = np.sort(svds(M.cpu().numpy(), k=20, which='LM', tol=1e-14, return_singular_vectors=False))[::-1]
+        # ARPACK on the host (scipy's svds: an independent implementation, the route of the reference's own partial solver
+        # linalg/svd_arnoldi.py) with the matrix-vector products on the device through torch -- the explicit M never travels (9.7 GB at
+        # n = 24576 complex128, where ~400 host products used to be a minute of the test)
+        from scipy.sparse.linalg import svds, LinearOperator
+        Mh = M.conj().T.contiguous() if M.is_complex() else M.T.contiguous()
+        todev = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(M.device).to(M.dtype)
+        op = LinearOperator(M.shape, matvec=lambda x: (M @ todev(x)).cpu().numpy(), rmatvec=lambda x: (Mh @ todev(x)).cpu().numpy(),
+                            dtype=np.complex128 if M.is_complex() else np.float64)
+        ref = np.sort(svds(op, k=20, which='LM', tol=1e-14, return_singular_vectors=False))[::-1]
+        del Mh
         assert np.abs(S[:20].cpu().numpy() - ref).max() < 1e-11 * s0
     k = int((S2 > 0).sum())
     U, V, Sk = U[:, :k], V[:, :k], S2[:k]
