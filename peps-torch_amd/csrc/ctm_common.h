@@ -140,6 +140,7 @@ struct ctm_ctx {
     bool lz_async = true;               // block Krylov recurrence issued without host synchronisations (status words checked at the extraction)
     bool lz_force_sync = false;         // (internal) the current solve is being repeated on the synchronous path
     long lz_async_fallbacks = 0, lz_third_passes = 0;
+    int lz_two_pass = 1;                // orthonormalise_block_async with two passes for units whose previous solve needed no third (svd_lanczos)
     bool lz_local_project = true;       // first Gram-Schmidt pass of a block step against the previous block only, second against all
     int last_sweeps = 0;
     long total_sweeps = 0, jacobi_calls = 0;

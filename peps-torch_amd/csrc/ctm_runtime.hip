@@ -238,6 +238,7 @@ int ctm_set_option(ctm_ctx* ctx, const char* key, double value) {
     // -- stationary fast path of the implicit-operator truncation (ctm_args.projector_warm_tol)
     else if (k == "warm_accept_tol") ctx->warm_accept_tol = value;
     else if (k == "ritz_warm") ctx->ritz_warm = (int)value;
+    else if (k == "lz_two_pass") ctx->lz_two_pass = (int)value;
     else if (k == "sign_follow") ctx->sign_follow = (int)value;
     else if (k == "warm_try_factor") ctx->warm_try_factor = value;
     else if (k == "warm_accept_max_run") ctx->warm_accept_max_run = (int)value;

@@ -338,7 +338,7 @@ __global__ __launch_bounds__(64) void pivchol64_inv_kernel(const double* __restr
 // mode 0 (first pass): when a pivot of A falls below 1e-10 (rows nearly dependent: cond(W) > ~1e5, beyond two Cholesky-QR passes)
 //   the factorisation is repeated on A + 1e-10 I (shifted Cholesky-QR: the result is only roughly orthonormal, cond ~ 1e-5 cond(W))
 //   and *flag3 is set: a third pass then finishes.  mode 1: plain.  mode 2 (third pass): returns at once unless *flag3.
-// status[0] = smallest pivot of the accepted factorisation, [1] = smallest, [2] = largest row norm.  Nothing is decided on the
+// status[0] = smallest pivot of the accepted factorisation (NEGATED when the first pass shifted), [1] = smallest, [2] = largest row norm.  Nothing is decided on the
 // host here: the caller reads the status words of all its steps at its next host synchronisation.
 #ifdef CTM_KERNEL_CLOCKS
 __device__ double ctm_dbg_clocks[4];    // phase clocks of the single-wave kernels (tools/bench_small_kernels.hip); NOT in the callers' status words
@@ -357,8 +357,10 @@ __global__ __launch_bounds__(64) void chol64_scaled_inv_kernel(const double* __r
     double a[M];                    // row `lane` of A, then of L
     double rinv = 0.0;              // lane j: 1 / L_jj
     double pmin = 1e300;
+    bool shifted = false;
     for (int attempt = 0; attempt < 2; ++attempt) {
         const double shift = attempt == 0 ? 0.0 : 1e-10;
+        shifted = attempt == 1;
 #pragma unroll
         for (int k = 0; k < M; ++k)     // G is symmetric: column `lane` read along rows (coalesced) is row `lane`
             a[k] = act ? G[k * M + lane] * dinv * lane_bcast(dinv, k) + ((k == lane) ? shift : 0.0) : 0.0;
@@ -406,7 +408,7 @@ __global__ __launch_bounds__(64) void chol64_scaled_inv_kernel(const double* __r
     }
     double mn = act ? (dg > 0.0 ? sqrt(dg) : 0.0) : 1e300, mx = act ? (dg > 0.0 ? sqrt(dg) : 0.0) : 0.0;
     for (int off = 32; off > 0; off >>= 1) { mn = fmin(mn, __shfl_down(mn, off, 64)); mx = fmax(mx, __shfl_down(mx, off, 64)); }
-    if (lane == 0) { status[0] = pmin; status[1] = mn; status[2] = mx; }
+    if (lane == 0) { status[0] = shifted ? -pmin : pmin; status[1] = mn; status[2] = mx; }      // (negative: the first pass had to shift -- a third pass is due)
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -500,7 +502,7 @@ int rows_times_c(ctm_ctx* ctx, const double* X, long long ldx, int R, int kin, i
 int matop_apply_c(ctm_ctx* ctx, const MatOp& op, bool adjoint, const double* B, long long ldb, int R, double* C, long long ldc);
 int svd_iter_c(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* Ut, double* Vt, bool* converged, bool* want_krylov = nullptr);
 int orthonormalise_block(ctm_ctx* ctx, double* W, int rows, int n, double* norms, double* inv, double* min_norm, double* max_norm);
-int orthonormalise_block_async(ctm_ctx* ctx, double* W, int b, int n, double* G, double* Li, double* status, int* flag3);
+int orthonormalise_block_async(ctm_ctx* ctx, double* W, int b, int n, double* G, double* Li, double* status, int* flag3, int npass = 3);
 int project_out(ctm_ctx* ctx, double* W, int b, int n, const double* B, int m, double* G, int reps = 2, int local = 0);
 int svd_lanczos(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* Ut, double* Vt, bool* converged);
 int orthonormalise_block_c(ctm_ctx* ctx, CRows W, int rows, int n, double* norms, double* inv, double* min_norm, double* max_norm, bool* ok);

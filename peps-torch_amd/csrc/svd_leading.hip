@@ -55,7 +55,9 @@ enum { HDR_SKIP = 0, HDR_STEPS = 1, HDR_EST = 2, HDR_FAILS = 3, HDR_BLOCK = 4,  
        // [10] doubles the workspace holds BEHIND the header row (written by whoever allocated it; 0 = none): the Ritz region of the block Krylov
        // solvers -- [0] rows m of the stored rotation matrix, [1] block size of the recurrence it belongs to, [16 ...] the m x m accumulated
        // rotations of the unit's last Ritz extraction (svd_full: rot), the start of the next one (include/ctm_hip.h: warm-start workspace)
-       HDR_RITZ_CAP = 10, HDR_WORDS = 11,
+       HDR_RITZ_CAP = 10,
+       // [11] 1: the last accepted block Krylov solve of the unit needed a third Cholesky-QR pass somewhere (or was repeated on the synchronous path)
+       HDR_THIRD = 11, HDR_WORDS = 12,
        HDR_SPREV = 16 /* from here: the k singular values of the previous solve (spectrum_movement) */ };
 
 inline int warm_skip_calls(const ctm_ctx* ctx, double r) {
@@ -521,11 +523,12 @@ int orthonormalise_block(ctm_ctx* ctx, double* W, int rows, int n, double* norms
 // rows of W (64 x n) -> orthonormal rows spanning the same space: two Cholesky-QR passes, and a third one -- decided on the device --
 // when the first had to shift (nearly dependent rows); no host synchronisation.  Status words of the three passes go to
 // `status` (9 doubles: pivot, min norm, max norm per pass; a skipped third pass reports 1), `flag3` is a device word.
-int orthonormalise_block_async(ctm_ctx* ctx, double* W, int b, int n, double* G, double* Li, double* status, int* flag3) {
+// npass = 2: the third, flag-skipped pass is not even launched (three idle launches per block); a first pass that shifted is then visible
+// in its status word (negative pivot) and the caller repeats the solve with three passes (svd_lanczos: units whose previous solve needed none).
+int orthonormalise_block_async(ctm_ctx* ctx, double* W, int b, int n, double* G, double* Li, double* status, int* flag3, int npass) {
     // (Two passes for 32-row blocks were tried: no shifted first pass in any run on random tensors, three idle launches per block saved, < 0.5 % of
     // a sweep -- but on an SU(2)-symmetric state (RVB D = 3 tiled on the 2 x 2 cell, chi = 80: exactly dependent rows inside multiplets) a shifted
     // pass then sends the whole solve to the synchronous path.  The third, flag-skipped pass stays for every block size.)
-    const int npass = 3;
     for (int pass = 0; pass < npass; ++pass) {
         GemmDesc g; g.M = b; g.N = b; g.K = n; g.A = W; g.sam = n; g.sak = 1; g.B = W; g.sbk = 1; g.sbn = n; g.C = G; g.ldc = b;
         if (pass == 2) g.skip_all = flag3;
@@ -603,6 +606,7 @@ int svd_lanczos(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* Ut, dou
         CTM_TRY(arena_alloc(ctx, sizeof(double) * SW * nstat, (void**)&ostat));
         CTM_TRY(arena_alloc(ctx, sizeof(double) * 64 * 64, (void**)&Li));
         CTM_TRY(arena_alloc(ctx, sizeof(int) * 64, (void**)&flag3));
+        CTM_TRY(fill_f64(ctx, ostat, (size_t)SW * nstat, -1.0));       // (a pass that is not launched reads as "skipped")
     }
     auto resync = [&]() -> int {          // redo this solve on the synchronous path
         if (ctx->jacobi_verbose) fprintf(stderr, "[lz] n=%d asynchronous recurrence flagged: repeating on the synchronous path\n", n);
@@ -610,6 +614,7 @@ int svd_lanczos(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* Ut, dou
         ctx->lz_force_sync = true;
         const int st = svd_lanczos(ctx, op, k, S, Ut, Vt, converged);
         ctx->lz_force_sync = false;
+        if (st == CTM_OK && op.warm_hdr) return fill_f64(ctx, op.warm_hdr + HDR_THIRD, 1, 1.0);      // the unit's next solve launches all three passes
         return st;
     };
     const double tol = resid_tol(ctx, n);
@@ -628,13 +633,20 @@ int svd_lanczos(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* Ut, dou
     else if (hdr[HDR_STEPS] >= jmin && hdr[HDR_STEPS] <= jmax && hdr[HDR_EST] > 0.0 && (int)hdr[HDR_BLOCK] == b)
         // the estimate falls by a factor 7-17 per block step (measured, D = 6 and 8): one step less when it passed with more than
         // that to spare, one more when it passed narrowly (a failed look costs five steps)
-        jnext = (int)hdr[HDR_STEPS] + (hdr[HDR_EST] <= tol / 30.0 ? -1 : (hdr[HDR_EST] > tol / 3.0 ? 1 : 0));
+        // (with the Ritz extraction warm started from the previous one -- same basis size: 3 Jacobi sweeps; a basis that grew by a block: 8; one that
+        //  shrank: a cold start, 13 -- a step less is only worth it when the estimate passed with orders of magnitude to spare: 30 until round 5
+        //  made units oscillate between two step counts)
+        jnext = (int)hdr[HDR_STEPS] + (hdr[HDR_EST] <= tol * (ctx->ritz_warm ? 1e-3 : 1.0 / 30.0) ? -1 : (hdr[HDR_EST] > tol / 3.0 ? 1 : 0));
     else jnext = (int)std::ceil((b == 32 ? ctx->lz_first_factor32 : ctx->lz_first_factor) * k / b);
     jnext = std::max(jmin, std::min(jnext, jmax));
     double est_prev = 0.0; int steps_prev = 0;
     double mn, mx, s0 = 0.0;
+    // two Cholesky-QR passes per block where the unit's previous accepted solve never needed the third (its launches are idle then: ~130 of a
+    // unit's ~1100); a first pass that shifts after all is seen at the next look and the solve is repeated (resync)
+    const int npass = (ctx->lz_two_pass && op.warm_hdr && hdr[HDR_STEPS] >= 1.0 && hdr[HDR_THIRD] < 1.0) ? 2 : 3;
+    bool any_third = false;
     CTM_LAUNCH(ctx, hash_fill_kernel, dim3(1024), dim3(256), 0, Vall, b, n, (long long)n, 0x51f15eedULL);
-    if (async) CTM_TRY(orthonormalise_block_async(ctx, Vall, b, n, G, Li, ostat + SW * (nstat - 1), flag3));
+    if (async) CTM_TRY(orthonormalise_block_async(ctx, Vall, b, n, G, Li, ostat + SW * (nstat - 1), flag3, npass));
     else CTM_TRY(orthonormalise_block(ctx, Vall, b, n, norms, inv, &mn, &mx));
     int applications = 0;
     for (int j = 0; j < jmax; ++j) {
@@ -647,7 +659,7 @@ int svd_lanczos(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* Ut, dou
         CTM_TRY(matop_apply(ctx, op, true, Vj, n, b, Wj, n, want_mid ? VRall + (size_t)j * b * n : nullptr)); applications += b;
         CTM_HIP_CHECK(ctx, hipMemcpyAsync(Uj, Wj, sizeof(double) * (size_t)b * n, hipMemcpyDeviceToDevice, ctx->stream));
         CTM_TRY(project_out(ctx, Uj, b, n, Uall, j * b, G, 2, ctx->lz_local_project ? b : 0));
-        if (async) CTM_TRY(orthonormalise_block_async(ctx, Uj, b, n, G, Li, ostat + SW * (2 * j), flag3));
+        if (async) CTM_TRY(orthonormalise_block_async(ctx, Uj, b, n, G, Li, ostat + SW * (2 * j), flag3, npass));
         else {
             CTM_TRY(orthonormalise_block(ctx, Uj, b, n, norms, inv, &mn, &mx));
             s0 = std::max(s0, mx);
@@ -657,7 +669,7 @@ int svd_lanczos(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* Ut, dou
         CTM_TRY(matop_apply(ctx, op, false, Uj, n, b, Zj, n, want_mid ? URall + (size_t)j * b * n : nullptr)); applications += b;
         CTM_HIP_CHECK(ctx, hipMemcpyAsync(Vn, Zj, sizeof(double) * (size_t)b * n, hipMemcpyDeviceToDevice, ctx->stream));
         CTM_TRY(project_out(ctx, Vn, b, n, Vall, (j + 1) * b, G, 2, ctx->lz_local_project ? b : 0));
-        if (async) CTM_TRY(orthonormalise_block_async(ctx, Vn, b, n, G, Li, ostat + SW * (2 * j + 1), flag3));
+        if (async) CTM_TRY(orthonormalise_block_async(ctx, Vn, b, n, G, Li, ostat + SW * (2 * j + 1), flag3, npass));
         else {
             CTM_TRY(orthonormalise_block(ctx, Vn, b, n, norms, inv, &mn, &mx));
             if (mn <= 1e-13 * s0) { if (ctx->jacobi_verbose) fprintf(stderr, "[lz] n=%d breakdown at step %d (V)\n", n, j); return CTM_OK; }
@@ -674,13 +686,16 @@ int svd_lanczos(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* Ut, dou
             auto check = [&](int slot, bool left) {
                 const double* q = hst.data() + SW * slot;
                 const bool third = q[7] >= 0.0;                                // the device ran the third pass (first one was shifted)
+                const bool shifted = q[0] < 0.0;                               // (chol64_scaled_inv_kernel negates the pivot of a shifted first pass)
                 const double last = third ? q[6] : q[3];                       // pivot of the last pass: rows orthonormal to rounding iff ~1
+                if (shifted || third) any_third = true;
+                if (shifted && !third) { bad = true; return; }                 // two-pass mode met a block that needs the third pass: repeat
                 if (left) s0a = std::max(s0a, q[2]);
                 // breakdown of the recurrence: a new block with (numerically) nothing in it -- the Krylov space has exhausted the range of a
                 // rank-deficient operator (symmetric states at small chi: every solve).  Not a case for this solver on either path: leave
                 // at once, as the synchronous recurrence does, instead of repeating the whole solve there to find the same thing
                 if (q[1] == q[1] && !(q[1] > 1e-13 * std::max(s0a, 1e-300)) && slot != nstat - 1) { broke = true; return; }
-                if (!(q[0] > 0.0) || !(last > 0.5) || !(q[1] > 0.0)) bad = true;   // (NaN fails too), zero row
+                if (!(std::fabs(q[0]) > 0.0) || !(last > 0.5) || !(q[1] > 0.0)) bad = true;   // (NaN fails too), zero row
                 if (third) ctx->lz_third_passes += 1;
             };
             check(nstat - 1, false);
@@ -844,6 +859,7 @@ int svd_lanczos(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* Ut, dou
                 CTM_TRY(fill_f64(ctx, op.warm_hdr + HDR_STEPS, 1, (double)steps));
                 CTM_TRY(fill_f64(ctx, op.warm_hdr + HDR_EST, 1, std::max(est / hs[0], 1e-300)));
                 CTM_TRY(fill_f64(ctx, op.warm_hdr + HDR_BLOCK, 1, (double)b));
+                if (async) CTM_TRY(fill_f64(ctx, op.warm_hdr + HDR_THIRD, 1, any_third ? 1.0 : 0.0));
             }
             CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
             *converged = true;
@@ -1005,7 +1021,10 @@ int svd_lanczos_c(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* Ut, d
     int jnext;
     if (ctx->lz_first > 0) jnext = ctx->lz_first;
     else if (hdr[HDR_STEPS] >= jmin && hdr[HDR_STEPS] <= jmax && hdr[HDR_EST] > 0.0 && (int)hdr[HDR_BLOCK] == b)
-        jnext = (int)hdr[HDR_STEPS] + (hdr[HDR_EST] <= tol / 30.0 ? -1 : (hdr[HDR_EST] > tol / 3.0 ? 1 : 0));
+        // (with the Ritz extraction warm started from the previous one -- same basis size: 3 Jacobi sweeps; a basis that grew by a block: 8; one that
+        //  shrank: a cold start, 13 -- a step less is only worth it when the estimate passed with orders of magnitude to spare: 30 until round 5
+        //  made units oscillate between two step counts)
+        jnext = (int)hdr[HDR_STEPS] + (hdr[HDR_EST] <= tol * (ctx->ritz_warm ? 1e-3 : 1.0 / 30.0) ? -1 : (hdr[HDR_EST] > tol / 3.0 ? 1 : 0));
     else jnext = (int)std::ceil((b == 32 ? ctx->lz_first_factor32 : ctx->lz_first_factor) * k / b);
     jnext = std::max(jmin, std::min(jnext, jmax));
     double est_prev = 0.0; int steps_prev = 0;

@@ -217,3 +217,53 @@ def test_complex_krylov_solver_variants_agree(eng):
 
 
 LZ_BLOCK_C_DEFAULT = 32          # csrc/ctm_common.h
+
+
+def test_warm_started_ritz_extraction_and_two_pass_recurrence_give_the_same_sweeps(eng):
+    """Round 6 routes of the block Krylov truncation (csrc/svd_leading.hip): the dense SVD of the Ritz matrix started from the rotations of the
+    unit's previous extraction (`ritz_warm`; needs the orientation of the returned vectors to follow the previous decomposition, `sign_follow`,
+    or the operator of the next sweep is a different matrix) and two instead of three Cholesky-QR passes per block where the unit's previous
+    solve needed no third (`lz_two_pass`).  Six sweeps of a signed D = 4 chi = 64 state with the routes on and off: same corner spectra and
+    rdm2x2 (1e-10; the gauge of the environment tensors differs by signs), the warm start really is taken, and it needs fewer Jacobi sweeps."""
+    import config as cfg
+    from ipeps.ipeps import IPEPS
+    from ctm.generic.env import ENV, init_env
+    from ctm.generic import ctmrg, rdm
+    rng = np.random.default_rng(9)
+    D, chi, nsweeps = 4, 64, 6
+    sites = {}
+    for y in range(2):
+        for x in range(2):
+            A = rng.random((2, D, D, D, D)) - 0.5
+            sites[(x, y)] = dev(A / np.abs(A).max())
+    engines = [eng] + list(eng.workers)
+    out = {}
+    try:
+        for on in (1, 0):
+            for e in engines:
+                for key in ("ritz_warm", "sign_follow", "lz_two_pass"):
+                    e.set_option(key, on)
+            st = IPEPS(dict(sites)); env = ENV(chi, st); init_env(st, env)
+            per = []
+            for _ in range(nsweeps):
+                x0, w0, s0 = eng.stat("lz_extractions"), eng.stat("ritz_warm_starts"), eng.stat("ritz_sweeps")
+                for d in cfg.ctm_args.ctm_move_sequence:
+                    for _r in range(2):
+                        ctmrg.ctm_MOVE(d, st, env)
+                nx = eng.stat("lz_extractions") - x0
+                per.append((int(nx), int(eng.stat("ritz_warm_starts") - w0), (eng.stat("ritz_sweeps") - s0) / max(nx, 1)))
+            out[on] = (per, {k: (s_ / s_[0]).cpu().numpy() for k, s_ in env.get_spectra().items()}, rdm.rdm2x2((0, 0), st, env).cpu().numpy())
+            env.__dict__.pop("_corner_cache", None)
+    finally:
+        for e in engines:
+            for key in ("ritz_warm", "sign_follow", "lz_two_pass"):
+                e.set_option(key, 1)
+    (p1, s1, r1), (p0, s0_, r0) = out[1], out[0]
+    assert all(nx >= 32 for nx, _, _ in p1[1:]) and all(w == 0 for _, w, _ in p0)
+    assert sum(w for _, w, _ in p1) > 32, p1                                    # the warm start is taken ...
+    assert p1[-1][2] < 0.75 * p0[-1][2], (p1, p0)                                # ... and the late sweeps need fewer Jacobi sweeps per extraction
+    for k in s1:
+        assert np.abs(s1[k] - s0_[k]).max() < 1e-10, k
+    assert np.abs(r1 - r0).max() < 1e-10
+    print(f"\nJacobi sweeps per Ritz extraction, sweep by sweep: routes on {[round(x[2], 2) for x in p1]} (warm started {[x[1] for x in p1]}), off {[round(x[2], 2) for x in p0]}")
+    eng.trim()
