@@ -755,13 +755,6 @@ int svd_lanczos(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* Ut, dou
         ctx->si_enable = save;
         CTM_TRY(st);
         ctx->lz_extractions += 1; ctx->ritz_sweeps += ctx->total_sweeps - sw0;
-        if (rot && getenv("CTM_RITZ_DBG")) {      // development: the same matrix again from the rotations just stored -- its first sweep must find nothing
-            fprintf(stderr, "[lz-dbg] repeat of the extraction from its own rotations:\n");
-            ctx->si_enable = false;
-            const int st2 = svd_full(ctx, T, m, kq, Ss, Xt, Yt, nullptr, rot, true);
-            ctx->si_enable = save;
-            CTM_TRY(st2);
-        }
         if (ritz) {
             const double rh[3] = {(double)m, (double)b, (double)mr};
             CTM_HIP_CHECK(ctx, hipMemcpyAsync(ritz, rh, sizeof(rh), hipMemcpyHostToDevice, ctx->stream));
