@@ -140,8 +140,11 @@ def cpu_baseline(kind, D, chi, sites, env_np=None, budget_s=25.0, svd_n=None):
         t_svd = t["svd"] * ((n / nsub) ** 3 if nsub else 1.0)
         dt = t["corners"] + t["halves"] + t_svd + t["proj"] + t["absorb"]
         how = "measured" if not nsub else f"dgesdd measured at n_s={nsub} ({t['svd']:.1f} s) and scaled by (n/n_s)^3 = {t_svd:.0f} s, everything else measured at full size"
+        # (the driver keeps the first 120 characters of the sample: what is extrapolated comes first)
+        lead = (f"EXTRAPOLATED: dgesdd timed at n_s={nsub}, scaled x(n/n_s)^3 to n={n} = {100 * t_svd / dt:.0f}% of 1 unit; x32 units/sweep. " if nsub
+                else "1 unit measured in full, x32 units/sweep (extrapolated). ")
         return {"value": 1.0 / (32 * dt), "unit": "sweeps/s", "cores": r["threads"], "kind": "port",
-                "sample": f"1 of the 32 (site,direction) units of one sweep, C++ restatement on OpenBLAS/LAPACK ({r['threads']} threads of "
+                "sample": lead + f"1 of the 32 (site,direction) units of one sweep, C++ restatement on OpenBLAS/LAPACK ({r['threads']} threads of "
                           f"{os.cpu_count()} host cpus) on the {env_what}: 4 corners {t['corners']:.1f} s + R, Rt, M (3 n^3 dgemm) {t['halves']:.1f} s + "
                           f"dgesdd {t_svd:.1f} s + projectors {t['proj']:.2f} s + absorb {t['absorb']:.1f} s = {dt:.1f} s/unit ({how}), x32 units/sweep"}
     if n > 6000:
