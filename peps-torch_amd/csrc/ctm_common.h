@@ -95,7 +95,6 @@ struct ctm_ctx {
     double rank_tol = 5e-13;             // numerical-rank threshold of the leading-k solvers (relative to s_0)
     long si_hits = 0, si_fallbacks = 0, si_total_iters = 0, si_warm_starts = 0;
     long svd_polar_completions = 0, svd_eig_completions = 0;     // rank-deficient full SVDs: V completed by the polar iteration / by eigenvectors
-    int svd_deflate = 1, svd_deflate_min_n = 256; long svd_deflated = 0;      // full real SVD with vectors: leading-rank solve + orthonormal completion (svd_full_deflated)
     int svd_polar = 1, svd_polar_min_n = 96;   // full real SVD with vectors (differentiable route): polar decomposition + shifted symmetric Jacobi
     long svd_polar_solves = 0;
     int lz_abs_accuracy = 0;           // experiment: absolute criterion for the Ritz extraction of the block Krylov solver

@@ -216,7 +216,6 @@ int ctm_set_option(ctm_ctx* ctx, const char* key, double value) {
     else if (k == "si_tol") ctx->si_tol = value;
     else if (k == "svd_abs_accuracy") ctx->svd_abs_accuracy = (int)value;
     else if (k == "svd_polar") ctx->svd_polar = (int)value;
-    else if (k == "svd_deflate") ctx->svd_deflate = (int)value;
     // -- which solver / kernel route
     else if (k == "si_enable") ctx->si_enable = value != 0.0;
     else if (k == "si_min_n") ctx->si_min_n = (int)value;
@@ -295,7 +294,6 @@ int ctm_get_stat(ctm_ctx* ctx, const char* key, double* value) {
     else if (k == "lz_total_rows") *value = (double)ctx->lz_total_rows;
     else if (k == "lz_extractions") *value = (double)ctx->lz_extractions;
     else if (k == "ritz_warm_starts") *value = (double)ctx->ritz_warm_starts;
-    else if (k == "svd_deflated") *value = (double)ctx->svd_deflated;
     else if (k == "ritz_sweeps") *value = (double)ctx->ritz_sweeps;
     else if (k == "lz_last_est") *value = ctx->lz_last_est;
     else if (k == "lz_async_fallbacks") *value = (double)ctx->lz_async_fallbacks;

@@ -1431,57 +1431,6 @@ int spectrum_movement(ctm_ctx* ctx, double* hdr_row, int n, const double* S, int
     return CTM_OK;
 }
 
-// Full decomposition with vectors of a real n x n matrix whose spectrum falls to the rounding level long before n -- every M = R^T Rt of the
-// differentiable route (numerical rank ~ 100-150 at n = 512): resolve ONLY the triplets above svd_null_tol x s_0 with the
-// leading-k solvers of the forward path (block power iteration / block Krylov on the explicit matrix, warm started from the workspace's
-// leading rows), and complete U and V with orthonormal bases of the complements (complete_null_rows: any basis of the numerically null space
-// is as good -- what the full Jacobi spent most of its sweeps on was diagonalising noise inside that space).  The reference decomposes in
-// full with LAPACK (linalg/svd_gesdd.py:77-96) and differentiates with a regularised backward (:209-328) in which rows at the rounding
-// level of M carry no weight.  *done = false: not applicable (rank above 0.6 n, or the solver did not accept) -- the caller decomposes in full.
-// warm: n x n workspace (rows: right vectors of the previous decomposition of a nearby matrix) + header row (HDR_RANK: its numerical rank).
-enum { HDR_RANK = 12 };
-int svd_full_deflated(ctm_ctx* ctx, const double* M, int n, double* S, double* Ut, double* Vt, double* warm, double* warm_hdr, bool* done) {
-    *done = false;
-    double hw[16] = {0.0};
-    if (warm_hdr) {
-        CTM_HIP_CHECK(ctx, hipMemcpyAsync(hw, warm_hdr, sizeof(hw), hipMemcpyDeviceToHost, ctx->stream));
-        CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-    }
-    const int rprev = (int)hw[HDR_RANK];
-    int kk = rprev > 0 ? rprev + std::max(16, rprev / 8) : n / 4;
-    kk = std::min(n, (kk + 15) / 16 * 16);
-    std::vector<double> hs;
-    int kg = 0;
-    for (int attempt = 0; attempt < 3; ++attempt) {
-        if (kk > (6 * n) / 10 || kk >= n) return CTM_OK;
-        MatOp op; op.n = n; op.M = M;
-        op.warm = (warm && rprev > 0) ? warm : nullptr;          // its first kk rows: the leading right vectors of the previous call (zero rows are skipped by the solver)
-        const long fb0 = ctx->si_fallbacks;
-        CTM_TRY(jacobi_svd_top_op(ctx, op, kk, S, Ut, Vt));
-        if (ctx->si_fallbacks != fb0) return CTM_OK;             // the leading-k solvers did not accept: a dense decomposition ran inside -- not a case for this route
-        hs.resize(kk);
-        CTM_HIP_CHECK(ctx, hipMemcpyAsync(hs.data(), S, sizeof(double) * kk, hipMemcpyDeviceToHost, ctx->stream));
-        CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-        if (!(hs[0] > 0.0)) return CTM_OK;
-        kg = 0;
-        while (kg < kk && hs[kg] > ctx->svd_null_tol * hs[0]) ++kg;
-        if (kg + 2 <= kk) break;                                 // the computed values reach below the threshold: everything above it is resolved
-        kk = std::min(n, (2 * kk + 15) / 16 * 16);
-        kg = -1;
-    }
-    if (kg <= 0) return CTM_OK;
-    // values and rows below the threshold: exact zeros and orthonormal complements (rows kg .. n-1 of Ut, Vt)
-    CTM_TRY(fill_f64(ctx, S + kg, (size_t)(n - kg), 0.0));
-    CTM_TRY(complete_null_rows(ctx, Ut, kg, n, n));
-    CTM_TRY(complete_null_rows(ctx, Vt, kg, n, n));
-    if (warm) CTM_HIP_CHECK(ctx, hipMemcpyAsync(warm, Vt, sizeof(double) * (size_t)n * n, hipMemcpyDeviceToDevice, ctx->stream));
-    if (warm_hdr) CTM_TRY(fill_f64(ctx, warm_hdr + HDR_RANK, 1, (double)kg));
-    CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-    ctx->svd_deflated += 1;
-    *done = true;
-    return CTM_OK;
-}
-
 int jacobi_svd_top_op(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* Ut, double* Vt) {
     const int n = op.n;
     if (n <= 0 || k <= 0 || k > n) { ctx->set_error("jacobi_svd_top: bad n/k"); return CTM_ERR_BADARG; }
@@ -1637,11 +1586,6 @@ int jacobi_svd_top_op(ctm_ctx* ctx, const MatOp& op, int k, double* S, double* U
         ctx->si_fallbacks += 1;
     }
     if (op.M) {
-        if (k == n && Ut && Vt && ctx->svd_deflate && ctx->si_enable && n >= std::max(ctx->si_min_n, ctx->svd_deflate_min_n)) {
-            bool done = false;
-            CTM_TRY(svd_full_deflated(ctx, op.M, n, S, Ut, Vt, op.warm, op.warm_hdr, &done));       // workspace: right vectors
-            if (done) return CTM_OK;
-        }
         if (k == n && Ut && Vt && ctx->svd_polar && n >= ctx->svd_polar_min_n) return svd_full_polar(ctx, op.M, n, S, Ut, Vt, op.warm);   // workspace: right vectors
         if (k == n) return svd_full(ctx, op.M, n, k, S, Ut, Vt, op.warm);                   // full decomposition: the workspace keeps the left vectors
         CTM_TRY(svd_full(ctx, op.M, n, k, S, Ut, Vt)); return keep_warm();

@@ -313,70 +313,3 @@ def test_concurrently_built_graphs_are_reproducible(eng, tmp_path):
     for r in runs[1:]:
         assert float(np.abs(np.array(r) - np.array(runs[0])).max()) < 1e-12, runs
 
-
-def test_deflated_full_decomposition_gives_the_same_energy_and_gradient(eng):
-    """Round 6 (`svd_deflate`, csrc/svd_leading.hip: svd_full_deflated): at n >= 256 the SVD node of the differentiable route resolves only
-    the triplets above svd_null_tol x s_0 (leading-rank solve on the explicit M) and completes U and V with orthonormal bases of the
-    complements, instead of a full n x n Jacobi / polar decomposition.  The reference decomposes in full and differentiates with a
-    regularised backward in which the numerically null rows carry no weight (linalg/svd_gesdd.py:77-96, 209-328): the energy after four
-    differentiable moves and its gradient with respect to the site tensors must not depend on the route.  D = 4, chi = 16 (n = 256),
-    signed state, one move per direction, twice (the second evaluation warm starts from the first one's vectors)."""
-    import config as cfg
-    from ipeps.ipeps import IPEPS
-    from ctm.generic.env import ENV, init_env
-    from ctm.generic import ctmrg
-    from models import j1j2
-    rng = np.random.default_rng(3)
-    D, chi = 4, 16
-    base = {(x, y): rng.random((2, D, D, D, D)) - 0.5 for y in range(2) for x in range(2)}
-    model = j1j2.J1J2(j1=1.0, j2=0.3)
-    res = {}
-    try:
-        for on in (1, 0):
-            eng.set_option("svd_deflate", on)
-            d0 = eng.stat("svd_deflated")
-            env = None
-            out = []
-            for rep in range(2):
-                sites = {c: dev(a + rep * 1e-3 * np.cos(np.arange(a.size).reshape(a.shape))).requires_grad_(True) for c, a in base.items()}
-                st = IPEPS(sites, lX=2, lY=2)
-                if env is None:
-                    env = ENV(chi, st)
-                init_env(st, env)
-                for d in cfg.ctm_args.ctm_move_sequence:
-                    ctmrg.ctm_MOVE(d, st, env)
-                e = model.energy_2x2_4site(st, env)
-                e.backward()
-                out.append((float(e), torch.cat([t.grad.reshape(-1) for t in sites.values()]).cpu().numpy()))
-                env = env.detach()
-            res[on] = (out, int(eng.stat("svd_deflated") - d0))
-    finally:
-        eng.set_option("svd_deflate", 1)
-    assert res[1][1] > 0 and res[0][1] == 0, (res[1][1], res[0][1])             # the route is taken / is off
-    for (e1, g1), (e0, g0) in zip(res[1][0], res[0][0]):
-        assert abs(e1 - e0) < 1e-11 * max(abs(e0), 1e-3), (e1, e0)
-        assert np.abs(g1 - g0).max() < 1e-8 * np.abs(g0).max(), (np.abs(g1 - g0).max(), np.abs(g0).max())
-
-
-def test_deflated_full_decomposition_of_a_graded_matrix(eng):
-    """The primitive: full SVD (chi = n) of a matrix whose spectrum is graded down to the rounding level, n = 384, numerical rank ~ 120:
-    singular values above svd_null_tol x s_0 against numpy, exact zeros below, U and V orthogonal n x n, U S V^T = M to rounding -- cold,
-    and again on a nearby matrix from the warm workspace."""
-    rng = np.random.default_rng(8)
-    n = 384
-    U0, _ = np.linalg.qr(rng.standard_normal((n, n))); V0, _ = np.linalg.qr(rng.standard_normal((n, n)))
-    s = np.exp(-0.28 * np.arange(n)); s[150:] = 0.0
-    M = (U0 * s) @ V0.T + 1e-17 * rng.standard_normal((n, n))
-    basis = eng.warm_basis(n, n, torch.float64)
-    d0 = eng.stat("svd_deflated")
-    for it in range(2):
-        Mi = M + it * 1e-4 * (U0[:, :5] * s[:5]) @ V0[:, 5:10].T
-        U, S, V = eng.truncated_svd(dev(Mi), n, eng.cfg(keep_multiplets=False), basis=basis)
-        U, S, V = U.cpu().numpy(), S.cpu().numpy(), V.cpu().numpy()
-        ref = np.linalg.svd(Mi, compute_uv=False)
-        kg = int((ref > 1e-11 * ref[0]).sum())
-        assert np.abs(S[:kg] - ref[:kg]).max() < 1e-13 * ref[0]
-        assert np.all(S[kg + 2:] == 0.0)
-        assert np.abs(U.T @ U - np.eye(n)).max() < 1e-12 and np.abs(V.T @ V - np.eye(n)).max() < 1e-12
-        assert np.abs((U * S) @ V.T - Mi).max() < 1e-11 * ref[0]               # (what lies below svd_null_tol x s_0 is dropped)
-    assert eng.stat("svd_deflated") - d0 == 2

@@ -1,4 +1,4 @@
-"""GPU: the option surface of the engine (ctm_set_option, csrc/ctm_runtime.hip).  41 keys; each is named here with its default, is
+"""GPU: the option surface of the engine (ctm_set_option, csrc/ctm_runtime.hip).  40 keys; each is named here with its default, is
 accepted by the library, and -- where it selects a route or a kernel -- is exercised: the same small problems (a truncated SVD on a
 slowly decaying spectrum through the block Krylov solver, a symmetric truncation with a warm workspace, a complex GEMM, a fused
 projector unit) give the same answers with the option at its other value.  Keys the library no longer has (variants that lost their
@@ -21,7 +21,7 @@ OPTIONS = {
     "eigh_orth_double": (2, 0), "proj_from_krylov": (1, 0), "use_layer2": (1, 0), "gemm_fast": (1, 0), "xgemm_stack_rows": (1, 0),
     # round 6: Ritz extraction warm started from the unit's previous one, orientation of returned vectors follows the previous decomposition,
     # two Cholesky-QR passes where the unit's history allows (tests/test_gpu_stationary.py / test_gpu_iterative.py drive them on sweeps)
-    "ritz_warm": (1, 0), "sign_follow": (1, 0), "lz_two_pass": (1, 0), "svd_deflate": (1, 0),
+    "ritz_warm": (1, 0), "sign_follow": (1, 0), "lz_two_pass": (1, 0),
     # stationary fast path (tests/test_gpu_stationary.py drives it)
     "warm_accept_tol": (0.0, None), "warm_try_factor": (1e-4, None), "warm_accept_max_run": (32, None),
     # row-block GEMM epilogues (tests/test_gpu_gemm_rows.py drives them)
@@ -72,7 +72,7 @@ TOL = {"svd_S": 1e-12, "svd_resid": 1.0, "eigh_D": 1e-11, "cgemm": 1e-10, "gemm"
 
 def test_every_option_is_accepted_and_removed_ones_are_refused(eng):
     import _native
-    assert len(OPTIONS) == 41
+    assert len(OPTIONS) == 40
     for k, (default, _) in OPTIONS.items():
         eng.set_option(k, default)
     for k in REMOVED:
