@@ -267,3 +267,44 @@ def test_warm_started_ritz_extraction_and_two_pass_recurrence_give_the_same_swee
     assert np.abs(r1 - r0).max() < 1e-10
     print(f"\nJacobi sweeps per Ritz extraction, sweep by sweep: routes on {[round(x[2], 2) for x in p1]} (warm started {[x[1] for x in p1]}), off {[round(x[2], 2) for x in p0]}")
     eng.trim()
+
+
+def test_round6_routes_on_a_state_with_exact_multiplets(eng):
+    """The same three routes on an SU(2)-symmetric state (RVB D = 3 of the reference's test-input, tiled on the 2 x 2 cell, chi = 80: exactly
+    degenerate singular values, exactly dependent rows inside multiplets -- where a first Cholesky-QR pass shifts and a two-pass solve has to be
+    repeated with three, where vectors inside a multiplet have no orientation to follow, and where the Ritz matrix has exactly degenerate
+    values): five sweeps with the routes on and off give the same corner spectra."""
+    import os
+    import config as cfg
+    from ipeps.ipeps_c4v import read_ipeps_c4v
+    from ipeps.ipeps import IPEPS
+    from ctm.generic.env import ENV, init_env
+    from ctm.generic import ctmrg
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    A = read_ipeps_c4v(os.path.join(root, "tests", "golden", "test-input", "RVB_1x1.in")).site().cuda()
+    engines = [eng] + list(eng.workers)
+    res = {}
+    try:
+        for on in (1, 0):
+            for e in engines:
+                for key in ("ritz_warm", "sign_follow", "lz_two_pass"):
+                    e.set_option(key, on)
+            st = IPEPS({(x, y): A.clone() for x in range(2) for y in range(2)})
+            env = ENV(80, st); init_env(st, env)
+            l0, f0, a0 = eng.stat("lz_hits"), eng.stat("si_fallbacks"), eng.stat("lz_async_fallbacks")
+            for _ in range(5):
+                for d in cfg.ctm_args.ctm_move_sequence:
+                    for _r in range(2):
+                        ctmrg.ctm_MOVE(d, st, env)
+            res[on] = ({k: (v / v[0]).cpu().numpy() for k, v in env.get_spectra().items()},
+                       int(eng.stat("lz_hits") - l0), int(eng.stat("si_fallbacks") - f0), int(eng.stat("lz_async_fallbacks") - a0))
+            env.__dict__.pop("_corner_cache", None)
+    finally:
+        for e in engines:
+            for key in ("ritz_warm", "sign_follow", "lz_two_pass"):
+                e.set_option(key, 1)
+    print(f"\nRVB chi = 80: routes on: {res[1][1]} block Krylov solves, {res[1][2]} dense fallbacks, {res[1][3]} repeats on the synchronous path; "
+          f"off: {res[0][1]}, {res[0][2]}, {res[0][3]}")
+    for k in res[1][0]:
+        assert np.abs(res[1][0][k] - res[0][0][k]).max() < 1e-10, k
+    eng.trim()
