@@ -383,6 +383,8 @@ def run_workload(args, eng, dev, kind, D, chi, dtype, signed, steps, warmup, wor
            "ritz_extractions": int(eng.stat("lz_extractions")),
            # ... of which started from the rotations of the unit's previous extraction, and the Jacobi sweeps an extraction took on average
            "ritz_warm_starts": int(eng.stat("ritz_warm_starts")),
+           # corner passes this rank computed as one half of a rank pair that shares the unit (twice as many ranks as sites; 0 otherwise)
+           "shared_corner_passes": int(eng.stat("comm_calls")),
            "avg_sweeps_per_ritz_extraction": round(eng.stat("ritz_sweeps") / max(eng.stat("lz_extractions"), 1), 2)}
     eng.set_option("gemm_timing", 0)
     if args.profile:

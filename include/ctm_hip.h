@@ -93,9 +93,23 @@ int ctm_gemm_intervals(ctm_ctx* ctx, double* out, long long capacity_doubles, lo
  *     deterministic kernels: no broadcast of their results);
  *   - projectors P, Pt come out replicated; the host layer exchanges them between groups as it does between single ranks
  *     (parallel.exchange).
- * Returns CTM_ERR_UNSUPPORTED for nranks > 1 in this build (the split is specified, costed and not built: it cannot be executed on
- * the single-GPU boxes this library is developed on), CTM_ERR_BADARG for rank outside [0, nranks). */
+ * What this build executes (round 6) is the first kind only, on REPLICATED corners: every rank of the group builds and keeps the whole
+ * corners (no memory saving, corner construction and absorb not split) and computes, in every corner pass of a float64 unit, the column
+ * block [rank n'/nranks, (rank+1) n'/nranks) of the (rows x n') product, followed by one all-gather of (rows x n'/nranks) doubles per rank;
+ * every rank ends each pass with the same bits, everything else of the unit is replicated.  complex128 units are not split (every rank
+ * computes them in full).  nranks is 1 or 2.
+ * ctm_set_comm: the all-gathers are ncclAllGather calls on the context's stream (librccl is resolved at run time with dlopen: the library
+ * does not link it) -- CTM_ERR_UNSUPPORTED when it cannot be resolved.  Exercised with a ONE-rank communicator only (no multi-GPU box in
+ * the build loop): with nranks == 1 and a communicator the passes go through the same code (one part, all-gather onto itself).
+ * ctm_set_comm_ops: the same split with HOST-DRIVEN all-gathers -- the test harness of the build loop (two gloo ranks sharing one device,
+ * tests/test_gpu_dist.py) and any transport that is not RCCL: the context writes `count` doubles into send_buf (device, caller-owned,
+ * capacity_doubles each for send_buf and recv_buf / nranks), drains its stream and calls allgather(user, count); on return recv_buf must hold
+ * the nranks contributions back to back (rank-major), visible to the context's stream.  allgather == NULL detaches.
+ * CTM_ERR_BADARG for rank outside [0, nranks) or nranks > 2. */
 int ctm_set_comm(ctm_ctx* ctx, void* rccl_comm /* ncclComm_t or NULL */, int rank, int nranks);
+typedef int (*ctm_allgather_fn)(void* user, long long count);
+int ctm_set_comm_ops(ctm_ctx* ctx, ctm_allgather_fn allgather, void* user, double* send_buf, double* recv_buf, long long capacity_doubles,
+                     int rank, int nranks);
 
 /* ---- primitives (replace tn_interface.py:3-27 contract/mm/permute) ------------------------------ */
 /* C[M,N] = alpha op(A) op(B) + beta C ; row-major; trans = 0 ('N') or 1 ('T', plain transpose); CTM_C128 also 2 ('C', conjugate

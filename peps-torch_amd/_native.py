@@ -34,6 +34,9 @@ class TruncCfg(C.Structure):
                 ("keep_multiplets", C.c_int), ("fix_signs", C.c_int)]
 
 
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_longlong)      # include/ctm_hip.h: ctm_allgather_fn
+
+
 class MoveUnit(C.Structure):
     """include/ctm_hip.h: ctm_move_unit (one site of a whole-move call)."""
     _fields_ = [("proj", C.c_void_p * 16), ("proj_adims", C.c_int * 20), ("basis", C.c_void_p), ("corner_buf", C.c_void_p * 4),
@@ -51,6 +54,7 @@ _SIGS = {
     "ctm_trim": [C.c_void_p],
     "ctm_set_option": [C.c_void_p, C.c_char_p, C.c_double],
     "ctm_set_comm": [C.c_void_p, C.c_void_p, C.c_int, C.c_int],
+    "ctm_set_comm_ops": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_int, C.c_int],
     "ctm_get_stat": [C.c_void_p, C.c_char_p, C.POINTER(C.c_double)],
     "ctm_timers": [C.c_void_p, C.POINTER(C.c_double), C.c_int],
     "ctm_gemm_intervals": [C.c_void_p, C.POINTER(C.c_double), C.c_longlong, C.POINTER(C.c_longlong)],
@@ -274,6 +278,44 @@ class Engine:
             if st != CTM_OK:
                 self.h = h
                 self._ck(st, "set_comm")
+
+    def set_group(self, members, capacity_doubles=0):
+        """Rank group (global ranks of the default torch.distributed group, this rank among them; at most two) that shares the units of this
+        engine's float64 context: every corner pass of the implicit operator computes this rank's column block and the group all-gathers
+        the blocks (include/ctm_hip.h: ctm_set_comm_ops -- the host-driven form: torch.distributed on whatever backend the job runs,
+        gloo in the build loop's tests, RCCL on a node).  capacity_doubles: rows x columns / len(members) of the largest pass.
+        members None or one rank: detach.  Every rank of the group must make the same engine calls while it is attached."""
+        import torch.distributed as dist
+        h = self._handles[torch.float64]
+        if not members or len(members) < 2:
+            st = self.lib.ctm_set_comm_ops(h, None, None, None, None, 0, 0, 1)
+            self._group = None
+            if st != CTM_OK:
+                self.h = h; self._ck(st, "set_comm_ops")
+            return
+        import parallel
+        g = len(members)
+        rank_in = list(members).index(dist.get_rank())
+        grp = parallel._process_group(list(members))
+        cap = int(capacity_doubles)
+        keep = getattr(self, "_group_bufs", None)
+        if keep is None or keep[0].numel() < cap:
+            keep = self._group_bufs = (torch.empty(cap, dtype=torch.float64, device=self.device), torch.empty(g * cap, dtype=torch.float64, device=self.device))
+        send, recv = keep
+
+        def allgather(user, count):
+            try:
+                dist.all_gather_into_tensor(recv[:g * count], send[:count], group=grp)
+                torch.cuda.synchronize(self.device)
+                return 0
+            except Exception as e:                    # (a Python exception must not unwind through the C frames)
+                self._group_error = repr(e)
+                return 1
+        cb = ALLGATHER_FN(allgather)
+        self._group = (cb, grp, tuple(members))        # keeps the callback alive while the library holds it
+        st = self.lib.ctm_set_comm_ops(h, C.cast(cb, C.c_void_p), None, C.c_void_p(send.data_ptr()), C.c_void_p(recv.data_ptr()), send.numel(), rank_in, g)
+        if st != CTM_OK:
+            self.h = h; self._ck(st, "set_comm_ops")
 
     def stat(self, key):
         tot = sum(w.stat(key) for w in self.workers)

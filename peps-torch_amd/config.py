@@ -50,7 +50,7 @@ class CTMARGS(_Args):
         ctm_max_iter=50, ctm_warmup_iter=-1, ctm_env_init_type='CTMRG', ctm_conv_tol=1.0e-8,
         ctm_absorb_normalization='inf', dtype_rdm='DEFAULT', conv_check_cpu=False,
         projector_method='4X4', projector_svd_method='DEFAULT', warmup_projector_svd_method='DEFAULT',
-        projector_full_matrices=True, projector_warm_start=True, projector_warm_tol=0.0, native_move=True, concurrent_units=True, unit_stagger_ms=float(os.environ.get('CTM_STAGGER_MS', 0.0)), corner_cache=True, absorb_skip_zero_columns=True, absorb_skip_min_n=8192, projector_svd_reltol=1.0e-8, projector_svd_reltol_block=0.0,
+        projector_full_matrices=True, projector_warm_start=True, projector_warm_tol=0.0, native_move=True, share_units=True, concurrent_units=True, unit_stagger_ms=float(os.environ.get('CTM_STAGGER_MS', 0.0)), corner_cache=True, absorb_skip_zero_columns=True, absorb_skip_min_n=8192, projector_svd_reltol=1.0e-8, projector_svd_reltol_block=0.0,
         projector_eps_multiplet=1.0e-8, projector_multiplet_abstol=1.0e-14, ad_decomp_reg=1.0e-12,
         ctm_move_sequence=[(0, -1), (-1, 0), (0, 1), (1, 0)], randomize_ctm_move_sequence=False,
         ctm_force_dl=False, ctm_logging=False,

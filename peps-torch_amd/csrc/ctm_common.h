@@ -199,6 +199,12 @@ struct ctm_ctx {
     double k_ms[5] = {0, 0, 0, 0, 0}, k_flops[5] = {0, 0, 0, 0, 0};
     long k_calls[5] = {0, 0, 0, 0, 0};
     void* comm = nullptr; int comm_rank = 0, comm_nranks = 1;   // rank group sharing one unit (ctm_set_comm; column split: include/ctm_hip.h)
+    // all-gather of the group: RCCL on this context's stream (comm_nccl_allgather = ncclAllGather resolved with dlopen) or a host callback
+    void* comm_nccl_allgather = nullptr;
+    int (*comm_host_allgather)(void*, long long) = nullptr; void* comm_user = nullptr;
+    double* comm_send = nullptr; double* comm_recv = nullptr; long long comm_cap = 0;      // host-callback staging buffers (caller-owned)
+    double* comm_own_buf = nullptr; long long comm_own_cap = 0;                            // RCCL staging buffers (library-owned: send | recv)
+    long comm_calls = 0; double comm_doubles = 0.0;
     bool cplx = false;                   // CTM_C128 context: every tensor pointer of the C-ABI is interleaved complex128
     alignas(8) unsigned char orth_cur_storage[64] = {0};      // adaptive state of the symmetric orthogonal iteration for the workspace of the CURRENT call (eigh.hip: OrthState)
     // stationary fast path of the implicit-operator truncation (svd_leading.hip: svd_stationary).  0 = off: every truncation is solved to resid_tol

@@ -3,6 +3,7 @@
 #include <execinfo.h>
 #include <signal.h>
 #include <unistd.h>
+#include <dlfcn.h>
 #include <mutex>
 #include <atomic>
 
@@ -160,6 +161,7 @@ int ctm_destroy(ctm_ctx* ctx) {
     for (auto& e : ctx->ev_pool) (void)hipEventDestroy(e);
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
     if (ctx->tile_cnt) (void)hipFree(ctx->tile_cnt);
+    if (ctx->comm_own_buf) (void)hipFree(ctx->comm_own_buf);
     if (ctx->h_scratch) (void)hipHostFree(ctx->h_scratch);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -191,12 +193,37 @@ int ctm_sync(ctm_ctx* ctx) {
 int ctm_set_comm(ctm_ctx* ctx, void* rccl_comm, int rank, int nranks) {
     return ctm_entry_nolock(ctx, "ctm_set_comm", [&]() -> int {
     if (!ctx) return CTM_ERR_BADARG;
-    if (nranks < 1 || rank < 0 || rank >= nranks) { ctx->set_error("set_comm: rank outside [0, nranks)"); return CTM_ERR_BADARG; }
-    if (nranks > 1) {
-        ctx->set_error("set_comm: the column split of a unit over a rank group (include/ctm_hip.h) is not built: nranks must be 1");
-        return CTM_ERR_UNSUPPORTED;
-    }
-    ctx->comm = rccl_comm; ctx->comm_rank = rank; ctx->comm_nranks = nranks;      // a one-rank group: every collective is the identity
+    if (nranks < 1 || nranks > 2 || rank < 0 || rank >= nranks) { ctx->set_error("set_comm: nranks must be 1 or 2 and rank inside [0, nranks)"); return CTM_ERR_BADARG; }
+    ctx->comm_host_allgather = nullptr; ctx->comm_user = nullptr; ctx->comm_send = nullptr; ctx->comm_recv = nullptr; ctx->comm_cap = 0;
+    ctx->comm_nccl_allgather = nullptr;
+    if (rccl_comm) {
+        // the library does not link librccl: resolve ncclAllGather in the process (torch's bundled librccl when torch.distributed uses the
+        // "nccl" backend, or a system librccl)
+        void* h = nullptr;
+        for (const char* name : {"librccl.so", "librccl.so.1"}) {
+            h = dlopen(name, RTLD_NOW | RTLD_NOLOAD);
+            if (!h) h = dlopen(name, RTLD_NOW);
+            if (h) break;
+        }
+        void* fn = h ? dlsym(h, "ncclAllGather") : dlsym(RTLD_DEFAULT, "ncclAllGather");
+        if (!fn) { ctx->set_error("set_comm: ncclAllGather could not be resolved (librccl.so not loadable in this process)"); return CTM_ERR_UNSUPPORTED; }
+        ctx->comm_nccl_allgather = fn;
+    } else if (nranks > 1) { ctx->set_error("set_comm: a group of more than one rank needs a communicator (or ctm_set_comm_ops)"); return CTM_ERR_BADARG; }
+    ctx->comm = rccl_comm; ctx->comm_rank = rank; ctx->comm_nranks = nranks;
+    return CTM_OK;
+    });
+}
+
+int ctm_set_comm_ops(ctm_ctx* ctx, ctm_allgather_fn allgather, void* user, double* send_buf, double* recv_buf, long long capacity_doubles,
+                     int rank, int nranks) {
+    return ctm_entry_nolock(ctx, "ctm_set_comm_ops", [&]() -> int {
+    if (!ctx) return CTM_ERR_BADARG;
+    if (nranks < 1 || nranks > 2 || rank < 0 || rank >= nranks) { ctx->set_error("set_comm_ops: nranks must be 1 or 2 and rank inside [0, nranks)"); return CTM_ERR_BADARG; }
+    if (allgather && (!send_buf || !recv_buf || capacity_doubles < 1)) { ctx->set_error("set_comm_ops: staging buffers missing"); return CTM_ERR_BADARG; }
+    ctx->comm = nullptr; ctx->comm_nccl_allgather = nullptr;
+    ctx->comm_host_allgather = allgather; ctx->comm_user = user;
+    ctx->comm_send = allgather ? send_buf : nullptr; ctx->comm_recv = allgather ? recv_buf : nullptr; ctx->comm_cap = allgather ? capacity_doubles : 0;
+    ctx->comm_rank = allgather ? rank : 0; ctx->comm_nranks = allgather ? nranks : 1;
     return CTM_OK;
     });
 }
@@ -294,6 +321,8 @@ int ctm_get_stat(ctm_ctx* ctx, const char* key, double* value) {
     else if (k == "lz_total_rows") *value = (double)ctx->lz_total_rows;
     else if (k == "lz_extractions") *value = (double)ctx->lz_extractions;
     else if (k == "ritz_warm_starts") *value = (double)ctx->ritz_warm_starts;
+    else if (k == "comm_calls") *value = (double)ctx->comm_calls;
+    else if (k == "comm_doubles") *value = ctx->comm_doubles;
     else if (k == "ritz_sweeps") *value = (double)ctx->ritz_sweeps;
     else if (k == "lz_last_est") *value = ctx->lz_last_est;
     else if (k == "lz_async_fallbacks") *value = (double)ctx->lz_async_fallbacks;

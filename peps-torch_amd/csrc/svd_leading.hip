@@ -13,6 +13,51 @@ int rows_times(ctm_ctx* ctx, const double* X, long long ldx, int p, int kin, int
     return gemm_f64(ctx, g);
 }
 
+// A corner pass shared by a rank group (ctm_set_comm / ctm_set_comm_ops, include/ctm_hip.h): this rank computes the column block
+// [r nout / g, (r + 1) nout / g) of Y = X op(Z) -- the same kernels on a sub-block of the big operand: column block of Z, or row block for
+// the transposed orientation -- into a contiguous staging buffer, the group all-gathers the blocks (ncclAllGather on this stream, or the
+// host callback after draining it) and every rank unpacks the same bits into Y.  g == 1 with a communicator: one part, gathered onto itself
+// (the only form the RCCL path can take on a one-GPU box).
+typedef int (*nccl_allgather_t)(const void*, void*, size_t, int, void*, hipStream_t);
+// (a pass whose block does not fit the staging buffers -- the dense fallback materialises M with n rows -- is computed in full by every
+//  rank of the group: the same decision on every rank, the same bits)
+static bool pass_is_shared(const ctm_ctx* ctx, int nout, int p) {
+    if (!(ctx->comm_nccl_allgather || ctx->comm_host_allgather) || ctx->cplx || nout % (2 * ctx->comm_nranks) != 0) return false;
+    const long long cnt = (long long)p * (nout / ctx->comm_nranks);
+    return ctx->comm_host_allgather ? cnt <= ctx->comm_cap : p <= 1024;
+}
+int rows_times_shared(ctm_ctx* ctx, const double* X, long long ldx, int p, int kin, int nout, const double* Z, bool transZ, double* Y, long long ldy) {
+    const int g = ctx->comm_nranks, r = ctx->comm_rank, nb = nout / g;
+    const long long cnt = (long long)p * nb;
+    double *send, *recv;
+    if (ctx->comm_host_allgather) {
+        if (cnt > ctx->comm_cap) { ctx->set_error("shared corner pass: staging buffers of ctm_set_comm_ops too small"); return CTM_ERR_BADARG; }
+        send = ctx->comm_send; recv = ctx->comm_recv;
+    } else {
+        if (ctx->comm_own_cap < cnt * (1 + g)) {
+            if (ctx->comm_own_buf) { CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->comm_own_buf); ctx->comm_own_buf = nullptr; ctx->comm_own_cap = 0; }
+            CTM_HIP_CHECK(ctx, hipMalloc((void**)&ctx->comm_own_buf, sizeof(double) * (size_t)cnt * (1 + g)));
+            ctx->comm_own_cap = cnt * (1 + g);
+        }
+        send = ctx->comm_own_buf; recv = ctx->comm_own_buf + cnt;
+    }
+    GemmDesc gd; gd.M = p; gd.N = nb; gd.K = kin; gd.A = X; gd.sam = ldx; gd.sak = 1;
+    if (transZ) { gd.B = Z + (size_t)r * nb * kin; gd.sbk = 1; gd.sbn = kin; }       // rows [r nb, (r+1) nb) of Z (nout x kin) = columns of Z^T
+    else { gd.B = Z + (size_t)r * nb; gd.sbk = nout; gd.sbn = 1; }                   // columns [r nb, (r+1) nb) of Z (kin x nout)
+    gd.C = send; gd.ldc = nb;
+    CTM_TRY(gemm_f64(ctx, gd));
+    if (ctx->comm_host_allgather) {
+        CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->comm_host_allgather(ctx->comm_user, cnt) != 0) { ctx->set_error("shared corner pass: the all-gather callback failed"); return CTM_ERR_HIP; }
+    } else {
+        const int st = reinterpret_cast<nccl_allgather_t>(ctx->comm_nccl_allgather)(send, recv, (size_t)cnt, 8 /* ncclFloat64 */, ctx->comm, ctx->stream);
+        if (st != 0) { ctx->set_error("shared corner pass: ncclAllGather returned " + std::to_string(st)); return CTM_ERR_HIP; }
+    }
+    for (int q = 0; q < g; ++q) CTM_TRY(copy2d(ctx, recv + (size_t)q * cnt, nb, Y + (size_t)q * nb, ldy, p, nb));
+    ctx->comm_calls += 1; ctx->comm_doubles += (double)cnt * g;
+    return CTM_OK;
+}
+
 // C = B * M (transpose == false) or B * M^T (transpose == true) for the operator M of `op`
 // mid (optional, p x n, leading dimension n; implicit operators only): receives the half-way product B R^T (transpose == false)
 // or B Rt^T (transpose == true)
@@ -26,17 +71,22 @@ int matop_apply(ctm_ctx* ctx, const MatOp& op, bool transpose, const double* B, 
     double *t1, *t2 = mid;
     CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)p * mw, (void**)&t1));
     if (!t2) CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)p * mw, (void**)&t2));
+    // (a rank group that shares this unit splits every pass by output columns: rows_times_shared)
+    auto pass = [&](const double* X, long long ldx, int kin, int nout, const double* Z, bool tZ, double* Yo, long long ldy) -> int {
+        if (pass_is_shared(ctx, nout, p)) return rows_times_shared(ctx, X, ldx, p, kin, nout, Z, tZ, Yo, ldy);
+        return rows_times(ctx, X, ldx, p, kin, nout, Z, tZ, Yo, ldy);
+    };
     if (!transpose) {   // B R^T Rt = ((B opB(cB)^T) opA(cA)^T) opC(cC) opD(cD)
-        CTM_TRY(rows_times(ctx, B, ldb, p, n, m0, op.c[1], !op.t[1], t1, m0));
-        CTM_TRY(rows_times(ctx, t1, m0, p, m0, n, op.c[0], !op.t[0], t2, n));
-        CTM_TRY(rows_times(ctx, t2, n, p, n, m1, op.c[2], op.t[2], t1, m1));
-        return rows_times(ctx, t1, m1, p, m1, n, op.c[3], op.t[3], C, ldc);
+        CTM_TRY(pass(B, ldb, n, m0, op.c[1], !op.t[1], t1, m0));
+        CTM_TRY(pass(t1, m0, m0, n, op.c[0], !op.t[0], t2, n));
+        CTM_TRY(pass(t2, n, n, m1, op.c[2], op.t[2], t1, m1));
+        return pass(t1, m1, m1, n, op.c[3], op.t[3], C, ldc);
     }
     // B Rt^T R = ((B opD(cD)^T) opC(cC)^T) opA(cA) opB(cB)
-    CTM_TRY(rows_times(ctx, B, ldb, p, n, m1, op.c[3], !op.t[3], t1, m1));
-    CTM_TRY(rows_times(ctx, t1, m1, p, m1, n, op.c[2], !op.t[2], t2, n));
-    CTM_TRY(rows_times(ctx, t2, n, p, n, m0, op.c[0], op.t[0], t1, m0));
-    return rows_times(ctx, t1, m0, p, m0, n, op.c[1], op.t[1], C, ldc);
+    CTM_TRY(pass(B, ldb, n, m1, op.c[3], !op.t[3], t1, m1));
+    CTM_TRY(pass(t1, m1, m1, n, op.c[2], !op.t[2], t2, n));
+    CTM_TRY(pass(t2, n, n, m0, op.c[0], op.t[0], t1, m0));
+    return pass(t1, m0, m0, n, op.c[1], op.t[1], C, ldc);
 }
 
 // Calls of a unit that start cold after its full-block warm probe (two half steps on k + k/2 rows) was handed to the Krylov solver

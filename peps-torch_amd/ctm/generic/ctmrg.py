@@ -163,7 +163,12 @@ def ctm_MOVE(direction, state, env, ctm_args=cfg.ctm_args, global_args=cfg.globa
 
 
 def _ctm_MOVE_units(direction, state, env, ctm_args, global_args, diagnostics, get_projectors, norm_kind, eng, coords):
-    mine = parallel.my_units(coords)
+    # twice as many ranks as sites (8 GPUs, 4-site cell): the two ranks {i, i + Nsites} SHARE unit i -- every corner pass of its truncation is
+    # split by output columns inside the native solver and all-gathered in the pair (Engine.set_group; float64, 4X4 projectors); everything
+    # else of the unit is replicated in the pair, and the exchanges between units go on as between single ranks (owner = the lower rank)
+    shared = parallel.unit_group_size(len(coords)) == 2 and getattr(ctm_args, "share_units", True) and ctm_args.projector_method == '4X4' \
+        and not next(iter(env.C.values())).dtype.is_complex and hasattr(eng, "set_group")
+    mine = parallel.my_units(coords, shared=shared)
     chi = env.chi
     # number of non-zero projector columns per site of THIS move (filled by the fused projector path)
     # (worth its host-side bookkeeping where an absorb takes milliseconds: n >= absorb_skip_min_n)
@@ -259,12 +264,21 @@ def _ctm_MOVE_units(direction, state, env, ctm_args, global_args, diagnostics, g
     ownersA, mineA = None, mine
     if parallel.is_distributed():
         ownersA = parallel.owners_shifted(coords, state.vertexToSite, _OWNER_SHIFT[direction])
-        mineA = [c for c, o in zip(coords, ownersA) if o == parallel.world()[0]]
+        mineA = [c for c, o in zip(coords, ownersA) if o == (parallel.world()[0] % len(coords) if shared else parallel.world()[0])]
     P, Pt = {}, {}
     stagger = float(getattr(ctm_args, "unit_stagger_ms", 0.0)) * 1e-3 if max(_proj_rows(direction, c, state, chi) for c in coords) >= 8192 else 0.0
-    for coord, (p_, pt_) in zip(mineA, _each(lambda c: get_projectors(direction, c, state, env, ctm_args, global_args,
-                                                                              diagnostics=diagnostics), mineA, stagger)):
-        P[coord], Pt[coord] = p_, pt_
+    if shared:
+        # (one unit per rank: issued serially on this engine; the group is attached only while its ranks make the same calls)
+        nmax = max(_proj_rows(direction, c, state, chi) for c in coords)
+        parallel.prepare_groups([parallel.unit_group(i, len(coords)) for i in range(len(coords))])      # (collective, cached: every rank names every group)
+        eng.set_group(parallel.unit_group(parallel.world()[0] % len(coords), len(coords)), capacity_doubles=(2 * chi + 128) * ((nmax + 1) // 2))
+    try:
+        for coord, (p_, pt_) in zip(mineA, _each(lambda c: get_projectors(direction, c, state, env, ctm_args, global_args,
+                                                                                  diagnostics=diagnostics), mineA, stagger)):
+            P[coord], Pt[coord] = p_, pt_
+    finally:
+        if shared:
+            eng.set_group(None)
     if hasattr(eng, "stat"):
         env.__dict__["_krylov_units"] = eng.stat("lz_hits") > lz_before
     if parallel.is_distributed():

@@ -38,9 +38,24 @@ def owner_of(index, nranks):
     return index % nranks
 
 
-def my_units(items):
-    """Subset of `items` (ordered) owned by this rank."""
+def unit_group_size(nitems):
+    """Ranks per unit when there are MORE ranks than units and they divide evenly (8 GPUs, 4-site cell: SURVEY 8e "pair (2r, 2r+1) splits unit
+    r" -- here the pair of unit i is {i, i + nitems}, the same grouping as site_groups): those ranks SHARE the unit (Engine.set_group: every
+    corner pass split by output columns inside the native solver).  1 otherwise.  Groups of two only (include/ctm_hip.h)."""
+    _, n = world()
+    return 2 if (is_distributed() and nitems > 0 and n == 2 * nitems) else 1
+
+
+def unit_group(index, nitems):
+    _, n = world()
+    return [r for r in range(n) if r % nitems == index]
+
+
+def my_units(items, shared=False):
+    """Subset of `items` (ordered) owned by this rank; shared (unit_group_size(len(items)) == 2): the unit this rank's group works on."""
     rank, n = world()
+    if shared:
+        return [x for i, x in enumerate(items) if rank % len(items) == i]
     return [x for i, x in enumerate(items) if owner_of(i, n) == rank]
 
 

@@ -68,5 +68,37 @@ def test_rccl_backend_executes_every_collective_on_one_rank():
     assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
     out = json.loads([l for l in r.stdout.strip().splitlines() if l.startswith("{")][-1])
     assert out["backend"] == "nccl" and len(out["checks"]) == 2
-    assert "not built" in out["set_comm_two_ranks"]
+    assert "needs a communicator" in out["set_comm_two_ranks"]
+    assert out["rccl_shared_passes_one_rank"] > 0           # ncclAllGather on the library's stream inside the truncation of a unit, same bits
     assert out["comm_s_torch.float64"] > 0.0 and out["comm_s_torch.complex128"] > 0.0
+
+
+def test_a_unit_shared_by_a_pair_of_ranks_equals_the_unsplit_solve(tmp_path):
+    """Twice as many ranks as sites (8 GPUs on a 4-site cell; here 2 gloo ranks on this GPU, one-site cell): the pair shares the
+    unit -- every corner pass of its truncation computes this rank's half of the output columns inside the native solver and the halves are
+    all-gathered (ctm_set_comm_ops, host-driven; csrc/svd_leading.hip: rows_times_shared).  Three sweeps of a signed D = 4 chi = 48 state
+    (n = 768: block Krylov solves): both ranks end with the SAME bits, equal to the one-process run to rounding (the half-width products
+    slice K differently), and the passes really were shared."""
+    import socket
+    import numpy as np
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, CTM_BENCH_ONE_DEVICE="1", CTM_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    tool = os.path.join(REPO, "tools", "check_pair_split.py")
+    one = os.path.join(str(tmp_path), "one"); two = os.path.join(str(tmp_path), "two")
+    r = subprocess.run([sys.executable, tool, one], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), tool, two], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    a = json.load(open(one + ".rank0.json"))
+    b0, b1 = json.load(open(two + ".rank0.json")), json.load(open(two + ".rank1.json"))
+    assert a["shared_passes"] == 0 and b0["shared_passes"] > 100 and b0["shared_passes"] == b1["shared_passes"]
+    assert b0["krylov_solves"] > 0
+    for k in a:
+        if k in ("shared_passes", "krylov_solves", "power_iteration_solves"):
+            continue
+        assert b0[k] == b1[k], k                                         # the pair: bit for bit
+        if k == "checksum":
+            assert abs(a[k] - b0[k]) < 1e-9 * abs(a[k])
+        else:
+            assert np.abs(np.array(a[k]) - np.array(b0[k])).max() < 1e-11, k

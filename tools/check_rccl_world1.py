@@ -85,14 +85,58 @@ for dtype in (torch.float64, torch.complex128):
     for k in renv.T:
         assert torch.equal(env.T[k], renv.T[k]), k
     out[f"energy_{dtype}"] = [e.real, e.imag]
-# the communicator handle at the C-ABI: a one-rank group attaches, a larger one is refused loudly
+# the communicator handle at the C-ABI: a one-rank group attaches, a larger one without a communicator is refused loudly
 eng = _native.engine()
 eng.set_comm(None, 0, 1)
 try:
     eng.set_comm(None, 0, 2)
-    raise SystemExit("ctm_set_comm accepted a two-rank group")
+    raise SystemExit("ctm_set_comm accepted a two-rank group without a communicator")
 except _native.NativeError as ex:
     out["set_comm_two_ranks"] = str(ex)
+# ... and the RCCL path of the shared corner pass (include/ctm_hip.h: ctm_set_comm; rows_times_shared in csrc/svd_leading.hip) with a raw
+# ONE-rank ncclComm_t made through librccl's own API: every corner pass of a unit's truncation then computes its one "column block" (the
+# whole product) into the staging buffer, ncclAllGather on the context's stream gathers it onto itself and the unpack kernel writes it back
+# -- the exact code a pair executes, with one part.  Same bits as the unit without a communicator.
+import ctypes, glob
+cands = glob.glob(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so*")) + ["librccl.so", "librccl.so.1"]
+rccl = None
+for c in cands:
+    try:
+        rccl = ctypes.CDLL(c); break
+    except OSError:
+        pass
+assert rccl is not None, "librccl not loadable"
+
+
+class UniqueId(ctypes.Structure):
+    _fields_ = [("internal", ctypes.c_char * 128)]
+uid = UniqueId()
+assert rccl.ncclGetUniqueId(ctypes.byref(uid)) == 0
+comm = ctypes.c_void_p()
+rccl.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, UniqueId, ctypes.c_int]
+assert rccl.ncclCommInitRank(ctypes.byref(comm), 1, uid, 0) == 0
+from ctm.generic.ctm_components import _halves_t
+rng = np.random.default_rng(23)
+D, chi = 4, 48
+sites = {(x, y): torch.from_numpy((lambda a: a / np.abs(a).max())(rng.random((2, D, D, D, D)) - 0.5)).cuda() for y in range(2) for x in range(2)}
+st = IPEPS(sites); env = ENV(chi, st); init_env(st, env)
+parallel.single_rank_is_distributed = False
+for _ in range(2):
+    for d in cfg.ctm_args.ctm_move_sequence:
+        for _r in range(2):
+            ctmrg.ctm_MOVE(d, st, env)
+t16 = _halves_t((0, -1), (0, 0), st, env)
+P0, Pt0, S0 = eng.projectors_4x4((0, -1), t16, chi, return_S=True)
+c0 = eng.stat("comm_calls")
+eng.set_comm(comm.value, 0, 1)
+P1, Pt1, S1 = eng.projectors_4x4((0, -1), t16, chi, return_S=True)
+eng.sync()
+eng.set_comm(None, 0, 1)
+out["rccl_shared_passes_one_rank"] = int(eng.stat("comm_calls") - c0)
+assert out["rccl_shared_passes_one_rank"] > 0
+assert torch.equal(S0, S1) and torch.equal(P0, P1) and torch.equal(Pt0, Pt1), "one-rank RCCL passes changed the bits"
+rccl.ncclCommDestroy.argtypes = [ctypes.c_void_p]
+rccl.ncclCommDestroy(comm)
 dist.barrier()
 dist.destroy_process_group()
 import ctypes
