@@ -19,7 +19,21 @@ def _worker(rank, world, port, out_dir, name):
     cfg.global_args.device = 'cpu'
     import backend
     from fake_engine import FakeEngine
-    backend.set_engine(FakeEngine())
+    attached = []
+    if os.environ.get("CTM_TEST_SHARED_UNITS"):
+        # the orchestration of a unit shared by a rank pair (twice as many ranks as sites; DESIGN.md section 6 "Round 6") with an engine double
+        # whose set_group() only proves that both members attach the same process group at the same point (the split passes themselves
+        # are native: tests/test_gpu_dist.py)
+        class SharingEngine(FakeEngine):
+            def set_group(self, members, capacity_doubles=0):
+                if members:
+                    import parallel as par
+                    got = [torch.zeros(1, dtype=torch.int64) for _ in members]
+                    dist.all_gather(got, torch.tensor([rank], dtype=torch.int64), group=par._process_group(list(members)))
+                    attached.append(sorted(int(x) for x in got))
+        backend.set_engine(SharingEngine())
+    else:
+        backend.set_engine(FakeEngine())
     from conftest import golden
     from helpers_cpu import sites_from
     from ipeps.ipeps import IPEPS
@@ -36,6 +50,10 @@ def _worker(rank, world, port, out_dir, name):
         for d in cfg.ctm_args.ctm_move_sequence:
             for _r in range(2):
                 ctmrg.ctm_MOVE(d, st, env)
+    if os.environ.get("CTM_TEST_SHARED_UNITS"):
+        shared_ok = world == 8 and not next(iter(st.sites.values())).is_complex()
+        assert len(attached) == (16 if shared_ok else 0), (rank, len(attached))          # every move of a float64 run with 2 x Nsites ranks
+        assert all(a == [rank % 4, rank % 4 + 4] for a in attached), attached
     e = float(j1j2.J1J2(j1=1.0, j2=0.5).energy_per_site(st, env))
     key = lambda k: f"{k[0][0]}_{k[0][1]}_{k[1][0]}_{k[1][1]}"
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), energy=e, **{"C" + key(k): t.numpy() for k, t in env.C.items()},
@@ -134,3 +152,15 @@ def test_sharded_differentiable_move_gives_the_reference_gradient(tmp_path, name
         for k in out.files:
             if k.startswith("grad_"):
                 assert float(np.abs(out[k] - g[k]).max()) < 1e-9 * max(1.0, float(np.abs(g[k]).max())), (r, k)
+
+
+@pytest.mark.parametrize("name,world", [("generic_D2_chi8_f64", 8), ("generic_D2_chi8_c128", 8), ("generic_D2_chi8_f64", 5)])
+def test_units_shared_by_rank_pairs_equal_single_process(tmp_path, name, world):
+    """Twice as many ranks as sites: the ranks {i, i + 4} both work on unit i (ctmrg._ctm_MOVE_units: `shared`; owner of the exchanges = the
+    lower rank), attach their pair to the engine for the projector phase of every move -- float64 only; complex128 and rank counts other
+    than 2 x Nsites keep the one-owner sharding -- and every rank ends with the single-process environment."""
+    os.environ["CTM_TEST_SHARED_UNITS"] = "1"
+    try:
+        test_sharded_move_equals_single_process(tmp_path, name, world)
+    finally:
+        os.environ.pop("CTM_TEST_SHARED_UNITS", None)
