@@ -37,6 +37,10 @@ class TruncCfg(C.Structure):
 ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_longlong)      # include/ctm_hip.h: ctm_allgather_fn
 
 
+class _NcclUniqueId(C.Structure):
+    _fields_ = [("internal", C.c_char * 128)]
+
+
 class MoveUnit(C.Structure):
     """include/ctm_hip.h: ctm_move_unit (one site of a whole-move call)."""
     _fields_ = [("proj", C.c_void_p * 16), ("proj_adims", C.c_int * 20), ("basis", C.c_void_p), ("corner_buf", C.c_void_p * 4),
@@ -279,6 +283,56 @@ class Engine:
                 self.h = h
                 self._ck(st, "set_comm")
 
+    # ---- a raw RCCL communicator for a rank group (the transport ctm_set_comm takes: ncclAllGather on the library's own stream) ----------
+    _rccl = None
+
+    @classmethod
+    def _librccl(cls):
+        if cls._rccl is None:
+            import glob
+            cands = glob.glob(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so*")) + ["librccl.so", "librccl.so.1"]
+            for c in cands:
+                try:
+                    cls._rccl = C.CDLL(c)
+                    break
+                except OSError:
+                    pass
+            if cls._rccl is None:
+                raise NativeError("librccl.so is not loadable in this process")
+            cls._rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, _NcclUniqueId, C.c_int]
+            cls._rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+        return cls._rccl
+
+    def attach_rccl_group(self, members):
+        """ncclCommInitRank over `members` (global ranks of the default torch.distributed group; the unique id travels from the first member
+        through torch.distributed) and ctm_set_comm: the corner passes of this engine's float64 units are then split over the group and
+        all-gathered with ncclAllGather on the engine's stream.  One communicator per group, kept for the life of the engine.
+        Executed in the build loop with ONE member only (tools/check_rccl_world1.py); opt-in for pairs: CTM_GROUP_TRANSPORT=rccl."""
+        import torch.distributed as dist
+        import parallel
+        key = tuple(members)
+        cache = self.__dict__.setdefault("_rccl_comms", {})
+        rank_in = list(members).index(dist.get_rank())
+        if key not in cache:
+            lib = self._librccl()
+            uid = _NcclUniqueId()
+            if rank_in == 0 and lib.ncclGetUniqueId(C.byref(uid)) != 0:
+                raise NativeError("ncclGetUniqueId failed")
+            box = [bytes(uid.internal) if rank_in == 0 else None]
+            if dist.is_initialized():
+                grp = parallel._process_group(list(members)) if len(members) < dist.get_world_size() else None
+                dist.broadcast_object_list(box, src=members[0], group=grp)
+            C.memmove(C.byref(uid), box[0], 128)
+            comm = C.c_void_p()
+            with torch.cuda.device(self.device):
+                if lib.ncclCommInitRank(C.byref(comm), len(members), uid, rank_in) != 0:
+                    raise NativeError("ncclCommInitRank failed")
+            cache[key] = comm
+        self.set_comm(cache[key].value, rank_in, len(members))
+
+    def detach_group(self):
+        self.set_comm(None, 0, 1)
+
     def set_group(self, members, capacity_doubles=0):
         """Rank group (global ranks of the default torch.distributed group, this rank among them; at most two) that shares the units of this
         engine's float64 context: every corner pass of the implicit operator computes this rank's column block and the group all-gathers
@@ -287,6 +341,10 @@ class Engine:
         members None or one rank: detach.  Every rank of the group must make the same engine calls while it is attached."""
         import torch.distributed as dist
         h = self._handles[torch.float64]
+        if os.environ.get("CTM_GROUP_TRANSPORT") == "rccl":           # (opt-in: never executed with two ranks -- DESIGN.md section 6)
+            if members and len(members) >= 2:
+                return self.attach_rccl_group(list(members))
+            return self.detach_group()
         if not members or len(members) < 2:
             st = self.lib.ctm_set_comm_ops(h, None, None, None, None, 0, 0, 1)
             self._group = None

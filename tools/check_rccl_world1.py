@@ -94,27 +94,9 @@ try:
 except _native.NativeError as ex:
     out["set_comm_two_ranks"] = str(ex)
 # ... and the RCCL path of the shared corner pass (include/ctm_hip.h: ctm_set_comm; rows_times_shared in csrc/svd_leading.hip) with a raw
-# ONE-rank ncclComm_t made through librccl's own API: every corner pass of a unit's truncation then computes its one "column block" (the
+# ONE-rank ncclComm_t made through librccl's own API (_native.Engine.attach_rccl_group -- what CTM_GROUP_TRANSPORT=rccl uses for a pair): every corner pass of a unit's truncation then computes its one "column block" (the
 # whole product) into the staging buffer, ncclAllGather on the context's stream gathers it onto itself and the unpack kernel writes it back
 # -- the exact code a pair executes, with one part.  Same bits as the unit without a communicator.
-import ctypes, glob
-cands = glob.glob(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so*")) + ["librccl.so", "librccl.so.1"]
-rccl = None
-for c in cands:
-    try:
-        rccl = ctypes.CDLL(c); break
-    except OSError:
-        pass
-assert rccl is not None, "librccl not loadable"
-
-
-class UniqueId(ctypes.Structure):
-    _fields_ = [("internal", ctypes.c_char * 128)]
-uid = UniqueId()
-assert rccl.ncclGetUniqueId(ctypes.byref(uid)) == 0
-comm = ctypes.c_void_p()
-rccl.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, UniqueId, ctypes.c_int]
-assert rccl.ncclCommInitRank(ctypes.byref(comm), 1, uid, 0) == 0
 from ctm.generic.ctm_components import _halves_t
 rng = np.random.default_rng(23)
 D, chi = 4, 48
@@ -128,15 +110,14 @@ for _ in range(2):
 t16 = _halves_t((0, -1), (0, 0), st, env)
 P0, Pt0, S0 = eng.projectors_4x4((0, -1), t16, chi, return_S=True)
 c0 = eng.stat("comm_calls")
-eng.set_comm(comm.value, 0, 1)
+eng.attach_rccl_group([0])           # ncclGetUniqueId, its trip through torch.distributed, ncclCommInitRank, ctm_set_comm
 P1, Pt1, S1 = eng.projectors_4x4((0, -1), t16, chi, return_S=True)
 eng.sync()
-eng.set_comm(None, 0, 1)
+eng.detach_group()
 out["rccl_shared_passes_one_rank"] = int(eng.stat("comm_calls") - c0)
 assert out["rccl_shared_passes_one_rank"] > 0
 assert torch.equal(S0, S1) and torch.equal(P0, P1) and torch.equal(Pt0, Pt1), "one-rank RCCL passes changed the bits"
-rccl.ncclCommDestroy.argtypes = [ctypes.c_void_p]
-rccl.ncclCommDestroy(comm)
+_native.Engine._librccl().ncclCommDestroy(eng._rccl_comms.pop((0,)))
 dist.barrier()
 dist.destroy_process_group()
 import ctypes
