@@ -318,7 +318,7 @@ class Engine:
             uid = _NcclUniqueId()
             if rank_in == 0 and lib.ncclGetUniqueId(C.byref(uid)) != 0:
                 raise NativeError("ncclGetUniqueId failed")
-            box = [bytes(uid.internal) if rank_in == 0 else None]
+            box = [C.string_at(C.byref(uid), 128) if rank_in == 0 else None]      # (all 128 bytes: a c_char array field reads as a C string)
             if dist.is_initialized():
                 grp = parallel._process_group(list(members)) if len(members) < dist.get_world_size() else None
                 dist.broadcast_object_list(box, src=members[0], group=grp)
