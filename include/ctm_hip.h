@@ -183,6 +183,12 @@ int ctm_halves(ctm_ctx* ctx, int dir, const double* const* tensors16, int chi, c
 /* ctm_get_projectors_from_matrices (ctm_projectors.py:142-293): P, Pt n x chi, S chi (may be NULL) */
 int ctm_projectors(ctm_ctx* ctx, const double* R, const double* Rt, int n, int chi, const ctm_trunc_cfg* cfg, double* P,
                    double* Pt, double* S);
+/* The same for RECTANGULAR halves R, Rt (a x b, row-major): bond dimensions that differ along one cut -- the reference only asserts
+ * R.shape == Rt.shape (ctm_projectors.py:209).  a = the truncated bond (rows of P, Pt), b = the far side: M = R^T Rt is b x b, P and Pt
+ * are a x min(chi, b), S holds min(chi, b) values.  The fused entries below take square halves (a == b) only and return
+ * CTM_ERR_UNSUPPORTED otherwise; the host layer then builds the halves (ctm_halves: any shapes) and calls this. */
+int ctm_projectors_rect(ctm_ctx* ctx, const double* R, const double* Rt, int a, int b, int chi, const ctm_trunc_cfg* cfg, double* P,
+                        double* Pt, double* S);
 /* ctm_get_projectors_4x4 (ctm_projectors.py:14-64) as ONE call: the four enlarged corners of the move are built and
  * M = R^T Rt is applied implicitly (R, Rt, M are only materialised if the leading-chi iteration falls back to the full
  * decomposition).  tensors16 / adims4x5 as for ctm_halves. */

@@ -318,6 +318,48 @@ def chi_ramp_case(name, D, chi0, chi1, complex_, seed, n0, n1):
     np.savez_compressed(os.path.join(GOLD, name + ".npz"), **out)
 
 
+def rect_cut_case(name, chi, nsweeps, complex_=False, seed=3):
+    """Bond dimensions that differ along one cut: horizontal bonds of dimension 2 in the upper row and 3 in the lower row of a 2x2 cell make
+    the halves of an UP / DOWN move rectangular (a = chi 2^2, b = chi 3^2; the reference only asserts R.shape == Rt.shape,
+    ctm_projectors.py:209).  The REFERENCE's moves: one per direction from the CTMRG init, then `nsweeps` sweeps -- corner spectra,
+    |C|, |T|; the oracle is checked against the same."""
+    set_dtype(complex_)
+    rng = np.random.default_rng(seed)
+    sites = {}
+    for y in range(2):
+        for x in range(2):
+            A = rng.random((2, 2, 2 + y, 2, 2 + y)) - 0.3                     # a[p,u,l,d,r]: l = r = 2 (row 0), 3 (row 1)
+            if complex_:
+                A = A + 1j * (rng.random((2, 2, 2 + y, 2, 2 + y)) - 0.3)
+            sites[(x, y)] = A / np.abs(A).max()
+    st = ref_state(sites); ost = O.State(sites)
+    out = {f"site_{k[0]}_{k[1]}": v for k, v in sites.items()}
+    out["chi"] = np.array(chi); out["nsweeps"] = np.array(nsweeps)
+    for dn, d in DIRS.items():
+        env = ENV(chi, st); init_env(st, env)
+        ctmrg.ctm_MOVE(d, st, env)
+        C1, T1 = env_to_np(env)
+        oe = O.init_env_ctmrg(ost, chi)
+        O.ctm_move(d, ost, oe)
+        for k in C1: close(np.abs(oe.C[k]), np.abs(C1[k]), 1e-8, f"rect move {dn} C{k}")
+        for k in T1: close(np.abs(oe.T[k]), np.abs(T1[k]), 1e-8, f"rect move {dn} T{k}")
+        pack_env(f"move_{dn}_", C1, T1, out)
+    env = ENV(chi, st); init_env(st, env)
+    env = _run_fixed(st, env, nsweeps)
+    spec = {k: t2n(v) for k, v in env.get_spectra().items()}
+    oe = O.init_env_ctmrg(ost, chi)
+    for _ in range(nsweeps): O.ctm_sweep(ost, oe)
+    so = O.corner_spectra(oe)
+    worst = max(np.abs(so[k] - spec[k]).max() for k in spec)
+    print(f"  {name}: {nsweeps} sweeps, oracle-vs-ref spectra {worst:.2e}")
+    assert worst < 1e-10
+    for (c, v), s_ in spec.items():
+        out[f"spec_{c[0]}_{c[1]}_{v[0]}_{v[1]}"] = s_
+    C1, T1 = env_to_np(env)
+    pack_env("end_", C1, T1, out)
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **out)
+
+
 def svd_cases():
     """truncated_svd_gesdd incl. multiplet back-off + fix_svd_signs; truncated_eig_sym."""
     set_dtype(False)
@@ -973,7 +1015,7 @@ def chiral_case():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["decomp", "generic", "c4v", "c4v_ad", "generic_ad", "c4v_j3", "generic_corr", "envinit", "rvb", "files", "variants", "aklt", "inputs", "backward", "fixed_point", "chi_ramp"]
+    which = sys.argv[1:] or ["decomp", "generic", "c4v", "c4v_ad", "generic_ad", "c4v_j3", "generic_corr", "envinit", "rvb", "files", "variants", "aklt", "inputs", "backward", "fixed_point", "chi_ramp", "rect_cut"]
     if "chiral" in which:
         chiral_case()
     if "backward" in which:
@@ -986,6 +1028,9 @@ if __name__ == "__main__":
         variants_check()
     if "decomp" in which:
         svd_cases()
+    if "rect_cut" in which:
+        rect_cut_case("rect_cut_chi5_f64", 5, 3)
+        rect_cut_case("rect_cut_chi5_c128", 5, 2, complex_=True, seed=4)
     if "fixed_point" in which:
         fixed_point_case("fixed_point_D3_chi48_f64", 3, 48, False, 11, 26)
         fixed_point_case("fixed_point_D3_chi48_c128", 3, 48, True, 12, 26)

@@ -57,6 +57,7 @@ _SIGS = {
     "ctm_sync": [C.c_void_p],
     "ctm_trim": [C.c_void_p],
     "ctm_set_option": [C.c_void_p, C.c_char_p, C.c_double],
+    "ctm_projectors_rect": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(TruncCfg), C.c_void_p, C.c_void_p, C.c_void_p],
     "ctm_set_comm": [C.c_void_p, C.c_void_p, C.c_int, C.c_int],
     "ctm_set_comm_ops": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_int, C.c_int],
     "ctm_get_stat": [C.c_void_p, C.c_char_p, C.POINTER(C.c_double)],
@@ -611,9 +612,12 @@ class Engine:
         ts, arr, ad = self._pack16(tensors16)
         chi = ts[0].shape[0]
         d = DIR_INDEX[direction] if isinstance(direction, tuple) else direction
-        # the halves are square in the truncated bond n = chi * D_cut^2 (bond dimensions may differ between directions)
-        n = chi * ts[3].shape[CUT_LEG[d]] ** 2
-        R, Rt = self.empty(n, n), self.empty(n, n)
+        # R: (truncated bond at the site of its first corner) x (the same leg at the site of its second corner); Rt: the opposite legs of
+        # its two sites.  Square unless bond dimensions differ along the cut (rectangular halves: projectors(R, Rt) handles both)
+        leg = CUT_LEG[d]; opp = {1: 3, 2: 4, 3: 1, 4: 2}[leg]
+        shR = (chi * ts[3].shape[leg] ** 2, chi * ts[7].shape[leg] ** 2)
+        shRt = (chi * ts[11].shape[opp] ** 2, chi * ts[15].shape[opp] ** 2)
+        R, Rt = self.empty(*shR), self.empty(*shRt)
         self._ck(self.lib.ctm_halves(self.h, d, arr, chi, ad, _ptr(R), _ptr(Rt)), "halves")
         return R, Rt
 
@@ -621,11 +625,11 @@ class Engine:
         R, Rt = self._bind(R, Rt)
         if R.shape != Rt.shape or R.dim() != 2:
             raise AssertionError("R and Rt must be matrices of equal shape")     # ctm_projectors.py:209
-        n = R.shape[0]
-        kc = min(chi, n)
-        P, Pt, S = self.empty(n, kc), self.empty(n, kc), self.empty_real(kc)
+        a, b = R.shape                         # rectangular halves (bond dimensions that differ along one cut): M = R^T Rt is b x b
+        kc = min(chi, b)
+        P, Pt, S = self.empty(a, kc), self.empty(a, kc), self.empty_real(kc)
         cfg = cfg or self.default_cfg
-        self._ck(self.lib.ctm_projectors(self.h, _ptr(R), _ptr(Rt), n, chi, C.byref(cfg), _ptr(P), _ptr(Pt), _ptr(S)), "projectors")
+        self._ck(self.lib.ctm_projectors_rect(self.h, _ptr(R), _ptr(Rt), a, b, chi, C.byref(cfg), _ptr(P), _ptr(Pt), _ptr(S)), "projectors")
         return (P, Pt, S) if return_S else (P, Pt)
 
     @staticmethod

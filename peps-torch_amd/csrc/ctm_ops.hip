@@ -711,16 +711,26 @@ int upload_scale(ctm_ctx* ctx, const TruncOut& to, int kc, double reltol, double
 int ctm_projectors(ctm_ctx* ctx, const double* R, const double* Rt, int n, int chi, const ctm_trunc_cfg* cfg_, double* P,
                    double* Pt, double* S_out) {
     return ctm_entry(ctx, "ctm_projectors", [&]() -> int {
+    return ctm_projectors_rect(ctx, R, Rt, n, n, chi, cfg_, P, Pt, S_out);
+    });
+}
+
+// R, Rt: a x b (a = the bond that is truncated, b = the far side of the half; the reference only asserts R.shape == Rt.shape,
+// ctm_projectors.py:209): M = R^T Rt is b x b, P = R conj(U) S^-1/2 and Pt = Rt V S^-1/2 are a x min(chi, b)
+int ctm_projectors_rect(ctm_ctx* ctx, const double* R, const double* Rt, int a, int b, int chi, const ctm_trunc_cfg* cfg_, double* P,
+                        double* Pt, double* S_out) {
+    return ctm_entry(ctx, "ctm_projectors_rect", [&]() -> int {
     const ctm_trunc_cfg cfg = cfg_ ? *cfg_ : kDefaultCfg;
-    if (chi < 1 || n < 1) { ctx->set_error("projectors: bad dims"); return CTM_ERR_BADARG; }
+    if (chi < 1 || a < 1 || b < 1) { ctx->set_error("projectors: bad dims"); return CTM_ERR_BADARG; }
     ArenaScope scope(ctx);
     IO io(ctx);
+    const int n = b;
     const int k = (chi < n) ? chi + 1 : n, kc = std::min(chi, n), cz = ctx->cplx ? 2 : 1;
     DT tR, tRt, tM, tP, tPt;
-    CTM_TRY(io.in(R, {n, n}, &tR));
-    CTM_TRY(io.in(Rt, {n, n}, &tRt));
-    CTM_TRY(io.out(P, (size_t)n * kc, &tP));
-    CTM_TRY(io.out(Pt, (size_t)n * kc, &tPt));
+    CTM_TRY(io.in(R, {a, n}, &tR));
+    CTM_TRY(io.in(Rt, {a, n}, &tRt));
+    CTM_TRY(io.out(P, (size_t)a * kc, &tP));
+    CTM_TRY(io.out(Pt, (size_t)a * kc, &tPt));
     CTM_TRY(alloc_dt(ctx, {n, n}, &tM));
     double *Ut, *Vt, *dS, *dScale;
     CTM_TRY(arena_alloc(ctx, sizeof(double) * (size_t)k * n * cz, (void**)&Ut));
@@ -729,7 +739,7 @@ int ctm_projectors(ctm_ctx* ctx, const double* R, const double* Rt, int n, int c
     CTM_TRY(arena_alloc(ctx, sizeof(double) * kc, (void**)&dScale));
     {   // M = R^T Rt  (ctm_projectors.py:263, plain transpose)
         PhaseTimer pt(ctx, CTM_T_HALVES);
-        CTM_TRY(xgemm(ctx, n, n, n, xm(tR, n, true), xm(tRt, n, false), tM.p, tM.q, n));
+        CTM_TRY(xgemm(ctx, n, n, a, xm(tR, n, true), xm(tRt, n, false), tM.p, tM.q, n));
     }
     TruncOut to;
     { PhaseTimer pt(ctx, CTM_T_SVD); CTM_TRY(svd_rows(ctx, tM, n, chi, cfg, Ut, Vt, dS, &to)); }
@@ -740,11 +750,11 @@ int ctm_projectors(ctm_ctx* ctx, const double* R, const double* Rt, int n, int c
     // conj(U) = Ut^T (plain transpose), V = Vt^H -> NT GEMMs + fused column scale; zero-scale columns are not computed
     const size_t kn = (size_t)k * n;
     XM u{Ut, ctx->cplx ? Ut + kn : nullptr, n, true, false}, v{Vt, ctx->cplx ? Vt + kn : nullptr, n, true, true};
-    CTM_TRY(fill_f64(ctx, tP.p, (size_t)n * kc * (tP.q ? 2 : 1), 0.0));
-    CTM_TRY(fill_f64(ctx, tPt.p, (size_t)n * kc * (tPt.q ? 2 : 1), 0.0));
+    CTM_TRY(fill_f64(ctx, tP.p, (size_t)a * kc * (tP.q ? 2 : 1), 0.0));
+    CTM_TRY(fill_f64(ctx, tPt.p, (size_t)a * kc * (tPt.q ? 2 : 1), 0.0));
     if (ncol > 0) {
-        CTM_TRY(xgemm(ctx, n, ncol, n, xm(tR, n, false), u, tP.p, tP.q, kc, dScale));
-        CTM_TRY(xgemm(ctx, n, ncol, n, xm(tRt, n, false), v, tPt.p, tPt.q, kc, dScale));
+        CTM_TRY(xgemm(ctx, a, ncol, n, xm(tR, n, false), u, tP.p, tP.q, kc, dScale));
+        CTM_TRY(xgemm(ctx, a, ncol, n, xm(tRt, n, false), v, tPt.p, tPt.q, kc, dScale));
     }
     CTM_TRY(io.finish());
     CTM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));

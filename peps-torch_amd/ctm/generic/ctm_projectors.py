@@ -53,6 +53,18 @@ def _unit_inputs(eng, direction, coord, state, env, ctm_args):
     return t16, basis, corners, fresh
 
 
+_CUT_LEG = {(0, -1): 2, (-1, 0): 3, (0, 1): 4, (1, 0): 1}
+
+
+def rectangular_unit(direction, coord, state, env):
+    """Bond dimensions that differ along the cut of this (direction, site) unit: its halves R, Rt are a x b with a != b (the reference only
+    asserts R.shape == Rt.shape, ctm_projectors.py:209).  The fused implicit-operator path truncates square halves; such a unit goes the
+    explicit way (ctm_halves -> ctm_projectors_rect)."""
+    t16 = _halves_t(direction, coord, state, env)
+    leg = _CUT_LEG[direction]
+    return t16[3].shape[leg] != t16[7].shape[leg]
+
+
 def _sync_warm_tol(eng, ctm_args):
     wtol = float(getattr(ctm_args, "projector_warm_tol", 0.0) or 0.0)
     if getattr(eng, "_warm_tol", 0.0) != wtol and hasattr(eng, "set_option"):      # (per engine: the units of a move run on worker engines)
@@ -68,7 +80,7 @@ def ctm_get_projectors_4x4(direction, coord, state, env, ctm_args=cfg.ctm_args, 
         raise ValueError(f"Projector svd method \"{ctm_args.projector_svd_method}\" not implemented")
     _note_method(ctm_args.projector_svd_method)
     eng = get_engine()
-    if hasattr(eng, "projectors_4x4"):
+    if hasattr(eng, "projectors_4x4") and not rectangular_unit(direction, coord, state, env):
         # fused native path: corners -> implicit M = R^T Rt -> P, Pt (halves never materialised).  The environment
         # remembers, per (direction, site), the right singular basis of the previous sweep: the leading-chi iteration of
         # the next sweep starts from it (residual-verified either way; `projector_warm_start=False` disables it).

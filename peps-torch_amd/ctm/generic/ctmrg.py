@@ -16,7 +16,8 @@ import config as cfg
 from backend import get_engine
 from _native import NativeError, CTM_ERR_NOMEM
 import parallel
-from ctm.generic.ctm_projectors import ctm_get_projectors_4x4, ctm_get_projectors_4x2, _trunc_cfg, _unit_inputs, _sync_warm_tol, SVD_METHODS, _note_method
+from ctm.generic.ctm_projectors import ctm_get_projectors_4x4, ctm_get_projectors_4x2, _trunc_cfg, _unit_inputs, _sync_warm_tol, SVD_METHODS, _note_method, \
+    rectangular_unit
 from ctm.generic.ctm_components import _halves_t
 
 log = logging.getLogger(__name__)
@@ -210,7 +211,7 @@ def _ctm_MOVE_units(direction, state, env, ctm_args, global_args, diagnostics, g
         return pool.map(fn, items, stagger=stagger) if pool is not None else [fn(it) for it in items]
 
     if getattr(ctm_args, "native_move", True) and ctm_args.projector_method == '4X4' and hasattr(eng, "move") and not parallel.is_distributed() \
-            and float(getattr(ctm_args, "unit_stagger_ms", 0.0)) == 0.0:
+            and float(getattr(ctm_args, "unit_stagger_ms", 0.0)) == 0.0 and not any(rectangular_unit(direction, c, state, env) for c in coords):
         # the whole move in ONE native call (ctm_move, include/ctm_hip.h; reference seam ctm_MOVE_c, ctmrg.py:233-283): both phases and
         # the threads that overlap their units live in the library, on the worker contexts of the device's unit pool
         workers = pool.engines() if pool is not None else ()

@@ -336,22 +336,43 @@ def test_one_move_beyond_the_fused_kernel(eng):
     for k in oe.T: assert relerr(env.T[k].abs(), np.abs(oe.T[k])) < 1e-7, k
 
 
-def test_bond_dimensions_that_differ_along_one_cut_are_refused_by_name(eng):
+@pytest.mark.parametrize("name", ["rect_cut_chi5_f64", "rect_cut_chi5_c128"])
+def test_bond_dimensions_that_differ_along_one_cut(eng, name):
     """The reference only asserts R.shape == Rt.shape (ctm/generic/ctm_projectors.py:209): horizontal bonds of dimension 2 in the upper row
-    and 3 in the lower row make the halves of an UP / DOWN move rectangular (n0 = chi 2^2, n1 = chi 3^2).  The engine truncates square
-    halves only; the host layer says so with a ValueError that names the limitation, raised by the entry's own shape check before any
-    kernel runs.  LEFT / RIGHT moves of the same state (vertical bonds all equal) go through."""
+    and 3 in the lower row make the halves of an UP / DOWN move rectangular (a = chi 2^2 rows -- the truncated bond -- by b = chi 3^2).  The
+    fused implicit-operator entry truncates square halves and says so by name (ValueError from its own shape check, before any kernel);
+    the host layer sends such a unit the explicit way (ctm_halves -> ctm_projectors_rect: M = R^T Rt is b x b, P = R conj(U) S^-1/2 is
+    a x chi).  One move per direction and whole sweeps against the REFERENCE's run of the same state
+    (tests/golden/rect_cut_*.npz, oracle/gen_golden.py rect_cut)."""
+    import config as cfg
+    from conftest import golden
+    from helpers import sites_from, env_from, DIRS
     from ipeps.ipeps import IPEPS
     from ctm.generic.env import ENV, init_env
-    from ctm.generic.ctm_projectors import ctm_get_projectors_4x4
-    rng = np.random.default_rng(3)
-    chi = 5
-    sites = {(x, y): dev(rng.random((2, 2, 2 + y, 2, 2 + y)) - 0.3) for y in range(2) for x in range(2)}     # a[p,u,l,d,r]: l = r = 2 (row 0), 3 (row 1)
-    st = IPEPS(sites)
+    from ctm.generic import ctmrg
+    from ctm.generic.ctm_projectors import rectangular_unit
+    from ctm.generic.ctm_components import _halves_t
+    g = golden(name)
+    chi, nsweeps = int(g["chi"]), int(g["nsweeps"])
+    st = IPEPS({k: dev(v) for k, v in sites_from(g).items()})
     env = ENV(chi, st); init_env(st, env)
-    for d in [(0, -1), (0, 1)]:
-        with pytest.raises(ValueError, match="differ along one cut"):
-            ctm_get_projectors_4x4(d, (0, 0), st, env)
-    for d in [(-1, 0), (1, 0)]:
-        P, Pt = ctm_get_projectors_4x4(d, (0, 0), st, env)
-        assert torch.isfinite(P).all() and torch.isfinite(Pt).all()
+    assert rectangular_unit((0, -1), (0, 0), st, env) and rectangular_unit((0, 1), (0, 0), st, env)
+    assert not rectangular_unit((-1, 0), (0, 0), st, env) and not rectangular_unit((1, 0), (0, 0), st, env)
+    with pytest.raises(ValueError, match="differ along one cut"):
+        eng.projectors_4x4((0, -1), _halves_t((0, -1), (0, 0), st, env), chi)
+    for dn, d in DIRS.items():
+        env = ENV(chi, st); init_env(st, env)
+        ctmrg.ctm_MOVE(d, st, env)
+        C1, T1 = env_from(g, f"move_{dn}_")
+        for k in C1: assert relerr(env.C[k].abs(), np.abs(C1[k])) < 1e-7, (dn, k)
+        for k in T1: assert relerr(env.T[k].abs(), np.abs(T1[k])) < 1e-7, (dn, k)
+    env = ENV(chi, st); init_env(st, env)
+    for _ in range(nsweeps):
+        for d in cfg.ctm_args.ctm_move_sequence:
+            for _r in range(2):
+                ctmrg.ctm_MOVE(d, st, env)
+    for k, s_ in env.get_spectra().items():
+        assert np.abs(s_.cpu().numpy() - g[f"spec_{k[0][0]}_{k[0][1]}_{k[1][0]}_{k[1][1]}"]).max() < 1e-10, k
+    C1, T1 = env_from(g, "end_")
+    for k in C1: assert relerr(env.C[k].abs(), np.abs(C1[k])) < 1e-7, k
+    for k in T1: assert relerr(env.T[k].abs(), np.abs(T1[k])) < 1e-7, k

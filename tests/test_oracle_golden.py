@@ -233,3 +233,22 @@ def test_oracle_chi_ramped_run_vs_reference(name):
         assert np.abs(s - g[f"spec_{k[0][0]}_{k[0][1]}_{k[1][0]}_{k[1][1]}"]).max() < 1e-10, k
     e = OJ.energy_per_site([O.rdm2x2(c, ost, oe) for c in sites], 1.0, 0.5)
     assert abs(e - float(g["energy"])) < 1e-10 * abs(float(g["energy"]))
+
+
+@pytest.mark.parametrize("name", ["rect_cut_chi5_f64", "rect_cut_chi5_c128"])
+def test_oracle_with_bond_dimensions_that_differ_along_one_cut(name):
+    """Rectangular halves (the reference only asserts R.shape == Rt.shape, ctm_projectors.py:209): the oracle's moves and sweeps against the
+    REFERENCE's (tests/golden/rect_cut_*.npz, oracle/gen_golden.py rect_cut)."""
+    g = golden(name)
+    chi, nsweeps = int(g["chi"]), int(g["nsweeps"])
+    ost = O.State(sites_from(g))
+    for dn, d in DIRS.items():
+        oe = O.init_env_ctmrg(ost, chi)
+        O.ctm_move(d, ost, oe)
+        C1, T1 = env_from(g, f"move_{dn}_")
+        for k in C1: assert rel(np.abs(oe.C[k]), np.abs(C1[k])) < 1e-8, (dn, k)
+        for k in T1: assert rel(np.abs(oe.T[k]), np.abs(T1[k])) < 1e-8, (dn, k)
+    oe = O.init_env_ctmrg(ost, chi)
+    for _ in range(nsweeps): O.ctm_sweep(ost, oe)
+    for k, s in O.corner_spectra(oe).items():
+        assert np.abs(s - g[f"spec_{k[0][0]}_{k[0][1]}_{k[1][0]}_{k[1][1]}"]).max() < 1e-10, k
